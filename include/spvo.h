@@ -1,0 +1,209 @@
+/*
+ * spvo.h -- C ABI of the MI355X-native SuperPoint stereo-VO front end.
+ *
+ * This is the drop-in boundary beneath the reference's C++ `FeatureFrontEnd`
+ * (reference: src/odml_visual_odometry/include/odml_visual_odometry/
+ * feature_detection.hpp:96-178, "hpp" below).  The reference calls TensorRT,
+ * OpenCV and Ceres directly from that class; here the class in
+ * superpoint-stereo-visual-odometry_amd/host/ keeps the same public API and
+ * forwards every heavy call to the entry points below, which run hand-written
+ * gfx950 HIP kernels.  Plain pointers and sizes only; no C++, OpenCV, ROS or
+ * torch types.  All functions return 0 on success or a negative spvo_status;
+ * nothing throws across this boundary (the reference logs ROS_ERROR and
+ * returns: neural_network.cpp:53-55,96-100).  A context is NOT thread-safe and
+ * is bound to one HIP device (the reference is single-threaded: node.cpp:445-449).
+ *
+ * "nn.cpp"   = src/odml_visual_odometry/src/feature_detection_neural_network.cpp
+ * "base.cpp" = src/odml_visual_odometry/src/feature_detection_base.cpp
+ * "cost.hpp" = src/odml_visual_odometry/include/odml_visual_odometry/ceres_cost_function.hpp
+ */
+#ifndef SPVO_H
+#define SPVO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct spvo_ctx spvo_ctx;
+
+typedef enum {
+  SPVO_OK = 0,
+  SPVO_ERR_INVALID = -1,   /* bad argument / shape */
+  SPVO_ERR_DEVICE = -2,    /* HIP runtime error, no gfx950 device, ... */
+  SPVO_ERR_IO = -3,        /* weight file missing / malformed (nn.cpp:53-55) */
+  SPVO_ERR_STATE = -4,     /* call order (no weights loaded, slot empty, ...) */
+  SPVO_ERR_CAPACITY = -5   /* caller buffer too small */
+} spvo_status;
+
+/* Constructor arguments of SuperPointFeatureFrontEnd that matter below the
+ * class (hpp:272-295); defaults are the reference's laptop launch file
+ * (launch/visual_odometry_superpoint.launch:3-26). */
+typedef struct {
+  int device;          /* HIP device ordinal                                  */
+  int net_height;      /* input_height, multiple of 8 (hpp:296)     [360]     */
+  int net_width;       /* input_width,  multiple of 8               [1176]    */
+  int max_batch;       /* images per network call: 1 or 2 (hpp:342-344) [2]   */
+  float conf_thresh;   /* heat > conf_thresh, strict (nn.cpp:203)   [0.015]   */
+  int dist_thresh;     /* NMS Chebyshev radius (nn.cpp:246-254)     [4]       */
+  int border_remove;   /* nn.cpp:239-244                            [4]       */
+  int max_keypoints;   /* hpp:368 (static constexpr 1000)           [1000]    */
+  int bug_compat_p;    /* 1: keep the reference's no-op principal-point shift
+                          (base.cpp:95,111 writes at<float> into a CV_64F P);
+                          0: apply the intended cx/cy -= crop offset.   [1]   */
+} spvo_config;
+
+void spvo_default_config(spvo_config *cfg);
+
+int spvo_create(const spvo_config *cfg, spvo_ctx **out);
+void spvo_destroy(spvo_ctx *ctx);
+const char *spvo_last_error(const spvo_ctx *ctx);   /* ctx may be NULL */
+
+/* Replaces loadTrtEngine (nn.cpp:43-137): load a .spvw plan + fp32 weights
+ * (written by spvo/weights.py) and repack them on the device. */
+int spvo_load_weights(spvo_ctx *ctx, const char *path);
+
+/* ------------------------------------------------------------------ stages
+ * One entry point per reference stage so that each can be parity-checked
+ * alone.  Unless a name ends in _dev every pointer is HOST memory and the call
+ * is synchronous (copies in, runs on the context's stream, copies out).      */
+
+/* preprocessImageImpl (base.cpp:68-121) + preprocessImage (nn.cpp:139-161):
+ * centre-crop to the network aspect ratio, cv::resize(INTER_LINEAR) 8-bit
+ * fixed-point semantics, scale P rows 0-1.  `P` (3x4 row-major, f64) is
+ * updated in place.  `resized_u8` (net_height*net_width) may be NULL. */
+int spvo_preprocess(spvo_ctx *ctx, const uint8_t *img, int rows, int cols, size_t stride,
+                    double P[12], uint8_t *resized_u8);
+
+/* runNeuralNetwork (nn.cpp:163-176): input [batch,1,H,W] f32 in [0,1];
+ * det [batch,65,H/8,W/8] NCHW; desc_nhwc [batch,H/8,W/8,256] (unit L2 norm
+ * over the last axis; the reference's NCHW `output_desc` transposed, which is
+ * what nn.cpp:339-342 computes on the CPU before sampling). Either output may
+ * be NULL. */
+int spvo_forward(spvo_ctx *ctx, const float *input, int batch, float *det, float *desc_nhwc);
+
+/* Fetch an intermediate activation of the last spvo_forward as dense NCHW
+ * [batch,C,h,w]; tensor ids are the plan's (spvo/weights.py). Test hook. */
+int spvo_debug_tensor(spvo_ctx *ctx, int tensor_id, int batch, float *out, size_t out_floats);
+
+/* postprocessDetectionAndDescription, detector half (nn.cpp:266-326):
+ * det [65,H/8,W/8] -> heat [H,W]. */
+int spvo_heatmap(spvo_ctx *ctx, const float *det, float *heat);
+
+/* processOneHeatmap (nn.cpp:188-262): threshold, rank (confidence desc, then
+ * column-major pixel index asc), exact greedy NMS, border filter, cap.
+ * xy: [max_keypoints][2] int32 (x, y) in rank order; *n: count. */
+int spvo_nms(spvo_ctx *ctx, const float *heat, int32_t *xy, int *n);
+
+/* bilinearInterpolationDesc (nn.cpp:366-431) for n keypoints on one image:
+ * desc_nhwc [H/8,W/8,256] -> out [n,256] (re-normalised, nn.cpp:428). */
+int spvo_sample_descriptors(spvo_ctx *ctx, const float *desc_nhwc, const int32_t *xy, int n,
+                            float *out);
+
+typedef struct {
+  int n;            /* keypoints found (<= max_keypoints)                      */
+  float *xy;        /* caller buffer [max_keypoints][2]: x, y (integers stored
+                       as float, like cv::KeyPoint::pt; nn.cpp:243)            */
+  float *desc;      /* caller buffer [max_keypoints][256]                      */
+} spvo_features;
+
+/* addStereoImagePair (nn.cpp:449-498), everything but the deque bookkeeping:
+ * preprocess both images, run the network, post-process.  P_l/P_r are updated
+ * in place (nn.cpp:465-466 clones then mutates).  The device copies of the
+ * keypoints/descriptors are kept in feature slots `slot_l`/`slot_r` (0..3, the
+ * caller's ring of prevL, prevR, currL, currR; hpp:66-72) for spvo_match_slots.
+ * `resized_l`/`resized_r` (net_height*net_width u8, what nn.cpp:154 pushes to
+ * images_dq) may be NULL. */
+int spvo_detect(spvo_ctx *ctx, const uint8_t *img_l, const uint8_t *img_r, int rows, int cols,
+                size_t stride, double P_l[12], double P_r[12], int slot_l, int slot_r,
+                spvo_features *out_l, spvo_features *out_r, uint8_t *resized_l,
+                uint8_t *resized_r);
+
+/* Same, with both images already resident in device memory (u8, `stride` bytes
+ * per row) and no host copies of descriptors (out_*->desc may be NULL). */
+int spvo_detect_dev(spvo_ctx *ctx, const void *d_img_l, const void *d_img_r, int rows, int cols,
+                    size_t stride, double P_l[12], double P_r[12], int slot_l, int slot_r,
+                    spvo_features *out_l, spvo_features *out_r);
+
+typedef enum { SPVO_SELECT_NN = 0, SPVO_SELECT_KNN = 1 } spvo_selector;
+
+/* matchDescriptors (base.cpp:434-491) = cv::BFMatcher(NORM_L2) match / knnMatch
+ * k=2 + ratio test.  For every query row i: train_idx[i] = matched train row or
+ * -1 (this is maps_of_indices, base.cpp:483-491) and distance[i] = L2 distance
+ * of the best neighbour (valid where train_idx[i] >= 0).  NN + cross_check
+ * keeps mutual nearest neighbours only (base.cpp:27-28).  KNN keeps i iff
+ * d0 < ratio*d1 (base.cpp:469); with nb < 2 nothing is kept. */
+int spvo_match(spvo_ctx *ctx, const float *desc_a, int na, const float *desc_b, int nb,
+               int selector, int cross_check, float ratio, int32_t *train_idx, float *distance);
+
+/* Same on the device-resident descriptors of two feature slots. */
+int spvo_match_slots(spvo_ctx *ctx, int slot_a, int slot_b, int selector, int cross_check,
+                     float ratio, int32_t *train_idx, float *distance);
+
+/* cv::triangulatePoints + convertPointsFromHomogeneous (base.cpp:211-223):
+ * DLT null vector of the 4x4 system in f64, stored f32, then x/w.
+ * xy_l, xy_r: [n][2] f32; xyz: [n][3] f32. */
+int spvo_triangulate(spvo_ctx *ctx, const double P_l[12], const double P_r[12], const float *xy_l,
+                     const float *xy_r, int n, float *xyz);
+
+/* Deterministic P3P-RANSAC standing in for cv::solvePnPRansac(..., true, 500,
+ * 2.0, 0.999, inliers, USAC_ACCURATE) (base.cpp:237-239).  K = P_l[:, :3].
+ * rvec/tvec: in = motion prior, out = model.  inliers: caller buffer [n].
+ * Returns 0 with *ok = 0 when no model with >= 4 inliers was found. */
+typedef struct {
+  int iterations;          /* [500]   */
+  double reproj_error;     /* [2.0]   */
+  double confidence;       /* [0.999] (kept for signature parity; the loop is not
+                              terminated early so results do not depend on it) */
+  uint32_t seed;           /* sample stream seed [0] */
+} spvo_ransac_opts;
+
+int spvo_pnp_ransac(spvo_ctx *ctx, const double K[9], const float *xyz, const float *xy, int n,
+                    const spvo_ransac_opts *opts, double rvec[3], double tvec[3],
+                    int32_t *inliers, int *n_inliers, int *ok);
+
+/* One residual block of the refinement problem (CostFunctor32, cost.hpp:8-58). */
+typedef struct {
+  float X[3];          /* 3-D point (cv::Vec3f)                 */
+  float uv[2];         /* observation (cv::Point2f)             */
+  int32_t cam;         /* 0: P_l, 1: P_r                        */
+  int32_t inverse;     /* inverse_transformation_ (cost.hpp:35) */
+} spvo_obs;
+
+typedef struct {
+  int max_iterations;      /* [40] base.cpp:362 */
+  double huber_delta;      /* [1.0] base.cpp:286 */
+} spvo_refine_opts;
+
+typedef struct {
+  int iterations;
+  int converged;           /* termination_type == CONVERGENCE (base.cpp:366-367) */
+  int usable;
+  double initial_cost, final_cost;
+} spvo_refine_summary;
+
+/* ceres::Solve on the CostFunctor32 blocks (base.cpp:282-375): Levenberg-
+ * Marquardt with Huber loss, quaternion local parameterisation, f64.
+ * q: Eigen coefficient order x,y,z,w (base.cpp:302); in = start, out = result. */
+int spvo_pnp_refine(spvo_ctx *ctx, const double P_l[12], const double P_r[12],
+                    const spvo_obs *obs, int n_obs, const spvo_refine_opts *opts, double q[4],
+                    double t[3], spvo_refine_summary *summary);
+
+/* ---------------------------------------------------------------- plumbing */
+void *spvo_stream(spvo_ctx *ctx);                 /* hipStream_t of the context */
+int spvo_synchronize(spvo_ctx *ctx);
+
+/* Per-stage HIP-event timing on the context's stream (bench.py's roofline leg).
+ * Stage names: "conv:<op index>", "net", "post", "match", ...; see DESIGN.md. */
+int spvo_profile_enable(spvo_ctx *ctx, int on);
+int spvo_profile_reset(spvo_ctx *ctx);
+int spvo_profile_count(spvo_ctx *ctx);
+int spvo_profile_get(spvo_ctx *ctx, int i, char *name, size_t name_cap, double *total_ms,
+                     long long *calls, double *flops_per_call, double *bytes_per_call);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPVO_H */

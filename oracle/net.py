@@ -1,0 +1,52 @@
+"""Oracle for the CNN: torch-CPU fp32 executor.
+
+Follows what the reference's TensorRT engine computes at
+feature_detection_neural_network.cpp:163-176 (`context_->enqueue`): the ONNX
+graph {Conv, Relu, MaxPool, Concat, ReduceL2, Div} in fp32, input [B,1,H,W] in
+[0,1], outputs `output_det` [B,65,H/8,W/8] and `output_desc` [B,256,H/8,W/8]
+(L2-normalised over channels in-graph, no epsilon).  TensorRT's own summation
+order is unknowable, so parity is within a stated tolerance, not bit-exact.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from spvo import weights as W
+
+
+def forward(plan: W.Plan, x: np.ndarray, return_all: bool = False):
+    """x: float32 [B,1,H,W].  Returns (det, desc) as float32 numpy NCHW."""
+    assert x.dtype == np.float32 and x.ndim == 4 and x.shape[1] == 1
+    torch.set_grad_enabled(False)
+    B, _, H, Wd = x.shape
+    vals = {}
+    vals[plan.input_tensor] = torch.from_numpy(x)
+    for op in plan.ops:
+        src = vals[op.inp]
+        in_off = getattr(op, "in_c_off", 0)
+        if op.type == W.OP_CONV:
+            xin = src[:, in_off:in_off + op.cin]
+            y = F.conv2d(xin, torch.from_numpy(op.weight), torch.from_numpy(op.bias),
+                         stride=1, padding=op.ksize // 2)
+            if op.flags & W.FLAG_RELU:
+                y = F.relu(y)
+            if op.flags & W.FLAG_POOL:
+                y = F.max_pool2d(y, 2, 2)
+            ch, lvl = plan.tensors[op.out]
+            if op.out not in vals:
+                vals[op.out] = torch.zeros((B, ch, H >> lvl, Wd >> lvl), dtype=torch.float32)
+            vals[op.out][:, op.out_c_off:op.out_c_off + op.cout] = y
+        elif op.type == W.OP_MAXPOOL:
+            vals[op.out] = F.max_pool2d(src, 2, 2)
+        elif op.type == W.OP_L2NORM:
+            # ONNX tail: ReduceL2(axes=[1], keepdims=1) then Div, no epsilon
+            vals[op.out] = src / torch.sqrt((src * src).sum(dim=1, keepdim=True))
+        else:
+            raise NotImplementedError(op.type)
+    det = vals[plan.det_tensor].numpy()
+    desc = vals[plan.desc_tensor].numpy()
+    if return_all:
+        return det, desc, {k: v.numpy() for k, v in vals.items()}
+    return det, desc

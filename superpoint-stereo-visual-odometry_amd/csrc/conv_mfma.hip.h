@@ -1,0 +1,310 @@
+// conv_mfma.hip.h -- K2/K3: 3x3 and 1x1 convolution as an implicit GEMM on the
+// gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32), bias + ReLU (+ 2x2 max-pool)
+// fused in the epilogue.
+//
+// Replaces the TensorRT engine the reference enqueues at
+// feature_detection_neural_network.cpp:169 for every Conv/Relu/MaxPool node of
+// the SuperPoint graphs.
+//
+// Data layout (DESIGN.md "HBM layout"): activations are padded planes
+//   act[b][c][Hp][Wp],  pixel (y, x) at [y + PADY][x + PADX],  PADY = 1, PADX = 4,
+//   Hp = roundup(H, 8) + 2,  Wp = roundup(W, 64) + 8,
+// and everything outside the H x W interior is zero and never written, so the
+// halo loads need no bounds checks and every 16-byte load is aligned.
+//
+// GEMM mapping: D[co][pixel] = sum_k Wt[co][k] * X[k][pixel], k = (tap, ci).
+//   A operand (32 rows = output channels): lane l holds Wt[co = l&31][k = l>>5]
+//   B operand (32 cols = 32 consecutive x): lane l holds X[k = l>>5][x = l&31]
+//   D: lane l holds column x = l&31, rows (reg&3) + 8*(reg>>2) + 4*(l>>5)
+// so each accumulator register stores to 32 consecutive pixels of one channel
+// (128-byte segments) and both LDS operand reads are bank-conflict-free
+// ds_read_b32 (consecutive lanes -> consecutive dwords).
+//
+// A workgroup is 4 waves; it owns 64 output channels x (4*WR rows) x (32*WC cols).
+// Wave w owns rows [w*WR, w*WR+WR) and all WC column tiles: 2 x WR*WC
+// accumulator tiles.  The reduction runs over chunks of CK input channels; each
+// chunk's input halo tile and weight slab are fetched straight into LDS
+// (global_load_lds_dwordx4), double-buffered, one barrier per chunk.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace spvo {
+
+constexpr int PADX = 4;
+constexpr int PADY = 1;
+constexpr int CO_TILE = 64;
+
+__host__ __device__ inline int padded_h(int h) { return ((h + 7) / 8) * 8 + 2; }
+__host__ __device__ inline int padded_w(int w) { return ((w + 63) / 64) * 64 + 8; }
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+  const float *in;     // padded planes of the input tensor (batch 0, channel 0)
+  float *out;          // padded planes of the output tensor
+  const float *wpack;  // [co_tiles][n_chunks][KS*KS][CK][64]
+  const float *bias;   // [co_tiles*64], zero padded
+  int H, W;            // conv resolution (input == pre-pool output)
+  int in_hp, in_wp, in_ctot, in_coff;
+  int out_hp, out_wp, out_ctot, out_coff;
+  int cout;            // real output channels of this op
+  int n_chunks;        // cin / CK
+  int tiles_x, tiles_y, co_tiles;
+};
+
+__device__ __forceinline__ void glds16(const float *src, float *lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(
+      (const __attribute__((address_space(1))) void *)src,
+      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+template <int KS, int CK, int WR, int WC>
+struct ConvTile {
+  static constexpr int TH = 4 * WR;
+  static constexpr int TW = 32 * WC;
+  static constexpr int HALO = KS / 2;
+  static constexpr int LW = TW + (KS == 3 ? 8 : 0);  // LDS row: x0-4 .. x0+TW+3
+  static constexpr int LH = TH + 2 * HALO;
+  static constexpr int IN_FLOATS = CK * LH * LW;
+  static constexpr int W_FLOATS = KS * KS * CK * CO_TILE;
+  static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
+  static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4;
+};
+
+template <int KS, int CK, int WR, int WC, bool POOL, bool RELU>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+  using T = ConvTile<KS, CK, WR, WC>;
+  constexpr int NT = WR * WC;
+  constexpr int LW = T::LW, LH = T::LH, LW4 = LW / 4;
+  constexpr int IN_V4 = T::IN_FLOATS / 4, W_V4 = T::W_FLOATS / 4, TOT_V4 = IN_V4 + W_V4;
+  constexpr int NIT = (TOT_V4 + 255) / 256;
+  constexpr int XO = (KS == 3) ? 3 : 0;  // LDS column of output column 0, tap kx = 0
+  static_assert(!POOL || WR == 2, "fused pooling needs both rows of a 2x2 window in one wave");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int half = lane >> 5;
+  const int j = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // tile decode: x fastest, then y, then co tile, then image
+  int bid = blockIdx.x;
+  const int tx = bid % a.tiles_x;
+  bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  bid /= a.tiles_y;
+  const int ct = bid % a.co_tiles;
+  const int img = bid / a.co_tiles;
+  const int x0 = tx * T::TW, y0 = ty * T::TH;
+
+  const size_t in_plane = (size_t)a.in_hp * a.in_wp;
+  const float *in_base = a.in + ((size_t)img * a.in_ctot + a.in_coff) * in_plane +
+                         (size_t)(y0 + PADY - T::HALO) * a.in_wp + (x0 + PADX - (KS == 3 ? 4 : 0));
+  const float *w_base = a.wpack + (size_t)ct * a.n_chunks * T::W_FLOATS;
+
+  auto issue = [&](int chunk, float *buf) {
+    const float *inb = in_base + (size_t)chunk * CK * in_plane;
+    const float *wb = w_base + (size_t)chunk * T::W_FLOATS;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = it * 256 + tid;
+      if (idx < TOT_V4) {
+        const float *src;
+        if (idx < IN_V4) {
+          const int ci = idx / (LH * LW4);
+          const int rem = idx - ci * (LH * LW4);
+          const int r = rem / LW4;
+          const int q = rem - r * LW4;
+          src = inb + (size_t)ci * in_plane + r * a.in_wp + q * 4;
+        } else {
+          src = wb + (idx - IN_V4) * 4;
+        }
+        glds16(src, buf + (it * 256 + wave * 64) * 4);
+      }
+    }
+  };
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    f32x16 bv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      bv[r] = a.bias[ct * CO_TILE + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = bv;
+  }
+
+  issue(0, smem);
+  const int b_lane = half * (LH * LW) + (wave * WR) * LW + j + XO;
+  const int a_lane = T::IN_FLOATS + half * CO_TILE + j;
+
+  for (int c = 0; c < a.n_chunks; ++c) {
+    // chunk c has landed for every wave (each wave drains its own LDS-DMA, then the
+    // barrier); after the barrier buffer (c+1)&1 is no longer read by anyone.  The
+    // explicit wait is required: hipcc does not count global_load_lds in the wait it
+    // emits for __syncthreads() here (checked in the .s).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (c + 1 < a.n_chunks) issue(c + 1, smem + ((c + 1) & 1) * T::BUF_FLOATS);
+    const float *buf = smem + (c & 1) * T::BUF_FLOATS;
+#pragma unroll
+    for (int t = 0; t < KS * KS; ++t) {
+      const int ky = t / KS, kx = t % KS;
+#pragma unroll
+      for (int p = 0; p < CK / 2; ++p) {
+        float av[2], bv[NT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) av[m] = buf[a_lane + (t * CK + 2 * p) * CO_TILE + 32 * m];
+#pragma unroll
+        for (int rr = 0; rr < WR; ++rr)
+#pragma unroll
+          for (int cc = 0; cc < WC; ++cc)
+            bv[rr * WC + cc] = buf[b_lane + 2 * p * (LH * LW) + (rr + ky) * LW + cc * 32 + kx];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
+      }
+    }
+  }
+
+  // ------------------------------------------------------------- epilogue
+  const size_t out_plane = (size_t)a.out_hp * a.out_wp;
+  float *out_img = a.out + ((size_t)img * a.out_ctot + a.out_coff) * out_plane;
+  if constexpr (!POOL) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int rr = 0; rr < WR; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < WC; ++cc) {
+          const int y = y0 + wave * WR + rr;
+          const int x = x0 + cc * 32 + j;
+          const bool ok = (y < a.H) && (x < a.W);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = ct * CO_TILE + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = acc[m][rr * WC + cc][r];
+            if (RELU) v = fmaxf(v, 0.f);
+            if (ok && co < a.cout)
+              out_img[(size_t)co * out_plane + (size_t)(y + PADY) * a.out_wp + (x + PADX)] = v;
+          }
+        }
+  } else {
+    const int OH = a.H >> 1, OW = a.W >> 1;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int cc = 0; cc < WC; ++cc) {
+        const int y = (y0 >> 1) + wave;
+        const int x = (x0 + cc * 32 + j) >> 1;
+        const bool ok = (y < OH) && (x < OW) && !(j & 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = ct * CO_TILE + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
+          float v = fmaxf(acc[m][0 * WC + cc][r], acc[m][1 * WC + cc][r]);
+          v = fmaxf(v, __shfl_xor(v, 1));
+          if (RELU) v = fmaxf(v, 0.f);
+          if (ok && co < a.cout)
+            out_img[(size_t)co * out_plane + (size_t)(y + PADY) * a.out_wp + (x + PADX)] = v;
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K1: first layer, Cin = 1 (K = 9): direct convolution on the vector ALU; the
+// layer is bound by writing its 64-channel output, not by arithmetic.
+// Weights (64 x 9) and bias are wave-uniform -> scalar loads.
+// One thread = one pixel, all output channels; consecutive lanes = consecutive x.
+// ---------------------------------------------------------------------------
+template <bool RELU>
+__global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict__ in,
+                                                         float *__restrict__ out,
+                                                         const float *__restrict__ w,  // [cout][9]
+                                                         const float *__restrict__ bias, int H,
+                                                         int W, int hp, int wp, int out_ctot,
+                                                         int out_coff, int cout) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int img = blockIdx.z;
+  if (x >= W || y >= H) return;
+  const size_t plane = (size_t)hp * wp;
+  const float *ip = in + (size_t)img * plane + (size_t)(y + PADY - 1) * wp + (x + PADX - 1);
+  float v[9];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) v[ky * 3 + kx] = ip[ky * wp + kx];
+  float *op = out + ((size_t)img * out_ctot + out_coff) * plane + (size_t)(y + PADY) * wp + (x + PADX);
+  for (int co = 0; co < cout; ++co) {
+    float s = bias[co];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) s = fmaf(w[co * 9 + t], v[t], s);
+    if (RELU) s = fmaxf(s, 0.f);
+    op[(size_t)co * plane] = s;
+  }
+}
+
+// Stand-alone 2x2/2 max-pool (squeeze graph: pool after a Concat).
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float *__restrict__ in,
+                                                       float *__restrict__ out, int C, int OH,
+                                                       int OW, int in_hp, int in_wp, int out_hp,
+                                                       int out_wp) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int c = blockIdx.z;  // image * C + channel
+  if (x >= OW || y >= OH) return;
+  const float *ip = in + (size_t)c * in_hp * in_wp + (size_t)(2 * y + PADY) * in_wp + (2 * x + PADX);
+  const float v = fmaxf(fmaxf(ip[0], ip[1]), fmaxf(ip[in_wp], ip[in_wp + 1]));
+  out[(size_t)c * out_hp * out_wp + (size_t)(y + PADY) * out_wp + (x + PADX)] = v;
+}
+
+// K6: descriptor tail -- channel-wise L2 normalisation (ONNX ReduceL2 + Div, no
+// epsilon) fused with the NCHW -> NHWC transpose the reference does on the CPU
+// (neural_network.cpp:339-342).  A block handles 32
+// consecutive pixels of one row; each thread first walks channels for "its"
+// pixel (coalesced along x), the tile goes through LDS and leaves as
+// [pixel][256] rows (coalesced along channels).
+template <int C>
+__global__ __launch_bounds__(256) void l2norm_nhwc_kernel(const float *__restrict__ in,
+                                                          float *__restrict__ out, int H, int W,
+                                                          int hp, int wp) {
+  constexpr int PX = 32, CG = 256 / PX;
+  __shared__ float tile[PX][C + 1];
+  __shared__ float part[CG][PX];
+  __shared__ float nrm[PX];
+  const int x0 = blockIdx.x * PX, y = blockIdx.y, img = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int px = tid & (PX - 1), cg = tid / PX;
+  const size_t plane = (size_t)hp * wp;
+  const float *ip = in + (size_t)img * C * plane + (size_t)(y + PADY) * wp + (x0 + PADX);
+  float ss = 0.f;
+  for (int c = cg; c < C; c += CG) {
+    const float v = (x0 + px < W) ? ip[(size_t)c * plane + px] : 0.f;
+    tile[px][c] = v;
+    ss = fmaf(v, v, ss);
+  }
+  part[cg][px] = ss;
+  __syncthreads();
+  if (tid < PX) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < CG; ++g) s += part[g][tid];  // fixed order
+    nrm[tid] = sqrtf(s);
+  }
+  __syncthreads();
+  float *op = out + (((size_t)img * H + y) * W + x0) * C;
+  const int npx = min(PX, W - x0);
+  for (int i = tid; i < npx * C; i += 256) {
+    const int p = i / C, c = i - p * C;
+    op[i] = tile[p][c] / nrm[p];
+  }
+}
+
+}  // namespace spvo

@@ -1,0 +1,179 @@
+// conv_bench.hip -- standalone check + timing of the MFMA convolution variants.
+// Build: hipcc --offload-arch=gfx950 -O3 -I superpoint-stereo-visual-odometry_amd/csrc tools/conv_bench.hip -o tools/conv_bench
+// Run on the GPU box: ./tools/conv_bench
+// Checks every variant against a naive one-thread-per-output kernel on the same
+// data, then times it with HIP events and prints achieved TFLOP/s.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include <string>
+#include "conv_mfma.hip.h"
+
+using namespace spvo;
+
+#define CK_HIP(x)                                                                  \
+  do {                                                                             \
+    hipError_t e = (x);                                                            \
+    if (e != hipSuccess) {                                                         \
+      fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); \
+      exit(1);                                                                     \
+    }                                                                              \
+  } while (0)
+
+__global__ void naive_conv(const float *in, float *out, const float *w, const float *bias, int B,
+                           int cin, int cout, int KS, int H, int W, int hp, int wp, int relu) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  const int co = blockIdx.z % cout, b = blockIdx.z / cout;
+  if (x >= W) return;
+  const size_t plane = (size_t)hp * wp;
+  float s = bias[co];
+  const int hk = KS / 2;
+  for (int ky = 0; ky < KS; ++ky)
+    for (int kx = 0; kx < KS; ++kx)
+      for (int ci = 0; ci < cin; ++ci)
+        s = fmaf(w[((size_t)(co * cin + ci) * KS + ky) * KS + kx],
+                 in[((size_t)b * cin + ci) * plane + (size_t)(y + PADY + ky - hk) * wp + (x + PADX + kx - hk)], s);
+  if (relu) s = fmaxf(s, 0.f);
+  out[((size_t)b * cout + co) * plane + (size_t)(y + PADY) * wp + (x + PADX)] = s;
+}
+
+__global__ void naive_pool(const float *in, float *out, int C, int OH, int OW, int ihp, int iwp, int ohp, int owp) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y, c = blockIdx.z;
+  if (x >= OW) return;
+  const float *ip = in + (size_t)c * ihp * iwp + (size_t)(2 * y + PADY) * iwp + (2 * x + PADX);
+  out[(size_t)c * ohp * owp + (size_t)(y + PADY) * owp + x + PADX] = fmaxf(fmaxf(ip[0], ip[1]), fmaxf(ip[iwp], ip[iwp + 1]));
+}
+
+static void pack_weights(const std::vector<float> &w, int cout, int cin, int KS, int CK, std::vector<float> &out, int &co_tiles) {
+  co_tiles = (cout + CO_TILE - 1) / CO_TILE;
+  const int nch = cin / CK, taps = KS * KS;
+  out.assign((size_t)co_tiles * nch * taps * CK * CO_TILE, 0.f);
+  for (int ct = 0; ct < co_tiles; ++ct)
+    for (int ch = 0; ch < nch; ++ch)
+      for (int t = 0; t < taps; ++t)
+        for (int c = 0; c < CK; ++c)
+          for (int o = 0; o < CO_TILE; ++o) {
+            const int co = ct * CO_TILE + o, ci = ch * CK + c;
+            if (co < cout)
+              out[((((size_t)ct * nch + ch) * taps + t) * CK + c) * CO_TILE + o] = w[((size_t)co * cin + ci) * taps + t];
+          }
+}
+
+template <int KS, int CK, int WR, int WC, bool POOL>
+static double run_variant(const char *name, int B, int cin, int cout, int H, int W, int reps) {
+  using T = ConvTile<KS, CK, WR, WC>;
+  const int hp = padded_h(H), wp = padded_w(W);
+  const int OH = POOL ? H / 2 : H, OW = POOL ? W / 2 : W;
+  const int ohp = padded_h(OH), owp = padded_w(OW);
+  const size_t in_n = (size_t)B * cin * hp * wp, out_n = (size_t)B * cout * ohp * owp, full_n = (size_t)B * cout * hp * wp;
+  std::vector<float> hin(in_n, 0.f), hw((size_t)cout * cin * KS * KS), hb(((cout + 63) / 64) * 64, 0.f);
+  srand(1234);
+  auto rnd = []() { return (float)rand() / RAND_MAX * 2.f - 1.f; };
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < cin; ++c)
+      for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) hin[(((size_t)b * cin + c) * hp + y + PADY) * wp + x + PADX] = rnd();
+  const float ws = sqrtf(2.f / (cin * KS * KS));
+  for (auto &v : hw) v = rnd() * ws * 1.7f;
+  for (int i = 0; i < cout; ++i) hb[i] = rnd() * 0.1f;
+  std::vector<float> hpk;
+  int co_tiles;
+  pack_weights(hw, cout, cin, KS, CK, hpk, co_tiles);
+
+  float *din, *dout, *dref, *dfull, *dw, *dpk, *db;
+  CK_HIP(hipMalloc(&din, in_n * 4));
+  CK_HIP(hipMalloc(&dout, out_n * 4));
+  CK_HIP(hipMalloc(&dref, out_n * 4));
+  CK_HIP(hipMalloc(&dfull, full_n * 4));
+  CK_HIP(hipMalloc(&dw, hw.size() * 4));
+  CK_HIP(hipMalloc(&dpk, hpk.size() * 4));
+  CK_HIP(hipMalloc(&db, hb.size() * 4));
+  CK_HIP(hipMemcpy(din, hin.data(), in_n * 4, hipMemcpyHostToDevice));
+  CK_HIP(hipMemcpy(dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+  CK_HIP(hipMemcpy(dpk, hpk.data(), hpk.size() * 4, hipMemcpyHostToDevice));
+  CK_HIP(hipMemcpy(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+  CK_HIP(hipMemset(dout, 0, out_n * 4));
+  CK_HIP(hipMemset(dref, 0, out_n * 4));
+  CK_HIP(hipMemset(dfull, 0, full_n * 4));
+
+  // reference
+  naive_conv<<<dim3((W + 63) / 64, H, B * cout), 64>>>(din, POOL ? dfull : dref, dw, db, B, cin, cout, KS, H, W, hp, wp, 1);
+  if (POOL) naive_pool<<<dim3((OW + 63) / 64, OH, B * cout), 64>>>(dfull, dref, B * cout, OH, OW, hp, wp, ohp, owp);
+  CK_HIP(hipDeviceSynchronize());
+
+  ConvArgs a;
+  a.in = din; a.out = dout; a.wpack = dpk; a.bias = db;
+  a.H = H; a.W = W; a.in_hp = hp; a.in_wp = wp; a.in_ctot = cin; a.in_coff = 0;
+  a.out_hp = ohp; a.out_wp = owp; a.out_ctot = cout; a.out_coff = 0; a.cout = cout;
+  a.n_chunks = cin / CK;
+  a.tiles_x = (W + T::TW - 1) / T::TW; a.tiles_y = (H + T::TH - 1) / T::TH; a.co_tiles = co_tiles;
+  const int grid = a.tiles_x * a.tiles_y * co_tiles * B;
+  auto kern = conv_mfma_kernel<KS, CK, WR, WC, POOL, true>;
+  CK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+  kern<<<grid, 256, T::LDS_BYTES>>>(a);
+  CK_HIP(hipDeviceSynchronize());
+  std::vector<float> ho(out_n), hr(out_n);
+  CK_HIP(hipMemcpy(ho.data(), dout, out_n * 4, hipMemcpyDeviceToHost));
+  CK_HIP(hipMemcpy(hr.data(), dref, out_n * 4, hipMemcpyDeviceToHost));
+  double maxd = 0, maxr = 0;
+  size_t bad = 0;
+  for (size_t i = 0; i < out_n; ++i) {
+    const double d = fabs((double)ho[i] - hr[i]);
+    if (d > maxd) maxd = d;
+    if (fabs(hr[i]) > maxr) maxr = fabs(hr[i]);
+    if (d > 1e-4 * (1 + fabs(hr[i]))) ++bad;
+  }
+  hipEvent_t e0, e1;
+  CK_HIP(hipEventCreate(&e0));
+  CK_HIP(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) kern<<<grid, 256, T::LDS_BYTES>>>(a);
+  CK_HIP(hipEventRecord(e0));
+  for (int i = 0; i < reps; ++i) kern<<<grid, 256, T::LDS_BYTES>>>(a);
+  CK_HIP(hipEventRecord(e1));
+  CK_HIP(hipEventSynchronize(e1));
+  float ms;
+  CK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  const double flops = 2.0 * B * H * W * (double)cout * cin * KS * KS;
+  printf("%-28s B%d %3d->%3d %4dx%-4d k%d grid %5d lds %6d : %8.3f ms  %7.2f TFLOP/s  maxdiff %.3g (ref max %.3g) bad %zu %s\n",
+         name, B, cin, cout, H, W, KS, grid, T::LDS_BYTES, ms, flops / ms * 1e-9, maxd, maxr, bad, bad ? "FAIL" : "ok");
+  hipFree(din); hipFree(dout); hipFree(dref); hipFree(dfull); hipFree(dw); hipFree(dpk); hipFree(db);
+  return ms;
+}
+
+int main(int argc, char **argv) {
+  const int reps = argc > 1 ? atoi(argv[1]) : 10;
+  hipDeviceProp_t prop;
+  CK_HIP(hipGetDeviceProperties(&prop, 0));
+  printf("device: %s, %d CUs, arch %s\n", prop.name, prop.multiProcessorCount, prop.gcnArchName);
+  // small ragged shapes first (correctness incl. edges)
+  run_variant<3, 8, 2, 2, false>("small k3 8x64", 1, 16, 64, 21, 75, 2);
+  run_variant<3, 8, 2, 2, true>("small k3 8x64 pool", 2, 16, 70, 22, 74, 2);
+  run_variant<3, 8, 1, 1, false>("small k3 4x32", 1, 8, 65, 13, 41, 2);
+  run_variant<1, 16, 1, 1, false>("small k1 4x32", 2, 32, 65, 13, 41, 2);
+  run_variant<1, 16, 2, 2, false>("small k1 8x64", 1, 16, 48, 21, 75, 2);
+  // VGG layer shapes at 360x1176, stereo pair (B = 2)
+  run_variant<3, 8, 2, 2, true>("conv1b 8x64 pool ck8", 2, 64, 64, 360, 1176, reps);
+  run_variant<3, 4, 2, 2, true>("conv1b 8x64 pool ck4", 2, 64, 64, 360, 1176, reps);
+  run_variant<3, 8, 2, 1, true>("conv1b 8x32 pool ck8", 2, 64, 64, 360, 1176, reps);
+  run_variant<3, 8, 2, 2, false>("conv2a 8x64", 2, 64, 64, 180, 588, reps);
+  run_variant<3, 8, 1, 2, false>("conv2a 4x64", 2, 64, 64, 180, 588, reps);
+  run_variant<3, 8, 2, 2, true>("conv2b 8x64 pool", 2, 64, 64, 180, 588, reps);
+  run_variant<3, 8, 2, 1, true>("conv2b 8x32 pool", 2, 64, 64, 180, 588, reps);
+  run_variant<3, 8, 2, 2, false>("conv3a 8x64", 2, 64, 128, 90, 294, reps);
+  run_variant<3, 8, 1, 2, false>("conv3a 4x64", 2, 64, 128, 90, 294, reps);
+  run_variant<3, 8, 1, 1, false>("conv3a 4x32", 2, 64, 128, 90, 294, reps);
+  run_variant<3, 8, 2, 1, true>("conv3b 8x32 pool", 2, 128, 128, 90, 294, reps);
+  run_variant<3, 8, 2, 2, true>("conv3b 8x64 pool", 2, 128, 128, 90, 294, reps);
+  run_variant<3, 8, 1, 1, false>("conv4a 4x32", 2, 128, 128, 45, 147, reps);
+  run_variant<3, 8, 1, 2, false>("conv4a 4x64", 2, 128, 128, 45, 147, reps);
+  run_variant<3, 8, 1, 1, false>("heads3x3 4x32", 2, 128, 512, 45, 147, reps);
+  run_variant<3, 8, 1, 2, false>("heads3x3 4x64", 2, 128, 512, 45, 147, reps);
+  run_variant<1, 16, 1, 1, false>("convDb 4x32", 2, 256, 256, 45, 147, reps);
+  run_variant<1, 16, 1, 1, false>("convPb 4x32", 2, 256, 65, 45, 147, reps);
+  return 0;
+}
