@@ -1,0 +1,80 @@
+"""Oracle for descriptor matching.
+
+TEST INFRASTRUCTURE ONLY.  Restates FeatureFrontEnd::initMatcher (base.cpp:10-33)
+and FeatureFrontEnd::matchDescriptors (base.cpp:434-491) with
+cv::BFMatcher(NORM_L2) semantics [OpenCV 4.5.4, not installed here: restated from
+its published behaviour, "parity unpinned"]:
+  * distance = sqrt(sum_k (a_k - b_k)^2) in float32.  OpenCV's SIMD partial-sum
+    order is build-dependent; the canonical order pinned here is a sequential
+    sum over k with separately rounded multiply and add (the scalar loop of
+    normL2Sqr_: `s += t*t`).
+  * best match = strict '<' scan over train rows, so the lowest train index wins
+    ties; knnMatch(k=2) returns the two best in ascending order.
+  * crossCheck (batchDistance, crosscheck=true): for every train row, of the
+    queries whose best is that row, only the one with the smallest distance
+    (lowest query index on ties) keeps its match.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def sq_distances(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """float32 [na, nb], canonical summation order (sequential over k)."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    acc = np.zeros((a.shape[0], b.shape[0]), np.float32)
+    for k in range(a.shape[1]):
+        t = a[:, k, None] - b[None, :, k]
+        acc = acc + t * t
+    return acc
+
+
+def best_two(d2: np.ndarray):
+    """Two smallest per row under (distance, index) order.  Returns d2_0, d2_1, i0, i1."""
+    na, nb = d2.shape
+    i0 = np.argmin(d2, axis=1)                        # first occurrence = lowest index on ties
+    r = np.arange(na)
+    v0 = d2[r, i0]
+    if nb < 2:
+        return v0, np.full(na, np.inf, np.float32), i0, np.full(na, -1, np.int64)
+    masked = d2.copy()
+    masked[r, i0] = np.inf
+    i1 = np.argmin(masked, axis=1)
+    return v0, masked[r, i1], i0, i1
+
+
+def bf_match(desc_a: np.ndarray, desc_b: np.ndarray, selector: str = "KNN", cross_check: bool = False,
+             ratio: float = 0.8):
+    """Returns (train_idx int32 [na] with -1 = no match, distance f32 [na]).
+
+    train_idx is exactly maps_of_indices[match_type] of base.cpp:483-491; the
+    DMatch list of the reference is {(i, train_idx[i], distance[i]) : train_idx[i] >= 0}
+    in query order.
+    """
+    na, nb = len(desc_a), len(desc_b)
+    if na == 0 or nb == 0:
+        return np.full(na, -1, np.int32), np.zeros(na, np.float32)
+    d2 = sq_distances(desc_a, desc_b)
+    v0, v1, i0, i1 = best_two(d2)
+    d0 = np.sqrt(v0.astype(np.float32))
+    d1 = np.sqrt(v1.astype(np.float32))
+    out = np.full(na, -1, np.int32)
+    if selector == "NN":
+        out[:] = i0
+        if cross_check:                                # base.cpp:27-28
+            best_q = {}
+            for q in range(na):
+                t = int(i0[q])
+                if t not in best_q or d0[q] < d0[best_q[t]]:
+                    best_q[t] = q
+            for q in range(na):
+                if best_q[int(i0[q])] != q:
+                    out[q] = -1
+    elif selector == "KNN":
+        if nb >= 2:
+            keep = d0 < np.float32(ratio) * d1          # base.cpp:469
+            out[keep] = i0[keep]
+    else:
+        raise ValueError(selector)
+    return out, d0

@@ -1,0 +1,226 @@
+// match.hip.h -- K12/K13: brute-force 256-d L2 descriptor matching.
+//
+// Replaces cv::BFMatcher(NORM_L2)::match / knnMatch(k=2) + ratio test
+// (reference: src/odml_visual_odometry/src/feature_detection_base.cpp:27-28,
+// 462-491).  Structure:
+//   K12a  S = A * B^T on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), tile
+//         32 queries x 128 train rows per workgroup, approximate
+//         d2 = |a|^2 + |b|^2 - 2 S, per-(query, 128-column group) top-4 kept in LDS
+//   K12b  exact re-rank: one wave per query recomputes the canonical distance
+//         sum_k (a_k - b_k)^2 (sequential k, separate multiply and add roundings,
+//         i.e. bit-identical to the oracle) for the <= 4*groups shortlisted rows
+//         and picks the best two under (distance, train index) order -- strict
+//         '<' so the lowest train index wins ties, as BFMatcher does
+//   K13   selector: NN (+ OpenCV's crossCheck rule) or KNN ratio test
+// Integer outputs (train indices) are therefore independent of the MFMA
+// rounding; the MFMA only prunes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "conv_mfma.hip.h"
+
+namespace spvo {
+
+constexpr int MATCH_D = 256;
+constexpr int MATCH_QT = 32;     // queries per workgroup
+constexpr int MATCH_TT = 128;    // train rows per workgroup (4 waves x 32)
+constexpr int MATCH_KEEP = 4;    // shortlist per (query, column group)
+
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const float *__restrict__ x, int n,
+                                                         float *__restrict__ out) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= n) return;
+  const float4 v = *(const float4 *)(x + (size_t)r * MATCH_D + lane * 4);
+  float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) out[r] = s;
+}
+
+// K12a. grid = (ceil(nb/128), ceil(na/32)).  shortlist[q][group][MATCH_KEEP] (train idx, -1 = none)
+__global__ __launch_bounds__(256) void match_gemm_kernel(const float *__restrict__ A, int na,
+                                                         const float *__restrict__ B, int nb,
+                                                         const float *__restrict__ nA,
+                                                         const float *__restrict__ nB,
+                                                         int *__restrict__ shortlist, int groups) {
+  constexpr int KH = 128;          // K processed in two halves
+  constexpr int LD = KH + 1;       // padded row: conflict-free ds_read_b32 down a column
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *sA = smem;                       // [32][LD]
+  float *sB = smem + MATCH_QT * LD;       // [128][LD]
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q0 = blockIdx.y * MATCH_QT, t0 = blockIdx.x * MATCH_TT;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  for (int kh = 0; kh < MATCH_D; kh += KH) {
+    __syncthreads();
+    // stage A (32 x 128) and B (128 x 128) halves; float4 global loads, scalar LDS stores
+    for (int i = tid; i < (MATCH_QT + MATCH_TT) * (KH / 4); i += 256) {
+      const int row = i / (KH / 4), c4 = i - row * (KH / 4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      float *dst;
+      if (row < MATCH_QT) {
+        if (q0 + row < na) v = *(const float4 *)(A + (size_t)(q0 + row) * MATCH_D + kh + c4 * 4);
+        dst = sA + row * LD + c4 * 4;
+      } else {
+        const int tr = row - MATCH_QT;
+        if (t0 + tr < nb) v = *(const float4 *)(B + (size_t)(t0 + tr) * MATCH_D + kh + c4 * 4);
+        dst = sB + tr * LD + c4 * 4;
+      }
+      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+    __syncthreads();
+    // D[i = query][jj = train]: A operand lane -> A[q = j][k = 2s + half], B operand -> B[t = j][k]
+    const float *pa = sA + j * LD + half;
+    const float *pb = sB + (wave * 32 + j) * LD + half;
+#pragma unroll 16
+    for (int s = 0; s < KH / 2; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * s], pb[2 * s], acc, 0, 0, 0);
+  }
+  __syncthreads();
+  // approximate squared distances -> LDS [32 q][128 t + 1]
+  float *sD = smem;
+  constexpr int LDD = MATCH_TT + 1;
+  {
+    const int t = t0 + wave * 32 + j;
+    const float nbv = (t < nb) ? nB[t] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int q = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float nav = (q0 + q < na) ? nA[q0 + q] : 0.f;
+      sD[q * LDD + wave * 32 + j] = (t < nb) ? (nav + nbv - 2.f * acc[r]) : __builtin_inff();
+    }
+  }
+  __syncthreads();
+  if (tid < MATCH_QT && q0 + tid < na) {
+    float bd[MATCH_KEEP];
+    int bi[MATCH_KEEP];
+#pragma unroll
+    for (int k = 0; k < MATCH_KEEP; ++k) { bd[k] = __builtin_inff(); bi[k] = -1; }
+    const int ncol = min(MATCH_TT, nb - t0);
+    for (int c = 0; c < ncol; ++c) {
+      float d = sD[tid * LDD + c];
+      int idx = t0 + c;
+      // insertion into the sorted shortlist; strict '<' keeps the lower index on ties
+#pragma unroll
+      for (int k = 0; k < MATCH_KEEP; ++k) {
+        if (d < bd[k]) {
+          const float td = bd[k]; const int ti = bi[k];
+          bd[k] = d; bi[k] = idx; d = td; idx = ti;
+        }
+      }
+    }
+    int *o = shortlist + ((size_t)(q0 + tid) * groups + blockIdx.x) * MATCH_KEEP;
+#pragma unroll
+    for (int k = 0; k < MATCH_KEEP; ++k) o[k] = bi[k];
+  }
+}
+
+// K12b. One wave per query; lane c re-scores shortlisted candidate c exactly.
+// Handles groups*MATCH_KEEP candidates in passes of 64.
+// best[q] = {d2_0, d2_1 (f32 bits), idx0, idx1}
+__global__ __launch_bounds__(256) void match_rerank_kernel(const float *__restrict__ A, int na,
+                                                           const float *__restrict__ B, int nb,
+                                                           const int *__restrict__ shortlist,
+                                                           int groups, float *__restrict__ best_d2,
+                                                           int *__restrict__ best_idx) {
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (q >= na) return;
+  const int ncand = groups * MATCH_KEEP;
+  const float *a = A + (size_t)q * MATCH_D;
+  float d0 = __builtin_inff(), d1 = __builtin_inff();
+  int i0 = -1, i1 = -1;
+  for (int base = 0; base < ncand; base += 64) {
+    const int c = base + lane;
+    const int idx = (c < ncand) ? shortlist[(size_t)q * ncand + c] : -1;
+    float d = __builtin_inff();
+    if (idx >= 0) {
+      const float *b = B + (size_t)idx * MATCH_D;
+      float s = 0.f;
+      for (int k = 0; k < MATCH_D; k += 4) {
+        const float4 av = *(const float4 *)(a + k);
+        const float4 bv = *(const float4 *)(b + k);
+        float t;
+        t = __fsub_rn(av.x, bv.x); s = __fadd_rn(s, __fmul_rn(t, t));
+        t = __fsub_rn(av.y, bv.y); s = __fadd_rn(s, __fmul_rn(t, t));
+        t = __fsub_rn(av.z, bv.z); s = __fadd_rn(s, __fmul_rn(t, t));
+        t = __fsub_rn(av.w, bv.w); s = __fadd_rn(s, __fmul_rn(t, t));
+      }
+      d = s;
+    }
+    // two rounds of wave arg-min under (d, idx) order
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+      float md = d;
+      int mi = (idx >= 0) ? idx : 0x7FFFFFFF;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        const float od = __shfl_xor(md, o);
+        const int oi = __shfl_xor(mi, o);
+        if (od < md || (od == md && oi < mi)) { md = od; mi = oi; }
+      }
+      if (mi == 0x7FFFFFFF || md == __builtin_inff()) break;
+      // merge (md, mi) into the running best two
+      if (md < d0 || (md == d0 && mi < i0) || i0 < 0) {
+        d1 = d0; i1 = i0; d0 = md; i0 = mi;
+      } else if (md < d1 || (md == d1 && mi < i1) || i1 < 0) {
+        d1 = md; i1 = mi;
+      }
+      if (idx == mi) d = __builtin_inff();  // remove the winner for the second round
+    }
+  }
+  if (lane == 0) {
+    best_d2[2 * q] = d0; best_d2[2 * q + 1] = d1;
+    best_idx[2 * q] = i0; best_idx[2 * q + 1] = i1;
+  }
+}
+
+// OpenCV crossCheck (batchDistance, crosscheck=true, K=1): for every train row the
+// query with the smallest distance among those that chose it (lowest query index
+// on ties) wins; other queries that chose the same train row are dropped.
+__global__ __launch_bounds__(256) void match_cross_scatter_kernel(const float *__restrict__ best_d2,
+                                                                  const int *__restrict__ best_idx,
+                                                                  int na,
+                                                                  unsigned long long *__restrict__ train_best) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= na) return;
+  const int t = best_idx[2 * q];
+  if (t < 0) return;
+  const float d = sqrtf(best_d2[2 * q]);
+  atomicMin(&train_best[t], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)q);
+}
+
+// K13. selector 0 = NN, 1 = KNN(k=2) + ratio test (base.cpp:462-473).
+__global__ __launch_bounds__(256) void match_select_kernel(const float *__restrict__ best_d2,
+                                                           const int *__restrict__ best_idx, int na,
+                                                           int selector, int cross_check, float ratio,
+                                                           const unsigned long long *__restrict__ train_best,
+                                                           int *__restrict__ train_idx,
+                                                           float *__restrict__ distance) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= na) return;
+  const int i0 = best_idx[2 * q], i1 = best_idx[2 * q + 1];
+  const float d0 = sqrtf(best_d2[2 * q]);   // BFMatcher L2 returns sqrt(sum of squares)
+  const float d1 = sqrtf(best_d2[2 * q + 1]);
+  int out = -1;
+  if (selector == 0) {
+    if (i0 >= 0) {
+      out = i0;
+      if (cross_check && (int)(train_best[i0] & 0xFFFFFFFFull) != q) out = -1;
+    }
+  } else {
+    // the reference reads knn_match[1] unguarded (base.cpp:469); with < 2 train rows
+    // there is no second neighbour and nothing is kept here
+    if (i0 >= 0 && i1 >= 0 && d0 < __fmul_rn(ratio, d1)) out = i0;
+  }
+  train_idx[q] = out;
+  distance[q] = d0;
+}
+
+}  // namespace spvo

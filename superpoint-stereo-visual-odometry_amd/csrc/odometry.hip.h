@@ -1,0 +1,725 @@
+// odometry.hip.h -- K14 (stereo triangulation), K15 (deterministic PnP-RANSAC)
+// and K16 (PnP refinement: Levenberg-Marquardt on CostFunctor32 blocks), all f64.
+//
+// Replaces, in FeatureFrontEnd::solveStereoOdometry
+// (reference: src/odml_visual_odometry/src/feature_detection_base.cpp:125-399):
+//   cv::triangulatePoints + convertPointsFromHomogeneous      base.cpp:211-223
+//   cv::solvePnPRansac(..., 500, 2.0, 0.999, USAC_ACCURATE)   base.cpp:237-239
+//   ceres::Solve on CostFunctor32 blocks, HuberLoss(1.0)      base.cpp:282-375,
+//       include/odml_visual_odometry/ceres_cost_function.hpp:27-58
+// These are latency-bound kernels (a few thousand residuals): wave/block
+// reductions, no MFMA.  Algorithms are stated in oracle/odometry.py.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace spvo {
+
+// ------------------------------------------------------------- small f64 helpers
+__device__ __forceinline__ void quat_to_rot(const double *q, double *R) {
+  // Eigen::Quaternion::toRotationMatrix (no normalisation)
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+  R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+__device__ __forceinline__ void quat_mul(const double *a, const double *b, double *o) {
+  const double ax = a[0], ay = a[1], az = a[2], aw = a[3];
+  const double bx = b[0], by = b[1], bz = b[2], bw = b[3];
+  o[0] = aw * bx + ax * bw + ay * bz - az * by;
+  o[1] = aw * by - ax * bz + ay * bw + az * bx;
+  o[2] = aw * bz + ax * by - ay * bx + az * bw;
+  o[3] = aw * bw - ax * bx - ay * by - az * bz;
+}
+
+__device__ inline void rvec_to_quat(const double *r, double *q) {
+  // base.cpp:274-278: AngleAxisd(|r|, r.normalized()) -> Quaterniond
+  const double angle = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  double ax = r[0], ay = r[1], az = r[2];
+  if (angle > 0) { ax /= angle; ay /= angle; az /= angle; }
+  const double s = sin(angle / 2);
+  q[0] = ax * s; q[1] = ay * s; q[2] = az * s; q[3] = cos(angle / 2);
+}
+
+__device__ inline void quat_to_rvec(const double *qin, double *r) {
+  double x = qin[0], y = qin[1], z = qin[2], w = qin[3];
+  if (w < 0) { x = -x; y = -y; z = -z; w = -w; }
+  const double n = sqrt(x * x + y * y + z * z);
+  if (n < 1e-300) { r[0] = r[1] = r[2] = 0; return; }
+  const double angle = 2 * atan2(n, w);
+  r[0] = x / n * angle; r[1] = y / n * angle; r[2] = z / n * angle;
+}
+
+// Gaussian elimination with partial pivoting, N x N, A row-major, solves A x = b in place.
+template <int N>
+__device__ inline bool solve_linear(double *A, double *b) {
+  for (int c = 0; c < N; ++c) {
+    int piv = c;
+    double best = fabs(A[c * N + c]);
+    for (int r = c + 1; r < N; ++r) {
+      const double v = fabs(A[r * N + c]);
+      if (v > best) { best = v; piv = r; }
+    }
+    if (!(best > 1e-300) || !isfinite(best)) return false;
+    if (piv != c) {
+      for (int k = 0; k < N; ++k) { const double tmp = A[c * N + k]; A[c * N + k] = A[piv * N + k]; A[piv * N + k] = tmp; }
+      const double tb = b[c]; b[c] = b[piv]; b[piv] = tb;
+    }
+    const double inv = 1.0 / A[c * N + c];
+    for (int r = c + 1; r < N; ++r) {
+      const double f = A[r * N + c] * inv;
+      if (f != 0) {
+        for (int k = c; k < N; ++k) A[r * N + k] -= f * A[c * N + k];
+        b[r] -= f * b[c];
+      }
+    }
+  }
+  for (int r = N - 1; r >= 0; --r) {
+    double s = b[r];
+    for (int k = r + 1; k < N; ++k) s -= A[r * N + k] * b[k];
+    b[r] = s / A[r * N + r];
+  }
+  for (int k = 0; k < N; ++k)
+    if (!isfinite(b[k])) return false;
+  return true;
+}
+
+// ------------------------------------------------------------------------- K14
+// One thread per point: 4x4 DLT system, one-sided Jacobi SVD (Hestenes) in f64,
+// right-singular vector of the smallest singular value, stored f32, then x/w in f32.
+__global__ __launch_bounds__(256) void triangulate_kernel(const double *__restrict__ Pl,
+                                                          const double *__restrict__ Pr,
+                                                          const float *__restrict__ xyl,
+                                                          const float *__restrict__ xyr, int n,
+                                                          float *__restrict__ xyz) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double A[16], V[16];
+  {
+    const double x0 = xyl[2 * i], y0 = xyl[2 * i + 1], x1 = xyr[2 * i], y1 = xyr[2 * i + 1];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      A[0 * 4 + k] = x0 * Pl[8 + k] - Pl[0 + k];
+      A[1 * 4 + k] = y0 * Pl[8 + k] - Pl[4 + k];
+      A[2 * 4 + k] = x1 * Pr[8 + k] - Pr[0 + k];
+      A[3 * 4 + k] = y1 * Pr[8 + k] - Pr[4 + k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) V[k] = ((k >> 2) == (k & 3)) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    bool changed = false;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int q = p + 1; q < 4; ++q) {
+        double a = 0, b = 0, c = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          a += A[r * 4 + p] * A[r * 4 + p];
+          b += A[r * 4 + q] * A[r * 4 + q];
+          c += A[r * 4 + p] * A[r * 4 + q];
+        }
+        if (fabs(c) <= 2.220446049250313e-16 * sqrt(a * b)) continue;
+        changed = true;
+        const double zeta = (b - a) / (2.0 * c);
+        const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double ap = A[r * 4 + p], aq = A[r * 4 + q];
+          A[r * 4 + p] = cs * ap - sn * aq;
+          A[r * 4 + q] = sn * ap + cs * aq;
+          const double vp = V[r * 4 + p], vq = V[r * 4 + q];
+          V[r * 4 + p] = cs * vp - sn * vq;
+          V[r * 4 + q] = sn * vp + cs * vq;
+        }
+      }
+    if (!changed) break;
+  }
+  int best = 0;
+  double bn = 1e300;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double s = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s += A[r * 4 + c] * A[r * 4 + c];
+    if (s < bn) { bn = s; best = c; }
+  }
+  float h[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double v = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v = (c == best) ? V[r * 4 + c] : v;
+    h[r] = (float)v;
+  }
+  const float scale = (h[3] != 0.f) ? __fdiv_rn(1.0f, h[3]) : 1.0f;
+  xyz[3 * i + 0] = __fmul_rn(h[0], scale);
+  xyz[3 * i + 1] = __fmul_rn(h[1], scale);
+  xyz[3 * i + 2] = __fmul_rn(h[2], scale);
+}
+
+// ------------------------------------------------------------------------- K15
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+
+// residual (2) and Jacobian (2x6: small left rotation, translation) of one 3D-2D pair
+__device__ __forceinline__ void pnp_residual_jac(const double *K, const double *R, const double *t,
+                                                 const double *X, const double *uv, double *r,
+                                                 double *J) {
+  const double Y0 = R[0] * X[0] + R[1] * X[1] + R[2] * X[2];
+  const double Y1 = R[3] * X[0] + R[4] * X[1] + R[5] * X[2];
+  const double Y2 = R[6] * X[0] + R[7] * X[1] + R[8] * X[2];
+  const double c0 = Y0 + t[0], c1 = Y1 + t[1], c2 = Y2 + t[2];
+  const double p0 = K[0] * c0 + K[1] * c1 + K[2] * c2;
+  const double p1 = K[3] * c0 + K[4] * c1 + K[5] * c2;
+  const double p2 = K[6] * c0 + K[7] * c1 + K[8] * c2;
+  const double u = p0 / p2, v = p1 / p2;
+  r[0] = u - uv[0];
+  r[1] = v - uv[1];
+  if (J) {
+    const double du0 = (K[0] - u * K[6]) / p2, du1 = (K[1] - u * K[7]) / p2, du2 = (K[2] - u * K[8]) / p2;
+    const double dv0 = (K[3] - v * K[6]) / p2, dv1 = (K[4] - v * K[7]) / p2, dv2 = (K[5] - v * K[8]) / p2;
+    // -(d . [Y]x): column k of -[Y]x ; [Y]x = [[0,-Y2,Y1],[Y2,0,-Y0],[-Y1,Y0,0]]
+    J[0] = -(du1 * Y2 - du2 * Y1);
+    J[1] = -(-du0 * Y2 + du2 * Y0);
+    J[2] = -(du0 * Y1 - du1 * Y0);
+    J[3] = du0; J[4] = du1; J[5] = du2;
+    J[6] = -(dv1 * Y2 - dv2 * Y1);
+    J[7] = -(-dv0 * Y2 + dv2 * Y0);
+    J[8] = -(dv0 * Y1 - dv1 * Y0);
+    J[9] = dv0; J[10] = dv1; J[11] = dv2;
+  }
+}
+
+__device__ __forceinline__ void apply_delta(double *q, double *t, const double *d) {
+  const double dq[4] = {d[0] / 2, d[1] / 2, d[2] / 2, 1.0};
+  double qn[4];
+  quat_mul(dq, q, qn);
+  const double n = sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+  q[0] = qn[0] / n; q[1] = qn[1] / n; q[2] = qn[2] / n; q[3] = qn[3] / n;
+  t[0] += d[3]; t[1] += d[4]; t[2] += d[5];
+}
+
+__device__ __forceinline__ bool reproj_inlier(const double *K, const double *R, const double *t,
+                                              const float *X, const float *uv, double thr2) {
+  const double x = X[0], y = X[1], z = X[2];
+  const double c0 = R[0] * x + R[1] * y + R[2] * z + t[0];
+  const double c1 = R[3] * x + R[4] * y + R[5] * z + t[1];
+  const double c2 = R[6] * x + R[7] * y + R[8] * z + t[2];
+  const double p0 = K[0] * c0 + K[1] * c1 + K[2] * c2;
+  const double p1 = K[3] * c0 + K[4] * c1 + K[5] * c2;
+  const double p2 = K[6] * c0 + K[7] * c1 + K[8] * c2;
+  const double du = p0 / p2 - (double)uv[0], dv = p1 / p2 - (double)uv[1];
+  const double e2 = du * du + dv * dv;
+  return (p2 > 0) && (e2 <= thr2);
+}
+
+struct RansacWork {      // device scratch
+  int *counts;           // [iterations]  (-1 = invalid hypothesis)
+  double *poses;         // [iterations][7]  q(xyzw), t
+  double *result;        // [8]: rvec(3), tvec(3), ok, n_inliers
+  int *inliers;          // [n]
+};
+
+// one wave per hypothesis: lane 0 solves the minimal problem, all lanes score
+__global__ __launch_bounds__(64) void ransac_hypothesis_kernel(const double *__restrict__ Kd,
+                                                               const float *__restrict__ xyz,
+                                                               const float *__restrict__ xy, int n,
+                                                               const double *__restrict__ prior,  // rvec, tvec
+                                                               uint32_t seed, double thr2,
+                                                               RansacWork w) {
+  __shared__ double sh[16];
+  __shared__ double sJ[36], sf[6], sd[6];   // lane 0's Newton system (LDS: dynamically indexed)
+  __shared__ int sh_ok;
+  const int it = blockIdx.x, lane = threadIdx.x;
+  double K[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) K[k] = Kd[k];
+  if (lane == 0) {
+    int idx[3];
+    for (int k = 0; k < 3; ++k) {
+      uint32_t attempt = 0;
+      while (true) {
+        const uint32_t r = hash32(seed * 0x9E3779B9u + (uint32_t)it * 0x85EBCA6Bu + (uint32_t)k * 0xC2B2AE35u + attempt * 0x27D4EB2Fu) % (uint32_t)n;
+        bool dup = false;
+        for (int m = 0; m < k; ++m) dup |= (idx[m] == (int)r);
+        if (!dup) { idx[k] = (int)r; break; }
+        ++attempt;
+      }
+    }
+    double q[4], t[3];
+    rvec_to_quat(prior, q);
+    t[0] = prior[3]; t[1] = prior[4]; t[2] = prior[5];
+    double X3[9], uv3[6];
+    for (int k = 0; k < 3; ++k) {
+      for (int c = 0; c < 3; ++c) X3[3 * k + c] = xyz[3 * idx[k] + c];
+      for (int c = 0; c < 2; ++c) uv3[2 * k + c] = xy[2 * idx[k] + c];
+    }
+    bool ok = false, bad = false;
+    for (int iter = 0; iter < 10 && !bad; ++iter) {
+      double R[9];
+      double *f = sf, *J = sJ;
+      quat_to_rot(q, R);
+      for (int k = 0; k < 3; ++k) pnp_residual_jac(K, R, t, X3 + 3 * k, uv3 + 2 * k, f + 2 * k, J + 12 * k);
+      double fm = 0;
+      bool fin = true;
+      for (int k = 0; k < 6; ++k) { fm = fmax(fm, fabs(f[k])); fin &= isfinite(f[k]); }
+      for (int k = 0; k < 36; ++k) fin &= isfinite(J[k]);
+      if (!fin) { bad = true; break; }
+      if (fm < 1e-9) { ok = true; break; }
+      double *d = sd;
+      for (int k = 0; k < 6; ++k) d[k] = -f[k];
+      if (!solve_linear<6>(J, d)) { bad = true; break; }
+      double dm = 0;
+      for (int k = 0; k < 6; ++k) dm = fmax(dm, fabs(d[k]));
+      if (dm > 1e3) { bad = true; break; }
+      apply_delta(q, t, d);
+    }
+    if (!ok && !bad) {
+      double R[9], f[2];
+      quat_to_rot(q, R);
+      double fm = 0;
+      bool fin = true;
+      for (int k = 0; k < 3; ++k) {
+        pnp_residual_jac(K, R, t, X3 + 3 * k, uv3 + 2 * k, f, nullptr);
+        fm = fmax(fm, fmax(fabs(f[0]), fabs(f[1])));
+        fin &= isfinite(f[0]) && isfinite(f[1]);
+      }
+      ok = fin && fm < 1e-6;
+    }
+    sh_ok = (ok && !bad) ? 1 : 0;
+    for (int k = 0; k < 4; ++k) sh[k] = q[k];
+    for (int k = 0; k < 3; ++k) sh[4 + k] = t[k];
+  }
+  __syncthreads();
+  if (!sh_ok) {
+    if (lane == 0) w.counts[it] = -1;
+    return;
+  }
+  double R[9], t[3];
+  quat_to_rot(sh, R);
+  t[0] = sh[4]; t[1] = sh[5]; t[2] = sh[6];
+  int cnt = 0;
+  for (int i = lane; i < n; i += 64) cnt += reproj_inlier(K, R, t, xyz + 3 * i, xy + 2 * i, thr2) ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
+  if (lane == 0) {
+    w.counts[it] = cnt;
+    for (int k = 0; k < 7; ++k) w.poses[7 * it + k] = sh[k];
+  }
+}
+
+// deterministic block reduction of NV doubles per thread; result valid in thread 0's `out`
+template <int NV, int NT>
+__device__ inline void block_reduce(const double *v, double *out, double *scratch /*[NV][NT/64]*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double x = v[k];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
+    if (lane == 0) scratch[k * (NT / 64) + wave] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      double s = 0;
+      for (int wv = 0; wv < NT / 64; ++wv) s += scratch[k * (NT / 64) + wv];
+      out[k] = s;
+    }
+  }
+  __syncthreads();
+}
+
+// pick the best hypothesis, list its inliers in ascending order, Gauss-Newton refit
+__global__ __launch_bounds__(256) void ransac_select_kernel(const double *__restrict__ Kd,
+                                                            const float *__restrict__ xyz,
+                                                            const float *__restrict__ xy, int n,
+                                                            const double *__restrict__ prior,
+                                                            int iterations, double thr2, RansacWork w) {
+  __shared__ int s_cnt[256], s_it[256];
+  __shared__ double s_pose[7];
+  __shared__ int s_base, s_wave_cnt[4];
+  __shared__ double s_red[27 * 4];
+  __shared__ double s_sum[27];
+  __shared__ int s_flag;
+  __shared__ double s_A[36], s_d[6];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double K[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) K[k] = Kd[k];
+  int bc = -1, bi = 0x7FFFFFFF;
+  for (int it = tid; it < iterations; it += 256) {
+    const int c = w.counts[it];
+    if (c > bc) { bc = c; bi = it; }   // ascending it per thread: first max kept
+  }
+  s_cnt[tid] = bc; s_it[tid] = bi;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if (tid < s) {
+      const int oc = s_cnt[tid + s], oi = s_it[tid + s];
+      if (oc > s_cnt[tid] || (oc == s_cnt[tid] && oi < s_it[tid])) { s_cnt[tid] = oc; s_it[tid] = oi; }
+    }
+    __syncthreads();
+  }
+  const int best_cnt = s_cnt[0], best_it = s_it[0];
+  if (best_cnt < 4) {
+    if (tid == 0) {
+      for (int k = 0; k < 6; ++k) w.result[k] = prior[k];
+      w.result[6] = 0; w.result[7] = 0;
+    }
+    return;
+  }
+  if (tid < 7) s_pose[tid] = w.poses[7 * best_it + tid];
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  double R[9], t[3];
+  quat_to_rot(s_pose, R);
+  t[0] = s_pose[4]; t[1] = s_pose[5]; t[2] = s_pose[6];
+  // ordered compaction of the inlier indices
+  for (int base = 0; base < n; base += 256) {
+    const int i = base + tid;
+    const bool in = (i < n) && reproj_inlier(K, R, t, xyz + 3 * i, xy + 2 * i, thr2);
+    const unsigned long long m = __ballot(in);
+    if (lane == 0) s_wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = s_base;
+    for (int wv = 0; wv < wave; ++wv) off += s_wave_cnt[wv];
+    if (in) w.inliers[off + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    __syncthreads();
+    if (tid == 0) s_base += s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+    __syncthreads();
+  }
+  const int ninl = s_base;
+  // Gauss-Newton refit on the inliers (left camera, no robust loss)
+  for (int iter = 0; iter < 10; ++iter) {
+    quat_to_rot(s_pose, R);
+    t[0] = s_pose[4]; t[1] = s_pose[5]; t[2] = s_pose[6];
+    double acc[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] = 0;
+    for (int k = tid; k < ninl; k += 256) {
+      const int i = w.inliers[k];
+      const double X[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+      const double uv[2] = {xy[2 * i], xy[2 * i + 1]};
+      double r[2], J[12];
+      pnp_residual_jac(K, R, t, X, uv, r, J);
+      int o = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 6; ++b) acc[o++] += J[a] * J[b] + J[6 + a] * J[6 + b];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r[0] + J[6 + a] * r[1];
+    }
+    block_reduce<27, 256>(acc, s_sum, s_red);
+    if (tid == 0) {
+      double *A = s_A, *d = s_d;
+      int o = 0;
+      for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b) { A[a * 6 + b] = s_sum[o]; A[b * 6 + a] = s_sum[o]; ++o; }
+      for (int a = 0; a < 6; ++a) d[a] = -s_sum[21 + a];
+      int flag = 0;
+      if (solve_linear<6>(A, d)) {
+        apply_delta(s_pose, s_pose + 4, d);
+        double dm = 0;
+        for (int a = 0; a < 6; ++a) dm = fmax(dm, fabs(d[a]));
+        flag = (dm < 1e-10) ? 1 : 0;
+      } else {
+        flag = 1;
+      }
+      s_flag = flag;
+    }
+    __syncthreads();
+    if (s_flag) break;
+  }
+  if (tid == 0) {
+    quat_to_rvec(s_pose, w.result);
+    w.result[3] = s_pose[4]; w.result[4] = s_pose[5]; w.result[5] = s_pose[6];
+    w.result[6] = 1; w.result[7] = (double)ninl;
+  }
+}
+
+// ------------------------------------------------------------------------- K16
+struct ObsDev {   // mirrors spvo_obs (include/spvo.h)
+  float X[3];
+  float uv[2];
+  int32_t cam;
+  int32_t inverse;
+};
+
+// CostFunctor32 (cost.hpp:27-58): residual and analytic Jacobian wrt the
+// EigenQuaternionParameterization tangent (3) and t (3).
+__device__ __forceinline__ void cost32(const double *P /*3x4*/, const double *q, const double *R,
+                                       const double *t, const ObsDev &ob, double *r, double *J) {
+  const double X[3] = {ob.X[0], ob.X[1], ob.X[2]};
+  const bool inv = ob.inverse != 0;
+  const double w0 = inv ? X[0] - t[0] : X[0], w1 = inv ? X[1] - t[1] : X[1], w2 = inv ? X[2] - t[2] : X[2];
+  double T0, T1, T2;
+  if (!inv) {
+    T0 = R[0] * w0 + R[1] * w1 + R[2] * w2 + t[0];
+    T1 = R[3] * w0 + R[4] * w1 + R[5] * w2 + t[1];
+    T2 = R[6] * w0 + R[7] * w1 + R[8] * w2 + t[2];
+  } else {  // R^T (X - t)
+    T0 = R[0] * w0 + R[3] * w1 + R[6] * w2;
+    T1 = R[1] * w0 + R[4] * w1 + R[7] * w2;
+    T2 = R[2] * w0 + R[5] * w1 + R[8] * w2;
+  }
+  const double p0 = P[0] * T0 + P[1] * T1 + P[2] * T2 + P[3];
+  const double p1 = P[4] * T0 + P[5] * T1 + P[6] * T2 + P[7];
+  const double p2 = P[8] * T0 + P[9] * T1 + P[10] * T2 + P[11];
+  const double u = p0 / p2, v = p1 / p2;
+  r[0] = u - (double)ob.uv[0];
+  r[1] = v - (double)ob.uv[1];
+  if (!J) return;
+  const double du[3] = {(P[0] - u * P[8]) / p2, (P[1] - u * P[9]) / p2, (P[2] - u * P[10]) / p2};
+  const double dv[3] = {(P[4] - v * P[8]) / p2, (P[5] - v * P[9]) / p2, (P[6] - v * P[10]) / p2};
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  // dR/dq_k (Eigen polynomial), rows
+  const double dRx[9] = {0, 2 * y, 2 * z, 2 * y, -4 * x, -2 * w, 2 * z, 2 * w, -4 * x};
+  const double dRy[9] = {-4 * y, 2 * x, 2 * w, 2 * x, 0, 2 * z, -2 * w, 2 * z, -4 * y};
+  const double dRz[9] = {-4 * z, -2 * w, 2 * x, 2 * w, -4 * z, 2 * y, 2 * x, 2 * y, 0};
+  const double dRw[9] = {0, -2 * z, 2 * y, 2 * z, 0, -2 * x, -2 * y, 2 * x, 0};
+  const double *dR[4] = {dRx, dRy, dRz, dRw};
+  double Jq_u[4], Jq_v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double *D = dR[k];
+    double e0, e1, e2;
+    if (!inv) {
+      e0 = D[0] * w0 + D[1] * w1 + D[2] * w2;
+      e1 = D[3] * w0 + D[4] * w1 + D[5] * w2;
+      e2 = D[6] * w0 + D[7] * w1 + D[8] * w2;
+    } else {
+      e0 = D[0] * w0 + D[3] * w1 + D[6] * w2;
+      e1 = D[1] * w0 + D[4] * w1 + D[7] * w2;
+      e2 = D[2] * w0 + D[5] * w1 + D[8] * w2;
+    }
+    Jq_u[k] = du[0] * e0 + du[1] * e1 + du[2] * e2;
+    Jq_v[k] = dv[0] * e0 + dv[1] * e1 + dv[2] * e2;
+  }
+  // Plus jacobian G (4x3): rows [w,z,-y], [-z,w,x], [y,-x,w], [-x,-y,-z]
+  J[0] = Jq_u[0] * w - Jq_u[1] * z + Jq_u[2] * y - Jq_u[3] * x;
+  J[1] = Jq_u[0] * z + Jq_u[1] * w - Jq_u[2] * x - Jq_u[3] * y;
+  J[2] = -Jq_u[0] * y + Jq_u[1] * x + Jq_u[2] * w - Jq_u[3] * z;
+  J[6] = Jq_v[0] * w - Jq_v[1] * z + Jq_v[2] * y - Jq_v[3] * x;
+  J[7] = Jq_v[0] * z + Jq_v[1] * w - Jq_v[2] * x - Jq_v[3] * y;
+  J[8] = -Jq_v[0] * y + Jq_v[1] * x + Jq_v[2] * w - Jq_v[3] * z;
+  if (!inv) {
+    J[3] = du[0]; J[4] = du[1]; J[5] = du[2];
+    J[9] = dv[0]; J[10] = dv[1]; J[11] = dv[2];
+  } else {  // d/dt R^T (X - t) = -R^T  ->  -(d . R^T) = -(R d)
+    J[3] = -(R[0] * du[0] + R[3] * du[1] + R[6] * du[2]);
+    J[4] = -(R[1] * du[0] + R[4] * du[1] + R[7] * du[2]);
+    J[5] = -(R[2] * du[0] + R[5] * du[1] + R[8] * du[2]);
+    J[9] = -(R[0] * dv[0] + R[3] * dv[1] + R[6] * dv[2]);
+    J[10] = -(R[1] * dv[0] + R[4] * dv[1] + R[7] * dv[2]);
+    J[11] = -(R[2] * dv[0] + R[5] * dv[1] + R[8] * dv[2]);
+  }
+}
+
+struct RefineOut {   // device, doubles: q(4) t(3) iterations converged usable initial_cost final_cost
+  double v[12];
+};
+
+// Whole Levenberg-Marquardt loop in ONE workgroup: no host round trips.
+// All threads evaluate residual blocks; thread 0 runs the trust-region logic.
+template <int NT>
+__global__ __launch_bounds__(NT) void pnp_refine_kernel(const double *__restrict__ Pl,
+                                                        const double *__restrict__ Pr,
+                                                        const ObsDev *__restrict__ obs, int n_obs,
+                                                        const double *__restrict__ start /*q,t*/,
+                                                        int max_iterations, double huber_delta,
+                                                        RefineOut *__restrict__ out) {
+  __shared__ double s_P[24];
+  __shared__ double s_x[7], s_c[7];       // current / candidate parameters
+  __shared__ double s_red[28 * (NT / 64)];
+  __shared__ double s_sum[28];
+  __shared__ int s_action;                 // 0 continue with candidate eval, 1 stop
+  __shared__ int s_eval_jac;
+  const int tid = threadIdx.x;
+  if (tid < 12) { s_P[tid] = Pl[tid]; s_P[12 + tid] = Pr[tid]; }
+  if (tid < 7) s_x[tid] = start[tid];
+  __syncthreads();
+  const double b2 = huber_delta * huber_delta;
+
+  // evaluate at params p: acc[0..20] JtJ upper, [21..26] Jtr, [27] = sum rho
+  auto evaluate = [&](const double *p, bool want_jac) {
+    double q[4] = {p[0], p[1], p[2], p[3]}, t[3] = {p[4], p[5], p[6]}, R[9];
+    quat_to_rot(q, R);
+    double acc[28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) acc[k] = 0;
+    for (int i = tid; i < n_obs; i += NT) {
+      const ObsDev ob = obs[i];
+      double r[2], J[12];
+      cost32(s_P + (ob.cam ? 12 : 0), q, R, t, ob, r, want_jac ? J : nullptr);
+      const double s = r[0] * r[0] + r[1] * r[1];
+      double rho, rho1;
+      if (s > b2) { const double sq = sqrt(s); rho = 2 * huber_delta * sq - b2; rho1 = huber_delta / sq; }
+      else { rho = s; rho1 = 1.0; }
+      acc[27] += rho;
+      if (want_jac) {
+        // corrector with rho'' <= 0: residual and Jacobian scaled by sqrt(rho')
+        int o = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int b = a; b < 6; ++b) acc[o++] += rho1 * (J[a] * J[b] + J[6 + a] * J[6 + b]);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) acc[21 + a] += rho1 * (J[a] * r[0] + J[6 + a] * r[1]);
+      }
+    }
+    block_reduce<28, NT>(acc, s_sum, s_red);
+  };
+
+  // thread-0 state (arrays in LDS: they are indexed dynamically)
+  __shared__ double A[36], g[6], scale[6], ds[6], s_As[36], s_gs[6], s_M[36], s_rhs[6];
+  double cost = 0, radius = 1e4, decrease = 2.0, x_norm = 0;
+  double model_change = 0;
+  int invalid = 0, it = 0, converged = 0, usable = 0;
+  double initial_cost = 0, final_cost = 0;
+
+  evaluate(s_x, true);
+  if (tid == 0) {
+    int o = 0;
+    for (int a = 0; a < 6; ++a)
+      for (int b = a; b < 6; ++b) { A[a * 6 + b] = s_sum[o]; A[b * 6 + a] = s_sum[o]; ++o; }
+    for (int a = 0; a < 6; ++a) g[a] = s_sum[21 + a];
+    cost = 0.5 * s_sum[27];
+    initial_cost = final_cost = cost;
+    for (int a = 0; a < 6; ++a) scale[a] = 1.0 / (1.0 + sqrt(A[a * 6 + a]));
+    x_norm = 0;
+    for (int k = 0; k < 7; ++k) x_norm += s_x[k] * s_x[k];
+    x_norm = sqrt(x_norm);
+    int stop = 0;
+    if (!isfinite(cost)) stop = 1;
+    else {
+      usable = 1;
+      double gm = 0;
+      for (int a = 0; a < 6; ++a) gm = fmax(gm, fabs(g[a]));
+      if (gm <= 1e-10) { converged = 1; stop = 1; }
+    }
+    if (n_obs == 0) { converged = 1; usable = 1; stop = 1; }
+    s_action = stop;
+  }
+  __syncthreads();
+
+  while (!s_action) {
+    // ---- thread 0: compute a trust-region step (possibly several invalid ones)
+    if (tid == 0) {
+      int stop = 0, have_step = 0;
+      while (!stop && !have_step) {
+        if (it >= max_iterations) { stop = 1; break; }
+        ++it;
+        double *As = s_As, *gs = s_gs, *M = s_M, *rhs = s_rhs;
+        for (int a = 0; a < 6; ++a) {
+          gs[a] = g[a] * scale[a];
+          for (int b = 0; b < 6; ++b) As[a * 6 + b] = A[a * 6 + b] * scale[a] * scale[b];
+        }
+        for (int k = 0; k < 36; ++k) M[k] = As[k];
+        for (int a = 0; a < 6; ++a) {
+          const double dg = fmin(fmax(As[a * 6 + a], 1e-6), 1e32) / radius;
+          M[a * 6 + a] += dg;
+          rhs[a] = -gs[a];
+        }
+        bool ok = solve_linear<6>(M, rhs);
+        model_change = 0;
+        if (ok) {
+          for (int a = 0; a < 6; ++a) {
+            ds[a] = rhs[a];
+            double Ad = 0;
+            for (int b = 0; b < 6; ++b) Ad += As[a * 6 + b] * rhs[b];
+            model_change -= rhs[a] * (gs[a] + 0.5 * Ad);
+          }
+        }
+        if (!ok || !(model_change > 0)) {
+          if (++invalid >= 5) { usable = 0; stop = 1; break; }
+          radius /= decrease; decrease *= 2;
+          continue;
+        }
+        invalid = 0;
+        // candidate = Plus(x, ds * scale)
+        double d[6];
+        for (int a = 0; a < 6; ++a) d[a] = ds[a] * scale[a];
+        const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        double qc[4];
+        if (nd > 0) {
+          const double sn = sin(nd) / nd;
+          const double dq[4] = {sn * d[0], sn * d[1], sn * d[2], cos(nd)};
+          quat_mul(dq, s_x, qc);
+        } else {
+          for (int k = 0; k < 4; ++k) qc[k] = s_x[k];
+        }
+        for (int k = 0; k < 4; ++k) s_c[k] = qc[k];
+        for (int k = 0; k < 3; ++k) s_c[4 + k] = s_x[4 + k] + d[3 + k];
+        have_step = 1;
+      }
+      s_action = stop;
+    }
+    __syncthreads();
+    if (s_action) break;
+    evaluate(s_c, false);
+    if (tid == 0) {
+      const double cand_cost = 0.5 * s_sum[27];
+      double sn2 = 0;
+      for (int k = 0; k < 7; ++k) sn2 += (s_c[k] - s_x[k]) * (s_c[k] - s_x[k]);
+      int stop = 0, accept = 0;
+      if (sqrt(sn2) <= 1e-8 * (x_norm + 1e-8)) { converged = 1; stop = 1; }
+      else {
+        const double cost_change = cost - cand_cost;
+        if (fabs(cost_change) <= 1e-6 * cost) { converged = 1; stop = 1; }
+        else {
+          const double rel = cost_change / model_change;
+          if (isfinite(cand_cost) && rel > 1e-3) {
+            accept = 1;
+            radius = fmin(1e16, radius / fmax(1.0 / 3.0, 1.0 - (2.0 * rel - 1.0) * (2.0 * rel - 1.0) * (2.0 * rel - 1.0)));
+            decrease = 2.0;
+          } else {
+            radius /= decrease; decrease *= 2;
+          }
+        }
+      }
+      if (accept) for (int k = 0; k < 7; ++k) s_x[k] = s_c[k];
+      s_eval_jac = accept;
+      s_action = stop;
+    }
+    __syncthreads();
+    if (s_action) break;
+    if (s_eval_jac) {
+      evaluate(s_x, true);
+      if (tid == 0) {
+        int o = 0;
+        for (int a = 0; a < 6; ++a)
+          for (int b = a; b < 6; ++b) { A[a * 6 + b] = s_sum[o]; A[b * 6 + a] = s_sum[o]; ++o; }
+        for (int a = 0; a < 6; ++a) g[a] = s_sum[21 + a];
+        cost = 0.5 * s_sum[27];
+        final_cost = cost;
+        x_norm = 0;
+        for (int k = 0; k < 7; ++k) x_norm += s_x[k] * s_x[k];
+        x_norm = sqrt(x_norm);
+        double gm = 0;
+        for (int a = 0; a < 6; ++a) gm = fmax(gm, fabs(g[a]));
+        if (gm <= 1e-10 || radius < 1e-32) { converged = 1; s_action = 1; }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) {
+    for (int k = 0; k < 7; ++k) out->v[k] = s_x[k];
+    out->v[7] = it; out->v[8] = converged; out->v[9] = usable;
+    out->v[10] = initial_cost; out->v[11] = final_cost;
+  }
+}
+
+}  // namespace spvo

@@ -1,0 +1,301 @@
+// post.hip.h -- K0 (preprocess), K7 (softmax + depth-to-space), K8-K10 (threshold,
+// exact parallel greedy NMS, ranked emission) and K11 (descriptor sampling).
+//
+// Replaces the CPU post-processing of the reference:
+//   nn.cpp = src/odml_visual_odometry/src/feature_detection_neural_network.cpp
+//   base.cpp = src/odml_visual_odometry/src/feature_detection_base.cpp
+// All of these kernels are HBM/latency-bound integer and byte work: no MFMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "conv_mfma.hip.h"
+
+namespace spvo {
+
+// ---------------------------------------------------------------------------
+// K0: crop + cv::resize(INTER_LINEAR, 8-bit fixed point) + /255
+// (base.cpp:68-121, nn.cpp:159-160).  The per-row / per-column source index and
+// the two 11-bit coefficients are tabulated on the host in float32 exactly as
+// OpenCV does (resize.cpp); the kernel applies the integer arithmetic:
+//   hor = S[x0]*a0 + S[x1]*a1                         (int, scaled 2^11)
+//   out = (((b0*(hor0>>4))>>16) + ((b1*(hor1>>4))>>16) + 2) >> 2
+// Writes the resized u8 image (what nn.cpp:154 pushes to images_dq) and the
+// network input plane (padded layout, f32 = u8 * (1/255)).
+// ---------------------------------------------------------------------------
+struct ResizeTab {  // device arrays
+  const int *xi, *xa0, *xa1;  // [W]
+  const int *yi, *yb0, *yb1;  // [H]
+};
+
+__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t *__restrict__ src,
+                                                         size_t stride, int src_rows, int src_cols,
+                                                         int row_off, int col_off, int crop_rows,
+                                                         int crop_cols, ResizeTab tab, int H, int W,
+                                                         uint8_t *__restrict__ out_u8,
+                                                         float *__restrict__ out_plane, int hp,
+                                                         int wp, int identity) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= W || y >= H) return;
+  int v;
+  if (identity) {  // cv::resize copies when the sizes already match
+    v = src[(size_t)(row_off + y) * stride + col_off + x];
+  } else {
+    const int x0 = tab.xi[x], x1 = min(x0 + 1, crop_cols - 1);
+    const int y0 = tab.yi[y], y1 = min(y0 + 1, crop_rows - 1);
+    const int a0 = tab.xa0[x], a1 = tab.xa1[x], b0 = tab.yb0[y], b1 = tab.yb1[y];
+    const uint8_t *r0 = src + (size_t)(row_off + y0) * stride + col_off;
+    const uint8_t *r1 = src + (size_t)(row_off + y1) * stride + col_off;
+    const int h0 = (int)r0[x0] * a0 + (int)r0[x1] * a1;
+    const int h1 = (int)r1[x0] * a0 + (int)r1[x1] * a1;
+    v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+    v = min(max(v, 0), 255);
+  }
+  if (out_u8) out_u8[(size_t)y * W + x] = (uint8_t)v;
+  out_plane[(size_t)(y + PADY) * wp + (x + PADX)] = __fmul_rn((float)v, 1.0f / 255.0f);
+}
+
+// Dense f32 [B,1,H,W] -> padded input planes (spvo_forward's host-input path).
+__global__ __launch_bounds__(256) void pad_input_kernel(const float *__restrict__ in,
+                                                        float *__restrict__ out, int H, int W,
+                                                        int hp, int wp) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int img = blockIdx.z;
+  if (x >= W || y >= H) return;
+  out[(size_t)img * hp * wp + (size_t)(y + PADY) * wp + (x + PADX)] = in[((size_t)img * H + y) * W + x];
+}
+
+// Padded planes -> dense NCHW (test hook / det output).
+__global__ __launch_bounds__(256) void unpad_kernel(const float *__restrict__ in,
+                                                    float *__restrict__ out, int C, int H, int W,
+                                                    int hp, int wp) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int c = blockIdx.z;  // image*C + channel
+  if (x >= W || y >= H) return;
+  out[((size_t)c * H + y) * W + x] = in[(size_t)c * hp * wp + (size_t)(y + PADY) * wp + (x + PADX)];
+}
+
+// ---------------------------------------------------------------------------
+// K7: softmax over 65 channels (exp without max-subtraction, +1e-5 in the
+// denominator), drop the dustbin, depth-to-space 8x8  (nn.cpp:266-326):
+//   heat[8i+u][8j+v] = exp(det[8u+v][i][j]) / (sum_c exp(det[c][i][j]) + 1e-5)
+// One thread per coarse cell; reads are coalesced along j.  `det` is either the
+// padded-plane tensor (PADDED) or a dense [65][Hc][Wc] array.
+// ---------------------------------------------------------------------------
+template <bool PADDED>
+__global__ __launch_bounds__(256) void heatmap_kernel(const float *__restrict__ det,
+                                                      float *__restrict__ heat, int Hc, int Wc,
+                                                      int hp, int wp) {
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int img = blockIdx.z;
+  if (i >= Hc || j >= Wc) return;
+  const size_t plane = PADDED ? (size_t)hp * wp : (size_t)Hc * Wc;
+  const float *p = det + (size_t)img * 65 * plane +
+                   (PADDED ? (size_t)(i + PADY) * wp + (j + PADX) : (size_t)i * Wc + j);
+  float e[65];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < 65; ++c) {
+    e[c] = expf(p[(size_t)c * plane]);
+    s = __fadd_rn(s, e[c]);
+  }
+  s = __fadd_rn(s, 0.00001f);
+  const int W = Wc * 8;
+  float *h = heat + (size_t)img * (Hc * 8) * W + (size_t)(i * 8) * W + j * 8;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    float4 lo, hi;
+    lo.x = __fdiv_rn(e[u * 8 + 0], s);
+    lo.y = __fdiv_rn(e[u * 8 + 1], s);
+    lo.z = __fdiv_rn(e[u * 8 + 2], s);
+    lo.w = __fdiv_rn(e[u * 8 + 3], s);
+    hi.x = __fdiv_rn(e[u * 8 + 4], s);
+    hi.y = __fdiv_rn(e[u * 8 + 5], s);
+    hi.z = __fdiv_rn(e[u * 8 + 6], s);
+    hi.w = __fdiv_rn(e[u * 8 + 7], s);
+    *(float4 *)(h + (size_t)u * W) = lo;
+    *(float4 *)(h + (size_t)u * W + 4) = hi;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K8-K10: processOneHeatmap (nn.cpp:188-262) as an exact parallel algorithm.
+//
+// Rank: the reference sorts candidates by confidence descending with an
+// unstable std::sort after walking a column-major sparse matrix; the total
+// order pinned here (and in the oracle) is
+//     key = (0xFFFFFFFF - float_bits(conf)) << 32 | (x*H + y),  smaller = earlier.
+// Greedy NMS visits candidates in rank order and keeps one iff no earlier KEPT
+// candidate lies within Chebyshev distance `dist` (nn.cpp:229-254).  That is the
+// lexicographically-first maximal independent set of the "within dist" graph,
+// which is computed without sorting by monotone local decisions:
+//     UNDECIDED -> SUPPRESSED  if a KEPT candidate is in its window
+//     UNDECIDED -> KEPT        if no KEPT and no better-ranked UNDECIDED candidate
+//                              is in its window
+// Decisions are final and each one equals the greedy outcome, whatever order or
+// staleness the neighbour states are observed with (a stale read can only show
+// UNDECIDED, which defers the decision).  The best undecided candidate of the
+// whole image is always decided, so the loop terminates.
+// Border candidates suppress but are not emitted (nn.cpp:239-244); the cap keeps
+// the first `max_kp` emitted in rank order (nn.cpp:256-257).
+// ---------------------------------------------------------------------------
+enum : uint8_t { ST_NONE = 0, ST_UNDECIDED = 1, ST_KEPT = 2, ST_SUPPRESSED = 3 };
+
+struct NmsBuffers {   // per image
+  uint8_t *state;     // [H*W]
+  int *cand;          // [H*W] row-major pixel index of each candidate
+  int *counters;      // [0] n_cand, [1] n_survivors, [2] n_out, [3] overflow, [8..8+MAXR) remaining per launch
+  unsigned long long *surv_key;  // [surv_cap]
+  int *out_xy;        // [max_kp][2]
+};
+constexpr int NMS_MAX_LAUNCH = 48;
+constexpr int NMS_COUNTER_INTS = 8 + NMS_MAX_LAUNCH;
+
+__device__ __forceinline__ unsigned long long rank_key(float conf, int x, int y, int H) {
+  return ((unsigned long long)(0xFFFFFFFFu - __float_as_uint(conf)) << 32) | (unsigned)(x * H + y);
+}
+
+__global__ __launch_bounds__(256) void nms_threshold_kernel(const float *__restrict__ heat, int H,
+                                                            int W, float thresh, NmsBuffers nb) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= W || y >= H) return;
+  const int p = y * W + x;
+  const bool c = heat[p] > thresh;  // strict, nn.cpp:203
+  nb.state[p] = c ? ST_UNDECIDED : ST_NONE;
+  if (c) nb.cand[atomicAdd(&nb.counters[0], 1)] = p;
+}
+
+template <int INNER>
+__global__ __launch_bounds__(256) void nms_round_kernel(const float *__restrict__ heat, int H, int W,
+                                                        int dist, NmsBuffers nb, int launch) {
+  if (launch > 0 && nb.counters[8 + launch - 1] == 0) return;  // nothing left undecided
+  const int n = nb.counters[0];
+  const int gid = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+  volatile uint8_t *state = nb.state;
+  for (int it = 0; it < INNER; ++it) {
+    for (int i = gid; i < n; i += stride) {
+      const int p = nb.cand[i];
+      if (state[p] != ST_UNDECIDED) continue;
+      const int y = p / W, x = p - y * W;
+      const unsigned long long key = rank_key(heat[p], x, y, H);
+      bool any_kept = false, any_better = false;
+      const int y0 = max(y - dist, 0), y1 = min(y + dist, H - 1);
+      const int x0 = max(x - dist, 0), x1 = min(x + dist, W - 1);
+      for (int yy = y0; yy <= y1; ++yy)
+        for (int xx = x0; xx <= x1; ++xx) {
+          const int q = yy * W + xx;
+          const uint8_t s = state[q];
+          if (s == ST_KEPT) any_kept = true;
+          else if (s == ST_UNDECIDED && q != p && rank_key(heat[q], xx, yy, H) < key) any_better = true;
+        }
+      if (any_kept) state[p] = ST_SUPPRESSED;
+      else if (!any_better) state[p] = ST_KEPT;
+    }
+    __syncthreads();
+  }
+  int rem = 0;
+  for (int i = gid; i < n; i += stride) rem += (state[nb.cand[i]] == ST_UNDECIDED) ? 1 : 0;
+  if (rem) atomicAdd(&nb.counters[8 + launch], rem);
+}
+
+__global__ __launch_bounds__(256) void nms_collect_kernel(const float *__restrict__ heat, int H,
+                                                          int W, int border, int surv_cap,
+                                                          NmsBuffers nb) {
+  const int n = nb.counters[0];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int p = nb.cand[i];
+    if (nb.state[p] != ST_KEPT) continue;
+    const int y = p / W, x = p - y * W;
+    if (y >= border && y + border < H && x >= border && x + border < W) {  // nn.cpp:239-242
+      const int s = atomicAdd(&nb.counters[1], 1);
+      if (s < surv_cap) nb.surv_key[s] = rank_key(heat[p], x, y, H);
+      else nb.counters[3] = 1;
+    }
+  }
+}
+
+// rank by counting: out position of a survivor = number of survivors with a smaller key
+__global__ __launch_bounds__(256) void nms_emit_kernel(int H, int max_kp, int surv_cap, NmsBuffers nb) {
+  __shared__ unsigned long long tile[1024];
+  const int n = min(nb.counters[1], surv_cap);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long key = (i < n) ? nb.surv_key[i] : 0ull;
+  int rank = 0;
+  for (int base = 0; base < n; base += 1024) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < 1024; t += 256) tile[t] = (base + t < n) ? nb.surv_key[base + t] : ~0ull;
+    __syncthreads();
+    if (i < n) {
+      const int m = min(1024, n - base);
+      for (int t = 0; t < m; ++t) rank += (tile[t] < key) ? 1 : 0;
+    }
+  }
+  if (i < n && rank < max_kp) {
+    const unsigned cm = (unsigned)(key & 0xFFFFFFFFull);
+    nb.out_xy[2 * rank + 0] = (int)(cm / (unsigned)H);
+    nb.out_xy[2 * rank + 1] = (int)(cm % (unsigned)H);
+  }
+  if (i == 0) nb.counters[2] = min(n, max_kp);
+}
+
+// ---------------------------------------------------------------------------
+// K11: bilinearInterpolationDesc (nn.cpp:366-431): align_corners=True mapping,
+// 4-tap blend, re-normalise.  One wave per keypoint, 4 channels per lane
+// (16-byte loads from the NHWC map: each tap is one contiguous 1 KiB row).
+// Blend order as written at nn.cpp:423-427 with no FMA contraction.
+// The count comes from device memory so no host round trip is needed.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sample_desc_kernel(const float *__restrict__ desc_nhwc,
+                                                          const int *__restrict__ xy,
+                                                          const int *__restrict__ n_ptr, int n_fixed,
+                                                          int H, int W, int Hc, int Wc,
+                                                          float *__restrict__ out,
+                                                          float *__restrict__ out_xy_f32) {
+  const int n = n_ptr ? *n_ptr : n_fixed;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (k >= n) return;
+  const int col = xy[2 * k], row = xy[2 * k + 1];
+  if (out_xy_f32 && lane == 0) {
+    out_xy_f32[2 * k] = (float)col;
+    out_xy_f32[2 * k + 1] = (float)row;
+  }
+  const float row8 = __fmul_rn(__fdiv_rn((float)row, (float)(H - 1)), (float)(Hc - 1));
+  const float col8 = __fmul_rn(__fdiv_rn((float)col, (float)(W - 1)), (float)(Wc - 1));
+  const int r0 = (int)floorf(row8), c0 = (int)floorf(col8);
+  const float rr = __fsub_rn(1.0f, __fsub_rn(row8, (float)r0));
+  const float cr = __fsub_rn(1.0f, __fsub_rn(col8, (float)c0));
+  const float rr1 = __fsub_rn(1.0f, rr), cr1 = __fsub_rn(1.0f, cr);
+  const int r1 = min(r0 + 1, Hc - 1), c1 = min(c0 + 1, Wc - 1);
+  const float4 tl = *(const float4 *)(desc_nhwc + ((size_t)r0 * Wc + c0) * 256 + lane * 4);
+  const float4 tr = *(const float4 *)(desc_nhwc + ((size_t)r0 * Wc + c1) * 256 + lane * 4);
+  const float4 bl = *(const float4 *)(desc_nhwc + ((size_t)r1 * Wc + c0) * 256 + lane * 4);
+  const float4 br = *(const float4 *)(desc_nhwc + ((size_t)r1 * Wc + c1) * 256 + lane * 4);
+  auto blend = [&](float a, float b, float c, float d) {
+    const float t0 = __fmul_rn(__fmul_rn(a, rr), cr);
+    const float t1 = __fmul_rn(__fmul_rn(b, rr), cr1);
+    const float t2 = __fmul_rn(__fmul_rn(c, rr1), cr);
+    const float t3 = __fmul_rn(__fmul_rn(d, rr1), cr1);
+    return __fadd_rn(__fadd_rn(__fadd_rn(t0, t1), t2), t3);
+  };
+  float4 v;
+  v.x = blend(tl.x, tr.x, bl.x, br.x);
+  v.y = blend(tl.y, tr.y, bl.y, br.y);
+  v.z = blend(tl.z, tr.z, bl.z, br.z);
+  v.w = blend(tl.w, tr.w, bl.w, br.w);
+  float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+  const float nrm = sqrtf(ss);
+  v.x = __fdiv_rn(v.x, nrm);
+  v.y = __fdiv_rn(v.y, nrm);
+  v.z = __fdiv_rn(v.z, nrm);
+  v.w = __fdiv_rn(v.w, nrm);
+  *(float4 *)(out + (size_t)k * 256 + lane * 4) = v;
+}
+
+}  // namespace spvo

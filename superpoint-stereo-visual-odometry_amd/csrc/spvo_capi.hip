@@ -1,0 +1,1123 @@
+// spvo_capi.hip -- the extern "C" shim declared in include/spvo.h: context,
+// weight loading / repacking, the network executor and one entry point per
+// reference stage.  Everything heavy is a hand-written gfx950 kernel from the
+// headers next to this file; this file only allocates, launches and copies.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/spvo.h"
+#include "conv_mfma.hip.h"
+#include "match.hip.h"
+#include "odometry.hip.h"
+#include "post.hip.h"
+
+using namespace spvo;
+
+namespace {
+
+thread_local std::string g_error;  // for calls without a context
+
+struct Tensor {
+  int ch = 0, level = 0, H = 0, W = 0, hp = 0, wp = 0;
+  bool nhwc = false;  // dense [B][H][W][C] (descriptor map) instead of padded planes
+  float *d = nullptr;
+  size_t per_image = 0;  // floats
+};
+
+enum { OP_CONV = 1, OP_MAXPOOL = 2, OP_L2NORM = 3 };
+enum { FLAG_RELU = 1, FLAG_POOL = 2 };
+
+struct Op {
+  int type = 0, in = 0, out = 0, out_c_off = 0, in_c_off = 0, cin = 0, cout = 0, ks = 0, flags = 0;
+  int ck = 0, n_chunks = 0, co_tiles = 0, wr = 0, wc = 0;
+  float *d_w = nullptr, *d_b = nullptr;
+  double flops_per_image = 0;
+  int stage = -1;
+};
+
+struct Stage {
+  std::string name;
+  double total_ms = 0;
+  long long calls = 0;
+  double flops = 0, bytes = 0;  // algorithmic, per call (last call's value)
+};
+
+struct Pending { int stage; hipEvent_t e0, e1; };
+
+struct FeatureSlot {
+  int n = 0;
+  int *d_xy = nullptr;      // [cap][2] int
+  float *d_xyf = nullptr;   // [cap][2] float
+  float *d_desc = nullptr;  // [cap][256]
+};
+
+struct NmsImage {
+  NmsBuffers b;
+};
+
+}  // namespace
+
+struct spvo_ctx {
+  spvo_config cfg;
+  hipStream_t stream = nullptr;
+  std::string error;
+  bool weights = false;
+  int H = 0, W = 0, Hc = 0, Wc = 0, B = 0;
+
+  std::vector<Tensor> tensors;
+  std::vector<Op> ops;
+  int t_input = 0, t_det = 0, t_desc = 0;
+  int last_batch = 0;
+
+  // post-processing buffers
+  float *d_dense_in = nullptr;   // [B][H][W] staging for spvo_forward
+  float *d_det_dense = nullptr;  // [B][65][Hc][Wc]
+  float *d_heat = nullptr;       // [B][H][W]
+  NmsImage nms[2];
+  int surv_cap = 0;
+  int *h_counters = nullptr;     // pinned [2][NMS_COUNTER_INTS]
+  uint8_t *d_img[2] = {nullptr, nullptr};
+  size_t img_cap = 0;
+  uint8_t *d_resized = nullptr;  // [2][H][W]
+  int *d_tab = nullptr;          // resize tables: xi,xa0,xa1 [W] ; yi,yb0,yb1 [H]
+  int tab_rows = -1, tab_cols = -1;
+  FeatureSlot slots[4];
+  int *d_xy_tmp = nullptr;       // [cap][2] for spvo_sample_descriptors
+  float *d_desc_tmp = nullptr;   // [cap][256]
+
+  // matching scratch
+  int match_cap = 0;
+  float *d_ma = nullptr, *d_mb = nullptr, *d_na = nullptr, *d_nb = nullptr, *d_best_d2 = nullptr, *d_dist = nullptr;
+  int *d_short = nullptr, *d_best_idx = nullptr, *d_train_idx = nullptr;
+  unsigned long long *d_train_best = nullptr;
+
+  // odometry scratch
+  int odo_cap = 0, ransac_cap = 0, obs_cap = 0;
+  double *d_P = nullptr;         // Pl[12], Pr[12], K[9], prior[6], start[7]
+  float *d_pts_a = nullptr, *d_pts_b = nullptr, *d_xyz = nullptr;
+  RansacWork rw{};
+  ObsDev *d_obs = nullptr;
+  RefineOut *d_refine = nullptr;
+
+  // profiling
+  bool prof = false;
+  std::vector<Stage> stages;
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> free_events;
+};
+
+namespace {
+
+int fail(spvo_ctx *c, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->error = buf;
+  g_error = buf;
+  return code;
+}
+
+#define HIP_TRY(c, expr)                                                                     \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      return fail(c, SPVO_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                  __FILE__, __LINE__);                                                       \
+  } while (0)
+
+template <typename T>
+int dev_alloc(spvo_ctx *c, T **p, size_t count, bool zero = true) {
+  HIP_TRY(c, hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T)));
+  if (zero) HIP_TRY(c, hipMemsetAsync(*p, 0, std::max<size_t>(count, 1) * sizeof(T), c->stream));
+  return SPVO_OK;
+}
+
+int stage_id(spvo_ctx *c, const std::string &name) {
+  for (size_t i = 0; i < c->stages.size(); ++i)
+    if (c->stages[i].name == name) return (int)i;
+  Stage s;
+  s.name = name;
+  c->stages.push_back(s);
+  return (int)c->stages.size() - 1;
+}
+
+hipEvent_t get_event(spvo_ctx *c) {
+  if (!c->free_events.empty()) {
+    hipEvent_t e = c->free_events.back();
+    c->free_events.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void resolve_pending(spvo_ctx *c) {
+  if (c->pending.empty()) return;
+  (void)hipEventSynchronize(c->pending.back().e1);
+  for (auto &p : c->pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+      c->stages[p.stage].total_ms += ms;
+      c->stages[p.stage].calls += 1;
+    }
+    c->free_events.push_back(p.e0);
+    c->free_events.push_back(p.e1);
+  }
+  c->pending.clear();
+}
+
+struct ScopedStage {
+  spvo_ctx *c;
+  int id = -1;
+  hipEvent_t e0 = nullptr;
+  ScopedStage(spvo_ctx *ctx, int stage, double flops = 0, double bytes = 0) : c(ctx) {
+    if (!c->prof || stage < 0) return;
+    id = stage;
+    if (flops > 0) c->stages[id].flops = flops;
+    if (bytes > 0) c->stages[id].bytes = bytes;
+    e0 = get_event(c);
+    (void)hipEventRecord(e0, c->stream);
+  }
+  ~ScopedStage() {
+    if (id < 0) return;
+    hipEvent_t e1 = get_event(c);
+    (void)hipEventRecord(e1, c->stream);
+    c->pending.push_back({id, e0, e1});
+    if (c->pending.size() > 8192) resolve_pending(c);
+  }
+};
+
+// ---------------------------------------------------------------- conv dispatch
+template <int KS, int CK, int WR, int WC, bool POOL>
+int launch_conv_variant(spvo_ctx *c, const ConvArgs &a, int batch, bool relu) {
+  using T = ConvTile<KS, CK, WR, WC>;
+  ConvArgs args = a;
+  args.tiles_x = (a.W + T::TW - 1) / T::TW;
+  args.tiles_y = (a.H + T::TH - 1) / T::TH;
+  const int grid = args.tiles_x * args.tiles_y * args.co_tiles * batch;
+  static bool attr_done[64][2] = {};
+  const int dev = c->cfg.device & 63;
+  if (relu) {
+    auto k = conv_mfma_kernel<KS, CK, WR, WC, POOL, true>;
+    if (!attr_done[dev][1]) {
+      HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+      attr_done[dev][1] = true;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), T::LDS_BYTES, c->stream, args);
+  } else {
+    auto k = conv_mfma_kernel<KS, CK, WR, WC, POOL, false>;
+    if (!attr_done[dev][0]) {
+      HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+      attr_done[dev][0] = true;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), T::LDS_BYTES, c->stream, args);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return SPVO_OK;
+}
+
+// tile choice: minimise padded work / fill, small tiles pay a little for lower operand reuse
+void choose_tile(int H, int W, int co_tiles, int batch, bool pool, int *wr, int *wc) {
+  struct Cand { int wr, wc; double pen; };
+  static const Cand nopool[] = {{2, 2, 1.00}, {1, 2, 1.03}, {1, 1, 1.06}};
+  static const Cand withpool[] = {{2, 2, 1.00}, {2, 1, 1.03}};
+  const Cand *cands = pool ? withpool : nopool;
+  const int nc = pool ? 2 : 3;
+  double best = 1e300;
+  for (int i = 0; i < nc; ++i) {
+    const int th = 4 * cands[i].wr, tw = 32 * cands[i].wc;
+    const int tx = (W + tw - 1) / tw, ty = (H + th - 1) / th;
+    const double grid = (double)tx * ty * co_tiles * batch;
+    const double work = (double)tx * tw * ty * th;
+    const double cost = work * cands[i].pen / std::min(1.0, grid / 256.0);
+    if (cost < best) { best = cost; *wr = cands[i].wr; *wc = cands[i].wc; }
+  }
+}
+
+int launch_conv(spvo_ctx *c, const Op &op, int batch) {
+  const Tensor &ti = c->tensors[op.in];
+  const Tensor &to = c->tensors[op.out];
+  const bool relu = op.flags & FLAG_RELU, pool = op.flags & FLAG_POOL;
+  if (op.cin == 1) {
+    if (op.ks != 3 || pool) return fail(c, SPVO_ERR_INVALID, "first-layer kernel supports 3x3 without pooling");
+    dim3 grid((ti.W + 63) / 64, (ti.H + 3) / 4, batch);
+    if (relu)
+      hipLaunchKernelGGL(conv_first_kernel<true>, grid, dim3(256), 0, c->stream, ti.d, to.d, op.d_w, op.d_b, ti.H, ti.W, ti.hp, ti.wp, to.ch, op.out_c_off, op.cout);
+    else
+      hipLaunchKernelGGL(conv_first_kernel<false>, grid, dim3(256), 0, c->stream, ti.d, to.d, op.d_w, op.d_b, ti.H, ti.W, ti.hp, ti.wp, to.ch, op.out_c_off, op.cout);
+    HIP_TRY(c, hipGetLastError());
+    return SPVO_OK;
+  }
+  ConvArgs a;
+  a.in = ti.d; a.out = to.d; a.wpack = op.d_w; a.bias = op.d_b;
+  a.H = ti.H; a.W = ti.W;
+  a.in_hp = ti.hp; a.in_wp = ti.wp; a.in_ctot = ti.ch; a.in_coff = op.in_c_off;
+  a.out_hp = to.hp; a.out_wp = to.wp; a.out_ctot = to.ch; a.out_coff = op.out_c_off;
+  a.cout = op.cout; a.n_chunks = op.n_chunks; a.co_tiles = op.co_tiles;
+  a.tiles_x = a.tiles_y = 0;
+  const int key = op.ks * 1000 + op.wr * 100 + op.wc * 10 + (pool ? 1 : 0);
+  switch (key) {
+    case 3220: return launch_conv_variant<3, 8, 2, 2, false>(c, a, batch, relu);
+    case 3120: return launch_conv_variant<3, 8, 1, 2, false>(c, a, batch, relu);
+    case 3110: return launch_conv_variant<3, 8, 1, 1, false>(c, a, batch, relu);
+    case 3221: return launch_conv_variant<3, 8, 2, 2, true>(c, a, batch, relu);
+    case 3211: return launch_conv_variant<3, 8, 2, 1, true>(c, a, batch, relu);
+    case 1220: return launch_conv_variant<1, 16, 2, 2, false>(c, a, batch, relu);
+    case 1120: return launch_conv_variant<1, 16, 1, 2, false>(c, a, batch, relu);
+    case 1110: return launch_conv_variant<1, 16, 1, 1, false>(c, a, batch, relu);
+    default: return fail(c, SPVO_ERR_INVALID, "no conv kernel variant for key %d", key);
+  }
+}
+
+int run_network(spvo_ctx *c, int batch) {
+  ScopedStage net(c, stage_id(c, "net"));
+  for (auto &op : c->ops) {
+    const Tensor &ti = c->tensors[op.in];
+    const Tensor &to = c->tensors[op.out];
+    if (op.type == OP_CONV) {
+      ScopedStage st(c, op.stage, op.flops_per_image * batch, 0);
+      int rc = launch_conv(c, op, batch);
+      if (rc) return rc;
+    } else if (op.type == OP_MAXPOOL) {
+      ScopedStage st(c, op.stage);
+      dim3 grid((to.W + 63) / 64, (to.H + 3) / 4, batch * to.ch);
+      hipLaunchKernelGGL(maxpool2_kernel, grid, dim3(256), 0, c->stream, ti.d, to.d, to.ch, to.H, to.W, ti.hp, ti.wp, to.hp, to.wp);
+      HIP_TRY(c, hipGetLastError());
+    } else if (op.type == OP_L2NORM) {
+      ScopedStage st(c, op.stage);
+      dim3 grid((ti.W + 31) / 32, ti.H, batch);
+      hipLaunchKernelGGL(l2norm_nhwc_kernel<256>, grid, dim3(256), 0, c->stream, ti.d, to.d, ti.H, ti.W, ti.hp, ti.wp);
+      HIP_TRY(c, hipGetLastError());
+    }
+  }
+  c->last_batch = batch;
+  return SPVO_OK;
+}
+
+// ---------------------------------------------------------------- resize tables
+void linear_coeffs(int dst, int src, std::vector<int> &idx, std::vector<int> &a0, std::vector<int> &a1) {
+  // OpenCV resize.cpp, INTER_LINEAR, 8-bit: float32 fractional part, 11-bit coefficients
+  const double scale = (double)src / (double)dst;
+  idx.resize(dst); a0.resize(dst); a1.resize(dst);
+  for (int d = 0; d < dst; ++d) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)std::floor(f);
+    f -= (float)s;
+    if (s < 0) { s = 0; f = 0.f; }
+    if (s >= src - 1) { s = src - 1; f = 0.f; }
+    idx[d] = s;
+    a0[d] = (int)std::nearbyint((1.f - f) * 2048.f);
+    a1[d] = (int)std::nearbyint(f * 2048.f);
+  }
+}
+
+struct CropGeom { int row_off, col_off, crop_rows, crop_cols; float scale; };
+
+CropGeom crop_geometry(int rows, int cols, int net_h, int net_w) {
+  // base.cpp:75-119, float32 arithmetic and int truncation as written there
+  CropGeom g{0, 0, rows, cols, 1.f};
+  const float real = (float)cols / (float)rows;
+  const float expected = (float)net_w / (float)net_h;
+  if (expected > real) {
+    g.crop_rows = (int)((float)cols / expected);
+    g.row_off = (rows - g.crop_rows) / 2;
+  } else if (expected < real) {
+    g.crop_cols = (int)((float)rows * expected);
+    g.col_off = (cols - g.crop_cols) / 2;
+  }
+  g.scale = (float)net_w / (float)g.crop_cols;
+  return g;
+}
+
+void fix_projection(double P[12], const CropGeom &g, int rows, int cols, int bug_compat) {
+  if (bug_compat) {
+    // base.cpp:95,111: at<float>(r, 2) on a CV_64F matrix = low 32 bits of P[r][1]
+    float lo;
+    if (g.crop_rows != rows) {
+      std::memcpy(&lo, (char *)&P[4 + 1], 4);
+      lo -= (float)g.row_off;
+      std::memcpy((char *)&P[4 + 1], &lo, 4);
+    } else if (g.crop_cols != cols) {
+      std::memcpy(&lo, (char *)&P[0 + 1], 4);
+      lo -= (float)g.col_off;
+      std::memcpy((char *)&P[0 + 1], &lo, 4);
+    }
+  } else {
+    if (g.crop_rows != rows) P[4 + 2] -= (double)(float)g.row_off;
+    else if (g.crop_cols != cols) P[0 + 2] -= (double)(float)g.col_off;
+  }
+  for (int k = 0; k < 8; ++k) P[k] *= (double)g.scale;  // base.cpp:120
+}
+
+int ensure_tables(spvo_ctx *c, const CropGeom &g) {
+  if (c->tab_rows == g.crop_rows && c->tab_cols == g.crop_cols) return SPVO_OK;
+  std::vector<int> xi, xa0, xa1, yi, yb0, yb1;
+  linear_coeffs(c->W, g.crop_cols, xi, xa0, xa1);
+  linear_coeffs(c->H, g.crop_rows, yi, yb0, yb1);
+  std::vector<int> all;
+  all.insert(all.end(), xi.begin(), xi.end());
+  all.insert(all.end(), xa0.begin(), xa0.end());
+  all.insert(all.end(), xa1.begin(), xa1.end());
+  all.insert(all.end(), yi.begin(), yi.end());
+  all.insert(all.end(), yb0.begin(), yb0.end());
+  all.insert(all.end(), yb1.begin(), yb1.end());
+  HIP_TRY(c, hipMemcpyAsync(c->d_tab, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // `all` is a stack-lifetime buffer
+  c->tab_rows = g.crop_rows;
+  c->tab_cols = g.crop_cols;
+  return SPVO_OK;
+}
+
+int launch_preprocess(spvo_ctx *c, const uint8_t *d_src, int rows, int cols, size_t stride, const CropGeom &g, int slot) {
+  int rc = ensure_tables(c, g);
+  if (rc) return rc;
+  ResizeTab tab;
+  tab.xi = c->d_tab; tab.xa0 = c->d_tab + c->W; tab.xa1 = c->d_tab + 2 * c->W;
+  tab.yi = c->d_tab + 3 * c->W; tab.yb0 = tab.yi + c->H; tab.yb1 = tab.yi + 2 * c->H;
+  const Tensor &tin = c->tensors[c->t_input];
+  const int identity = (g.crop_rows == c->H && g.crop_cols == c->W) ? 1 : 0;
+  dim3 grid((c->W + 63) / 64, (c->H + 3) / 4);
+  hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, c->stream, d_src, stride, rows, cols, g.row_off, g.col_off, g.crop_rows, g.crop_cols, tab, c->H, c->W,
+                     c->d_resized + (size_t)slot * c->H * c->W, tin.d + (size_t)slot * tin.per_image, tin.hp, tin.wp, identity);
+  HIP_TRY(c, hipGetLastError());
+  return SPVO_OK;
+}
+
+// ---------------------------------------------------------------- NMS pipeline
+constexpr int NMS_INNER = 4;
+constexpr int NMS_GRID = 128;
+
+int launch_nms(spvo_ctx *c, int img, int first_launch, int n_launch) {
+  const float *heat = c->d_heat + (size_t)img * c->H * c->W;
+  NmsBuffers nb = c->nms[img].b;
+  if (first_launch == 0) {
+    HIP_TRY(c, hipMemsetAsync(nb.counters, 0, NMS_COUNTER_INTS * sizeof(int), c->stream));
+    dim3 grid((c->W + 63) / 64, (c->H + 3) / 4);
+    hipLaunchKernelGGL(nms_threshold_kernel, grid, dim3(256), 0, c->stream, heat, c->H, c->W, c->cfg.conf_thresh, nb);
+  }
+  for (int l = first_launch; l < first_launch + n_launch && l < NMS_MAX_LAUNCH; ++l)
+    hipLaunchKernelGGL(nms_round_kernel<NMS_INNER>, dim3(NMS_GRID), dim3(256), 0, c->stream, heat, c->H, c->W, c->cfg.dist_thresh, nb, l);
+  HIP_TRY(c, hipGetLastError());
+  return SPVO_OK;
+}
+
+int launch_nms_emit(spvo_ctx *c, int img) {
+  const float *heat = c->d_heat + (size_t)img * c->H * c->W;
+  NmsBuffers nb = c->nms[img].b;
+  HIP_TRY(c, hipMemsetAsync(nb.counters + 1, 0, 3 * sizeof(int), c->stream));
+  hipLaunchKernelGGL(nms_collect_kernel, dim3(NMS_GRID), dim3(256), 0, c->stream, heat, c->H, c->W, c->cfg.border_remove, c->surv_cap, nb);
+  hipLaunchKernelGGL(nms_emit_kernel, dim3((c->surv_cap + 255) / 256), dim3(256), 0, c->stream, c->H, c->cfg.max_keypoints, c->surv_cap, nb);
+  HIP_TRY(c, hipGetLastError());
+  return SPVO_OK;
+}
+
+// runs threshold + rounds + emit for images [0, nimg); leaves counters in h_counters; syncs.
+int run_nms(spvo_ctx *c, int nimg) {
+  const int first = 3;
+  for (int i = 0; i < nimg; ++i) {
+    int rc = launch_nms(c, i, 0, first);
+    if (rc) return rc;
+    rc = launch_nms_emit(c, i);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->h_counters + i * NMS_COUNTER_INTS, c->nms[i].b.counters, NMS_COUNTER_INTS * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  // rare: decision chains longer than first*NMS_INNER rounds -> keep going
+  for (int i = 0; i < nimg; ++i) {
+    int done = first;
+    while (c->h_counters[i * NMS_COUNTER_INTS + 8 + done - 1] != 0) {
+      if (done >= NMS_MAX_LAUNCH) return fail(c, SPVO_ERR_DEVICE, "NMS did not settle in %d rounds", NMS_MAX_LAUNCH * NMS_INNER);
+      const int more = std::min(4, NMS_MAX_LAUNCH - done);
+      int rc = launch_nms(c, i, done, more);
+      if (rc) return rc;
+      done += more;
+      rc = launch_nms_emit(c, i);
+      if (rc) return rc;
+      HIP_TRY(c, hipMemcpyAsync(c->h_counters + i * NMS_COUNTER_INTS, c->nms[i].b.counters, NMS_COUNTER_INTS * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    if (c->h_counters[i * NMS_COUNTER_INTS + 3]) return fail(c, SPVO_ERR_CAPACITY, "NMS survivor buffer overflow");
+  }
+  return SPVO_OK;
+}
+
+// nms_collect uses a grid-stride-free layout: make sure NMS_GRID*256 covers the candidates
+// (handled inside the kernels with strided loops).
+
+int ensure_match(spvo_ctx *c, int na, int nb) {
+  const int need = std::max(na, nb);
+  if (need <= c->match_cap) return SPVO_OK;
+  const int cap = std::max(need, std::max(c->cfg.max_keypoints, 1024));
+  for (void *p : {(void *)c->d_ma, (void *)c->d_mb, (void *)c->d_na, (void *)c->d_nb, (void *)c->d_best_d2, (void *)c->d_dist, (void *)c->d_short, (void *)c->d_best_idx, (void *)c->d_train_idx, (void *)c->d_train_best})
+    if (p) (void)hipFree(p);
+  const int groups = (cap + MATCH_TT - 1) / MATCH_TT;
+  int rc;
+  if ((rc = dev_alloc(c, &c->d_ma, (size_t)cap * MATCH_D))) return rc;
+  if ((rc = dev_alloc(c, &c->d_mb, (size_t)cap * MATCH_D))) return rc;
+  if ((rc = dev_alloc(c, &c->d_na, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_nb, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_best_d2, (size_t)cap * 2))) return rc;
+  if ((rc = dev_alloc(c, &c->d_dist, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_short, (size_t)cap * groups * MATCH_KEEP))) return rc;
+  if ((rc = dev_alloc(c, &c->d_best_idx, (size_t)cap * 2))) return rc;
+  if ((rc = dev_alloc(c, &c->d_train_idx, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_train_best, cap))) return rc;
+  c->match_cap = cap;
+  return SPVO_OK;
+}
+
+int run_match(spvo_ctx *c, const float *dA, int na, const float *dB, int nb, int selector, int cross_check, float ratio, int32_t *train_idx, float *distance) {
+  if (na == 0) return SPVO_OK;
+  if (nb == 0) {
+    for (int i = 0; i < na; ++i) { train_idx[i] = -1; distance[i] = 0.f; }
+    return SPVO_OK;
+  }
+  const int groups = (nb + MATCH_TT - 1) / MATCH_TT;
+  {
+    ScopedStage st(c, stage_id(c, "match"), 2.0 * na * nb * MATCH_D, 4.0 * (na + nb) * MATCH_D);
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((na + 3) / 4), dim3(256), 0, c->stream, dA, na, c->d_na);
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((nb + 3) / 4), dim3(256), 0, c->stream, dB, nb, c->d_nb);
+    const size_t lds = (size_t)(MATCH_QT + MATCH_TT) * 129 * sizeof(float);
+    static bool attr[64] = {};
+    if (!attr[c->cfg.device & 63]) {
+      HIP_TRY(c, hipFuncSetAttribute((const void *)match_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr[c->cfg.device & 63] = true;
+    }
+    {
+      ScopedStage sg(c, stage_id(c, "match_gemm"), 2.0 * na * nb * MATCH_D, 4.0 * (na + nb) * MATCH_D);
+      hipLaunchKernelGGL(match_gemm_kernel, dim3(groups, (na + MATCH_QT - 1) / MATCH_QT), dim3(256), lds, c->stream, dA, na, dB, nb, c->d_na, c->d_nb, c->d_short, groups);
+    }
+    hipLaunchKernelGGL(match_rerank_kernel, dim3((na + 3) / 4), dim3(256), 0, c->stream, dA, na, dB, nb, c->d_short, groups, c->d_best_d2, c->d_best_idx);
+    if (selector == SPVO_SELECT_NN && cross_check) {
+      HIP_TRY(c, hipMemsetAsync(c->d_train_best, 0xFF, (size_t)nb * sizeof(unsigned long long), c->stream));
+      hipLaunchKernelGGL(match_cross_scatter_kernel, dim3((na + 255) / 256), dim3(256), 0, c->stream, c->d_best_d2, c->d_best_idx, na, c->d_train_best);
+    }
+    hipLaunchKernelGGL(match_select_kernel, dim3((na + 255) / 256), dim3(256), 0, c->stream, c->d_best_d2, c->d_best_idx, na, selector, cross_check, ratio, c->d_train_best, c->d_train_idx, c->d_dist);
+    HIP_TRY(c, hipGetLastError());
+  }
+  HIP_TRY(c, hipMemcpyAsync(train_idx, c->d_train_idx, (size_t)na * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(distance, c->d_dist, (size_t)na * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SPVO_OK;
+}
+
+int ensure_odometry(spvo_ctx *c, int n, int iterations, int n_obs) {
+  int rc;
+  if (!c->d_P) {
+    if ((rc = dev_alloc(c, &c->d_P, 64))) return rc;
+    if ((rc = dev_alloc(c, &c->rw.result, 8))) return rc;
+    if ((rc = dev_alloc(c, &c->d_refine, 1))) return rc;
+  }
+  if (n > c->odo_cap) {
+    const int cap = std::max(n, 2048);
+    for (void *p : {(void *)c->d_pts_a, (void *)c->d_pts_b, (void *)c->d_xyz, (void *)c->rw.inliers})
+      if (p) (void)hipFree(p);
+    if ((rc = dev_alloc(c, &c->d_pts_a, (size_t)cap * 3))) return rc;
+    if ((rc = dev_alloc(c, &c->d_pts_b, (size_t)cap * 3))) return rc;
+    if ((rc = dev_alloc(c, &c->d_xyz, (size_t)cap * 3))) return rc;
+    if ((rc = dev_alloc(c, &c->rw.inliers, cap))) return rc;
+    c->odo_cap = cap;
+  }
+  if (iterations > c->ransac_cap) {
+    const int cap = std::max(iterations, 512);
+    if (c->rw.counts) (void)hipFree(c->rw.counts);
+    if (c->rw.poses) (void)hipFree(c->rw.poses);
+    if ((rc = dev_alloc(c, &c->rw.counts, cap))) return rc;
+    if ((rc = dev_alloc(c, &c->rw.poses, (size_t)cap * 7))) return rc;
+    c->ransac_cap = cap;
+  }
+  if (n_obs > c->obs_cap) {
+    const int cap = std::max(n_obs, 8192);
+    if (c->d_obs) (void)hipFree(c->d_obs);
+    if ((rc = dev_alloc(c, &c->d_obs, cap))) return rc;
+    c->obs_cap = cap;
+  }
+  return SPVO_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+extern "C" {
+
+void spvo_default_config(spvo_config *cfg) {
+  if (!cfg) return;
+  cfg->device = 0;
+  cfg->net_height = 360;
+  cfg->net_width = 1176;
+  cfg->max_batch = 2;
+  cfg->conf_thresh = 0.015f;
+  cfg->dist_thresh = 4;
+  cfg->border_remove = 4;
+  cfg->max_keypoints = 1000;
+  cfg->bug_compat_p = 1;
+}
+
+const char *spvo_last_error(const spvo_ctx *ctx) { return ctx ? ctx->error.c_str() : g_error.c_str(); }
+
+int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
+  if (!cfg || !out) return fail(nullptr, SPVO_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->net_height <= 0 || cfg->net_width <= 0 || cfg->net_height % 8 || cfg->net_width % 8)
+    return fail(nullptr, SPVO_ERR_INVALID, "net size %dx%d must be positive multiples of 8 (feature_detection.hpp:296)", cfg->net_height, cfg->net_width);
+  if (cfg->max_batch != 1 && cfg->max_batch != 2)
+    return fail(nullptr, SPVO_ERR_INVALID, "Wrong batch size (%d)", cfg->max_batch);  // nn.cpp:490
+  if (cfg->max_keypoints <= 0 || cfg->dist_thresh < 0 || cfg->border_remove < 0)
+    return fail(nullptr, SPVO_ERR_INVALID, "bad post-processing parameters");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, SPVO_ERR_DEVICE, "no HIP device visible: this library has no CPU path");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, SPVO_ERR_DEVICE, "device %d out of range (%d visible)", cfg->device, ndev);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return fail(nullptr, SPVO_ERR_DEVICE, "hipGetDeviceProperties failed");
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, SPVO_ERR_DEVICE, "device %d is %s; the kernels are built for gfx950 only", cfg->device, prop.gcnArchName);
+  spvo_ctx *c = new spvo_ctx();
+  c->cfg = *cfg;
+  c->H = cfg->net_height; c->W = cfg->net_width; c->Hc = c->H / 8; c->Wc = c->W / 8; c->B = 2;
+  if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+    delete c;
+    return fail(nullptr, SPVO_ERR_DEVICE, "cannot create a stream on device %d", cfg->device);
+  }
+  int rc = SPVO_OK;
+  const size_t hw = (size_t)c->H * c->W;
+  const int cap = cfg->max_keypoints;
+  // one survivor per (dist+1)^2 cell at most
+  const int cell = cfg->dist_thresh + 1;
+  c->surv_cap = ((c->H + cell - 1) / cell) * ((c->W + cell - 1) / cell) + 64;
+  do {
+    if ((rc = dev_alloc(c, &c->d_dense_in, 2 * hw))) break;
+    if ((rc = dev_alloc(c, &c->d_det_dense, (size_t)2 * 65 * c->Hc * c->Wc))) break;
+    if ((rc = dev_alloc(c, &c->d_heat, 2 * hw))) break;
+    if ((rc = dev_alloc(c, &c->d_resized, 2 * hw))) break;
+    if ((rc = dev_alloc(c, &c->d_tab, (size_t)3 * (c->H + c->W)))) break;
+    for (int i = 0; i < 2 && !rc; ++i) {
+      NmsBuffers &b = c->nms[i].b;
+      if ((rc = dev_alloc(c, &b.state, hw))) break;
+      if ((rc = dev_alloc(c, &b.cand, hw))) break;
+      if ((rc = dev_alloc(c, &b.counters, NMS_COUNTER_INTS))) break;
+      if ((rc = dev_alloc(c, &b.surv_key, c->surv_cap))) break;
+      if ((rc = dev_alloc(c, &b.out_xy, (size_t)cap * 2))) break;
+    }
+    if (rc) break;
+    for (int i = 0; i < 4 && !rc; ++i) {
+      if ((rc = dev_alloc(c, &c->slots[i].d_xy, (size_t)cap * 2))) break;
+      if ((rc = dev_alloc(c, &c->slots[i].d_xyf, (size_t)cap * 2))) break;
+      if ((rc = dev_alloc(c, &c->slots[i].d_desc, (size_t)cap * 256))) break;
+    }
+    if (rc) break;
+    if ((rc = dev_alloc(c, &c->d_xy_tmp, (size_t)cap * 2))) break;
+    if ((rc = dev_alloc(c, &c->d_desc_tmp, (size_t)cap * 256))) break;
+    if (hipHostMalloc((void **)&c->h_counters, 2 * NMS_COUNTER_INTS * sizeof(int)) != hipSuccess) { rc = fail(c, SPVO_ERR_DEVICE, "hipHostMalloc failed"); break; }
+  } while (0);
+  if (rc) {
+    g_error = c->error;
+    spvo_destroy(c);
+    return rc;
+  }
+  (void)hipStreamSynchronize(c->stream);
+  *out = c;
+  return SPVO_OK;
+}
+
+void spvo_destroy(spvo_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->cfg.device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  resolve_pending(c);
+  for (auto e : c->free_events) (void)hipEventDestroy(e);
+  for (auto &t : c->tensors) if (t.d) (void)hipFree(t.d);
+  for (auto &o : c->ops) { if (o.d_w) (void)hipFree(o.d_w); if (o.d_b) (void)hipFree(o.d_b); }
+  void *ptrs[] = {c->d_dense_in, c->d_det_dense, c->d_heat, c->d_resized, c->d_tab, c->d_img[0], c->d_img[1], c->d_xy_tmp, c->d_desc_tmp,
+                  c->d_ma, c->d_mb, c->d_na, c->d_nb, c->d_best_d2, c->d_dist, c->d_short, c->d_best_idx, c->d_train_idx, c->d_train_best,
+                  c->d_P, c->d_pts_a, c->d_pts_b, c->d_xyz, c->rw.counts, c->rw.poses, c->rw.result, c->rw.inliers, c->d_obs, c->d_refine};
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  for (int i = 0; i < 2; ++i) {
+    NmsBuffers &b = c->nms[i].b;
+    void *q[] = {b.state, b.cand, b.counters, b.surv_key, b.out_xy};
+    for (void *p : q) if (p) (void)hipFree(p);
+  }
+  for (int i = 0; i < 4; ++i) {
+    void *q[] = {c->slots[i].d_xy, c->slots[i].d_xyf, c->slots[i].d_desc};
+    for (void *p : q) if (p) (void)hipFree(p);
+  }
+  if (c->h_counters) (void)hipHostFree(c->h_counters);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int spvo_load_weights(spvo_ctx *c, const char *path) {
+  if (!c || !path) return fail(c, SPVO_ERR_INVALID, "null argument");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  FILE *f = std::fopen(path, "rb");
+  if (!f) return fail(c, SPVO_ERR_IO, "no such engine file: %s", path);  // nn.cpp:53-55
+  std::fseek(f, 0, SEEK_END);
+  const long sz = std::ftell(f);
+  std::fseek(f, 0, SEEK_SET);
+  std::vector<unsigned char> buf((size_t)std::max(sz, 0L));
+  const size_t got = std::fread(buf.data(), 1, buf.size(), f);
+  std::fclose(f);
+  if (got != buf.size() || buf.size() < 48 || std::memcmp(buf.data(), "SPVW0002", 8) != 0)
+    return fail(c, SPVO_ERR_IO, "%s is not a SPVW0002 weight file", path);
+  const uint32_t *hdr = (const uint32_t *)(buf.data() + 8);
+  const uint32_t nt = hdr[0], no = hdr[1];
+  size_t pos = 40;
+  if (buf.size() < pos + (size_t)nt * 8 + (size_t)no * 48 + 8) return fail(c, SPVO_ERR_IO, "%s: truncated", path);
+  // drop a previously loaded plan
+  for (auto &t : c->tensors) if (t.d) (void)hipFree(t.d);
+  for (auto &o : c->ops) { if (o.d_w) (void)hipFree(o.d_w); if (o.d_b) (void)hipFree(o.d_b); }
+  c->tensors.clear(); c->ops.clear(); c->weights = false;
+  c->t_input = hdr[2]; c->t_det = hdr[3]; c->t_desc = hdr[4];
+  for (uint32_t i = 0; i < nt; ++i) {
+    const uint32_t *r = (const uint32_t *)(buf.data() + pos);
+    pos += 8;
+    Tensor t;
+    t.ch = r[0]; t.level = r[1];
+    if (t.level > 3 || (c->H >> t.level) << t.level != c->H) return fail(c, SPVO_ERR_IO, "bad tensor level");
+    t.H = c->H >> t.level; t.W = c->W >> t.level;
+    t.hp = padded_h(t.H); t.wp = padded_w(t.W);
+    c->tensors.push_back(t);
+  }
+  struct Raw { uint32_t v[8]; uint64_t w_off, b_off; };
+  std::vector<Raw> raws(no);
+  for (uint32_t i = 0; i < no; ++i) { std::memcpy(&raws[i], buf.data() + pos, 48); pos += 48; }
+  uint64_t nfl;
+  std::memcpy(&nfl, buf.data() + pos, 8);
+  pos += 8;
+  if (buf.size() < pos + nfl * 4) return fail(c, SPVO_ERR_IO, "%s: truncated payload", path);
+  const float *payload = (const float *)(buf.data() + pos);
+  if (c->t_input >= (int)nt || c->t_det >= (int)nt || c->t_desc >= (int)nt) return fail(c, SPVO_ERR_IO, "bad tensor ids");
+
+  for (uint32_t i = 0; i < no; ++i) {
+    const Raw &r = raws[i];
+    Op op;
+    op.type = r.v[0]; op.in = r.v[1]; op.out = r.v[2]; op.out_c_off = r.v[3];
+    op.cin = r.v[4] & 0xFFFF; op.in_c_off = r.v[4] >> 16; op.cout = r.v[5]; op.ks = r.v[6]; op.flags = r.v[7];
+    if (op.in >= (int)nt || op.out >= (int)nt) return fail(c, SPVO_ERR_IO, "op %u: bad tensor id", i);
+    if (op.type == OP_L2NORM) c->tensors[op.out].nhwc = true;
+    c->ops.push_back(op);
+  }
+  // allocate activations (padded planes stay zero outside the interior for ever)
+  for (auto &t : c->tensors) {
+    t.per_image = t.nhwc ? (size_t)t.H * t.W * t.ch : (size_t)t.ch * t.hp * t.wp;
+    int rc = dev_alloc(c, &t.d, t.per_image * c->B);
+    if (rc) return rc;
+  }
+  for (uint32_t i = 0; i < no; ++i) {
+    Op &op = c->ops[i];
+    const Raw &r = raws[i];
+    const Tensor &ti = c->tensors[op.in];
+    const Tensor &to = c->tensors[op.out];
+    char name[64];
+    if (op.type == OP_CONV) {
+      std::snprintf(name, sizeof name, "conv:%u", i);
+      op.stage = stage_id(c, name);
+      const int taps = op.ks * op.ks;
+      if (op.ks != 1 && op.ks != 3) return fail(c, SPVO_ERR_IO, "op %u: kernel size %d", i, op.ks);
+      if (r.w_off + (uint64_t)op.cout * op.cin * taps > nfl || r.b_off + op.cout > nfl) return fail(c, SPVO_ERR_IO, "op %u: weights out of range", i);
+      if (op.in_c_off + op.cin > ti.ch || op.out_c_off + op.cout > to.ch) return fail(c, SPVO_ERR_IO, "op %u: channel slice out of range", i);
+      const bool pool = op.flags & FLAG_POOL;
+      if (to.level != ti.level + (pool ? 1 : 0)) return fail(c, SPVO_ERR_IO, "op %u: level mismatch", i);
+      if (pool && ((ti.H | ti.W) & 1)) return fail(c, SPVO_ERR_IO, "op %u: pooling an odd-sized map", i);
+      op.flops_per_image = 2.0 * ti.H * ti.W * op.cout * op.cin * taps;
+      const float *w = payload + r.w_off;
+      const float *b = payload + r.b_off;
+      if (op.cin == 1) {
+        int rc = dev_alloc(c, &op.d_w, (size_t)op.cout * 9, false);
+        if (rc) return rc;
+        if ((rc = dev_alloc(c, &op.d_b, op.cout, false))) return rc;
+        HIP_TRY(c, hipMemcpy(op.d_w, w, (size_t)op.cout * 9 * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(op.d_b, b, (size_t)op.cout * 4, hipMemcpyHostToDevice));
+        continue;
+      }
+      op.ck = (op.ks == 3) ? 8 : 16;
+      if (op.cin % op.ck) return fail(c, SPVO_ERR_IO, "op %u: cin %d is not a multiple of %d", i, op.cin, op.ck);
+      op.n_chunks = op.cin / op.ck;
+      op.co_tiles = (op.cout + CO_TILE - 1) / CO_TILE;
+      choose_tile(ti.H, ti.W, op.co_tiles, c->cfg.max_batch, pool, &op.wr, &op.wc);
+      // repack OIHW -> [co_tile][chunk][tap][ci][64]
+      std::vector<float> pk((size_t)op.co_tiles * op.n_chunks * taps * op.ck * CO_TILE, 0.f), bp((size_t)op.co_tiles * CO_TILE, 0.f);
+      for (int ct = 0; ct < op.co_tiles; ++ct)
+        for (int ch = 0; ch < op.n_chunks; ++ch)
+          for (int t = 0; t < taps; ++t)
+            for (int ci = 0; ci < op.ck; ++ci)
+              for (int o = 0; o < CO_TILE; ++o) {
+                const int co = ct * CO_TILE + o;
+                if (co < op.cout)
+                  pk[((((size_t)ct * op.n_chunks + ch) * taps + t) * op.ck + ci) * CO_TILE + o] = w[((size_t)co * op.cin + ch * op.ck + ci) * taps + t];
+              }
+      for (int o = 0; o < op.cout; ++o) bp[o] = b[o];
+      int rc = dev_alloc(c, &op.d_w, pk.size(), false);
+      if (rc) return rc;
+      if ((rc = dev_alloc(c, &op.d_b, bp.size(), false))) return rc;
+      HIP_TRY(c, hipMemcpy(op.d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+      HIP_TRY(c, hipMemcpy(op.d_b, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+    } else if (op.type == OP_MAXPOOL) {
+      std::snprintf(name, sizeof name, "pool:%u", i);
+      op.stage = stage_id(c, name);
+      if (to.level != ti.level + 1 || to.ch != ti.ch) return fail(c, SPVO_ERR_IO, "op %u: bad pool", i);
+    } else if (op.type == OP_L2NORM) {
+      std::snprintf(name, sizeof name, "l2norm:%u", i);
+      op.stage = stage_id(c, name);
+      if (ti.ch != 256 || to.ch != 256 || ti.level != 3) return fail(c, SPVO_ERR_IO, "op %u: descriptor tail must be 256 channels at 1/8", i);
+    } else {
+      return fail(c, SPVO_ERR_IO, "op %u: unknown type %d", i, op.type);
+    }
+  }
+  const Tensor &td = c->tensors[c->t_det];
+  const Tensor &ts = c->tensors[c->t_desc];
+  if (td.ch != 65 || td.level != 3 || td.nhwc || !ts.nhwc || c->tensors[c->t_input].ch != 1 || c->tensors[c->t_input].level != 0)
+    return fail(c, SPVO_ERR_IO, "%s: unexpected output tensors", path);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->weights = true;
+  return SPVO_OK;
+}
+
+int spvo_preprocess(spvo_ctx *c, const uint8_t *img, int rows, int cols, size_t stride, double P[12], uint8_t *resized_u8) {
+  if (!c || !img || !P || rows <= 0 || cols <= 0 || stride < (size_t)cols) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  const size_t bytes = (size_t)rows * stride;
+  if (bytes > c->img_cap) {
+    for (int i = 0; i < 2; ++i) { if (c->d_img[i]) (void)hipFree(c->d_img[i]); c->d_img[i] = nullptr; }
+    for (int i = 0; i < 2; ++i) { int rc = dev_alloc(c, &c->d_img[i], bytes, false); if (rc) return rc; }
+    c->img_cap = bytes;
+  }
+  const CropGeom g = crop_geometry(rows, cols, c->H, c->W);
+  HIP_TRY(c, hipMemcpyAsync(c->d_img[0], img, bytes, hipMemcpyHostToDevice, c->stream));
+  int rc = launch_preprocess(c, c->d_img[0], rows, cols, stride, g, 0);
+  if (rc) return rc;
+  fix_projection(P, g, rows, cols, c->cfg.bug_compat_p);
+  if (resized_u8) HIP_TRY(c, hipMemcpyAsync(resized_u8, c->d_resized, (size_t)c->H * c->W, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SPVO_OK;
+}
+
+int spvo_forward(spvo_ctx *c, const float *input, int batch, float *det, float *desc_nhwc) {
+  if (!c || !input) return fail(c, SPVO_ERR_INVALID, "null argument");
+  if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
+  if (batch < 1 || batch > c->B) return fail(c, SPVO_ERR_INVALID, "batch %d out of range", batch);
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  const size_t hw = (size_t)c->H * c->W;
+  const Tensor &tin = c->tensors[c->t_input];
+  HIP_TRY(c, hipMemcpyAsync(c->d_dense_in, input, batch * hw * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(pad_input_kernel, dim3((c->W + 63) / 64, (c->H + 3) / 4, batch), dim3(256), 0, c->stream, c->d_dense_in, tin.d, c->H, c->W, tin.hp, tin.wp);
+  int rc = run_network(c, batch);
+  if (rc) return rc;
+  const Tensor &td = c->tensors[c->t_det];
+  if (det) {
+    hipLaunchKernelGGL(unpad_kernel, dim3((td.W + 63) / 64, (td.H + 3) / 4, batch * 65), dim3(256), 0, c->stream, td.d, c->d_det_dense, 65, td.H, td.W, td.hp, td.wp);
+    HIP_TRY(c, hipMemcpyAsync(det, c->d_det_dense, (size_t)batch * 65 * td.H * td.W * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  }
+  if (desc_nhwc) {
+    const Tensor &ts = c->tensors[c->t_desc];
+    HIP_TRY(c, hipMemcpyAsync(desc_nhwc, ts.d, (size_t)batch * ts.per_image * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SPVO_OK;
+}
+
+int spvo_debug_tensor(spvo_ctx *c, int tensor_id, int batch, float *out, size_t out_floats) {
+  if (!c || !out) return fail(c, SPVO_ERR_INVALID, "null argument");
+  if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
+  if (tensor_id < 0 || tensor_id >= (int)c->tensors.size() || batch < 1 || batch > c->B) return fail(c, SPVO_ERR_INVALID, "bad tensor id / batch");
+  const Tensor &t = c->tensors[tensor_id];
+  const size_t need = (size_t)batch * t.ch * t.H * t.W;
+  if (out_floats < need) return fail(c, SPVO_ERR_CAPACITY, "need %zu floats", need);
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  if (t.nhwc) {
+    HIP_TRY(c, hipMemcpy(out, t.d, need * sizeof(float), hipMemcpyDeviceToHost));
+    return SPVO_OK;
+  }
+  float *tmp = nullptr;
+  HIP_TRY(c, hipMalloc((void **)&tmp, need * sizeof(float)));
+  hipLaunchKernelGGL(unpad_kernel, dim3((t.W + 63) / 64, (t.H + 3) / 4, batch * t.ch), dim3(256), 0, c->stream, t.d, tmp, t.ch, t.H, t.W, t.hp, t.wp);
+  hipError_t e = hipMemcpyAsync(out, tmp, need * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) return fail(c, SPVO_ERR_DEVICE, "debug copy failed: %s", hipGetErrorString(e));
+  return SPVO_OK;
+}
+
+int spvo_heatmap(spvo_ctx *c, const float *det, float *heat) {
+  if (!c || !det || !heat) return fail(c, SPVO_ERR_INVALID, "null argument");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  HIP_TRY(c, hipMemcpyAsync(c->d_det_dense, det, (size_t)65 * c->Hc * c->Wc * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(heatmap_kernel<false>, dim3((c->Wc + 63) / 64, (c->Hc + 3) / 4, 1), dim3(256), 0, c->stream, c->d_det_dense, c->d_heat, c->Hc, c->Wc, 0, 0);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(heat, c->d_heat, (size_t)c->H * c->W * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SPVO_OK;
+}
+
+int spvo_nms(spvo_ctx *c, const float *heat, int32_t *xy, int *n) {
+  if (!c || !heat || !xy || !n) return fail(c, SPVO_ERR_INVALID, "null argument");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  HIP_TRY(c, hipMemcpyAsync(c->d_heat, heat, (size_t)c->H * c->W * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  int rc = run_nms(c, 1);
+  if (rc) return rc;
+  *n = c->h_counters[2];
+  HIP_TRY(c, hipMemcpy(xy, c->nms[0].b.out_xy, (size_t)(*n) * 2 * sizeof(int), hipMemcpyDeviceToHost));
+  return SPVO_OK;
+}
+
+int spvo_sample_descriptors(spvo_ctx *c, const float *desc_nhwc, const int32_t *xy, int n, float *out) {
+  if (!c || !desc_nhwc || (n > 0 && (!xy || !out))) return fail(c, SPVO_ERR_INVALID, "null argument");
+  if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
+  if (n < 0 || n > c->cfg.max_keypoints) return fail(c, SPVO_ERR_CAPACITY, "n = %d exceeds max_keypoints", n);
+  if (n == 0) return SPVO_OK;
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  const Tensor &ts = c->tensors[c->t_desc];
+  HIP_TRY(c, hipMemcpyAsync(ts.d, desc_nhwc, ts.per_image * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_xy_tmp, xy, (size_t)n * 2 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(sample_desc_kernel, dim3((n + 3) / 4), dim3(256), 0, c->stream, ts.d, c->d_xy_tmp, (const int *)nullptr, n, c->H, c->W, c->Hc, c->Wc, c->d_desc_tmp, (float *)nullptr);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(out, c->d_desc_tmp, (size_t)n * 256 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SPVO_OK;
+}
+
+static int detect_common(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, int rows, int cols, size_t stride, double P_l[12], double P_r[12],
+                         int slot_l, int slot_r, spvo_features *out_l, spvo_features *out_r, uint8_t *resized_l, uint8_t *resized_r) {
+  if (slot_l < 0 || slot_l > 3 || slot_r < 0 || slot_r > 3 || slot_l == slot_r) return fail(c, SPVO_ERR_INVALID, "bad feature slots %d, %d", slot_l, slot_r);
+  const CropGeom g = crop_geometry(rows, cols, c->H, c->W);
+  const Tensor &td = c->tensors[c->t_det];
+  const Tensor &ts = c->tensors[c->t_desc];
+  const uint8_t *srcs[2] = {d_l, d_r};
+  {
+    ScopedStage st(c, stage_id(c, "detect"));
+    {
+      ScopedStage sp(c, stage_id(c, "preprocess"));
+      for (int i = 0; i < 2; ++i) { int rc = launch_preprocess(c, srcs[i], rows, cols, stride, g, i); if (rc) return rc; }
+    }
+    if (c->cfg.max_batch == 2) {
+      int rc = run_network(c, 2);
+      if (rc) return rc;
+      ScopedStage sh(c, stage_id(c, "heatmap"));
+      hipLaunchKernelGGL(heatmap_kernel<true>, dim3((c->Wc + 63) / 64, (c->Hc + 3) / 4, 2), dim3(256), 0, c->stream, td.d, c->d_heat, c->Hc, c->Wc, td.hp, td.wp);
+    } else {
+      // model_batch_size_ == 1 (nn.cpp:468-475): left then right through the same buffers
+      return fail(c, SPVO_ERR_INVALID, "max_batch == 1 detect path is not built yet; use max_batch = 2");
+    }
+    HIP_TRY(c, hipGetLastError());
+    {
+      ScopedStage sn(c, stage_id(c, "nms"));
+      int rc = run_nms(c, 2);
+      if (rc) return rc;
+    }
+    const int slots[2] = {slot_l, slot_r};
+    ScopedStage ss(c, stage_id(c, "sample"));
+    for (int i = 0; i < 2; ++i) {
+      FeatureSlot &s = c->slots[slots[i]];
+      s.n = c->h_counters[i * NMS_COUNTER_INTS + 2];
+      if (s.n > 0) {
+        HIP_TRY(c, hipMemcpyAsync(s.d_xy, c->nms[i].b.out_xy, (size_t)s.n * 2 * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(sample_desc_kernel, dim3((s.n + 3) / 4), dim3(256), 0, c->stream, ts.d + (size_t)i * ts.per_image, s.d_xy, (const int *)nullptr, s.n, c->H, c->W, c->Hc, c->Wc, s.d_desc, s.d_xyf);
+      }
+    }
+    HIP_TRY(c, hipGetLastError());
+  }
+  spvo_features *outs[2] = {out_l, out_r};
+  const int slots[2] = {slot_l, slot_r};
+  for (int i = 0; i < 2; ++i) {
+    FeatureSlot &s = c->slots[slots[i]];
+    if (!outs[i]) continue;
+    outs[i]->n = s.n;
+    if (s.n > 0 && outs[i]->xy) HIP_TRY(c, hipMemcpyAsync(outs[i]->xy, s.d_xyf, (size_t)s.n * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (s.n > 0 && outs[i]->desc) HIP_TRY(c, hipMemcpyAsync(outs[i]->desc, s.d_desc, (size_t)s.n * 256 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  }
+  uint8_t *res[2] = {resized_l, resized_r};
+  for (int i = 0; i < 2; ++i)
+    if (res[i]) HIP_TRY(c, hipMemcpyAsync(res[i], c->d_resized + (size_t)i * c->H * c->W, (size_t)c->H * c->W, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  fix_projection(P_l, g, rows, cols, c->cfg.bug_compat_p);
+  fix_projection(P_r, g, rows, cols, c->cfg.bug_compat_p);
+  return SPVO_OK;
+}
+
+int spvo_detect(spvo_ctx *c, const uint8_t *img_l, const uint8_t *img_r, int rows, int cols, size_t stride, double P_l[12], double P_r[12],
+                int slot_l, int slot_r, spvo_features *out_l, spvo_features *out_r, uint8_t *resized_l, uint8_t *resized_r) {
+  if (!c || !img_l || !img_r || !P_l || !P_r || rows <= 0 || cols <= 0 || stride < (size_t)cols) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  const size_t bytes = (size_t)rows * stride;
+  if (bytes > c->img_cap) {
+    for (int i = 0; i < 2; ++i) { if (c->d_img[i]) (void)hipFree(c->d_img[i]); c->d_img[i] = nullptr; }
+    for (int i = 0; i < 2; ++i) { int rc = dev_alloc(c, &c->d_img[i], bytes, false); if (rc) return rc; }
+    c->img_cap = bytes;
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->d_img[0], img_l, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_img[1], img_r, bytes, hipMemcpyHostToDevice, c->stream));
+  return detect_common(c, c->d_img[0], c->d_img[1], rows, cols, stride, P_l, P_r, slot_l, slot_r, out_l, out_r, resized_l, resized_r);
+}
+
+int spvo_detect_dev(spvo_ctx *c, const void *d_img_l, const void *d_img_r, int rows, int cols, size_t stride, double P_l[12], double P_r[12],
+                    int slot_l, int slot_r, spvo_features *out_l, spvo_features *out_r) {
+  if (!c || !d_img_l || !d_img_r || !P_l || !P_r || rows <= 0 || cols <= 0 || stride < (size_t)cols) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  return detect_common(c, (const uint8_t *)d_img_l, (const uint8_t *)d_img_r, rows, cols, stride, P_l, P_r, slot_l, slot_r, out_l, out_r, nullptr, nullptr);
+}
+
+int spvo_match(spvo_ctx *c, const float *desc_a, int na, const float *desc_b, int nb, int selector, int cross_check, float ratio, int32_t *train_idx, float *distance) {
+  if (!c || na < 0 || nb < 0 || (na > 0 && (!desc_a || !train_idx || !distance)) || (nb > 0 && !desc_b)) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  if (selector != SPVO_SELECT_NN && selector != SPVO_SELECT_KNN) return fail(c, SPVO_ERR_INVALID, "bad selector");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  int rc = ensure_match(c, na, nb);
+  if (rc) return rc;
+  if (na) HIP_TRY(c, hipMemcpyAsync(c->d_ma, desc_a, (size_t)na * MATCH_D * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  if (nb) HIP_TRY(c, hipMemcpyAsync(c->d_mb, desc_b, (size_t)nb * MATCH_D * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  return run_match(c, c->d_ma, na, c->d_mb, nb, selector, cross_check, ratio, train_idx, distance);
+}
+
+int spvo_match_slots(spvo_ctx *c, int slot_a, int slot_b, int selector, int cross_check, float ratio, int32_t *train_idx, float *distance) {
+  if (!c || slot_a < 0 || slot_a > 3 || slot_b < 0 || slot_b > 3) return fail(c, SPVO_ERR_INVALID, "bad slot");
+  if (selector != SPVO_SELECT_NN && selector != SPVO_SELECT_KNN) return fail(c, SPVO_ERR_INVALID, "bad selector");
+  const FeatureSlot &a = c->slots[slot_a], &b = c->slots[slot_b];
+  if (a.n > 0 && (!train_idx || !distance)) return fail(c, SPVO_ERR_INVALID, "null output");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  int rc = ensure_match(c, a.n, b.n);
+  if (rc) return rc;
+  return run_match(c, a.d_desc, a.n, b.d_desc, b.n, selector, cross_check, ratio, train_idx, distance);
+}
+
+int spvo_triangulate(spvo_ctx *c, const double P_l[12], const double P_r[12], const float *xy_l, const float *xy_r, int n, float *xyz) {
+  if (!c || !P_l || !P_r || n < 0 || (n > 0 && (!xy_l || !xy_r || !xyz))) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  if (n == 0) return SPVO_OK;
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  int rc = ensure_odometry(c, n, 0, 0);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->d_P, P_l, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_P + 12, P_r, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_pts_a, xy_l, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_pts_b, xy_r, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  {
+    ScopedStage st(c, stage_id(c, "triangulate"));
+    hipLaunchKernelGGL(triangulate_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_P, c->d_P + 12, c->d_pts_a, c->d_pts_b, n, c->d_xyz);
+  }
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(xyz, c->d_xyz, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SPVO_OK;
+}
+
+int spvo_pnp_ransac(spvo_ctx *c, const double K[9], const float *xyz, const float *xy, int n, const spvo_ransac_opts *opts, double rvec[3], double tvec[3],
+                    int32_t *inliers, int *n_inliers, int *ok) {
+  if (!c || !K || !rvec || !tvec || !n_inliers || !ok || n < 0 || (n > 0 && (!xyz || !xy || !inliers))) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  spvo_ransac_opts o = {500, 2.0, 0.999, 0};
+  if (opts) o = *opts;
+  if (o.iterations <= 0 || o.iterations > 65536 || !(o.reproj_error > 0)) return fail(c, SPVO_ERR_INVALID, "bad RANSAC options");
+  *ok = 0;
+  *n_inliers = 0;
+  if (n < 4) return SPVO_OK;  // not enough points for a model: prior is kept
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  int rc = ensure_odometry(c, n, o.iterations, 0);
+  if (rc) return rc;
+  double prior[6] = {rvec[0], rvec[1], rvec[2], tvec[0], tvec[1], tvec[2]};
+  HIP_TRY(c, hipMemcpyAsync(c->d_P + 24, K, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_P + 33, prior, 6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_pts_a, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_pts_b, xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  {
+    ScopedStage st(c, stage_id(c, "ransac"));
+    hipLaunchKernelGGL(ransac_hypothesis_kernel, dim3(o.iterations), dim3(64), 0, c->stream, c->d_P + 24, c->d_pts_a, c->d_pts_b, n, c->d_P + 33, o.seed, o.reproj_error * o.reproj_error, c->rw);
+    hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(256), 0, c->stream, c->d_P + 24, c->d_pts_a, c->d_pts_b, n, c->d_P + 33, o.iterations, o.reproj_error * o.reproj_error, c->rw);
+  }
+  HIP_TRY(c, hipGetLastError());
+  double res[8];
+  HIP_TRY(c, hipMemcpyAsync(res, c->rw.result, sizeof res, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  *ok = res[6] != 0;
+  *n_inliers = (int)res[7];
+  for (int k = 0; k < 3; ++k) { rvec[k] = res[k]; tvec[k] = res[3 + k]; }
+  if (*n_inliers > 0) HIP_TRY(c, hipMemcpy(inliers, c->rw.inliers, (size_t)(*n_inliers) * sizeof(int), hipMemcpyDeviceToHost));
+  return SPVO_OK;
+}
+
+int spvo_pnp_refine(spvo_ctx *c, const double P_l[12], const double P_r[12], const spvo_obs *obs, int n_obs, const spvo_refine_opts *opts, double q[4], double t[3],
+                    spvo_refine_summary *summary) {
+  if (!c || !P_l || !P_r || !q || !t || n_obs < 0 || (n_obs > 0 && !obs)) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  spvo_refine_opts o = {40, 1.0};
+  if (opts) o = *opts;
+  if (o.max_iterations < 0 || !(o.huber_delta > 0)) return fail(c, SPVO_ERR_INVALID, "bad refine options");
+  static_assert(sizeof(spvo_obs) == sizeof(ObsDev), "spvo_obs layout");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  int rc = ensure_odometry(c, 0, 0, n_obs);
+  if (rc) return rc;
+  double start[7] = {q[0], q[1], q[2], q[3], t[0], t[1], t[2]};
+  HIP_TRY(c, hipMemcpyAsync(c->d_P, P_l, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_P + 12, P_r, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_P + 40, start, sizeof start, hipMemcpyHostToDevice, c->stream));
+  if (n_obs) HIP_TRY(c, hipMemcpyAsync(c->d_obs, obs, (size_t)n_obs * sizeof(spvo_obs), hipMemcpyHostToDevice, c->stream));
+  {
+    ScopedStage st(c, stage_id(c, "refine"));
+    hipLaunchKernelGGL(pnp_refine_kernel<512>, dim3(1), dim3(512), 0, c->stream, c->d_P, c->d_P + 12, c->d_obs, n_obs, c->d_P + 40, o.max_iterations, o.huber_delta, c->d_refine);
+  }
+  HIP_TRY(c, hipGetLastError());
+  RefineOut r;
+  HIP_TRY(c, hipMemcpyAsync(&r, c->d_refine, sizeof r, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int k = 0; k < 4; ++k) q[k] = r.v[k];
+  for (int k = 0; k < 3; ++k) t[k] = r.v[4 + k];
+  if (summary) {
+    summary->iterations = (int)r.v[7];
+    summary->converged = (int)r.v[8];
+    summary->usable = (int)r.v[9];
+    summary->initial_cost = r.v[10];
+    summary->final_cost = r.v[11];
+  }
+  return SPVO_OK;
+}
+
+void *spvo_stream(spvo_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int spvo_synchronize(spvo_ctx *c) {
+  if (!c) return fail(c, SPVO_ERR_INVALID, "null context");
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SPVO_OK;
+}
+
+int spvo_profile_enable(spvo_ctx *c, int on) {
+  if (!c) return fail(c, SPVO_ERR_INVALID, "null context");
+  if (!on) resolve_pending(c);
+  c->prof = on != 0;
+  return SPVO_OK;
+}
+
+int spvo_profile_reset(spvo_ctx *c) {
+  if (!c) return fail(c, SPVO_ERR_INVALID, "null context");
+  resolve_pending(c);
+  for (auto &s : c->stages) { s.total_ms = 0; s.calls = 0; }
+  return SPVO_OK;
+}
+
+int spvo_profile_count(spvo_ctx *c) {
+  if (!c) return 0;
+  resolve_pending(c);
+  return (int)c->stages.size();
+}
+
+int spvo_profile_get(spvo_ctx *c, int i, char *name, size_t name_cap, double *total_ms, long long *calls, double *flops_per_call, double *bytes_per_call) {
+  if (!c || i < 0 || i >= (int)c->stages.size()) return fail(c, SPVO_ERR_INVALID, "bad stage index");
+  resolve_pending(c);
+  const Stage &s = c->stages[i];
+  if (name && name_cap) { std::strncpy(name, s.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (total_ms) *total_ms = s.total_ms;
+  if (calls) *calls = s.calls;
+  if (flops_per_call) *flops_per_call = s.flops;
+  if (bytes_per_call) *bytes_per_call = s.bytes;
+  return SPVO_OK;
+}
+
+}  // extern "C"

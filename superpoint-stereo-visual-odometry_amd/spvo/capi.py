@@ -1,0 +1,315 @@
+"""ctypes binding of the C ABI in include/spvo.h (used by tests/ and bench.py).
+
+There is no CPU path: `load()` raises if libspvo.so has not been built
+(`python __graft_entry__.py` or `make -C superpoint-stereo-visual-odometry_amd`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libspvo.so")
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int), ("net_height", C.c_int), ("net_width", C.c_int),
+                ("max_batch", C.c_int), ("conf_thresh", C.c_float), ("dist_thresh", C.c_int),
+                ("border_remove", C.c_int), ("max_keypoints", C.c_int), ("bug_compat_p", C.c_int)]
+
+
+class Features(C.Structure):
+    _fields_ = [("n", C.c_int), ("xy", C.POINTER(C.c_float)), ("desc", C.POINTER(C.c_float))]
+
+
+class RansacOpts(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("reproj_error", C.c_double), ("confidence", C.c_double),
+                ("seed", C.c_uint32)]
+
+
+class RefineOpts(C.Structure):
+    _fields_ = [("max_iterations", C.c_int), ("huber_delta", C.c_double)]
+
+
+class RefineSummary(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("converged", C.c_int), ("usable", C.c_int),
+                ("initial_cost", C.c_double), ("final_cost", C.c_double)]
+
+
+OBS_DTYPE = np.dtype([("X", np.float32, 3), ("uv", np.float32, 2), ("cam", np.int32), ("inverse", np.int32)])
+
+# every symbol include/spvo.h declares
+SYMBOLS = [
+    "spvo_default_config", "spvo_create", "spvo_destroy", "spvo_last_error", "spvo_load_weights",
+    "spvo_preprocess", "spvo_forward", "spvo_debug_tensor", "spvo_heatmap", "spvo_nms",
+    "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_match", "spvo_match_slots",
+    "spvo_triangulate", "spvo_pnp_ransac", "spvo_pnp_refine", "spvo_stream", "spvo_synchronize",
+    "spvo_profile_enable", "spvo_profile_reset", "spvo_profile_count", "spvo_profile_get",
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build the HIP library first "
+                           "(python __graft_entry__.py); there is no CPU path")
+    lib = C.CDLL(LIB_PATH)
+    vp, ip, fp, dp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double)
+    lib.spvo_default_config.argtypes = [C.POINTER(Config)]
+    lib.spvo_default_config.restype = None
+    lib.spvo_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    lib.spvo_destroy.argtypes = [vp]
+    lib.spvo_destroy.restype = None
+    lib.spvo_last_error.argtypes = [vp]
+    lib.spvo_last_error.restype = C.c_char_p
+    lib.spvo_load_weights.argtypes = [vp, C.c_char_p]
+    lib.spvo_preprocess.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, dp, vp]
+    lib.spvo_forward.argtypes = [vp, vp, C.c_int, vp, vp]
+    lib.spvo_debug_tensor.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t]
+    lib.spvo_heatmap.argtypes = [vp, vp, vp]
+    lib.spvo_nms.argtypes = [vp, vp, vp, ip]
+    lib.spvo_sample_descriptors.argtypes = [vp, vp, vp, C.c_int, vp]
+    lib.spvo_detect.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, dp, dp, C.c_int, C.c_int,
+                                C.POINTER(Features), C.POINTER(Features), vp, vp]
+    lib.spvo_detect_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, dp, dp, C.c_int, C.c_int,
+                                    C.POINTER(Features), C.POINTER(Features)]
+    lib.spvo_match.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
+    lib.spvo_match_slots.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
+    lib.spvo_triangulate.argtypes = [vp, dp, dp, vp, vp, C.c_int, vp]
+    lib.spvo_pnp_ransac.argtypes = [vp, dp, vp, vp, C.c_int, C.POINTER(RansacOpts), dp, dp, vp, ip, ip]
+    lib.spvo_pnp_refine.argtypes = [vp, dp, dp, vp, C.c_int, C.POINTER(RefineOpts), dp, dp,
+                                    C.POINTER(RefineSummary)]
+    lib.spvo_stream.argtypes = [vp]
+    lib.spvo_stream.restype = vp
+    lib.spvo_synchronize.argtypes = [vp]
+    lib.spvo_profile_enable.argtypes = [vp, C.c_int]
+    lib.spvo_profile_reset.argtypes = [vp]
+    lib.spvo_profile_count.argtypes = [vp]
+    lib.spvo_profile_get.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t, dp, C.POINTER(C.c_longlong), dp, dp]
+    _lib = lib
+    return lib
+
+
+class SpvoError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"spvo error {code}: {msg}")
+        self.code = code
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _dptr(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Context:
+    """Thin object wrapper: one method per C entry point, numpy in / numpy out."""
+
+    def __init__(self, **kw):
+        self.lib = load()
+        self.cfg = Config()
+        self.lib.spvo_default_config(C.byref(self.cfg))
+        for k, v in kw.items():
+            if not hasattr(self.cfg, k):
+                raise TypeError(k)
+            setattr(self.cfg, k, v)
+        self.h = C.c_void_p()
+        rc = self.lib.spvo_create(C.byref(self.cfg), C.byref(self.h))
+        if rc:
+            raise SpvoError(rc, self.lib.spvo_last_error(None).decode())
+        self.H, self.W = self.cfg.net_height, self.cfg.net_width
+        self.Hc, self.Wc = self.H // 8, self.W // 8
+        self.cap = self.cfg.max_keypoints
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.spvo_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc:
+            raise SpvoError(rc, self.lib.spvo_last_error(self.h).decode())
+
+    def load_weights(self, path: str):
+        self._check(self.lib.spvo_load_weights(self.h, path.encode()))
+
+    def preprocess(self, img: np.ndarray, P: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        img = np.ascontiguousarray(img, np.uint8)
+        P2 = np.ascontiguousarray(P, np.float64).reshape(12).copy()
+        out = np.empty((self.H, self.W), np.uint8)
+        self._check(self.lib.spvo_preprocess(self.h, _ptr(img), img.shape[0], img.shape[1], img.strides[0],
+                                             _dptr(P2), _ptr(out)))
+        return out, P2.reshape(3, 4)
+
+    def forward(self, x: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        x = np.ascontiguousarray(x, np.float32)
+        b = x.shape[0]
+        assert x.shape == (b, 1, self.H, self.W)
+        det = np.empty((b, 65, self.Hc, self.Wc), np.float32)
+        desc = np.empty((b, self.Hc, self.Wc, 256), np.float32)
+        self._check(self.lib.spvo_forward(self.h, _ptr(x), b, _ptr(det), _ptr(desc)))
+        return det, desc
+
+    def debug_tensor(self, tid: int, batch: int, channels: int, level: int) -> np.ndarray:
+        out = np.empty((batch, channels, self.H >> level, self.W >> level), np.float32)
+        self._check(self.lib.spvo_debug_tensor(self.h, tid, batch, _ptr(out), out.size))
+        return out
+
+    def heatmap(self, det: np.ndarray) -> np.ndarray:
+        det = np.ascontiguousarray(det, np.float32)
+        assert det.shape == (65, self.Hc, self.Wc)
+        heat = np.empty((self.H, self.W), np.float32)
+        self._check(self.lib.spvo_heatmap(self.h, _ptr(det), _ptr(heat)))
+        return heat
+
+    def nms(self, heat: np.ndarray) -> np.ndarray:
+        heat = np.ascontiguousarray(heat, np.float32)
+        assert heat.shape == (self.H, self.W)
+        xy = np.zeros((self.cap, 2), np.int32)
+        n = C.c_int(0)
+        self._check(self.lib.spvo_nms(self.h, _ptr(heat), _ptr(xy), C.byref(n)))
+        return xy[:n.value].copy()
+
+    def sample_descriptors(self, desc_nhwc: np.ndarray, xy: np.ndarray) -> np.ndarray:
+        desc_nhwc = np.ascontiguousarray(desc_nhwc, np.float32)
+        assert desc_nhwc.shape == (self.Hc, self.Wc, 256)
+        xy = np.ascontiguousarray(xy, np.int32).reshape(-1, 2)
+        out = np.empty((len(xy), 256), np.float32)
+        self._check(self.lib.spvo_sample_descriptors(self.h, _ptr(desc_nhwc), _ptr(xy), len(xy), _ptr(out)))
+        return out
+
+    def _features(self, want_desc=True):
+        xy = np.zeros((self.cap, 2), np.float32)
+        desc = np.zeros((self.cap, 256), np.float32) if want_desc else None
+        f = Features(0, xy.ctypes.data_as(C.POINTER(C.c_float)),
+                     desc.ctypes.data_as(C.POINTER(C.c_float)) if want_desc else None)
+        return f, xy, desc
+
+    def detect(self, img_l: np.ndarray, img_r: np.ndarray, P_l, P_r, slot_l=2, slot_r=3, want_resized=False):
+        img_l = np.ascontiguousarray(img_l, np.uint8)
+        img_r = np.ascontiguousarray(img_r, np.uint8)
+        assert img_l.shape == img_r.shape and img_l.strides == img_r.strides
+        Pl = np.ascontiguousarray(P_l, np.float64).reshape(12).copy()
+        Pr = np.ascontiguousarray(P_r, np.float64).reshape(12).copy()
+        fl, xyl, dl = self._features()
+        fr, xyr, dr = self._features()
+        rl = np.empty((self.H, self.W), np.uint8) if want_resized else None
+        rr = np.empty((self.H, self.W), np.uint8) if want_resized else None
+        self._check(self.lib.spvo_detect(self.h, _ptr(img_l), _ptr(img_r), img_l.shape[0], img_l.shape[1],
+                                         img_l.strides[0], _dptr(Pl), _dptr(Pr), slot_l, slot_r,
+                                         C.byref(fl), C.byref(fr), _ptr(rl), _ptr(rr)))
+        out = dict(xy_l=xyl[:fl.n].copy(), desc_l=dl[:fl.n].copy(), xy_r=xyr[:fr.n].copy(),
+                   desc_r=dr[:fr.n].copy(), P_l=Pl.reshape(3, 4), P_r=Pr.reshape(3, 4))
+        if want_resized:
+            out["resized_l"], out["resized_r"] = rl, rr
+        return out
+
+    def detect_dev(self, d_img_l: int, d_img_r: int, rows: int, cols: int, stride: int, P_l, P_r,
+                   slot_l=2, slot_r=3, want_desc=False):
+        Pl = np.ascontiguousarray(P_l, np.float64).reshape(12).copy()
+        Pr = np.ascontiguousarray(P_r, np.float64).reshape(12).copy()
+        fl, xyl, dl = self._features(want_desc)
+        fr, xyr, dr = self._features(want_desc)
+        self._check(self.lib.spvo_detect_dev(self.h, C.c_void_p(d_img_l), C.c_void_p(d_img_r), rows, cols, stride,
+                                             _dptr(Pl), _dptr(Pr), slot_l, slot_r, C.byref(fl), C.byref(fr)))
+        return dict(xy_l=xyl[:fl.n], xy_r=xyr[:fr.n], desc_l=None if dl is None else dl[:fl.n],
+                    desc_r=None if dr is None else dr[:fr.n], P_l=Pl.reshape(3, 4), P_r=Pr.reshape(3, 4))
+
+    def match(self, a: np.ndarray, b: np.ndarray, selector="KNN", cross_check=False, ratio=0.8):
+        a = np.ascontiguousarray(a, np.float32).reshape(-1, 256)
+        b = np.ascontiguousarray(b, np.float32).reshape(-1, 256)
+        idx = np.full(len(a), -1, np.int32)
+        dist = np.zeros(len(a), np.float32)
+        self._check(self.lib.spvo_match(self.h, _ptr(a), len(a), _ptr(b), len(b), 1 if selector == "KNN" else 0,
+                                        int(cross_check), ratio, _ptr(idx), _ptr(dist)))
+        return idx, dist
+
+    def match_slots(self, slot_a: int, slot_b: int, n_a: int, selector="KNN", cross_check=False, ratio=0.8):
+        idx = np.full(max(n_a, 1), -1, np.int32)
+        dist = np.zeros(max(n_a, 1), np.float32)
+        self._check(self.lib.spvo_match_slots(self.h, slot_a, slot_b, 1 if selector == "KNN" else 0,
+                                              int(cross_check), ratio, _ptr(idx), _ptr(dist)))
+        return idx[:n_a], dist[:n_a]
+
+    def triangulate(self, P_l, P_r, xy_l, xy_r) -> np.ndarray:
+        Pl = np.ascontiguousarray(P_l, np.float64).reshape(12)
+        Pr = np.ascontiguousarray(P_r, np.float64).reshape(12)
+        a = np.ascontiguousarray(xy_l, np.float32).reshape(-1, 2)
+        b = np.ascontiguousarray(xy_r, np.float32).reshape(-1, 2)
+        out = np.zeros((len(a), 3), np.float32)
+        self._check(self.lib.spvo_triangulate(self.h, _dptr(Pl), _dptr(Pr), _ptr(a), _ptr(b), len(a), _ptr(out)))
+        return out
+
+    def pnp_ransac(self, K, xyz, xy, rvec0, tvec0, iterations=500, reproj_error=2.0, seed=0):
+        K = np.ascontiguousarray(K, np.float64).reshape(9)
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        r = np.ascontiguousarray(rvec0, np.float64).reshape(3).copy()
+        t = np.ascontiguousarray(tvec0, np.float64).reshape(3).copy()
+        inl = np.zeros(max(len(xyz), 1), np.int32)
+        n_inl, ok = C.c_int(0), C.c_int(0)
+        opts = RansacOpts(iterations, reproj_error, 0.999, seed)
+        self._check(self.lib.spvo_pnp_ransac(self.h, _dptr(K), _ptr(xyz), _ptr(xy), len(xyz), C.byref(opts),
+                                             _dptr(r), _dptr(t), _ptr(inl), C.byref(n_inl), C.byref(ok)))
+        return bool(ok.value), r, t, inl[:n_inl.value].copy()
+
+    def pnp_refine(self, P_l, P_r, obs: np.ndarray, q0, t0, max_iterations=40, huber_delta=1.0):
+        Pl = np.ascontiguousarray(P_l, np.float64).reshape(12)
+        Pr = np.ascontiguousarray(P_r, np.float64).reshape(12)
+        obs = np.ascontiguousarray(obs, OBS_DTYPE)
+        q = np.ascontiguousarray(q0, np.float64).reshape(4).copy()
+        t = np.ascontiguousarray(t0, np.float64).reshape(3).copy()
+        s = RefineSummary()
+        opts = RefineOpts(max_iterations, huber_delta)
+        self._check(self.lib.spvo_pnp_refine(self.h, _dptr(Pl), _dptr(Pr), _ptr(obs), len(obs), C.byref(opts),
+                                             _dptr(q), _dptr(t), C.byref(s)))
+        return q, t, s
+
+    def stream(self) -> int:
+        return self.lib.spvo_stream(self.h) or 0
+
+    def synchronize(self):
+        self._check(self.lib.spvo_synchronize(self.h))
+
+    def profile_enable(self, on=True):
+        self._check(self.lib.spvo_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        self._check(self.lib.spvo_profile_reset(self.h))
+
+    def profile(self):
+        out = {}
+        n = self.lib.spvo_profile_count(self.h)
+        for i in range(n):
+            name = C.create_string_buffer(64)
+            ms, fl, by = C.c_double(), C.c_double(), C.c_double()
+            calls = C.c_longlong()
+            self._check(self.lib.spvo_profile_get(self.h, i, name, 64, C.byref(ms), C.byref(calls), C.byref(fl), C.byref(by)))
+            out[name.value.decode()] = dict(total_ms=ms.value, calls=calls.value, flops=fl.value, bytes=by.value)
+        return out
+
+
+def obs_array(X, uv, cam, inverse) -> np.ndarray:
+    n = len(X)
+    a = np.zeros(n, OBS_DTYPE)
+    if n:
+        a["X"] = np.asarray(X, np.float32).reshape(n, 3)
+        a["uv"] = np.asarray(uv, np.float32).reshape(n, 2)
+        a["cam"] = np.asarray(cam, np.int32)
+        a["inverse"] = np.asarray(inverse, np.int32)
+    return a

@@ -1,0 +1,86 @@
+"""GPU parity of the CNN (K1-K6) against the torch-CPU fp32 oracle, through the C ABI.
+
+Tolerance (stated, per BASELINE.json north_star "within 1e-4 float"): the fp32 MFMA
+is an exact k-ordered fmaf chain, torch-CPU (oneDNN) sums in another order, so
+values agree to accumulated fp32 rounding: |gpu - oracle| <= 1e-4 * max(1, max|oracle|).
+"""
+import numpy as np
+import pytest
+
+import oracle  # noqa: F401
+from oracle import net
+from tests.conftest import make_ctx
+
+pytestmark = pytest.mark.gpu
+
+
+def _tol(ref):
+    return 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+def _input(sample_images, H, W, batch):
+    xs = []
+    for b in range(batch):
+        img = sample_images[b % len(sample_images)]
+        xs.append(img[5:5 + H, 20 + 3 * b:20 + 3 * b + W].astype(np.float32) / 255.0)
+    return np.stack(xs)[:, None]
+
+
+@pytest.mark.parametrize("H,W,batch", [(120, 392, 2), (360, 1176, 2), (192, 640, 1)])
+def test_vgg_forward_matches_oracle(vgg_weights_path, vgg_plan, sample_images, H, W, batch):
+    ctx = make_ctx(vgg_weights_path, net_height=H, net_width=W)
+    x = _input(sample_images, H, W, batch)
+    det, desc = ctx.forward(x)
+    rdet, rdesc, vals = net.forward(vgg_plan, x, return_all=True)
+    # every intermediate activation (conv1a .. heads)
+    for tid, (ch, lvl) in enumerate(vgg_plan.tensors):
+        if tid in (vgg_plan.input_tensor, vgg_plan.desc_tensor):
+            continue
+        got = ctx.debug_tensor(tid, batch, ch, lvl)
+        assert np.abs(got - vals[tid]).max() <= _tol(vals[tid]), f"tensor {tid}"
+    assert np.abs(det - rdet).max() <= _tol(rdet)
+    assert np.abs(desc - rdesc.transpose(0, 2, 3, 1)).max() <= 1e-4
+    assert np.allclose(np.linalg.norm(desc, axis=-1), 1.0, atol=1e-5)
+    ctx.close()
+
+
+def test_squeeze_forward_matches_oracle(ctx_squeeze, squeeze_plan, sample_images):
+    x = _input(sample_images, 360, 1176, 2)
+    det, desc = ctx_squeeze.forward(x)
+    rdet, rdesc = net.forward(squeeze_plan, x)
+    assert np.abs(det - rdet).max() <= _tol(rdet)
+    assert np.abs(desc - rdesc.transpose(0, 2, 3, 1)).max() <= 1e-4
+
+
+def test_forward_is_deterministic_and_batch_independent(ctx_vgg, sample_images):
+    x = _input(sample_images, 360, 1176, 2)
+    d1, s1 = ctx_vgg.forward(x)
+    d2, s2 = ctx_vgg.forward(x)
+    assert np.array_equal(d1, d2) and np.array_equal(s1, s2)          # bit-identical reruns
+    d3, s3 = ctx_vgg.forward(x[1:2])
+    assert np.array_equal(d3[0], d1[1]) and np.array_equal(s3[0], s1[1])  # image 1 alone == image 1 in the pair
+
+
+def test_forward_linearity_of_first_layers(ctx_vgg, vgg_plan):
+    # size-independent property at full size: a zero image gives relu(bias) = 0 everywhere in conv1a (bias 0)
+    x = np.zeros((1, 1, 360, 1176), np.float32)
+    ctx_vgg.forward(x)
+    a = ctx_vgg.debug_tensor(1, 1, 64, 0)
+    assert np.all(a == 0)
+
+
+def test_errors(vgg_weights_path, tmp_path):
+    from spvo import capi
+    ctx = make_ctx(None)
+    with pytest.raises(capi.SpvoError) as e:                          # nn.cpp:53-55 "no such engine file"
+        ctx.load_weights(str(tmp_path / "missing.spvw"))
+    assert e.value.code == -3 and "no such engine file" in str(e.value)
+    with pytest.raises(capi.SpvoError) as e:
+        ctx.forward(np.zeros((1, 1, 360, 1176), np.float32))
+    assert e.value.code == -4
+    bad = tmp_path / "bad.spvw"
+    bad.write_bytes(b"not a weight file at all, just bytes" * 4)
+    with pytest.raises(capi.SpvoError) as e:
+        ctx.load_weights(str(bad))
+    assert e.value.code == -3
+    ctx.close()

@@ -1,0 +1,96 @@
+"""GPU parity of K14 (triangulation), K15 (RANSAC) and K16 (LM refinement) against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle  # noqa: F401
+from oracle import odometry as od
+from spvo import capi, synth
+from tests.test_oracle_cpu import _scene
+
+pytestmark = pytest.mark.gpu
+
+
+def test_triangulate(ctx_vgg, golden_dir):
+    o = np.load(os.path.join(golden_dir, "oracle_odometry.npz"))
+    got = ctx_vgg.triangulate(o["P_l"], o["P_r"], o["cl"], o["cr"])
+    ref = od.triangulate(o["P_l"], o["P_r"], o["cl"], o["cr"])
+    assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)) <= 1e-4     # north_star tolerance
+    assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)) <= 2e-6     # what is actually achieved
+    assert len(ctx_vgg.triangulate(o["P_l"], o["P_r"], o["cl"][:0], o["cr"][:0])) == 0
+    # bug-compatible projection matrices (denormal P[0][1]) go through unchanged
+    P_l, P_r = o["P_l"].copy(), o["P_r"].copy()
+    P_l[0, 1] = P_r[0, 1] = 1.5e-314
+    assert np.allclose(ctx_vgg.triangulate(P_l, P_r, o["cl"], o["cr"]), ref, rtol=1e-5)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_ransac_matches_oracle(ctx_vgg, seed):
+    P_l, P_r, Xc, cl, cr, pl, pr, rv, tv, bad = _scene(seed=seed, n=400, noise=0.3, outliers=0.3)
+    pts = od.triangulate(P_l, P_r, cl, cr)
+    prior_r, prior_t = np.array([0.0, 0.0, 0.0]), np.array([0.0, 0.0, 0.8])
+    ok, r, t, inl = ctx_vgg.pnp_ransac(P_l[:, :3], pts, pl, prior_r, prior_t, 500, 2.0, seed)
+    rok, rr, rt, rinl = od.pnp_ransac(P_l[:, :3], pts, pl, prior_r, prior_t, 500, 2.0, seed)
+    assert ok == rok and np.array_equal(inl, rinl)                       # integer output: bit-exact
+    assert np.allclose(r, rr, atol=1e-8) and np.allclose(t, rt, atol=1e-8)
+    assert np.allclose(r, rv, atol=3e-3) and np.allclose(t, tv, atol=3e-2)
+
+
+def test_ransac_degenerate_inputs(ctx_vgg):
+    P_l, P_r, Xc, cl, cr, pl, *_ = _scene(n=30)
+    pts = od.triangulate(P_l, P_r, cl, cr)
+    ok, r, t, inl = ctx_vgg.pnp_ransac(P_l[:, :3], pts[:3], pl[:3], np.zeros(3), np.ones(3), 500, 2.0, 0)
+    assert not ok and len(inl) == 0 and np.all(t == 1)                   # fewer than 4 points: prior is kept
+    # pure garbage correspondences: oracle and GPU agree on failure or on the same (small) consensus
+    rng = np.random.RandomState(0)
+    junk = rng.uniform(0, 1000, (30, 2)).astype(np.float32)
+    g = ctx_vgg.pnp_ransac(P_l[:, :3], pts, junk, np.zeros(3), np.zeros(3), 200, 2.0, 1)
+    o = od.pnp_ransac(P_l[:, :3], pts, junk, np.zeros(3), np.zeros(3), 200, 2.0, 1)
+    assert g[0] == o[0] and np.array_equal(g[3], o[3])
+
+
+def _obs_from(P_l, P_r, pts, pl, pr, cl, cr, Xp, inl, degree):
+    X, uv, cam, inv = [], [], [], []
+    for i in inl:
+        X.append(pts[i]); uv.append(pl[i]); cam.append(0); inv.append(0)
+        if degree >= 2:
+            X.append(pts[i]); uv.append(pr[i]); cam.append(1); inv.append(0)
+        if degree >= 3:
+            X.append(Xp[i]); uv.append(cl[i]); cam.append(0); inv.append(1)
+        if degree >= 4:
+            X.append(Xp[i]); uv.append(cr[i]); cam.append(1); inv.append(1)
+    return (np.asarray(X, np.float32), np.asarray(uv, np.float32), np.asarray(cam), np.asarray(inv))
+
+
+@pytest.mark.parametrize("degree", [1, 2, 4])
+def test_refine_matches_oracle(ctx_vgg, degree):
+    P_l, P_r, Xc, cl, cr, pl, pr, rv, tv, bad = _scene(seed=3, n=300, noise=0.4, outliers=0.1)
+    pts = od.triangulate(P_l, P_r, cl, cr)
+    R = od.quat_to_rot(od.rvec_to_quat(rv))
+    Xp = (Xc @ R.T + tv).astype(np.float32)
+    inl = np.nonzero(~bad)[0]
+    X, uv, cam, inv = _obs_from(P_l, P_r, pts, pl, pr, cl, cr, Xp, inl, degree)
+    q0 = od.rvec_to_quat(rv + 0.01)
+    t0 = tv + 0.05
+    q, t, s = ctx_vgg.pnp_refine(P_l, P_r, capi.obs_array(X, uv, cam, inv), q0, t0)
+    rq, rt, rs = od.pnp_refine(P_l, P_r, (X.astype(np.float64), uv.astype(np.float64), cam, inv), q0, t0)
+    assert (s.iterations, bool(s.converged), bool(s.usable)) == (rs.iterations, rs.converged, rs.usable)
+    assert np.allclose(q, rq, atol=1e-9) and np.allclose(t, rt, atol=1e-9)     # far inside the 1e-4 bar
+    assert s.initial_cost == pytest.approx(rs.initial_cost, rel=1e-10)
+    assert s.final_cost == pytest.approx(rs.final_cost, rel=1e-9)
+    assert np.allclose(od.quat_to_rvec(q), rv, atol=2e-3) and np.allclose(t, tv, atol=2e-2)
+
+
+def test_refine_edge_cases(ctx_vgg):
+    P_l, P_r = synth.projection_matrices()
+    q, t, s = ctx_vgg.pnp_refine(P_l, P_r, capi.obs_array([], [], [], []), [0, 0, 0, 1], [0, 0, 0])
+    assert s.converged and s.usable and np.allclose(q, [0, 0, 0, 1])
+    # max_iterations = 1 -> NO_CONVERGENCE (the reference then discards the result, base.cpp:366-374)
+    P_l, P_r, Xc, cl, cr, pl, pr, rv, tv, bad = _scene(seed=4, n=80)
+    pts = od.triangulate(P_l, P_r, cl, cr)
+    obs = capi.obs_array(pts, pl, np.zeros(80, int), np.zeros(80, int))
+    q, t, s = ctx_vgg.pnp_refine(P_l, P_r, obs, [0, 0, 0, 1], [0, 0, 0], max_iterations=1)
+    _, _, rs = od.pnp_refine(P_l, P_r, (pts.astype(np.float64), pl.astype(np.float64), np.zeros(80, int), np.zeros(80, int)),
+                             np.array([0, 0, 0, 1.0]), np.zeros(3), max_iterations=1)
+    assert not s.converged and s.usable and s.iterations == rs.iterations == 1

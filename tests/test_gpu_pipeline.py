@@ -1,0 +1,65 @@
+"""End-to-end GPU checks: spvo_detect / spvo_match_slots vs the oracle on the same stereo pair,
+and full-size properties that do not depend on the oracle finishing quickly."""
+import numpy as np
+import pytest
+
+import oracle  # noqa: F401
+from oracle import frontend as fe, matching
+from spvo import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def stereo_pair(golden_dir):
+    import os
+    frames, poses, P_l, P_r = synth.stereo_sequence(2, os.path.join(golden_dir, "images", "0000000000.png"), seed=0)
+    return frames, poses, P_l, P_r
+
+
+def test_detect_matches_oracle_end_to_end(ctx_squeeze, squeeze_plan, stereo_pair):
+    frames, _, P_l, P_r = stereo_pair
+    L, R = frames[0]
+    out = ctx_squeeze.detect(L, R, P_l, P_r, 2, 3, want_resized=True)
+    rl = fe.detect(squeeze_plan, L, P_l, 360, 1176)
+    rr = fe.detect(squeeze_plan, R, P_r, 360, 1176)
+    assert np.array_equal(out["resized_l"], rl["resized"]) and np.array_equal(out["resized_r"], rr["resized"])
+    assert np.array_equal(out["P_l"], rl["P"]) and np.array_equal(out["P_r"], rr["P"])
+    for side, ref in (("l", rl), ("r", rr)):
+        xy = out["xy_" + side].astype(np.int32)
+        # keypoints are threshold/sort outcomes of floats that agree to ~1e-6: report set agreement
+        a, b = set(map(tuple, xy.tolist())), set(map(tuple, ref["xy"].tolist()))
+        assert len(a & b) / len(a | b) > 0.97, len(a & b)
+        assert len(xy) == len(ref["xy"]) == 1000
+        # descriptors of the common keypoints agree to 1e-4 (north_star tolerance)
+        pos = {tuple(p): i for i, p in enumerate(ref["xy"].tolist())}
+        common = [(i, pos[tuple(p)]) for i, p in enumerate(xy.tolist()) if tuple(p) in pos]
+        gi, ri = map(np.array, zip(*common))
+        assert np.abs(out["desc_" + side][gi] - ref["descriptors"][ri]).max() <= 1e-4
+    # device-resident slots give the same matches as host descriptors through the oracle matcher
+    idx, d = ctx_squeeze.match_slots(2, 3, len(out["xy_l"]))
+    ridx, rd = matching.bf_match(out["desc_l"], out["desc_r"], "KNN", False, 0.8)
+    assert np.array_equal(idx, ridx) and np.array_equal(d, rd)
+    assert (idx >= 0).sum() > 500
+
+
+def test_detect_properties_full_size(ctx_vgg, stereo_pair):
+    frames, _, P_l, P_r = stereo_pair
+    L, R = frames[1]
+    a = ctx_vgg.detect(L, R, P_l, P_r, 0, 1)
+    b = ctx_vgg.detect(L, R, P_l, P_r, 2, 3)
+    for k in ("xy_l", "xy_r", "desc_l", "desc_r"):
+        assert np.array_equal(a[k], b[k])                                    # idempotent, slot-independent
+    xy = a["xy_l"]
+    assert len(xy) <= 1000 and np.all(xy == np.round(xy))                    # integer coordinates (nn.cpp:243)
+    assert xy[:, 0].min() >= 4 and xy[:, 0].max() < 1176 - 4 and xy[:, 1].min() >= 4 and xy[:, 1].max() < 360 - 4
+    d = np.abs(xy[:, None, :] - xy[None, :, :]).max(-1)
+    np.fill_diagonal(d, 99)
+    assert d.min() > 4                                                       # NMS: Chebyshev distance > dist_thresh
+    assert np.allclose(np.linalg.norm(a["desc_l"], axis=1), 1, atol=1e-5)
+    # swapping left and right swaps the outputs
+    c = ctx_vgg.detect(R, L, P_r, P_l, 0, 1)
+    assert np.array_equal(c["xy_l"], a["xy_r"]) and np.array_equal(c["desc_r"], a["desc_l"])
+    # a stereo pair matched against itself: every keypoint finds itself at distance 0 (NN)
+    idx, dist = ctx_vgg.match_slots(0, 0, len(c["xy_l"]), "NN", True)
+    assert np.array_equal(idx, np.arange(len(idx))) and np.all(dist == 0)

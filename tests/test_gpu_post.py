@@ -1,0 +1,99 @@
+"""GPU parity of K0, K7-K11 against the oracle.  Integer/byte outputs bit-exact."""
+import numpy as np
+import pytest
+
+import oracle  # noqa: F401
+from oracle import frontend as fe, net
+from tests.conftest import make_ctx
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("H,W", [(360, 1176), (240, 784), (120, 392), (376, 1240), (192, 640)])
+@pytest.mark.parametrize("bug", [1, 0])
+def test_preprocess_bit_exact(vgg_weights_path, kitti_P, H, W, bug):
+    rng = np.random.RandomState(H + bug)
+    img = rng.randint(0, 256, (376, 1241)).astype(np.uint8)
+    ctx = make_ctx(vgg_weights_path, net_height=H, net_width=W, bug_compat_p=bug)
+    got, P = ctx.preprocess(img, kitti_P[1])
+    ref, Pref = fe.preprocess(img, kitti_P[1], H, W, bool(bug))
+    assert np.array_equal(got, ref)
+    assert np.array_equal(P.view(np.uint64), Pref.view(np.uint64))       # f64 bit patterns, incl. the denormal
+    ctx.close()
+
+
+def test_preprocess_strided_rows_and_sample_size(vgg_weights_path, kitti_P, sample_images):
+    ctx = make_ctx(vgg_weights_path)
+    big = np.zeros((375, 1300), np.uint8)
+    big[:, :1242] = sample_images[0]
+    view = big[:, :1242]                                                   # stride 1300 != cols
+    got, _ = ctx.preprocess(view, kitti_P[0])
+    ref, _ = fe.preprocess(sample_images[0], kitti_P[0], 360, 1176)
+    assert np.array_equal(got, ref)
+    ctx.close()
+
+
+def test_heatmap(ctx_squeeze, squeeze_plan, sample_images):
+    x = (sample_images[0][:360, :1176].astype(np.float32) / 255)[None, None]
+    det, _ = net.forward(squeeze_plan, x)
+    heat = ctx_squeeze.heatmap(det[0])
+    ref = fe.heatmap(det[0])
+    # expf (ocml) vs numpy exp: <= 2 ulp each; heat values are <= 1
+    assert np.abs(heat - ref).max() <= 2e-6
+    assert np.all((heat > 0.015) == (ref > 0.015)) or np.sum((heat > 0.015) != (ref > 0.015)) <= 3
+
+
+def _nms_both(ctx, heat):
+    got = ctx.nms(heat)
+    ref = fe.nms(heat, ctx.cfg.conf_thresh, ctx.cfg.dist_thresh, ctx.cfg.border_remove, ctx.cfg.max_keypoints)
+    return got, ref
+
+
+def test_nms_bit_exact_on_real_heatmap(ctx_squeeze, squeeze_plan, sample_images):
+    for k in range(2):
+        x = (sample_images[k][:360, :1176].astype(np.float32) / 255)[None, None]
+        det, _ = net.forward(squeeze_plan, x)
+        heat = fe.heatmap(det[0])
+        got, ref = _nms_both(ctx_squeeze, heat)
+        assert len(ref) == 1000 and np.array_equal(got, ref)
+
+
+def test_nms_edge_cases(vgg_weights_path):
+    ctx = make_ctx(vgg_weights_path, net_height=120, net_width=392, max_keypoints=50)
+    H, W = 120, 392
+    # empty
+    got, ref = _nms_both(ctx, np.zeros((H, W), np.float32))
+    assert len(got) == 0 and len(ref) == 0
+    # everything a candidate with identical confidence: pure tie-break order, long suppression chains
+    got, ref = _nms_both(ctx, np.full((H, W), 0.5, np.float32))
+    assert np.array_equal(got, ref) and len(ref) == 50
+    # monotone ramp: the worst case for parallel rounds (each decision depends on its neighbour)
+    ramp = (np.arange(H * W, dtype=np.float32).reshape(H, W) + 1) / (H * W)
+    got, ref = _nms_both(ctx, ramp)
+    assert np.array_equal(got, ref)
+    # random field with many exact ties, threshold strictness, border points
+    rng = np.random.RandomState(0)
+    heat = (rng.randint(0, 40, (H, W)) / 40.0).astype(np.float32)
+    heat[0, :] = 1.0
+    heat[:, W - 1] = 1.0
+    got, ref = _nms_both(ctx, heat)
+    assert np.array_equal(got, ref)
+    ctx.close()
+    # uncapped, other radius/border
+    ctx = make_ctx(vgg_weights_path, net_height=120, net_width=392, max_keypoints=4000, dist_thresh=2, border_remove=0)
+    heat = rng.rand(H, W).astype(np.float32)
+    got, ref = _nms_both(ctx, heat)
+    assert np.array_equal(got, ref) and len(ref) > 1000
+    ctx.close()
+
+
+def test_sample_descriptors(ctx_squeeze, squeeze_plan, sample_images):
+    x = (sample_images[0][:360, :1176].astype(np.float32) / 255)[None, None]
+    det, desc = net.forward(squeeze_plan, x)
+    xy = fe.nms(fe.heatmap(det[0]))
+    # add the extreme in-bounds pixels (nn.cpp:385-386 asserts are compiled out)
+    xy = np.concatenate([xy[:300], np.array([[0, 0], [1175, 359], [1175, 0], [0, 359], [4, 4]], np.int32)])
+    got = ctx_squeeze.sample_descriptors(np.ascontiguousarray(desc[0].transpose(1, 2, 0)), xy)
+    ref = fe.sample_descriptors(desc[0], xy, 360, 1176)
+    assert np.abs(got - ref).max() <= 1e-6
+    assert len(ctx_squeeze.sample_descriptors(np.ascontiguousarray(desc[0].transpose(1, 2, 0)), xy[:0])) == 0
