@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- stereo frames/s of the MI355X-native SuperPoint stereo-VO front end.
+
+One "step" = one stereoCallback of the reference (visual_odometry_node.cpp:150-262):
+addStereoImagePair (preprocess + VGG SuperPoint fp32 + post-processing of BOTH images),
+matchDescriptors x2, solveStereoOdometry -> one 6-DoF relative pose, driven through the
+C++ host mirror of FeatureFrontEnd over the C ABI (include/spvo.h).
+
+Workload (BASELINE.json configs[1]): VGG SuperPoint fp32 (seeded synthetic weights with the
+reference's exact 1 300 865-parameter layout: the real ones are missing from the reference
+tree), 1241x376 KITTI-sized synthetic stereo pairs, network size 360x1176 (the reference's
+largest), reference launch-file parameters.  Input images are resident in HBM before the timed
+region.  N GPUs = N independent stereo streams, one rank per GPU (weak scaling); the only
+collective is the per-step all-gather of the 7-double pose over RCCL.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "superpoint-stereo-visual-odometry_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+NET_H, NET_W = 360, 1176
+SEQ_LEN = 8
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def cpu_baseline(frames, P_l, P_r, plan):
+    """The oracle ("port") timed on the host cores: a bounded sample of the same workload."""
+    import torch
+
+    import oracle  # noqa: F401
+    from oracle import frontend as fe, odometry as od
+    st = od.FrontEndState()
+    times = []
+    for k in range(3):                                     # frame 0 = warm-up / first-frame path
+        L, R = frames[k]
+        t0 = time.time()
+        rl = fe.detect(plan, L, P_l, NET_H, NET_W)
+        rr = fe.detect(plan, R, P_r, NET_H, NET_W)
+        od.add_features(st, rl["xy"], rl["descriptors"], rr["xy"], rr["descriptors"], rl["P"], rr["P"])
+        od.match_descriptors(st, 0)
+        if k:
+            od.match_descriptors(st, 1)
+            od.solve_stereo_odometry(st)
+            times.append(time.time() - t0)
+    return {"value": round(1.0 / float(np.mean(times)), 4), "unit": "stereo frames/s", "cores": int(torch.get_num_threads()),
+            "kind": "port", "sample": f"{len(times)} stereo frames (after 1 warm-up) through oracle/: torch-CPU fp32 conv "
+            f"on {torch.get_num_threads()} threads + numpy post-processing, matching, RANSAC, LM"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["SPVO_DEVICE"] = str(local_rank)
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from spvo import host, synth, weights
+
+    plan = weights.vgg_plan(seed=0)
+    tmp = tempfile.mkdtemp(prefix=f"spvo_bench_{rank}_")
+    os.makedirs(os.path.join(tmp, "laptop"))
+    weights.save(plan, os.path.join(tmp, "laptop", weights.engine_name("superpoint_pretrained", 2, NET_H, NET_W, "FP32")))
+
+    # every rank renders its own stream (different seed = different ego-motion); sample-image texture
+    tex = os.path.join(ROOT, "tests", "golden", "images", "0000000000.png")
+    frames, poses, P_l, P_r = synth.stereo_sequence(SEQ_LEN, tex, seed=rank)
+    d_frames = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
+    rows, cols = frames[0][0].shape
+    order = list(range(SEQ_LEN)) + list(range(SEQ_LEN - 2, 0, -1))       # ping-pong: every step is a real motion
+
+    fe = host.FrontEnd(tmp, prefix="superpoint_pretrained", selector="KNN", cross_check=True, batch=2,
+                       height=NET_H, width=NET_W, conf_thresh=0.015, dist_thresh=4, border_remove=4,
+                       stereo_threshold=2.0, min_disparity=0.25, refinement_degree=4)
+    if not fe.engine_loaded:
+        raise SystemExit("engine load failed: " + fe.last_error)
+    ctx = fe.context()
+    pose_buf = torch.zeros(7, dtype=torch.float64, device="cuda")
+    gathered = [torch.zeros(7, dtype=torch.float64, device="cuda") for _ in range(world)] if world > 1 else None
+
+    def step(i):
+        dl, dr = d_frames[order[i % len(order)]]
+        res = fe.step_device(dl.data_ptr(), dr.data_ptr(), rows, cols, dl.stride(0), P_l, P_r)
+        if world > 1:
+            if res is not None:
+                pose_buf.copy_(torch.from_numpy(np.concatenate(res)))
+            dist.all_gather(gathered, pose_buf)                            # RCCL: 56 B per rank
+        return res
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    if not args.no_profile:
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = {}
+    if not args.no_profile:
+        prof = ctx.profile()
+        ctx.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_frames = args.steps * world
+        out = {
+            "metric": "stereo frames/sec (1241x376 KITTI)", "value": round(total_frames / elapsed, 2), "unit": "stereo frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SuperPoint VGG fp32 (seeded synthetic weights, 1300865 params), 1241x376 stereo pairs, "
+                                   "net 360x1176, 1000 kp cap, BF+KNN 0.8, P3P-style RANSAC 500 it, LM refinement degree 4; "
+                                   "one stereo stream per GPU, RCCL all-gather of poses",
+                       "net_size": [NET_H, NET_W], "input_size": [rows, cols], "streams": world},
+        }
+        dom = prof.get("conv:1")                                           # conv1b: 43 % of all CNN FLOPs
+        if dom and dom["calls"]:
+            avg_ms = dom["total_ms"] / dom["calls"]
+            achieved = dom["flops"] / (avg_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel<3,8,2,1,pool,relu> (conv1b 64->64 @360x1176, 2 images)",
+                               "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "avg_kernel_ms": round(avg_ms, 5), "flops_per_launch": dom["flops"]}
+            conv_ms = sum(v["total_ms"] for k, v in prof.items() if k.startswith("conv:")) / max(dom["calls"], 1)
+            conv_fl = sum(v["flops"] for k, v in prof.items() if k.startswith("conv:"))
+            out["stages_ms"] = {k: round(v["total_ms"] / max(v["calls"], 1), 4) for k, v in prof.items()
+                                if not k.startswith(("conv:", "pool:", "l2norm:"))}
+            out["stages_ms"]["conv_stack_sum"] = round(conv_ms, 4)
+            out["conv_stack_tflops"] = round(conv_fl / (conv_ms * 1e-3) / 1e12, 2)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(frames, P_l, P_r, plan)
+        print(json.dumps(out), flush=True)
+    fe.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

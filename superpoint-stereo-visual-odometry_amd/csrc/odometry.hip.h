@@ -519,12 +519,12 @@ __device__ __forceinline__ void cost32(const double *P /*3x4*/, const double *q,
     J[3] = du[0]; J[4] = du[1]; J[5] = du[2];
     J[9] = dv[0]; J[10] = dv[1]; J[11] = dv[2];
   } else {  // d/dt R^T (X - t) = -R^T  ->  -(d . R^T) = -(R d)
-    J[3] = -(R[0] * du[0] + R[3] * du[1] + R[6] * du[2]);
-    J[4] = -(R[1] * du[0] + R[4] * du[1] + R[7] * du[2]);
-    J[5] = -(R[2] * du[0] + R[5] * du[1] + R[8] * du[2]);
-    J[9] = -(R[0] * dv[0] + R[3] * dv[1] + R[6] * dv[2]);
-    J[10] = -(R[1] * dv[0] + R[4] * dv[1] + R[7] * dv[2]);
-    J[11] = -(R[2] * dv[0] + R[5] * dv[1] + R[8] * dv[2]);
+    J[3] = -(R[0] * du[0] + R[1] * du[1] + R[2] * du[2]);
+    J[4] = -(R[3] * du[0] + R[4] * du[1] + R[5] * du[2]);
+    J[5] = -(R[6] * du[0] + R[7] * du[1] + R[8] * du[2]);
+    J[9] = -(R[0] * dv[0] + R[1] * dv[1] + R[2] * dv[2]);
+    J[10] = -(R[3] * dv[0] + R[4] * dv[1] + R[5] * dv[2]);
+    J[11] = -(R[6] * dv[0] + R[7] * dv[1] + R[8] * dv[2]);
   }
 }
 

@@ -1,0 +1,475 @@
+// feature_detection.cpp -- host side of the front end: the bookkeeping the reference does in
+//   src/odml_visual_odometry/src/feature_detection_base.cpp            ("base.cpp")
+//   src/odml_visual_odometry/src/feature_detection_neural_network.cpp  ("nn.cpp")
+// with every numeric step forwarded to the C ABI (include/spvo.h).  Error convention as in
+// the reference: log and return, never throw (nn.cpp:53-55, 96-100, 490-491).
+#include "feature_detection.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+// ------------------------------------------------------------------------- tf2lite
+namespace tf2lite {
+double Vector3::length() const { return std::sqrt(x * x + y * y + z * z); }
+
+static void rotate(const Quaternion &q, const double v[3], double out[3]) {
+  // unit quaternion rotation, same polynomial as Eigen's toRotationMatrix
+  const double x = q.x, y = q.y, z = q.z, w = q.w;
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  out[0] = (1 - (tyy + tzz)) * v[0] + (txy - twz) * v[1] + (txz + twy) * v[2];
+  out[1] = (txy + twz) * v[0] + (1 - (txx + tzz)) * v[1] + (tyz - twx) * v[2];
+  out[2] = (txz - twy) * v[0] + (tyz + twx) * v[1] + (1 - (txx + tyy)) * v[2];
+}
+
+Transform Transform::inverse() const {
+  Transform r;
+  const double n = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  r.q = Quaternion{-q.x / n, -q.y / n, -q.z / n, q.w / n};
+  const double v[3] = {t.x, t.y, t.z};
+  double o[3];
+  rotate(r.q, v, o);
+  r.t = Vector3{-o[0], -o[1], -o[2]};
+  return r;
+}
+
+Transform Transform::operator*(const Transform &o) const {
+  Transform r;
+  r.q.x = q.w * o.q.x + q.x * o.q.w + q.y * o.q.z - q.z * o.q.y;
+  r.q.y = q.w * o.q.y - q.x * o.q.z + q.y * o.q.w + q.z * o.q.x;
+  r.q.z = q.w * o.q.z + q.x * o.q.y - q.y * o.q.x + q.z * o.q.w;
+  r.q.w = q.w * o.q.w - q.x * o.q.x - q.y * o.q.y - q.z * o.q.z;
+  const double v[3] = {o.t.x, o.t.y, o.t.z};
+  double rv[3];
+  rotate(q, v, rv);
+  r.t = Vector3{rv[0] + t.x, rv[1] + t.y, rv[2] + t.z};
+  return r;
+}
+}  // namespace tf2lite
+
+// ------------------------------------------------------------------------- logging
+void FeatureFrontEnd::logError(const std::string &msg) {
+  last_error_ = msg;
+  std::fprintf(stderr, "[ERROR] %s\n", msg.c_str());  // ROS_ERROR stand-in
+}
+void FeatureFrontEnd::logInfo(const std::string &msg) const {
+  if (verbose_) std::fprintf(stderr, "[ INFO] %s\n", msg.c_str());
+}
+
+// ------------------------------------------------------------------------- base.cpp:10-33
+void FeatureFrontEnd::initMatcher() {
+  if (matcher_type_ == MatcherType::BF) {
+    if (descriptor_type_ != DescriptorType::SIFT && descriptor_type_ != DescriptorType::SuperPoint) {
+      // NORM_HAMMING descriptors belong to the classic CPU baseline (classic.cpp), not to this path
+      logError("[initMatcher] only NORM_L2 descriptors (SuperPoint/SIFT) are implemented on the GPU path");
+      return;
+    }
+    // cv::BFMatcher::create(norm_type, cross_check_ & (selector_type_ != KNN))   base.cpp:27-28
+    matcher_cross_check_ = cross_check_ && (selector_type_ != SelectorType::KNN);
+    matcher_ready_ = true;
+  } else {
+    logError("[initMatcher] FLANN matcher is not implemented on the GPU path (base.cpp:29-32); use BF");
+  }
+}
+
+// ------------------------------------------------------------------------- base.cpp:35-66
+void FeatureFrontEnd::clearLagecyData() {
+  images_dq.clear();
+  keypoints_dq.clear();
+  descriptors_dq.clear();
+  slots_dq_.clear();
+  for (auto &m : cv_DMatches_list) m.clear();
+  projection_matrix_l_.release();
+  projection_matrix_r_.release();
+  for (int k = 0; k < 3; ++k) r_vec_pred[k] = t_vec_pred[k] = 0;
+  frame_count = 0;
+  for (auto &m : maps_of_indices) m.clear();
+  prev_left_points_3d_inited = false;
+  inliers_postmatching.clear();
+  inliers_pnp.clear();
+  prev_left_points_3d.clear();
+  map_from_prev_left_matched_to_prev_valid_index.clear();
+  map_from_curr_valid_to_prev_left_matched_index.clear();
+  map_from_curr_left_matched_to_curr_valid_index.clear();
+}
+
+// ------------------------------------------------------------------------- base.cpp:434-500
+void FeatureFrontEnd::matchDescriptors(const MatchType match_type) {
+  if (!ctx_ || !matcher_ready_) {
+    logError("matchDescriptors: front end not initialised");
+    return;
+  }
+  const int p0 = match_type_to_positions[match_type].first, p1 = match_type_to_positions[match_type].second;
+  const int n_dq = (int)keypoints_dq.size();
+  if (n_dq + p0 < 0 || n_dq + p1 < 0) {
+    logError("matchDescriptors: not enough frames for " + MatchType_str[match_type]);
+    return;
+  }
+  const std::vector<cv::KeyPoint> &keypoints0 = keypoints_dq.end()[p0];
+  const int slot0 = slots_dq_.end()[p0], slot1 = slots_dq_.end()[p1];
+  if (descriptors_dq.end()[p0].rows < 10) std::fprintf(stderr, "[ WARN] descriptors0.rows == %d < 10\n", descriptors_dq.end()[p0].rows);
+  if (descriptors_dq.end()[p1].rows < 10) std::fprintf(stderr, "[ WARN] descriptors1.rows == %d < 10\n", descriptors_dq.end()[p1].rows);
+
+  std::vector<cv::DMatch> &cv_Dmatches = cv_DMatches_list[match_type];
+  cv_Dmatches.clear();
+  const int n0 = (int)keypoints0.size();
+  std::vector<int32_t> train(std::max(n0, 1), -1);
+  std::vector<float> dist(std::max(n0, 1), 0.f);
+  const int rc = spvo_match_slots(ctx_, slot0, slot1, selector_type_ == SelectorType::KNN ? SPVO_SELECT_KNN : SPVO_SELECT_NN,
+                                  matcher_cross_check_ ? 1 : 0, knn_threshold_, train.data(), dist.data());
+  if (rc != SPVO_OK) {
+    logError(std::string("spvo_match_slots: ") + spvo_last_error(ctx_));
+    return;
+  }
+  for (int i = 0; i < n0; ++i)
+    if (train[i] >= 0) {
+      cv::DMatch m;
+      m.queryIdx = i; m.trainIdx = train[i]; m.imgIdx = 0; m.distance = dist[i];
+      cv_Dmatches.push_back(m);
+    }
+
+  if (match_type == MatchType::CURR_LEFT_CURR_RIGHT)  // base.cpp:475-481
+    maps_of_indices[MatchType::PREV_LEFT_PREV_RIGHT] = maps_of_indices[MatchType::CURR_LEFT_CURR_RIGHT];
+
+  std::vector<int> &map = maps_of_indices.at(match_type);
+  map.clear();
+  map.resize(keypoints0.size(), -1);
+  for (const cv::DMatch &m : cv_Dmatches) map.at(m.queryIdx) = m.trainIdx;
+
+  if (verbose_) logInfo(std::to_string(cv_Dmatches.size()) + " matches for " + MatchType_str[match_type]);
+  if (cv_Dmatches.size() < 10) std::fprintf(stderr, "[ WARN] %zu matches < 10 for %s\n", cv_Dmatches.size(), MatchType_str[match_type].c_str());
+}
+
+// ------------------------------------------------------------------------- base.cpp:125-399
+void FeatureFrontEnd::solveStereoOdometry(tf2::Transform &cam0_curr_T_cam0_prev) {
+  if (!ctx_ || keypoints_dq.size() < 4) {
+    logError("solveStereoOdometry needs two stereo frames");
+    return;
+  }
+  const std::vector<cv::DMatch> &stereo = cv_DMatches_list[CURR_LEFT_CURR_RIGHT];
+  const size_t num_curr_stereo = stereo.size();
+  std::vector<float> kp_cl, kp_cr, kp_pl, kp_pr;  // n x 2 each
+  kp_cl.reserve(2 * num_curr_stereo); kp_cr.reserve(2 * num_curr_stereo);
+  kp_pl.reserve(2 * num_curr_stereo); kp_pr.reserve(2 * num_curr_stereo);
+  inliers_postmatching.clear();
+  inliers_postmatching.reserve(num_curr_stereo);
+
+  if (refinement_degree_ >= 3) {
+    map_from_curr_left_matched_to_curr_valid_index.clear();
+    map_from_curr_left_matched_to_curr_valid_index.resize(keypoints_dq.end()[CURR_LEFT].size(), -1);
+    map_from_curr_valid_to_prev_left_matched_index.clear();
+    map_from_curr_valid_to_prev_left_matched_index.reserve(num_curr_stereo);
+  }
+  const auto &map_temporal = maps_of_indices[CURR_LEFT_PREV_LEFT];
+  const auto &map_prev = maps_of_indices[PREV_LEFT_PREV_RIGHT];
+  // the reference indexes with .at(): out-of-range would throw there; here it is reported
+  for (const auto &m : stereo) {
+    const int i_cl = m.queryIdx;
+    if (i_cl >= (int)map_temporal.size()) { logError("maps_of_indices out of range"); return; }
+    if (map_temporal[i_cl] == -1) continue;
+    const cv::Point2f &a = keypoints_dq.end()[CURR_LEFT][i_cl].pt;
+    const cv::Point2f &b = keypoints_dq.end()[CURR_RIGHT][m.trainIdx].pt;
+    if (std::abs(a.y - b.y) > stereo_threshold_ || std::abs(a.x - b.x) < min_disparity_) continue;  // base.cpp:169-172
+    const int i_pl = map_temporal[i_cl];
+    if (i_pl >= (int)map_prev.size()) { logError("maps_of_indices out of range"); return; }
+    if (map_prev[i_pl] == -1) continue;
+    const cv::Point2f &c = keypoints_dq.end()[PREV_LEFT][i_pl].pt;
+    const cv::Point2f &d = keypoints_dq.end()[PREV_RIGHT][map_prev[i_pl]].pt;
+    kp_cl.push_back(a.x); kp_cl.push_back(a.y);
+    kp_cr.push_back(b.x); kp_cr.push_back(b.y);
+    kp_pl.push_back(c.x); kp_pl.push_back(c.y);
+    kp_pr.push_back(d.x); kp_pr.push_back(d.y);
+    inliers_postmatching.push_back(i_cl);
+    if (refinement_degree_ >= 3) {
+      map_from_curr_left_matched_to_curr_valid_index[i_cl] = (int)(kp_cl.size() / 2) - 1;
+      map_from_curr_valid_to_prev_left_matched_index.push_back(i_pl);
+    }
+  }
+  const int n = (int)(kp_cl.size() / 2);
+
+  // triangulation (base.cpp:211-223)
+  std::vector<float> pts3d((size_t)std::max(n, 1) * 3, 0.f);
+  const double *Pl = projection_matrix_l_.ptr<double>(0), *Pr = projection_matrix_r_.ptr<double>(0);
+  if (spvo_triangulate(ctx_, Pl, Pr, kp_cl.data(), kp_cr.data(), n, pts3d.data()) != SPVO_OK) {
+    logError(std::string("spvo_triangulate: ") + spvo_last_error(ctx_));
+    return;
+  }
+
+  // PnP (base.cpp:227-239)
+  const double K[9] = {Pl[0], Pl[1], Pl[2], Pl[4], Pl[5], Pl[6], Pl[8], Pl[9], Pl[10]};
+  double r_vec[3] = {r_vec_pred[0], r_vec_pred[1], r_vec_pred[2]};
+  double t_vec[3] = {t_vec_pred[0], t_vec_pred[1], t_vec_pred[2]};
+  inliers_pnp.assign(std::max(n, 1), 0);
+  int n_inl = 0, pnp_result = 0;
+  spvo_ransac_opts ro = {500, 2.0, 0.999, ransac_seed};
+  if (spvo_pnp_ransac(ctx_, K, pts3d.data(), kp_pl.data(), n, &ro, r_vec, t_vec, inliers_pnp.data(), &n_inl, &pnp_result) != SPVO_OK) {
+    logError(std::string("spvo_pnp_ransac: ") + spvo_last_error(ctx_));
+    return;
+  }
+  inliers_pnp.resize(n_inl);
+
+  const double acceleration = std::sqrt((t_vec[0] - t_vec_pred[0]) * (t_vec[0] - t_vec_pred[0]) + (t_vec[1] - t_vec_pred[1]) * (t_vec[1] - t_vec_pred[1]) +
+                                        (t_vec[2] - t_vec_pred[2]) * (t_vec[2] - t_vec_pred[2])) / TIME_INTERVAL;
+  bool do_optmz = false;
+  if (!pnp_result) {
+    logError("solvePnPRansac failed! Identity transformation will be applied.");
+    for (int k = 0; k < 3; ++k) { r_vec[k] = r_vec_pred[k]; t_vec[k] = t_vec_pred[k]; }
+  } else if (frame_count > IGNORE_FRAME_COUNT && acceleration > MAX_ACCELERATION) {
+    logError("solvePnPRansac succeeded but acceleration is abnormally large!");
+    for (int k = 0; k < 3; ++k) { r_vec[k] = r_vec_pred[k]; t_vec[k] = t_vec_pred[k]; }
+  } else {
+    for (int k = 0; k < 3; ++k) { r_vec_pred[k] = r_vec[k]; t_vec_pred[k] = t_vec[k]; }
+    do_optmz = true;
+  }
+
+  // base.cpp:274-280: AngleAxisd(|r|, r.normalized()) -> quaternion
+  const double angle = std::sqrt(r_vec[0] * r_vec[0] + r_vec[1] * r_vec[1] + r_vec[2] * r_vec[2]);
+  double axis[3] = {r_vec[0], r_vec[1], r_vec[2]};
+  if (angle > 0) for (int k = 0; k < 3; ++k) axis[k] /= angle;
+  const double s = std::sin(angle / 2);
+  const double q_init[4] = {axis[0] * s, axis[1] * s, axis[2] * s, std::cos(angle / 2)};
+  double q_opt[4] = {q_init[0], q_init[1], q_init[2], q_init[3]};
+  double t_opt[3] = {t_vec[0], t_vec[1], t_vec[2]};
+
+  if (do_optmz && refinement_degree_ > 0) {
+    std::vector<spvo_obs> obs;
+    obs.reserve(4 * inliers_pnp.size());
+    auto push = [&](const float *X, const float *uv, int cam, int inv) {
+      spvo_obs o;
+      o.X[0] = X[0]; o.X[1] = X[1]; o.X[2] = X[2];
+      o.uv[0] = uv[0]; o.uv[1] = uv[1];
+      o.cam = cam; o.inverse = inv;
+      obs.push_back(o);
+    };
+    for (const int vi : inliers_pnp) {  // block order of base.cpp:291-356
+      push(&pts3d[3 * vi], &kp_pl[2 * vi], 0, 0);
+      if (refinement_degree_ <= 1) continue;
+      push(&pts3d[3 * vi], &kp_pr[2 * vi], 1, 0);
+      if (refinement_degree_ <= 2) continue;
+      if (!prev_left_points_3d_inited) continue;
+      const int matched_prev = map_from_curr_valid_to_prev_left_matched_index.at(vi);
+      if (matched_prev >= (int)map_from_prev_left_matched_to_prev_valid_index.size()) continue;
+      const int valid_prev = map_from_prev_left_matched_to_prev_valid_index[matched_prev];
+      if (valid_prev == -1) continue;
+      push(&prev_left_points_3d[3 * valid_prev], &kp_cl[2 * vi], 0, 1);
+      if (refinement_degree_ <= 3) continue;
+      push(&prev_left_points_3d[3 * valid_prev], &kp_cr[2 * vi], 1, 1);
+    }
+    spvo_refine_opts fo = {40, 1.0};
+    spvo_refine_summary summary;
+    if (spvo_pnp_refine(ctx_, Pl, Pr, obs.data(), (int)obs.size(), &fo, q_opt, t_opt, &summary) != SPVO_OK) {
+      logError(std::string("spvo_pnp_refine: ") + spvo_last_error(ctx_));
+      summary.usable = 0;
+      summary.converged = 0;
+    }
+    if (!summary.usable || !summary.converged) {  // base.cpp:366-374
+      logError("summary.IsSolutionUsable() == false or NOT CONVERGENT");
+      for (int k = 0; k < 4; ++k) q_opt[k] = q_init[k];
+      for (int k = 0; k < 3; ++k) t_opt[k] = t_vec[k];
+    }
+  }
+
+  tf2::Transform cam0_prev_T_cam0_curr;
+  cam0_prev_T_cam0_curr.setRotation(tf2::Quaternion{q_opt[0], q_opt[1], q_opt[2], q_opt[3]});
+  cam0_prev_T_cam0_curr.setOrigin(tf2::Vector3{t_opt[0], t_opt[1], t_opt[2]});
+  cam0_curr_T_cam0_prev = cam0_prev_T_cam0_curr.inverse();
+
+  if (refinement_degree_ >= 3) {  // base.cpp:388-394
+    map_from_prev_left_matched_to_prev_valid_index = map_from_curr_left_matched_to_curr_valid_index;
+    prev_left_points_3d.assign(pts3d.begin(), pts3d.begin() + (size_t)n * 3);
+    prev_left_points_3d_inited = true;
+  }
+  ++frame_count;
+}
+
+cv::Mat FeatureFrontEnd::visualizeMatches(const MatchType match_type) {
+  if (images_dq.size() < 4) return cv::Mat();
+  return images_dq.end()[match_type_to_positions[match_type].second].clone();
+}
+
+cv::Mat FeatureFrontEnd::visualizeInliers(const ImagePosition image_position) {
+  if (image_position != CURR_LEFT) logError("inlier visualization for " + ImagePosition_str.at(image_position) + " is not implemented yet");
+  if (images_dq.empty()) return cv::Mat();
+  return images_dq.end()[image_position].clone();
+}
+
+// ------------------------------------------------------------------------- SuperPoint front end
+static std::string g_models_dir;
+
+void SuperPointFeatureFrontEnd::setModelsDir(const std::string &dir) { g_models_dir = dir; }
+
+SuperPointFeatureFrontEnd::SuperPointFeatureFrontEnd()
+    : SuperPointFeatureFrontEnd(MatcherType::BF, SelectorType::NN, true, "superpoint_pretrained", 2, "laptop", TRT_FP32, 120, 392,
+                                0.015f, 4, 12, 4, 2.0f, 1.0f, 4, true) {}
+
+SuperPointFeatureFrontEnd::SuperPointFeatureFrontEnd(const MatcherType matcher_type, const SelectorType selector_type, const bool cross_check,
+                                                     const std::string model_name_prefix, const int model_batch_size, const std::string machine_name,
+                                                     const TensorRtPrecision trt_precision, const int input_height, const int input_width,
+                                                     const float conf_thresh, const int dist_thresh, const int num_threads, const int border_remove,
+                                                     const float stereo_threshold, const float min_disparity, const int refinement_degree,
+                                                     const bool verbose)
+    : FeatureFrontEnd(DetectorType::SuperPoint, DescriptorType::SuperPoint, matcher_type, selector_type, cross_check, stereo_threshold, min_disparity,
+                      refinement_degree, verbose, input_height, input_width),
+      model_name_prefix_(model_name_prefix), model_batch_size_(model_batch_size), machine_name_(machine_name), trt_precision_(trt_precision),
+      conf_thresh_(conf_thresh), dist_thresh_(dist_thresh), border_remove_(border_remove), num_threads_(num_threads) {
+  initMatcher();
+  loadEngine();
+}
+
+SuperPointFeatureFrontEnd::~SuperPointFeatureFrontEnd() {
+  if (ctx_) spvo_destroy(ctx_);
+  ctx_ = nullptr;
+}
+
+void SuperPointFeatureFrontEnd::loadEngine() {
+  spvo_config cfg;
+  spvo_default_config(&cfg);
+  if (const char *dev = std::getenv("SPVO_DEVICE")) cfg.device = std::atoi(dev);
+  cfg.net_height = input_height_;
+  cfg.net_width = input_width_;
+  // model_batch_size_ only changes how the reference batches its TensorRT calls (hpp:342-344);
+  // both images always go through the network together here.
+  cfg.max_batch = 2;
+  cfg.conf_thresh = conf_thresh_;
+  cfg.dist_thresh = dist_thresh_;
+  cfg.border_remove = border_remove_;
+  cfg.max_keypoints = max_keypoints_;
+  if (const char *bc = std::getenv("SPVO_BUG_COMPAT_P")) cfg.bug_compat_p = std::atoi(bc);
+  if (model_batch_size_ != 1 && model_batch_size_ != 2) {
+    logError("Wrong batch size (" + std::to_string(model_batch_size_) + ")");  // nn.cpp:490
+    return;
+  }
+  if (trt_precision_ != TRT_FP32) {
+    logError("only FP32 engines are built so far");
+    return;
+  }
+  if (spvo_create(&cfg, &ctx_) != SPVO_OK) {
+    logError(std::string("spvo_create: ") + spvo_last_error(nullptr));
+    ctx_ = nullptr;
+    return;
+  }
+  std::string dir = g_models_dir;
+  if (dir.empty())
+    if (const char *e = std::getenv("SPVO_MODELS_DIR")) dir = e;
+  const std::string model_name_full = dir + "/" + machine_name_ + "/" + model_name_prefix_ + "_" + std::to_string(model_batch_size_) + "_" +
+                                      std::to_string(input_height_) + "_" + std::to_string(input_width_) + "_" +
+                                      trt_precision_enum2string.at(trt_precision_) + ".spvw";
+  if (spvo_load_weights(ctx_, model_name_full.c_str()) != SPVO_OK) {
+    logError(spvo_last_error(ctx_));  // "no such engine file: ..." (nn.cpp:53-55): object stays half-initialised
+    return;
+  }
+  logInfo("engine file `" + model_name_full + "` loaded");
+  for (int i = 0; i < 2; ++i) {
+    xy_buf_[i].assign((size_t)max_keypoints_ * 2, 0.f);
+    desc_buf_[i].assign((size_t)max_keypoints_ * output_desc_channel_, 0.f);
+  }
+  engine_loaded_ = true;
+}
+
+void SuperPointFeatureFrontEnd::addStereoImagePair(cv::Mat &img_l, cv::Mat &img_r, const cv::Mat &projection_matrix_l,
+                                                   const cv::Mat &projection_matrix_r) {
+  if (!engine_loaded_) {
+    logError("addStereoImagePair: no engine loaded");
+    return;
+  }
+  if (img_l.depth != cvlite::CV_8U || img_r.depth != cvlite::CV_8U || img_l.rows != img_r.rows || img_l.cols != img_r.cols ||
+      img_l.step != img_r.step || projection_matrix_l.depth != cvlite::CV_64F || projection_matrix_r.depth != cvlite::CV_64F ||
+      projection_matrix_l.rows != 3 || projection_matrix_l.cols != 4) {
+    logError("addStereoImagePair: expected two equal-sized CV_8UC1 images and 3x4 CV_64F projection matrices (node.cpp:91,163-168)");
+    return;
+  }
+  projection_matrix_l_ = projection_matrix_l.clone();  // nn.cpp:465-466
+  projection_matrix_r_ = projection_matrix_r.clone();
+
+  int slot_l, slot_r;
+  pickSlots(&slot_l, &slot_r);
+  spvo_features fl{0, xy_buf_[0].data(), desc_buf_[0].data()}, fr{0, xy_buf_[1].data(), desc_buf_[1].data()};
+  cv::Mat res_l(input_height_, input_width_, cvlite::CV_8U), res_r(input_height_, input_width_, cvlite::CV_8U);
+  const int rc = spvo_detect(ctx_, img_l.data, img_r.data, img_l.rows, img_l.cols, img_l.step, projection_matrix_l_.ptr<double>(0),
+                             projection_matrix_r_.ptr<double>(0), slot_l, slot_r, &fl, &fr, res_l.data, res_r.data);
+  if (rc != SPVO_OK) {
+    logError(std::string("spvo_detect: ") + spvo_last_error(ctx_));
+    return;
+  }
+  // the reference mutates the caller's images in place (crop + resize + convertTo float,
+  // base.cpp:89,105,115; nn.cpp:159); hand back the resized image, keep u8
+  img_l = res_l;
+  img_r = res_r;
+  const spvo_features *f[2] = {&fl, &fr};
+  const cv::Mat *res[2] = {&res_l, &res_r};
+  const int slots[2] = {slot_l, slot_r};
+  pushFeatures(f, res, slots, true);
+}
+
+void SuperPointFeatureFrontEnd::addStereoImagePairDevice(const void *d_img_l, const void *d_img_r, int rows, int cols, size_t stride,
+                                                         const cv::Mat &projection_matrix_l, const cv::Mat &projection_matrix_r,
+                                                         bool host_descriptors) {
+  if (!engine_loaded_) {
+    logError("addStereoImagePairDevice: no engine loaded");
+    return;
+  }
+  if (projection_matrix_l.depth != cvlite::CV_64F || projection_matrix_r.depth != cvlite::CV_64F || projection_matrix_l.rows != 3 ||
+      projection_matrix_l.cols != 4) {
+    logError("addStereoImagePairDevice: expected 3x4 CV_64F projection matrices");
+    return;
+  }
+  projection_matrix_l_ = projection_matrix_l.clone();
+  projection_matrix_r_ = projection_matrix_r.clone();
+  int slot_l, slot_r;
+  pickSlots(&slot_l, &slot_r);
+  spvo_features fl{0, xy_buf_[0].data(), host_descriptors ? desc_buf_[0].data() : nullptr};
+  spvo_features fr{0, xy_buf_[1].data(), host_descriptors ? desc_buf_[1].data() : nullptr};
+  const int rc = spvo_detect_dev(ctx_, d_img_l, d_img_r, rows, cols, stride, projection_matrix_l_.ptr<double>(0),
+                                 projection_matrix_r_.ptr<double>(0), slot_l, slot_r, &fl, &fr);
+  if (rc != SPVO_OK) {
+    logError(std::string("spvo_detect_dev: ") + spvo_last_error(ctx_));
+    return;
+  }
+  const spvo_features *f[2] = {&fl, &fr};
+  const cv::Mat empty;
+  const cv::Mat *res[2] = {&empty, &empty};
+  const int slots[2] = {slot_l, slot_r};
+  pushFeatures(f, res, slots, host_descriptors);
+}
+
+void SuperPointFeatureFrontEnd::pickSlots(int *slot_l, int *slot_r) const {
+  // device slots: the two oldest entries of the ring are recycled
+  *slot_l = 0;
+  if (!slots_dq_.empty()) {
+    const bool used01 = std::find(slots_dq_.end() - std::min<size_t>(2, slots_dq_.size()), slots_dq_.end(), 0) != slots_dq_.end();
+    *slot_l = used01 ? 2 : 0;
+  }
+  *slot_r = *slot_l + 1;
+}
+
+void SuperPointFeatureFrontEnd::pushFeatures(const spvo_features *f[2], const cv::Mat *images[2], const int slots[2], bool host_descriptors) {
+  for (int i = 0; i < 2; ++i) {
+    images_dq.push_back(images[i]->empty() ? cv::Mat() : images[i]->clone());  // nn.cpp:154
+    std::vector<cv::KeyPoint> kps;
+    kps.reserve(f[i]->n);
+    for (int k = 0; k < f[i]->n; ++k) kps.emplace_back(cv::Point2f{f[i]->xy[2 * k], f[i]->xy[2 * k + 1]}, 1.f);  // nn.cpp:243
+    keypoints_dq.push_back(std::move(kps));
+    cv::Mat d;
+    if (host_descriptors) {
+      d.create(f[i]->n, output_desc_channel_, cvlite::CV_32F);
+      if (f[i]->n) std::memcpy(d.data, f[i]->desc, (size_t)f[i]->n * output_desc_channel_ * sizeof(float));
+    } else {
+      d.rows = f[i]->n;  // header only: the descriptors live in the device slot
+      d.cols = 0;
+      d.depth = cvlite::CV_32F;
+    }
+    descriptors_dq.push_back(d);
+    slots_dq_.push_back(slots[i]);
+  }
+  if (verbose_) logInfo(std::to_string(keypoints_dq.end()[-2].size()) + ", " + std::to_string(keypoints_dq.end()[-1].size()) + " keypoints for img_l and img_r");
+  while (images_dq.size() > 4) {  // nn.cpp:494-498
+    images_dq.pop_front();
+    keypoints_dq.pop_front();
+    descriptors_dq.pop_front();
+    slots_dq_.pop_front();
+  }
+}

@@ -1,0 +1,270 @@
+// feature_detection.hpp -- host-side mirror of the reference's front-end interface
+// (reference: src/odml_visual_odometry/include/odml_visual_odometry/feature_detection.hpp).
+//
+// Same enums, class names, constructor argument order, public methods and public
+// data members as the reference, so visual_odometry_node.cpp's call sequence
+// (node.cpp:175-244, 316, 396-403) reads unchanged.  What differs:
+//   * NvInfer.h / cuda_runtime_api.h / Eigen thread pool members are gone; every heavy call
+//     goes to the C ABI in include/spvo.h (hand-written gfx950 kernels);
+//   * where OpenCV / tf2 / ROS headers are absent (this build image), the few types
+//     the interface mentions are the minimal PODs below (`cvlite`, `tf2lite`), with the same
+//     field names the node touches; INTEGRATION.md shows the adapter for a real ROS build.
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <deque>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/spvo.h"
+
+// --------------------------------------------------------------------------- POD stand-ins
+namespace cvlite {
+enum { CV_8U = 0, CV_32F = 5, CV_64F = 6 };
+
+// minimal dense 2-D matrix with cv::Mat's field names (rows, cols, data, step)
+struct Mat {
+  int rows = 0, cols = 0, depth = CV_8U;
+  size_t step = 0;  // bytes per row
+  std::shared_ptr<std::vector<uint8_t>> buf;
+  uint8_t *data = nullptr;
+
+  Mat() = default;
+  Mat(int r, int c, int d) { create(r, c, d); }
+  static size_t elem(int d) { return d == CV_8U ? 1 : d == CV_32F ? 4 : 8; }
+  void create(int r, int c, int d) {
+    rows = r; cols = c; depth = d; step = (size_t)c * elem(d);
+    buf = std::make_shared<std::vector<uint8_t>>((size_t)r * step, 0);
+    data = buf->data();
+  }
+  bool empty() const { return rows == 0 || cols == 0; }
+  Mat clone() const {
+    Mat m(rows, cols, depth);
+    for (int r = 0; r < rows; ++r) std::copy(data + r * step, data + r * step + m.step, m.data + r * m.step);
+    return m;
+  }
+  void release() { *this = Mat(); }
+  template <typename T> T &at(int r, int c) { return *reinterpret_cast<T *>(data + r * step + c * sizeof(T)); }
+  template <typename T> const T &at(int r, int c) const { return *reinterpret_cast<const T *>(data + r * step + c * sizeof(T)); }
+  template <typename T> T *ptr(int r) { return reinterpret_cast<T *>(data + r * step); }
+  template <typename T> const T *ptr(int r) const { return reinterpret_cast<const T *>(data + r * step); }
+};
+
+struct Point2f { float x = 0, y = 0; };
+struct KeyPoint {
+  Point2f pt;
+  float size = 0;
+  KeyPoint() = default;
+  KeyPoint(Point2f p, float s) : pt(p), size(s) {}
+};
+struct DMatch {
+  int queryIdx = -1, trainIdx = -1, imgIdx = -1;
+  float distance = 0;
+};
+}  // namespace cvlite
+
+namespace tf2lite {
+// rigid transform with tf2::Transform's accessors the node uses
+struct Quaternion { double x = 0, y = 0, z = 0, w = 1; };
+struct Vector3 {
+  double x = 0, y = 0, z = 0;
+  double length() const;
+};
+struct Transform {
+  Quaternion q;
+  Vector3 t;
+  void setRotation(const Quaternion &r) { q = r; }
+  void setOrigin(const Vector3 &o) { t = o; }
+  const Quaternion &getRotation() const { return q; }
+  const Vector3 &getOrigin() const { return t; }
+  Transform inverse() const;
+  Transform operator*(const Transform &o) const;
+  void setIdentity() { q = Quaternion(); t = Vector3(); }
+};
+}  // namespace tf2lite
+
+#ifndef SPVO_USE_OPENCV
+namespace cv = cvlite;
+namespace tf2 = tf2lite;
+#endif
+
+///////////////////////////////////////////////////////////////////////////////////////
+/////////////////////////// Type and macro definitions (hpp:24-90) ////////////////////
+///////////////////////////////////////////////////////////////////////////////////////
+
+enum class DetectorType { ShiTomasi, BRISK, FAST, ORB, AKAZE, SIFT, SuperPoint };
+const std::unordered_map<std::string, DetectorType> detector_name_to_type = {
+    {"ShiTomasi", DetectorType::ShiTomasi}, {"BRISK", DetectorType::BRISK}, {"FAST", DetectorType::FAST},
+    {"ORB", DetectorType::ORB}, {"AKAZE", DetectorType::AKAZE}, {"SIFT", DetectorType::SIFT},
+    {"SuperPoint", DetectorType::SuperPoint}};
+enum class DescriptorType { BRISK, ORB, BRIEF, AKAZE, FREAK, SIFT, SuperPoint };
+const std::unordered_map<std::string, DescriptorType> descriptor_name_to_type = {
+    {"BRISK", DescriptorType::BRISK}, {"ORB", DescriptorType::ORB}, {"BRIEF", DescriptorType::BRIEF},
+    {"AKAZE", DescriptorType::AKAZE}, {"FREAK", DescriptorType::FREAK}, {"SIFT", DescriptorType::SIFT},
+    {"SuperPoint", DescriptorType::SuperPoint}};
+enum class MatcherType { BF, FLANN };
+const std::unordered_map<std::string, MatcherType> matcher_name_to_type = {{"BF", MatcherType::BF}, {"FLANN", MatcherType::FLANN}};
+enum class SelectorType { NN, KNN };
+const std::unordered_map<std::string, SelectorType> selector_name_to_type = {{"NN", SelectorType::NN}, {"KNN", SelectorType::KNN}};
+
+enum ImagePosition { PREV_LEFT = -4, PREV_RIGHT = -3, CURR_LEFT = -2, CURR_RIGHT = -1, NUM_IMAGE_POSITIONS = 4 };
+const std::map<int, std::string> ImagePosition_str = {
+    {PREV_LEFT, "PREV_LEFT"}, {PREV_RIGHT, "PREV_RIGHT"}, {CURR_LEFT, "CURR_LEFT"}, {CURR_RIGHT, "CURR_RIGHT"}};
+
+enum MatchType { CURR_LEFT_CURR_RIGHT = 0, CURR_LEFT_PREV_LEFT = 1, PREV_LEFT_PREV_RIGHT = 2, MATCH_TYPE_NUM = 3 };
+const std::string MatchType_str[] = {"CURR_LEFT_CURR_RIGHT", "CURR_LEFT_PREV_LEFT", "PREV_LEFT_PREV_RIGHT"};
+const std::array<std::pair<int, int>, MATCH_TYPE_NUM> match_type_to_positions = {
+    std::pair<int, int>(CURR_LEFT, CURR_RIGHT), std::pair<int, int>(CURR_LEFT, PREV_LEFT),
+    std::pair<int, int>(PREV_LEFT, PREV_RIGHT)};
+
+enum TensorRtPrecision { TRT_FP32 = 0, TRT_FP16 = 1, NUM_TRT_PRECISION_CHOICES = 2 };
+const std::unordered_map<std::string, TensorRtPrecision> trt_precision_string2enum = {{"FP32", TRT_FP32}, {"FP16", TRT_FP16}};
+const std::array<std::string, NUM_TRT_PRECISION_CHOICES> trt_precision_enum2string = {"FP32", "FP16"};
+
+///////////////////////////////////////////////////////////////////////////////////////
+//////////////////////////////// Abstract class (hpp:96-178) //////////////////////////
+///////////////////////////////////////////////////////////////////////////////////////
+
+class FeatureFrontEnd {
+public:
+  FeatureFrontEnd(const DetectorType detector_type, const DescriptorType descriptor_type,
+                  const MatcherType matcher_type, const SelectorType selector_type, const bool cross_check,
+                  const float stereo_threshold, const float min_disparity, const int refinement_degree,
+                  const bool verbose, const int input_height, const int input_width)
+      : verbose_(verbose), detector_type_(detector_type), descriptor_type_(descriptor_type),
+        matcher_type_(matcher_type), selector_type_(selector_type), cross_check_(cross_check),
+        stereo_threshold_(stereo_threshold), min_disparity_(min_disparity),
+        refinement_degree_(refinement_degree), input_height_(input_height), input_width_(input_width) {}
+  virtual ~FeatureFrontEnd() {}
+  void initMatcher();
+  void clearLagecyData();
+  virtual void addStereoImagePair(cv::Mat &img_l, cv::Mat &img_r, const cv::Mat &projection_matrix_l,
+                                  const cv::Mat &projection_matrix_r) = 0;
+  void matchDescriptors(const MatchType match_type);
+  void solveStereoOdometry(tf2::Transform &cam0_curr_T_cam0_prev);
+  // Drawing only (base.cpp:401-432, 502-553): out of the hot-path scope; they return the
+  // stored image untouched so that the node's publish calls keep working.
+  cv::Mat visualizeMatches(const MatchType match_type);
+  cv::Mat visualizeInliers(const ImagePosition image_position);
+
+  std::deque<cv::Mat> images_dq;
+  std::deque<std::vector<cv::KeyPoint>> keypoints_dq;
+  std::deque<cv::Mat> descriptors_dq;
+  std::array<std::vector<cv::DMatch>, MATCH_TYPE_NUM> cv_DMatches_list;
+
+  const bool verbose_;
+
+  // introspection for tests / the latency CSV (not in the reference)
+  const std::array<std::vector<int>, MATCH_TYPE_NUM> &mapsOfIndices() const { return maps_of_indices; }
+  const std::vector<int> &inliersPnp() const { return inliers_pnp; }
+  const std::vector<int> &inliersPostmatching() const { return inliers_postmatching; }
+  const std::string &lastError() const { return last_error_; }
+  int frameCount() const { return frame_count; }
+  uint32_t ransac_seed = 0;
+
+protected:
+  const DetectorType detector_type_;
+  const DescriptorType descriptor_type_;
+  const MatcherType matcher_type_;
+  const float knn_threshold_ = 0.8;
+  const SelectorType selector_type_;
+  const bool cross_check_;
+  const float stereo_threshold_;
+  const float min_disparity_;
+  const int refinement_degree_;
+  constexpr static double TIME_INTERVAL = 0.1;
+  constexpr static double MAX_ACCELERATION = 8.0;
+  constexpr static int IGNORE_FRAME_COUNT = 10;
+  const int input_height_;
+  const int input_width_;
+
+  // replaces cv::Ptr<cv::DescriptorMatcher> matcher_: the matcher lives behind the C ABI
+  bool matcher_ready_ = false;
+  bool matcher_cross_check_ = false;
+
+  cv::Mat projection_matrix_l_;
+  cv::Mat projection_matrix_r_;
+
+  double r_vec_pred[3] = {0, 0, 0};
+  double t_vec_pred[3] = {0, 0, 0};
+  int frame_count = 0;
+
+  std::array<std::vector<int>, MATCH_TYPE_NUM> maps_of_indices;
+
+  bool prev_left_points_3d_inited = false;
+  std::vector<float> prev_left_points_3d;  // n x 3
+  std::vector<int> map_from_prev_left_matched_to_prev_valid_index;
+  std::vector<int> map_from_curr_valid_to_prev_left_matched_index;
+  std::vector<int> map_from_curr_left_matched_to_curr_valid_index;
+
+  std::vector<int> inliers_postmatching;
+  std::vector<int> inliers_pnp;
+
+  // C-ABI context and the device feature slot each deque entry lives in
+  spvo_ctx *ctx_ = nullptr;
+  std::deque<int> slots_dq_;
+  std::string last_error_;
+  void logError(const std::string &msg);
+  void logInfo(const std::string &msg) const;
+};
+
+///////////////////////////////////////////////////////////////////////////////////////
+////////////////////////// SuperPoint front end (hpp:253-391) /////////////////////////
+///////////////////////////////////////////////////////////////////////////////////////
+
+class SuperPointFeatureFrontEnd : public FeatureFrontEnd {
+public:
+  SuperPointFeatureFrontEnd();
+  SuperPointFeatureFrontEnd(const MatcherType matcher_type, const SelectorType selector_type,
+                            const bool cross_check, const std::string model_name_prefix,
+                            const int model_batch_size, const std::string machine_name,
+                            const TensorRtPrecision trt_precision, const int input_height,
+                            const int input_width, const float conf_thresh, const int dist_thresh,
+                            const int num_threads, const int border_remove, const float stereo_threshold,
+                            const float min_disparity, const int refinement_degree, const bool verbose);
+  ~SuperPointFeatureFrontEnd();
+
+  // loadTrtEngine's successor: <models dir>/<machine>/<prefix>_<B>_<H>_<W>_<FP32|FP16>.spvw
+  // (same naming rule as nn.cpp:44-49).  The models dir replaces ros::package::getPath:
+  // environment variable SPVO_MODELS_DIR, or setModelsDir() before construction.
+  void loadEngine();
+  static void setModelsDir(const std::string &dir);
+
+  void addStereoImagePair(cv::Mat &img_l, cv::Mat &img_r, const cv::Mat &projection_matrix_l,
+                          const cv::Mat &projection_matrix_r) override;
+
+  // Extension (not in the reference): the stereo pair is already resident in device memory
+  // (u8, `stride` bytes per row), e.g. written by a GPU camera/rectification pipeline.  Same
+  // bookkeeping as addStereoImagePair; images_dq receives empty placeholders and, unless
+  // `host_descriptors` is set, descriptors_dq holds n x 0 headers (the descriptors stay on the
+  // device, where matchDescriptors reads them).
+  void addStereoImagePairDevice(const void *d_img_l, const void *d_img_r, int rows, int cols, size_t stride,
+                                const cv::Mat &projection_matrix_l, const cv::Mat &projection_matrix_r,
+                                bool host_descriptors = false);
+  spvo_ctx *context() const { return ctx_; }
+
+  inline int getInputHeight() const { return input_height_; }
+  inline int getInputWidth() const { return input_width_; }
+  bool engineLoaded() const { return engine_loaded_; }
+
+private:
+  const std::string model_name_prefix_;
+  const int model_batch_size_;
+  const std::string machine_name_;
+  const TensorRtPrecision trt_precision_;
+  static constexpr int output_det_channel_ = 65;
+  static constexpr int output_desc_channel_ = 256;
+  const float conf_thresh_;
+  const int dist_thresh_;
+  const int border_remove_;
+  static constexpr int max_keypoints_ = 1000;
+  const int num_threads_;  // kept for signature parity; the work runs on the GPU
+  bool engine_loaded_ = false;
+  std::vector<float> xy_buf_[2], desc_buf_[2];
+  void pickSlots(int *slot_l, int *slot_r) const;
+  void pushFeatures(const spvo_features *f[2], const cv::Mat *images[2], const int slots[2], bool host_descriptors);
+};

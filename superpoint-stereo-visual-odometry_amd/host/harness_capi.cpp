@@ -1,0 +1,111 @@
+// harness_capi.cpp -- a flat C wrapper around the C++ SuperPointFeatureFrontEnd so that the
+// Python tests and bench.py can drive the host class exactly as visual_odometry_node.cpp does
+// (node.cpp:150-262).  Test/bench scaffolding only: a ROS build links the class directly.
+#include <cstring>
+
+#include "feature_detection.hpp"
+
+extern "C" {
+
+void *spvo_host_create(const char *models_dir, const char *prefix, const char *machine, int selector_knn, int cross_check, int batch,
+                       int height, int width, float conf_thresh, int dist_thresh, int border_remove, float stereo_threshold,
+                       float min_disparity, int refinement_degree, int verbose) {
+  SuperPointFeatureFrontEnd::setModelsDir(models_dir ? models_dir : "");
+  auto *fe = new SuperPointFeatureFrontEnd(MatcherType::BF, selector_knn ? SelectorType::KNN : SelectorType::NN, cross_check != 0, prefix, batch,
+                                           machine, TRT_FP32, height, width, conf_thresh, dist_thresh, /*num_threads=*/6, border_remove,
+                                           stereo_threshold, min_disparity, refinement_degree, verbose != 0);
+  return fe;
+}
+
+void spvo_host_destroy(void *h) { delete static_cast<SuperPointFeatureFrontEnd *>(h); }
+
+int spvo_host_engine_loaded(void *h) { return static_cast<SuperPointFeatureFrontEnd *>(h)->engineLoaded() ? 1 : 0; }
+
+const char *spvo_host_last_error(void *h) { return static_cast<SuperPointFeatureFrontEnd *>(h)->lastError().c_str(); }
+
+void spvo_host_set_seed(void *h, unsigned seed) { static_cast<SuperPointFeatureFrontEnd *>(h)->ransac_seed = seed; }
+
+// node.cpp:163-175
+void spvo_host_add_stereo_pair(void *h, const uint8_t *img_l, const uint8_t *img_r, int rows, int cols, const double *P_l, const double *P_r) {
+  auto *fe = static_cast<SuperPointFeatureFrontEnd *>(h);
+  cv::Mat l(rows, cols, cvlite::CV_8U), r(rows, cols, cvlite::CV_8U), pl(3, 4, cvlite::CV_64F), pr(3, 4, cvlite::CV_64F);
+  std::memcpy(l.data, img_l, (size_t)rows * cols);
+  std::memcpy(r.data, img_r, (size_t)rows * cols);
+  std::memcpy(pl.data, P_l, 12 * sizeof(double));
+  std::memcpy(pr.data, P_r, 12 * sizeof(double));
+  fe->addStereoImagePair(l, r, pl, pr);
+}
+
+void spvo_host_add_stereo_pair_dev(void *h, const void *d_l, const void *d_r, int rows, int cols, size_t stride, const double *P_l, const double *P_r,
+                                   int host_descriptors) {
+  auto *fe = static_cast<SuperPointFeatureFrontEnd *>(h);
+  cv::Mat pl(3, 4, cvlite::CV_64F), pr(3, 4, cvlite::CV_64F);
+  std::memcpy(pl.data, P_l, 12 * sizeof(double));
+  std::memcpy(pr.data, P_r, 12 * sizeof(double));
+  fe->addStereoImagePairDevice(d_l, d_r, rows, cols, stride, pl, pr, host_descriptors != 0);
+}
+
+void *spvo_host_ctx(void *h) { return static_cast<SuperPointFeatureFrontEnd *>(h)->context(); }
+
+void spvo_host_match(void *h, int match_type) { static_cast<SuperPointFeatureFrontEnd *>(h)->matchDescriptors((MatchType)match_type); }
+
+// out: q (x, y, z, w), t of cam0_curr_T_cam0_prev
+void spvo_host_solve(void *h, double *q, double *t) {
+  tf2::Transform T;
+  static_cast<SuperPointFeatureFrontEnd *>(h)->solveStereoOdometry(T);
+  q[0] = T.getRotation().x; q[1] = T.getRotation().y; q[2] = T.getRotation().z; q[3] = T.getRotation().w;
+  t[0] = T.getOrigin().x; t[1] = T.getOrigin().y; t[2] = T.getOrigin().z;
+}
+
+void spvo_host_clear(void *h) { static_cast<SuperPointFeatureFrontEnd *>(h)->clearLagecyData(); }
+
+int spvo_host_dq_size(void *h) { return (int)static_cast<SuperPointFeatureFrontEnd *>(h)->keypoints_dq.size(); }
+
+// position: -4..-1 (ImagePosition)
+int spvo_host_keypoints(void *h, int position, float *xy, int cap) {
+  auto *fe = static_cast<SuperPointFeatureFrontEnd *>(h);
+  if ((int)fe->keypoints_dq.size() + position < 0) return -1;
+  const auto &k = fe->keypoints_dq.end()[position];
+  for (int i = 0; i < (int)k.size() && i < cap; ++i) { xy[2 * i] = k[i].pt.x; xy[2 * i + 1] = k[i].pt.y; }
+  return (int)k.size();
+}
+
+int spvo_host_descriptors(void *h, int position, float *desc, int cap) {
+  auto *fe = static_cast<SuperPointFeatureFrontEnd *>(h);
+  if ((int)fe->descriptors_dq.size() + position < 0) return -1;
+  const auto &d = fe->descriptors_dq.end()[position];
+  const int n = d.rows < cap ? d.rows : cap;
+  if (n) std::memcpy(desc, d.data, (size_t)n * 256 * sizeof(float));
+  return d.rows;
+}
+
+int spvo_host_image(void *h, int position, uint8_t *out, int cap) {
+  auto *fe = static_cast<SuperPointFeatureFrontEnd *>(h);
+  if ((int)fe->images_dq.size() + position < 0) return -1;
+  const auto &m = fe->images_dq.end()[position];
+  if (m.rows * m.cols <= cap) std::memcpy(out, m.data, (size_t)m.rows * m.cols);
+  return m.rows * m.cols;
+}
+
+int spvo_host_matches(void *h, int match_type, int *query, int *train, float *dist, int cap) {
+  const auto &m = static_cast<SuperPointFeatureFrontEnd *>(h)->cv_DMatches_list[match_type];
+  for (int i = 0; i < (int)m.size() && i < cap; ++i) { query[i] = m[i].queryIdx; train[i] = m[i].trainIdx; dist[i] = m[i].distance; }
+  return (int)m.size();
+}
+
+int spvo_host_map(void *h, int match_type, int *out, int cap) {
+  const auto &m = static_cast<SuperPointFeatureFrontEnd *>(h)->mapsOfIndices()[match_type];
+  for (int i = 0; i < (int)m.size() && i < cap; ++i) out[i] = m[i];
+  return (int)m.size();
+}
+
+int spvo_host_inliers(void *h, int which, int *out, int cap) {
+  auto *fe = static_cast<SuperPointFeatureFrontEnd *>(h);
+  const auto &v = which == 0 ? fe->inliersPnp() : fe->inliersPostmatching();
+  for (int i = 0; i < (int)v.size() && i < cap; ++i) out[i] = v[i];
+  return (int)v.size();
+}
+
+int spvo_host_frame_count(void *h) { return static_cast<SuperPointFeatureFrontEnd *>(h)->frameCount(); }
+
+}  // extern "C"

@@ -1,0 +1,187 @@
+"""ctypes binding of host/harness_capi.cpp: drives the C++ SuperPointFeatureFrontEnd
+(the mirror of the reference's class) with the call sequence of visual_odometry_node.cpp."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libspvo_host.so")
+_lib = None
+
+CURR_LEFT_CURR_RIGHT, CURR_LEFT_PREV_LEFT, PREV_LEFT_PREV_RIGHT = 0, 1, 2
+PREV_LEFT, PREV_RIGHT, CURR_LEFT, CURR_RIGHT = -4, -3, -2, -1
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python __graft_entry__.py` first")
+        lib = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        lib.spvo_host_create.restype = vp
+        lib.spvo_host_create.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int]
+        lib.spvo_host_destroy.argtypes = [vp]
+        lib.spvo_host_destroy.restype = None
+        lib.spvo_host_last_error.argtypes = [vp]
+        lib.spvo_host_last_error.restype = C.c_char_p
+        for name in ("spvo_host_engine_loaded", "spvo_host_dq_size", "spvo_host_frame_count"):
+            getattr(lib, name).argtypes = [vp]
+        lib.spvo_host_set_seed.argtypes = [vp, C.c_uint]
+        lib.spvo_host_set_seed.restype = None
+        lib.spvo_host_add_stereo_pair.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
+        lib.spvo_host_add_stereo_pair.restype = None
+        lib.spvo_host_add_stereo_pair_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, vp, vp, C.c_int]
+        lib.spvo_host_add_stereo_pair_dev.restype = None
+        lib.spvo_host_ctx.argtypes = [vp]
+        lib.spvo_host_ctx.restype = vp
+        lib.spvo_host_match.argtypes = [vp, C.c_int]
+        lib.spvo_host_match.restype = None
+        lib.spvo_host_solve.argtypes = [vp, vp, vp]
+        lib.spvo_host_solve.restype = None
+        lib.spvo_host_clear.argtypes = [vp]
+        lib.spvo_host_clear.restype = None
+        lib.spvo_host_keypoints.argtypes = [vp, C.c_int, vp, C.c_int]
+        lib.spvo_host_descriptors.argtypes = [vp, C.c_int, vp, C.c_int]
+        lib.spvo_host_image.argtypes = [vp, C.c_int, vp, C.c_int]
+        lib.spvo_host_matches.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int]
+        lib.spvo_host_map.argtypes = [vp, C.c_int, vp, C.c_int]
+        lib.spvo_host_inliers.argtypes = [vp, C.c_int, vp, C.c_int]
+        _lib = lib
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class FrontEnd:
+    """SuperPointFeatureFrontEnd with the reference launch-file defaults
+    (launch/visual_odometry_superpoint.launch:3-26)."""
+
+    def __init__(self, models_dir, prefix="superpoint_pretrained", machine="laptop", selector="KNN", cross_check=True,
+                 batch=2, height=360, width=1176, conf_thresh=0.015, dist_thresh=4, border_remove=4,
+                 stereo_threshold=2.0, min_disparity=0.25, refinement_degree=4, verbose=False):
+        self.lib = load()
+        self.h = self.lib.spvo_host_create(models_dir.encode(), prefix.encode(), machine.encode(),
+                                           1 if selector == "KNN" else 0, int(cross_check), batch, height, width,
+                                           conf_thresh, dist_thresh, border_remove, stereo_threshold, min_disparity,
+                                           refinement_degree, int(verbose))
+        self.H, self.W = height, width
+
+    def close(self):
+        if self.h:
+            self.lib.spvo_host_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def engine_loaded(self):
+        return bool(self.lib.spvo_host_engine_loaded(self.h))
+
+    @property
+    def last_error(self):
+        return self.lib.spvo_host_last_error(self.h).decode()
+
+    def set_seed(self, seed):
+        self.lib.spvo_host_set_seed(self.h, seed)
+
+    def add_stereo_image_pair(self, img_l, img_r, P_l, P_r):
+        img_l = np.ascontiguousarray(img_l, np.uint8)
+        img_r = np.ascontiguousarray(img_r, np.uint8)
+        Pl = np.ascontiguousarray(P_l, np.float64)
+        Pr = np.ascontiguousarray(P_r, np.float64)
+        self.lib.spvo_host_add_stereo_pair(self.h, _p(img_l), _p(img_r), img_l.shape[0], img_l.shape[1], _p(Pl), _p(Pr))
+
+    def add_stereo_image_pair_device(self, d_l: int, d_r: int, rows: int, cols: int, stride: int, P_l, P_r, host_descriptors=False):
+        Pl = np.ascontiguousarray(P_l, np.float64)
+        Pr = np.ascontiguousarray(P_r, np.float64)
+        self.lib.spvo_host_add_stereo_pair_dev(self.h, C.c_void_p(d_l), C.c_void_p(d_r), rows, cols, stride, _p(Pl), _p(Pr),
+                                               int(host_descriptors))
+
+    def context(self):
+        """The spvo_ctx of this front end wrapped for the profiling calls of spvo.capi."""
+        from . import capi
+        c = capi.Context.__new__(capi.Context)
+        c.lib = capi.load()
+        c.h = C.c_void_p(self.lib.spvo_host_ctx(self.h))
+        c.close = lambda: None                         # owned by the C++ object
+        return c
+
+    def step_device(self, d_l, d_r, rows, cols, stride, P_l, P_r):
+        self.add_stereo_image_pair_device(d_l, d_r, rows, cols, stride, P_l, P_r)
+        if self.dq_size() < 4:
+            self.match_descriptors(CURR_LEFT_CURR_RIGHT)
+            return None
+        self.match_descriptors(CURR_LEFT_CURR_RIGHT)
+        self.match_descriptors(CURR_LEFT_PREV_LEFT)
+        return self.solve_stereo_odometry()
+
+    def match_descriptors(self, match_type):
+        self.lib.spvo_host_match(self.h, match_type)
+
+    def solve_stereo_odometry(self):
+        q = np.zeros(4)
+        t = np.zeros(3)
+        self.lib.spvo_host_solve(self.h, _p(q), _p(t))
+        return q, t
+
+    def clear(self):
+        self.lib.spvo_host_clear(self.h)
+
+    def dq_size(self):
+        return self.lib.spvo_host_dq_size(self.h)
+
+    def frame_count(self):
+        return self.lib.spvo_host_frame_count(self.h)
+
+    def keypoints(self, position):
+        xy = np.zeros((1000, 2), np.float32)
+        n = self.lib.spvo_host_keypoints(self.h, position, _p(xy), 1000)
+        return xy[:max(n, 0)].copy()
+
+    def descriptors(self, position):
+        d = np.zeros((1000, 256), np.float32)
+        n = self.lib.spvo_host_descriptors(self.h, position, _p(d), 1000)
+        return d[:max(n, 0)].copy()
+
+    def image(self, position):
+        out = np.zeros((self.H, self.W), np.uint8)
+        n = self.lib.spvo_host_image(self.h, position, _p(out), out.size)
+        return out if n == out.size else None
+
+    def matches(self, match_type):
+        q = np.zeros(1000, np.int32)
+        t = np.zeros(1000, np.int32)
+        d = np.zeros(1000, np.float32)
+        n = self.lib.spvo_host_matches(self.h, match_type, _p(q), _p(t), _p(d), 1000)
+        return q[:n].copy(), t[:n].copy(), d[:n].copy()
+
+    def map_of_indices(self, match_type):
+        m = np.zeros(4096, np.int32)
+        n = self.lib.spvo_host_map(self.h, match_type, _p(m), 4096)
+        return m[:n].copy()
+
+    def inliers(self, which="pnp"):
+        v = np.zeros(4096, np.int32)
+        n = self.lib.spvo_host_inliers(self.h, 0 if which == "pnp" else 1, _p(v), 4096)
+        return v[:n].copy()
+
+    def step(self, img_l, img_r, P_l, P_r):
+        """One stereoCallback (node.cpp:150-262).  Returns (q, t) or None on the first frame."""
+        self.add_stereo_image_pair(img_l, img_r, P_l, P_r)
+        if self.dq_size() < 4:
+            self.match_descriptors(CURR_LEFT_CURR_RIGHT)          # node.cpp:188-193
+            return None
+        self.match_descriptors(CURR_LEFT_CURR_RIGHT)              # node.cpp:196-198
+        self.match_descriptors(CURR_LEFT_PREV_LEFT)
+        return self.solve_stereo_odometry()                      # node.cpp:218

@@ -1,0 +1,94 @@
+"""The C++ host mirror of FeatureFrontEnd (host/feature_detection.cpp), driven with the call
+sequence of visual_odometry_node.cpp:150-262, against the oracle's restatement of the same state
+machine fed with identical upstream features (so that poses must agree to 1e-4)."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+import oracle  # noqa: F401
+from oracle import odometry as od
+from spvo import host, synth, weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def models_dir(tmp_path_factory, squeeze_weights_path):
+    d = tmp_path_factory.mktemp("models")
+    os.makedirs(d / "laptop")
+    shutil.copyfile(squeeze_weights_path, d / "laptop" / weights.engine_name("sp_squeeze", 2, 360, 1176, "FP32"))
+    return str(d)
+
+
+@pytest.fixture(scope="module")
+def sequence(golden_dir):
+    return synth.stereo_sequence(5, os.path.join(golden_dir, "images", "0000000000.png"), seed=0)
+
+
+def _angle(q):
+    q = q / np.linalg.norm(q)
+    return 2 * np.arctan2(np.linalg.norm(q[:3]), abs(q[3]))
+
+
+@pytest.mark.parametrize("selector,cross", [("KNN", True), ("NN", True)])
+def test_host_sequence_matches_oracle_state_machine(models_dir, sequence, selector, cross):
+    frames, poses, P_l, P_r = sequence
+    fe = host.FrontEnd(models_dir, prefix="sp_squeeze", selector=selector, cross_check=cross)
+    assert fe.engine_loaded, fe.last_error
+    st = od.FrontEndState()
+    errs = []
+    for k, (L, R) in enumerate(frames):
+        res = fe.step(L, R, P_l, P_r)
+        # identical upstream for the oracle: the GPU's own keypoints / descriptors / P
+        from oracle import frontend as ofe
+        _, Pl2 = ofe.preprocess(L, P_l, 360, 1176, True)
+        _, Pr2 = ofe.preprocess(R, P_r, 360, 1176, True)
+        od.add_features(st, fe.keypoints(host.CURR_LEFT), fe.descriptors(host.CURR_LEFT),
+                        fe.keypoints(host.CURR_RIGHT), fe.descriptors(host.CURR_RIGHT), Pl2, Pr2)
+        ocross = cross and selector != "KNN"                       # base.cpp:27-28
+        idx0, _ = od.match_descriptors(st, 0, selector, ocross)
+        assert np.array_equal(fe.map_of_indices(0), idx0)          # maps_of_indices: bit-exact
+        q, tr, d = fe.matches(0)
+        assert np.array_equal(q, np.nonzero(idx0 >= 0)[0]) and np.array_equal(tr, idx0[idx0 >= 0])
+        if k == 0:
+            assert res is None and fe.dq_size() == 2
+            continue
+        idx1, _ = od.match_descriptors(st, 1, selector, ocross)
+        assert np.array_equal(fe.map_of_indices(1), idx1)
+        assert np.array_equal(fe.map_of_indices(2), st.maps[2])    # PREV_LEFT_PREV_RIGHT roll (base.cpp:475-481)
+        oq, ot, dbg = od.solve_stereo_odometry(st)
+        gq, gt = res
+        assert np.array_equal(fe.inliers("post"), dbg["join"]["post"])
+        assert np.array_equal(fe.inliers("pnp"), dbg["inliers"])   # integer outputs: bit-exact
+        assert np.abs(gt - ot).max() <= 1e-4 and _angle(od.quat_mul(gq, np.array([-oq[0], -oq[1], -oq[2], oq[3]]))) <= 1e-4
+        assert fe.dq_size() == 4 and fe.frame_count() == k
+        # ground truth (reported): relative pose error of this synthetic step
+        Rgt, tgt = synth.relative_pose(poses[k - 1], poses[k])
+        errs.append(np.linalg.norm(gt - tgt))
+    assert max(errs) < 0.05, errs                                   # metres per ~0.8 m step
+    fe.clear()
+    assert fe.dq_size() == 0 and fe.frame_count() == 0
+    fe.close()
+
+
+def test_host_error_conventions(models_dir, tmp_path):
+    # missing engine file: logged, object left half-initialised, calls return without throwing (nn.cpp:53-55)
+    fe = host.FrontEnd(str(tmp_path), prefix="does_not_exist")
+    assert not fe.engine_loaded and "no such engine file" in fe.last_error
+    img = np.zeros((376, 1241), np.uint8)
+    P_l, P_r = synth.projection_matrices()
+    fe.add_stereo_image_pair(img, img, P_l, P_r)
+    assert fe.dq_size() == 0
+    fe.close()
+    # wrong batch size (nn.cpp:489-491)
+    fe = host.FrontEnd(models_dir, prefix="sp_squeeze", batch=3)
+    assert not fe.engine_loaded and "Wrong batch size" in fe.last_error
+    fe.close()
+    # blank images: no keypoints, no matches, no crash; pose falls back to the prior (base.cpp:244-250)
+    fe = host.FrontEnd(models_dir, prefix="sp_squeeze")
+    assert fe.step(img, img, P_l, P_r) is None
+    q, t = fe.step(img, img, P_l, P_r)
+    assert np.allclose(q, [0, 0, 0, 1]) and np.allclose(t, 0)
+    fe.close()
