@@ -82,7 +82,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from spvo import host, synth, weights
+    from spvo import host, posegather, synth, weights
 
     plan = weights.vgg_plan(seed=0)
     tmp = tempfile.mkdtemp(prefix=f"spvo_bench_{rank}_")
@@ -91,7 +91,7 @@ def main():
 
     # every rank renders its own stream (different seed = different ego-motion); sample-image texture
     tex = os.path.join(ROOT, "tests", "golden", "images", "0000000000.png")
-    frames, poses, P_l, P_r = synth.stereo_sequence(SEQ_LEN, tex, seed=rank)
+    frames, poses, P_l, P_r = synth.stereo_sequence(SEQ_LEN, tex, seed=posegather.stream_seed(rank))
     d_frames = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
     rows, cols = frames[0][0].shape
     order = list(range(SEQ_LEN)) + list(range(SEQ_LEN - 2, 0, -1))       # ping-pong: every step is a real motion
@@ -102,16 +102,13 @@ def main():
     if not fe.engine_loaded:
         raise SystemExit("engine load failed: " + fe.last_error)
     ctx = fe.context()
-    pose_buf = torch.zeros(7, dtype=torch.float64, device="cuda")
-    gathered = [torch.zeros(7, dtype=torch.float64, device="cuda") for _ in range(world)] if world > 1 else None
+    pg = posegather.PoseGather(torch.device("cuda", local_rank))
 
     def step(i):
         dl, dr = d_frames[order[i % len(order)]]
         res = fe.step_device(dl.data_ptr(), dr.data_ptr(), rows, cols, dl.stride(0), P_l, P_r)
-        if world > 1:
-            if res is not None:
-                pose_buf.copy_(torch.from_numpy(np.concatenate(res)))
-            dist.all_gather(gathered, pose_buf)                            # RCCL: 56 B per rank
+        if world > 1:                                                       # RCCL all-gather, 56 B per rank
+            pg.gather(*(res if res is not None else (None, None)))
         return res
 
     def barrier():
@@ -154,7 +151,7 @@ def main():
         if dom and dom["calls"]:
             avg_ms = dom["total_ms"] / dom["calls"]
             achieved = dom["flops"] / (avg_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel<3,8,2,1,pool,relu> (conv1b 64->64 @360x1176, 2 images)",
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel<KS=3,...,POOL,RELU> instance of op 1 = conv1b 64->64 @360x1176, 2 images",
                                "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                                "avg_kernel_ms": round(avg_ms, 5), "flops_per_launch": dom["flops"]}

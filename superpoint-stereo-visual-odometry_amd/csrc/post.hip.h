@@ -144,84 +144,136 @@ __global__ __launch_bounds__(256) void heatmap_kernel(const float *__restrict__ 
 // ---------------------------------------------------------------------------
 enum : uint8_t { ST_NONE = 0, ST_UNDECIDED = 1, ST_KEPT = 2, ST_SUPPRESSED = 3 };
 
+// The state map is padded (NMS_PAD rows/columns of ST_NONE on every side, row pitch a multiple
+// of 4) so that a candidate's whole window is read with aligned 32-bit loads and no clipping.
+constexpr int NMS_PAD = 8;           // >= largest supported dist_thresh
+constexpr int NMS_MAX_LAUNCH = 16;   // round launches per host batch
+constexpr int NMS_COUNTER_INTS = 8 + NMS_MAX_LAUNCH;
+
+__host__ __device__ inline int nms_state_pitch(int W) { return ((W + 2 * NMS_PAD + 3) / 4) * 4; }
+
 struct NmsBuffers {   // per image
-  uint8_t *state;     // [H*W]
+  uint8_t *state;     // [(H + 2*NMS_PAD)][pitch]
   int *cand;          // [H*W] row-major pixel index of each candidate
-  int *counters;      // [0] n_cand, [1] n_survivors, [2] n_out, [3] overflow, [8..8+MAXR) remaining per launch
+  int *counters;      // [0] n_cand, [1] n_survivors, [2] n_out, [3] overflow, [8 + l] undecided after launch l
   unsigned long long *surv_key;  // [surv_cap]
   int *out_xy;        // [max_kp][2]
 };
-constexpr int NMS_MAX_LAUNCH = 48;
-constexpr int NMS_COUNTER_INTS = 8 + NMS_MAX_LAUNCH;
+struct NmsPair { NmsBuffers b[2]; };   // blockIdx.y / blockIdx.z selects the image
 
 __device__ __forceinline__ unsigned long long rank_key(float conf, int x, int y, int H) {
   return ((unsigned long long)(0xFFFFFFFFu - __float_as_uint(conf)) << 32) | (unsigned)(x * H + y);
 }
 
 __global__ __launch_bounds__(256) void nms_threshold_kernel(const float *__restrict__ heat, int H,
-                                                            int W, float thresh, NmsBuffers nb) {
+                                                            int W, float thresh, NmsPair np) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const NmsBuffers nb = np.b[blockIdx.z];
   if (x >= W || y >= H) return;
   const int p = y * W + x;
-  const bool c = heat[p] > thresh;  // strict, nn.cpp:203
-  nb.state[p] = c ? ST_UNDECIDED : ST_NONE;
+  const bool c = heat[(size_t)blockIdx.z * H * W + p] > thresh;  // strict, nn.cpp:203
+  nb.state[(y + NMS_PAD) * nms_state_pitch(W) + x + NMS_PAD] = c ? ST_UNDECIDED : ST_NONE;
   if (c) nb.cand[atomicAdd(&nb.counters[0], 1)] = p;
 }
 
-template <int INNER>
+// One thread per candidate (grid-stride).  DIST > 0: compile-time radius, every window row is
+// fetched with 3 independent aligned word loads (27 loads in flight for the 9x9 window);
+// DIST == 0: run-time radius (<= NMS_PAD), byte loads.
+template <int INNER, int DIST>
 __global__ __launch_bounds__(256) void nms_round_kernel(const float *__restrict__ heat, int H, int W,
-                                                        int dist, NmsBuffers nb, int launch) {
+                                                        int dist_rt, NmsPair np, int launch) {
+  const NmsBuffers nb = np.b[blockIdx.y];
   if (launch > 0 && nb.counters[8 + launch - 1] == 0) return;  // nothing left undecided
+  const float *hm = heat + (size_t)blockIdx.y * H * W;
   const int n = nb.counters[0];
+  const int pitch = nms_state_pitch(W);
   const int gid = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
-  volatile uint8_t *state = nb.state;
+  uint8_t *state = nb.state;
+  const int dist = DIST > 0 ? DIST : dist_rt;
   for (int it = 0; it < INNER; ++it) {
     for (int i = gid; i < n; i += stride) {
       const int p = nb.cand[i];
-      if (state[p] != ST_UNDECIDED) continue;
       const int y = p / W, x = p - y * W;
-      const unsigned long long key = rank_key(heat[p], x, y, H);
+      const int sp = (y + NMS_PAD) * pitch + x + NMS_PAD;
+      if (((volatile uint8_t *)state)[sp] != ST_UNDECIDED) continue;
+      const unsigned long long key = rank_key(hm[p], x, y, H);
       bool any_kept = false, any_better = false;
-      const int y0 = max(y - dist, 0), y1 = min(y + dist, H - 1);
-      const int x0 = max(x - dist, 0), x1 = min(x + dist, W - 1);
-      for (int yy = y0; yy <= y1; ++yy)
-        for (int xx = x0; xx <= x1; ++xx) {
-          const int q = yy * W + xx;
-          const uint8_t s = state[q];
-          if (s == ST_KEPT) any_kept = true;
-          else if (s == ST_UNDECIDED && q != p && rank_key(heat[q], xx, yy, H) < key) any_better = true;
+      if constexpr (DIST > 0) {
+        constexpr int NW = (2 * DIST + 1 + 3 + 3) / 4;  // words that cover the window from an aligned start
+        const int a = (x + NMS_PAD - DIST) & ~3;        // aligned first column (padded coordinates)
+        uint32_t w[2 * DIST + 1][NW];
+#pragma unroll
+        for (int dy = 0; dy <= 2 * DIST; ++dy) {
+          const uint32_t *row = (const uint32_t *)(state + (y + NMS_PAD + dy - DIST) * pitch + a);
+#pragma unroll
+          for (int k = 0; k < NW; ++k) w[dy][k] = __builtin_nontemporal_load(row + k);
         }
-      if (any_kept) state[p] = ST_SUPPRESSED;
-      else if (!any_better) state[p] = ST_KEPT;
+#pragma unroll
+        for (int dy = 0; dy <= 2 * DIST; ++dy)
+#pragma unroll
+          for (int k = 0; k < NW; ++k) {
+            const uint32_t v = w[dy][k];
+            if (v == 0) continue;                       // four ST_NONE
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              const int s = (v >> (8 * b)) & 0xFF;
+              const int xx = a + 4 * k + b - NMS_PAD;
+              if (s == ST_NONE || xx < x - DIST || xx > x + DIST) continue;
+              if (s == ST_KEPT) any_kept = true;
+              else if (s == ST_UNDECIDED) {
+                const int yy = y + dy - DIST;
+                if ((yy != y || xx != x) && rank_key(hm[yy * W + xx], xx, yy, H) < key) any_better = true;
+              }
+            }
+          }
+      } else {
+        for (int yy = y - dist; yy <= y + dist; ++yy)
+          for (int xx = x - dist; xx <= x + dist; ++xx) {
+            const uint8_t s = ((volatile uint8_t *)state)[(yy + NMS_PAD) * pitch + xx + NMS_PAD];
+            if (s == ST_KEPT) any_kept = true;
+            else if (s == ST_UNDECIDED && (yy != y || xx != x) && rank_key(hm[yy * W + xx], xx, yy, H) < key) any_better = true;
+          }
+      }
+      if (any_kept) ((volatile uint8_t *)state)[sp] = ST_SUPPRESSED;
+      else if (!any_better) ((volatile uint8_t *)state)[sp] = ST_KEPT;
     }
     __syncthreads();
   }
   int rem = 0;
-  for (int i = gid; i < n; i += stride) rem += (state[nb.cand[i]] == ST_UNDECIDED) ? 1 : 0;
+  for (int i = gid; i < n; i += stride) {
+    const int p = nb.cand[i];
+    const int y = p / W, x = p - y * W;
+    rem += (((volatile uint8_t *)state)[(y + NMS_PAD) * pitch + x + NMS_PAD] == ST_UNDECIDED) ? 1 : 0;
+  }
   if (rem) atomicAdd(&nb.counters[8 + launch], rem);
 }
 
 __global__ __launch_bounds__(256) void nms_collect_kernel(const float *__restrict__ heat, int H,
                                                           int W, int border, int surv_cap,
-                                                          NmsBuffers nb) {
+                                                          NmsPair np) {
+  const NmsBuffers nb = np.b[blockIdx.y];
+  const float *hm = heat + (size_t)blockIdx.y * H * W;
   const int n = nb.counters[0];
+  const int pitch = nms_state_pitch(W);
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const int p = nb.cand[i];
-    if (nb.state[p] != ST_KEPT) continue;
     const int y = p / W, x = p - y * W;
+    if (nb.state[(y + NMS_PAD) * pitch + x + NMS_PAD] != ST_KEPT) continue;
     if (y >= border && y + border < H && x >= border && x + border < W) {  // nn.cpp:239-242
       const int s = atomicAdd(&nb.counters[1], 1);
-      if (s < surv_cap) nb.surv_key[s] = rank_key(heat[p], x, y, H);
+      if (s < surv_cap) nb.surv_key[s] = rank_key(hm[p], x, y, H);
       else nb.counters[3] = 1;
     }
   }
 }
 
 // rank by counting: out position of a survivor = number of survivors with a smaller key
-__global__ __launch_bounds__(256) void nms_emit_kernel(int H, int max_kp, int surv_cap, NmsBuffers nb) {
+__global__ __launch_bounds__(256) void nms_emit_kernel(int H, int max_kp, int surv_cap, NmsPair np) {
   __shared__ unsigned long long tile[1024];
+  const NmsBuffers nb = np.b[blockIdx.y];
   const int n = min(nb.counters[1], surv_cap);
+  if (blockIdx.x * 256 >= n && blockIdx.x > 0) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
   const unsigned long long key = (i < n) ? nb.surv_key[i] : 0ull;
   int rank = 0;

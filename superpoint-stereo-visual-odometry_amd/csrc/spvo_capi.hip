@@ -397,62 +397,62 @@ int launch_preprocess(spvo_ctx *c, const uint8_t *d_src, int rows, int cols, siz
 constexpr int NMS_INNER = 4;
 constexpr int NMS_GRID = 128;
 
-int launch_nms(spvo_ctx *c, int img, int first_launch, int n_launch) {
-  const float *heat = c->d_heat + (size_t)img * c->H * c->W;
-  NmsBuffers nb = c->nms[img].b;
-  if (first_launch == 0) {
-    HIP_TRY(c, hipMemsetAsync(nb.counters, 0, NMS_COUNTER_INTS * sizeof(int), c->stream));
-    dim3 grid((c->W + 63) / 64, (c->H + 3) / 4);
-    hipLaunchKernelGGL(nms_threshold_kernel, grid, dim3(256), 0, c->stream, heat, c->H, c->W, c->cfg.conf_thresh, nb);
-  }
-  for (int l = first_launch; l < first_launch + n_launch && l < NMS_MAX_LAUNCH; ++l)
-    hipLaunchKernelGGL(nms_round_kernel<NMS_INNER>, dim3(NMS_GRID), dim3(256), 0, c->stream, heat, c->H, c->W, c->cfg.dist_thresh, nb, l);
-  HIP_TRY(c, hipGetLastError());
-  return SPVO_OK;
+NmsPair nms_pair(spvo_ctx *c) {
+  NmsPair p;
+  p.b[0] = c->nms[0].b;
+  p.b[1] = c->nms[1].b;
+  return p;
 }
 
-int launch_nms_emit(spvo_ctx *c, int img) {
-  const float *heat = c->d_heat + (size_t)img * c->H * c->W;
-  NmsBuffers nb = c->nms[img].b;
-  HIP_TRY(c, hipMemsetAsync(nb.counters + 1, 0, 3 * sizeof(int), c->stream));
-  hipLaunchKernelGGL(nms_collect_kernel, dim3(NMS_GRID), dim3(256), 0, c->stream, heat, c->H, c->W, c->cfg.border_remove, c->surv_cap, nb);
-  hipLaunchKernelGGL(nms_emit_kernel, dim3((c->surv_cap + 255) / 256), dim3(256), 0, c->stream, c->H, c->cfg.max_keypoints, c->surv_cap, nb);
-  HIP_TRY(c, hipGetLastError());
-  return SPVO_OK;
-}
-
-// runs threshold + rounds + emit for images [0, nimg); leaves counters in h_counters; syncs.
-int run_nms(spvo_ctx *c, int nimg) {
-  const int first = 3;
+// threshold (first batch only) + `n_launch` round launches + collect + emit for `nimg` images,
+// then the counters travel to the host.  Launch 0 of a batch never exits early.
+int launch_nms_batch(spvo_ctx *c, int nimg, bool first, int n_launch) {
+  const NmsPair np = nms_pair(c);
   for (int i = 0; i < nimg; ++i) {
-    int rc = launch_nms(c, i, 0, first);
-    if (rc) return rc;
-    rc = launch_nms_emit(c, i);
-    if (rc) return rc;
+    NmsBuffers &nb = c->nms[i].b;
+    if (first) HIP_TRY(c, hipMemsetAsync(nb.counters, 0, NMS_COUNTER_INTS * sizeof(int), c->stream));
+    else HIP_TRY(c, hipMemsetAsync(nb.counters + 1, 0, (NMS_COUNTER_INTS - 1) * sizeof(int), c->stream));
+  }
+  if (first) {
+    dim3 grid((c->W + 63) / 64, (c->H + 3) / 4, nimg);
+    hipLaunchKernelGGL(nms_threshold_kernel, grid, dim3(256), 0, c->stream, c->d_heat, c->H, c->W, c->cfg.conf_thresh, np);
+  }
+  for (int l = 0; l < n_launch; ++l) {
+    if (c->cfg.dist_thresh == 4)
+      hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 4>), dim3(NMS_GRID, nimg), dim3(256), 0, c->stream, c->d_heat, c->H, c->W, 4, np, l);
+    else
+      hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 0>), dim3(NMS_GRID, nimg), dim3(256), 0, c->stream, c->d_heat, c->H, c->W, c->cfg.dist_thresh, np, l);
+  }
+  hipLaunchKernelGGL(nms_collect_kernel, dim3(NMS_GRID, nimg), dim3(256), 0, c->stream, c->d_heat, c->H, c->W, c->cfg.border_remove, c->surv_cap, np);
+  hipLaunchKernelGGL(nms_emit_kernel, dim3((c->surv_cap + 255) / 256, nimg), dim3(256), 0, c->stream, c->H, c->cfg.max_keypoints, c->surv_cap, np);
+  HIP_TRY(c, hipGetLastError());
+  for (int i = 0; i < nimg; ++i)
     HIP_TRY(c, hipMemcpyAsync(c->h_counters + i * NMS_COUNTER_INTS, c->nms[i].b.counters, NMS_COUNTER_INTS * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  }
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  // rare: decision chains longer than first*NMS_INNER rounds -> keep going
-  for (int i = 0; i < nimg; ++i) {
-    int done = first;
-    while (c->h_counters[i * NMS_COUNTER_INTS + 8 + done - 1] != 0) {
-      if (done >= NMS_MAX_LAUNCH) return fail(c, SPVO_ERR_DEVICE, "NMS did not settle in %d rounds", NMS_MAX_LAUNCH * NMS_INNER);
-      const int more = std::min(4, NMS_MAX_LAUNCH - done);
-      int rc = launch_nms(c, i, done, more);
-      if (rc) return rc;
-      done += more;
-      rc = launch_nms_emit(c, i);
-      if (rc) return rc;
-      HIP_TRY(c, hipMemcpyAsync(c->h_counters + i * NMS_COUNTER_INTS, c->nms[i].b.counters, NMS_COUNTER_INTS * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-    if (c->h_counters[i * NMS_COUNTER_INTS + 3]) return fail(c, SPVO_ERR_CAPACITY, "NMS survivor buffer overflow");
-  }
   return SPVO_OK;
 }
 
-// nms_collect uses a grid-stride-free layout: make sure NMS_GRID*256 covers the candidates
-// (handled inside the kernels with strided loops).
+// Runs the whole of processOneHeatmap for images [0, nimg); counters end up in h_counters; syncs.
+// Real heat maps settle in 3-4 rounds; adversarial ones (e.g. a constant image: one decision
+// chain across the whole picture) simply take more batches -- every launch decides at least
+// the best undecided candidate, so the loop terminates.
+int run_nms(spvo_ctx *c, int nimg) {
+  int rc = launch_nms_batch(c, nimg, true, 3);
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int last = 3;
+  for (;;) {
+    bool pending = false;
+    for (int i = 0; i < nimg; ++i) pending |= c->h_counters[i * NMS_COUNTER_INTS + 8 + last - 1] != 0;
+    if (!pending) break;
+    last = NMS_MAX_LAUNCH;
+    rc = launch_nms_batch(c, nimg, false, last);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  for (int i = 0; i < nimg; ++i)
+    if (c->h_counters[i * NMS_COUNTER_INTS + 3]) return fail(c, SPVO_ERR_CAPACITY, "NMS survivor buffer overflow");
+  return SPVO_OK;
+}
 
 int ensure_match(spvo_ctx *c, int na, int nb) {
   const int need = std::max(na, nb);
@@ -572,8 +572,8 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
     return fail(nullptr, SPVO_ERR_INVALID, "net size %dx%d must be positive multiples of 8 (feature_detection.hpp:296)", cfg->net_height, cfg->net_width);
   if (cfg->max_batch != 1 && cfg->max_batch != 2)
     return fail(nullptr, SPVO_ERR_INVALID, "Wrong batch size (%d)", cfg->max_batch);  // nn.cpp:490
-  if (cfg->max_keypoints <= 0 || cfg->dist_thresh < 0 || cfg->border_remove < 0)
-    return fail(nullptr, SPVO_ERR_INVALID, "bad post-processing parameters");
+  if (cfg->max_keypoints <= 0 || cfg->dist_thresh < 0 || cfg->dist_thresh > NMS_PAD || cfg->border_remove < 0)
+    return fail(nullptr, SPVO_ERR_INVALID, "bad post-processing parameters (dist_thresh must be in [0, %d])", NMS_PAD);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, SPVO_ERR_DEVICE, "no HIP device visible: this library has no CPU path");
@@ -603,7 +603,7 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
     if ((rc = dev_alloc(c, &c->d_tab, (size_t)3 * (c->H + c->W)))) break;
     for (int i = 0; i < 2 && !rc; ++i) {
       NmsBuffers &b = c->nms[i].b;
-      if ((rc = dev_alloc(c, &b.state, hw))) break;
+      if ((rc = dev_alloc(c, &b.state, (size_t)(c->H + 2 * NMS_PAD) * nms_state_pitch(c->W)))) break;
       if ((rc = dev_alloc(c, &b.cand, hw))) break;
       if ((rc = dev_alloc(c, &b.counters, NMS_COUNTER_INTS))) break;
       if ((rc = dev_alloc(c, &b.surv_key, c->surv_cap))) break;

@@ -1,0 +1,60 @@
+"""world_size-2 gloo test of the multi-GPU layer (one process per GPU, pose all-gather)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from spvo import posegather, synth
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pg = posegather.PoseGather()
+    # every rank owns a different stream
+    poses = synth.ego_motion(3, seed=posegather.stream_seed(rank))
+    R, t = synth.relative_pose(poses[0], poses[1])
+    first = pg.gather(None, None)                                   # frame 0: no pose yet
+    mine = np.array([0.0, 0.01 * (rank + 1), 0.0, 1.0])
+    allp = pg.gather(mine, t)
+    q.put((rank, first, allp, t))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pose_allgather_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ts = [r[3] for r in res]
+    assert not np.allclose(ts[0], ts[1])                            # different streams per rank
+    for rank, first, allp, _ in res:
+        assert first.shape == (2, 7) and np.allclose(first, posegather.IDENTITY_POSE)
+        assert allp.shape == (2, 7)
+        for r in range(world):                                      # every rank sees every pose, in rank order
+            assert np.allclose(allp[r, :4], [0.0, 0.01 * (r + 1), 0.0, 1.0]) and np.allclose(allp[r, 4:], ts[r])
+
+
+def test_single_process_gather_is_identity_passthrough():
+    pg = posegather.PoseGather()
+    out = pg.gather([0, 0, 0, 1], [1, 2, 3])
+    assert out.shape == (1, 7) and np.allclose(out[0], [0, 0, 0, 1, 1, 2, 3])
