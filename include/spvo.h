@@ -142,6 +142,14 @@ int spvo_match(spvo_ctx *ctx, const float *desc_a, int na, const float *desc_b, 
 int spvo_match_slots(spvo_ctx *ctx, int slot_a, int slot_b, int selector, int cross_check,
                      float ratio, int32_t *train_idx, float *distance);
 
+/* Optional latency hiding for the reference's fixed call order (node.cpp:175-198: detect, then
+ * match CURR_LEFT->CURR_RIGHT, then CURR_LEFT->PREV_LEFT): when enabled, spvo_detect* enqueues
+ * those two matches (slot_l -> slot_r, slot_l -> the previous call's slot_l) with these selector
+ * parameters in the same GPU submission, and spvo_match_slots returns the stored result when it
+ * is asked for exactly that match (same slots, same slot contents, same parameters).  Results
+ * are identical with it on or off. */
+int spvo_set_prematch(spvo_ctx *ctx, int enable, int selector, int cross_check, float ratio);
+
 /* cv::triangulatePoints + convertPointsFromHomogeneous (base.cpp:211-223):
  * DLT null vector of the 4x4 system in f64, stored f32, then x/w.
  * xy_l, xy_r: [n][2] f32; xyz: [n][3] f32. */
@@ -190,6 +198,40 @@ typedef struct {
 int spvo_pnp_refine(spvo_ctx *ctx, const double P_l[12], const double P_r[12],
                     const spvo_obs *obs, int n_obs, const spvo_refine_opts *opts, double q[4],
                     double t[3], spvo_refine_summary *summary);
+
+/* The numeric body of solveStereoOdometry after the correspondence join (base.cpp:209-375) in ONE
+ * submission: triangulate -> RANSAC -> gating (base.cpp:241-272) -> residual blocks in the order
+ * of base.cpp:291-356 -> LM refinement -> "not converged => keep the RANSAC pose" (base.cpp:366-374).
+ * Identical to calling spvo_triangulate, spvo_pnp_ransac and spvo_pnp_refine in sequence with the
+ * host-side glue in between, minus the round trips. */
+typedef struct {
+  int n;                        /* joined correspondences (base.cpp:156-207)            */
+  const float *xy_cl, *xy_cr;   /* [n][2] current left / right                          */
+  const float *xy_pl, *xy_pr;   /* [n][2] previous left / right                         */
+  const float *prev_xyz;        /* [n][3] previous-frame 3-D point of each correspondence,
+                                   or NULL before the first solved frame (base.cpp:323)  */
+  const int32_t *prev_valid;    /* [n] 1 where prev_xyz[i] exists (base.cpp:326-332)     */
+  double P_l[12], P_r[12];
+  double rvec_pred[3], tvec_pred[3];   /* motion prior (hpp:156-157)                     */
+  int frame_count;              /* hpp:158                                               */
+  int refinement_degree;        /* hpp:143                                               */
+  spvo_ransac_opts ransac;
+  spvo_refine_opts refine;
+} spvo_solve_input;
+
+typedef struct {
+  double q[4], t[3];            /* cam0_prev_T_cam0_curr to invert (base.cpp:377-385); q = x,y,z,w */
+  double rvec[3], tvec[3];      /* pose after gating = the new motion prior when `accepted`       */
+  int pnp_ok;                   /* solvePnPRansac's return value                                  */
+  int accepted;                 /* do_optmz (base.cpp:243-272)                                    */
+  int refined;                  /* refinement ran, converged and was kept                         */
+  int n_inliers;
+  spvo_refine_summary summary;
+} spvo_solve_output;
+
+int spvo_solve_stereo_odometry(spvo_ctx *ctx, const spvo_solve_input *in, spvo_solve_output *out,
+                               float *xyz /* [n][3] triangulated points */,
+                               int32_t *inliers /* [n] RANSAC inliers, ascending */);
 
 /* ---------------------------------------------------------------- plumbing */
 void *spvo_stream(spvo_ctx *ctx);                 /* hipStream_t of the context */

@@ -26,8 +26,14 @@ constexpr int MATCH_QT = 32;     // queries per workgroup
 constexpr int MATCH_TT = 128;    // train rows per workgroup (4 waves x 32)
 constexpr int MATCH_KEEP = 4;    // shortlist per (query, column group)
 
-__global__ __launch_bounds__(256) void row_sqnorm_kernel(const float *__restrict__ x, int n,
+// Row counts come either from the host (n_host) or, when the call is enqueued before the
+// detector's counts are known on the host, from device memory (n_ptr).
+__device__ __forceinline__ int dev_count(int n_host, const int *n_ptr) { return n_ptr ? *n_ptr : n_host; }
+
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const float *__restrict__ x, int n_host,
+                                                         const int *__restrict__ n_ptr,
                                                          float *__restrict__ out) {
+  const int n = dev_count(n_host, n_ptr);
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (r >= n) return;
@@ -39,8 +45,10 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float *__restrict
 }
 
 // K12a. grid = (ceil(nb/128), ceil(na/32)).  shortlist[q][group][MATCH_KEEP] (train idx, -1 = none)
-__global__ __launch_bounds__(256) void match_gemm_kernel(const float *__restrict__ A, int na,
-                                                         const float *__restrict__ B, int nb,
+__global__ __launch_bounds__(256) void match_gemm_kernel(const float *__restrict__ A, int na_host,
+                                                         const int *__restrict__ na_ptr,
+                                                         const float *__restrict__ B, int nb_host,
+                                                         const int *__restrict__ nb_ptr,
                                                          const float *__restrict__ nA,
                                                          const float *__restrict__ nB,
                                                          int *__restrict__ shortlist, int groups) {
@@ -52,6 +60,16 @@ __global__ __launch_bounds__(256) void match_gemm_kernel(const float *__restrict
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q0 = blockIdx.y * MATCH_QT, t0 = blockIdx.x * MATCH_TT;
+  const int na = dev_count(na_host, na_ptr), nb = dev_count(nb_host, nb_ptr);
+  if (q0 >= na) return;
+  if (t0 >= nb) {   // empty column group: the shortlist must still say "none"
+    if (tid < MATCH_QT && q0 + tid < na) {
+      int *o = shortlist + ((size_t)(q0 + tid) * groups + blockIdx.x) * MATCH_KEEP;
+#pragma unroll
+      for (int k = 0; k < MATCH_KEEP; ++k) o[k] = -1;
+    }
+    return;
+  }
 
   f32x16 acc;
 #pragma unroll
@@ -124,13 +142,15 @@ __global__ __launch_bounds__(256) void match_gemm_kernel(const float *__restrict
 // K12b. One wave per query; lane c re-scores shortlisted candidate c exactly.
 // Handles groups*MATCH_KEEP candidates in passes of 64.
 // best[q] = {d2_0, d2_1 (f32 bits), idx0, idx1}
-__global__ __launch_bounds__(256) void match_rerank_kernel(const float *__restrict__ A, int na,
-                                                           const float *__restrict__ B, int nb,
+__global__ __launch_bounds__(256) void match_rerank_kernel(const float *__restrict__ A, int na_host,
+                                                           const int *__restrict__ na_ptr,
+                                                           const float *__restrict__ B,
                                                            const int *__restrict__ shortlist,
                                                            int groups, float *__restrict__ best_d2,
                                                            int *__restrict__ best_idx) {
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
+  const int na = dev_count(na_host, na_ptr);
   if (q >= na) return;
   const int ncand = groups * MATCH_KEEP;
   const float *a = A + (size_t)q * MATCH_D;
@@ -186,8 +206,9 @@ __global__ __launch_bounds__(256) void match_rerank_kernel(const float *__restri
 // on ties) wins; other queries that chose the same train row are dropped.
 __global__ __launch_bounds__(256) void match_cross_scatter_kernel(const float *__restrict__ best_d2,
                                                                   const int *__restrict__ best_idx,
-                                                                  int na,
+                                                                  int na_host, const int *__restrict__ na_ptr,
                                                                   unsigned long long *__restrict__ train_best) {
+  const int na = dev_count(na_host, na_ptr);
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= na) return;
   const int t = best_idx[2 * q];
@@ -198,11 +219,12 @@ __global__ __launch_bounds__(256) void match_cross_scatter_kernel(const float *_
 
 // K13. selector 0 = NN, 1 = KNN(k=2) + ratio test (base.cpp:462-473).
 __global__ __launch_bounds__(256) void match_select_kernel(const float *__restrict__ best_d2,
-                                                           const int *__restrict__ best_idx, int na,
-                                                           int selector, int cross_check, float ratio,
+                                                           const int *__restrict__ best_idx, int na_host,
+                                                           const int *__restrict__ na_ptr, int selector, int cross_check, float ratio,
                                                            const unsigned long long *__restrict__ train_best,
                                                            int *__restrict__ train_idx,
                                                            float *__restrict__ distance) {
+  const int na = dev_count(na_host, na_ptr);
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= na) return;
   const int i0 = best_idx[2 * q], i1 = best_idx[2 * q + 1];

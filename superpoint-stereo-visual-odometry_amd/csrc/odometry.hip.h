@@ -534,13 +534,24 @@ struct RefineOut {   // device, doubles: q(4) t(3) iterations converged usable i
 
 // Whole Levenberg-Marquardt loop in ONE workgroup: no host round trips.
 // All threads evaluate residual blocks; thread 0 runs the trust-region logic.
+// `ctl` (optional, device): ctl[0] = run flag, ctl[1] = n_obs -- written by solve_gate_build_kernel
+// when the whole of solveStereoOdometry is enqueued without a host round trip.
 template <int NT>
 __global__ __launch_bounds__(NT) void pnp_refine_kernel(const double *__restrict__ Pl,
                                                         const double *__restrict__ Pr,
-                                                        const ObsDev *__restrict__ obs, int n_obs,
+                                                        const ObsDev *__restrict__ obs, int n_obs_host,
+                                                        const int *__restrict__ ctl,
                                                         const double *__restrict__ start /*q,t*/,
                                                         int max_iterations, double huber_delta,
                                                         RefineOut *__restrict__ out) {
+  const int n_obs = ctl ? ctl[1] : n_obs_host;
+  if (ctl && ctl[0] == 0) {   // gated out (base.cpp:244-260) or refinement_degree == 0
+    if (threadIdx.x == 0) {
+      for (int k = 0; k < 7; ++k) out->v[k] = start[k];
+      out->v[7] = 0; out->v[8] = 0; out->v[9] = 0; out->v[10] = 0; out->v[11] = 0;
+    }
+    return;
+  }
   __shared__ double s_P[24];
   __shared__ double s_x[7], s_c[7];       // current / candidate parameters
   __shared__ double s_red[28 * (NT / 64)];
@@ -719,6 +730,96 @@ __global__ __launch_bounds__(NT) void pnp_refine_kernel(const double *__restrict
     for (int k = 0; k < 7; ++k) out->v[k] = s_x[k];
     out->v[7] = it; out->v[8] = converged; out->v[9] = usable;
     out->v[10] = initial_cost; out->v[11] = final_cost;
+  }
+}
+
+// ------------------------------------------------------------------------- fused solve glue
+// Gating (base.cpp:241-272), rvec -> quaternion (base.cpp:274-280) and the residual-block list in
+// the order base.cpp:291-356 adds it, all on the device so that triangulation, RANSAC and the
+// refinement run back to back.  One workgroup.
+//   hdr (doubles): [0..11] P_l, [12..23] P_r, [24..32] K, [33..38] prior rvec,tvec,
+//                  [39] frame_count, [40] refinement_degree, [41] max_acceleration, [42] time_interval,
+//                  [43] ignore_frame_count
+//   gate_out (doubles): [0..6] start q,t   [7] do_optmz   [8] pnp_ok   [9] accepted rvec/tvec follow in [10..15]
+__global__ __launch_bounds__(256) void solve_gate_build_kernel(const double *__restrict__ hdr,
+                                                               const double *__restrict__ ransac_result,
+                                                               const int *__restrict__ inliers,
+                                                               const float *__restrict__ xyz,
+                                                               const float *__restrict__ xy_cl,
+                                                               const float *__restrict__ xy_cr,
+                                                               const float *__restrict__ xy_pl,
+                                                               const float *__restrict__ xy_pr,
+                                                               const float *__restrict__ prev_xyz,
+                                                               const int *__restrict__ prev_valid,
+                                                               ObsDev *__restrict__ obs, int *__restrict__ ctl,
+                                                               double *__restrict__ gate_out) {
+  __shared__ int s_scan[256];
+  __shared__ int s_run, s_base;
+  const int tid = threadIdx.x;
+  const int degree = (int)hdr[40];
+  const int ninl = (int)ransac_result[7];
+  if (tid == 0) {
+    const bool ok = ransac_result[6] != 0;
+    double r[3], t[3];
+    for (int k = 0; k < 3; ++k) { r[k] = ransac_result[k]; t[k] = ransac_result[3 + k]; }
+    const double dx = t[0] - hdr[36], dy = t[1] - hdr[37], dz = t[2] - hdr[38];
+    const double acc = sqrt(dx * dx + dy * dy + dz * dz) / hdr[42];
+    int do_opt = 0;
+    if (!ok || ((int)hdr[39] > (int)hdr[43] && acc > hdr[41])) {
+      for (int k = 0; k < 3; ++k) { r[k] = hdr[33 + k]; t[k] = hdr[36 + k]; }
+    } else {
+      do_opt = 1;
+    }
+    double q[4];
+    rvec_to_quat(r, q);
+    for (int k = 0; k < 4; ++k) gate_out[k] = q[k];
+    for (int k = 0; k < 3; ++k) { gate_out[4 + k] = t[k]; gate_out[10 + k] = r[k]; gate_out[13 + k] = t[k]; }
+    gate_out[7] = do_opt;
+    gate_out[8] = ok ? 1 : 0;
+    s_run = (do_opt && degree > 0) ? 1 : 0;
+    s_base = 0;
+  }
+  __syncthreads();
+  const int run = s_run;
+  if (run) {
+    for (int base = 0; base < ninl; base += 256) {
+      const int k = base + tid;
+      int vi = 0, cnt = 0, pv = 0;
+      if (k < ninl) {
+        vi = inliers[k];
+        pv = (prev_xyz && prev_valid) ? (prev_valid[vi] != 0) : 0;
+        cnt = 1 + (degree >= 2 ? 1 : 0) + (pv ? ((degree >= 3 ? 1 : 0) + (degree >= 4 ? 1 : 0)) : 0);
+      }
+      s_scan[tid] = cnt;
+      __syncthreads();
+      for (int o = 1; o < 256; o <<= 1) {
+        const int v = (tid >= o) ? s_scan[tid - o] : 0;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+      }
+      int off = s_base + s_scan[tid] - cnt;
+      if (k < ninl) {
+        auto put = [&](const float *X, const float *uv, int cam, int inv) {
+          ObsDev o;
+          o.X[0] = X[0]; o.X[1] = X[1]; o.X[2] = X[2];
+          o.uv[0] = uv[0]; o.uv[1] = uv[1];
+          o.cam = cam; o.inverse = inv;
+          obs[off++] = o;
+        };
+        put(xyz + 3 * vi, xy_pl + 2 * vi, 0, 0);
+        if (degree >= 2) put(xyz + 3 * vi, xy_pr + 2 * vi, 1, 0);
+        if (pv && degree >= 3) put(prev_xyz + 3 * vi, xy_cl + 2 * vi, 0, 1);
+        if (pv && degree >= 4) put(prev_xyz + 3 * vi, xy_cr + 2 * vi, 1, 1);
+      }
+      __syncthreads();
+      if (tid == 255) s_base += s_scan[255];
+      __syncthreads();
+    }
+  }
+  if (tid == 0) {
+    ctl[0] = run;
+    ctl[1] = run ? s_base : 0;
   }
 }
 

@@ -157,6 +157,7 @@ struct NmsBuffers {   // per image
   int *cand;          // [H*W] row-major pixel index of each candidate
   int *counters;      // [0] n_cand, [1] n_survivors, [2] n_out, [3] overflow, [8 + l] undecided after launch l
   unsigned long long *surv_key;  // [surv_cap]
+  int *rank;          // [surv_cap], zero between uses
   int *out_xy;        // [max_kp][2]
 };
 struct NmsPair { NmsBuffers b[2]; };   // blockIdx.y / blockIdx.z selects the image
@@ -165,21 +166,86 @@ __device__ __forceinline__ unsigned long long rank_key(float conf, int x, int y,
   return ((unsigned long long)(0xFFFFFFFFu - __float_as_uint(conf)) << 32) | (unsigned)(x * H + y);
 }
 
+// K8: threshold + stream compaction.  One atomic per workgroup (wave ballots + LDS prefix), so
+// the candidate list comes out grouped by 64x4-pixel tiles: neighbours in the image are
+// neighbours in the list, which keeps most NMS decisions inside one workgroup of K10.
 __global__ __launch_bounds__(256) void nms_threshold_kernel(const float *__restrict__ heat, int H,
                                                             int W, float thresh, NmsPair np) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x = blockIdx.x * 64 + lane;
+  const int y = blockIdx.y * 4 + wave;
   const NmsBuffers nb = np.b[blockIdx.z];
-  if (x >= W || y >= H) return;
+  const bool valid = x < W && y < H;
   const int p = y * W + x;
-  const bool c = heat[(size_t)blockIdx.z * H * W + p] > thresh;  // strict, nn.cpp:203
-  nb.state[(y + NMS_PAD) * nms_state_pitch(W) + x + NMS_PAD] = c ? ST_UNDECIDED : ST_NONE;
-  if (c) nb.cand[atomicAdd(&nb.counters[0], 1)] = p;
+  const bool c = valid && heat[(size_t)blockIdx.z * H * W + p] > thresh;  // strict, nn.cpp:203
+  if (valid) nb.state[(y + NMS_PAD) * nms_state_pitch(W) + x + NMS_PAD] = c ? ST_UNDECIDED : ST_NONE;
+  const unsigned long long m = __ballot(c);
+  if (lane == 0) s_wave[wave] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    s_base = tot ? atomicAdd(&nb.counters[0], tot) : 0;
+  }
+  __syncthreads();
+  if (c) {
+    int off = s_base + __popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) off += s_wave[w];
+    nb.cand[off] = p;
+  }
 }
 
-// One thread per candidate (grid-stride).  DIST > 0: compile-time radius, every window row is
-// fetched with 3 independent aligned word loads (27 loads in flight for the 9x9 window);
-// DIST == 0: run-time radius (<= NMS_PAD), byte loads.
+// decision for one undecided candidate: returns ST_KEPT / ST_SUPPRESSED / ST_UNDECIDED
+template <int DIST>
+__device__ __forceinline__ uint8_t nms_decide(const float *__restrict__ hm, uint8_t *state, int H,
+                                              int W, int pitch, int dist_rt, int p, int x, int y) {
+  const unsigned long long key = rank_key(hm[p], x, y, H);
+  bool any_kept = false, any_better = false;
+  if constexpr (DIST > 0) {
+    constexpr int NW = (2 * DIST + 1 + 3 + 3) / 4;  // words that cover the window from an aligned start
+    const int a = (x + NMS_PAD - DIST) & ~3;        // aligned first column (padded coordinates)
+    uint32_t w[2 * DIST + 1][NW];
+#pragma unroll
+    for (int dy = 0; dy <= 2 * DIST; ++dy) {
+      const uint32_t *row = (const uint32_t *)(state + (y + NMS_PAD + dy - DIST) * pitch + a);
+#pragma unroll
+      for (int k = 0; k < NW; ++k) w[dy][k] = __builtin_nontemporal_load(row + k);
+    }
+#pragma unroll
+    for (int dy = 0; dy <= 2 * DIST; ++dy)
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        const uint32_t v = w[dy][k];
+        if (v == 0) continue;                       // four ST_NONE
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int s = (v >> (8 * b)) & 0xFF;
+          const int xx = a + 4 * k + b - NMS_PAD;
+          if (s == ST_NONE || xx < x - DIST || xx > x + DIST) continue;
+          if (s == ST_KEPT) any_kept = true;
+          else if (s == ST_UNDECIDED) {
+            const int yy = y + dy - DIST;
+            if ((yy != y || xx != x) && rank_key(hm[yy * W + xx], xx, yy, H) < key) any_better = true;
+          }
+        }
+      }
+  } else {
+    for (int yy = y - dist_rt; yy <= y + dist_rt; ++yy)
+      for (int xx = x - dist_rt; xx <= x + dist_rt; ++xx) {
+        const uint8_t s = ((volatile uint8_t *)state)[(yy + NMS_PAD) * pitch + xx + NMS_PAD];
+        if (s == ST_KEPT) any_kept = true;
+        else if (s == ST_UNDECIDED && (yy != y || xx != x) && rank_key(hm[yy * W + xx], xx, yy, H) < key) any_better = true;
+      }
+  }
+  return any_kept ? ST_SUPPRESSED : (any_better ? ST_UNDECIDED : ST_KEPT);
+}
+
+// K10.  Grid-stride over the candidate list; the first candidate of every thread (all of them
+// when n <= grid size, the usual case) is tracked in registers, so decided threads cost nothing
+// in the following in-kernel rounds.  DIST > 0: compile-time radius, every window row is fetched
+// with 3 independent aligned word loads (27 loads in flight for the 9x9 window);
+// DIST == 0: run-time radius (<= NMS_PAD).
 template <int INNER, int DIST>
 __global__ __launch_bounds__(256) void nms_round_kernel(const float *__restrict__ heat, int H, int W,
                                                         int dist_rt, NmsPair np, int launch) {
@@ -190,63 +256,48 @@ __global__ __launch_bounds__(256) void nms_round_kernel(const float *__restrict_
   const int pitch = nms_state_pitch(W);
   const int gid = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
   uint8_t *state = nb.state;
-  const int dist = DIST > 0 ? DIST : dist_rt;
+  int p0 = 0, x0 = 0, y0 = 0, sp0 = 0;
+  bool live0 = false;
+  if (gid < n) {
+    p0 = nb.cand[gid];
+    y0 = p0 / W;
+    x0 = p0 - y0 * W;
+    sp0 = (y0 + NMS_PAD) * pitch + x0 + NMS_PAD;
+    live0 = ((volatile uint8_t *)state)[sp0] == ST_UNDECIDED;
+  }
+  const bool extra = gid + stride < n;
   for (int it = 0; it < INNER; ++it) {
-    for (int i = gid; i < n; i += stride) {
+    if (live0) {
+      const uint8_t d = nms_decide<DIST>(hm, state, H, W, pitch, dist_rt, p0, x0, y0);
+      if (d != ST_UNDECIDED) {
+        ((volatile uint8_t *)state)[sp0] = d;
+        live0 = false;
+      }
+    }
+    if (extra)
+      for (int i = gid + stride; i < n; i += stride) {
+        const int p = nb.cand[i];
+        const int y = p / W, x = p - y * W;
+        const int sp = (y + NMS_PAD) * pitch + x + NMS_PAD;
+        if (((volatile uint8_t *)state)[sp] != ST_UNDECIDED) continue;
+        const uint8_t d = nms_decide<DIST>(hm, state, H, W, pitch, dist_rt, p, x, y);
+        if (d != ST_UNDECIDED) ((volatile uint8_t *)state)[sp] = d;
+      }
+    if (!__syncthreads_or(live0 || extra)) break;
+  }
+  int rem = live0 ? 1 : 0;
+  if (extra)
+    for (int i = gid + stride; i < n; i += stride) {
       const int p = nb.cand[i];
       const int y = p / W, x = p - y * W;
-      const int sp = (y + NMS_PAD) * pitch + x + NMS_PAD;
-      if (((volatile uint8_t *)state)[sp] != ST_UNDECIDED) continue;
-      const unsigned long long key = rank_key(hm[p], x, y, H);
-      bool any_kept = false, any_better = false;
-      if constexpr (DIST > 0) {
-        constexpr int NW = (2 * DIST + 1 + 3 + 3) / 4;  // words that cover the window from an aligned start
-        const int a = (x + NMS_PAD - DIST) & ~3;        // aligned first column (padded coordinates)
-        uint32_t w[2 * DIST + 1][NW];
-#pragma unroll
-        for (int dy = 0; dy <= 2 * DIST; ++dy) {
-          const uint32_t *row = (const uint32_t *)(state + (y + NMS_PAD + dy - DIST) * pitch + a);
-#pragma unroll
-          for (int k = 0; k < NW; ++k) w[dy][k] = __builtin_nontemporal_load(row + k);
-        }
-#pragma unroll
-        for (int dy = 0; dy <= 2 * DIST; ++dy)
-#pragma unroll
-          for (int k = 0; k < NW; ++k) {
-            const uint32_t v = w[dy][k];
-            if (v == 0) continue;                       // four ST_NONE
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-              const int s = (v >> (8 * b)) & 0xFF;
-              const int xx = a + 4 * k + b - NMS_PAD;
-              if (s == ST_NONE || xx < x - DIST || xx > x + DIST) continue;
-              if (s == ST_KEPT) any_kept = true;
-              else if (s == ST_UNDECIDED) {
-                const int yy = y + dy - DIST;
-                if ((yy != y || xx != x) && rank_key(hm[yy * W + xx], xx, yy, H) < key) any_better = true;
-              }
-            }
-          }
-      } else {
-        for (int yy = y - dist; yy <= y + dist; ++yy)
-          for (int xx = x - dist; xx <= x + dist; ++xx) {
-            const uint8_t s = ((volatile uint8_t *)state)[(yy + NMS_PAD) * pitch + xx + NMS_PAD];
-            if (s == ST_KEPT) any_kept = true;
-            else if (s == ST_UNDECIDED && (yy != y || xx != x) && rank_key(hm[yy * W + xx], xx, yy, H) < key) any_better = true;
-          }
-      }
-      if (any_kept) ((volatile uint8_t *)state)[sp] = ST_SUPPRESSED;
-      else if (!any_better) ((volatile uint8_t *)state)[sp] = ST_KEPT;
+      rem += (((volatile uint8_t *)state)[(y + NMS_PAD) * pitch + x + NMS_PAD] == ST_UNDECIDED) ? 1 : 0;
     }
-    __syncthreads();
+  const unsigned long long m = __ballot(rem != 0);
+  if (m) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) rem += __shfl_xor(rem, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&nb.counters[8 + launch], rem);
   }
-  int rem = 0;
-  for (int i = gid; i < n; i += stride) {
-    const int p = nb.cand[i];
-    const int y = p / W, x = p - y * W;
-    rem += (((volatile uint8_t *)state)[(y + NMS_PAD) * pitch + x + NMS_PAD] == ST_UNDECIDED) ? 1 : 0;
-  }
-  if (rem) atomicAdd(&nb.counters[8 + launch], rem);
 }
 
 __global__ __launch_bounds__(256) void nms_collect_kernel(const float *__restrict__ heat, int H,
@@ -268,30 +319,42 @@ __global__ __launch_bounds__(256) void nms_collect_kernel(const float *__restric
   }
 }
 
-// rank by counting: out position of a survivor = number of survivors with a smaller key
-__global__ __launch_bounds__(256) void nms_emit_kernel(int H, int max_kp, int surv_cap, NmsPair np) {
-  __shared__ unsigned long long tile[1024];
+// K9: rank by counting -- the output position of a survivor is the number of survivors with a
+// smaller key.  2-D decomposition: block (bi, bj) counts 256 keys against a 1024-key LDS tile.
+constexpr int RANK_TILE = 1024;
+__global__ __launch_bounds__(256) void nms_rank_kernel(int surv_cap, NmsPair np) {
+  __shared__ __attribute__((aligned(16))) unsigned long long tile[RANK_TILE];
+  const NmsBuffers nb = np.b[blockIdx.z];
+  const int n = min(nb.counters[1], surv_cap);
+  const int i = blockIdx.x * 256 + threadIdx.x, j0 = blockIdx.y * RANK_TILE;
+  if (blockIdx.x * 256 >= n || j0 >= n) return;
+  for (int t = threadIdx.x; t < RANK_TILE; t += 256) tile[t] = (j0 + t < n) ? nb.surv_key[j0 + t] : ~0ull;
+  __syncthreads();
+  if (i >= n) return;
+  const unsigned long long key = nb.surv_key[i];
+  int cnt = 0;
+  const ulonglong2 *t2 = (const ulonglong2 *)tile;
+#pragma unroll 8
+  for (int t = 0; t < RANK_TILE / 2; ++t) {
+    const ulonglong2 v = t2[t];
+    cnt += (v.x < key ? 1 : 0) + (v.y < key ? 1 : 0);
+  }
+  if (cnt) atomicAdd(&nb.rank[i], cnt);
+}
+
+__global__ __launch_bounds__(256) void nms_write_kernel(int H, int max_kp, int surv_cap, NmsPair np) {
   const NmsBuffers nb = np.b[blockIdx.y];
   const int n = min(nb.counters[1], surv_cap);
-  if (blockIdx.x * 256 >= n && blockIdx.x > 0) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
-  const unsigned long long key = (i < n) ? nb.surv_key[i] : 0ull;
-  int rank = 0;
-  for (int base = 0; base < n; base += 1024) {
-    __syncthreads();
-    for (int t = threadIdx.x; t < 1024; t += 256) tile[t] = (base + t < n) ? nb.surv_key[base + t] : ~0ull;
-    __syncthreads();
-    if (i < n) {
-      const int m = min(1024, n - base);
-      for (int t = 0; t < m; ++t) rank += (tile[t] < key) ? 1 : 0;
-    }
-  }
-  if (i < n && rank < max_kp) {
-    const unsigned cm = (unsigned)(key & 0xFFFFFFFFull);
+  if (i == 0) nb.counters[2] = min(n, max_kp);
+  if (i >= n) return;
+  const int rank = nb.rank[i];
+  nb.rank[i] = 0;
+  if (rank < max_kp) {
+    const unsigned cm = (unsigned)(nb.surv_key[i] & 0xFFFFFFFFull);
     nb.out_xy[2 * rank + 0] = (int)(cm / (unsigned)H);
     nb.out_xy[2 * rank + 1] = (int)(cm % (unsigned)H);
   }
-  if (i == 0) nb.counters[2] = min(n, max_kp);
 }
 
 // ---------------------------------------------------------------------------
@@ -306,15 +369,22 @@ __global__ __launch_bounds__(256) void sample_desc_kernel(const float *__restric
                                                           const int *__restrict__ n_ptr, int n_fixed,
                                                           int H, int W, int Hc, int Wc,
                                                           float *__restrict__ out,
-                                                          float *__restrict__ out_xy_f32) {
+                                                          float *__restrict__ out_xy_f32,
+                                                          int *__restrict__ out_xy_i32,
+                                                          int *__restrict__ out_n) {
   const int n = n_ptr ? *n_ptr : n_fixed;
   const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
+  if (out_n && blockIdx.x == 0 && threadIdx.x == 0) *out_n = n;
   if (k >= n) return;
   const int col = xy[2 * k], row = xy[2 * k + 1];
   if (out_xy_f32 && lane == 0) {
     out_xy_f32[2 * k] = (float)col;
     out_xy_f32[2 * k + 1] = (float)row;
+  }
+  if (out_xy_i32 && lane == 0) {
+    out_xy_i32[2 * k] = col;
+    out_xy_i32[2 * k + 1] = row;
   }
   const float row8 = __fmul_rn(__fdiv_rn((float)row, (float)(H - 1)), (float)(Hc - 1));
   const float col8 = __fmul_rn(__fdiv_rn((float)col, (float)(W - 1)), (float)(Wc - 1));

@@ -56,6 +56,24 @@ struct FeatureSlot {
   int *d_xy = nullptr;      // [cap][2] int
   float *d_xyf = nullptr;   // [cap][2] float
   float *d_desc = nullptr;  // [cap][256]
+  int *d_n = nullptr;       // device copy of n (read by kernels enqueued before the host knows n)
+  unsigned long long gen = 0;  // bumped whenever the slot is rewritten
+};
+
+// matches enqueued together with the detector (spvo_set_prematch); results live in pinned memory
+struct MatchCache {
+  bool valid = false;
+  int slot_a = -1, slot_b = -1, selector = 0, cross = 0;
+  float ratio = 0.f;
+  unsigned long long gen_a = 0, gen_b = 0;
+  int32_t *h_idx = nullptr;   // pinned [cap]
+  float *h_dist = nullptr;    // pinned [cap]
+};
+
+struct MatchScratch {         // one set per concurrently enqueued match
+  float *d_na = nullptr, *d_nb = nullptr, *d_best_d2 = nullptr, *d_dist = nullptr;
+  int *d_short = nullptr, *d_best_idx = nullptr, *d_train_idx = nullptr;
+  unsigned long long *d_train_best = nullptr;
 };
 
 struct NmsImage {
@@ -91,12 +109,17 @@ struct spvo_ctx {
   FeatureSlot slots[4];
   int *d_xy_tmp = nullptr;       // [cap][2] for spvo_sample_descriptors
   float *d_desc_tmp = nullptr;   // [cap][256]
+  float *h_xy = nullptr;         // pinned [2][cap][2]
+  int last_slot_l = -1;          // left slot of the previous spvo_detect* call (temporal partner)
 
   // matching scratch
   int match_cap = 0;
-  float *d_ma = nullptr, *d_mb = nullptr, *d_na = nullptr, *d_nb = nullptr, *d_best_d2 = nullptr, *d_dist = nullptr;
-  int *d_short = nullptr, *d_best_idx = nullptr, *d_train_idx = nullptr;
-  unsigned long long *d_train_best = nullptr;
+  float *d_ma = nullptr, *d_mb = nullptr;
+  MatchScratch ms[2];
+  MatchCache mcache[2];
+  bool prematch = false;
+  int pm_selector = SPVO_SELECT_KNN, pm_cross = 0;
+  float pm_ratio = 0.8f;
 
   // odometry scratch
   int odo_cap = 0, ransac_cap = 0, obs_cap = 0;
@@ -105,6 +128,12 @@ struct spvo_ctx {
   RansacWork rw{};
   ObsDev *d_obs = nullptr;
   RefineOut *d_refine = nullptr;
+  // fused solve: one packed input, one packed result
+  int solve_cap = 0;
+  char *d_solve_in = nullptr, *h_solve_in = nullptr;    // 64 doubles + 12*cap words
+  double *d_solve_res = nullptr, *h_solve_res = nullptr;  // ransac[8] gate[16] refine[12] + pad
+  char *d_solve_o = nullptr, *h_solve_o = nullptr;      // xyz [3n] floats, inliers [n] ints
+  int *d_ctl = nullptr;
 
   // profiling
   bool prof = false;
@@ -424,28 +453,33 @@ int launch_nms_batch(spvo_ctx *c, int nimg, bool first, int n_launch) {
       hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 0>), dim3(NMS_GRID, nimg), dim3(256), 0, c->stream, c->d_heat, c->H, c->W, c->cfg.dist_thresh, np, l);
   }
   hipLaunchKernelGGL(nms_collect_kernel, dim3(NMS_GRID, nimg), dim3(256), 0, c->stream, c->d_heat, c->H, c->W, c->cfg.border_remove, c->surv_cap, np);
-  hipLaunchKernelGGL(nms_emit_kernel, dim3((c->surv_cap + 255) / 256, nimg), dim3(256), 0, c->stream, c->H, c->cfg.max_keypoints, c->surv_cap, np);
+  hipLaunchKernelGGL(nms_rank_kernel, dim3((c->surv_cap + 255) / 256, (c->surv_cap + RANK_TILE - 1) / RANK_TILE, nimg), dim3(256), 0, c->stream, c->surv_cap, np);
+  hipLaunchKernelGGL(nms_write_kernel, dim3((c->surv_cap + 255) / 256, nimg), dim3(256), 0, c->stream, c->H, c->cfg.max_keypoints, c->surv_cap, np);
   HIP_TRY(c, hipGetLastError());
   for (int i = 0; i < nimg; ++i)
     HIP_TRY(c, hipMemcpyAsync(c->h_counters + i * NMS_COUNTER_INTS, c->nms[i].b.counters, NMS_COUNTER_INTS * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   return SPVO_OK;
 }
 
-// Runs the whole of processOneHeatmap for images [0, nimg); counters end up in h_counters; syncs.
-// Real heat maps settle in 3-4 rounds; adversarial ones (e.g. a constant image: one decision
-// chain across the whole picture) simply take more batches -- every launch decides at least
-// the best undecided candidate, so the loop terminates.
-int run_nms(spvo_ctx *c, int nimg) {
-  int rc = launch_nms_batch(c, nimg, true, 3);
-  if (rc) return rc;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  int last = 3;
+// processOneHeatmap for images [0, nimg).  Real heat maps settle in 2-3 launches of 4 in-kernel
+// rounds; adversarial ones (e.g. a constant image: one decision chain across the whole picture)
+// simply take more batches -- every launch decides at least the best undecided candidate, so the
+// loop terminates.  nms_enqueue only submits; nms_settle runs after the caller's sync and returns
+// 1 if it had to redo work (the caller then re-runs what depends on the keypoints).
+constexpr int NMS_FIRST = 3;
+
+int nms_enqueue(spvo_ctx *c, int nimg) { return launch_nms_batch(c, nimg, true, NMS_FIRST); }
+
+int nms_settle(spvo_ctx *c, int nimg, bool *redone) {
+  int last = NMS_FIRST;
+  *redone = false;
   for (;;) {
     bool pending = false;
     for (int i = 0; i < nimg; ++i) pending |= c->h_counters[i * NMS_COUNTER_INTS + 8 + last - 1] != 0;
     if (!pending) break;
+    *redone = true;
     last = NMS_MAX_LAUNCH;
-    rc = launch_nms_batch(c, nimg, false, last);
+    int rc = launch_nms_batch(c, nimg, false, last);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
@@ -454,25 +488,69 @@ int run_nms(spvo_ctx *c, int nimg) {
   return SPVO_OK;
 }
 
+int run_nms(spvo_ctx *c, int nimg) {
+  int rc = nms_enqueue(c, nimg);
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  bool redone;
+  return nms_settle(c, nimg, &redone);
+}
+
 int ensure_match(spvo_ctx *c, int na, int nb) {
   const int need = std::max(na, nb);
   if (need <= c->match_cap) return SPVO_OK;
   const int cap = std::max(need, std::max(c->cfg.max_keypoints, 1024));
-  for (void *p : {(void *)c->d_ma, (void *)c->d_mb, (void *)c->d_na, (void *)c->d_nb, (void *)c->d_best_d2, (void *)c->d_dist, (void *)c->d_short, (void *)c->d_best_idx, (void *)c->d_train_idx, (void *)c->d_train_best})
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (void *p : {(void *)c->d_ma, (void *)c->d_mb})
     if (p) (void)hipFree(p);
+  for (auto &m : c->ms)
+    for (void *p : {(void *)m.d_na, (void *)m.d_nb, (void *)m.d_best_d2, (void *)m.d_dist, (void *)m.d_short, (void *)m.d_best_idx, (void *)m.d_train_idx, (void *)m.d_train_best})
+      if (p) (void)hipFree(p);
   const int groups = (cap + MATCH_TT - 1) / MATCH_TT;
   int rc;
   if ((rc = dev_alloc(c, &c->d_ma, (size_t)cap * MATCH_D))) return rc;
   if ((rc = dev_alloc(c, &c->d_mb, (size_t)cap * MATCH_D))) return rc;
-  if ((rc = dev_alloc(c, &c->d_na, cap))) return rc;
-  if ((rc = dev_alloc(c, &c->d_nb, cap))) return rc;
-  if ((rc = dev_alloc(c, &c->d_best_d2, (size_t)cap * 2))) return rc;
-  if ((rc = dev_alloc(c, &c->d_dist, cap))) return rc;
-  if ((rc = dev_alloc(c, &c->d_short, (size_t)cap * groups * MATCH_KEEP))) return rc;
-  if ((rc = dev_alloc(c, &c->d_best_idx, (size_t)cap * 2))) return rc;
-  if ((rc = dev_alloc(c, &c->d_train_idx, cap))) return rc;
-  if ((rc = dev_alloc(c, &c->d_train_best, cap))) return rc;
+  for (auto &m : c->ms) {
+    if ((rc = dev_alloc(c, &m.d_na, cap))) return rc;
+    if ((rc = dev_alloc(c, &m.d_nb, cap))) return rc;
+    if ((rc = dev_alloc(c, &m.d_best_d2, (size_t)cap * 2))) return rc;
+    if ((rc = dev_alloc(c, &m.d_dist, cap))) return rc;
+    if ((rc = dev_alloc(c, &m.d_short, (size_t)cap * groups * MATCH_KEEP))) return rc;
+    if ((rc = dev_alloc(c, &m.d_best_idx, (size_t)cap * 2))) return rc;
+    if ((rc = dev_alloc(c, &m.d_train_idx, cap))) return rc;
+    if ((rc = dev_alloc(c, &m.d_train_best, cap))) return rc;
+  }
   c->match_cap = cap;
+  return SPVO_OK;
+}
+
+// Enqueue one match.  (na, nb) are upper bounds when na_ptr / nb_ptr point at device counts.
+// Results (train_idx, distance) are copied to `out_idx` / `out_dist` (host) asynchronously.
+int enqueue_match(spvo_ctx *c, MatchScratch &m, const float *dA, int na, const int *na_ptr, const float *dB, int nb, const int *nb_ptr, int selector,
+                  int cross_check, float ratio, int32_t *out_idx, float *out_dist) {
+  const int groups = (nb + MATCH_TT - 1) / MATCH_TT;
+  ScopedStage st(c, stage_id(c, "match"), 2.0 * na * nb * MATCH_D, 4.0 * (na + nb) * MATCH_D);
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((na + 3) / 4), dim3(256), 0, c->stream, dA, na, na_ptr, m.d_na);
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((nb + 3) / 4), dim3(256), 0, c->stream, dB, nb, nb_ptr, m.d_nb);
+  const size_t lds = (size_t)(MATCH_QT + MATCH_TT) * 129 * sizeof(float);
+  static bool attr[64] = {};
+  if (!attr[c->cfg.device & 63]) {
+    HIP_TRY(c, hipFuncSetAttribute((const void *)match_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr[c->cfg.device & 63] = true;
+  }
+  {
+    ScopedStage sg(c, stage_id(c, "match_gemm"), 2.0 * na * nb * MATCH_D, 4.0 * (na + nb) * MATCH_D);
+    hipLaunchKernelGGL(match_gemm_kernel, dim3(groups, (na + MATCH_QT - 1) / MATCH_QT), dim3(256), lds, c->stream, dA, na, na_ptr, dB, nb, nb_ptr, m.d_na, m.d_nb, m.d_short, groups);
+  }
+  hipLaunchKernelGGL(match_rerank_kernel, dim3((na + 3) / 4), dim3(256), 0, c->stream, dA, na, na_ptr, dB, m.d_short, groups, m.d_best_d2, m.d_best_idx);
+  if (selector == SPVO_SELECT_NN && cross_check) {
+    HIP_TRY(c, hipMemsetAsync(m.d_train_best, 0xFF, (size_t)nb * sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(match_cross_scatter_kernel, dim3((na + 255) / 256), dim3(256), 0, c->stream, m.d_best_d2, m.d_best_idx, na, na_ptr, m.d_train_best);
+  }
+  hipLaunchKernelGGL(match_select_kernel, dim3((na + 255) / 256), dim3(256), 0, c->stream, m.d_best_d2, m.d_best_idx, na, na_ptr, selector, cross_check, ratio, m.d_train_best, m.d_train_idx, m.d_dist);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(out_idx, m.d_train_idx, (size_t)na * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(out_dist, m.d_dist, (size_t)na * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   return SPVO_OK;
 }
 
@@ -482,31 +560,8 @@ int run_match(spvo_ctx *c, const float *dA, int na, const float *dB, int nb, int
     for (int i = 0; i < na; ++i) { train_idx[i] = -1; distance[i] = 0.f; }
     return SPVO_OK;
   }
-  const int groups = (nb + MATCH_TT - 1) / MATCH_TT;
-  {
-    ScopedStage st(c, stage_id(c, "match"), 2.0 * na * nb * MATCH_D, 4.0 * (na + nb) * MATCH_D);
-    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((na + 3) / 4), dim3(256), 0, c->stream, dA, na, c->d_na);
-    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((nb + 3) / 4), dim3(256), 0, c->stream, dB, nb, c->d_nb);
-    const size_t lds = (size_t)(MATCH_QT + MATCH_TT) * 129 * sizeof(float);
-    static bool attr[64] = {};
-    if (!attr[c->cfg.device & 63]) {
-      HIP_TRY(c, hipFuncSetAttribute((const void *)match_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr[c->cfg.device & 63] = true;
-    }
-    {
-      ScopedStage sg(c, stage_id(c, "match_gemm"), 2.0 * na * nb * MATCH_D, 4.0 * (na + nb) * MATCH_D);
-      hipLaunchKernelGGL(match_gemm_kernel, dim3(groups, (na + MATCH_QT - 1) / MATCH_QT), dim3(256), lds, c->stream, dA, na, dB, nb, c->d_na, c->d_nb, c->d_short, groups);
-    }
-    hipLaunchKernelGGL(match_rerank_kernel, dim3((na + 3) / 4), dim3(256), 0, c->stream, dA, na, dB, nb, c->d_short, groups, c->d_best_d2, c->d_best_idx);
-    if (selector == SPVO_SELECT_NN && cross_check) {
-      HIP_TRY(c, hipMemsetAsync(c->d_train_best, 0xFF, (size_t)nb * sizeof(unsigned long long), c->stream));
-      hipLaunchKernelGGL(match_cross_scatter_kernel, dim3((na + 255) / 256), dim3(256), 0, c->stream, c->d_best_d2, c->d_best_idx, na, c->d_train_best);
-    }
-    hipLaunchKernelGGL(match_select_kernel, dim3((na + 255) / 256), dim3(256), 0, c->stream, c->d_best_d2, c->d_best_idx, na, selector, cross_check, ratio, c->d_train_best, c->d_train_idx, c->d_dist);
-    HIP_TRY(c, hipGetLastError());
-  }
-  HIP_TRY(c, hipMemcpyAsync(train_idx, c->d_train_idx, (size_t)na * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(distance, c->d_dist, (size_t)na * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  int rc = enqueue_match(c, c->ms[0], dA, na, nullptr, dB, nb, nullptr, selector, cross_check, ratio, train_idx, distance);
+  if (rc) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return SPVO_OK;
 }
@@ -607,6 +662,7 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
       if ((rc = dev_alloc(c, &b.cand, hw))) break;
       if ((rc = dev_alloc(c, &b.counters, NMS_COUNTER_INTS))) break;
       if ((rc = dev_alloc(c, &b.surv_key, c->surv_cap))) break;
+      if ((rc = dev_alloc(c, &b.rank, c->surv_cap))) break;
       if ((rc = dev_alloc(c, &b.out_xy, (size_t)cap * 2))) break;
     }
     if (rc) break;
@@ -614,11 +670,20 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
       if ((rc = dev_alloc(c, &c->slots[i].d_xy, (size_t)cap * 2))) break;
       if ((rc = dev_alloc(c, &c->slots[i].d_xyf, (size_t)cap * 2))) break;
       if ((rc = dev_alloc(c, &c->slots[i].d_desc, (size_t)cap * 256))) break;
+      if ((rc = dev_alloc(c, &c->slots[i].d_n, 1))) break;
     }
     if (rc) break;
     if ((rc = dev_alloc(c, &c->d_xy_tmp, (size_t)cap * 2))) break;
     if ((rc = dev_alloc(c, &c->d_desc_tmp, (size_t)cap * 256))) break;
-    if (hipHostMalloc((void **)&c->h_counters, 2 * NMS_COUNTER_INTS * sizeof(int)) != hipSuccess) { rc = fail(c, SPVO_ERR_DEVICE, "hipHostMalloc failed"); break; }
+    if (hipHostMalloc((void **)&c->h_counters, 2 * NMS_COUNTER_INTS * sizeof(int)) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_xy, (size_t)2 * cap * 2 * sizeof(float)) != hipSuccess) { rc = fail(c, SPVO_ERR_DEVICE, "hipHostMalloc failed"); break; }
+    for (auto &m : c->mcache)
+      if (hipHostMalloc((void **)&m.h_idx, (size_t)cap * sizeof(int32_t)) != hipSuccess || hipHostMalloc((void **)&m.h_dist, (size_t)cap * sizeof(float)) != hipSuccess) {
+        rc = fail(c, SPVO_ERR_DEVICE, "hipHostMalloc failed");
+        break;
+      }
+    if (rc) break;
+    if ((rc = ensure_match(c, cap, cap))) break;
   } while (0);
   if (rc) {
     g_error = c->error;
@@ -639,19 +704,28 @@ void spvo_destroy(spvo_ctx *c) {
   for (auto &t : c->tensors) if (t.d) (void)hipFree(t.d);
   for (auto &o : c->ops) { if (o.d_w) (void)hipFree(o.d_w); if (o.d_b) (void)hipFree(o.d_b); }
   void *ptrs[] = {c->d_dense_in, c->d_det_dense, c->d_heat, c->d_resized, c->d_tab, c->d_img[0], c->d_img[1], c->d_xy_tmp, c->d_desc_tmp,
-                  c->d_ma, c->d_mb, c->d_na, c->d_nb, c->d_best_d2, c->d_dist, c->d_short, c->d_best_idx, c->d_train_idx, c->d_train_best,
+                  c->d_ma, c->d_mb, c->ms[0].d_na, c->ms[0].d_nb, c->ms[0].d_best_d2, c->ms[0].d_dist, c->ms[0].d_short, c->ms[0].d_best_idx,
+                  c->ms[0].d_train_idx, c->ms[0].d_train_best, c->ms[1].d_na, c->ms[1].d_nb, c->ms[1].d_best_d2, c->ms[1].d_dist, c->ms[1].d_short,
+                  c->ms[1].d_best_idx, c->ms[1].d_train_idx, c->ms[1].d_train_best,
                   c->d_P, c->d_pts_a, c->d_pts_b, c->d_xyz, c->rw.counts, c->rw.poses, c->rw.result, c->rw.inliers, c->d_obs, c->d_refine};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (int i = 0; i < 2; ++i) {
     NmsBuffers &b = c->nms[i].b;
-    void *q[] = {b.state, b.cand, b.counters, b.surv_key, b.out_xy};
+    void *q[] = {b.state, b.cand, b.counters, b.surv_key, b.rank, b.out_xy};
     for (void *p : q) if (p) (void)hipFree(p);
   }
   for (int i = 0; i < 4; ++i) {
-    void *q[] = {c->slots[i].d_xy, c->slots[i].d_xyf, c->slots[i].d_desc};
+    void *q[] = {c->slots[i].d_xy, c->slots[i].d_xyf, c->slots[i].d_desc, c->slots[i].d_n};
     for (void *p : q) if (p) (void)hipFree(p);
   }
   if (c->h_counters) (void)hipHostFree(c->h_counters);
+  if (c->h_xy) (void)hipHostFree(c->h_xy);
+  for (void *hp : {(void *)c->h_solve_in, (void *)c->h_solve_res, (void *)c->h_solve_o}) if (hp) (void)hipHostFree(hp);
+  for (void *dp : {(void *)c->d_solve_in, (void *)c->d_solve_res, (void *)c->d_solve_o, (void *)c->d_ctl}) if (dp) (void)hipFree(dp);
+  for (auto &m : c->mcache) {
+    if (m.h_idx) (void)hipHostFree(m.h_idx);
+    if (m.h_dist) (void)hipHostFree(m.h_dist);
+  }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -881,66 +955,109 @@ int spvo_sample_descriptors(spvo_ctx *c, const float *desc_nhwc, const int32_t *
   const Tensor &ts = c->tensors[c->t_desc];
   HIP_TRY(c, hipMemcpyAsync(ts.d, desc_nhwc, ts.per_image * sizeof(float), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->d_xy_tmp, xy, (size_t)n * 2 * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(sample_desc_kernel, dim3((n + 3) / 4), dim3(256), 0, c->stream, ts.d, c->d_xy_tmp, (const int *)nullptr, n, c->H, c->W, c->Hc, c->Wc, c->d_desc_tmp, (float *)nullptr);
+  hipLaunchKernelGGL(sample_desc_kernel, dim3((n + 3) / 4), dim3(256), 0, c->stream, ts.d, c->d_xy_tmp, (const int *)nullptr, n, c->H, c->W, c->Hc, c->Wc, c->d_desc_tmp, (float *)nullptr, (int *)nullptr, (int *)nullptr);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(out, c->d_desc_tmp, (size_t)n * 256 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return SPVO_OK;
 }
 
+static int enqueue_sample(spvo_ctx *c, const int slots[2]) {
+  const Tensor &ts = c->tensors[c->t_desc];
+  ScopedStage ss(c, stage_id(c, "sample"));
+  const int cap = c->cfg.max_keypoints;
+  for (int i = 0; i < 2; ++i) {
+    FeatureSlot &s = c->slots[slots[i]];
+    // the keypoint count is read from the NMS counters on the device: no host round trip
+    hipLaunchKernelGGL(sample_desc_kernel, dim3((cap + 3) / 4), dim3(256), 0, c->stream, ts.d + (size_t)i * ts.per_image, c->nms[i].b.out_xy,
+                       (const int *)(c->nms[i].b.counters + 2), 0, c->H, c->W, c->Hc, c->Wc, s.d_desc, s.d_xyf, s.d_xy, s.d_n);
+    HIP_TRY(c, hipMemcpyAsync(c->h_xy + (size_t)i * cap * 2, s.d_xyf, (size_t)cap * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(c, hipGetLastError());
+  return SPVO_OK;
+}
+
+static int enqueue_prematch(spvo_ctx *c, int slot_l, int slot_r, int prev_l) {
+  const int cap = c->cfg.max_keypoints;
+  const int partner[2] = {slot_r, prev_l};
+  for (int k = 0; k < 2; ++k) {
+    MatchCache &mc = c->mcache[k];
+    mc.valid = false;
+    if (partner[k] < 0) continue;
+    FeatureSlot &a = c->slots[slot_l], &b = c->slots[partner[k]];
+    int rc = enqueue_match(c, c->ms[k], a.d_desc, cap, a.d_n, b.d_desc, cap, b.d_n, c->pm_selector, c->pm_cross, c->pm_ratio, mc.h_idx, mc.h_dist);
+    if (rc) return rc;
+    mc.slot_a = slot_l; mc.slot_b = partner[k];
+    mc.selector = c->pm_selector; mc.cross = c->pm_cross; mc.ratio = c->pm_ratio;
+    mc.valid = true;   // generations are stamped after the slots' counts are known
+  }
+  return SPVO_OK;
+}
+
 static int detect_common(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, int rows, int cols, size_t stride, double P_l[12], double P_r[12],
                          int slot_l, int slot_r, spvo_features *out_l, spvo_features *out_r, uint8_t *resized_l, uint8_t *resized_r) {
   if (slot_l < 0 || slot_l > 3 || slot_r < 0 || slot_r > 3 || slot_l == slot_r) return fail(c, SPVO_ERR_INVALID, "bad feature slots %d, %d", slot_l, slot_r);
+  if (c->cfg.max_batch != 2) return fail(c, SPVO_ERR_INVALID, "max_batch == 1 detect path is not built yet; use max_batch = 2");
   const CropGeom g = crop_geometry(rows, cols, c->H, c->W);
   const Tensor &td = c->tensors[c->t_det];
-  const Tensor &ts = c->tensors[c->t_desc];
   const uint8_t *srcs[2] = {d_l, d_r};
+  const int slots[2] = {slot_l, slot_r};
+  const int cap = c->cfg.max_keypoints;
+  // temporal partner = the left slot of the previous call, if it survives this call
+  int prev_l = c->last_slot_l;
+  if (prev_l == slot_l || prev_l == slot_r || (prev_l >= 0 && c->slots[prev_l].gen == 0)) prev_l = -1;
+  for (auto &mc : c->mcache) mc.valid = false;
+  // ---- everything below is enqueued without a host round trip; ONE sync at the end
   {
     ScopedStage st(c, stage_id(c, "detect"));
     {
       ScopedStage sp(c, stage_id(c, "preprocess"));
       for (int i = 0; i < 2; ++i) { int rc = launch_preprocess(c, srcs[i], rows, cols, stride, g, i); if (rc) return rc; }
     }
-    if (c->cfg.max_batch == 2) {
-      int rc = run_network(c, 2);
-      if (rc) return rc;
+    int rc = run_network(c, 2);
+    if (rc) return rc;
+    {
       ScopedStage sh(c, stage_id(c, "heatmap"));
       hipLaunchKernelGGL(heatmap_kernel<true>, dim3((c->Wc + 63) / 64, (c->Hc + 3) / 4, 2), dim3(256), 0, c->stream, td.d, c->d_heat, c->Hc, c->Wc, td.hp, td.wp);
-    } else {
-      // model_batch_size_ == 1 (nn.cpp:468-475): left then right through the same buffers
-      return fail(c, SPVO_ERR_INVALID, "max_batch == 1 detect path is not built yet; use max_batch = 2");
+      HIP_TRY(c, hipGetLastError());
     }
-    HIP_TRY(c, hipGetLastError());
     {
       ScopedStage sn(c, stage_id(c, "nms"));
-      int rc = run_nms(c, 2);
-      if (rc) return rc;
+      if ((rc = nms_enqueue(c, 2))) return rc;
     }
-    const int slots[2] = {slot_l, slot_r};
-    ScopedStage ss(c, stage_id(c, "sample"));
-    for (int i = 0; i < 2; ++i) {
-      FeatureSlot &s = c->slots[slots[i]];
-      s.n = c->h_counters[i * NMS_COUNTER_INTS + 2];
-      if (s.n > 0) {
-        HIP_TRY(c, hipMemcpyAsync(s.d_xy, c->nms[i].b.out_xy, (size_t)s.n * 2 * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
-        hipLaunchKernelGGL(sample_desc_kernel, dim3((s.n + 3) / 4), dim3(256), 0, c->stream, ts.d + (size_t)i * ts.per_image, s.d_xy, (const int *)nullptr, s.n, c->H, c->W, c->Hc, c->Wc, s.d_desc, s.d_xyf);
-      }
-    }
-    HIP_TRY(c, hipGetLastError());
+    if ((rc = enqueue_sample(c, slots))) return rc;
   }
-  spvo_features *outs[2] = {out_l, out_r};
-  const int slots[2] = {slot_l, slot_r};
-  for (int i = 0; i < 2; ++i) {
-    FeatureSlot &s = c->slots[slots[i]];
-    if (!outs[i]) continue;
-    outs[i]->n = s.n;
-    if (s.n > 0 && outs[i]->xy) HIP_TRY(c, hipMemcpyAsync(outs[i]->xy, s.d_xyf, (size_t)s.n * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    if (s.n > 0 && outs[i]->desc) HIP_TRY(c, hipMemcpyAsync(outs[i]->desc, s.d_desc, (size_t)s.n * 256 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  }
+  if (c->prematch) { int rc = enqueue_prematch(c, slot_l, slot_r, prev_l); if (rc) return rc; }
   uint8_t *res[2] = {resized_l, resized_r};
   for (int i = 0; i < 2; ++i)
     if (res[i]) HIP_TRY(c, hipMemcpyAsync(res[i], c->d_resized + (size_t)i * c->H * c->W, (size_t)c->H * c->W, hipMemcpyDeviceToHost, c->stream));
+  spvo_features *outs[2] = {out_l, out_r};
+  // descriptors: the count is not known yet, copy the full slot (1000 x 256 floats)
+  for (int i = 0; i < 2; ++i)
+    if (outs[i] && outs[i]->desc) HIP_TRY(c, hipMemcpyAsync(outs[i]->desc, c->slots[slots[i]].d_desc, (size_t)cap * 256 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  bool redone = false;
+  int rc = nms_settle(c, 2, &redone);
+  if (rc) return rc;
+  if (redone) {   // rare: the keypoints changed after the first batch -> redo what depends on them
+    if ((rc = enqueue_sample(c, slots))) return rc;
+    if (c->prematch && (rc = enqueue_prematch(c, slot_l, slot_r, prev_l))) return rc;
+    for (int i = 0; i < 2; ++i)
+      if (outs[i] && outs[i]->desc) HIP_TRY(c, hipMemcpyAsync(outs[i]->desc, c->slots[slots[i]].d_desc, (size_t)cap * 256 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  for (int i = 0; i < 2; ++i) {
+    FeatureSlot &s = c->slots[slots[i]];
+    s.n = c->h_counters[i * NMS_COUNTER_INTS + 2];
+    s.gen += 1;
+    if (outs[i]) {
+      outs[i]->n = s.n;
+      if (outs[i]->xy && s.n > 0) std::memcpy(outs[i]->xy, c->h_xy + (size_t)i * cap * 2, (size_t)s.n * 2 * sizeof(float));
+    }
+  }
+  for (auto &mc : c->mcache)
+    if (mc.valid) { mc.gen_a = c->slots[mc.slot_a].gen; mc.gen_b = c->slots[mc.slot_b].gen; }
+  c->last_slot_l = slot_l;
   fix_projection(P_l, g, rows, cols, c->cfg.bug_compat_p);
   fix_projection(P_r, g, rows, cols, c->cfg.bug_compat_p);
   return SPVO_OK;
@@ -986,10 +1103,30 @@ int spvo_match_slots(spvo_ctx *c, int slot_a, int slot_b, int selector, int cros
   if (selector != SPVO_SELECT_NN && selector != SPVO_SELECT_KNN) return fail(c, SPVO_ERR_INVALID, "bad selector");
   const FeatureSlot &a = c->slots[slot_a], &b = c->slots[slot_b];
   if (a.n > 0 && (!train_idx || !distance)) return fail(c, SPVO_ERR_INVALID, "null output");
+  for (const auto &mc : c->mcache)   // already computed alongside the detector (spvo_set_prematch)?
+    if (mc.valid && mc.slot_a == slot_a && mc.slot_b == slot_b && mc.gen_a == a.gen && mc.gen_b == b.gen && mc.selector == selector &&
+        mc.cross == (cross_check ? 1 : 0) && mc.ratio == ratio) {
+      if (a.n > 0) {
+        std::memcpy(train_idx, mc.h_idx, (size_t)a.n * sizeof(int32_t));
+        std::memcpy(distance, mc.h_dist, (size_t)a.n * sizeof(float));
+      }
+      return SPVO_OK;
+    }
   HIP_TRY(c, hipSetDevice(c->cfg.device));
   int rc = ensure_match(c, a.n, b.n);
   if (rc) return rc;
-  return run_match(c, a.d_desc, a.n, b.d_desc, b.n, selector, cross_check, ratio, train_idx, distance);
+  return run_match(c, a.d_desc, a.n, b.d_desc, b.n, selector, cross_check ? 1 : 0, ratio, train_idx, distance);
+}
+
+int spvo_set_prematch(spvo_ctx *c, int enable, int selector, int cross_check, float ratio) {
+  if (!c) return fail(c, SPVO_ERR_INVALID, "null context");
+  if (selector != SPVO_SELECT_NN && selector != SPVO_SELECT_KNN) return fail(c, SPVO_ERR_INVALID, "bad selector");
+  c->prematch = enable != 0;
+  c->pm_selector = selector;
+  c->pm_cross = cross_check ? 1 : 0;
+  c->pm_ratio = ratio;
+  for (auto &mc : c->mcache) mc.valid = false;
+  return SPVO_OK;
 }
 
 int spvo_triangulate(spvo_ctx *c, const double P_l[12], const double P_r[12], const float *xy_l, const float *xy_r, int n, float *xyz) {
@@ -1062,7 +1199,7 @@ int spvo_pnp_refine(spvo_ctx *c, const double P_l[12], const double P_r[12], con
   if (n_obs) HIP_TRY(c, hipMemcpyAsync(c->d_obs, obs, (size_t)n_obs * sizeof(spvo_obs), hipMemcpyHostToDevice, c->stream));
   {
     ScopedStage st(c, stage_id(c, "refine"));
-    hipLaunchKernelGGL(pnp_refine_kernel<512>, dim3(1), dim3(512), 0, c->stream, c->d_P, c->d_P + 12, c->d_obs, n_obs, c->d_P + 40, o.max_iterations, o.huber_delta, c->d_refine);
+    hipLaunchKernelGGL(pnp_refine_kernel<512>, dim3(1), dim3(512), 0, c->stream, c->d_P, c->d_P + 12, c->d_obs, n_obs, (const int *)nullptr, c->d_P + 40, o.max_iterations, o.huber_delta, c->d_refine);
   }
   HIP_TRY(c, hipGetLastError());
   RefineOut r;
@@ -1077,6 +1214,111 @@ int spvo_pnp_refine(spvo_ctx *c, const double P_l[12], const double P_r[12], con
     summary->initial_cost = r.v[10];
     summary->final_cost = r.v[11];
   }
+  return SPVO_OK;
+}
+
+int spvo_solve_stereo_odometry(spvo_ctx *c, const spvo_solve_input *in, spvo_solve_output *out, float *xyz, int32_t *inliers) {
+  if (!c || !in || !out) return fail(c, SPVO_ERR_INVALID, "null argument");
+  const int n = in->n;
+  if (n < 0 || (n > 0 && (!in->xy_cl || !in->xy_cr || !in->xy_pl || !in->xy_pr || !xyz || !inliers))) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  if (in->ransac.iterations <= 0 || in->ransac.iterations > 65536 || !(in->ransac.reproj_error > 0) || in->refine.max_iterations < 0 ||
+      !(in->refine.huber_delta > 0))
+    return fail(c, SPVO_ERR_INVALID, "bad solver options");
+  std::memset(out, 0, sizeof *out);
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  // rvec -> quaternion of the prior: the answer when nothing can be estimated (base.cpp:244-250, 274-280)
+  auto prior_pose = [&]() {
+    const double *r = in->rvec_pred;
+    const double a = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    double ax[3] = {r[0], r[1], r[2]};
+    if (a > 0) for (int k = 0; k < 3; ++k) ax[k] /= a;
+    const double sn = std::sin(a / 2);
+    out->q[0] = ax[0] * sn; out->q[1] = ax[1] * sn; out->q[2] = ax[2] * sn; out->q[3] = std::cos(a / 2);
+    for (int k = 0; k < 3; ++k) { out->t[k] = in->tvec_pred[k]; out->rvec[k] = in->rvec_pred[k]; out->tvec[k] = in->tvec_pred[k]; }
+  };
+  if (n == 0) { prior_pose(); return SPVO_OK; }
+  int rc = ensure_odometry(c, n, in->ransac.iterations, 4 * n);
+  if (rc) return rc;
+  if (n > c->solve_cap) {
+    const int cap = std::max(n, 2048);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (void *hp : {(void *)c->h_solve_in, (void *)c->h_solve_res, (void *)c->h_solve_o}) if (hp) (void)hipHostFree(hp);
+    for (void *dp : {(void *)c->d_solve_in, (void *)c->d_solve_res, (void *)c->d_solve_o, (void *)c->d_ctl}) if (dp) (void)hipFree(dp);
+    c->h_solve_in = c->h_solve_o = nullptr; c->h_solve_res = nullptr;
+    const size_t in_bytes = 64 * sizeof(double) + (size_t)12 * cap * 4, o_bytes = (size_t)4 * cap * 4;
+    if ((rc = dev_alloc(c, &c->d_solve_in, in_bytes))) return rc;
+    if ((rc = dev_alloc(c, &c->d_solve_res, 40))) return rc;
+    if ((rc = dev_alloc(c, &c->d_solve_o, o_bytes))) return rc;
+    if ((rc = dev_alloc(c, &c->d_ctl, 4))) return rc;
+    HIP_TRY(c, hipHostMalloc((void **)&c->h_solve_in, in_bytes));
+    HIP_TRY(c, hipHostMalloc((void **)&c->h_solve_res, 40 * sizeof(double)));
+    HIP_TRY(c, hipHostMalloc((void **)&c->h_solve_o, o_bytes));
+    c->solve_cap = cap;
+  }
+  // ---- pack: 64 doubles, then cl cr pl pr [2n each], prev_xyz [3n], prev_valid [n]
+  double *hdr = (double *)c->h_solve_in;
+  std::memset(hdr, 0, 64 * sizeof(double));
+  for (int k = 0; k < 12; ++k) { hdr[k] = in->P_l[k]; hdr[12 + k] = in->P_r[k]; }
+  const int kidx[9] = {0, 1, 2, 4, 5, 6, 8, 9, 10};
+  for (int k = 0; k < 9; ++k) hdr[24 + k] = in->P_l[kidx[k]];                      // K = P_l[:, :3]  (base.cpp:227)
+  for (int k = 0; k < 3; ++k) { hdr[33 + k] = in->rvec_pred[k]; hdr[36 + k] = in->tvec_pred[k]; }
+  hdr[39] = in->frame_count; hdr[40] = in->refinement_degree;
+  hdr[41] = 8.0; hdr[42] = 0.1; hdr[43] = 10;                                      // hpp:145-147
+  float *fw = (float *)(c->h_solve_in + 64 * sizeof(double));
+  std::memcpy(fw, in->xy_cl, (size_t)2 * n * 4);
+  std::memcpy(fw + 2 * n, in->xy_cr, (size_t)2 * n * 4);
+  std::memcpy(fw + 4 * n, in->xy_pl, (size_t)2 * n * 4);
+  std::memcpy(fw + 6 * n, in->xy_pr, (size_t)2 * n * 4);
+  const bool have_prev = in->prev_xyz && in->prev_valid;
+  if (have_prev) {
+    std::memcpy(fw + 8 * n, in->prev_xyz, (size_t)3 * n * 4);
+    std::memcpy(fw + 11 * n, in->prev_valid, (size_t)n * 4);
+  }
+  const size_t used = 64 * sizeof(double) + (size_t)12 * n * 4;
+  HIP_TRY(c, hipMemcpyAsync(c->d_solve_in, c->h_solve_in, used, hipMemcpyHostToDevice, c->stream));
+  const double *dh = (const double *)c->d_solve_in;
+  const float *df = (const float *)(c->d_solve_in + 64 * sizeof(double));
+  float *d_xyz = (float *)c->d_solve_o;
+  int *d_inl = (int *)(c->d_solve_o) + 3 * n;
+  RansacWork rw = c->rw;
+  rw.result = c->d_solve_res;
+  rw.inliers = d_inl;
+  const double thr2 = in->ransac.reproj_error * in->ransac.reproj_error;
+  {
+    ScopedStage st(c, stage_id(c, "solve"));
+    hipLaunchKernelGGL(triangulate_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, dh, dh + 12, df, df + 2 * n, n, d_xyz);
+    if (n >= 4) {
+      hipLaunchKernelGGL(ransac_hypothesis_kernel, dim3(in->ransac.iterations), dim3(64), 0, c->stream, dh + 24, d_xyz, df + 4 * n, n, dh + 33, in->ransac.seed, thr2, rw);
+      hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(256), 0, c->stream, dh + 24, d_xyz, df + 4 * n, n, dh + 33, in->ransac.iterations, thr2, rw);
+      hipLaunchKernelGGL(solve_gate_build_kernel, dim3(1), dim3(256), 0, c->stream, dh, c->d_solve_res, d_inl, d_xyz, df, df + 2 * n, df + 4 * n, df + 6 * n,
+                         have_prev ? df + 8 * n : (const float *)nullptr, have_prev ? (const int *)(df + 11 * n) : (const int *)nullptr, c->d_obs, c->d_ctl,
+                         c->d_solve_res + 8);
+      hipLaunchKernelGGL(pnp_refine_kernel<512>, dim3(1), dim3(512), 0, c->stream, dh, dh + 12, c->d_obs, 0, (const int *)c->d_ctl, c->d_solve_res + 8,
+                         in->refine.max_iterations, in->refine.huber_delta, (RefineOut *)(c->d_solve_res + 24));
+    }
+    HIP_TRY(c, hipGetLastError());
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->h_solve_o, c->d_solve_o, (size_t)4 * n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (n >= 4) HIP_TRY(c, hipMemcpyAsync(c->h_solve_res, c->d_solve_res, 40 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  std::memcpy(xyz, c->h_solve_o, (size_t)3 * n * 4);
+  if (n < 4) { prior_pose(); return SPVO_OK; }                                      // no model possible: prior is kept
+  const double *res = c->h_solve_res, *gate = res + 8, *ref = res + 24;
+  out->pnp_ok = res[6] != 0;
+  out->n_inliers = (int)res[7];
+  if (out->n_inliers > 0) std::memcpy(inliers, (const int *)c->h_solve_o + 3 * n, (size_t)out->n_inliers * 4);
+  out->accepted = gate[7] != 0;
+  for (int k = 0; k < 3; ++k) { out->rvec[k] = gate[10 + k]; out->tvec[k] = gate[13 + k]; }
+  const bool ran = out->accepted && in->refinement_degree > 0;
+  out->summary.iterations = (int)ref[7];
+  out->summary.converged = (int)ref[8];
+  out->summary.usable = (int)ref[9];
+  out->summary.initial_cost = ref[10];
+  out->summary.final_cost = ref[11];
+  out->refined = ran && out->summary.usable && out->summary.converged;             // base.cpp:366-374
+  const double *src = out->refined ? ref : gate;
+  for (int k = 0; k < 4; ++k) out->q[k] = src[k];
+  for (int k = 0; k < 3; ++k) out->t[k] = src[4 + k];
   return SPVO_OK;
 }
 

@@ -191,87 +191,49 @@ void FeatureFrontEnd::solveStereoOdometry(tf2::Transform &cam0_curr_T_cam0_prev)
   }
   const int n = (int)(kp_cl.size() / 2);
 
-  // triangulation (base.cpp:211-223)
-  std::vector<float> pts3d((size_t)std::max(n, 1) * 3, 0.f);
+  // everything numeric from here to the refined pose is ONE call into the C ABI:
+  // triangulation (base.cpp:211-223), PnP-RANSAC (227-239), gating (241-272), residual blocks
+  // (291-356), refinement and the "not converged => keep RANSAC" rule (358-375)
   const double *Pl = projection_matrix_l_.ptr<double>(0), *Pr = projection_matrix_r_.ptr<double>(0);
-  if (spvo_triangulate(ctx_, Pl, Pr, kp_cl.data(), kp_cr.data(), n, pts3d.data()) != SPVO_OK) {
-    logError(std::string("spvo_triangulate: ") + spvo_last_error(ctx_));
-    return;
-  }
-
-  // PnP (base.cpp:227-239)
-  const double K[9] = {Pl[0], Pl[1], Pl[2], Pl[4], Pl[5], Pl[6], Pl[8], Pl[9], Pl[10]};
-  double r_vec[3] = {r_vec_pred[0], r_vec_pred[1], r_vec_pred[2]};
-  double t_vec[3] = {t_vec_pred[0], t_vec_pred[1], t_vec_pred[2]};
-  inliers_pnp.assign(std::max(n, 1), 0);
-  int n_inl = 0, pnp_result = 0;
-  spvo_ransac_opts ro = {500, 2.0, 0.999, ransac_seed};
-  if (spvo_pnp_ransac(ctx_, K, pts3d.data(), kp_pl.data(), n, &ro, r_vec, t_vec, inliers_pnp.data(), &n_inl, &pnp_result) != SPVO_OK) {
-    logError(std::string("spvo_pnp_ransac: ") + spvo_last_error(ctx_));
-    return;
-  }
-  inliers_pnp.resize(n_inl);
-
-  const double acceleration = std::sqrt((t_vec[0] - t_vec_pred[0]) * (t_vec[0] - t_vec_pred[0]) + (t_vec[1] - t_vec_pred[1]) * (t_vec[1] - t_vec_pred[1]) +
-                                        (t_vec[2] - t_vec_pred[2]) * (t_vec[2] - t_vec_pred[2])) / TIME_INTERVAL;
-  bool do_optmz = false;
-  if (!pnp_result) {
-    logError("solvePnPRansac failed! Identity transformation will be applied.");
-    for (int k = 0; k < 3; ++k) { r_vec[k] = r_vec_pred[k]; t_vec[k] = t_vec_pred[k]; }
-  } else if (frame_count > IGNORE_FRAME_COUNT && acceleration > MAX_ACCELERATION) {
-    logError("solvePnPRansac succeeded but acceleration is abnormally large!");
-    for (int k = 0; k < 3; ++k) { r_vec[k] = r_vec_pred[k]; t_vec[k] = t_vec_pred[k]; }
-  } else {
-    for (int k = 0; k < 3; ++k) { r_vec_pred[k] = r_vec[k]; t_vec_pred[k] = t_vec[k]; }
-    do_optmz = true;
-  }
-
-  // base.cpp:274-280: AngleAxisd(|r|, r.normalized()) -> quaternion
-  const double angle = std::sqrt(r_vec[0] * r_vec[0] + r_vec[1] * r_vec[1] + r_vec[2] * r_vec[2]);
-  double axis[3] = {r_vec[0], r_vec[1], r_vec[2]};
-  if (angle > 0) for (int k = 0; k < 3; ++k) axis[k] /= angle;
-  const double s = std::sin(angle / 2);
-  const double q_init[4] = {axis[0] * s, axis[1] * s, axis[2] * s, std::cos(angle / 2)};
-  double q_opt[4] = {q_init[0], q_init[1], q_init[2], q_init[3]};
-  double t_opt[3] = {t_vec[0], t_vec[1], t_vec[2]};
-
-  if (do_optmz && refinement_degree_ > 0) {
-    std::vector<spvo_obs> obs;
-    obs.reserve(4 * inliers_pnp.size());
-    auto push = [&](const float *X, const float *uv, int cam, int inv) {
-      spvo_obs o;
-      o.X[0] = X[0]; o.X[1] = X[1]; o.X[2] = X[2];
-      o.uv[0] = uv[0]; o.uv[1] = uv[1];
-      o.cam = cam; o.inverse = inv;
-      obs.push_back(o);
-    };
-    for (const int vi : inliers_pnp) {  // block order of base.cpp:291-356
-      push(&pts3d[3 * vi], &kp_pl[2 * vi], 0, 0);
-      if (refinement_degree_ <= 1) continue;
-      push(&pts3d[3 * vi], &kp_pr[2 * vi], 1, 0);
-      if (refinement_degree_ <= 2) continue;
-      if (!prev_left_points_3d_inited) continue;
-      const int matched_prev = map_from_curr_valid_to_prev_left_matched_index.at(vi);
-      if (matched_prev >= (int)map_from_prev_left_matched_to_prev_valid_index.size()) continue;
+  std::vector<float> pts3d((size_t)std::max(n, 1) * 3, 0.f), prev_xyz;
+  std::vector<int32_t> prev_valid;
+  if (refinement_degree_ >= 3 && prev_left_points_3d_inited) {  // base.cpp:323-332
+    prev_xyz.assign((size_t)std::max(n, 1) * 3, 0.f);
+    prev_valid.assign(std::max(n, 1), 0);
+    for (int vi = 0; vi < n; ++vi) {
+      const int matched_prev = map_from_curr_valid_to_prev_left_matched_index[vi];
+      if (matched_prev < 0 || matched_prev >= (int)map_from_prev_left_matched_to_prev_valid_index.size()) continue;
       const int valid_prev = map_from_prev_left_matched_to_prev_valid_index[matched_prev];
       if (valid_prev == -1) continue;
-      push(&prev_left_points_3d[3 * valid_prev], &kp_cl[2 * vi], 0, 1);
-      if (refinement_degree_ <= 3) continue;
-      push(&prev_left_points_3d[3 * valid_prev], &kp_cr[2 * vi], 1, 1);
-    }
-    spvo_refine_opts fo = {40, 1.0};
-    spvo_refine_summary summary;
-    if (spvo_pnp_refine(ctx_, Pl, Pr, obs.data(), (int)obs.size(), &fo, q_opt, t_opt, &summary) != SPVO_OK) {
-      logError(std::string("spvo_pnp_refine: ") + spvo_last_error(ctx_));
-      summary.usable = 0;
-      summary.converged = 0;
-    }
-    if (!summary.usable || !summary.converged) {  // base.cpp:366-374
-      logError("summary.IsSolutionUsable() == false or NOT CONVERGENT");
-      for (int k = 0; k < 4; ++k) q_opt[k] = q_init[k];
-      for (int k = 0; k < 3; ++k) t_opt[k] = t_vec[k];
+      for (int k = 0; k < 3; ++k) prev_xyz[3 * vi + k] = prev_left_points_3d[3 * valid_prev + k];
+      prev_valid[vi] = 1;
     }
   }
+  spvo_solve_input si;
+  std::memset(&si, 0, sizeof si);
+  si.n = n;
+  si.xy_cl = kp_cl.data(); si.xy_cr = kp_cr.data(); si.xy_pl = kp_pl.data(); si.xy_pr = kp_pr.data();
+  si.prev_xyz = prev_xyz.empty() ? nullptr : prev_xyz.data();
+  si.prev_valid = prev_valid.empty() ? nullptr : prev_valid.data();
+  for (int k = 0; k < 12; ++k) { si.P_l[k] = Pl[k]; si.P_r[k] = Pr[k]; }
+  for (int k = 0; k < 3; ++k) { si.rvec_pred[k] = r_vec_pred[k]; si.tvec_pred[k] = t_vec_pred[k]; }
+  si.frame_count = frame_count;
+  si.refinement_degree = refinement_degree_;
+  si.ransac = spvo_ransac_opts{500, 2.0, 0.999, ransac_seed};   // base.cpp:239
+  si.refine = spvo_refine_opts{40, 1.0};                        // base.cpp:286, 362
+  spvo_solve_output so;
+  inliers_pnp.assign(std::max(n, 1), 0);
+  if (spvo_solve_stereo_odometry(ctx_, &si, &so, pts3d.data(), inliers_pnp.data()) != SPVO_OK) {
+    logError(std::string("spvo_solve_stereo_odometry: ") + spvo_last_error(ctx_));
+    return;
+  }
+  inliers_pnp.resize(so.n_inliers);
+  if (!so.pnp_ok) logError("solvePnPRansac failed! Identity transformation will be applied.");
+  else if (!so.accepted) logError("solvePnPRansac succeeded but acceleration is abnormally large!");
+  else for (int k = 0; k < 3; ++k) { r_vec_pred[k] = so.rvec[k]; t_vec_pred[k] = so.tvec[k]; }   // base.cpp:269-270
+  if (so.accepted && refinement_degree_ > 0 && !so.refined) logError("summary.IsSolutionUsable() == false or NOT CONVERGENT");
+  const double q_opt[4] = {so.q[0], so.q[1], so.q[2], so.q[3]};
+  const double t_opt[3] = {so.t[0], so.t[1], so.t[2]};
 
   tf2::Transform cam0_prev_T_cam0_curr;
   cam0_prev_T_cam0_curr.setRotation(tf2::Quaternion{q_opt[0], q_opt[1], q_opt[2], q_opt[3]});
@@ -363,6 +325,10 @@ void SuperPointFeatureFrontEnd::loadEngine() {
     return;
   }
   logInfo("engine file `" + model_name_full + "` loaded");
+  // stereoCallback always asks for CURR_LEFT->CURR_RIGHT and CURR_LEFT->PREV_LEFT right after the
+  // detector (node.cpp:196-198): have them enqueued in the detector's own submission
+  if (matcher_ready_ && !std::getenv("SPVO_NO_PREMATCH"))
+    spvo_set_prematch(ctx_, 1, selector_type_ == SelectorType::KNN ? SPVO_SELECT_KNN : SPVO_SELECT_NN, matcher_cross_check_ ? 1 : 0, knn_threshold_);
   for (int i = 0; i < 2; ++i) {
     xy_buf_[i].assign((size_t)max_keypoints_ * 2, 0.f);
     desc_buf_[i].assign((size_t)max_keypoints_ * output_desc_channel_, 0.f);

@@ -39,14 +39,27 @@ class RefineSummary(C.Structure):
                 ("initial_cost", C.c_double), ("final_cost", C.c_double)]
 
 
+class SolveInput(C.Structure):
+    _fields_ = [("n", C.c_int), ("xy_cl", C.c_void_p), ("xy_cr", C.c_void_p), ("xy_pl", C.c_void_p), ("xy_pr", C.c_void_p),
+                ("prev_xyz", C.c_void_p), ("prev_valid", C.c_void_p), ("P_l", C.c_double * 12), ("P_r", C.c_double * 12),
+                ("rvec_pred", C.c_double * 3), ("tvec_pred", C.c_double * 3), ("frame_count", C.c_int),
+                ("refinement_degree", C.c_int), ("ransac", RansacOpts), ("refine", RefineOpts)]
+
+
+class SolveOutput(C.Structure):
+    _fields_ = [("q", C.c_double * 4), ("t", C.c_double * 3), ("rvec", C.c_double * 3), ("tvec", C.c_double * 3),
+                ("pnp_ok", C.c_int), ("accepted", C.c_int), ("refined", C.c_int), ("n_inliers", C.c_int),
+                ("summary", RefineSummary)]
+
+
 OBS_DTYPE = np.dtype([("X", np.float32, 3), ("uv", np.float32, 2), ("cam", np.int32), ("inverse", np.int32)])
 
 # every symbol include/spvo.h declares
 SYMBOLS = [
     "spvo_default_config", "spvo_create", "spvo_destroy", "spvo_last_error", "spvo_load_weights",
     "spvo_preprocess", "spvo_forward", "spvo_debug_tensor", "spvo_heatmap", "spvo_nms",
-    "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_match", "spvo_match_slots",
-    "spvo_triangulate", "spvo_pnp_ransac", "spvo_pnp_refine", "spvo_stream", "spvo_synchronize",
+    "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_match", "spvo_match_slots", "spvo_set_prematch",
+    "spvo_triangulate", "spvo_pnp_ransac", "spvo_pnp_refine", "spvo_solve_stereo_odometry", "spvo_stream", "spvo_synchronize",
     "spvo_profile_enable", "spvo_profile_reset", "spvo_profile_count", "spvo_profile_get",
 ]
 
@@ -82,10 +95,12 @@ def load() -> C.CDLL:
                                     C.POINTER(Features), C.POINTER(Features)]
     lib.spvo_match.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
     lib.spvo_match_slots.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
+    lib.spvo_set_prematch.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float]
     lib.spvo_triangulate.argtypes = [vp, dp, dp, vp, vp, C.c_int, vp]
     lib.spvo_pnp_ransac.argtypes = [vp, dp, vp, vp, C.c_int, C.POINTER(RansacOpts), dp, dp, vp, ip, ip]
     lib.spvo_pnp_refine.argtypes = [vp, dp, dp, vp, C.c_int, C.POINTER(RefineOpts), dp, dp,
                                     C.POINTER(RefineSummary)]
+    lib.spvo_solve_stereo_odometry.argtypes = [vp, C.POINTER(SolveInput), C.POINTER(SolveOutput), vp, vp]
     lib.spvo_stream.argtypes = [vp]
     lib.spvo_stream.restype = vp
     lib.spvo_synchronize.argtypes = [vp]
@@ -246,6 +261,9 @@ class Context:
                                               int(cross_check), ratio, _ptr(idx), _ptr(dist)))
         return idx[:n_a], dist[:n_a]
 
+    def set_prematch(self, enable=True, selector="KNN", cross_check=False, ratio=0.8):
+        self._check(self.lib.spvo_set_prematch(self.h, int(enable), 1 if selector == "KNN" else 0, int(cross_check), ratio))
+
     def triangulate(self, P_l, P_r, xy_l, xy_r) -> np.ndarray:
         Pl = np.ascontiguousarray(P_l, np.float64).reshape(12)
         Pr = np.ascontiguousarray(P_r, np.float64).reshape(12)
@@ -279,6 +297,33 @@ class Context:
         self._check(self.lib.spvo_pnp_refine(self.h, _dptr(Pl), _dptr(Pr), _ptr(obs), len(obs), C.byref(opts),
                                              _dptr(q), _dptr(t), C.byref(s)))
         return q, t, s
+
+    def solve(self, P_l, P_r, cl, cr, pl, pr, prev_xyz=None, prev_valid=None, rvec_pred=(0, 0, 0), tvec_pred=(0, 0, 0),
+              frame_count=0, refinement_degree=4, seed=0, iterations=500, reproj_error=2.0, max_iterations=40):
+        arrs = [np.ascontiguousarray(a, np.float32).reshape(-1, 2) for a in (cl, cr, pl, pr)]
+        n = len(arrs[0])
+        si = SolveInput()
+        si.n = n
+        si.xy_cl, si.xy_cr, si.xy_pl, si.xy_pr = [a.ctypes.data for a in arrs]
+        if prev_xyz is not None:
+            px = np.ascontiguousarray(prev_xyz, np.float32).reshape(-1, 3)
+            pv = np.ascontiguousarray(prev_valid, np.int32)
+            si.prev_xyz, si.prev_valid = px.ctypes.data, pv.ctypes.data
+        si.P_l[:] = np.asarray(P_l, np.float64).reshape(12).tolist()
+        si.P_r[:] = np.asarray(P_r, np.float64).reshape(12).tolist()
+        si.rvec_pred[:] = list(map(float, rvec_pred))
+        si.tvec_pred[:] = list(map(float, tvec_pred))
+        si.frame_count, si.refinement_degree = frame_count, refinement_degree
+        si.ransac = RansacOpts(iterations, reproj_error, 0.999, seed)
+        si.refine = RefineOpts(max_iterations, 1.0)
+        so = SolveOutput()
+        xyz = np.zeros((max(n, 1), 3), np.float32)
+        inl = np.zeros(max(n, 1), np.int32)
+        self._check(self.lib.spvo_solve_stereo_odometry(self.h, C.byref(si), C.byref(so), _ptr(xyz), _ptr(inl)))
+        return dict(q=np.array(so.q[:]), t=np.array(so.t[:]), rvec=np.array(so.rvec[:]), tvec=np.array(so.tvec[:]),
+                    pnp_ok=bool(so.pnp_ok), accepted=bool(so.accepted), refined=bool(so.refined),
+                    inliers=inl[:so.n_inliers].copy(), xyz=xyz[:n].copy(), iterations=so.summary.iterations,
+                    converged=bool(so.summary.converged), final_cost=so.summary.final_cost)
 
     def stream(self) -> int:
         return self.lib.spvo_stream(self.h) or 0

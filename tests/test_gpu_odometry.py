@@ -94,3 +94,56 @@ def test_refine_edge_cases(ctx_vgg):
     _, _, rs = od.pnp_refine(P_l, P_r, (pts.astype(np.float64), pl.astype(np.float64), np.zeros(80, int), np.zeros(80, int)),
                              np.array([0, 0, 0, 1.0]), np.zeros(3), max_iterations=1)
     assert not s.converged and s.usable and s.iterations == rs.iterations == 1
+
+
+@pytest.mark.parametrize("degree,with_prev", [(4, True), (4, False), (2, True), (0, True)])
+def test_fused_solve_equals_staged_calls(ctx_vgg, degree, with_prev):
+    """spvo_solve_stereo_odometry == triangulate + ransac + host gating + refine, to the last bit."""
+    P_l, P_r, Xc, cl, cr, pl, pr, rv, tv, bad = _scene(seed=5, n=350, noise=0.3, outliers=0.25)
+    R = od.quat_to_rot(od.rvec_to_quat(rv))
+    Xp = (Xc @ R.T + tv).astype(np.float32)
+    rng = np.random.RandomState(0)
+    pvalid = (rng.rand(350) < 0.7).astype(np.int32)
+    prior_r, prior_t = np.array([0.0, 0.0, 0.0]), np.array([0.0, 0.0, 0.9])
+    f = ctx_vgg.solve(P_l, P_r, cl, cr, pl, pr, Xp if with_prev else None, pvalid if with_prev else None,
+                      prior_r, prior_t, frame_count=3, refinement_degree=degree, seed=2)
+    pts = ctx_vgg.triangulate(P_l, P_r, cl, cr)
+    ok, r, t, inl = ctx_vgg.pnp_ransac(P_l[:, :3], pts, pl, prior_r, prior_t, 500, 2.0, 2)
+    assert np.array_equal(f["xyz"], pts) and f["pnp_ok"] == ok and np.array_equal(f["inliers"], inl)
+    assert np.array_equal(f["rvec"], r) and np.array_equal(f["tvec"], t) and f["accepted"]
+    X, uv, cam, inv = [], [], [], []
+    for i in inl:
+        X.append(pts[i]); uv.append(pl[i]); cam.append(0); inv.append(0)
+        if degree >= 2:
+            X.append(pts[i]); uv.append(pr[i]); cam.append(1); inv.append(0)
+        if with_prev and pvalid[i] and degree >= 3:
+            X.append(Xp[i]); uv.append(cl[i]); cam.append(0); inv.append(1)
+        if with_prev and pvalid[i] and degree >= 4:
+            X.append(Xp[i]); uv.append(cr[i]); cam.append(1); inv.append(1)
+    q0 = od.rvec_to_quat(r)
+    if degree > 0:
+        q, t2, s = ctx_vgg.pnp_refine(P_l, P_r, capi.obs_array(X, uv, cam, inv), q0, t)
+        assert f["refined"] == bool(s.converged and s.usable) and f["iterations"] == s.iterations
+        assert np.allclose(f["q"], q, atol=1e-12) and np.allclose(f["t"], t2, atol=1e-12)
+    else:
+        assert not f["refined"] and np.allclose(f["q"], q0, atol=1e-15) and np.array_equal(f["t"], t)
+    # and against the oracle (same bars as the staged tests)
+    ook, orr, ot, oinl = od.pnp_ransac(P_l[:, :3], od.triangulate(P_l, P_r, cl, cr), pl, prior_r, prior_t, 500, 2.0, 2)
+    assert np.array_equal(f["inliers"], oinl) and np.allclose(f["tvec"], ot, atol=1e-8)
+
+
+def test_fused_solve_gating_and_small_inputs(ctx_vgg):
+    P_l, P_r, Xc, cl, cr, pl, pr, rv, tv, bad = _scene(seed=6, n=200, noise=0.2)
+    # acceleration gate (base.cpp:251-260): prior far from the estimate, frame_count > 10 -> prior is returned
+    prior_t = np.array([0.0, 0.0, 5.0])
+    f = ctx_vgg.solve(P_l, P_r, cl, cr, pl, pr, None, None, np.zeros(3), prior_t, frame_count=11)
+    assert f["pnp_ok"] and not f["accepted"] and not f["refined"]
+    assert np.allclose(f["t"], prior_t) and np.allclose(f["q"], [0, 0, 0, 1])
+    # ... but not during the first IGNORE_FRAME_COUNT frames
+    f = ctx_vgg.solve(P_l, P_r, cl, cr, pl, pr, None, None, np.zeros(3), prior_t, frame_count=10)
+    assert f["accepted"] and f["refined"] and np.allclose(f["t"], tv, atol=2e-2)
+    # fewer than 4 correspondences / none at all: no model, the prior comes back (base.cpp:244-250)
+    for k in (0, 3):
+        f = ctx_vgg.solve(P_l, P_r, cl[:k], cr[:k], pl[:k], pr[:k], None, None, [0, 0.1, 0], [1, 2, 3])
+        assert not f["pnp_ok"] and not f["accepted"] and len(f["inliers"]) == 0 and np.allclose(f["t"], [1, 2, 3])
+        assert np.allclose(f["q"], od.rvec_to_quat([0, 0.1, 0]))

@@ -63,3 +63,20 @@ def test_detect_properties_full_size(ctx_vgg, stereo_pair):
     # a stereo pair matched against itself: every keypoint finds itself at distance 0 (NN)
     idx, dist = ctx_vgg.match_slots(0, 0, len(c["xy_l"]), "NN", True)
     assert np.array_equal(idx, np.arange(len(idx))) and np.all(dist == 0)
+
+
+def test_prematch_is_transparent(ctx_squeeze, stereo_pair):
+    """spvo_set_prematch only moves the two standard matches into the detector's submission."""
+    frames, _, P_l, P_r = stereo_pair
+    res = {}
+    for on in (False, True):
+        ctx_squeeze.set_prematch(on, "KNN", False, 0.8)
+        a = ctx_squeeze.detect(frames[0][0], frames[0][1], P_l, P_r, 0, 1)
+        b = ctx_squeeze.detect(frames[1][0], frames[1][1], P_l, P_r, 2, 3)
+        n = len(b["xy_l"])
+        res[on] = (ctx_squeeze.match_slots(2, 3, n), ctx_squeeze.match_slots(2, 0, n),
+                   ctx_squeeze.match_slots(2, 3, n, "NN", True))       # different parameters: computed on demand
+    ctx_squeeze.set_prematch(False)
+    for x, y in zip(res[False], res[True]):
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+    assert (res[True][1][0] >= 0).sum() > 300                            # temporal matches exist
