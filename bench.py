@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--no-pipeline", action="store_true", help="do not hand the next stereo pair over early")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -106,7 +107,9 @@ def main():
 
     def step(i):
         dl, dr = d_frames[order[i % len(order)]]
-        res = fe.step_device(dl.data_ptr(), dr.data_ptr(), rows, cols, dl.stride(0), P_l, P_r)
+        nl, nr = d_frames[order[(i + 1) % len(order)]]
+        nxt = None if args.no_pipeline else (nl.data_ptr(), nr.data_ptr())   # the next pair is already in HBM
+        res = fe.step_device(dl.data_ptr(), dr.data_ptr(), rows, cols, dl.stride(0), P_l, P_r, nxt)
         if world > 1:                                                       # RCCL all-gather, 56 B per rank
             pg.gather(*(res if res is not None else (None, None)))
         return res

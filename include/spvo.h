@@ -127,6 +127,18 @@ int spvo_detect_dev(spvo_ctx *ctx, const void *d_img_l, const void *d_img_r, int
                     size_t stride, double P_l[12], double P_r[12], int slot_l, int slot_r,
                     spvo_features *out_l, spvo_features *out_r);
 
+/* Asynchronous form of spvo_detect_dev (at most one submission in flight): _submit returns as
+ * soon as the whole detector chain (and, with spvo_set_prematch, the two standard matches) is
+ * enqueued; _wait blocks until it has finished and hands out what spvo_detect_dev would have.
+ * Between the two the caller may run spvo_match_slots on precomputed matches and
+ * spvo_solve_stereo_odometry for the PREVIOUS pair: the ROS node receives the next image pair
+ * while it is still solving the current one.  The slots named here are rewritten while the
+ * submission is in flight. */
+int spvo_detect_dev_submit(spvo_ctx *ctx, const void *d_img_l, const void *d_img_r, int rows, int cols,
+                           size_t stride, int slot_l, int slot_r);
+int spvo_detect_wait(spvo_ctx *ctx, double P_l[12], double P_r[12], spvo_features *out_l,
+                     spvo_features *out_r);
+
 typedef enum { SPVO_SELECT_NN = 0, SPVO_SELECT_KNN = 1 } spvo_selector;
 
 /* matchDescriptors (base.cpp:434-491) = cv::BFMatcher(NORM_L2) match / knnMatch

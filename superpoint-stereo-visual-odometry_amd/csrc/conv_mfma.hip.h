@@ -72,8 +72,8 @@ struct ConvTile {
   static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4;
 };
 
-template <int KS, int CK, int WR, int WC, bool POOL, bool RELU>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+template <int KS, int CK, int WR, int WC, bool POOL, bool RELU, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) {
   using T = ConvTile<KS, CK, WR, WC>;
   constexpr int NT = WR * WC;
   constexpr int LW = T::LW, LH = T::LH, LW4 = LW / 4;
@@ -105,25 +105,31 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                          (size_t)(y0 + PADY - T::HALO) * a.in_wp + (x0 + PADX - (KS == 3 ? 4 : 0));
   const float *w_base = a.wpack + (size_t)ct * a.n_chunks * T::W_FLOATS;
 
+  // Per-thread staging plan, computed once: element offset of each of this thread's 16-byte
+  // pieces relative to the chunk's input base (pieces < IN_V4) or weight base (the rest).
+  // Per chunk the issue loop is then branch-free except for the ragged last piece.
+  int piece_off[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = it * 256 + tid;
+    if (idx < IN_V4) {
+      const int ci = idx / (LH * LW4);
+      const int rem = idx - ci * (LH * LW4);
+      const int r = rem / LW4;
+      const int q = rem - r * LW4;
+      piece_off[it] = ci * (int)in_plane + r * a.in_wp + q * 4;
+    } else {
+      piece_off[it] = (min(idx, TOT_V4 - 1) - IN_V4) * 4;
+    }
+  }
   auto issue = [&](int chunk, float *buf) {
     const float *inb = in_base + (size_t)chunk * CK * in_plane;
     const float *wb = w_base + (size_t)chunk * T::W_FLOATS;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int idx = it * 256 + tid;
-      if (idx < TOT_V4) {
-        const float *src;
-        if (idx < IN_V4) {
-          const int ci = idx / (LH * LW4);
-          const int rem = idx - ci * (LH * LW4);
-          const int r = rem / LW4;
-          const int q = rem - r * LW4;
-          src = inb + (size_t)ci * in_plane + r * a.in_wp + q * 4;
-        } else {
-          src = wb + (idx - IN_V4) * 4;
-        }
-        glds16(src, buf + (it * 256 + wave * 64) * 4);
-      }
+      const float *src = ((idx < IN_V4) ? inb : wb) + piece_off[it];
+      if (it < NIT - 1 || idx < TOT_V4) glds16(src, buf + (it * 256 + wave * 64) * 4);
     }
   };
 

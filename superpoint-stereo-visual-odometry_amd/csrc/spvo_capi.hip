@@ -82,9 +82,19 @@ struct NmsImage {
 
 }  // namespace
 
+struct CropGeomS { int row_off = 0, col_off = 0, crop_rows = 0, crop_cols = 0; float scale = 1.f; };
+
+struct PendingDetect {           // one spvo_detect*_submit in flight
+  bool active = false;
+  CropGeomS g;
+  int rows = 0, cols = 0, slot_l = 0, slot_r = 0, prev_l = -1, parity = 0;
+};
+
 struct spvo_ctx {
   spvo_config cfg;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // fused solve: overlaps with a detector submission in flight
+  PendingDetect pend;
   std::string error;
   bool weights = false;
   int H = 0, W = 0, Hc = 0, Wc = 0, B = 0;
@@ -116,7 +126,8 @@ struct spvo_ctx {
   int match_cap = 0;
   float *d_ma = nullptr, *d_mb = nullptr;
   MatchScratch ms[2];
-  MatchCache mcache[2];
+  MatchCache mcache[2][2];       // [submission parity][stereo, temporal]
+  int det_parity = 0;
   bool prematch = false;
   int pm_selector = SPVO_SELECT_KNN, pm_cross = 0;
   float pm_ratio = 0.8f;
@@ -192,9 +203,9 @@ hipEvent_t get_event(spvo_ctx *c) {
 
 void resolve_pending(spvo_ctx *c) {
   if (c->pending.empty()) return;
-  (void)hipEventSynchronize(c->pending.back().e1);
   for (auto &p : c->pending) {
     float ms = 0;
+    (void)hipEventSynchronize(p.e1);
     if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
       c->stages[p.stage].total_ms += ms;
       c->stages[p.stage].calls += 1;
@@ -209,18 +220,20 @@ struct ScopedStage {
   spvo_ctx *c;
   int id = -1;
   hipEvent_t e0 = nullptr;
-  ScopedStage(spvo_ctx *ctx, int stage, double flops = 0, double bytes = 0) : c(ctx) {
+  hipStream_t st = nullptr;
+  ScopedStage(spvo_ctx *ctx, int stage, double flops = 0, double bytes = 0, hipStream_t stream = nullptr) : c(ctx) {
     if (!c->prof || stage < 0) return;
     id = stage;
+    st = stream ? stream : c->stream;
     if (flops > 0) c->stages[id].flops = flops;
     if (bytes > 0) c->stages[id].bytes = bytes;
     e0 = get_event(c);
-    (void)hipEventRecord(e0, c->stream);
+    (void)hipEventRecord(e0, st);
   }
   ~ScopedStage() {
     if (id < 0) return;
     hipEvent_t e1 = get_event(c);
-    (void)hipEventRecord(e1, c->stream);
+    (void)hipEventRecord(e1, st);
     c->pending.push_back({id, e0, e1});
     if (c->pending.size() > 8192) resolve_pending(c);
   }
@@ -640,7 +653,7 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
   spvo_ctx *c = new spvo_ctx();
   c->cfg = *cfg;
   c->H = cfg->net_height; c->W = cfg->net_width; c->Hc = c->H / 8; c->Wc = c->W / 8; c->B = 2;
-  if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+  if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess) {
     delete c;
     return fail(nullptr, SPVO_ERR_DEVICE, "cannot create a stream on device %d", cfg->device);
   }
@@ -677,11 +690,10 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
     if ((rc = dev_alloc(c, &c->d_desc_tmp, (size_t)cap * 256))) break;
     if (hipHostMalloc((void **)&c->h_counters, 2 * NMS_COUNTER_INTS * sizeof(int)) != hipSuccess ||
         hipHostMalloc((void **)&c->h_xy, (size_t)2 * cap * 2 * sizeof(float)) != hipSuccess) { rc = fail(c, SPVO_ERR_DEVICE, "hipHostMalloc failed"); break; }
-    for (auto &m : c->mcache)
-      if (hipHostMalloc((void **)&m.h_idx, (size_t)cap * sizeof(int32_t)) != hipSuccess || hipHostMalloc((void **)&m.h_dist, (size_t)cap * sizeof(float)) != hipSuccess) {
-        rc = fail(c, SPVO_ERR_DEVICE, "hipHostMalloc failed");
-        break;
-      }
+    for (auto &set : c->mcache)
+      for (auto &m : set)
+        if (hipHostMalloc((void **)&m.h_idx, (size_t)cap * sizeof(int32_t)) != hipSuccess || hipHostMalloc((void **)&m.h_dist, (size_t)cap * sizeof(float)) != hipSuccess)
+          rc = fail(c, SPVO_ERR_DEVICE, "hipHostMalloc failed");
     if (rc) break;
     if ((rc = ensure_match(c, cap, cap))) break;
   } while (0);
@@ -699,6 +711,7 @@ void spvo_destroy(spvo_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->cfg.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   resolve_pending(c);
   for (auto e : c->free_events) (void)hipEventDestroy(e);
   for (auto &t : c->tensors) if (t.d) (void)hipFree(t.d);
@@ -722,11 +735,13 @@ void spvo_destroy(spvo_ctx *c) {
   if (c->h_xy) (void)hipHostFree(c->h_xy);
   for (void *hp : {(void *)c->h_solve_in, (void *)c->h_solve_res, (void *)c->h_solve_o}) if (hp) (void)hipHostFree(hp);
   for (void *dp : {(void *)c->d_solve_in, (void *)c->d_solve_res, (void *)c->d_solve_o, (void *)c->d_ctl}) if (dp) (void)hipFree(dp);
-  for (auto &m : c->mcache) {
-    if (m.h_idx) (void)hipHostFree(m.h_idx);
-    if (m.h_dist) (void)hipHostFree(m.h_dist);
-  }
+  for (auto &set : c->mcache)
+    for (auto &m : set) {
+      if (m.h_idx) (void)hipHostFree(m.h_idx);
+      if (m.h_dist) (void)hipHostFree(m.h_dist);
+    }
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   delete c;
 }
 
@@ -977,11 +992,11 @@ static int enqueue_sample(spvo_ctx *c, const int slots[2]) {
   return SPVO_OK;
 }
 
-static int enqueue_prematch(spvo_ctx *c, int slot_l, int slot_r, int prev_l) {
+static int enqueue_prematch(spvo_ctx *c, int slot_l, int slot_r, int prev_l, int parity) {
   const int cap = c->cfg.max_keypoints;
   const int partner[2] = {slot_r, prev_l};
   for (int k = 0; k < 2; ++k) {
-    MatchCache &mc = c->mcache[k];
+    MatchCache &mc = c->mcache[parity][k];
     mc.valid = false;
     if (partner[k] < 0) continue;
     FeatureSlot &a = c->slots[slot_l], &b = c->slots[partner[k]];
@@ -994,20 +1009,21 @@ static int enqueue_prematch(spvo_ctx *c, int slot_l, int slot_r, int prev_l) {
   return SPVO_OK;
 }
 
-static int detect_common(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, int rows, int cols, size_t stride, double P_l[12], double P_r[12],
-                         int slot_l, int slot_r, spvo_features *out_l, spvo_features *out_r, uint8_t *resized_l, uint8_t *resized_r) {
+static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, int rows, int cols, size_t stride, int slot_l, int slot_r) {
+  if (c->pend.active) return fail(c, SPVO_ERR_STATE, "a detector submission is already in flight");
   if (slot_l < 0 || slot_l > 3 || slot_r < 0 || slot_r > 3 || slot_l == slot_r) return fail(c, SPVO_ERR_INVALID, "bad feature slots %d, %d", slot_l, slot_r);
   if (c->cfg.max_batch != 2) return fail(c, SPVO_ERR_INVALID, "max_batch == 1 detect path is not built yet; use max_batch = 2");
   const CropGeom g = crop_geometry(rows, cols, c->H, c->W);
   const Tensor &td = c->tensors[c->t_det];
   const uint8_t *srcs[2] = {d_l, d_r};
   const int slots[2] = {slot_l, slot_r};
-  const int cap = c->cfg.max_keypoints;
   // temporal partner = the left slot of the previous call, if it survives this call
   int prev_l = c->last_slot_l;
   if (prev_l == slot_l || prev_l == slot_r || (prev_l >= 0 && c->slots[prev_l].gen == 0)) prev_l = -1;
-  for (auto &mc : c->mcache) mc.valid = false;
-  // ---- everything below is enqueued without a host round trip; ONE sync at the end
+  c->det_parity ^= 1;
+  const int parity = c->det_parity;
+  for (auto &mc : c->mcache[parity]) mc.valid = false;
+  // ---- everything below is enqueued without a host round trip
   {
     ScopedStage st(c, stage_id(c, "detect"));
     {
@@ -1027,23 +1043,39 @@ static int detect_common(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
     }
     if ((rc = enqueue_sample(c, slots))) return rc;
   }
-  if (c->prematch) { int rc = enqueue_prematch(c, slot_l, slot_r, prev_l); if (rc) return rc; }
+  if (c->prematch) { int rc = enqueue_prematch(c, slot_l, slot_r, prev_l, parity); if (rc) return rc; }
+  c->pend.active = true;
+  c->pend.g = CropGeomS{g.row_off, g.col_off, g.crop_rows, g.crop_cols, g.scale};
+  c->pend.rows = rows; c->pend.cols = cols;
+  c->pend.slot_l = slot_l; c->pend.slot_r = slot_r; c->pend.prev_l = prev_l; c->pend.parity = parity;
+  return SPVO_OK;
+}
+
+static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_features *out_l, spvo_features *out_r, uint8_t *resized_l, uint8_t *resized_r) {
+  if (!c->pend.active) return fail(c, SPVO_ERR_STATE, "no detector submission in flight");
+  const PendingDetect pd = c->pend;
+  c->pend.active = false;
+  const int slots[2] = {pd.slot_l, pd.slot_r};
+  const int cap = c->cfg.max_keypoints;
   uint8_t *res[2] = {resized_l, resized_r};
-  for (int i = 0; i < 2; ++i)
-    if (res[i]) HIP_TRY(c, hipMemcpyAsync(res[i], c->d_resized + (size_t)i * c->H * c->W, (size_t)c->H * c->W, hipMemcpyDeviceToHost, c->stream));
   spvo_features *outs[2] = {out_l, out_r};
-  // descriptors: the count is not known yet, copy the full slot (1000 x 256 floats)
-  for (int i = 0; i < 2; ++i)
-    if (outs[i] && outs[i]->desc) HIP_TRY(c, hipMemcpyAsync(outs[i]->desc, c->slots[slots[i]].d_desc, (size_t)cap * 256 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  bool redone = false;
-  int rc = nms_settle(c, 2, &redone);
-  if (rc) return rc;
-  if (redone) {   // rare: the keypoints changed after the first batch -> redo what depends on them
-    if ((rc = enqueue_sample(c, slots))) return rc;
-    if (c->prematch && (rc = enqueue_prematch(c, slot_l, slot_r, prev_l))) return rc;
+  auto copy_extras = [&]() -> int {
+    for (int i = 0; i < 2; ++i)
+      if (res[i]) HIP_TRY(c, hipMemcpyAsync(res[i], c->d_resized + (size_t)i * c->H * c->W, (size_t)c->H * c->W, hipMemcpyDeviceToHost, c->stream));
+    // descriptors: copy the full slot (1000 x 256 floats); rows >= n are stale
     for (int i = 0; i < 2; ++i)
       if (outs[i] && outs[i]->desc) HIP_TRY(c, hipMemcpyAsync(outs[i]->desc, c->slots[slots[i]].d_desc, (size_t)cap * 256 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    return SPVO_OK;
+  };
+  int rc = copy_extras();
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  bool redone = false;
+  if ((rc = nms_settle(c, 2, &redone))) return rc;
+  if (redone) {   // rare: the keypoints changed after the first batch -> redo what depends on them
+    if ((rc = enqueue_sample(c, slots))) return rc;
+    if (c->prematch && (rc = enqueue_prematch(c, pd.slot_l, pd.slot_r, pd.prev_l, pd.parity))) return rc;
+    if ((rc = copy_extras())) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
   for (int i = 0; i < 2; ++i) {
@@ -1055,12 +1087,20 @@ static int detect_common(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
       if (outs[i]->xy && s.n > 0) std::memcpy(outs[i]->xy, c->h_xy + (size_t)i * cap * 2, (size_t)s.n * 2 * sizeof(float));
     }
   }
-  for (auto &mc : c->mcache)
+  for (auto &mc : c->mcache[pd.parity])
     if (mc.valid) { mc.gen_a = c->slots[mc.slot_a].gen; mc.gen_b = c->slots[mc.slot_b].gen; }
-  c->last_slot_l = slot_l;
-  fix_projection(P_l, g, rows, cols, c->cfg.bug_compat_p);
-  fix_projection(P_r, g, rows, cols, c->cfg.bug_compat_p);
+  c->last_slot_l = pd.slot_l;
+  const CropGeom g{pd.g.row_off, pd.g.col_off, pd.g.crop_rows, pd.g.crop_cols, pd.g.scale};
+  if (P_l) fix_projection(P_l, g, pd.rows, pd.cols, c->cfg.bug_compat_p);
+  if (P_r) fix_projection(P_r, g, pd.rows, pd.cols, c->cfg.bug_compat_p);
   return SPVO_OK;
+}
+
+static int detect_common(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, int rows, int cols, size_t stride, double P_l[12], double P_r[12],
+                         int slot_l, int slot_r, spvo_features *out_l, spvo_features *out_r, uint8_t *resized_l, uint8_t *resized_r) {
+  int rc = detect_submit(c, d_l, d_r, rows, cols, stride, slot_l, slot_r);
+  if (rc) return rc;
+  return detect_wait(c, P_l, P_r, out_l, out_r, resized_l, resized_r);
 }
 
 int spvo_detect(spvo_ctx *c, const uint8_t *img_l, const uint8_t *img_r, int rows, int cols, size_t stride, double P_l[12], double P_r[12],
@@ -1087,6 +1127,19 @@ int spvo_detect_dev(spvo_ctx *c, const void *d_img_l, const void *d_img_r, int r
   return detect_common(c, (const uint8_t *)d_img_l, (const uint8_t *)d_img_r, rows, cols, stride, P_l, P_r, slot_l, slot_r, out_l, out_r, nullptr, nullptr);
 }
 
+int spvo_detect_dev_submit(spvo_ctx *c, const void *d_img_l, const void *d_img_r, int rows, int cols, size_t stride, int slot_l, int slot_r) {
+  if (!c || !d_img_l || !d_img_r || rows <= 0 || cols <= 0 || stride < (size_t)cols) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  return detect_submit(c, (const uint8_t *)d_img_l, (const uint8_t *)d_img_r, rows, cols, stride, slot_l, slot_r);
+}
+
+int spvo_detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_features *out_l, spvo_features *out_r) {
+  if (!c) return fail(c, SPVO_ERR_INVALID, "null context");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  return detect_wait(c, P_l, P_r, out_l, out_r, nullptr, nullptr);
+}
+
 int spvo_match(spvo_ctx *c, const float *desc_a, int na, const float *desc_b, int nb, int selector, int cross_check, float ratio, int32_t *train_idx, float *distance) {
   if (!c || na < 0 || nb < 0 || (na > 0 && (!desc_a || !train_idx || !distance)) || (nb > 0 && !desc_b)) return fail(c, SPVO_ERR_INVALID, "bad argument");
   if (selector != SPVO_SELECT_NN && selector != SPVO_SELECT_KNN) return fail(c, SPVO_ERR_INVALID, "bad selector");
@@ -1103,15 +1156,19 @@ int spvo_match_slots(spvo_ctx *c, int slot_a, int slot_b, int selector, int cros
   if (selector != SPVO_SELECT_NN && selector != SPVO_SELECT_KNN) return fail(c, SPVO_ERR_INVALID, "bad selector");
   const FeatureSlot &a = c->slots[slot_a], &b = c->slots[slot_b];
   if (a.n > 0 && (!train_idx || !distance)) return fail(c, SPVO_ERR_INVALID, "null output");
-  for (const auto &mc : c->mcache)   // already computed alongside the detector (spvo_set_prematch)?
-    if (mc.valid && mc.slot_a == slot_a && mc.slot_b == slot_b && mc.gen_a == a.gen && mc.gen_b == b.gen && mc.selector == selector &&
-        mc.cross == (cross_check ? 1 : 0) && mc.ratio == ratio) {
-      if (a.n > 0) {
-        std::memcpy(train_idx, mc.h_idx, (size_t)a.n * sizeof(int32_t));
-        std::memcpy(distance, mc.h_dist, (size_t)a.n * sizeof(float));
+  for (int set = 0; set < 2; ++set) {   // already computed alongside the detector (spvo_set_prematch)?
+    if (c->pend.active && set == c->pend.parity) continue;   // that set belongs to the submission in flight
+    for (const auto &mc : c->mcache[set])
+      if (mc.valid && mc.slot_a == slot_a && mc.slot_b == slot_b && mc.gen_a == a.gen && mc.gen_b == b.gen && mc.selector == selector &&
+          mc.cross == (cross_check ? 1 : 0) && mc.ratio == ratio) {
+        if (a.n > 0) {
+          std::memcpy(train_idx, mc.h_idx, (size_t)a.n * sizeof(int32_t));
+          std::memcpy(distance, mc.h_dist, (size_t)a.n * sizeof(float));
+        }
+        return SPVO_OK;
       }
-      return SPVO_OK;
-    }
+  }
+  if (c->pend.active) return fail(c, SPVO_ERR_STATE, "match not precomputed and a detector submission is rewriting the feature slots");
   HIP_TRY(c, hipSetDevice(c->cfg.device));
   int rc = ensure_match(c, a.n, b.n);
   if (rc) return rc;
@@ -1125,7 +1182,8 @@ int spvo_set_prematch(spvo_ctx *c, int enable, int selector, int cross_check, fl
   c->pm_selector = selector;
   c->pm_cross = cross_check ? 1 : 0;
   c->pm_ratio = ratio;
-  for (auto &mc : c->mcache) mc.valid = false;
+  for (auto &set : c->mcache)
+    for (auto &mc : set) mc.valid = false;
   return SPVO_OK;
 }
 
@@ -1237,11 +1295,14 @@ int spvo_solve_stereo_odometry(spvo_ctx *c, const spvo_solve_input *in, spvo_sol
     for (int k = 0; k < 3; ++k) { out->t[k] = in->tvec_pred[k]; out->rvec[k] = in->rvec_pred[k]; out->tvec[k] = in->tvec_pred[k]; }
   };
   if (n == 0) { prior_pose(); return SPVO_OK; }
+  // this call runs on the context's second stream so that it overlaps a detector submission in
+  // flight; buffers only grow on first use (then everything is drained once)
+  const bool grow = n > c->odo_cap || in->ransac.iterations > c->ransac_cap || 4 * n > c->obs_cap || !c->d_P || n > c->solve_cap;
+  if (grow) HIP_TRY(c, hipDeviceSynchronize());
   int rc = ensure_odometry(c, n, in->ransac.iterations, 4 * n);
   if (rc) return rc;
   if (n > c->solve_cap) {
     const int cap = std::max(n, 2048);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (void *hp : {(void *)c->h_solve_in, (void *)c->h_solve_res, (void *)c->h_solve_o}) if (hp) (void)hipHostFree(hp);
     for (void *dp : {(void *)c->d_solve_in, (void *)c->d_solve_res, (void *)c->d_solve_o, (void *)c->d_ctl}) if (dp) (void)hipFree(dp);
     c->h_solve_in = c->h_solve_o = nullptr; c->h_solve_res = nullptr;
@@ -1255,6 +1316,7 @@ int spvo_solve_stereo_odometry(spvo_ctx *c, const spvo_solve_input *in, spvo_sol
     HIP_TRY(c, hipHostMalloc((void **)&c->h_solve_o, o_bytes));
     c->solve_cap = cap;
   }
+  if (grow) HIP_TRY(c, hipDeviceSynchronize());
   // ---- pack: 64 doubles, then cl cr pl pr [2n each], prev_xyz [3n], prev_valid [n]
   double *hdr = (double *)c->h_solve_in;
   std::memset(hdr, 0, 64 * sizeof(double));
@@ -1275,7 +1337,7 @@ int spvo_solve_stereo_odometry(spvo_ctx *c, const spvo_solve_input *in, spvo_sol
     std::memcpy(fw + 11 * n, in->prev_valid, (size_t)n * 4);
   }
   const size_t used = 64 * sizeof(double) + (size_t)12 * n * 4;
-  HIP_TRY(c, hipMemcpyAsync(c->d_solve_in, c->h_solve_in, used, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_solve_in, c->h_solve_in, used, hipMemcpyHostToDevice, c->stream2));
   const double *dh = (const double *)c->d_solve_in;
   const float *df = (const float *)(c->d_solve_in + 64 * sizeof(double));
   float *d_xyz = (float *)c->d_solve_o;
@@ -1285,22 +1347,22 @@ int spvo_solve_stereo_odometry(spvo_ctx *c, const spvo_solve_input *in, spvo_sol
   rw.inliers = d_inl;
   const double thr2 = in->ransac.reproj_error * in->ransac.reproj_error;
   {
-    ScopedStage st(c, stage_id(c, "solve"));
-    hipLaunchKernelGGL(triangulate_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, dh, dh + 12, df, df + 2 * n, n, d_xyz);
+    ScopedStage st(c, stage_id(c, "solve"), 0, 0, c->stream2);
+    hipLaunchKernelGGL(triangulate_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream2, dh, dh + 12, df, df + 2 * n, n, d_xyz);
     if (n >= 4) {
-      hipLaunchKernelGGL(ransac_hypothesis_kernel, dim3(in->ransac.iterations), dim3(64), 0, c->stream, dh + 24, d_xyz, df + 4 * n, n, dh + 33, in->ransac.seed, thr2, rw);
-      hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(256), 0, c->stream, dh + 24, d_xyz, df + 4 * n, n, dh + 33, in->ransac.iterations, thr2, rw);
-      hipLaunchKernelGGL(solve_gate_build_kernel, dim3(1), dim3(256), 0, c->stream, dh, c->d_solve_res, d_inl, d_xyz, df, df + 2 * n, df + 4 * n, df + 6 * n,
+      hipLaunchKernelGGL(ransac_hypothesis_kernel, dim3(in->ransac.iterations), dim3(64), 0, c->stream2, dh + 24, d_xyz, df + 4 * n, n, dh + 33, in->ransac.seed, thr2, rw);
+      hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(256), 0, c->stream2, dh + 24, d_xyz, df + 4 * n, n, dh + 33, in->ransac.iterations, thr2, rw);
+      hipLaunchKernelGGL(solve_gate_build_kernel, dim3(1), dim3(256), 0, c->stream2, dh, c->d_solve_res, d_inl, d_xyz, df, df + 2 * n, df + 4 * n, df + 6 * n,
                          have_prev ? df + 8 * n : (const float *)nullptr, have_prev ? (const int *)(df + 11 * n) : (const int *)nullptr, c->d_obs, c->d_ctl,
                          c->d_solve_res + 8);
-      hipLaunchKernelGGL(pnp_refine_kernel<512>, dim3(1), dim3(512), 0, c->stream, dh, dh + 12, c->d_obs, 0, (const int *)c->d_ctl, c->d_solve_res + 8,
+      hipLaunchKernelGGL(pnp_refine_kernel<512>, dim3(1), dim3(512), 0, c->stream2, dh, dh + 12, c->d_obs, 0, (const int *)c->d_ctl, c->d_solve_res + 8,
                          in->refine.max_iterations, in->refine.huber_delta, (RefineOut *)(c->d_solve_res + 24));
     }
     HIP_TRY(c, hipGetLastError());
   }
-  HIP_TRY(c, hipMemcpyAsync(c->h_solve_o, c->d_solve_o, (size_t)4 * n * 4, hipMemcpyDeviceToHost, c->stream));
-  if (n >= 4) HIP_TRY(c, hipMemcpyAsync(c->h_solve_res, c->d_solve_res, 40 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_solve_o, c->d_solve_o, (size_t)4 * n * 4, hipMemcpyDeviceToHost, c->stream2));
+  if (n >= 4) HIP_TRY(c, hipMemcpyAsync(c->h_solve_res, c->d_solve_res, 40 * sizeof(double), hipMemcpyDeviceToHost, c->stream2));
+  HIP_TRY(c, hipStreamSynchronize(c->stream2));
   std::memcpy(xyz, c->h_solve_o, (size_t)3 * n * 4);
   if (n < 4) { prior_pose(); return SPVO_OK; }                                      // no model possible: prior is kept
   const double *res = c->h_solve_res, *gate = res + 8, *ref = res + 24;

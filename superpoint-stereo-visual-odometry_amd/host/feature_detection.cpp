@@ -283,6 +283,10 @@ SuperPointFeatureFrontEnd::SuperPointFeatureFrontEnd(const MatcherType matcher_t
 }
 
 SuperPointFeatureFrontEnd::~SuperPointFeatureFrontEnd() {
+  if (ctx_ && prefetch_.active) {
+    spvo_features dl{0, nullptr, nullptr}, dr{0, nullptr, nullptr};
+    spvo_detect_wait(ctx_, nullptr, nullptr, &dl, &dr);
+  }
   if (ctx_) spvo_destroy(ctx_);
   ctx_ = nullptr;
 }
@@ -386,11 +390,27 @@ void SuperPointFeatureFrontEnd::addStereoImagePairDevice(const void *d_img_l, co
   projection_matrix_l_ = projection_matrix_l.clone();
   projection_matrix_r_ = projection_matrix_r.clone();
   int slot_l, slot_r;
-  pickSlots(&slot_l, &slot_r);
   spvo_features fl{0, xy_buf_[0].data(), host_descriptors ? desc_buf_[0].data() : nullptr};
   spvo_features fr{0, xy_buf_[1].data(), host_descriptors ? desc_buf_[1].data() : nullptr};
-  const int rc = spvo_detect_dev(ctx_, d_img_l, d_img_r, rows, cols, stride, projection_matrix_l_.ptr<double>(0),
-                                 projection_matrix_r_.ptr<double>(0), slot_l, slot_r, &fl, &fr);
+  int rc;
+  const bool hit = prefetch_.active && prefetch_.l == d_img_l && prefetch_.r == d_img_r && prefetch_.rows == rows && prefetch_.cols == cols &&
+                   prefetch_.stride == stride;
+  if (prefetch_.active && !hit) {  // a different pair was announced: drain and drop it
+    spvo_features dl{0, nullptr, nullptr}, dr{0, nullptr, nullptr};
+    spvo_detect_wait(ctx_, nullptr, nullptr, &dl, &dr);
+    prefetch_.active = false;
+    logError("addStereoImagePairDevice: the prefetched pair was not the one passed in; prefetch discarded");
+  }
+  if (hit) {
+    slot_l = prefetch_.slot_l;
+    slot_r = prefetch_.slot_r;
+    prefetch_.active = false;
+    rc = spvo_detect_wait(ctx_, projection_matrix_l_.ptr<double>(0), projection_matrix_r_.ptr<double>(0), &fl, &fr);
+  } else {
+    pickSlots(&slot_l, &slot_r);
+    rc = spvo_detect_dev(ctx_, d_img_l, d_img_r, rows, cols, stride, projection_matrix_l_.ptr<double>(0),
+                         projection_matrix_r_.ptr<double>(0), slot_l, slot_r, &fl, &fr);
+  }
   if (rc != SPVO_OK) {
     logError(std::string("spvo_detect_dev: ") + spvo_last_error(ctx_));
     return;
@@ -400,6 +420,20 @@ void SuperPointFeatureFrontEnd::addStereoImagePairDevice(const void *d_img_l, co
   const cv::Mat *res[2] = {&empty, &empty};
   const int slots[2] = {slot_l, slot_r};
   pushFeatures(f, res, slots, host_descriptors);
+}
+
+void SuperPointFeatureFrontEnd::prefetchStereoImagePairDevice(const void *d_img_l, const void *d_img_r, int rows, int cols, size_t stride) {
+  if (!engine_loaded_ || prefetch_.active) return;
+  int slot_l, slot_r;
+  pickSlots(&slot_l, &slot_r);  // the slots of the oldest pair: its matches are already cached
+  if (spvo_detect_dev_submit(ctx_, d_img_l, d_img_r, rows, cols, stride, slot_l, slot_r) != SPVO_OK) {
+    logError(std::string("spvo_detect_dev_submit: ") + spvo_last_error(ctx_));
+    return;
+  }
+  prefetch_.active = true;
+  prefetch_.l = d_img_l; prefetch_.r = d_img_r;
+  prefetch_.rows = rows; prefetch_.cols = cols; prefetch_.stride = stride;
+  prefetch_.slot_l = slot_l; prefetch_.slot_r = slot_r;
 }
 
 void SuperPointFeatureFrontEnd::pickSlots(int *slot_l, int *slot_r) const {

@@ -245,6 +245,11 @@ public:
   void addStereoImagePairDevice(const void *d_img_l, const void *d_img_r, int rows, int cols, size_t stride,
                                 const cv::Mat &projection_matrix_l, const cv::Mat &projection_matrix_r,
                                 bool host_descriptors = false);
+  // Extension: hand over the NEXT stereo pair early.  The detector chain for it is enqueued at once
+  // and runs on the GPU while the caller is still matching / solving the current pair; the following
+  // addStereoImagePairDevice with the same pointers only collects the result.  Purely a latency-hiding
+  // hint: results are identical with or without it.
+  void prefetchStereoImagePairDevice(const void *d_img_l, const void *d_img_r, int rows, int cols, size_t stride);
   spvo_ctx *context() const { return ctx_; }
 
   inline int getInputHeight() const { return input_height_; }
@@ -265,6 +270,12 @@ private:
   const int num_threads_;  // kept for signature parity; the work runs on the GPU
   bool engine_loaded_ = false;
   std::vector<float> xy_buf_[2], desc_buf_[2];
+  struct Prefetch {
+    bool active = false;
+    const void *l = nullptr, *r = nullptr;
+    int rows = 0, cols = 0, slot_l = 0, slot_r = 0;
+    size_t stride = 0;
+  } prefetch_;
   void pickSlots(int *slot_l, int *slot_r) const;
   void pushFeatures(const spvo_features *f[2], const cv::Mat *images[2], const int slots[2], bool host_descriptors);
 };

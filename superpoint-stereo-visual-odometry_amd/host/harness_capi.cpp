@@ -45,6 +45,10 @@ void spvo_host_add_stereo_pair_dev(void *h, const void *d_l, const void *d_r, in
   fe->addStereoImagePairDevice(d_l, d_r, rows, cols, stride, pl, pr, host_descriptors != 0);
 }
 
+void spvo_host_prefetch_dev(void *h, const void *d_l, const void *d_r, int rows, int cols, size_t stride) {
+  static_cast<SuperPointFeatureFrontEnd *>(h)->prefetchStereoImagePairDevice(d_l, d_r, rows, cols, stride);
+}
+
 void *spvo_host_ctx(void *h) { return static_cast<SuperPointFeatureFrontEnd *>(h)->context(); }
 
 void spvo_host_match(void *h, int match_type) { static_cast<SuperPointFeatureFrontEnd *>(h)->matchDescriptors((MatchType)match_type); }

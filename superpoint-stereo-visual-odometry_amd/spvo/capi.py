@@ -58,7 +58,7 @@ OBS_DTYPE = np.dtype([("X", np.float32, 3), ("uv", np.float32, 2), ("cam", np.in
 SYMBOLS = [
     "spvo_default_config", "spvo_create", "spvo_destroy", "spvo_last_error", "spvo_load_weights",
     "spvo_preprocess", "spvo_forward", "spvo_debug_tensor", "spvo_heatmap", "spvo_nms",
-    "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_match", "spvo_match_slots", "spvo_set_prematch",
+    "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_detect_dev_submit", "spvo_detect_wait", "spvo_match", "spvo_match_slots", "spvo_set_prematch",
     "spvo_triangulate", "spvo_pnp_ransac", "spvo_pnp_refine", "spvo_solve_stereo_odometry", "spvo_stream", "spvo_synchronize",
     "spvo_profile_enable", "spvo_profile_reset", "spvo_profile_count", "spvo_profile_get",
 ]
@@ -93,6 +93,8 @@ def load() -> C.CDLL:
                                 C.POINTER(Features), C.POINTER(Features), vp, vp]
     lib.spvo_detect_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, dp, dp, C.c_int, C.c_int,
                                     C.POINTER(Features), C.POINTER(Features)]
+    lib.spvo_detect_dev_submit.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int]
+    lib.spvo_detect_wait.argtypes = [vp, dp, dp, C.POINTER(Features), C.POINTER(Features)]
     lib.spvo_match.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
     lib.spvo_match_slots.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
     lib.spvo_set_prematch.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float]

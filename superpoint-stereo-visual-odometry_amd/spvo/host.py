@@ -37,6 +37,8 @@ def load():
         lib.spvo_host_add_stereo_pair.restype = None
         lib.spvo_host_add_stereo_pair_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, vp, vp, C.c_int]
         lib.spvo_host_add_stereo_pair_dev.restype = None
+        lib.spvo_host_prefetch_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t]
+        lib.spvo_host_prefetch_dev.restype = None
         lib.spvo_host_ctx.argtypes = [vp]
         lib.spvo_host_ctx.restype = vp
         lib.spvo_host_match.argtypes = [vp, C.c_int]
@@ -117,8 +119,15 @@ class FrontEnd:
         c.close = lambda: None                         # owned by the C++ object
         return c
 
-    def step_device(self, d_l, d_r, rows, cols, stride, P_l, P_r):
+    def prefetch_device(self, d_l: int, d_r: int, rows: int, cols: int, stride: int):
+        self.lib.spvo_host_prefetch_dev(self.h, C.c_void_p(d_l), C.c_void_p(d_r), rows, cols, stride)
+
+    def step_device(self, d_l, d_r, rows, cols, stride, P_l, P_r, next_pair=None):
+        """One stereoCallback on a device-resident pair; `next_pair` = (d_l, d_r) of the following
+        frame, handed over early so that its detector overlaps this frame's matching / solving."""
         self.add_stereo_image_pair_device(d_l, d_r, rows, cols, stride, P_l, P_r)
+        if next_pair is not None:
+            self.prefetch_device(next_pair[0], next_pair[1], rows, cols, stride)
         if self.dq_size() < 4:
             self.match_descriptors(CURR_LEFT_CURR_RIGHT)
             return None

@@ -92,3 +92,27 @@ def test_host_error_conventions(models_dir, tmp_path):
     q, t = fe.step(img, img, P_l, P_r)
     assert np.allclose(q, [0, 0, 0, 1]) and np.allclose(t, 0)
     fe.close()
+
+
+def test_prefetch_pipeline_is_transparent(models_dir, sequence):
+    """Handing the next pair over early (detector overlapped with matching/solving) changes nothing."""
+    import torch
+    frames, poses, P_l, P_r = sequence
+    dev = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
+    rows, cols = frames[0][0].shape
+    out = {}
+    for pipelined in (False, True):
+        fe = host.FrontEnd(models_dir, prefix="sp_squeeze")
+        res = []
+        for k, (dl, dr) in enumerate(dev):
+            nxt = (dev[k + 1][0].data_ptr(), dev[k + 1][1].data_ptr()) if pipelined and k + 1 < len(dev) else None
+            r = fe.step_device(dl.data_ptr(), dr.data_ptr(), rows, cols, dl.stride(0), P_l, P_r, nxt)
+            res.append((r, fe.keypoints(host.CURR_LEFT), fe.map_of_indices(0), fe.map_of_indices(1) if k else None, fe.inliers("pnp")))
+        out[pipelined] = res
+        fe.close()
+    for a, b in zip(out[False], out[True]):
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4])
+        if a[3] is not None:
+            assert np.array_equal(a[3], b[3])
+        if a[0] is not None:
+            assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1])      # poses: bit-identical

@@ -63,7 +63,7 @@ static void pack_weights(const std::vector<float> &w, int cout, int cin, int KS,
           }
 }
 
-template <int KS, int CK, int WR, int WC, bool POOL>
+template <int KS, int CK, int WR, int WC, bool POOL, int MINW = 1>
 static double run_variant(const char *name, int B, int cin, int cout, int H, int W, int reps) {
   using T = ConvTile<KS, CK, WR, WC>;
   const int hp = padded_h(H), wp = padded_w(W);
@@ -112,7 +112,7 @@ static double run_variant(const char *name, int B, int cin, int cout, int H, int
   a.n_chunks = cin / CK;
   a.tiles_x = (W + T::TW - 1) / T::TW; a.tiles_y = (H + T::TH - 1) / T::TH; a.co_tiles = co_tiles;
   const int grid = a.tiles_x * a.tiles_y * co_tiles * B;
-  auto kern = conv_mfma_kernel<KS, CK, WR, WC, POOL, true>;
+  auto kern = conv_mfma_kernel<KS, CK, WR, WC, POOL, true, MINW>;
   CK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
   kern<<<grid, 256, T::LDS_BYTES>>>(a);
   CK_HIP(hipDeviceSynchronize());
@@ -158,21 +158,22 @@ int main(int argc, char **argv) {
   run_variant<1, 16, 2, 2, false>("small k1 8x64", 1, 16, 48, 21, 75, 2);
   // VGG layer shapes at 360x1176, stereo pair (B = 2)
   run_variant<3, 8, 2, 2, true>("conv1b 8x64 pool ck8", 2, 64, 64, 360, 1176, reps);
-  run_variant<3, 4, 2, 2, true>("conv1b 8x64 pool ck4", 2, 64, 64, 360, 1176, reps);
+  run_variant<3, 4, 2, 2, true, 2>("conv1b 8x64 pool ck4 w2", 2, 64, 64, 360, 1176, reps);
   run_variant<3, 8, 2, 1, true>("conv1b 8x32 pool ck8", 2, 64, 64, 360, 1176, reps);
+  run_variant<3, 4, 2, 1, true>("conv1b 8x32 pool ck4", 2, 64, 64, 360, 1176, reps);
   run_variant<3, 8, 2, 2, false>("conv2a 8x64", 2, 64, 64, 180, 588, reps);
   run_variant<3, 8, 1, 2, false>("conv2a 4x64", 2, 64, 64, 180, 588, reps);
+  run_variant<3, 8, 1, 1, false>("conv2a 4x32", 2, 64, 64, 180, 588, reps);
+  run_variant<3, 4, 1, 2, false>("conv2a 4x64 ck4", 2, 64, 64, 180, 588, reps);
   run_variant<3, 8, 2, 2, true>("conv2b 8x64 pool", 2, 64, 64, 180, 588, reps);
   run_variant<3, 8, 2, 1, true>("conv2b 8x32 pool", 2, 64, 64, 180, 588, reps);
-  run_variant<3, 8, 2, 2, false>("conv3a 8x64", 2, 64, 128, 90, 294, reps);
   run_variant<3, 8, 1, 2, false>("conv3a 4x64", 2, 64, 128, 90, 294, reps);
   run_variant<3, 8, 1, 1, false>("conv3a 4x32", 2, 64, 128, 90, 294, reps);
   run_variant<3, 8, 2, 1, true>("conv3b 8x32 pool", 2, 128, 128, 90, 294, reps);
-  run_variant<3, 8, 2, 2, true>("conv3b 8x64 pool", 2, 128, 128, 90, 294, reps);
   run_variant<3, 8, 1, 1, false>("conv4a 4x32", 2, 128, 128, 45, 147, reps);
-  run_variant<3, 8, 1, 2, false>("conv4a 4x64", 2, 128, 128, 45, 147, reps);
+  run_variant<3, 4, 1, 1, false>("conv4a 4x32 ck4", 2, 128, 128, 45, 147, reps);
   run_variant<3, 8, 1, 1, false>("heads3x3 4x32", 2, 128, 512, 45, 147, reps);
-  run_variant<3, 8, 1, 2, false>("heads3x3 4x64", 2, 128, 512, 45, 147, reps);
+  run_variant<3, 4, 1, 1, false>("heads3x3 4x32 ck4", 2, 128, 512, 45, 147, reps);
   run_variant<1, 16, 1, 1, false>("convDb 4x32", 2, 256, 256, 45, 147, reps);
   run_variant<1, 16, 1, 1, false>("convPb 4x32", 2, 256, 65, 45, 147, reps);
   return 0;
