@@ -157,25 +157,39 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
     __syncthreads();
     if (c + 1 < a.n_chunks) issue(c + 1, smem + ((c + 1) & 1) * T::BUF_FLOATS);
     const float *buf = smem + (c & 1) * T::BUF_FLOATS;
-#pragma unroll
-    for (int t = 0; t < KS * KS; ++t) {
+    // k-steps of this chunk: step = (tap, channel pair).  Operands of step s+1 are read from LDS
+    // into a second register set BEFORE the MFMAs of step s issue, so the LDS latency hides
+    // under 2*NT matrix instructions instead of stalling the head of every step.
+    constexpr int NSTEP = KS * KS * (CK / 2);
+    float av[2][2], bv[2][NT];
+    auto load_step = [&](int st, int slot) {
+      const int t = st / (CK / 2), p = st % (CK / 2);
       const int ky = t / KS, kx = t % KS;
 #pragma unroll
-      for (int p = 0; p < CK / 2; ++p) {
-        float av[2], bv[NT];
+      for (int m = 0; m < 2; ++m) av[slot][m] = buf[a_lane + (t * CK + 2 * p) * CO_TILE + 32 * m];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) av[m] = buf[a_lane + (t * CK + 2 * p) * CO_TILE + 32 * m];
+      for (int rr = 0; rr < WR; ++rr)
 #pragma unroll
-        for (int rr = 0; rr < WR; ++rr)
+        for (int cc = 0; cc < WC; ++cc)
+          bv[slot][rr * WC + cc] = buf[b_lane + 2 * p * (LH * LW) + (rr + ky) * LW + cc * 32 + kx];
+    };
+    load_step(0, 0);
 #pragma unroll
-          for (int cc = 0; cc < WC; ++cc)
-            bv[rr * WC + cc] = buf[b_lane + 2 * p * (LH * LW) + (rr + ky) * LW + cc * 32 + kx];
+    for (int st = 0; st < NSTEP; ++st) {
+      const int cur = st & 1;
+      // first matrix instruction of the step, then ALL LDS reads of the next step, then the other
+      // 2*NT-1 matrix instructions: when hipcc's lgkmcnt(0) in front of the next step is reached the
+      // reads are >= (2*NT-1)*64 cycles old.  sched_barrier(0) pins exactly this order.
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][0], bv[cur][0], acc[0][0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (st + 1 < NSTEP) load_step(st + 1, cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int n = 0; n < NT; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
-      }
+        for (int n = 0; n < NT; ++n)
+          if (m + n > 0) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][m], bv[cur][n], acc[m][n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 

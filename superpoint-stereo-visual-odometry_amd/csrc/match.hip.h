@@ -30,6 +30,19 @@ constexpr int MATCH_KEEP = 4;    // shortlist per (query, column group)
 // detector's counts are known on the host, from device memory (n_ptr).
 __device__ __forceinline__ int dev_count(int n_host, const int *n_ptr) { return n_ptr ? *n_ptr : n_host; }
 
+struct MatchJob {
+  const float *A, *B;             // [na][256], [nb][256]
+  int na, nb;                     // host counts (upper bounds when the *_ptr are set)
+  const int *na_ptr, *nb_ptr;     // device counts or NULL
+  const float *nA, *nB;           // squared row norms
+  int *shortlist;                 // [na][groups][MATCH_KEEP]
+  float *best_d2;                 // [na][2]
+  int *best_idx;                  // [na][2]
+  unsigned long long *train_best; // [nb] (cross-check only)
+  int2 *out;                      // [na] packed {train_idx, float bits of the distance}
+};
+struct MatchJobs { MatchJob j[2]; };   // blockIdx.z selects the job (stereo / temporal match)
+
 __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float *__restrict__ x, int n_host,
                                                          const int *__restrict__ n_ptr,
                                                          float *__restrict__ out) {
@@ -45,13 +58,15 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float *__restrict
 }
 
 // K12a. grid = (ceil(nb/128), ceil(na/32)).  shortlist[q][group][MATCH_KEEP] (train idx, -1 = none)
-__global__ __launch_bounds__(256) void match_gemm_kernel(const float *__restrict__ A, int na_host,
-                                                         const int *__restrict__ na_ptr,
-                                                         const float *__restrict__ B, int nb_host,
-                                                         const int *__restrict__ nb_ptr,
-                                                         const float *__restrict__ nA,
-                                                         const float *__restrict__ nB,
-                                                         int *__restrict__ shortlist, int groups) {
+__global__ __launch_bounds__(256) void match_gemm_kernel(MatchJobs jobs, int groups) {
+  const MatchJob jb = jobs.j[blockIdx.z];
+  const float *__restrict__ A = jb.A;
+  const float *__restrict__ B = jb.B;
+  const float *__restrict__ nA = jb.nA;
+  const float *__restrict__ nB = jb.nB;
+  int *__restrict__ shortlist = jb.shortlist;
+  const int na_host = jb.na, nb_host = jb.nb;
+  const int *na_ptr = jb.na_ptr, *nb_ptr = jb.nb_ptr;
   constexpr int KH = 128;          // K processed in two halves
   constexpr int LD = KH + 1;       // padded row: conflict-free ds_read_b32 down a column
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -142,15 +157,20 @@ __global__ __launch_bounds__(256) void match_gemm_kernel(const float *__restrict
 // K12b. One wave per query; lane c re-scores shortlisted candidate c exactly.
 // Handles groups*MATCH_KEEP candidates in passes of 64.
 // best[q] = {d2_0, d2_1 (f32 bits), idx0, idx1}
-__global__ __launch_bounds__(256) void match_rerank_kernel(const float *__restrict__ A, int na_host,
-                                                           const int *__restrict__ na_ptr,
-                                                           const float *__restrict__ B,
-                                                           const int *__restrict__ shortlist,
-                                                           int groups, float *__restrict__ best_d2,
-                                                           int *__restrict__ best_idx) {
+// When `select_here` is set (every mode but NN + cross-check) the selector of K13 runs at the end of
+// this kernel and the packed result is written directly; with cross-check the best-of-train scatter
+// happens here and match_select_kernel finishes the job.
+__global__ __launch_bounds__(256) void match_rerank_kernel(MatchJobs jobs, int groups, int selector,
+                                                           int cross_check, float ratio) {
+  const MatchJob jb = jobs.j[blockIdx.y];
+  const float *__restrict__ A = jb.A;
+  const float *__restrict__ B = jb.B;
+  const int *__restrict__ shortlist = jb.shortlist;
+  float *__restrict__ best_d2 = jb.best_d2;
+  int *__restrict__ best_idx = jb.best_idx;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const int na = dev_count(na_host, na_ptr);
+  const int na = dev_count(jb.na, jb.na_ptr);
   if (q >= na) return;
   const int ncand = groups * MATCH_KEEP;
   const float *a = A + (size_t)q * MATCH_D;
@@ -198,51 +218,32 @@ __global__ __launch_bounds__(256) void match_rerank_kernel(const float *__restri
   if (lane == 0) {
     best_d2[2 * q] = d0; best_d2[2 * q + 1] = d1;
     best_idx[2 * q] = i0; best_idx[2 * q + 1] = i1;
-  }
-}
-
-// OpenCV crossCheck (batchDistance, crosscheck=true, K=1): for every train row the
-// query with the smallest distance among those that chose it (lowest query index
-// on ties) wins; other queries that chose the same train row are dropped.
-__global__ __launch_bounds__(256) void match_cross_scatter_kernel(const float *__restrict__ best_d2,
-                                                                  const int *__restrict__ best_idx,
-                                                                  int na_host, const int *__restrict__ na_ptr,
-                                                                  unsigned long long *__restrict__ train_best) {
-  const int na = dev_count(na_host, na_ptr);
-  const int q = blockIdx.x * 256 + threadIdx.x;
-  if (q >= na) return;
-  const int t = best_idx[2 * q];
-  if (t < 0) return;
-  const float d = sqrtf(best_d2[2 * q]);
-  atomicMin(&train_best[t], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)q);
-}
-
-// K13. selector 0 = NN, 1 = KNN(k=2) + ratio test (base.cpp:462-473).
-__global__ __launch_bounds__(256) void match_select_kernel(const float *__restrict__ best_d2,
-                                                           const int *__restrict__ best_idx, int na_host,
-                                                           const int *__restrict__ na_ptr, int selector, int cross_check, float ratio,
-                                                           const unsigned long long *__restrict__ train_best,
-                                                           int *__restrict__ train_idx,
-                                                           float *__restrict__ distance) {
-  const int na = dev_count(na_host, na_ptr);
-  const int q = blockIdx.x * 256 + threadIdx.x;
-  if (q >= na) return;
-  const int i0 = best_idx[2 * q], i1 = best_idx[2 * q + 1];
-  const float d0 = sqrtf(best_d2[2 * q]);   // BFMatcher L2 returns sqrt(sum of squares)
-  const float d1 = sqrtf(best_d2[2 * q + 1]);
-  int out = -1;
-  if (selector == 0) {
-    if (i0 >= 0) {
-      out = i0;
-      if (cross_check && (int)(train_best[i0] & 0xFFFFFFFFull) != q) out = -1;
+    const float s0 = sqrtf(d0), s1 = sqrtf(d1);   // BFMatcher L2 returns sqrt(sum of squares)
+    if (selector == 0 && cross_check) {
+      if (i0 >= 0) atomicMin(&jb.train_best[i0], ((unsigned long long)__float_as_uint(s0) << 32) | (unsigned)q);
+    } else {
+      int out = -1;
+      if (selector == 0) out = i0;
+      else if (i0 >= 0 && i1 >= 0 && s0 < __fmul_rn(ratio, s1)) out = i0;   // base.cpp:469
+      jb.out[q] = make_int2(out, __float_as_int(s0));
     }
-  } else {
-    // the reference reads knn_match[1] unguarded (base.cpp:469); with < 2 train rows
-    // there is no second neighbour and nothing is kept here
-    if (i0 >= 0 && i1 >= 0 && d0 < __fmul_rn(ratio, d1)) out = i0;
   }
-  train_idx[q] = out;
-  distance[q] = d0;
+}
+
+// OpenCV crossCheck (batchDistance, crosscheck=true, K=1): for every train row the query with
+// the smallest distance among those that chose it (lowest query index on ties) wins; other
+// queries that chose the same train row are dropped.  The scatter (atomicMin on
+// {distance bits, query}) is done by match_rerank_kernel; this kernel applies it.
+__global__ __launch_bounds__(256) void match_select_cross_kernel(MatchJobs jobs) {
+  const MatchJob jb = jobs.j[blockIdx.y];
+  const int na = dev_count(jb.na, jb.na_ptr);
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= na) return;
+  const int i0 = jb.best_idx[2 * q];
+  const float d0 = sqrtf(jb.best_d2[2 * q]);
+  int out = -1;
+  if (i0 >= 0 && (int)(jb.train_best[i0] & 0xFFFFFFFFull) == q) out = i0;
+  jb.out[q] = make_int2(out, __float_as_int(d0));
 }
 
 }  // namespace spvo

@@ -196,6 +196,79 @@ __global__ __launch_bounds__(256) void nms_threshold_kernel(const float *__restr
   }
 }
 
+// K7 + K8 fused (product path): one thread per coarse cell computes its 8x8 block of the heat
+// map, writes it, writes the NMS state bytes and appends its candidates to the list.  ONE atomic
+// per workgroup (256 cells = 16 384 pixels): 72 atomics per stereo pair instead of one per
+// 64x4 tile, and no separate pass over the heat map.
+__global__ __launch_bounds__(256) void heatmap_nms_kernel(const float *__restrict__ det,
+                                                          float *__restrict__ heat, int Hc, int Wc,
+                                                          int hp, int wp, float thresh, NmsPair np) {
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  const int i = blockIdx.y * 4 + wave;
+  const int img = blockIdx.z;
+  const NmsBuffers nb = np.b[img];
+  const bool valid = i < Hc && j < Wc;
+  const int W = Wc * 8, H = Hc * 8;
+  const int pitch = nms_state_pitch(W);
+  unsigned long long cm = 0;   // bit 8u+v: pixel (8i+u, 8j+v) is a candidate
+  if (valid) {
+    const size_t plane = (size_t)hp * wp;
+    const float *p = det + (size_t)img * 65 * plane + (size_t)(i + PADY) * wp + (j + PADX);
+    float e[65];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 65; ++c) {
+      e[c] = expf(p[(size_t)c * plane]);
+      s = __fadd_rn(s, e[c]);
+    }
+    s = __fadd_rn(s, 0.00001f);
+    float *h = heat + (size_t)img * H * W + (size_t)(i * 8) * W + j * 8;
+    uint8_t *st = nb.state + (size_t)(i * 8 + NMS_PAD) * pitch + j * 8 + NMS_PAD;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float v[8];
+      uint32_t lo = 0, hi = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        v[k] = __fdiv_rn(e[u * 8 + k], s);
+        const bool c = v[k] > thresh;                       // strict, nn.cpp:203
+        if (c) cm |= 1ull << (u * 8 + k);
+        if (k < 4) lo |= (c ? (uint32_t)ST_UNDECIDED : 0u) << (8 * k);
+        else hi |= (c ? (uint32_t)ST_UNDECIDED : 0u) << (8 * (k - 4));
+      }
+      *(float4 *)(h + (size_t)u * W) = make_float4(v[0], v[1], v[2], v[3]);
+      *(float4 *)(h + (size_t)u * W + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      *(uint32_t *)(st + (size_t)u * pitch) = lo;
+      *(uint32_t *)(st + (size_t)u * pitch + 4) = hi;
+    }
+  }
+  // block-wide exclusive prefix of the per-thread candidate counts
+  const int cnt = __popcll(cm);
+  int incl = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    s_base = tot ? atomicAdd(&nb.counters[0], tot) : 0;
+  }
+  __syncthreads();
+  int off = s_base + incl - cnt;
+  for (int w = 0; w < wave; ++w) off += s_wave[w];
+  while (cm) {
+    const int b = __ffsll((long long)cm) - 1;
+    cm &= cm - 1;
+    nb.cand[off++] = (i * 8 + (b >> 3)) * W + j * 8 + (b & 7);
+  }
+}
+
 // decision for one undecided candidate: returns ST_KEPT / ST_SUPPRESSED / ST_UNDECIDED
 template <int DIST>
 __device__ __forceinline__ uint8_t nms_decide(const float *__restrict__ hm, uint8_t *state, int H,
@@ -203,14 +276,25 @@ __device__ __forceinline__ uint8_t nms_decide(const float *__restrict__ hm, uint
   const unsigned long long key = rank_key(hm[p], x, y, H);
   bool any_kept = false, any_better = false;
   if constexpr (DIST > 0) {
+    // state bytes and confidences of the whole window are fetched up front with independent
+    // aligned loads (27 words + 27 float4 for the 9x9 window); decisions are pure ALU after that
     constexpr int NW = (2 * DIST + 1 + 3 + 3) / 4;  // words that cover the window from an aligned start
     const int a = (x + NMS_PAD - DIST) & ~3;        // aligned first column (padded coordinates)
+    const int ah = a - NMS_PAD;                     // same column in image coordinates (may be < 0: masked by the state)
+    const float hp = hm[p];
+    const int idp = x * H + y;
     uint32_t w[2 * DIST + 1][NW];
+    float4 hv[2 * DIST + 1][NW];
 #pragma unroll
     for (int dy = 0; dy <= 2 * DIST; ++dy) {
       const uint32_t *row = (const uint32_t *)(state + (y + NMS_PAD + dy - DIST) * pitch + a);
+      const int yc = min(max(y + dy - DIST, 0), H - 1);   // rows outside the image are ST_NONE anyway
+      const float4 *hrow = (const float4 *)(hm + (ptrdiff_t)yc * W + ah);
 #pragma unroll
-      for (int k = 0; k < NW; ++k) w[dy][k] = __builtin_nontemporal_load(row + k);
+      for (int k = 0; k < NW; ++k) {
+        w[dy][k] = __builtin_nontemporal_load(row + k);
+        hv[dy][k] = hrow[k];
+      }
     }
 #pragma unroll
     for (int dy = 0; dy <= 2 * DIST; ++dy)
@@ -218,15 +302,18 @@ __device__ __forceinline__ uint8_t nms_decide(const float *__restrict__ hm, uint
       for (int k = 0; k < NW; ++k) {
         const uint32_t v = w[dy][k];
         if (v == 0) continue;                       // four ST_NONE
+        const float hq4[4] = {hv[dy][k].x, hv[dy][k].y, hv[dy][k].z, hv[dy][k].w};
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           const int s = (v >> (8 * b)) & 0xFF;
-          const int xx = a + 4 * k + b - NMS_PAD;
+          const int xx = ah + 4 * k + b;
           if (s == ST_NONE || xx < x - DIST || xx > x + DIST) continue;
           if (s == ST_KEPT) any_kept = true;
           else if (s == ST_UNDECIDED) {
             const int yy = y + dy - DIST;
-            if ((yy != y || xx != x) && rank_key(hm[yy * W + xx], xx, yy, H) < key) any_better = true;
+            const float hq = hq4[b];
+            // rank_key(q) < rank_key(p): higher confidence first, then smaller column-major index
+            if ((yy != y || xx != x) && (hq > hp || (hq == hp && xx * H + yy < idp))) any_better = true;
           }
         }
       }
@@ -342,8 +429,10 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(int surv_cap, NmsPair np)
   if (cnt) atomicAdd(&nb.rank[i], cnt);
 }
 
-__global__ __launch_bounds__(256) void nms_write_kernel(int H, int max_kp, int surv_cap, NmsPair np) {
+__global__ __launch_bounds__(256) void nms_write_kernel(int H, int max_kp, int surv_cap, NmsPair np, int *zero_next) {
   const NmsBuffers nb = np.b[blockIdx.y];
+  // hand the next submission a clean counter block (it belongs to the other parity)
+  if (zero_next && blockIdx.x == 0 && threadIdx.x < NMS_COUNTER_INTS) zero_next[blockIdx.y * NMS_COUNTER_INTS + threadIdx.x] = 0;
   const int n = min(nb.counters[1], surv_cap);
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0) nb.counters[2] = min(n, max_kp);
@@ -364,28 +453,37 @@ __global__ __launch_bounds__(256) void nms_write_kernel(int H, int max_kp, int s
 // Blend order as written at nn.cpp:423-427 with no FMA contraction.
 // The count comes from device memory so no host round trip is needed.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sample_desc_kernel(const float *__restrict__ desc_nhwc,
-                                                          const int *__restrict__ xy,
-                                                          const int *__restrict__ n_ptr, int n_fixed,
-                                                          int H, int W, int Hc, int Wc,
-                                                          float *__restrict__ out,
-                                                          float *__restrict__ out_xy_f32,
-                                                          int *__restrict__ out_xy_i32,
-                                                          int *__restrict__ out_n) {
-  const int n = n_ptr ? *n_ptr : n_fixed;
+struct SampleJob {
+  const float *desc_nhwc;   // this image's descriptor map
+  const int *xy;            // keypoints [n][2] int
+  const int *n_ptr;         // device count (or NULL -> n_fixed)
+  int n_fixed;
+  float *out;               // [n][256]
+  float *out_sqn;           // [n] squared norm of the stored descriptor (for K12a) or NULL
+  float *out_xy_f32;        // [n][2] or NULL
+  int *out_xy_i32;          // [n][2] or NULL
+  int *out_n;               // device copy of n or NULL
+};
+struct SampleJobs { SampleJob j[2]; };   // blockIdx.y selects the image
+
+__global__ __launch_bounds__(256) void sample_desc_kernel(SampleJobs jobs, int H, int W, int Hc, int Wc) {
+  const SampleJob jb = jobs.j[blockIdx.y];
+  const float *__restrict__ desc_nhwc = jb.desc_nhwc;
+  const int n = jb.n_ptr ? *jb.n_ptr : jb.n_fixed;
   const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (out_n && blockIdx.x == 0 && threadIdx.x == 0) *out_n = n;
+  if (jb.out_n && blockIdx.x == 0 && threadIdx.x == 0) *jb.out_n = n;
   if (k >= n) return;
-  const int col = xy[2 * k], row = xy[2 * k + 1];
-  if (out_xy_f32 && lane == 0) {
-    out_xy_f32[2 * k] = (float)col;
-    out_xy_f32[2 * k + 1] = (float)row;
+  const int col = jb.xy[2 * k], row = jb.xy[2 * k + 1];
+  if (jb.out_xy_f32 && lane == 0) {
+    jb.out_xy_f32[2 * k] = (float)col;
+    jb.out_xy_f32[2 * k + 1] = (float)row;
   }
-  if (out_xy_i32 && lane == 0) {
-    out_xy_i32[2 * k] = col;
-    out_xy_i32[2 * k + 1] = row;
+  if (jb.out_xy_i32 && lane == 0) {
+    jb.out_xy_i32[2 * k] = col;
+    jb.out_xy_i32[2 * k + 1] = row;
   }
+  float *out = jb.out;
   const float row8 = __fmul_rn(__fdiv_rn((float)row, (float)(H - 1)), (float)(Hc - 1));
   const float col8 = __fmul_rn(__fdiv_rn((float)col, (float)(W - 1)), (float)(Wc - 1));
   const int r0 = (int)floorf(row8), c0 = (int)floorf(col8);
@@ -418,6 +516,12 @@ __global__ __launch_bounds__(256) void sample_desc_kernel(const float *__restric
   v.z = __fdiv_rn(v.z, nrm);
   v.w = __fdiv_rn(v.w, nrm);
   *(float4 *)(out + (size_t)k * 256 + lane * 4) = v;
+  if (jb.out_sqn) {
+    float s2 = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o);
+    if (lane == 0) jb.out_sqn[k] = s2;
+  }
 }
 
 }  // namespace spvo

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -57,6 +58,7 @@ struct FeatureSlot {
   float *d_xyf = nullptr;   // [cap][2] float
   float *d_desc = nullptr;  // [cap][256]
   int *d_n = nullptr;       // device copy of n (read by kernels enqueued before the host knows n)
+  float *d_sqn = nullptr;   // [cap] squared norms of the descriptors (written by the sampler)
   unsigned long long gen = 0;  // bumped whenever the slot is rewritten
 };
 
@@ -66,14 +68,14 @@ struct MatchCache {
   int slot_a = -1, slot_b = -1, selector = 0, cross = 0;
   float ratio = 0.f;
   unsigned long long gen_a = 0, gen_b = 0;
-  int32_t *h_idx = nullptr;   // pinned [cap]
-  float *h_dist = nullptr;    // pinned [cap]
+  int2 *h_out = nullptr;      // pinned [cap] packed {train_idx, distance bits}
 };
 
 struct MatchScratch {         // one set per concurrently enqueued match
-  float *d_na = nullptr, *d_nb = nullptr, *d_best_d2 = nullptr, *d_dist = nullptr;
-  int *d_short = nullptr, *d_best_idx = nullptr, *d_train_idx = nullptr;
+  float *d_na = nullptr, *d_nb = nullptr, *d_best_d2 = nullptr;
+  int *d_short = nullptr, *d_best_idx = nullptr;
   unsigned long long *d_train_best = nullptr;
+  int2 *d_out = nullptr;      // packed result, points into spvo_ctx::d_match_out
 };
 
 struct NmsImage {
@@ -94,6 +96,9 @@ struct spvo_ctx {
   spvo_config cfg;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // fused solve: overlaps with a detector submission in flight
+  hipStream_t stream3 = nullptr;   // second image of the pair through the small layers
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int split_level = 99;   // measured: no gain from per-image streams on MI355X (kernels of two streams do not backfill); off
   PendingDetect pend;
   std::string error;
   bool weights = false;
@@ -107,7 +112,8 @@ struct spvo_ctx {
   // post-processing buffers
   float *d_dense_in = nullptr;   // [B][H][W] staging for spvo_forward
   float *d_det_dense = nullptr;  // [B][65][Hc][Wc]
-  float *d_heat = nullptr;       // [B][H][W]
+  float *d_heat = nullptr;       // [B][H][W], inside d_heat_base with a 64-float guard on both sides
+  float *d_heat_base = nullptr;
   NmsImage nms[2];
   int surv_cap = 0;
   int *h_counters = nullptr;     // pinned [2][NMS_COUNTER_INTS]
@@ -126,6 +132,11 @@ struct spvo_ctx {
   int match_cap = 0;
   float *d_ma = nullptr, *d_mb = nullptr;
   MatchScratch ms[2];
+  int2 *d_match_out = nullptr;   // [2][cap]: both jobs' results leave in one copy
+  int2 *h_match_out[2] = {nullptr, nullptr};   // pinned [2][cap] per submission parity
+  int2 *h_match_tmp = nullptr;   // pinned [cap] for the synchronous entry points
+  int *d_counters_all = nullptr; // [2 parities + 1 stand-alone set][2 images][NMS_COUNTER_INTS]
+  float *d_xy_stage = nullptr;   // [2][cap][2] keypoints of both images as floats: one copy
   MatchCache mcache[2][2];       // [submission parity][stereo, temporal]
   int det_parity = 0;
   bool prematch = false;
@@ -241,7 +252,7 @@ struct ScopedStage {
 
 // ---------------------------------------------------------------- conv dispatch
 template <int KS, int CK, int WR, int WC, bool POOL>
-int launch_conv_variant(spvo_ctx *c, const ConvArgs &a, int batch, bool relu) {
+int launch_conv_variant(spvo_ctx *c, const ConvArgs &a, int batch, bool relu, hipStream_t stream) {
   using T = ConvTile<KS, CK, WR, WC>;
   ConvArgs args = a;
   args.tiles_x = (a.W + T::TW - 1) / T::TW;
@@ -255,14 +266,14 @@ int launch_conv_variant(spvo_ctx *c, const ConvArgs &a, int batch, bool relu) {
       HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
       attr_done[dev][1] = true;
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), T::LDS_BYTES, c->stream, args);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), T::LDS_BYTES, stream, args);
   } else {
     auto k = conv_mfma_kernel<KS, CK, WR, WC, POOL, false>;
     if (!attr_done[dev][0]) {
       HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
       attr_done[dev][0] = true;
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), T::LDS_BYTES, c->stream, args);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), T::LDS_BYTES, stream, args);
   }
   HIP_TRY(c, hipGetLastError());
   return SPVO_OK;
@@ -286,22 +297,25 @@ void choose_tile(int H, int W, int co_tiles, int batch, bool pool, int *wr, int 
   }
 }
 
-int launch_conv(spvo_ctx *c, const Op &op, int batch) {
+// images [img0, img0 + batch) of the tensors, on `stream`
+int launch_conv(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream) {
   const Tensor &ti = c->tensors[op.in];
   const Tensor &to = c->tensors[op.out];
+  const float *tin = ti.d + (size_t)img0 * ti.per_image;
+  float *tout = to.d + (size_t)img0 * to.per_image;
   const bool relu = op.flags & FLAG_RELU, pool = op.flags & FLAG_POOL;
   if (op.cin == 1) {
     if (op.ks != 3 || pool) return fail(c, SPVO_ERR_INVALID, "first-layer kernel supports 3x3 without pooling");
     dim3 grid((ti.W + 63) / 64, (ti.H + 3) / 4, batch);
     if (relu)
-      hipLaunchKernelGGL(conv_first_kernel<true>, grid, dim3(256), 0, c->stream, ti.d, to.d, op.d_w, op.d_b, ti.H, ti.W, ti.hp, ti.wp, to.ch, op.out_c_off, op.cout);
+      hipLaunchKernelGGL(conv_first_kernel<true>, grid, dim3(256), 0, stream, tin, tout, op.d_w, op.d_b, ti.H, ti.W, ti.hp, ti.wp, to.ch, op.out_c_off, op.cout);
     else
-      hipLaunchKernelGGL(conv_first_kernel<false>, grid, dim3(256), 0, c->stream, ti.d, to.d, op.d_w, op.d_b, ti.H, ti.W, ti.hp, ti.wp, to.ch, op.out_c_off, op.cout);
+      hipLaunchKernelGGL(conv_first_kernel<false>, grid, dim3(256), 0, stream, tin, tout, op.d_w, op.d_b, ti.H, ti.W, ti.hp, ti.wp, to.ch, op.out_c_off, op.cout);
     HIP_TRY(c, hipGetLastError());
     return SPVO_OK;
   }
   ConvArgs a;
-  a.in = ti.d; a.out = to.d; a.wpack = op.d_w; a.bias = op.d_b;
+  a.in = tin; a.out = tout; a.wpack = op.d_w; a.bias = op.d_b;
   a.H = ti.H; a.W = ti.W;
   a.in_hp = ti.hp; a.in_wp = ti.wp; a.in_ctot = ti.ch; a.in_coff = op.in_c_off;
   a.out_hp = to.hp; a.out_wp = to.wp; a.out_ctot = to.ch; a.out_coff = op.out_c_off;
@@ -309,38 +323,64 @@ int launch_conv(spvo_ctx *c, const Op &op, int batch) {
   a.tiles_x = a.tiles_y = 0;
   const int key = op.ks * 1000 + op.wr * 100 + op.wc * 10 + (pool ? 1 : 0);
   switch (key) {
-    case 3220: return launch_conv_variant<3, 8, 2, 2, false>(c, a, batch, relu);
-    case 3120: return launch_conv_variant<3, 8, 1, 2, false>(c, a, batch, relu);
-    case 3110: return launch_conv_variant<3, 8, 1, 1, false>(c, a, batch, relu);
-    case 3221: return launch_conv_variant<3, 8, 2, 2, true>(c, a, batch, relu);
-    case 3211: return launch_conv_variant<3, 8, 2, 1, true>(c, a, batch, relu);
-    case 1220: return launch_conv_variant<1, 16, 2, 2, false>(c, a, batch, relu);
-    case 1120: return launch_conv_variant<1, 16, 1, 2, false>(c, a, batch, relu);
-    case 1110: return launch_conv_variant<1, 16, 1, 1, false>(c, a, batch, relu);
+    case 3220: return launch_conv_variant<3, 8, 2, 2, false>(c, a, batch, relu, stream);
+    case 3120: return launch_conv_variant<3, 8, 1, 2, false>(c, a, batch, relu, stream);
+    case 3110: return launch_conv_variant<3, 8, 1, 1, false>(c, a, batch, relu, stream);
+    case 3221: return launch_conv_variant<3, 8, 2, 2, true>(c, a, batch, relu, stream);
+    case 3211: return launch_conv_variant<3, 8, 2, 1, true>(c, a, batch, relu, stream);
+    case 1220: return launch_conv_variant<1, 16, 2, 2, false>(c, a, batch, relu, stream);
+    case 1120: return launch_conv_variant<1, 16, 1, 2, false>(c, a, batch, relu, stream);
+    case 1110: return launch_conv_variant<1, 16, 1, 1, false>(c, a, batch, relu, stream);
     default: return fail(c, SPVO_ERR_INVALID, "no conv kernel variant for key %d", key);
   }
 }
 
+int launch_op(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream) {
+  const Tensor &ti = c->tensors[op.in];
+  const Tensor &to = c->tensors[op.out];
+  if (op.type == OP_CONV) {
+    ScopedStage st(c, op.stage, op.flops_per_image * batch, 0, stream);
+    return launch_conv(c, op, img0, batch, stream);
+  }
+  const float *tin = ti.d + (size_t)img0 * ti.per_image;
+  float *tout = to.d + (size_t)img0 * to.per_image;
+  ScopedStage st(c, op.stage, 0, 0, stream);
+  if (op.type == OP_MAXPOOL) {
+    dim3 grid((to.W + 63) / 64, (to.H + 3) / 4, batch * to.ch);
+    hipLaunchKernelGGL(maxpool2_kernel, grid, dim3(256), 0, stream, tin, tout, to.ch, to.H, to.W, ti.hp, ti.wp, to.hp, to.wp);
+  } else if (op.type == OP_L2NORM) {
+    dim3 grid((ti.W + 31) / 32, ti.H, batch);
+    hipLaunchKernelGGL(l2norm_nhwc_kernel<256>, grid, dim3(256), 0, stream, tin, tout, ti.H, ti.W, ti.hp, ti.wp);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return SPVO_OK;
+}
+
+// The two images of a stereo pair are independent through the whole network.  Big layers run as
+// one launch over both images; from `split_level` on (small maps: the grid no longer fills the
+// chip evenly) each image gets its own stream, so that the ragged tail of one image's layer is
+// filled by the other image's kernels.
 int run_network(spvo_ctx *c, int batch) {
   ScopedStage net(c, stage_id(c, "net"));
+  bool forked = false;
   for (auto &op : c->ops) {
-    const Tensor &ti = c->tensors[op.in];
-    const Tensor &to = c->tensors[op.out];
-    if (op.type == OP_CONV) {
-      ScopedStage st(c, op.stage, op.flops_per_image * batch, 0);
-      int rc = launch_conv(c, op, batch);
-      if (rc) return rc;
-    } else if (op.type == OP_MAXPOOL) {
-      ScopedStage st(c, op.stage);
-      dim3 grid((to.W + 63) / 64, (to.H + 3) / 4, batch * to.ch);
-      hipLaunchKernelGGL(maxpool2_kernel, grid, dim3(256), 0, c->stream, ti.d, to.d, to.ch, to.H, to.W, ti.hp, ti.wp, to.hp, to.wp);
-      HIP_TRY(c, hipGetLastError());
-    } else if (op.type == OP_L2NORM) {
-      ScopedStage st(c, op.stage);
-      dim3 grid((ti.W + 31) / 32, ti.H, batch);
-      hipLaunchKernelGGL(l2norm_nhwc_kernel<256>, grid, dim3(256), 0, c->stream, ti.d, to.d, ti.H, ti.W, ti.hp, ti.wp);
-      HIP_TRY(c, hipGetLastError());
+    const bool split = batch == 2 && c->tensors[op.in].level >= c->split_level;
+    if (split && !forked) {
+      HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+      HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
+      forked = true;
     }
+    int rc;
+    if (forked) {
+      if ((rc = launch_op(c, op, 0, 1, c->stream))) return rc;
+      if ((rc = launch_op(c, op, 1, 1, c->stream3))) return rc;
+    } else {
+      if ((rc = launch_op(c, op, 0, batch, c->stream))) return rc;
+    }
+  }
+  if (forked) {
+    HIP_TRY(c, hipEventRecord(c->ev_join, c->stream3));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
   }
   c->last_batch = batch;
   return SPVO_OK;
@@ -439,26 +479,20 @@ int launch_preprocess(spvo_ctx *c, const uint8_t *d_src, int rows, int cols, siz
 constexpr int NMS_INNER = 4;
 constexpr int NMS_GRID = 128;
 
-NmsPair nms_pair(spvo_ctx *c) {
+// NMS counter blocks are double-buffered by submission parity: the last NMS kernel of one
+// submission zeroes the block of the next one, so the steady state needs no memset.
+NmsPair nms_pair(spvo_ctx *c, int parity) {
   NmsPair p;
-  p.b[0] = c->nms[0].b;
-  p.b[1] = c->nms[1].b;
+  for (int i = 0; i < 2; ++i) {
+    p.b[i] = c->nms[i].b;
+    p.b[i].counters = c->d_counters_all + (size_t)(parity * 2 + i) * NMS_COUNTER_INTS;
+  }
   return p;
 }
 
-// threshold (first batch only) + `n_launch` round launches + collect + emit for `nimg` images,
-// then the counters travel to the host.  Launch 0 of a batch never exits early.
-int launch_nms_batch(spvo_ctx *c, int nimg, bool first, int n_launch) {
-  const NmsPair np = nms_pair(c);
-  for (int i = 0; i < nimg; ++i) {
-    NmsBuffers &nb = c->nms[i].b;
-    if (first) HIP_TRY(c, hipMemsetAsync(nb.counters, 0, NMS_COUNTER_INTS * sizeof(int), c->stream));
-    else HIP_TRY(c, hipMemsetAsync(nb.counters + 1, 0, (NMS_COUNTER_INTS - 1) * sizeof(int), c->stream));
-  }
-  if (first) {
-    dim3 grid((c->W + 63) / 64, (c->H + 3) / 4, nimg);
-    hipLaunchKernelGGL(nms_threshold_kernel, grid, dim3(256), 0, c->stream, c->d_heat, c->H, c->W, c->cfg.conf_thresh, np);
-  }
+// `n_launch` round launches + collect + rank + write for `nimg` images, then the counters travel
+// to the host in one copy.  Launch 0 of a batch never exits early.
+int launch_nms_rounds(spvo_ctx *c, int nimg, const NmsPair &np, int n_launch, int *zero_next) {
   for (int l = 0; l < n_launch; ++l) {
     if (c->cfg.dist_thresh == 4)
       hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 4>), dim3(NMS_GRID, nimg), dim3(256), 0, c->stream, c->d_heat, c->H, c->W, 4, np, l);
@@ -467,10 +501,9 @@ int launch_nms_batch(spvo_ctx *c, int nimg, bool first, int n_launch) {
   }
   hipLaunchKernelGGL(nms_collect_kernel, dim3(NMS_GRID, nimg), dim3(256), 0, c->stream, c->d_heat, c->H, c->W, c->cfg.border_remove, c->surv_cap, np);
   hipLaunchKernelGGL(nms_rank_kernel, dim3((c->surv_cap + 255) / 256, (c->surv_cap + RANK_TILE - 1) / RANK_TILE, nimg), dim3(256), 0, c->stream, c->surv_cap, np);
-  hipLaunchKernelGGL(nms_write_kernel, dim3((c->surv_cap + 255) / 256, nimg), dim3(256), 0, c->stream, c->H, c->cfg.max_keypoints, c->surv_cap, np);
+  hipLaunchKernelGGL(nms_write_kernel, dim3((c->surv_cap + 255) / 256, nimg), dim3(256), 0, c->stream, c->H, c->cfg.max_keypoints, c->surv_cap, np, zero_next);
   HIP_TRY(c, hipGetLastError());
-  for (int i = 0; i < nimg; ++i)
-    HIP_TRY(c, hipMemcpyAsync(c->h_counters + i * NMS_COUNTER_INTS, c->nms[i].b.counters, NMS_COUNTER_INTS * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_counters, np.b[0].counters, (size_t)nimg * NMS_COUNTER_INTS * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   return SPVO_OK;
 }
 
@@ -481,9 +514,8 @@ int launch_nms_batch(spvo_ctx *c, int nimg, bool first, int n_launch) {
 // 1 if it had to redo work (the caller then re-runs what depends on the keypoints).
 constexpr int NMS_FIRST = 3;
 
-int nms_enqueue(spvo_ctx *c, int nimg) { return launch_nms_batch(c, nimg, true, NMS_FIRST); }
-
-int nms_settle(spvo_ctx *c, int nimg, bool *redone) {
+// more rounds for the (rare) submissions whose first batch left candidates undecided
+int nms_settle(spvo_ctx *c, int nimg, const NmsPair &np, bool *redone) {
   int last = NMS_FIRST;
   *redone = false;
   for (;;) {
@@ -492,7 +524,9 @@ int nms_settle(spvo_ctx *c, int nimg, bool *redone) {
     if (!pending) break;
     *redone = true;
     last = NMS_MAX_LAUNCH;
-    int rc = launch_nms_batch(c, nimg, false, last);
+    for (int i = 0; i < nimg; ++i)   // keep n_cand, clear the rest of the block
+      HIP_TRY(c, hipMemsetAsync(np.b[i].counters + 1, 0, (NMS_COUNTER_INTS - 1) * sizeof(int), c->stream));
+    int rc = launch_nms_rounds(c, nimg, np, last, nullptr);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
@@ -501,50 +535,90 @@ int nms_settle(spvo_ctx *c, int nimg, bool *redone) {
   return SPVO_OK;
 }
 
+// stand-alone entry (heat map already in d_heat): threshold + rounds, synchronous
 int run_nms(spvo_ctx *c, int nimg) {
-  int rc = nms_enqueue(c, nimg);
+  const NmsPair np = nms_pair(c, 2);   // its own counter set: the detector's two stay clean
+  for (int i = 0; i < nimg; ++i) HIP_TRY(c, hipMemsetAsync(np.b[i].counters, 0, NMS_COUNTER_INTS * sizeof(int), c->stream));
+  dim3 grid((c->W + 63) / 64, (c->H + 3) / 4, nimg);
+  hipLaunchKernelGGL(nms_threshold_kernel, grid, dim3(256), 0, c->stream, c->d_heat, c->H, c->W, c->cfg.conf_thresh, np);
+  int rc = launch_nms_rounds(c, nimg, np, NMS_FIRST, nullptr);
   if (rc) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   bool redone;
-  return nms_settle(c, nimg, &redone);
+  return nms_settle(c, nimg, np, &redone);
 }
 
 int ensure_match(spvo_ctx *c, int na, int nb) {
   const int need = std::max(na, nb);
   if (need <= c->match_cap) return SPVO_OK;
   const int cap = std::max(need, std::max(c->cfg.max_keypoints, 1024));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  for (void *p : {(void *)c->d_ma, (void *)c->d_mb})
+  HIP_TRY(c, hipDeviceSynchronize());
+  for (void *p : {(void *)c->d_ma, (void *)c->d_mb, (void *)c->d_match_out})
     if (p) (void)hipFree(p);
   for (auto &m : c->ms)
-    for (void *p : {(void *)m.d_na, (void *)m.d_nb, (void *)m.d_best_d2, (void *)m.d_dist, (void *)m.d_short, (void *)m.d_best_idx, (void *)m.d_train_idx, (void *)m.d_train_best})
+    for (void *p : {(void *)m.d_na, (void *)m.d_nb, (void *)m.d_best_d2, (void *)m.d_short, (void *)m.d_best_idx, (void *)m.d_train_best})
       if (p) (void)hipFree(p);
+  for (void *p : {(void *)c->h_match_out[0], (void *)c->h_match_out[1], (void *)c->h_match_tmp})
+    if (p) (void)hipHostFree(p);
   const int groups = (cap + MATCH_TT - 1) / MATCH_TT;
   int rc;
   if ((rc = dev_alloc(c, &c->d_ma, (size_t)cap * MATCH_D))) return rc;
   if ((rc = dev_alloc(c, &c->d_mb, (size_t)cap * MATCH_D))) return rc;
-  for (auto &m : c->ms) {
+  if ((rc = dev_alloc(c, &c->d_match_out, (size_t)2 * cap))) return rc;
+  for (int k = 0; k < 2; ++k) {
+    MatchScratch &m = c->ms[k];
     if ((rc = dev_alloc(c, &m.d_na, cap))) return rc;
     if ((rc = dev_alloc(c, &m.d_nb, cap))) return rc;
     if ((rc = dev_alloc(c, &m.d_best_d2, (size_t)cap * 2))) return rc;
-    if ((rc = dev_alloc(c, &m.d_dist, cap))) return rc;
     if ((rc = dev_alloc(c, &m.d_short, (size_t)cap * groups * MATCH_KEEP))) return rc;
     if ((rc = dev_alloc(c, &m.d_best_idx, (size_t)cap * 2))) return rc;
-    if ((rc = dev_alloc(c, &m.d_train_idx, cap))) return rc;
     if ((rc = dev_alloc(c, &m.d_train_best, cap))) return rc;
+    m.d_out = c->d_match_out + (size_t)k * cap;
+    HIP_TRY(c, hipHostMalloc((void **)&c->h_match_out[k], (size_t)2 * cap * sizeof(int2)));
   }
+  HIP_TRY(c, hipHostMalloc((void **)&c->h_match_tmp, (size_t)cap * sizeof(int2)));
+  for (int par = 0; par < 2; ++par)
+    for (int k = 0; k < 2; ++k) {
+      c->mcache[par][k].h_out = c->h_match_out[par] + (size_t)k * cap;
+      c->mcache[par][k].valid = false;
+    }
   c->match_cap = cap;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return SPVO_OK;
 }
 
-// Enqueue one match.  (na, nb) are upper bounds when na_ptr / nb_ptr point at device counts.
-// Results (train_idx, distance) are copied to `out_idx` / `out_dist` (host) asynchronously.
-int enqueue_match(spvo_ctx *c, MatchScratch &m, const float *dA, int na, const int *na_ptr, const float *dB, int nb, const int *nb_ptr, int selector,
-                  int cross_check, float ratio, int32_t *out_idx, float *out_dist) {
-  const int groups = (nb + MATCH_TT - 1) / MATCH_TT;
-  ScopedStage st(c, stage_id(c, "match"), 2.0 * na * nb * MATCH_D, 4.0 * (na + nb) * MATCH_D);
-  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((na + 3) / 4), dim3(256), 0, c->stream, dA, na, na_ptr, m.d_na);
-  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((nb + 3) / 4), dim3(256), 0, c->stream, dB, nb, nb_ptr, m.d_nb);
+struct MatchReq {
+  const float *dA, *dB;
+  int na, nb;                     // counts, or upper bounds when the pointers are set
+  const int *na_ptr, *nb_ptr;
+  const float *sqA, *sqB;         // squared norms if already known (feature slots), else NULL
+};
+
+// Enqueue 1 or 2 matches as ONE set of launches (blockIdx.z / .y = job) and one result copy:
+// packed {train_idx, distance bits} for job k lands at host_out + k*match_cap.
+int enqueue_matches(spvo_ctx *c, const MatchReq *req, int njobs, int selector, int cross_check, float ratio, int2 *host_out) {
+  MatchJobs jobs;
+  int na_max = 0, nb_max = 0;
+  for (int k = 0; k < njobs; ++k) {
+    MatchScratch &m = c->ms[k];
+    MatchJob &j = jobs.j[k];
+    j.A = req[k].dA; j.B = req[k].dB;
+    j.na = req[k].na; j.nb = req[k].nb;
+    j.na_ptr = req[k].na_ptr; j.nb_ptr = req[k].nb_ptr;
+    j.nA = req[k].sqA ? req[k].sqA : m.d_na;
+    j.nB = req[k].sqB ? req[k].sqB : m.d_nb;
+    j.shortlist = m.d_short; j.best_d2 = m.d_best_d2; j.best_idx = m.d_best_idx; j.train_best = m.d_train_best; j.out = m.d_out;
+    na_max = std::max(na_max, req[k].na);
+    nb_max = std::max(nb_max, req[k].nb);
+    if (!req[k].sqA) hipLaunchKernelGGL(row_sqnorm_kernel, dim3((req[k].na + 3) / 4), dim3(256), 0, c->stream, req[k].dA, req[k].na, req[k].na_ptr, m.d_na);
+    if (!req[k].sqB) hipLaunchKernelGGL(row_sqnorm_kernel, dim3((req[k].nb + 3) / 4), dim3(256), 0, c->stream, req[k].dB, req[k].nb, req[k].nb_ptr, m.d_nb);
+    if (selector == SPVO_SELECT_NN && cross_check)
+      HIP_TRY(c, hipMemsetAsync(m.d_train_best, 0xFF, (size_t)req[k].nb * sizeof(unsigned long long), c->stream));
+  }
+  if (njobs == 1) jobs.j[1] = jobs.j[0];
+  const int groups = (nb_max + MATCH_TT - 1) / MATCH_TT;
+  const double fl = 2.0 * na_max * nb_max * MATCH_D * njobs;
+  ScopedStage st(c, stage_id(c, "match"), fl, 4.0 * (na_max + nb_max) * MATCH_D * njobs);
   const size_t lds = (size_t)(MATCH_QT + MATCH_TT) * 129 * sizeof(float);
   static bool attr[64] = {};
   if (!attr[c->cfg.device & 63]) {
@@ -552,30 +626,36 @@ int enqueue_match(spvo_ctx *c, MatchScratch &m, const float *dA, int na, const i
     attr[c->cfg.device & 63] = true;
   }
   {
-    ScopedStage sg(c, stage_id(c, "match_gemm"), 2.0 * na * nb * MATCH_D, 4.0 * (na + nb) * MATCH_D);
-    hipLaunchKernelGGL(match_gemm_kernel, dim3(groups, (na + MATCH_QT - 1) / MATCH_QT), dim3(256), lds, c->stream, dA, na, na_ptr, dB, nb, nb_ptr, m.d_na, m.d_nb, m.d_short, groups);
+    ScopedStage sg(c, stage_id(c, "match_gemm"), fl, 4.0 * (na_max + nb_max) * MATCH_D * njobs);
+    hipLaunchKernelGGL(match_gemm_kernel, dim3(groups, (na_max + MATCH_QT - 1) / MATCH_QT, njobs), dim3(256), lds, c->stream, jobs, groups);
   }
-  hipLaunchKernelGGL(match_rerank_kernel, dim3((na + 3) / 4), dim3(256), 0, c->stream, dA, na, na_ptr, dB, m.d_short, groups, m.d_best_d2, m.d_best_idx);
-  if (selector == SPVO_SELECT_NN && cross_check) {
-    HIP_TRY(c, hipMemsetAsync(m.d_train_best, 0xFF, (size_t)nb * sizeof(unsigned long long), c->stream));
-    hipLaunchKernelGGL(match_cross_scatter_kernel, dim3((na + 255) / 256), dim3(256), 0, c->stream, m.d_best_d2, m.d_best_idx, na, na_ptr, m.d_train_best);
-  }
-  hipLaunchKernelGGL(match_select_kernel, dim3((na + 255) / 256), dim3(256), 0, c->stream, m.d_best_d2, m.d_best_idx, na, na_ptr, selector, cross_check, ratio, m.d_train_best, m.d_train_idx, m.d_dist);
+  hipLaunchKernelGGL(match_rerank_kernel, dim3((na_max + 3) / 4, njobs), dim3(256), 0, c->stream, jobs, groups, selector, cross_check, ratio);
+  if (selector == SPVO_SELECT_NN && cross_check)
+    hipLaunchKernelGGL(match_select_cross_kernel, dim3((na_max + 255) / 256, njobs), dim3(256), 0, c->stream, jobs);
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemcpyAsync(out_idx, m.d_train_idx, (size_t)na * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(out_dist, m.d_dist, (size_t)na * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  // jobs' outputs are adjacent in d_match_out (stride match_cap): one copy
+  const size_t count = (njobs == 2) ? (size_t)c->match_cap + req[1].na : (size_t)req[0].na;
+  HIP_TRY(c, hipMemcpyAsync(host_out, c->d_match_out, count * sizeof(int2), hipMemcpyDeviceToHost, c->stream));
   return SPVO_OK;
 }
 
-int run_match(spvo_ctx *c, const float *dA, int na, const float *dB, int nb, int selector, int cross_check, float ratio, int32_t *train_idx, float *distance) {
-  if (na == 0) return SPVO_OK;
-  if (nb == 0) {
-    for (int i = 0; i < na; ++i) { train_idx[i] = -1; distance[i] = 0.f; }
+void unpack_match(const int2 *packed, int n, int32_t *train_idx, float *distance) {
+  for (int i = 0; i < n; ++i) {
+    train_idx[i] = packed[i].x;
+    std::memcpy(&distance[i], &packed[i].y, sizeof(float));
+  }
+}
+
+int run_match(spvo_ctx *c, const MatchReq &r, int selector, int cross_check, float ratio, int32_t *train_idx, float *distance) {
+  if (r.na == 0) return SPVO_OK;
+  if (r.nb == 0) {
+    for (int i = 0; i < r.na; ++i) { train_idx[i] = -1; distance[i] = 0.f; }
     return SPVO_OK;
   }
-  int rc = enqueue_match(c, c->ms[0], dA, na, nullptr, dB, nb, nullptr, selector, cross_check, ratio, train_idx, distance);
+  int rc = enqueue_matches(c, &r, 1, selector, cross_check, ratio, c->h_match_tmp);
   if (rc) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  unpack_match(c->h_match_tmp, r.na, train_idx, distance);
   return SPVO_OK;
 }
 
@@ -652,8 +732,11 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
     return fail(nullptr, SPVO_ERR_DEVICE, "device %d is %s; the kernels are built for gfx950 only", cfg->device, prop.gcnArchName);
   spvo_ctx *c = new spvo_ctx();
   c->cfg = *cfg;
+  if (const char *e = std::getenv("SPVO_SPLIT_LEVEL")) c->split_level = std::atoi(e);
   c->H = cfg->net_height; c->W = cfg->net_width; c->Hc = c->H / 8; c->Wc = c->W / 8; c->B = 2;
-  if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess) {
+  if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess ||
+      hipStreamCreate(&c->stream3) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
     delete c;
     return fail(nullptr, SPVO_ERR_DEVICE, "cannot create a stream on device %d", cfg->device);
   }
@@ -666,14 +749,17 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
   do {
     if ((rc = dev_alloc(c, &c->d_dense_in, 2 * hw))) break;
     if ((rc = dev_alloc(c, &c->d_det_dense, (size_t)2 * 65 * c->Hc * c->Wc))) break;
-    if ((rc = dev_alloc(c, &c->d_heat, 2 * hw))) break;
+    if ((rc = dev_alloc(c, &c->d_counters_all, (size_t)6 * NMS_COUNTER_INTS))) break;   // parity 0, parity 1, stand-alone
+    if ((rc = dev_alloc(c, &c->d_xy_stage, (size_t)2 * cfg->max_keypoints * 2))) break;
+    if ((rc = dev_alloc(c, &c->d_heat_base, 2 * hw + 128))) break;
+    c->d_heat = c->d_heat_base + 64;   // K10 reads aligned float4 rows that may start left of column 0
     if ((rc = dev_alloc(c, &c->d_resized, 2 * hw))) break;
     if ((rc = dev_alloc(c, &c->d_tab, (size_t)3 * (c->H + c->W)))) break;
     for (int i = 0; i < 2 && !rc; ++i) {
       NmsBuffers &b = c->nms[i].b;
       if ((rc = dev_alloc(c, &b.state, (size_t)(c->H + 2 * NMS_PAD) * nms_state_pitch(c->W)))) break;
       if ((rc = dev_alloc(c, &b.cand, hw))) break;
-      if ((rc = dev_alloc(c, &b.counters, NMS_COUNTER_INTS))) break;
+      b.counters = nullptr;   // set per submission parity (nms_pair)
       if ((rc = dev_alloc(c, &b.surv_key, c->surv_cap))) break;
       if ((rc = dev_alloc(c, &b.rank, c->surv_cap))) break;
       if ((rc = dev_alloc(c, &b.out_xy, (size_t)cap * 2))) break;
@@ -684,16 +770,13 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
       if ((rc = dev_alloc(c, &c->slots[i].d_xyf, (size_t)cap * 2))) break;
       if ((rc = dev_alloc(c, &c->slots[i].d_desc, (size_t)cap * 256))) break;
       if ((rc = dev_alloc(c, &c->slots[i].d_n, 1))) break;
+      if ((rc = dev_alloc(c, &c->slots[i].d_sqn, cap))) break;
     }
     if (rc) break;
     if ((rc = dev_alloc(c, &c->d_xy_tmp, (size_t)cap * 2))) break;
     if ((rc = dev_alloc(c, &c->d_desc_tmp, (size_t)cap * 256))) break;
     if (hipHostMalloc((void **)&c->h_counters, 2 * NMS_COUNTER_INTS * sizeof(int)) != hipSuccess ||
         hipHostMalloc((void **)&c->h_xy, (size_t)2 * cap * 2 * sizeof(float)) != hipSuccess) { rc = fail(c, SPVO_ERR_DEVICE, "hipHostMalloc failed"); break; }
-    for (auto &set : c->mcache)
-      for (auto &m : set)
-        if (hipHostMalloc((void **)&m.h_idx, (size_t)cap * sizeof(int32_t)) != hipSuccess || hipHostMalloc((void **)&m.h_dist, (size_t)cap * sizeof(float)) != hipSuccess)
-          rc = fail(c, SPVO_ERR_DEVICE, "hipHostMalloc failed");
     if (rc) break;
     if ((rc = ensure_match(c, cap, cap))) break;
   } while (0);
@@ -712,36 +795,36 @@ void spvo_destroy(spvo_ctx *c) {
   (void)hipSetDevice(c->cfg.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+  if (c->stream3) (void)hipStreamSynchronize(c->stream3);
   resolve_pending(c);
   for (auto e : c->free_events) (void)hipEventDestroy(e);
   for (auto &t : c->tensors) if (t.d) (void)hipFree(t.d);
   for (auto &o : c->ops) { if (o.d_w) (void)hipFree(o.d_w); if (o.d_b) (void)hipFree(o.d_b); }
-  void *ptrs[] = {c->d_dense_in, c->d_det_dense, c->d_heat, c->d_resized, c->d_tab, c->d_img[0], c->d_img[1], c->d_xy_tmp, c->d_desc_tmp,
-                  c->d_ma, c->d_mb, c->ms[0].d_na, c->ms[0].d_nb, c->ms[0].d_best_d2, c->ms[0].d_dist, c->ms[0].d_short, c->ms[0].d_best_idx,
-                  c->ms[0].d_train_idx, c->ms[0].d_train_best, c->ms[1].d_na, c->ms[1].d_nb, c->ms[1].d_best_d2, c->ms[1].d_dist, c->ms[1].d_short,
-                  c->ms[1].d_best_idx, c->ms[1].d_train_idx, c->ms[1].d_train_best,
+  void *ptrs[] = {c->d_dense_in, c->d_det_dense, c->d_heat_base, c->d_resized, c->d_tab, c->d_img[0], c->d_img[1], c->d_xy_tmp, c->d_desc_tmp,
+                  c->d_ma, c->d_mb, c->d_match_out, c->d_counters_all, c->d_xy_stage,
+                  c->ms[0].d_na, c->ms[0].d_nb, c->ms[0].d_best_d2, c->ms[0].d_short, c->ms[0].d_best_idx, c->ms[0].d_train_best,
+                  c->ms[1].d_na, c->ms[1].d_nb, c->ms[1].d_best_d2, c->ms[1].d_short, c->ms[1].d_best_idx, c->ms[1].d_train_best,
                   c->d_P, c->d_pts_a, c->d_pts_b, c->d_xyz, c->rw.counts, c->rw.poses, c->rw.result, c->rw.inliers, c->d_obs, c->d_refine};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (int i = 0; i < 2; ++i) {
     NmsBuffers &b = c->nms[i].b;
-    void *q[] = {b.state, b.cand, b.counters, b.surv_key, b.rank, b.out_xy};
+    void *q[] = {b.state, b.cand, b.surv_key, b.rank, b.out_xy};
     for (void *p : q) if (p) (void)hipFree(p);
   }
   for (int i = 0; i < 4; ++i) {
-    void *q[] = {c->slots[i].d_xy, c->slots[i].d_xyf, c->slots[i].d_desc, c->slots[i].d_n};
+    void *q[] = {c->slots[i].d_xy, c->slots[i].d_xyf, c->slots[i].d_desc, c->slots[i].d_n, c->slots[i].d_sqn};
     for (void *p : q) if (p) (void)hipFree(p);
   }
   if (c->h_counters) (void)hipHostFree(c->h_counters);
   if (c->h_xy) (void)hipHostFree(c->h_xy);
   for (void *hp : {(void *)c->h_solve_in, (void *)c->h_solve_res, (void *)c->h_solve_o}) if (hp) (void)hipHostFree(hp);
   for (void *dp : {(void *)c->d_solve_in, (void *)c->d_solve_res, (void *)c->d_solve_o, (void *)c->d_ctl}) if (dp) (void)hipFree(dp);
-  for (auto &set : c->mcache)
-    for (auto &m : set) {
-      if (m.h_idx) (void)hipHostFree(m.h_idx);
-      if (m.h_dist) (void)hipHostFree(m.h_dist);
-    }
+  for (void *hp : {(void *)c->h_match_out[0], (void *)c->h_match_out[1], (void *)c->h_match_tmp}) if (hp) (void)hipHostFree(hp);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->stream3) (void)hipStreamDestroy(c->stream3);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   delete c;
 }
 
@@ -970,43 +1053,52 @@ int spvo_sample_descriptors(spvo_ctx *c, const float *desc_nhwc, const int32_t *
   const Tensor &ts = c->tensors[c->t_desc];
   HIP_TRY(c, hipMemcpyAsync(ts.d, desc_nhwc, ts.per_image * sizeof(float), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->d_xy_tmp, xy, (size_t)n * 2 * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(sample_desc_kernel, dim3((n + 3) / 4), dim3(256), 0, c->stream, ts.d, c->d_xy_tmp, (const int *)nullptr, n, c->H, c->W, c->Hc, c->Wc, c->d_desc_tmp, (float *)nullptr, (int *)nullptr, (int *)nullptr);
+  SampleJobs sj;
+  sj.j[0] = SampleJob{ts.d, c->d_xy_tmp, nullptr, n, c->d_desc_tmp, nullptr, nullptr, nullptr, nullptr};
+  sj.j[1] = sj.j[0];
+  hipLaunchKernelGGL(sample_desc_kernel, dim3((n + 3) / 4, 1), dim3(256), 0, c->stream, sj, c->H, c->W, c->Hc, c->Wc);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(out, c->d_desc_tmp, (size_t)n * 256 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return SPVO_OK;
 }
 
-static int enqueue_sample(spvo_ctx *c, const int slots[2]) {
+static int enqueue_sample(spvo_ctx *c, const int slots[2], const NmsPair &np) {
   const Tensor &ts = c->tensors[c->t_desc];
   ScopedStage ss(c, stage_id(c, "sample"));
   const int cap = c->cfg.max_keypoints;
+  SampleJobs sj;
   for (int i = 0; i < 2; ++i) {
     FeatureSlot &s = c->slots[slots[i]];
     // the keypoint count is read from the NMS counters on the device: no host round trip
-    hipLaunchKernelGGL(sample_desc_kernel, dim3((cap + 3) / 4), dim3(256), 0, c->stream, ts.d + (size_t)i * ts.per_image, c->nms[i].b.out_xy,
-                       (const int *)(c->nms[i].b.counters + 2), 0, c->H, c->W, c->Hc, c->Wc, s.d_desc, s.d_xyf, s.d_xy, s.d_n);
-    HIP_TRY(c, hipMemcpyAsync(c->h_xy + (size_t)i * cap * 2, s.d_xyf, (size_t)cap * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    sj.j[i] = SampleJob{ts.d + (size_t)i * ts.per_image, np.b[i].out_xy, (const int *)(np.b[i].counters + 2), 0, s.d_desc, s.d_sqn,
+                        c->d_xy_stage + (size_t)i * cap * 2, s.d_xy, s.d_n};
   }
+  hipLaunchKernelGGL(sample_desc_kernel, dim3((cap + 3) / 4, 2), dim3(256), 0, c->stream, sj, c->H, c->W, c->Hc, c->Wc);
   HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(c->h_xy, c->d_xy_stage, (size_t)2 * cap * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   return SPVO_OK;
 }
 
 static int enqueue_prematch(spvo_ctx *c, int slot_l, int slot_r, int prev_l, int parity) {
   const int cap = c->cfg.max_keypoints;
   const int partner[2] = {slot_r, prev_l};
+  MatchReq req[2];
+  int nj = 0;
   for (int k = 0; k < 2; ++k) {
     MatchCache &mc = c->mcache[parity][k];
     mc.valid = false;
     if (partner[k] < 0) continue;
     FeatureSlot &a = c->slots[slot_l], &b = c->slots[partner[k]];
-    int rc = enqueue_match(c, c->ms[k], a.d_desc, cap, a.d_n, b.d_desc, cap, b.d_n, c->pm_selector, c->pm_cross, c->pm_ratio, mc.h_idx, mc.h_dist);
-    if (rc) return rc;
-    mc.slot_a = slot_l; mc.slot_b = partner[k];
-    mc.selector = c->pm_selector; mc.cross = c->pm_cross; mc.ratio = c->pm_ratio;
-    mc.valid = true;   // generations are stamped after the slots' counts are known
+    req[nj] = MatchReq{a.d_desc, b.d_desc, cap, cap, a.d_n, b.d_n, a.d_sqn, b.d_sqn};
+    MatchCache &dst = c->mcache[parity][nj];   // job nj's result lands in cache entry nj
+    dst.slot_a = slot_l; dst.slot_b = partner[k];
+    dst.selector = c->pm_selector; dst.cross = c->pm_cross; dst.ratio = c->pm_ratio;
+    dst.valid = true;   // generations are stamped after the slots' counts are known
+    ++nj;
   }
-  return SPVO_OK;
+  if (nj == 0) return SPVO_OK;
+  return enqueue_matches(c, req, nj, c->pm_selector, c->pm_cross, c->pm_ratio, c->h_match_out[parity]);
 }
 
 static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, int rows, int cols, size_t stride, int slot_l, int slot_r) {
@@ -1032,16 +1124,20 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
     }
     int rc = run_network(c, 2);
     if (rc) return rc;
+    const NmsPair np = nms_pair(c, parity);
     {
+      // heat map + threshold + candidate list in one kernel; the counter block of this parity was
+      // zeroed by the previous submission's last NMS kernel (or at allocation)
       ScopedStage sh(c, stage_id(c, "heatmap"));
-      hipLaunchKernelGGL(heatmap_kernel<true>, dim3((c->Wc + 63) / 64, (c->Hc + 3) / 4, 2), dim3(256), 0, c->stream, td.d, c->d_heat, c->Hc, c->Wc, td.hp, td.wp);
+      hipLaunchKernelGGL(heatmap_nms_kernel, dim3((c->Wc + 63) / 64, (c->Hc + 3) / 4, 2), dim3(256), 0, c->stream, td.d, c->d_heat, c->Hc, c->Wc, td.hp, td.wp,
+                         c->cfg.conf_thresh, np);
       HIP_TRY(c, hipGetLastError());
     }
     {
       ScopedStage sn(c, stage_id(c, "nms"));
-      if ((rc = nms_enqueue(c, 2))) return rc;
+      if ((rc = launch_nms_rounds(c, 2, np, NMS_FIRST, c->d_counters_all + (size_t)((parity ^ 1) * 2) * NMS_COUNTER_INTS))) return rc;
     }
-    if ((rc = enqueue_sample(c, slots))) return rc;
+    if ((rc = enqueue_sample(c, slots, np))) return rc;
   }
   if (c->prematch) { int rc = enqueue_prematch(c, slot_l, slot_r, prev_l, parity); if (rc) return rc; }
   c->pend.active = true;
@@ -1071,9 +1167,10 @@ static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_feature
   if (rc) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   bool redone = false;
-  if ((rc = nms_settle(c, 2, &redone))) return rc;
+  const NmsPair np = nms_pair(c, pd.parity);
+  if ((rc = nms_settle(c, 2, np, &redone))) return rc;
   if (redone) {   // rare: the keypoints changed after the first batch -> redo what depends on them
-    if ((rc = enqueue_sample(c, slots))) return rc;
+    if ((rc = enqueue_sample(c, slots, np))) return rc;
     if (c->prematch && (rc = enqueue_prematch(c, pd.slot_l, pd.slot_r, pd.prev_l, pd.parity))) return rc;
     if ((rc = copy_extras())) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1148,7 +1245,7 @@ int spvo_match(spvo_ctx *c, const float *desc_a, int na, const float *desc_b, in
   if (rc) return rc;
   if (na) HIP_TRY(c, hipMemcpyAsync(c->d_ma, desc_a, (size_t)na * MATCH_D * sizeof(float), hipMemcpyHostToDevice, c->stream));
   if (nb) HIP_TRY(c, hipMemcpyAsync(c->d_mb, desc_b, (size_t)nb * MATCH_D * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  return run_match(c, c->d_ma, na, c->d_mb, nb, selector, cross_check, ratio, train_idx, distance);
+  return run_match(c, MatchReq{c->d_ma, c->d_mb, na, nb, nullptr, nullptr, nullptr, nullptr}, selector, cross_check ? 1 : 0, ratio, train_idx, distance);
 }
 
 int spvo_match_slots(spvo_ctx *c, int slot_a, int slot_b, int selector, int cross_check, float ratio, int32_t *train_idx, float *distance) {
@@ -1161,10 +1258,7 @@ int spvo_match_slots(spvo_ctx *c, int slot_a, int slot_b, int selector, int cros
     for (const auto &mc : c->mcache[set])
       if (mc.valid && mc.slot_a == slot_a && mc.slot_b == slot_b && mc.gen_a == a.gen && mc.gen_b == b.gen && mc.selector == selector &&
           mc.cross == (cross_check ? 1 : 0) && mc.ratio == ratio) {
-        if (a.n > 0) {
-          std::memcpy(train_idx, mc.h_idx, (size_t)a.n * sizeof(int32_t));
-          std::memcpy(distance, mc.h_dist, (size_t)a.n * sizeof(float));
-        }
+        if (a.n > 0) unpack_match(mc.h_out, a.n, train_idx, distance);
         return SPVO_OK;
       }
   }
@@ -1172,7 +1266,7 @@ int spvo_match_slots(spvo_ctx *c, int slot_a, int slot_b, int selector, int cros
   HIP_TRY(c, hipSetDevice(c->cfg.device));
   int rc = ensure_match(c, a.n, b.n);
   if (rc) return rc;
-  return run_match(c, a.d_desc, a.n, b.d_desc, b.n, selector, cross_check ? 1 : 0, ratio, train_idx, distance);
+  return run_match(c, MatchReq{a.d_desc, b.d_desc, a.n, b.n, nullptr, nullptr, a.d_sqn, b.d_sqn}, selector, cross_check ? 1 : 0, ratio, train_idx, distance);
 }
 
 int spvo_set_prematch(spvo_ctx *c, int enable, int selector, int cross_check, float ratio) {

@@ -156,6 +156,13 @@ int main(int argc, char **argv) {
   run_variant<3, 8, 1, 1, false>("small k3 4x32", 1, 8, 65, 13, 41, 2);
   run_variant<1, 16, 1, 1, false>("small k1 4x32", 2, 32, 65, 13, 41, 2);
   run_variant<1, 16, 2, 2, false>("small k1 8x64", 1, 16, 48, 21, 75, 2);
+  // perfectly divisible shapes: in-kernel efficiency without tile waste / grid quantisation
+  run_variant<3, 8, 2, 2, false>("ideal 8x64  (4 blk/CU)", 2, 64, 64, 256, 1024, reps);
+  run_variant<3, 8, 2, 1, true>("ideal 8x32p (8 blk/CU)", 2, 64, 64, 256, 1024, reps);
+  run_variant<3, 4, 2, 1, true>("ideal 8x32p ck4 (8/CU)", 2, 64, 64, 256, 1024, reps);
+  run_variant<3, 8, 1, 1, false>("ideal 4x32  (6 blk/CU)", 2, 64, 64, 96, 512, reps);
+  run_variant<3, 8, 1, 1, false>("ideal 4x32 128ch (6/CU)", 2, 128, 128, 48, 512, reps);
+  run_variant<3, 8, 1, 1, false>("ideal 4x32 128ch (3/CU)", 2, 128, 128, 48, 256, reps);
   // VGG layer shapes at 360x1176, stereo pair (B = 2)
   run_variant<3, 8, 2, 2, true>("conv1b 8x64 pool ck8", 2, 64, 64, 360, 1176, reps);
   run_variant<3, 4, 2, 2, true, 2>("conv1b 8x64 pool ck4 w2", 2, 64, 64, 360, 1176, reps);
