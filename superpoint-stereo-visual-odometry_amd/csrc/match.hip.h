@@ -57,29 +57,40 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float *__restrict
   if (lane == 0) out[r] = s;
 }
 
-// K12a. grid = (ceil(nb/128), ceil(na/32)).  shortlist[q][group][MATCH_KEEP] (train idx, -1 = none)
+// K12a. grid = (ceil(nb/128), ceil(na/32), jobs).  shortlist[q][group][MATCH_KEEP] (train idx, -1 = none)
+// LDS holds one K-slab (64 of the 256 dimensions) of the 32 query rows and the 128 train rows,
+// K-MAJOR: element (row r, dim k) at [k][r] with a row pitch of 161 floats, so that both MFMA
+// operand reads are consecutive-lane ds_read_b32 (conflict-free) while the staging loads stay
+// coalesced along k.  41 KB per workgroup -> three workgroups per CU overlap load and compute.
+constexpr int MATCH_KS = 64;                       // K-slab
+constexpr int MATCH_ROWS = MATCH_QT + MATCH_TT;    // 160
+constexpr int MATCH_LD = MATCH_ROWS + 1;           // 161
+constexpr int MATCH_LDS_BYTES = MATCH_KS * MATCH_LD * 4;
+
+__device__ __forceinline__ void shortlist_insert(float (&bd)[MATCH_KEEP], int (&bi)[MATCH_KEEP], float d, int idx) {
+  // sorted insertion under (distance, index) order: the lower index wins ties, as in BFMatcher's scan
+#pragma unroll
+  for (int k = 0; k < MATCH_KEEP; ++k) {
+    if (d < bd[k] || (d == bd[k] && (unsigned)idx < (unsigned)bi[k])) {
+      const float td = bd[k]; const int ti = bi[k];
+      bd[k] = d; bi[k] = idx; d = td; idx = ti;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void match_gemm_kernel(MatchJobs jobs, int groups) {
   const MatchJob jb = jobs.j[blockIdx.z];
   const float *__restrict__ A = jb.A;
   const float *__restrict__ B = jb.B;
-  const float *__restrict__ nA = jb.nA;
-  const float *__restrict__ nB = jb.nB;
-  int *__restrict__ shortlist = jb.shortlist;
-  const int na_host = jb.na, nb_host = jb.nb;
-  const int *na_ptr = jb.na_ptr, *nb_ptr = jb.nb_ptr;
-  constexpr int KH = 128;          // K processed in two halves
-  constexpr int LD = KH + 1;       // padded row: conflict-free ds_read_b32 down a column
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *sA = smem;                       // [32][LD]
-  float *sB = smem + MATCH_QT * LD;       // [128][LD]
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q0 = blockIdx.y * MATCH_QT, t0 = blockIdx.x * MATCH_TT;
-  const int na = dev_count(na_host, na_ptr), nb = dev_count(nb_host, nb_ptr);
+  const int na = dev_count(jb.na, jb.na_ptr), nb = dev_count(jb.nb, jb.nb_ptr);
   if (q0 >= na) return;
   if (t0 >= nb) {   // empty column group: the shortlist must still say "none"
     if (tid < MATCH_QT && q0 + tid < na) {
-      int *o = shortlist + ((size_t)(q0 + tid) * groups + blockIdx.x) * MATCH_KEEP;
+      int *o = jb.shortlist + ((size_t)(q0 + tid) * groups + blockIdx.x) * MATCH_KEEP;
 #pragma unroll
       for (int k = 0; k < MATCH_KEEP; ++k) o[k] = -1;
     }
@@ -90,30 +101,29 @@ __global__ __launch_bounds__(256) void match_gemm_kernel(MatchJobs jobs, int gro
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  for (int kh = 0; kh < MATCH_D; kh += KH) {
+  for (int k0 = 0; k0 < MATCH_D; k0 += MATCH_KS) {
     __syncthreads();
-    // stage A (32 x 128) and B (128 x 128) halves; float4 global loads, scalar LDS stores
-    for (int i = tid; i < (MATCH_QT + MATCH_TT) * (KH / 4); i += 256) {
-      const int row = i / (KH / 4), c4 = i - row * (KH / 4);
+    // 160 rows x 16 float4: consecutive threads walk along k (coalesced 256-byte runs)
+#pragma unroll
+    for (int it = 0; it < MATCH_ROWS * (MATCH_KS / 4) / 256; ++it) {
+      const int i = it * 256 + tid;
+      const int row = i >> 4, c4 = i & 15;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      float *dst;
       if (row < MATCH_QT) {
-        if (q0 + row < na) v = *(const float4 *)(A + (size_t)(q0 + row) * MATCH_D + kh + c4 * 4);
-        dst = sA + row * LD + c4 * 4;
-      } else {
-        const int tr = row - MATCH_QT;
-        if (t0 + tr < nb) v = *(const float4 *)(B + (size_t)(t0 + tr) * MATCH_D + kh + c4 * 4);
-        dst = sB + tr * LD + c4 * 4;
+        if (q0 + row < na) v = *(const float4 *)(A + (size_t)(q0 + row) * MATCH_D + k0 + c4 * 4);
+      } else if (t0 + row - MATCH_QT < nb) {
+        v = *(const float4 *)(B + (size_t)(t0 + row - MATCH_QT) * MATCH_D + k0 + c4 * 4);
       }
-      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+      float *dst = smem + (c4 * 4) * MATCH_LD + row;
+      dst[0] = v.x; dst[MATCH_LD] = v.y; dst[2 * MATCH_LD] = v.z; dst[3 * MATCH_LD] = v.w;
     }
     __syncthreads();
     // D[i = query][jj = train]: A operand lane -> A[q = j][k = 2s + half], B operand -> B[t = j][k]
-    const float *pa = sA + j * LD + half;
-    const float *pb = sB + (wave * 32 + j) * LD + half;
-#pragma unroll 16
-    for (int s = 0; s < KH / 2; ++s)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * s], pb[2 * s], acc, 0, 0, 0);
+    const float *pa = smem + half * MATCH_LD + j;
+    const float *pb = smem + half * MATCH_LD + MATCH_QT + wave * 32 + j;
+#pragma unroll 8
+    for (int s2 = 0; s2 < MATCH_KS / 2; ++s2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * s2 * MATCH_LD], pb[2 * s2 * MATCH_LD], acc, 0, 0, 0);
   }
   __syncthreads();
   // approximate squared distances -> LDS [32 q][128 t + 1]
@@ -121,36 +131,44 @@ __global__ __launch_bounds__(256) void match_gemm_kernel(MatchJobs jobs, int gro
   constexpr int LDD = MATCH_TT + 1;
   {
     const int t = t0 + wave * 32 + j;
-    const float nbv = (t < nb) ? nB[t] : 0.f;
+    const float nbv = (t < nb) ? jb.nB[t] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int q = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const float nav = (q0 + q < na) ? nA[q0 + q] : 0.f;
+      const float nav = (q0 + q < na) ? jb.nA[q0 + q] : 0.f;
       sD[q * LDD + wave * 32 + j] = (t < nb) ? (nav + nbv - 2.f * acc[r]) : __builtin_inff();
     }
   }
   __syncthreads();
-  if (tid < MATCH_QT && q0 + tid < na) {
+  // per query: 8 lanes each keep the best MATCH_KEEP of 16 columns, then merge by butterfly
+  {
+    const int q = tid >> 3, g = tid & 7;
     float bd[MATCH_KEEP];
     int bi[MATCH_KEEP];
 #pragma unroll
-    for (int k = 0; k < MATCH_KEEP; ++k) { bd[k] = __builtin_inff(); bi[k] = -1; }
+    for (int k = 0; k < MATCH_KEEP; ++k) { bd[k] = __builtin_inff(); bi[k] = 0x7FFFFFFF; }
     const int ncol = min(MATCH_TT, nb - t0);
-    for (int c = 0; c < ncol; ++c) {
-      float d = sD[tid * LDD + c];
-      int idx = t0 + c;
-      // insertion into the sorted shortlist; strict '<' keeps the lower index on ties
+    for (int c = g; c < ncol; c += 8) shortlist_insert(bd, bi, sD[q * LDD + c], t0 + c);
+    // merge the 8 partial lists of a query through LDS (behind the distance tile)
+    float *sMd = smem + MATCH_QT * LDD;                       // [32][8][KEEP] distances
+    int *sMi = (int *)(sMd + MATCH_QT * 8 * MATCH_KEEP);      // [32][8][KEEP] indices
 #pragma unroll
-      for (int k = 0; k < MATCH_KEEP; ++k) {
-        if (d < bd[k]) {
-          const float td = bd[k]; const int ti = bi[k];
-          bd[k] = d; bi[k] = idx; d = td; idx = ti;
-        }
+    for (int k = 0; k < MATCH_KEEP; ++k) {
+      sMd[(q * 8 + g) * MATCH_KEEP + k] = bd[k];
+      sMi[(q * 8 + g) * MATCH_KEEP + k] = bi[k];
+    }
+    __syncthreads();
+    if (g == 0) {
+      for (int e = MATCH_KEEP; e < 8 * MATCH_KEEP; ++e) {
+        const int oi = sMi[q * 8 * MATCH_KEEP + e];
+        if (oi != 0x7FFFFFFF) shortlist_insert(bd, bi, sMd[q * 8 * MATCH_KEEP + e], oi);
       }
     }
-    int *o = shortlist + ((size_t)(q0 + tid) * groups + blockIdx.x) * MATCH_KEEP;
+    if (g == 0 && q0 + q < na) {
+      int *o = jb.shortlist + ((size_t)(q0 + q) * groups + blockIdx.x) * MATCH_KEEP;
 #pragma unroll
-    for (int k = 0; k < MATCH_KEEP; ++k) o[k] = bi[k];
+      for (int k = 0; k < MATCH_KEEP; ++k) o[k] = (bi[k] == 0x7FFFFFFF) ? -1 : bi[k];
+    }
   }
 }
 

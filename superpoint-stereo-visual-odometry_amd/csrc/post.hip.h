@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void heatmap_kernel(const float *__restrict__ 
 // Border candidates suppress but are not emitted (nn.cpp:239-244); the cap keeps
 // the first `max_kp` emitted in rank order (nn.cpp:256-257).
 // ---------------------------------------------------------------------------
-enum : uint8_t { ST_NONE = 0, ST_UNDECIDED = 1, ST_KEPT = 2, ST_SUPPRESSED = 3 };
+enum : uint8_t { ST_NONE = 0, ST_UNDECIDED = 1, ST_KEPT = 2, ST_SUPPRESSED = 4 };   // one bit each: word-wide tests
 
 // The state map is padded (NMS_PAD rows/columns of ST_NONE on every side, row pitch a multiple
 // of 4) so that a candidate's whole window is read with aligned 32-bit loads and no clipping.
@@ -296,27 +296,41 @@ __device__ __forceinline__ uint8_t nms_decide(const float *__restrict__ hm, uint
         hv[dy][k] = hrow[k];
       }
     }
+    // word-wide tests: the window is the 2*DIST+1 bytes that start `o` bytes into the first word
+    const int o = (x + NMS_PAD - DIST) & 3;
+    uint32_t wmask[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      const int lo = 4 * k - o, hi = 4 * k + 3 - o;          // byte positions relative to the window start
+      uint32_t m = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) m |= ((lo + b >= 0 && lo + b <= 2 * DIST) ? 0xFFu : 0u) << (8 * b);
+      (void)hi;
+      wmask[k] = m;
+    }
+    uint32_t kept = 0;
 #pragma unroll
     for (int dy = 0; dy <= 2 * DIST; ++dy)
 #pragma unroll
-      for (int k = 0; k < NW; ++k) {
-        const uint32_t v = w[dy][k];
-        if (v == 0) continue;                       // four ST_NONE
-        const float hq4[4] = {hv[dy][k].x, hv[dy][k].y, hv[dy][k].z, hv[dy][k].w};
+      for (int k = 0; k < NW; ++k) kept |= w[dy][k] & wmask[k];
+    any_kept = (kept & (0x01010101u * ST_KEPT)) != 0;
+    if (!any_kept) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int s = (v >> (8 * b)) & 0xFF;
-          const int xx = ah + 4 * k + b;
-          if (s == ST_NONE || xx < x - DIST || xx > x + DIST) continue;
-          if (s == ST_KEPT) any_kept = true;
-          else if (s == ST_UNDECIDED) {
-            const int yy = y + dy - DIST;
-            const float hq = hq4[b];
+      for (int dy = 0; dy <= 2 * DIST; ++dy)
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+          uint32_t u = w[dy][k] & wmask[k] & (0x01010101u * ST_UNDECIDED);
+          while (u) {                                    // rare: undecided neighbours only
+            const int b = (__ffs((int)u) - 1) >> 3;
+            u &= u - 1;
+            const int xx = ah + 4 * k + b, yy = y + dy - DIST;
+            const float4 h4 = hv[dy][k];
+            const float hq = b == 0 ? h4.x : b == 1 ? h4.y : b == 2 ? h4.z : h4.w;
             // rank_key(q) < rank_key(p): higher confidence first, then smaller column-major index
             if ((yy != y || xx != x) && (hq > hp || (hq == hp && xx * H + yy < idp))) any_better = true;
           }
         }
-      }
+    }
   } else {
     for (int yy = y - dist_rt; yy <= y + dist_rt; ++yy)
       for (int xx = x - dist_rt; xx <= x + dist_rt; ++xx) {

@@ -619,7 +619,7 @@ int enqueue_matches(spvo_ctx *c, const MatchReq *req, int njobs, int selector, i
   const int groups = (nb_max + MATCH_TT - 1) / MATCH_TT;
   const double fl = 2.0 * na_max * nb_max * MATCH_D * njobs;
   ScopedStage st(c, stage_id(c, "match"), fl, 4.0 * (na_max + nb_max) * MATCH_D * njobs);
-  const size_t lds = (size_t)(MATCH_QT + MATCH_TT) * 129 * sizeof(float);
+  const size_t lds = MATCH_LDS_BYTES;
   static bool attr[64] = {};
   if (!attr[c->cfg.device & 63]) {
     HIP_TRY(c, hipFuncSetAttribute((const void *)match_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
