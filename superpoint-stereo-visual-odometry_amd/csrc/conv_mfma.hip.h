@@ -51,6 +51,7 @@ struct ConvArgs {
   int cout;            // real output channels of this op
   int n_chunks;        // cin / CK
   int tiles_x, tiles_y, co_tiles;
+  int batch;           // images in this launch
 };
 
 __device__ __forceinline__ void glds16(const float *src, float *lds_wave_base) {
@@ -72,7 +73,14 @@ struct ConvTile {
   static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4;
 };
 
-template <int KS, int CK, int WR, int WC, bool POOL, bool RELU, int MINW = 1>
+// The kernel is PERSISTENT: the grid is sized to what the chip holds at once (host side) and
+// every workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...  The LDS ring keeps
+// running across tile boundaries -- the first chunk of the next tile is fetched while the last
+// chunk of the current one is multiplied -- so the fill latency, the bias loads and the output
+// stores of a tile hide behind matrix work instead of bracketing it.
+// ABL (timing experiments only, results are wrong when != 0): 1 = stage only the first chunk,
+// 2 = additionally keep the MFMA operands in registers (no LDS reads in the loop).
+template <int KS, int CK, int WR, int WC, bool POOL, bool RELU, int MINW = 1, int ABL = 0>
 __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) {
   using T = ConvTile<KS, CK, WR, WC>;
   constexpr int NT = WR * WC;
@@ -89,21 +97,27 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
   const int half = lane >> 5;
   const int j = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  // tile decode: x fastest, then y, then co tile, then image
-  int bid = blockIdx.x;
-  const int tx = bid % a.tiles_x;
-  bid /= a.tiles_x;
-  const int ty = bid % a.tiles_y;
-  bid /= a.tiles_y;
-  const int ct = bid % a.co_tiles;
-  const int img = bid / a.co_tiles;
-  const int x0 = tx * T::TW, y0 = ty * T::TH;
-
   const size_t in_plane = (size_t)a.in_hp * a.in_wp;
-  const float *in_base = a.in + ((size_t)img * a.in_ctot + a.in_coff) * in_plane +
-                         (size_t)(y0 + PADY - T::HALO) * a.in_wp + (x0 + PADX - (KS == 3 ? 4 : 0));
-  const float *w_base = a.wpack + (size_t)ct * a.n_chunks * T::W_FLOATS;
+  const size_t out_plane = (size_t)a.out_hp * a.out_wp;
+  const int n_tiles = a.tiles_x * a.tiles_y * a.co_tiles * a.batch;
+
+  // tile id -> (x fastest, then y, then co tile, then image)
+  struct TileRef { const float *in_base, *w_base; int x0, y0, ct, img; };
+  auto decode = [&](int id) {
+    TileRef t;
+    const int tx = id % a.tiles_x;
+    id /= a.tiles_x;
+    const int ty = id % a.tiles_y;
+    id /= a.tiles_y;
+    t.ct = id % a.co_tiles;
+    t.img = id / a.co_tiles;
+    t.x0 = tx * T::TW;
+    t.y0 = ty * T::TH;
+    t.in_base = a.in + ((size_t)t.img * a.in_ctot + a.in_coff) * in_plane + (size_t)(t.y0 + PADY - T::HALO) * a.in_wp +
+                (t.x0 + PADX - (KS == 3 ? 4 : 0));
+    t.w_base = a.wpack + (size_t)t.ct * a.n_chunks * T::W_FLOATS;
+    return t;
+  };
 
   // Per-thread staging plan, computed once: element offset of each of this thread's 16-byte
   // pieces relative to the chunk's input base (pieces < IN_V4) or weight base (the rest).
@@ -122,9 +136,9 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
       piece_off[it] = (min(idx, TOT_V4 - 1) - IN_V4) * 4;
     }
   }
-  auto issue = [&](int chunk, float *buf) {
-    const float *inb = in_base + (size_t)chunk * CK * in_plane;
-    const float *wb = w_base + (size_t)chunk * T::W_FLOATS;
+  auto issue = [&](const TileRef &t, int chunk, float *buf) {
+    const float *inb = t.in_base + (size_t)chunk * CK * in_plane;
+    const float *wb = t.w_base + (size_t)chunk * T::W_FLOATS;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int idx = it * 256 + tid;
@@ -133,107 +147,126 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
     }
   };
 
-  f32x16 acc[2][NT];
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    f32x16 bv;
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      bv[r] = a.bias[ct * CO_TILE + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[m][n] = bv;
-  }
-
-  issue(0, smem);
   const int b_lane = half * (LH * LW) + (wave * WR) * LW + j + XO;
   const int a_lane = T::IN_FLOATS + half * CO_TILE + j;
 
-  for (int c = 0; c < a.n_chunks; ++c) {
-    // chunk c has landed for every wave (each wave drains its own LDS-DMA, then the
-    // barrier); after the barrier buffer (c+1)&1 is no longer read by anyone.  The
-    // explicit wait is required: hipcc does not count global_load_lds in the wait it
-    // emits for __syncthreads() here (checked in the .s).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (c + 1 < a.n_chunks) issue(c + 1, smem + ((c + 1) & 1) * T::BUF_FLOATS);
-    const float *buf = smem + (c & 1) * T::BUF_FLOATS;
-    // k-steps of this chunk: step = (tap, channel pair).  Operands of step s+1 are read from LDS
-    // into a second register set BEFORE the MFMAs of step s issue, so the LDS latency hides
-    // under 2*NT matrix instructions instead of stalling the head of every step.
-    constexpr int NSTEP = KS * KS * (CK / 2);
-    float av[2][2], bv[2][NT];
-    auto load_step = [&](int st, int slot) {
-      const int t = st / (CK / 2), p = st % (CK / 2);
-      const int ky = t / KS, kx = t % KS;
-#pragma unroll
-      for (int m = 0; m < 2; ++m) av[slot][m] = buf[a_lane + (t * CK + 2 * p) * CO_TILE + 32 * m];
-#pragma unroll
-      for (int rr = 0; rr < WR; ++rr)
-#pragma unroll
-        for (int cc = 0; cc < WC; ++cc)
-          bv[slot][rr * WC + cc] = buf[b_lane + 2 * p * (LH * LW) + (rr + ky) * LW + cc * 32 + kx];
-    };
-    load_step(0, 0);
-#pragma unroll
-    for (int st = 0; st < NSTEP; ++st) {
-      const int cur = st & 1;
-      // first matrix instruction of the step, then ALL LDS reads of the next step, then the other
-      // 2*NT-1 matrix instructions: when hipcc's lgkmcnt(0) in front of the next step is reached the
-      // reads are >= (2*NT-1)*64 cycles old.  sched_barrier(0) pins exactly this order.
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][0], bv[cur][0], acc[0][0], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (st + 1 < NSTEP) load_step(st + 1, cur ^ 1);
-      __builtin_amdgcn_sched_barrier(0);
+  int tile_id = blockIdx.x;
+  if (tile_id >= n_tiles) return;
+  TileRef cur = decode(tile_id);
+  issue(cur, 0, smem);
+  int ring = 0;                 // chunks consumed so far: selects the LDS buffer
+  int bias_ct = -1;
+  f32x16 bias_v[2];
+
+  for (; tile_id < n_tiles; tile_id += gridDim.x) {
+    const int next_id = tile_id + gridDim.x;
+    TileRef nxt = cur;
+    if (next_id < n_tiles) nxt = decode(next_id);
+
+    if (cur.ct != bias_ct) {    // bias of this output-channel tile (kept across tiles)
+      bias_ct = cur.ct;
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-          if (m + n > 0) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][m], bv[cur][n], acc[m][n], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int r = 0; r < 16; ++r) bias_v[m][r] = a.bias[cur.ct * CO_TILE + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half];
     }
-  }
-
-  // ------------------------------------------------------------- epilogue
-  const size_t out_plane = (size_t)a.out_hp * a.out_wp;
-  float *out_img = a.out + ((size_t)img * a.out_ctot + a.out_coff) * out_plane;
-  if constexpr (!POOL) {
+    f32x16 acc[2][NT];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int rr = 0; rr < WR; ++rr)
+      for (int n = 0; n < NT; ++n) acc[m][n] = bias_v[m];
+
+    for (int c = 0; c < a.n_chunks; ++c, ++ring) {
+      // chunk `ring` has landed for every wave (each wave drains its own LDS-DMA, then the
+      // barrier); after the barrier buffer (ring+1)&1 is no longer read by anyone.  The explicit
+      // wait is required: hipcc does not count global_load_lds in the wait it emits for
+      // __syncthreads() here (checked in the .s).
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      float *nbuf = smem + ((ring + 1) & 1) * T::BUF_FLOATS;
+      if (ABL == 0 || ring == 0) {
+        if (c + 1 < a.n_chunks) issue(cur, c + 1, nbuf);
+        else if (next_id < n_tiles) issue(nxt, 0, nbuf);      // first chunk of the NEXT tile
+      }
+      const float *buf = smem + (ring & 1) * T::BUF_FLOATS;
+      // k-steps of this chunk: step = (tap, channel pair).  Operands of step s+1 are read from LDS
+      // into a second register set BEFORE the MFMAs of step s issue, so the LDS latency hides
+      // under 2*NT matrix instructions instead of stalling the head of every step.
+      constexpr int NSTEP = KS * KS * (CK / 2);
+      float av[2][2], bv[2][NT];
+      auto load_step = [&](int st, int slot) {
+        const int t = st / (CK / 2), p = st % (CK / 2);
+        const int ky = t / KS, kx = t % KS;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) av[slot][m] = buf[a_lane + (t * CK + 2 * p) * CO_TILE + 32 * m];
+#pragma unroll
+        for (int rr = 0; rr < WR; ++rr)
+#pragma unroll
+          for (int cc = 0; cc < WC; ++cc)
+            bv[slot][rr * WC + cc] = buf[b_lane + 2 * p * (LH * LW) + (rr + ky) * LW + cc * 32 + kx];
+      };
+      load_step(0, 0);
+#pragma unroll
+      for (int st = 0; st < NSTEP; ++st) {
+        const int cs = st & 1;
+        // first matrix instruction of the step, then ALL LDS reads of the next step, then the other
+        // 2*NT-1 matrix instructions: when hipcc's lgkmcnt(0) in front of the next step is reached
+        // the reads are >= (2*NT-1)*64 cycles old.  sched_barrier(0) pins exactly this order.
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cs][0], bv[cs][0], acc[0][0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 1 < NSTEP && (ABL < 2 || st == 0)) load_step(st + 1, cs ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            if (m + n > 0) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cs][m], bv[cs][n], acc[m][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    // ----------------------------------------------------------- epilogue of this tile
+    float *out_img = a.out + ((size_t)cur.img * a.out_ctot + a.out_coff) * out_plane;
+    if constexpr (!POOL) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int rr = 0; rr < WR; ++rr)
+#pragma unroll
+          for (int cc = 0; cc < WC; ++cc) {
+            const int y = cur.y0 + wave * WR + rr;
+            const int x = cur.x0 + cc * 32 + j;
+            const bool ok = (y < a.H) && (x < a.W);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int co = cur.ct * CO_TILE + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
+              float v = acc[m][rr * WC + cc][r];
+              if (RELU) v = fmaxf(v, 0.f);
+              if (ok && co < a.cout)
+                out_img[(size_t)co * out_plane + (size_t)(y + PADY) * a.out_wp + (x + PADX)] = v;
+            }
+          }
+    } else {
+      const int OH = a.H >> 1, OW = a.W >> 1;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int cc = 0; cc < WC; ++cc) {
-          const int y = y0 + wave * WR + rr;
-          const int x = x0 + cc * 32 + j;
-          const bool ok = (y < a.H) && (x < a.W);
+          const int y = (cur.y0 >> 1) + wave;
+          const int x = (cur.x0 + cc * 32 + j) >> 1;
+          const bool ok = (y < OH) && (x < OW) && !(j & 1);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int co = ct * CO_TILE + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
-            float v = acc[m][rr * WC + cc][r];
+            const int co = cur.ct * CO_TILE + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = fmaxf(acc[m][0 * WC + cc][r], acc[m][1 * WC + cc][r]);
+            v = fmaxf(v, __shfl_xor(v, 1));
             if (RELU) v = fmaxf(v, 0.f);
             if (ok && co < a.cout)
               out_img[(size_t)co * out_plane + (size_t)(y + PADY) * a.out_wp + (x + PADX)] = v;
           }
         }
-  } else {
-    const int OH = a.H >> 1, OW = a.W >> 1;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int cc = 0; cc < WC; ++cc) {
-        const int y = (y0 >> 1) + wave;
-        const int x = (x0 + cc * 32 + j) >> 1;
-        const bool ok = (y < OH) && (x < OW) && !(j & 1);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = ct * CO_TILE + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
-          float v = fmaxf(acc[m][0 * WC + cc][r], acc[m][1 * WC + cc][r]);
-          v = fmaxf(v, __shfl_xor(v, 1));
-          if (RELU) v = fmaxf(v, 0.f);
-          if (ok && co < a.cout)
-            out_img[(size_t)co * out_plane + (size_t)(y + PADY) * a.out_wp + (x + PADX)] = v;
-        }
-      }
+    }
+    cur = nxt;
   }
 }
 

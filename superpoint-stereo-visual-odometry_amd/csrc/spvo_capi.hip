@@ -103,6 +103,7 @@ struct spvo_ctx {
   std::string error;
   bool weights = false;
   int H = 0, W = 0, Hc = 0, Wc = 0, B = 0;
+  int num_cus = 256;
 
   std::vector<Tensor> tensors;
   std::vector<Op> ops;
@@ -251,32 +252,35 @@ struct ScopedStage {
 };
 
 // ---------------------------------------------------------------- conv dispatch
+template <int KS, int CK, int WR, int WC, bool POOL, bool RELU>
+int launch_conv_instance(spvo_ctx *c, ConvArgs args, hipStream_t stream) {
+  using T = ConvTile<KS, CK, WR, WC>;
+  auto k = conv_mfma_kernel<KS, CK, WR, WC, POOL, RELU>;
+  static int per_cu[64] = {};   // resident workgroups per CU of this instance, per device
+  const int dev = c->cfg.device & 63;
+  if (!per_cu[dev]) {
+    HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+    int n = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k, 256, T::LDS_BYTES));
+    per_cu[dev] = std::max(n, 1);
+  }
+  // persistent grid: what the chip holds at once; each workgroup walks tiles with that stride
+  const int n_tiles = args.tiles_x * args.tiles_y * args.co_tiles * args.batch;
+  const int grid = std::min(n_tiles, c->num_cus * per_cu[dev]);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(256), T::LDS_BYTES, stream, args);
+  HIP_TRY(c, hipGetLastError());
+  return SPVO_OK;
+}
+
 template <int KS, int CK, int WR, int WC, bool POOL>
 int launch_conv_variant(spvo_ctx *c, const ConvArgs &a, int batch, bool relu, hipStream_t stream) {
   using T = ConvTile<KS, CK, WR, WC>;
   ConvArgs args = a;
   args.tiles_x = (a.W + T::TW - 1) / T::TW;
   args.tiles_y = (a.H + T::TH - 1) / T::TH;
-  const int grid = args.tiles_x * args.tiles_y * args.co_tiles * batch;
-  static bool attr_done[64][2] = {};
-  const int dev = c->cfg.device & 63;
-  if (relu) {
-    auto k = conv_mfma_kernel<KS, CK, WR, WC, POOL, true>;
-    if (!attr_done[dev][1]) {
-      HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
-      attr_done[dev][1] = true;
-    }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), T::LDS_BYTES, stream, args);
-  } else {
-    auto k = conv_mfma_kernel<KS, CK, WR, WC, POOL, false>;
-    if (!attr_done[dev][0]) {
-      HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
-      attr_done[dev][0] = true;
-    }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), T::LDS_BYTES, stream, args);
-  }
-  HIP_TRY(c, hipGetLastError());
-  return SPVO_OK;
+  args.batch = batch;
+  return relu ? launch_conv_instance<KS, CK, WR, WC, POOL, true>(c, args, stream)
+              : launch_conv_instance<KS, CK, WR, WC, POOL, false>(c, args, stream);
 }
 
 // tile choice: minimise padded work / fill, small tiles pay a little for lower operand reuse
@@ -321,6 +325,7 @@ int launch_conv(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stre
   a.out_hp = to.hp; a.out_wp = to.wp; a.out_ctot = to.ch; a.out_coff = op.out_c_off;
   a.cout = op.cout; a.n_chunks = op.n_chunks; a.co_tiles = op.co_tiles;
   a.tiles_x = a.tiles_y = 0;
+  a.batch = batch;
   const int key = op.ks * 1000 + op.wr * 100 + op.wc * 10 + (pool ? 1 : 0);
   switch (key) {
     case 3220: return launch_conv_variant<3, 8, 2, 2, false>(c, a, batch, relu, stream);
@@ -732,6 +737,7 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
     return fail(nullptr, SPVO_ERR_DEVICE, "device %d is %s; the kernels are built for gfx950 only", cfg->device, prop.gcnArchName);
   spvo_ctx *c = new spvo_ctx();
   c->cfg = *cfg;
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char *e = std::getenv("SPVO_SPLIT_LEVEL")) c->split_level = std::atoi(e);
   c->H = cfg->net_height; c->W = cfg->net_width; c->Hc = c->H / 8; c->Wc = c->W / 8; c->B = 2;
   if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess ||

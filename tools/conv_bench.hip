@@ -9,9 +9,11 @@
 #include <cmath>
 #include <vector>
 #include <string>
+#include <algorithm>
 #include "conv_mfma.hip.h"
 
 using namespace spvo;
+static int g_oversub = 1;
 
 #define CK_HIP(x)                                                                  \
   do {                                                                             \
@@ -63,7 +65,7 @@ static void pack_weights(const std::vector<float> &w, int cout, int cin, int KS,
           }
 }
 
-template <int KS, int CK, int WR, int WC, bool POOL, int MINW = 1>
+template <int KS, int CK, int WR, int WC, bool POOL, int MINW = 1, int ABL = 0>
 static double run_variant(const char *name, int B, int cin, int cout, int H, int W, int reps) {
   using T = ConvTile<KS, CK, WR, WC>;
   const int hp = padded_h(H), wp = padded_w(W);
@@ -111,9 +113,13 @@ static double run_variant(const char *name, int B, int cin, int cout, int H, int
   a.out_hp = ohp; a.out_wp = owp; a.out_ctot = cout; a.out_coff = 0; a.cout = cout;
   a.n_chunks = cin / CK;
   a.tiles_x = (W + T::TW - 1) / T::TW; a.tiles_y = (H + T::TH - 1) / T::TH; a.co_tiles = co_tiles;
-  const int grid = a.tiles_x * a.tiles_y * co_tiles * B;
-  auto kern = conv_mfma_kernel<KS, CK, WR, WC, POOL, true, MINW>;
-  CK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+  CK_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<KS, CK, WR, WC, POOL, true, MINW, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+  a.batch = B;
+  const int n_tiles = a.tiles_x * a.tiles_y * co_tiles * B;
+  int per_cu = 1;
+  CK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)conv_mfma_kernel<KS, CK, WR, WC, POOL, true, MINW, ABL>, 256, T::LDS_BYTES));
+  const int grid = std::min(n_tiles, 256 * std::max(per_cu, 1) * (g_oversub));
+  auto kern = conv_mfma_kernel<KS, CK, WR, WC, POOL, true, MINW, ABL>;
   kern<<<grid, 256, T::LDS_BYTES>>>(a);
   CK_HIP(hipDeviceSynchronize());
   std::vector<float> ho(out_n), hr(out_n);
@@ -139,14 +145,15 @@ static double run_variant(const char *name, int B, int cin, int cout, int H, int
   CK_HIP(hipEventElapsedTime(&ms, e0, e1));
   ms /= reps;
   const double flops = 2.0 * B * H * W * (double)cout * cin * KS * KS;
-  printf("%-28s B%d %3d->%3d %4dx%-4d k%d grid %5d lds %6d : %8.3f ms  %7.2f TFLOP/s  maxdiff %.3g (ref max %.3g) bad %zu %s\n",
-         name, B, cin, cout, H, W, KS, grid, T::LDS_BYTES, ms, flops / ms * 1e-9, maxd, maxr, bad, bad ? "FAIL" : "ok");
+  printf("%-28s B%d %3d->%3d %4dx%-4d k%d grid %5d(%d/CU) lds %6d : %8.3f ms  %7.2f TFLOP/s  maxdiff %.3g (ref max %.3g) bad %zu %s\n",
+         name, B, cin, cout, H, W, KS, grid, per_cu, T::LDS_BYTES, ms, flops / ms * 1e-9, maxd, maxr, bad, bad ? "FAIL" : "ok");
   hipFree(din); hipFree(dout); hipFree(dref); hipFree(dfull); hipFree(dw); hipFree(dpk); hipFree(db);
   return ms;
 }
 
 int main(int argc, char **argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 10;
+  if (argc > 2) g_oversub = atoi(argv[2]);
   hipDeviceProp_t prop;
   CK_HIP(hipGetDeviceProperties(&prop, 0));
   printf("device: %s, %d CUs, arch %s\n", prop.name, prop.multiProcessorCount, prop.gcnArchName);
@@ -156,6 +163,25 @@ int main(int argc, char **argv) {
   run_variant<3, 8, 1, 1, false>("small k3 4x32", 1, 8, 65, 13, 41, 2);
   run_variant<1, 16, 1, 1, false>("small k1 4x32", 2, 32, 65, 13, 41, 2);
   run_variant<1, 16, 2, 2, false>("small k1 8x64", 1, 16, 48, 21, 75, 2);
+  // ablations on an ideal shape (outputs are wrong by construction: FAIL is expected)
+  run_variant<3, 8, 2, 2, false, 1, 0>("abl0 8x64 full", 2, 64, 64, 256, 1024, reps);
+  run_variant<3, 8, 2, 2, false, 1, 1>("abl1 8x64 no glds", 2, 64, 64, 256, 1024, reps);
+  run_variant<3, 8, 2, 2, false, 1, 2>("abl2 8x64 no glds/ds", 2, 64, 64, 256, 1024, reps);
+  run_variant<3, 8, 2, 1, true, 1, 0>("abl0 8x32p full", 2, 64, 64, 256, 1024, reps);
+  run_variant<3, 8, 2, 1, true, 1, 1>("abl1 8x32p no glds", 2, 64, 64, 256, 1024, reps);
+  run_variant<3, 8, 2, 1, true, 1, 2>("abl2 8x32p no glds/ds", 2, 64, 64, 256, 1024, reps);
+  run_variant<3, 8, 2, 1, true, 1, 3>("abl3 8x32p stagger", 2, 64, 64, 256, 1024, reps);
+  run_variant<3, 4, 2, 2, false, 2, 0>("abl0 8x64 ck4 w2 full", 2, 64, 64, 256, 1024, reps);
+  run_variant<3, 4, 2, 2, false, 2, 3>("abl3 8x64 ck4 w2 stagger", 2, 64, 64, 256, 1024, reps);
+  run_variant<3, 8, 1, 1, false, 1, 0>("abl0 4x32 full", 2, 128, 128, 48, 512, reps);
+  run_variant<3, 8, 1, 1, false, 1, 1>("abl1 4x32 no glds", 2, 128, 128, 48, 512, reps);
+  run_variant<3, 8, 1, 1, false, 1, 2>("abl2 4x32 no glds/ds", 2, 128, 128, 48, 512, reps);
+  // scaling with the number of K-chunks (fixed cost vs per-chunk cost), 4 workgroups per CU in sequence
+  run_variant<3, 8, 2, 2, false>("scale cin 16", 2, 16, 64, 256, 1024, reps);
+  run_variant<3, 8, 2, 2, false>("scale cin 32", 2, 32, 64, 256, 1024, reps);
+  run_variant<3, 8, 2, 2, false>("scale cin 64", 2, 64, 64, 256, 1024, reps);
+  run_variant<3, 8, 2, 2, false>("scale cin 128", 2, 128, 64, 256, 1024, reps);
+  run_variant<3, 8, 2, 2, false>("scale cin 256", 2, 256, 64, 256, 1024, reps);
   // perfectly divisible shapes: in-kernel efficiency without tile waste / grid quantisation
   run_variant<3, 8, 2, 2, false>("ideal 8x64  (4 blk/CU)", 2, 64, 64, 256, 1024, reps);
   run_variant<3, 8, 2, 1, true>("ideal 8x32p (8 blk/CU)", 2, 64, 64, 256, 1024, reps);
