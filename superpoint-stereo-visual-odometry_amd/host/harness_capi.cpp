@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include "feature_detection.hpp"
+#include "vo_io.hpp"
 
 extern "C" {
 
@@ -108,6 +109,41 @@ int spvo_host_inliers(void *h, int which, int *out, int cap) {
   const auto &v = which == 0 ? fe->inliersPnp() : fe->inliersPostmatching();
   for (int i = 0; i < (int)v.size() && i < cap; ++i) out[i] = v[i];
   return (int)v.size();
+}
+
+// ---- result files (vo_io.hpp): pure host code, no GPU
+static tf2::Transform make_tf(const double *q, const double *t) {
+  tf2::Transform T;
+  T.setRotation(tf2::Quaternion{q[0], q[1], q[2], q[3]});
+  T.setOrigin(tf2::Vector3{t[0], t[1], t[2]});
+  return T;
+}
+
+// integrates n front-end outputs (q xyzw, t) and writes the KITTI pose file; returns lines written
+int spvo_host_write_kitti(const char *dir, int kitti_eval_id, int seq_start, const double *base_q, const double *base_t, const double *q, const double *t,
+                          int n, double *final_pose /* q(4) t(3) of world_T_base */) {
+  const tf2::Transform base_T_cam0 = make_tf(base_q, base_t);
+  PoseIntegrator integ(base_T_cam0);
+  KittiPoseWriter wr(base_T_cam0, seq_start);
+  if (!wr.open(dir, kitti_eval_id)) return -1;
+  for (int i = 0; i < n; ++i) wr.write(integ.integrate(make_tf(q + 4 * i, t + 3 * i)));
+  wr.close();
+  const tf2::Transform &P = integ.pose();
+  final_pose[0] = P.getRotation().x; final_pose[1] = P.getRotation().y; final_pose[2] = P.getRotation().z; final_pose[3] = P.getRotation().w;
+  final_pose[4] = P.getOrigin().x; final_pose[5] = P.getOrigin().y; final_pose[6] = P.getOrigin().z;
+  return n - (seq_start < n ? seq_start : n);
+}
+
+int spvo_host_write_latency(const char *dir, const char *prefix, int batch, int height, int width, const char *precision, int kitti_eval_id,
+                            const float *rows, int n, char *name_out, int name_cap) {
+  const std::string name = LatencyCsv::fileName(prefix, batch, height, width, precision, kitti_eval_id);
+  LatencyCsv csv;
+  if (!csv.open(std::string(dir) + "/" + name)) return -1;
+  for (int i = 0; i < n; ++i) csv.row(rows[4 * i], rows[4 * i + 1], rows[4 * i + 2], rows[4 * i + 3]);
+  csv.close();
+  std::strncpy(name_out, name.c_str(), name_cap - 1);
+  name_out[name_cap - 1] = 0;
+  return n;
 }
 
 int spvo_host_frame_count(void *h) { return static_cast<SuperPointFeatureFrontEnd *>(h)->frameCount(); }

@@ -53,8 +53,33 @@ def load():
         lib.spvo_host_matches.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int]
         lib.spvo_host_map.argtypes = [vp, C.c_int, vp, C.c_int]
         lib.spvo_host_inliers.argtypes = [vp, C.c_int, vp, C.c_int]
+        lib.spvo_host_write_kitti.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp]
+        lib.spvo_host_write_latency.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, vp, C.c_int,
+                                                C.c_char_p, C.c_int]
         _lib = lib
     return _lib
+
+
+def write_kitti_poses(directory, kitti_eval_id, rel_poses, base_T_cam0=((0, 0, 0, 1), (0, 0, 0)), seq_start=0):
+    """Integrate front-end outputs (q xyzw, t of cam0_curr_T_cam0_prev) and write <id>_pred.txt.
+    Returns (lines written, final world_T_base as (q, t))."""
+    lib = load()
+    q = np.ascontiguousarray([p[0] for p in rel_poses], np.float64).reshape(-1, 4)
+    t = np.ascontiguousarray([p[1] for p in rel_poses], np.float64).reshape(-1, 3)
+    bq = np.ascontiguousarray(base_T_cam0[0], np.float64)
+    bt = np.ascontiguousarray(base_T_cam0[1], np.float64)
+    final = np.zeros(7)
+    n = lib.spvo_host_write_kitti(str(directory).encode(), kitti_eval_id, seq_start, _p(bq), _p(bt), _p(q), _p(t), len(q), _p(final))
+    return n, (final[:4].copy(), final[4:].copy())
+
+
+def write_latency_csv(directory, prefix, batch, height, width, precision, kitti_eval_id, rows):
+    lib = load()
+    r = np.ascontiguousarray(rows, np.float32).reshape(-1, 4)
+    name = C.create_string_buffer(256)
+    n = lib.spvo_host_write_latency(str(directory).encode(), prefix.encode(), batch, height, width, precision.encode(), kitti_eval_id,
+                                    _p(r), len(r), name, 256)
+    return n, name.value.decode()
 
 
 def _p(a):
