@@ -42,8 +42,9 @@ def test_kitti_pose_file_matches_oracle(tmp_path):
     n, _ = host.write_kitti_poses(tmp_path, 0, rel[:3])
     lines = open(os.path.join(tmp_path, "00_pred.txt")).read().splitlines()
     P = np.array(lines[-1].split(), float).reshape(3, 4)
+    # ... relative to the FIRST written pose (dp.cpp:159-162): frame 0 -> frame 2 is two steps
     T = np.eye(4)
-    for q, t in rel[:3]:
+    for q, t in rel[1:3]:
         T = T @ np.linalg.inv(vo_io._mat(q, t))
     assert np.allclose(P, T[:3], atol=2e-5)
 
