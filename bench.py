@@ -154,9 +154,14 @@ def main():
         if dom and dom["calls"]:
             avg_ms = dom["total_ms"] / dom["calls"]
             achieved = dom["flops"] / (avg_ms * 1e-3) / 1e12
+            traffic = None                                                 # HBM bytes per launch from the committed PMC pass
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")
+            if os.path.exists(pmc):
+                traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
             out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel<KS=3,...,POOL,RELU> instance of op 1 = conv1b 64->64 @360x1176, 2 images",
                                "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                               "traffic_source": "profiles/r01_pmc_conv_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 per gfx950 note)",
                                "avg_kernel_ms": round(avg_ms, 5), "flops_per_launch": dom["flops"]}
             conv_ms = sum(v["total_ms"] for k, v in prof.items() if k.startswith("conv:")) / max(dom["calls"], 1)
             conv_fl = sum(v["flops"] for k, v in prof.items() if k.startswith("conv:"))
