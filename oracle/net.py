@@ -2,7 +2,8 @@
 
 Follows what the reference's TensorRT engine computes at
 feature_detection_neural_network.cpp:163-176 (`context_->enqueue`): the ONNX
-graph {Conv, Relu, MaxPool, Concat, ReduceL2, Div} in fp32, input [B,1,H,W] in
+graph {Conv (dense and depthwise), Relu, MaxPool, Concat, BatchNormalization, Add,
+ReduceL2, Div} in fp32, input [B,1,H,W] in
 [0,1], outputs `output_det` [B,65,H/8,W/8] and `output_desc` [B,256,H/8,W/8]
 (L2-normalised over channels in-graph, no epsilon).  TensorRT's own summation
 order is unknowable, so parity is within a stated tolerance, not bit-exact.
@@ -26,12 +27,20 @@ def forward(plan: W.Plan, x: np.ndarray, return_all: bool = False):
     for op in plan.ops:
         src = vals[op.inp]
         in_off = getattr(op, "in_c_off", 0)
-        if op.type == W.OP_CONV:
+        if op.type in (W.OP_CONV, W.OP_DWCONV):
             xin = src[:, in_off:in_off + op.cin]
             y = F.conv2d(xin, torch.from_numpy(op.weight), torch.from_numpy(op.bias),
-                         stride=1, padding=op.ksize // 2)
+                         stride=1, padding=op.ksize // 2,
+                         groups=op.cin if op.type == W.OP_DWCONV else 1)
             if op.flags & W.FLAG_RELU:
                 y = F.relu(y)
+            if op.flags & W.FLAG_BN:
+                # ONNX BatchNormalization (inference): (x - mean) / sqrt(var + eps) * gamma + beta
+                c = op.cout
+                gam, bet, mean, var = (torch.from_numpy(op.bn[i * c:(i + 1) * c].copy()) for i in range(4))
+                y = F.relu(F.batch_norm(y, mean, var, gam, bet, training=False, eps=float(op.bn[4 * c])))
+            if op.flags & W.FLAG_ADD:
+                y = F.relu(y + vals[op.residual])
             if op.flags & W.FLAG_POOL:
                 y = F.max_pool2d(y, 2, 2)
             ch, lvl = plan.tensors[op.out]

@@ -52,6 +52,10 @@ struct ConvArgs {
   int n_chunks;        // cin / CK
   int tiles_x, tiles_y, co_tiles;
   int batch;           // images in this launch
+  // MobileNet epilogues (EPI template parameter of the kernel), applied per element BEFORE pooling
+  const float *bn_scale = nullptr, *bn_shift = nullptr;  // EPI 1: v = relu(v * scale[co] + shift[co]), [co_tiles*64]
+  const float *residual = nullptr;                       // EPI 2: v = relu(v + residual[co][y][x]); planes of the
+                                                         //        input's geometry (in_hp x in_wp), cout channels
 };
 
 __device__ __forceinline__ void glds16(const float *src, float *lds_wave_base) {
@@ -80,7 +84,7 @@ struct ConvTile {
 // stores of a tile hide behind matrix work instead of bracketing it.
 // ABL (timing experiments only, results are wrong when != 0): 1 = stage only the first chunk,
 // 2 = additionally keep the MFMA operands in registers (no LDS reads in the loop).
-template <int KS, int CK, int WR, int WC, bool POOL, bool RELU, int MINW = 1, int ABL = 0>
+template <int KS, int CK, int WR, int WC, bool POOL, bool RELU, int MINW = 1, int ABL = 0, int EPI = 0>
 __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) {
   using T = ConvTile<KS, CK, WR, WC>;
   constexpr int NT = WR * WC;
@@ -227,6 +231,19 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
 
     // ----------------------------------------------------------- epilogue of this tile
     float *out_img = a.out + ((size_t)cur.img * a.out_ctot + a.out_coff) * out_plane;
+    // element-wise tail in graph order: ReLU, then (EPI 1) BatchNorm + ReLU or (EPI 2) residual + ReLU
+    const size_t res_plane = (size_t)a.in_hp * a.in_wp;
+    const float *res_img = EPI == 2 ? a.residual + (size_t)cur.img * a.cout * res_plane : nullptr;
+    auto tail = [&](float v, int co, int y, int x) -> float {
+      if (RELU) v = fmaxf(v, 0.f);
+      if constexpr (EPI == 1) v = fmaxf(fmaf(v, a.bn_scale[co], a.bn_shift[co]), 0.f);
+      if constexpr (EPI == 2) {
+        // the padded plane covers the whole tile (zeros outside the image); channels past cout do not exist
+        const float rv = co < a.cout ? res_img[(size_t)co * res_plane + (size_t)(y + PADY) * a.in_wp + (x + PADX)] : 0.f;
+        v = fmaxf(v + rv, 0.f);
+      }
+      return v;
+    };
     if constexpr (!POOL) {
 #pragma unroll
       for (int m = 0; m < 2; ++m)
@@ -240,8 +257,7 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int co = cur.ct * CO_TILE + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
-              float v = acc[m][rr * WC + cc][r];
-              if (RELU) v = fmaxf(v, 0.f);
+              const float v = tail(acc[m][rr * WC + cc][r], co, y, x);
               if (ok && co < a.cout)
                 out_img[(size_t)co * out_plane + (size_t)(y + PADY) * a.out_wp + (x + PADX)] = v;
             }
@@ -252,15 +268,22 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int cc = 0; cc < WC; ++cc) {
+          const int yi = cur.y0 + wave * 2, xi = cur.x0 + cc * 32 + j;
           const int y = (cur.y0 >> 1) + wave;
-          const int x = (cur.x0 + cc * 32 + j) >> 1;
+          const int x = xi >> 1;
           const bool ok = (y < OH) && (x < OW) && !(j & 1);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int co = cur.ct * CO_TILE + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
-            float v = fmaxf(acc[m][0 * WC + cc][r], acc[m][1 * WC + cc][r]);
-            v = fmaxf(v, __shfl_xor(v, 1));
-            if (RELU) v = fmaxf(v, 0.f);
+            float v;
+            if constexpr (EPI == 0) {   // ReLU commutes with max: one clamp instead of four
+              v = fmaxf(acc[m][0 * WC + cc][r], acc[m][1 * WC + cc][r]);
+              v = fmaxf(v, __shfl_xor(v, 1));
+              if (RELU) v = fmaxf(v, 0.f);
+            } else {
+              v = fmaxf(tail(acc[m][0 * WC + cc][r], co, yi, xi), tail(acc[m][1 * WC + cc][r], co, yi + 1, xi));
+              v = fmaxf(v, __shfl_xor(v, 1));
+            }
             if (ok && co < a.cout)
               out_img[(size_t)co * out_plane + (size_t)(y + PADY) * a.out_wp + (x + PADX)] = v;
           }
@@ -271,36 +294,83 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
 }
 
 // ---------------------------------------------------------------------------
-// K1: first layer, Cin = 1 (K = 9): direct convolution on the vector ALU; the
-// layer is bound by writing its 64-channel output, not by arithmetic.
-// Weights (64 x 9) and bias are wave-uniform -> scalar loads.
+// K1: layers with Cin = 1 (K = 9 or 1): direct convolution on the vector ALU; such a
+// layer is bound by writing its output planes, not by arithmetic.
+// Weights (cout x KS*KS) and bias are wave-uniform -> scalar loads.
 // One thread = one pixel, all output channels; consecutive lanes = consecutive x.
+// bn_scale != nullptr: BatchNorm + ReLU after the activation (mbv1's second layer).
 // ---------------------------------------------------------------------------
-template <bool RELU>
+template <int KS, bool RELU>
 __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict__ in,
                                                          float *__restrict__ out,
-                                                         const float *__restrict__ w,  // [cout][9]
-                                                         const float *__restrict__ bias, int H,
+                                                         const float *__restrict__ w,  // [cout][KS*KS]
+                                                         const float *__restrict__ bias,
+                                                         const float *__restrict__ bn_scale,
+                                                         const float *__restrict__ bn_shift, int H,
                                                          int W, int hp, int wp, int out_ctot,
                                                          int out_coff, int cout) {
+  constexpr int TAPS = KS * KS, HALO = KS / 2;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int img = blockIdx.z;
   if (x >= W || y >= H) return;
   const size_t plane = (size_t)hp * wp;
-  const float *ip = in + (size_t)img * plane + (size_t)(y + PADY - 1) * wp + (x + PADX - 1);
-  float v[9];
+  const float *ip = in + (size_t)img * plane + (size_t)(y + PADY - HALO) * wp + (x + PADX - HALO);
+  float v[TAPS];
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky)
+  for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) v[ky * 3 + kx] = ip[ky * wp + kx];
+    for (int kx = 0; kx < KS; ++kx) v[ky * KS + kx] = ip[ky * wp + kx];
   float *op = out + ((size_t)img * out_ctot + out_coff) * plane + (size_t)(y + PADY) * wp + (x + PADX);
   for (int co = 0; co < cout; ++co) {
     float s = bias[co];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) s = fmaf(w[co * 9 + t], v[t], s);
+    for (int t = 0; t < TAPS; ++t) s = fmaf(w[co * TAPS + t], v[t], s);
     if (RELU) s = fmaxf(s, 0.f);
+    if (bn_scale) s = fmaxf(fmaf(s, bn_scale[co], bn_shift[co]), 0.f);
     op[(size_t)co * plane] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K1b: depthwise 3x3 convolution (+ bias, ReLU) of the MobileNet graphs: 9 MACs per output, so the
+// layer is HBM-bound (read a plane, write a plane).  One thread = 4 consecutive pixels of one row of
+// one channel: three aligned 16-byte loads plus the two neighbours per row; the channel is
+// blockIdx.z, so its 9 weights and bias are scalar loads.
+// ---------------------------------------------------------------------------
+template <bool RELU>
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const float *__restrict__ in,
+                                                        float *__restrict__ out,
+                                                        const float *__restrict__ w,  // [C][9]
+                                                        const float *__restrict__ bias, int C, int H,
+                                                        int W, int hp, int wp) {
+  const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int pc = blockIdx.z;  // image * C + channel
+  const int c = pc % C;
+  if (x >= W || y >= H) return;
+  const size_t plane = (size_t)hp * wp;
+  const float *ip = in + (size_t)pc * plane + (size_t)(y + PADY - 1) * wp + (x + PADX);
+  float wk[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wk[t] = w[c * 9 + t];
+  const float b = bias[c];
+  float s[4] = {b, b, b, b};
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const float *rp = ip + (size_t)ky * wp;
+    const float4 m = *reinterpret_cast<const float4 *>(rp);
+    const float r[6] = {rp[-1], m.x, m.y, m.z, m.w, rp[4]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) s[i] = fmaf(wk[ky * 3 + kx], r[i + kx], s[i]);
+  }
+  float *op = out + (size_t)pc * plane + (size_t)(y + PADY) * wp + (x + PADX);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (x + i >= W) break;   // the border columns must stay zero
+    op[i] = RELU ? fmaxf(s[i], 0.f) : s[i];
   }
 }
 

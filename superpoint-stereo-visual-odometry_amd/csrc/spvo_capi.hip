@@ -32,13 +32,14 @@ struct Tensor {
   size_t per_image = 0;  // floats
 };
 
-enum { OP_CONV = 1, OP_MAXPOOL = 2, OP_L2NORM = 3 };
-enum { FLAG_RELU = 1, FLAG_POOL = 2 };
+enum { OP_CONV = 1, OP_MAXPOOL = 2, OP_L2NORM = 3, OP_DWCONV = 4 };
+enum { FLAG_RELU = 1, FLAG_POOL = 2, FLAG_BN = 4, FLAG_ADD = 8 };
 
 struct Op {
   int type = 0, in = 0, out = 0, out_c_off = 0, in_c_off = 0, cin = 0, cout = 0, ks = 0, flags = 0;
   int ck = 0, n_chunks = 0, co_tiles = 0, wr = 0, wc = 0;
-  float *d_w = nullptr, *d_b = nullptr;
+  int residual = 0;  // tensor added before the last ReLU (FLAG_ADD)
+  float *d_w = nullptr, *d_b = nullptr, *d_bn_scale = nullptr, *d_bn_shift = nullptr;
   double flops_per_image = 0;
   int stage = -1;
 };
@@ -252,10 +253,10 @@ struct ScopedStage {
 };
 
 // ---------------------------------------------------------------- conv dispatch
-template <int KS, int CK, int WR, int WC, bool POOL, bool RELU>
+template <int KS, int CK, int WR, int WC, bool POOL, bool RELU, int EPI = 0>
 int launch_conv_instance(spvo_ctx *c, ConvArgs args, hipStream_t stream) {
   using T = ConvTile<KS, CK, WR, WC>;
-  auto k = conv_mfma_kernel<KS, CK, WR, WC, POOL, RELU>;
+  auto k = conv_mfma_kernel<KS, CK, WR, WC, POOL, RELU, 1, 0, EPI>;
   static int per_cu[64] = {};   // resident workgroups per CU of this instance, per device
   const int dev = c->cfg.device & 63;
   if (!per_cu[dev]) {
@@ -283,6 +284,18 @@ int launch_conv_variant(spvo_ctx *c, const ConvArgs &a, int batch, bool relu, hi
               : launch_conv_instance<KS, CK, WR, WC, POOL, false>(c, args, stream);
 }
 
+// MobileNet 1x1 layers: EPI 1 = ReLU, BatchNorm, ReLU (mbv1); EPI 2 = residual add, ReLU (mbv2)
+template <int WR, int WC, bool POOL>
+int launch_conv_epi(spvo_ctx *c, const ConvArgs &a, int batch, int epi, hipStream_t stream) {
+  using T = ConvTile<1, 16, WR, WC>;
+  ConvArgs args = a;
+  args.tiles_x = (a.W + T::TW - 1) / T::TW;
+  args.tiles_y = (a.H + T::TH - 1) / T::TH;
+  args.batch = batch;
+  return epi == 1 ? launch_conv_instance<1, 16, WR, WC, POOL, true, 1>(c, args, stream)
+                  : launch_conv_instance<1, 16, WR, WC, POOL, false, 2>(c, args, stream);
+}
+
 // tile choice: minimise padded work / fill, small tiles pay a little for lower operand reuse
 void choose_tile(int H, int W, int co_tiles, int batch, bool pool, int *wr, int *wc) {
   struct Cand { int wr, wc; double pen; };
@@ -308,13 +321,23 @@ int launch_conv(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stre
   const float *tin = ti.d + (size_t)img0 * ti.per_image;
   float *tout = to.d + (size_t)img0 * to.per_image;
   const bool relu = op.flags & FLAG_RELU, pool = op.flags & FLAG_POOL;
-  if (op.cin == 1) {
-    if (op.ks != 3 || pool) return fail(c, SPVO_ERR_INVALID, "first-layer kernel supports 3x3 without pooling");
-    dim3 grid((ti.W + 63) / 64, (ti.H + 3) / 4, batch);
+  const int epi = (op.flags & FLAG_BN) ? 1 : (op.flags & FLAG_ADD) ? 2 : 0;
+  if (op.type == OP_DWCONV) {
+    dim3 grid((ti.W + 255) / 256, (ti.H + 3) / 4, batch * op.cout);
     if (relu)
-      hipLaunchKernelGGL(conv_first_kernel<true>, grid, dim3(256), 0, stream, tin, tout, op.d_w, op.d_b, ti.H, ti.W, ti.hp, ti.wp, to.ch, op.out_c_off, op.cout);
+      hipLaunchKernelGGL(dwconv3x3_kernel<true>, grid, dim3(256), 0, stream, tin, tout, op.d_w, op.d_b, op.cout, ti.H, ti.W, ti.hp, ti.wp);
     else
-      hipLaunchKernelGGL(conv_first_kernel<false>, grid, dim3(256), 0, stream, tin, tout, op.d_w, op.d_b, ti.H, ti.W, ti.hp, ti.wp, to.ch, op.out_c_off, op.cout);
+      hipLaunchKernelGGL(dwconv3x3_kernel<false>, grid, dim3(256), 0, stream, tin, tout, op.d_w, op.d_b, op.cout, ti.H, ti.W, ti.hp, ti.wp);
+    HIP_TRY(c, hipGetLastError());
+    return SPVO_OK;
+  }
+  if (op.cin == 1) {
+    dim3 grid((ti.W + 63) / 64, (ti.H + 3) / 4, batch);
+#define SPVO_FIRST(KS, RELU) hipLaunchKernelGGL((conv_first_kernel<KS, RELU>), grid, dim3(256), 0, stream, tin, tout, op.d_w, op.d_b, \
+                                                op.d_bn_scale, op.d_bn_shift, ti.H, ti.W, ti.hp, ti.wp, to.ch, op.out_c_off, op.cout)
+    if (op.ks == 3) { if (relu) SPVO_FIRST(3, true); else SPVO_FIRST(3, false); }
+    else            { if (relu) SPVO_FIRST(1, true); else SPVO_FIRST(1, false); }
+#undef SPVO_FIRST
     HIP_TRY(c, hipGetLastError());
     return SPVO_OK;
   }
@@ -327,6 +350,18 @@ int launch_conv(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stre
   a.tiles_x = a.tiles_y = 0;
   a.batch = batch;
   const int key = op.ks * 1000 + op.wr * 100 + op.wc * 10 + (pool ? 1 : 0);
+  if (epi) {
+    a.bn_scale = op.d_bn_scale; a.bn_shift = op.d_bn_shift;
+    if (epi == 2) a.residual = c->tensors[op.residual].d + (size_t)img0 * c->tensors[op.residual].per_image;
+    switch (key) {
+      case 1220: return launch_conv_epi<2, 2, false>(c, a, batch, epi, stream);
+      case 1120: return launch_conv_epi<1, 2, false>(c, a, batch, epi, stream);
+      case 1110: return launch_conv_epi<1, 1, false>(c, a, batch, epi, stream);
+      case 1221: return launch_conv_epi<2, 2, true>(c, a, batch, epi, stream);
+      case 1211: return launch_conv_epi<2, 1, true>(c, a, batch, epi, stream);
+      default: return fail(c, SPVO_ERR_INVALID, "no conv kernel variant for key %d with epilogue %d", key, epi);
+    }
+  }
   switch (key) {
     case 3220: return launch_conv_variant<3, 8, 2, 2, false>(c, a, batch, relu, stream);
     case 3120: return launch_conv_variant<3, 8, 1, 2, false>(c, a, batch, relu, stream);
@@ -336,6 +371,8 @@ int launch_conv(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stre
     case 1220: return launch_conv_variant<1, 16, 2, 2, false>(c, a, batch, relu, stream);
     case 1120: return launch_conv_variant<1, 16, 1, 2, false>(c, a, batch, relu, stream);
     case 1110: return launch_conv_variant<1, 16, 1, 1, false>(c, a, batch, relu, stream);
+    case 1221: return launch_conv_variant<1, 16, 2, 2, true>(c, a, batch, relu, stream);
+    case 1211: return launch_conv_variant<1, 16, 2, 1, true>(c, a, batch, relu, stream);
     default: return fail(c, SPVO_ERR_INVALID, "no conv kernel variant for key %d", key);
   }
 }
@@ -343,7 +380,7 @@ int launch_conv(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stre
 int launch_op(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream) {
   const Tensor &ti = c->tensors[op.in];
   const Tensor &to = c->tensors[op.out];
-  if (op.type == OP_CONV) {
+  if (op.type == OP_CONV || op.type == OP_DWCONV) {
     ScopedStage st(c, op.stage, op.flops_per_image * batch, 0, stream);
     return launch_conv(c, op, img0, batch, stream);
   }
@@ -805,7 +842,8 @@ void spvo_destroy(spvo_ctx *c) {
   resolve_pending(c);
   for (auto e : c->free_events) (void)hipEventDestroy(e);
   for (auto &t : c->tensors) if (t.d) (void)hipFree(t.d);
-  for (auto &o : c->ops) { if (o.d_w) (void)hipFree(o.d_w); if (o.d_b) (void)hipFree(o.d_b); }
+  for (auto &o : c->ops)
+    for (float *p : {o.d_w, o.d_b, o.d_bn_scale, o.d_bn_shift}) if (p) (void)hipFree(p);
   void *ptrs[] = {c->d_dense_in, c->d_det_dense, c->d_heat_base, c->d_resized, c->d_tab, c->d_img[0], c->d_img[1], c->d_xy_tmp, c->d_desc_tmp,
                   c->d_ma, c->d_mb, c->d_match_out, c->d_counters_all, c->d_xy_stage,
                   c->ms[0].d_na, c->ms[0].d_nb, c->ms[0].d_best_d2, c->ms[0].d_short, c->ms[0].d_best_idx, c->ms[0].d_train_best,
@@ -845,15 +883,16 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
   std::vector<unsigned char> buf((size_t)std::max(sz, 0L));
   const size_t got = std::fread(buf.data(), 1, buf.size(), f);
   std::fclose(f);
-  if (got != buf.size() || buf.size() < 48 || std::memcmp(buf.data(), "SPVW0002", 8) != 0)
-    return fail(c, SPVO_ERR_IO, "%s is not a SPVW0002 weight file", path);
+  if (got != buf.size() || buf.size() < 48 || std::memcmp(buf.data(), "SPVW0003", 8) != 0)
+    return fail(c, SPVO_ERR_IO, "%s is not a SPVW0003 weight file", path);
   const uint32_t *hdr = (const uint32_t *)(buf.data() + 8);
   const uint32_t nt = hdr[0], no = hdr[1];
   size_t pos = 40;
-  if (buf.size() < pos + (size_t)nt * 8 + (size_t)no * 48 + 8) return fail(c, SPVO_ERR_IO, "%s: truncated", path);
+  if (buf.size() < pos + (size_t)nt * 8 + (size_t)no * 72 + 8) return fail(c, SPVO_ERR_IO, "%s: truncated", path);
   // drop a previously loaded plan
   for (auto &t : c->tensors) if (t.d) (void)hipFree(t.d);
-  for (auto &o : c->ops) { if (o.d_w) (void)hipFree(o.d_w); if (o.d_b) (void)hipFree(o.d_b); }
+  for (auto &o : c->ops)
+    for (float *p : {o.d_w, o.d_b, o.d_bn_scale, o.d_bn_shift}) if (p) (void)hipFree(p);
   c->tensors.clear(); c->ops.clear(); c->weights = false;
   c->t_input = hdr[2]; c->t_det = hdr[3]; c->t_desc = hdr[4];
   for (uint32_t i = 0; i < nt; ++i) {
@@ -866,9 +905,10 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
     t.hp = padded_h(t.H); t.wp = padded_w(t.W);
     c->tensors.push_back(t);
   }
-  struct Raw { uint32_t v[8]; uint64_t w_off, b_off; };
+  struct Raw { uint32_t v[12]; uint64_t w_off, b_off, bn_off; };
+  static_assert(sizeof(Raw) == 72, "op record layout");
   std::vector<Raw> raws(no);
-  for (uint32_t i = 0; i < no; ++i) { std::memcpy(&raws[i], buf.data() + pos, 48); pos += 48; }
+  for (uint32_t i = 0; i < no; ++i) { std::memcpy(&raws[i], buf.data() + pos, 72); pos += 72; }
   uint64_t nfl;
   std::memcpy(&nfl, buf.data() + pos, 8);
   pos += 8;
@@ -881,7 +921,8 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
     Op op;
     op.type = r.v[0]; op.in = r.v[1]; op.out = r.v[2]; op.out_c_off = r.v[3];
     op.cin = r.v[4] & 0xFFFF; op.in_c_off = r.v[4] >> 16; op.cout = r.v[5]; op.ks = r.v[6]; op.flags = r.v[7];
-    if (op.in >= (int)nt || op.out >= (int)nt) return fail(c, SPVO_ERR_IO, "op %u: bad tensor id", i);
+    op.residual = r.v[8];
+    if (op.in >= (int)nt || op.out >= (int)nt || op.residual >= (int)nt) return fail(c, SPVO_ERR_IO, "op %u: bad tensor id", i);
     if (op.type == OP_L2NORM) c->tensors[op.out].nhwc = true;
     c->ops.push_back(op);
   }
@@ -897,10 +938,49 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
     const Tensor &ti = c->tensors[op.in];
     const Tensor &to = c->tensors[op.out];
     char name[64];
-    if (op.type == OP_CONV) {
+    if (op.type == OP_DWCONV) {
+      std::snprintf(name, sizeof name, "dwconv:%u", i);
+      op.stage = stage_id(c, name);
+      if (op.ks != 3 || op.cin != op.cout || op.in_c_off || op.out_c_off || ti.ch != op.cin || to.ch != op.cout || to.level != ti.level ||
+          (op.flags & ~FLAG_RELU))
+        return fail(c, SPVO_ERR_IO, "op %u: unsupported depthwise convolution", i);
+      if (r.w_off + (uint64_t)op.cout * 9 > nfl || r.b_off + op.cout > nfl) return fail(c, SPVO_ERR_IO, "op %u: weights out of range", i);
+      op.flops_per_image = 2.0 * ti.H * ti.W * op.cout * 9;
+      int rc = dev_alloc(c, &op.d_w, (size_t)op.cout * 9, false);
+      if (rc) return rc;
+      if ((rc = dev_alloc(c, &op.d_b, op.cout, false))) return rc;
+      HIP_TRY(c, hipMemcpy(op.d_w, payload + r.w_off, (size_t)op.cout * 9 * 4, hipMemcpyHostToDevice));
+      HIP_TRY(c, hipMemcpy(op.d_b, payload + r.b_off, (size_t)op.cout * 4, hipMemcpyHostToDevice));
+    } else if (op.type == OP_CONV) {
       std::snprintf(name, sizeof name, "conv:%u", i);
       op.stage = stage_id(c, name);
       const int taps = op.ks * op.ks;
+      const bool bn = op.flags & FLAG_BN, add = op.flags & FLAG_ADD;
+      if ((bn && (add || !(op.flags & FLAG_RELU))) || (add && (op.flags & FLAG_RELU)))
+        return fail(c, SPVO_ERR_IO, "op %u: epilogue flags 0x%x are not a graph order this library executes", i, op.flags);
+      if ((bn || add) && op.cin > 1 && op.ks != 1) return fail(c, SPVO_ERR_IO, "op %u: BatchNorm / residual epilogues exist for 1x1 convolutions only", i);
+      if (add) {
+        const Tensor &tr = c->tensors[op.residual];
+        if (op.cin == 1 || tr.ch != op.cout || tr.level != ti.level || tr.nhwc || op.residual == op.out)
+          return fail(c, SPVO_ERR_IO, "op %u: bad residual tensor", i);
+      }
+      const int co_pad = ((op.cout + CO_TILE - 1) / CO_TILE) * CO_TILE;
+      if (bn) {
+        // ONNX BatchNormalization, inference form, folded to one fma: scale = gamma / sqrt(var + eps)
+        if (r.bn_off + 4ull * op.cout + 1 > nfl) return fail(c, SPVO_ERR_IO, "op %u: BatchNorm parameters out of range", i);
+        const float *q = payload + r.bn_off;
+        std::vector<float> sc(co_pad, 0.f), sh(co_pad, 0.f);
+        for (int o = 0; o < op.cout; ++o) {
+          const double k = (double)q[o] / std::sqrt((double)q[3 * op.cout + o] + (double)q[4 * op.cout]);
+          sc[o] = (float)k;
+          sh[o] = (float)((double)q[op.cout + o] - (double)q[2 * op.cout + o] * k);
+        }
+        int rc = dev_alloc(c, &op.d_bn_scale, co_pad, false);
+        if (rc) return rc;
+        if ((rc = dev_alloc(c, &op.d_bn_shift, co_pad, false))) return rc;
+        HIP_TRY(c, hipMemcpy(op.d_bn_scale, sc.data(), co_pad * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(op.d_bn_shift, sh.data(), co_pad * 4, hipMemcpyHostToDevice));
+      }
       if (op.ks != 1 && op.ks != 3) return fail(c, SPVO_ERR_IO, "op %u: kernel size %d", i, op.ks);
       if (r.w_off + (uint64_t)op.cout * op.cin * taps > nfl || r.b_off + op.cout > nfl) return fail(c, SPVO_ERR_IO, "op %u: weights out of range", i);
       if (op.in_c_off + op.cin > ti.ch || op.out_c_off + op.cout > to.ch) return fail(c, SPVO_ERR_IO, "op %u: channel slice out of range", i);
@@ -911,10 +991,11 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
       const float *w = payload + r.w_off;
       const float *b = payload + r.b_off;
       if (op.cin == 1) {
-        int rc = dev_alloc(c, &op.d_w, (size_t)op.cout * 9, false);
+        if (pool || add) return fail(c, SPVO_ERR_IO, "op %u: single-channel-input layers have no pooling / residual form", i);
+        int rc = dev_alloc(c, &op.d_w, (size_t)op.cout * taps, false);
         if (rc) return rc;
         if ((rc = dev_alloc(c, &op.d_b, op.cout, false))) return rc;
-        HIP_TRY(c, hipMemcpy(op.d_w, w, (size_t)op.cout * 9 * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(op.d_w, w, (size_t)op.cout * taps * 4, hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(op.d_b, b, (size_t)op.cout * 4, hipMemcpyHostToDevice));
         continue;
       }

@@ -9,17 +9,21 @@ execution plan (tensors + ops) and the raw fp32 OIHW weights; the C-ABI library
 own layout, so the file stays canonical and human-checkable.
 
 File layout (little endian):
-    char  magic[8]  = b"SPVW0002"
+    char  magic[8]  = b"SPVW0003"
     u32   n_tensors, n_ops, input_tensor, det_tensor, desc_tensor, reserved[3]
     n_tensors x { u32 channels, u32 level }          level = log2(downscale)
-    n_ops     x { u32 type, in, out, out_c_off, cin, cout, ksize, flags;
-                  u64 w_off, b_off }                 offsets in floats into payload
+    n_ops     x { u32 type, in, out, out_c_off, cin | in_c_off << 16, cout, ksize, flags,
+                  residual_tensor, reserved[3]; u64 w_off, b_off, bn_off }   offsets in floats
     u64   payload_floats
     f32   payload[payload_floats]
 
 Op types: 1 = CONV (ksize 1|3, pad ksize//2, stride 1), 2 = MAXPOOL2x2,
-          3 = L2NORM over channels (descriptor tail: ReduceL2 + Div, no epsilon).
-Flags:    bit0 = ReLU after bias, bit1 = fused 2x2/2 max-pool after ReLU.
+          3 = L2NORM over channels (descriptor tail: ReduceL2 + Div, no epsilon),
+          4 = DWCONV (depthwise 3x3, pad 1: the MobileNet graphs).
+Epilogue of CONV / DWCONV, in this order (flags):
+          bit0 ReLU after bias; bit2 BatchNorm (gamma, beta, mean, var [cout] each + eps at bn_off)
+          followed by ReLU (mbv1 puts BN AFTER the activation, so it cannot be folded into the conv);
+          bit3 add `residual_tensor` then ReLU (mbv2); bit1 2x2/2 max-pool last.
 """
 from __future__ import annotations
 
@@ -31,9 +35,9 @@ import numpy as np
 
 from . import onnx_lite
 
-MAGIC = b"SPVW0002"
-OP_CONV, OP_MAXPOOL, OP_L2NORM = 1, 2, 3
-FLAG_RELU, FLAG_POOL = 1, 2
+MAGIC = b"SPVW0003"
+OP_CONV, OP_MAXPOOL, OP_L2NORM, OP_DWCONV = 1, 2, 3, 4
+FLAG_RELU, FLAG_POOL, FLAG_BN, FLAG_ADD = 1, 2, 4, 8
 
 # reference: feature_detection.hpp:355-359
 DET_CHANNELS, DESC_CHANNELS, CELL = 65, 256, 8
@@ -51,6 +55,9 @@ class Op:
     flags: int = 0
     weight: Optional[np.ndarray] = None  # OIHW fp32
     bias: Optional[np.ndarray] = None
+    in_c_off: int = 0
+    residual: int = 0                    # tensor added before the final ReLU (FLAG_ADD)
+    bn: Optional[np.ndarray] = None      # [4*cout + 1]: gamma, beta, mean, var, eps (FLAG_BN)
 
 
 @dataclass
@@ -147,10 +154,14 @@ def vgg_plan(seed: int = 0, dustbin_bias: float = 4.7) -> Plan:
 
 
 # --------------------------------------------------------------------------
-# ONNX graph -> plan (ops present in the reference's models: Conv, Relu,
-# MaxPool, Concat, ReduceL2, Div; BatchNormalization / Add / depthwise are
-# the mbv1 / mbv2 graphs and are rejected here until their kernels exist).
+# ONNX graph -> plan.  Ops present in the reference's models: Conv (dense 1x1 / 3x3 and depthwise
+# 3x3), Relu, MaxPool, Concat (squeeze), BatchNormalization after Relu (mbv1), Add (mbv2),
+# ReduceL2, Div.  Every Relu / BatchNormalization / Add / MaxPool that directly follows a
+# convolution is fused into that convolution's epilogue.
 # --------------------------------------------------------------------------
+_ST_BIAS, _ST_RELU, _ST_BN, _ST_BN_RELU, _ST_ADD, _ST_ADD_RELU, _ST_POOL = range(7)
+
+
 def onnx_plan(path: str) -> Plan:
     g = onnx_lite.load(path)
     p = Plan()
@@ -158,26 +169,22 @@ def onnx_plan(path: str) -> Plan:
     for n in g.nodes:
         for i in n.inputs:
             consumers.setdefault(i, []).append(n)
-    tid: Dict[str, Tuple[int, int]] = {}  # value name -> (tensor id, channel offset)
+    produced_by = {o: n for n in g.nodes for o in n.outputs}
+    tid: Dict[str, Tuple[int, int]] = {}   # materialised value -> (tensor id, channel offset)
     level_of: Dict[int, int] = {}
     p.input_tensor = p.add_tensor(1, 0)
     tid[g.inputs[0]] = (p.input_tensor, 0)
     level_of[p.input_tensor] = 0
 
-    # pre-assign concat outputs so producers can write straight into their slice
-    produced_by = {o: n for n in g.nodes for o in n.outputs}
-
     def channels_of(name: str) -> int:
         n = produced_by[name]
         if n.op == "Conv":
             return g.initializers[n.inputs[1]].shape[0]
-        if n.op in ("Relu", "MaxPool", "Div"):
-            return channels_of(n.inputs[0])
         if n.op == "Concat":
             return sum(channels_of(i) for i in n.inputs)
-        raise NotImplementedError(n.op)
+        return channels_of(n.inputs[0])
 
-    concat_slot: Dict[str, Tuple[str, int]] = {}  # value -> (concat output, offset)
+    concat_slot: Dict[str, Tuple[str, int]] = {}  # value -> (concat output, channel offset)
     for n in g.nodes:
         if n.op == "Concat":
             off = 0
@@ -185,33 +192,90 @@ def onnx_plan(path: str) -> Plan:
                 concat_slot[i] = (n.outputs[0], off)
                 off += channels_of(i)
 
-    pending_conv: Dict[str, Op] = {}
+    pending: Dict[str, Tuple[Op, int]] = {}   # not yet materialised value -> (op, epilogue stage)
+
+    def can_fuse(value: str, stage: int) -> bool:
+        nxt = consumers.get(value, [])
+        if len(nxt) != 1 or value in ("output_det", "output_desc") or value in concat_slot:
+            return False
+        n = nxt[0]
+        if n.op == "Relu":
+            return stage in (_ST_BIAS, _ST_BN, _ST_ADD)
+        if n.op == "BatchNormalization":
+            return stage == _ST_RELU
+        if n.op == "Add":
+            other = [i for i in n.inputs if i != value]
+            return stage == _ST_BIAS and len(other) == 1 and other[0] in tid
+        if n.op == "MaxPool":
+            return stage in (_ST_RELU, _ST_BN_RELU, _ST_ADD_RELU)
+        return False
+
+    def settle(value: str, op: Op, stage: int):
+        """Keep fusing, or materialise `value` as the output tensor of `op`."""
+        if can_fuse(value, stage):
+            pending[value] = (op, stage)
+            return
+        assert stage not in (_ST_BN, _ST_ADD), "BatchNormalization / Add must be followed by Relu in these graphs"
+        lvl = level_of[op.inp] + (1 if op.flags & FLAG_POOL else 0)
+        if value in concat_slot:
+            cname, off = concat_slot[value]
+            if cname not in tid:
+                t = p.add_tensor(channels_of(cname), lvl)
+                level_of[t] = lvl
+                tid[cname] = (t, 0)
+            op.out, op.out_c_off = tid[cname][0], off
+            tid[value] = (op.out, off)
+        else:
+            t = p.add_tensor(op.cout, lvl)
+            level_of[t] = lvl
+            op.out, op.out_c_off = t, 0
+            tid[value] = (t, 0)
+
     for n in g.nodes:
         if n.op == "Conv":
             w = g.initializers[n.inputs[1]].astype(np.float32)
             b = g.initializers[n.inputs[2]].astype(np.float32)
-            if n.attrs.get("group", 1) != 1:
-                raise NotImplementedError("grouped/depthwise conv (mbv1/mbv2) has no kernel yet")
             k = w.shape[2]
             assert n.attrs["strides"] == [1, 1] and n.attrs["pads"] == [k // 2] * 4
             src, src_off = tid[n.inputs[0]]
-            op = Op(OP_CONV, src, -1, 0, w.shape[1], w.shape[0], k, 0, w, b)
+            group = n.attrs.get("group", 1)
+            if group == 1:
+                op = Op(OP_CONV, src, -1, 0, w.shape[1], w.shape[0], k, 0, w, b)
+            else:
+                assert group == w.shape[0] and w.shape[1] == 1 and k == 3, "only depthwise 3x3 grouped convs occur"
+                op = Op(OP_DWCONV, src, -1, 0, w.shape[0], w.shape[0], k, 0, w, b)
             op.in_c_off = src_off
-            pending_conv[n.outputs[0]] = op
             p.ops.append(op)
-            _finalize_if_terminal(p, g, n.outputs[0], op, consumers, concat_slot, tid, level_of)
+            settle(n.outputs[0], op, _ST_BIAS)
         elif n.op == "Relu":
-            op = pending_conv.pop(n.inputs[0])
-            op.flags |= FLAG_RELU
-            pending_conv[n.outputs[0]] = op
-            _finalize_if_terminal(p, g, n.outputs[0], op, consumers, concat_slot, tid, level_of)
+            op, stage = pending.pop(n.inputs[0])
+            if stage == _ST_BIAS:
+                op.flags |= FLAG_RELU
+                settle(n.outputs[0], op, _ST_RELU)
+            else:
+                settle(n.outputs[0], op, _ST_BN_RELU if stage == _ST_BN else _ST_ADD_RELU)
+        elif n.op == "BatchNormalization":
+            op, stage = pending.pop(n.inputs[0])
+            gam, bet, mean, var = [g.initializers[i].astype(np.float32) for i in n.inputs[1:5]]
+            op.bn = np.concatenate([gam, bet, mean, var, np.array([n.attrs.get("epsilon", 1e-5)], np.float32)])
+            op.flags |= FLAG_BN
+            settle(n.outputs[0], op, _ST_BN)
+        elif n.op == "Add":
+            pend = [i for i in n.inputs if i in pending]
+            assert len(pend) == 1, "Add must combine one convolution output with one stored tensor"
+            op, stage = pending.pop(pend[0])
+            other = [i for i in n.inputs if i != pend[0]][0]
+            rt, roff = tid[other]
+            assert roff == 0 and p.tensors[rt][0] == op.cout and level_of[rt] == level_of[op.inp]
+            op.residual = rt
+            op.flags |= FLAG_ADD
+            settle(n.outputs[0], op, _ST_ADD)
         elif n.op == "MaxPool":
-            assert n.attrs["kernel_shape"] == [2, 2] and n.attrs["strides"] == [2, 2]
-            if n.inputs[0] in pending_conv:
-                op = pending_conv.pop(n.inputs[0])
+            assert n.attrs["kernel_shape"] == [2, 2] and n.attrs["strides"] == [2, 2] and not n.attrs.get("ceil_mode", 0)
+            if n.inputs[0] in pending:
+                op, stage = pending.pop(n.inputs[0])
                 op.flags |= FLAG_POOL
-                pending_conv[n.outputs[0]] = op
-                _finalize_if_terminal(p, g, n.outputs[0], op, consumers, concat_slot, tid, level_of)
+                settle(n.outputs[0], op, _ST_POOL)
             else:
                 src, src_off = tid[n.inputs[0]]
                 assert src_off == 0
@@ -233,50 +297,12 @@ def onnx_plan(path: str) -> Plan:
             tid[n.outputs[0]] = (dst, 0)
         else:
             raise NotImplementedError(f"ONNX op {n.op}")
+    assert not pending, f"unmaterialised values: {list(pending)}"
     p.det_tensor = tid["output_det"][0]
     p.desc_tensor = tid["output_desc"][0]
     for op in p.ops:
         assert op.out >= 0, "unfinalised conv"
     return p
-
-
-def _finalize_if_terminal(p, g, value, op, consumers, concat_slot, tid, level_of):
-    """Give `op` its output tensor once no more Relu/MaxPool can be fused onto `value`."""
-    nxt = consumers.get(value, [])
-    fuse_relu = len(nxt) == 1 and nxt[0].op == "Relu" and not (op.flags & (FLAG_RELU | FLAG_POOL))
-    fuse_pool = len(nxt) == 1 and nxt[0].op == "MaxPool" and not (op.flags & FLAG_POOL)
-    if fuse_relu or fuse_pool:
-        return
-    lvl = level_of[op.inp] + (1 if op.flags & FLAG_POOL else 0)
-    if value in concat_slot:
-        cname, off = concat_slot[value]
-        if cname not in tid:
-            total = off
-            # total channel count = sum over all members of this concat
-            total = sum(c for c in _concat_members(g, cname))
-            t = p.add_tensor(total, lvl)
-            level_of[t] = lvl
-            tid[cname] = (t, 0)
-        op.out, op.out_c_off = tid[cname][0], off
-        tid[value] = (op.out, off)
-    else:
-        t = p.add_tensor(op.cout, lvl)
-        level_of[t] = lvl
-        op.out, op.out_c_off = t, 0
-        tid[value] = (t, 0)
-
-
-def _concat_members(g, cname):
-    produced_by = {o: n for n in g.nodes for o in n.outputs}
-    node = produced_by[cname]
-
-    def ch(name):
-        n = produced_by[name]
-        if n.op == "Conv":
-            return g.initializers[n.inputs[1]].shape[0]
-        return ch(n.inputs[0])
-
-    return [ch(i) for i in node.inputs]
 
 
 # --------------------------------------------------------------------------
@@ -285,17 +311,19 @@ def save(plan: Plan, path: str) -> None:
     off = 0
     recs = []
     for op in plan.ops:
-        w_off = b_off = 0
+        w_off = b_off = bn_off = 0
         if op.weight is not None:
             w = np.ascontiguousarray(op.weight, np.float32).ravel()
             b = np.ascontiguousarray(op.bias, np.float32).ravel()
             w_off, off = off, off + w.size
             b_off, off = off, off + b.size
             payload += [w, b]
-        in_c_off = getattr(op, "in_c_off", 0)
-        # the input channel offset travels in the upper half of `cin`
-        recs.append(struct.pack("<8I2Q", op.type, op.inp, op.out, op.out_c_off,
-                                op.cin | (in_c_off << 16), op.cout, op.ksize, op.flags, w_off, b_off))
+        if op.bn is not None:
+            bn = np.ascontiguousarray(op.bn, np.float32).ravel()
+            bn_off, off = off, off + bn.size
+            payload.append(bn)
+        recs.append(struct.pack("<12I3Q", op.type, op.inp, op.out, op.out_c_off, op.cin | (op.in_c_off << 16), op.cout,
+                                op.ksize, op.flags, op.residual, 0, 0, 0, w_off, b_off, bn_off))
     with open(path, "wb") as fh:
         fh.write(MAGIC)
         fh.write(struct.pack("<8I", len(plan.tensors), len(plan.ops), plan.input_tensor,
@@ -312,7 +340,7 @@ def save(plan: Plan, path: str) -> None:
 def load(path: str) -> Plan:
     with open(path, "rb") as fh:
         buf = fh.read()
-    assert buf[:8] == MAGIC, "not a .spvw file"
+    assert buf[:8] == MAGIC, "not a .spvw file of this version"
     nt, no, it, dt, st, _, _, _ = struct.unpack_from("<8I", buf, 8)
     pos = 40
     p = Plan(input_tensor=it, det_tensor=dt, desc_tensor=st)
@@ -322,18 +350,24 @@ def load(path: str) -> Plan:
         p.tensors.append((ch, lvl))
     raw_ops = []
     for _ in range(no):
-        raw_ops.append(struct.unpack_from("<8I2Q", buf, pos))
-        pos += 48
+        raw_ops.append(struct.unpack_from("<12I3Q", buf, pos))
+        pos += 72
     (nfl,) = struct.unpack_from("<Q", buf, pos)
     pos += 8
     payload = np.frombuffer(buf, np.float32, nfl, pos)
-    for t, i, o, oc, cin, cout, k, fl, wo, bo in raw_ops:
+    for t, i, o, oc, cin, cout, k, fl, res, _r0, _r1, _r2, wo, bo, bno in raw_ops:
         op = Op(t, i, o, oc, cin & 0xFFFF, cout, k, fl)
         op.in_c_off = cin >> 16
+        op.residual = res
         if t == OP_CONV:
             n = cout * op.cin * k * k
             op.weight = payload[wo:wo + n].reshape(cout, op.cin, k, k).copy()
             op.bias = payload[bo:bo + cout].copy()
+        elif t == OP_DWCONV:
+            op.weight = payload[wo:wo + cout * 9].reshape(cout, 1, 3, 3).copy()
+            op.bias = payload[bo:bo + cout].copy()
+        if fl & FLAG_BN:
+            op.bn = payload[bno:bno + 4 * cout + 1].copy()
         p.ops.append(op)
     return p
 

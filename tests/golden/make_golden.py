@@ -1,12 +1,13 @@
 """Generates the committed fixtures under tests/golden/ (run in the build container only).
 
-  * sp_squeeze.spvw     -- the reference's src/odml_visual_odometry/models/sp_squeeze_b1.onnx
+  * sp_squeeze.spvw, sp_mbv1.spvw, sp_mbv2.spvw
+                        -- the reference's src/odml_visual_odometry/models/sp_{squeeze,mbv1,mbv2}_b1.onnx
                            (real trained weights: DATA, not source) re-packed by spvo/weights.py
   * images/*.png        -- three of the reference's sample frames (src/odml_visual_odometry/sample_images)
   * oracle_*.npz        -- outputs of the oracle on small inputs; they pin the oracle against
                            regressions (the reference itself holds no golden vectors: SURVEY.md 4, 8c)
 
-Usage: python tests/golden/make_golden.py   (needs /root/reference)
+Usage: python tests/golden/make_golden.py [--weights-only]   (needs /root/reference)
 """
 import os
 import shutil
@@ -31,8 +32,12 @@ def main():
         dst = os.path.join(HERE, "images", f"{i:010d}.png")
         if not os.path.exists(dst):
             shutil.copyfile(src, dst)
+    for name in ("mbv1", "mbv2"):
+        weights.save(weights.onnx_plan(f"{REF}/models/sp_{name}_b1.onnx"), os.path.join(HERE, f"sp_{name}.spvw"))
     plan = weights.onnx_plan(f"{REF}/models/sp_squeeze_b1.onnx")
     weights.save(plan, os.path.join(HERE, "sp_squeeze.spvw"))
+    if "--weights-only" in sys.argv:
+        return
 
     from PIL import Image
     img = np.asarray(Image.open(os.path.join(HERE, "images", "0000000000.png")))

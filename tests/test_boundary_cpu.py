@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from spvo import capi, weights
+from tests.conftest import GOLDEN
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -77,3 +78,51 @@ def test_squeeze_fixture_is_the_reference_graph(squeeze_plan):
     assert squeeze_plan.n_params() == 844353
     assert squeeze_plan.tensors[squeeze_plan.det_tensor] == (65, 3)
     assert squeeze_plan.tensors[squeeze_plan.desc_tensor] == (256, 3)
+
+
+@pytest.mark.parametrize("name,n_params,n_dw", [("mbv1", 752779, 7), ("mbv2", 945035, 7)])
+def test_mobilenet_fixtures_are_the_reference_graphs(name, n_params, n_dw):
+    """sp_mbv1 / sp_mbv2 (config 3's graphs): every Relu / BatchNormalization / Add / MaxPool of the ONNX
+    graph is folded into the producing convolution, so the plan holds convolutions and the L2 tail only."""
+    from spvo import weights
+    plan = weights.load(os.path.join(GOLDEN, f"sp_{name}.spvw"))
+    n = sum(op.weight.size + op.bias.size + (op.bn.size - 1 if op.bn is not None else 0)
+            for op in plan.ops if op.weight is not None)
+    assert n == n_params
+    kinds = [op.type for op in plan.ops]
+    assert kinds.count(weights.OP_DWCONV) == n_dw and kinds.count(weights.OP_MAXPOOL) == 0
+    assert kinds[-1] == weights.OP_L2NORM
+    assert plan.tensors[plan.det_tensor] == (65, 3) and plan.tensors[plan.desc_tensor] == (256, 3)
+    if name == "mbv1":
+        assert all((op.flags & weights.FLAG_BN) for op in plan.ops[1:16:2])       # each pointwise layer
+    else:
+        res = [op for op in plan.ops if op.flags & weights.FLAG_ADD]
+        assert len(res) == 6 and all(plan.tensors[op.residual][0] == op.cout for op in res)
+
+
+@pytest.mark.parametrize("name", ["mbv1", "mbv2"])
+def test_oracle_runs_mobilenet_graphs(name):
+    """The oracle's executor against a direct numpy evaluation of one fused MobileNet epilogue."""
+    import torch
+    from oracle import net
+    from spvo import weights
+    plan = weights.load(os.path.join(GOLDEN, f"sp_{name}.spvw"))
+    rng = np.random.RandomState(0)
+    x = rng.rand(1, 1, 16, 24).astype(np.float32)
+    det, desc, vals = net.forward(plan, x, return_all=True)
+    assert det.shape == (1, 65, 2, 3) and desc.shape == (1, 256, 2, 3)
+    assert np.allclose(np.linalg.norm(desc, axis=1), 1.0, atol=1e-5)
+    op = next(o for o in plan.ops if o.flags & (weights.FLAG_BN | weights.FLAG_ADD) and o.cin > 1)
+    xin = vals[op.inp].astype(np.float64)
+    y = np.einsum("oc,bchw->bohw", op.weight[:, :, 0, 0].astype(np.float64), xin) + op.bias[None, :, None, None]
+    if op.flags & weights.FLAG_RELU:
+        y = np.maximum(y, 0)
+    if op.flags & weights.FLAG_BN:
+        c = op.cout
+        g, b, m, v = (op.bn[i * c:(i + 1) * c].astype(np.float64)[None, :, None, None] for i in range(4))
+        y = np.maximum((y - m) / np.sqrt(v + float(op.bn[4 * c])) * g + b, 0)
+    if op.flags & weights.FLAG_ADD:
+        y = np.maximum(y + vals[op.residual], 0)
+    if op.flags & weights.FLAG_POOL:
+        y = y.reshape(1, op.cout, y.shape[2] // 2, 2, y.shape[3] // 2, 2).max(axis=(3, 5))
+    assert np.abs(vals[op.out] - y).max() < 1e-4

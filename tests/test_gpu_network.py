@@ -52,6 +52,30 @@ def test_squeeze_forward_matches_oracle(ctx_squeeze, squeeze_plan, sample_images
     assert np.abs(desc - rdesc.transpose(0, 2, 3, 1)).max() <= 1e-4
 
 
+@pytest.mark.parametrize("name", ["mbv1", "mbv2"])
+@pytest.mark.parametrize("H,W,batch", [(120, 392, 2), (360, 1176, 2)])
+def test_mobilenet_forward_matches_oracle(name, H, W, batch, sample_images):
+    """Config 3's graphs in fp32: depthwise 3x3, BatchNorm after ReLU (mbv1), residual Add + ReLU (mbv2),
+    every one of them fused into the producing convolution; each intermediate tensor is compared."""
+    import os
+    from spvo import weights
+    from tests.conftest import GOLDEN
+    path = os.path.join(GOLDEN, f"sp_{name}.spvw")
+    plan = weights.load(path)
+    ctx = make_ctx(path, net_height=H, net_width=W)
+    x = _input(sample_images, H, W, batch)
+    det, desc = ctx.forward(x)
+    rdet, rdesc, vals = net.forward(plan, x, return_all=True)
+    for tid, (ch, lvl) in enumerate(plan.tensors):
+        if tid in (plan.input_tensor, plan.desc_tensor):
+            continue
+        got = ctx.debug_tensor(tid, batch, ch, lvl)
+        assert np.abs(got - vals[tid]).max() <= _tol(vals[tid]), f"{name} tensor {tid}"
+    assert np.abs(det - rdet).max() <= _tol(rdet)
+    assert np.abs(desc - rdesc.transpose(0, 2, 3, 1)).max() <= 1e-4
+    ctx.close()
+
+
 def test_forward_is_deterministic_and_batch_independent(ctx_vgg, sample_images):
     x = _input(sample_images, 360, 1176, 2)
     d1, s1 = ctx_vgg.forward(x)
