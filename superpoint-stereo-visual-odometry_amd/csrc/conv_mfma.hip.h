@@ -28,23 +28,27 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 namespace spvo {
 
-constexpr int PADX = 4;
+#ifndef SPVO_PADX
+#define SPVO_PADX 4
+#endif
+constexpr int PADX = SPVO_PADX;   // multiple of 4 (16-byte aligned rows)
 constexpr int PADY = 1;
 constexpr int CO_TILE = 64;
 
 __host__ __device__ inline int padded_h(int h) { return ((h + 7) / 8) * 8 + 2; }
-__host__ __device__ inline int padded_w(int w) { return ((w + 63) / 64) * 64 + 8; }
+__host__ __device__ inline int padded_w(int w) { return ((w + 63) / 64) * 64 + 2 * PADX; }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct ConvArgs {
   const float *in;     // padded planes of the input tensor (batch 0, channel 0)
   float *out;          // padded planes of the output tensor
-  const float *wpack;  // [co_tiles][n_chunks][KS*KS][CK][64]
-  const float *bias;   // [co_tiles*64], zero padded
+  const float *wpack;  // [co_tiles][n_chunks][KS*KS*CK + 1][64]: pack_conv_weights() below
+  const float *bias;   // [cout]: read by the Cin = 1 / depthwise kernels only (the MFMA kernel finds its bias in wpack)
   int H, W;            // conv resolution (input == pre-pool output)
   int in_hp, in_wp, in_ctot, in_coff;
   int out_hp, out_wp, out_ctot, out_coff;
@@ -56,6 +60,8 @@ struct ConvArgs {
   const float *bn_scale = nullptr, *bn_shift = nullptr;  // EPI 1: v = relu(v * scale[co] + shift[co]), [co_tiles*64]
   const float *residual = nullptr;                       // EPI 2: v = relu(v + residual[co][y][x]); planes of the
                                                          //        input's geometry (in_hp x in_wp), cout channels
+  unsigned long long *stamps = nullptr;                  // diagnostic build (ABL 4) only: per workgroup
+                                                         //        {shader cycles, 100 MHz ticks} around the tile loop
 };
 
 __device__ __forceinline__ void glds16(const float *src, float *lds_wave_base) {
@@ -72,10 +78,31 @@ struct ConvTile {
   static constexpr int LW = TW + (KS == 3 ? 8 : 0);  // LDS row: x0-4 .. x0+TW+3
   static constexpr int LH = TH + 2 * HALO;
   static constexpr int IN_FLOATS = CK * LH * LW;
-  static constexpr int W_FLOATS = KS * KS * CK * CO_TILE;
+  static constexpr int W_ROWS = KS * KS * CK;            // (tap, ci) rows of 64 output channels ...
+  static constexpr int W_FLOATS = (W_ROWS + 1) * CO_TILE;  // ... plus one row that holds the bias in chunk 0's slab
   static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
   static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4;
 };
+
+// Host side: OIHW weights + bias -> the slabs the kernel stages, [co_tile][chunk][(tap, ci) rows + 1][64].
+// The extra row carries the bias of the co tile in chunk 0 (zeros elsewhere): the kernel reads it from
+// LDS together with the weights instead of through a separate global load.
+inline std::vector<float> pack_conv_weights(const float *w, const float *bias, int cout, int cin, int ks, int ck) {
+  const int co_tiles = (cout + CO_TILE - 1) / CO_TILE, nch = cin / ck, taps = ks * ks, rows = taps * ck + 1;
+  std::vector<float> out((size_t)co_tiles * nch * rows * CO_TILE, 0.f);
+  for (int ct = 0; ct < co_tiles; ++ct)
+    for (int ch = 0; ch < nch; ++ch) {
+      float *slab = out.data() + ((size_t)ct * nch + ch) * rows * CO_TILE;
+      for (int o = 0; o < CO_TILE; ++o) {
+        const int co = ct * CO_TILE + o;
+        if (co >= cout) continue;
+        for (int t = 0; t < taps; ++t)
+          for (int c = 0; c < ck; ++c) slab[(t * ck + c) * CO_TILE + o] = w[((size_t)co * cin + ch * ck + c) * taps + t];
+        if (ch == 0) slab[(rows - 1) * CO_TILE + o] = bias[co];
+      }
+    }
+  return out;
+}
 
 // The kernel is PERSISTENT: the grid is sized to what the chip holds at once (host side) and
 // every workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...  The LDS ring keeps
@@ -83,7 +110,8 @@ struct ConvTile {
 // chunk of the current one is multiplied -- so the fill latency, the bias loads and the output
 // stores of a tile hide behind matrix work instead of bracketing it.
 // ABL (timing experiments only, results are wrong when != 0): 1 = stage only the first chunk,
-// 2 = additionally keep the MFMA operands in registers (no LDS reads in the loop).
+// 2 = additionally keep the MFMA operands in registers (no LDS reads in the loop);
+// 4 = correct results plus clock stamps around the tile loop (in-kernel clock = cycles / ticks * 100 MHz).
 template <int KS, int CK, int WR, int WC, bool POOL, bool RELU, int MINW = 1, int ABL = 0, int EPI = 0>
 __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) {
   using T = ConvTile<KS, CK, WR, WC>;
@@ -156,47 +184,56 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
 
   int tile_id = blockIdx.x;
   if (tile_id >= n_tiles) return;
+  unsigned long long stamp_c = 0, stamp_r = 0;
+  if constexpr (ABL == 4) { stamp_c = __builtin_amdgcn_s_memtime(); stamp_r = __builtin_amdgcn_s_memrealtime(); }
   TileRef cur = decode(tile_id);
   issue(cur, 0, smem);
   int ring = 0;                 // chunks consumed so far: selects the LDS buffer
-  int bias_ct = -1;
-  f32x16 bias_v[2];
+  bool first_landed = false;
+
+  constexpr int NSTEP = KS * KS * (CK / 2);
+  constexpr unsigned OOB = 0xFFFFFFFFu;   // buffer-store offset of a lane that must not write
 
   for (; tile_id < n_tiles; tile_id += gridDim.x) {
     const int next_id = tile_id + gridDim.x;
     TileRef nxt = cur;
     if (next_id < n_tiles) nxt = decode(next_id);
 
-    if (cur.ct != bias_ct) {    // bias of this output-channel tile (kept across tiles)
-      bias_ct = cur.ct;
+    // Chunk `ring` has landed for every wave once each wave has drained its own LDS-DMA and passed the
+    // barrier; after the barrier buffer (ring+1)&1 is no longer read by anyone.  The wait is explicit
+    // because hipcc does not count global_load_lds in the waits it emits.  At the first chunk of a tile
+    // (but the very first) the wait already happened in front of the previous tile's epilogue, so that
+    // tile's output stores -- younger than the LDS-DMA and counted by the same in-order counter -- stay
+    // in flight under this tile's matrix work instead of being drained here.  A bare s_barrier, not
+    // __syncthreads(): its release fence would drain them too.
+    if (!first_landed) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_barrier" ::: "memory");
+    // The accumulators start as one extra k-step, A = (bias, 0), B = (1, 1), C = 0: 0 + bias * 1 + 0 * 1
+    // is exactly the bias, so the chain equals one that starts from the bias.  The bias row sits behind
+    // the weights of chunk 0 in LDS.
+    f32x16 acc[2][NT];
+    {
+      const float *buf0 = smem + (ring & 1) * T::BUF_FLOATS;
+      float bias_a[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) bias_a[m] = half ? 0.f : buf0[T::IN_FLOATS + T::W_ROWS * CO_TILE + 32 * m + j];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bias_v[m][r] = a.bias[cur.ct * CO_TILE + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half];
+        for (int n = 0; n < NT; ++n) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a[m], 1.0f, acc[m][n], 0, 0, 0);
+        }
     }
-    f32x16 acc[2][NT];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int n = 0; n < NT; ++n) acc[m][n] = bias_v[m];
 
     for (int c = 0; c < a.n_chunks; ++c, ++ring) {
-      // chunk `ring` has landed for every wave (each wave drains its own LDS-DMA, then the
-      // barrier); after the barrier buffer (ring+1)&1 is no longer read by anyone.  The explicit
-      // wait is required: hipcc does not count global_load_lds in the wait it emits for
-      // __syncthreads() here (checked in the .s).
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      if (c > 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
       float *nbuf = smem + ((ring + 1) & 1) * T::BUF_FLOATS;
-      if (ABL == 0 || ring == 0) {
-        if (c + 1 < a.n_chunks) issue(cur, c + 1, nbuf);
-        else if (next_id < n_tiles) issue(nxt, 0, nbuf);      // first chunk of the NEXT tile
-      }
       const float *buf = smem + (ring & 1) * T::BUF_FLOATS;
       // k-steps of this chunk: step = (tap, channel pair).  Operands of step s+1 are read from LDS
       // into a second register set BEFORE the MFMAs of step s issue, so the LDS latency hides
       // under 2*NT matrix instructions instead of stalling the head of every step.
-      constexpr int NSTEP = KS * KS * (CK / 2);
       float av[2][2], bv[2][NT];
       auto load_step = [&](int st, int slot) {
         const int t = st / (CK / 2), p = st % (CK / 2);
@@ -213,12 +250,20 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
 #pragma unroll
       for (int st = 0; st < NSTEP; ++st) {
         const int cs = st & 1;
-        // first matrix instruction of the step, then ALL LDS reads of the next step, then the other
-        // 2*NT-1 matrix instructions: when hipcc's lgkmcnt(0) in front of the next step is reached
-        // the reads are >= (2*NT-1)*64 cycles old.  sched_barrier(0) pins exactly this order.
+        // One wave per SIMD issues in order and -- measured, tools/conv_bench "abl" -- every vector-ALU,
+        // LDS or memory instruction placed between two matrix instructions delays the next one by about
+        // its own issue time, so the loop holds nothing but the operand reads.  First matrix instruction
+        // of the step, then ALL LDS reads of the next step, then the other 2*NT-1 matrix instructions:
+        // when hipcc's lgkmcnt(0) in front of the next step is reached the reads are >= (2*NT-1)*64
+        // cycles old.  sched_barrier(0) pins exactly this order.
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cs][0], bv[cs][0], acc[0][0], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (st + 1 < NSTEP && (ABL < 2 || st == 0)) load_step(st + 1, cs ^ 1);
+        if (st == 0 && (ABL == 0 || ABL == 4 || ring == 0)) {
+          // the next chunk's LDS-DMA is issued behind the first matrix instruction, not in front of it
+          if (c + 1 < a.n_chunks) issue(cur, c + 1, nbuf);
+          else if (next_id < n_tiles) issue(nxt, 0, nbuf);      // first chunk of the NEXT tile
+        }
+        if (st + 1 < NSTEP && (ABL != 2 || st == 0)) load_step(st + 1, cs ^ 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -229,20 +274,53 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
       }
     }
 
+    // the next tile's first chunk (issued one chunk ago) has landed before this tile's stores queue up
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    first_landed = true;
+
     // ----------------------------------------------------------- epilogue of this tile
-    float *out_img = a.out + ((size_t)cur.img * a.out_ctot + a.out_coff) * out_plane;
+    // 2*NT*16 values per lane leave through raw buffer stores: the descriptor (co tile of this image)
+    // and the channel offset are wave-uniform scalars, the pixel is ONE per-lane byte offset per
+    // (row, column tile), and a lane that must not write carries the offset 0xFFFFFFFF, which the
+    // hardware range check drops -- no 64-bit address arithmetic and no exec-mask branch per store.
+    // Values are converted 16 at a time into distinct registers before their stores issue, so neither
+    // a dependent chain nor a store still reading its data register stalls the next conversion.
+    float *co_base = a.out + (((size_t)cur.img * a.out_ctot + a.out_coff) + (size_t)cur.ct * CO_TILE) * out_plane;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(co_base, 0, 0x7FFFFFFF, 0x00020000);
+    const int oplane = (int)out_plane;
+    const bool co_full = (cur.ct + 1) * CO_TILE <= a.cout;   // wave-uniform: every channel of the tile exists
+    const int kmax = a.cout - (cur.ct * CO_TILE + 4 * half); // channels k < kmax of the co tile exist for this lane
     // element-wise tail in graph order: ReLU, then (EPI 1) BatchNorm + ReLU or (EPI 2) residual + ReLU
     const size_t res_plane = (size_t)a.in_hp * a.in_wp;
     const float *res_img = EPI == 2 ? a.residual + (size_t)cur.img * a.cout * res_plane : nullptr;
-    auto tail = [&](float v, int co, int y, int x) -> float {
-      if (RELU) v = fmaxf(v, 0.f);
-      if constexpr (EPI == 1) v = fmaxf(fmaf(v, a.bn_scale[co], a.bn_shift[co]), 0.f);
-      if constexpr (EPI == 2) {
-        // the padded plane covers the whole tile (zeros outside the image); channels past cout do not exist
-        const float rv = co < a.cout ? res_img[(size_t)co * res_plane + (size_t)(y + PADY) * a.in_wp + (x + PADX)] : 0.f;
-        v = fmaxf(v + rv, 0.f);
+    auto relu = [](float v) { return __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()); };   // one instruction
+    auto tail = [&](float v, int k, int y, int x) -> float {
+      if (RELU) v = relu(v);
+      if constexpr (EPI != 0) {
+        const int co = cur.ct * CO_TILE + 4 * half + k;
+        if constexpr (EPI == 1) v = relu(fmaf(v, a.bn_scale[co], a.bn_shift[co]));
+        if constexpr (EPI == 2) {
+          // the padded plane covers the whole tile (zeros outside the image); channels past cout do not exist
+          const float rv = co < a.cout ? res_img[(size_t)co * res_plane + (size_t)(y + PADY) * a.in_wp + (x + PADX)] : 0.f;
+          v = relu(v + rv);
+        }
       }
       return v;
+    };
+    auto store16 = [&](const float (&pv)[16], int m, unsigned voff) {
+      if (co_full) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = 32 * m + (r & 3) + 8 * (r >> 2);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pv[r]), rsrc, voff, k * oplane * 4, 0);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = 32 * m + (r & 3) + 8 * (r >> 2);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pv[r]), rsrc, k < kmax ? voff : OOB, k * oplane * 4, 0);
+        }
+      }
     };
     if constexpr (!POOL) {
 #pragma unroll
@@ -253,14 +331,11 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
           for (int cc = 0; cc < WC; ++cc) {
             const int y = cur.y0 + wave * WR + rr;
             const int x = cur.x0 + cc * 32 + j;
-            const bool ok = (y < a.H) && (x < a.W);
+            const unsigned voff = ((y < a.H) && (x < a.W)) ? 4u * (unsigned)(4 * half * oplane + (y + PADY) * a.out_wp + (x + PADX)) : OOB;
+            float pv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int co = cur.ct * CO_TILE + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
-              const float v = tail(acc[m][rr * WC + cc][r], co, y, x);
-              if (ok && co < a.cout)
-                out_img[(size_t)co * out_plane + (size_t)(y + PADY) * a.out_wp + (x + PADX)] = v;
-            }
+            for (int r = 0; r < 16; ++r) pv[r] = tail(acc[m][rr * WC + cc][r], 32 * m + (r & 3) + 8 * (r >> 2), y, x);
+            store16(pv, m, voff);
           }
     } else {
       const int OH = a.H >> 1, OW = a.W >> 1;
@@ -271,25 +346,32 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
           const int yi = cur.y0 + wave * 2, xi = cur.x0 + cc * 32 + j;
           const int y = (cur.y0 >> 1) + wave;
           const int x = xi >> 1;
-          const bool ok = (y < OH) && (x < OW) && !(j & 1);
+          const unsigned voff = ((y < OH) && (x < OW) && !(j & 1)) ? 4u * (unsigned)(4 * half * oplane + (y + PADY) * a.out_wp + (x + PADX)) : OOB;
+          float pv[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int co = cur.ct * CO_TILE + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int k = 32 * m + (r & 3) + 8 * (r >> 2);
             float v;
             if constexpr (EPI == 0) {   // ReLU commutes with max: one clamp instead of four
               v = fmaxf(acc[m][0 * WC + cc][r], acc[m][1 * WC + cc][r]);
               v = fmaxf(v, __shfl_xor(v, 1));
-              if (RELU) v = fmaxf(v, 0.f);
+              if (RELU) v = relu(v);
             } else {
-              v = fmaxf(tail(acc[m][0 * WC + cc][r], co, yi, xi), tail(acc[m][1 * WC + cc][r], co, yi + 1, xi));
+              v = fmaxf(tail(acc[m][0 * WC + cc][r], k, yi, xi), tail(acc[m][1 * WC + cc][r], k, yi + 1, xi));
               v = fmaxf(v, __shfl_xor(v, 1));
             }
-            if (ok && co < a.cout)
-              out_img[(size_t)co * out_plane + (size_t)(y + PADY) * a.out_wp + (x + PADX)] = v;
+            pv[r] = v;
           }
+          store16(pv, m, voff);
         }
     }
     cur = nxt;
+  }
+  if constexpr (ABL == 4) {
+    if (tid == 0) {
+      a.stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - stamp_c;
+      a.stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - stamp_r;
+    }
   }
 }
 

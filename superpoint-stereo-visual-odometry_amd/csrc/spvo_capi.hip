@@ -1004,17 +1004,9 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
       op.n_chunks = op.cin / op.ck;
       op.co_tiles = (op.cout + CO_TILE - 1) / CO_TILE;
       choose_tile(ti.H, ti.W, op.co_tiles, c->cfg.max_batch, pool, &op.wr, &op.wc);
-      // repack OIHW -> [co_tile][chunk][tap][ci][64]
-      std::vector<float> pk((size_t)op.co_tiles * op.n_chunks * taps * op.ck * CO_TILE, 0.f), bp((size_t)op.co_tiles * CO_TILE, 0.f);
-      for (int ct = 0; ct < op.co_tiles; ++ct)
-        for (int ch = 0; ch < op.n_chunks; ++ch)
-          for (int t = 0; t < taps; ++t)
-            for (int ci = 0; ci < op.ck; ++ci)
-              for (int o = 0; o < CO_TILE; ++o) {
-                const int co = ct * CO_TILE + o;
-                if (co < op.cout)
-                  pk[((((size_t)ct * op.n_chunks + ch) * taps + t) * op.ck + ci) * CO_TILE + o] = w[((size_t)co * op.cin + ch * op.ck + ci) * taps + t];
-              }
+      // repack OIHW + bias -> [co_tile][chunk][(tap, ci) rows + bias row][64]
+      const std::vector<float> pk = pack_conv_weights(w, b, op.cout, op.cin, op.ks, op.ck);
+      std::vector<float> bp((size_t)op.co_tiles * CO_TILE, 0.f);
       for (int o = 0; o < op.cout; ++o) bp[o] = b[o];
       int rc = dev_alloc(c, &op.d_w, pk.size(), false);
       if (rc) return rc;

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <vector>
 #include <string>
+#include <cstring>
 #include <algorithm>
 #include "conv_mfma.hip.h"
 
@@ -50,19 +51,9 @@ __global__ void naive_pool(const float *in, float *out, int C, int OH, int OW, i
   out[(size_t)c * ohp * owp + (size_t)(y + PADY) * owp + x + PADX] = fmaxf(fmaxf(ip[0], ip[1]), fmaxf(ip[iwp], ip[iwp + 1]));
 }
 
-static void pack_weights(const std::vector<float> &w, int cout, int cin, int KS, int CK, std::vector<float> &out, int &co_tiles) {
+static void pack_weights(const std::vector<float> &w, const std::vector<float> &bias, int cout, int cin, int KS, int CK, std::vector<float> &out, int &co_tiles) {
   co_tiles = (cout + CO_TILE - 1) / CO_TILE;
-  const int nch = cin / CK, taps = KS * KS;
-  out.assign((size_t)co_tiles * nch * taps * CK * CO_TILE, 0.f);
-  for (int ct = 0; ct < co_tiles; ++ct)
-    for (int ch = 0; ch < nch; ++ch)
-      for (int t = 0; t < taps; ++t)
-        for (int c = 0; c < CK; ++c)
-          for (int o = 0; o < CO_TILE; ++o) {
-            const int co = ct * CO_TILE + o, ci = ch * CK + c;
-            if (co < cout)
-              out[((((size_t)ct * nch + ch) * taps + t) * CK + c) * CO_TILE + o] = w[((size_t)co * cin + ci) * taps + t];
-          }
+  out = pack_conv_weights(w.data(), bias.data(), cout, cin, KS, CK);
 }
 
 template <int KS, int CK, int WR, int WC, bool POOL, int MINW = 1, int ABL = 0>
@@ -84,7 +75,7 @@ static double run_variant(const char *name, int B, int cin, int cout, int H, int
   for (int i = 0; i < cout; ++i) hb[i] = rnd() * 0.1f;
   std::vector<float> hpk;
   int co_tiles;
-  pack_weights(hw, cout, cin, KS, CK, hpk, co_tiles);
+  pack_weights(hw, hb, cout, cin, KS, CK, hpk, co_tiles);
 
   float *din, *dout, *dref, *dfull, *dw, *dpk, *db;
   CK_HIP(hipMalloc(&din, in_n * 4));
@@ -151,12 +142,111 @@ static double run_variant(const char *name, int B, int cin, int cout, int H, int
   return ms;
 }
 
+// In-kernel clock of a production variant under sustained load (MI355X_MICROARCH.md, DVFS give-back
+// item 6): >= 2 s of back-to-back launches, then the stamps of the last launch, median over workgroups.
+template <int KS, int CK, int WR, int WC, bool POOL, int ABL = 4>
+static void run_clock(const char *name, int B, int cin, int cout, int H, int W, double seconds) {
+  using T = ConvTile<KS, CK, WR, WC>;
+  const int hp = padded_h(H), wp = padded_w(W);
+  const int OH = POOL ? H / 2 : H, OW = POOL ? W / 2 : W;
+  const int ohp = padded_h(OH), owp = padded_w(OW);
+  const size_t in_n = (size_t)B * cin * hp * wp, out_n = (size_t)B * cout * ohp * owp;
+  std::vector<float> hin(in_n, 0.f), hw((size_t)cout * cin * KS * KS), hb(((cout + 63) / 64) * 64, 0.f), hpk;
+  srand(99);
+  auto rnd = []() { return (float)rand() / RAND_MAX * 2.f - 1.f; };
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < cin; ++c)
+      for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) hin[(((size_t)b * cin + c) * hp + y + PADY) * wp + x + PADX] = rnd();
+  for (auto &v : hw) v = rnd() * 0.1f;
+  int co_tiles;
+  pack_weights(hw, hb, cout, cin, KS, CK, hpk, co_tiles);
+  float *din, *dout, *dpk, *db;
+  unsigned long long *dst;
+  CK_HIP(hipMalloc(&din, in_n * 4)); CK_HIP(hipMalloc(&dout, out_n * 4)); CK_HIP(hipMalloc(&dpk, hpk.size() * 4)); CK_HIP(hipMalloc(&db, hb.size() * 4));
+  CK_HIP(hipMemcpy(din, hin.data(), in_n * 4, hipMemcpyHostToDevice));
+  CK_HIP(hipMemcpy(dpk, hpk.data(), hpk.size() * 4, hipMemcpyHostToDevice));
+  CK_HIP(hipMemcpy(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+  CK_HIP(hipMemset(dout, 0, out_n * 4));
+  ConvArgs a;
+  a.in = din; a.out = dout; a.wpack = dpk; a.bias = db;
+  a.H = H; a.W = W; a.in_hp = hp; a.in_wp = wp; a.in_ctot = cin; a.in_coff = 0;
+  a.out_hp = ohp; a.out_wp = owp; a.out_ctot = cout; a.out_coff = 0; a.cout = cout;
+  a.n_chunks = cin / CK;
+  a.tiles_x = (W + T::TW - 1) / T::TW; a.tiles_y = (H + T::TH - 1) / T::TH; a.co_tiles = co_tiles; a.batch = B;
+  auto kern = conv_mfma_kernel<KS, CK, WR, WC, POOL, true, 1, ABL>;
+  CK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+  int per_cu = 1;
+  CK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, 256, T::LDS_BYTES));
+  const int n_tiles = a.tiles_x * a.tiles_y * co_tiles * B;
+  const int grid = std::min(n_tiles, 256 * std::max(per_cu, 1));
+  CK_HIP(hipMalloc(&dst, (size_t)grid * 16));
+  a.stamps = dst;
+  hipEvent_t e0, e1;
+  CK_HIP(hipEventCreate(&e0)); CK_HIP(hipEventCreate(&e1));
+  kern<<<grid, 256, T::LDS_BYTES>>>(a);
+  CK_HIP(hipDeviceSynchronize());
+  double total_ms = 0, last = 0;
+  int launches = 0;
+  while (total_ms < seconds * 1e3) {
+    CK_HIP(hipEventRecord(e0));
+    for (int i = 0; i < 200; ++i) kern<<<grid, 256, T::LDS_BYTES>>>(a);
+    CK_HIP(hipEventRecord(e1));
+    CK_HIP(hipEventSynchronize(e1));
+    float ms;
+    CK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    total_ms += ms; launches += 200; last = ms / 200;
+  }
+  if (ABL != 4) {
+    const double fl = 2.0 * B * H * W * (double)cout * cin * KS * KS;
+    printf("%-22s grid %5d: %7.3f ms/launch sustained  %7.2f TFLOP/s (ablation %d: results not checked)\n", name, grid, last, fl / last * 1e-9, ABL);
+    hipFree(din); hipFree(dout); hipFree(dpk); hipFree(db); hipFree(dst);
+    return;
+  }
+  std::vector<unsigned long long> st((size_t)grid * 2);
+  CK_HIP(hipMemcpy(st.data(), dst, st.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<double> mhz, busy_ms;
+  for (int i = 0; i < grid; ++i) {
+    mhz.push_back((double)st[2 * i] / (double)st[2 * i + 1] * 100.0);
+    busy_ms.push_back((double)st[2 * i + 1] * 1e-5);
+  }
+  std::sort(mhz.begin(), mhz.end());
+  std::sort(busy_ms.begin(), busy_ms.end());
+  const double flops = 2.0 * B * H * W * (double)cout * cin * KS * KS;
+  const double clk = mhz[grid / 2];
+  printf("%-22s grid %5d: %7.3f ms/launch (last 200 of %d)  %7.2f TFLOP/s | in-kernel clock median %6.0f MHz (min %6.0f max %6.0f) -> peak at that clock %6.1f TF, frac %.3f | workgroup lifetime median %.3f ms max %.3f ms\n",
+         name, grid, last, launches, flops / last * 1e-9, clk, mhz.front(), mhz.back(), 157.3 * clk / 2400.0,
+         flops / last * 1e-9 / (157.3 * clk / 2400.0), busy_ms[grid / 2], busy_ms.back());
+  hipFree(din); hipFree(dout); hipFree(dpk); hipFree(db); hipFree(dst);
+}
+
 int main(int argc, char **argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 10;
   if (argc > 2) g_oversub = atoi(argv[2]);
   hipDeviceProp_t prop;
   CK_HIP(hipGetDeviceProperties(&prop, 0));
   printf("device: %s, %d CUs, arch %s\n", prop.name, prop.multiProcessorCount, prop.gcnArchName);
+  if (argc > 3 && !strcmp(argv[3], "clock")) {
+    run_clock<3, 8, 2, 2, true>("conv1b 8x64 pool", 2, 64, 64, 360, 1176, 2.5);
+    run_clock<3, 8, 2, 2, false>("ideal 8x64", 2, 64, 64, 256, 1024, 2.5);
+    run_clock<3, 8, 1, 2, false>("conv2a 4x64", 2, 64, 64, 180, 588, 2.0);
+    run_clock<3, 8, 1, 1, false>("conv4a 4x32", 2, 128, 128, 45, 147, 2.0);
+    return 0;
+  }
+  if (argc > 3 && !strcmp(argv[3], "abl")) {   // what each part of the kernel costs, at sustained clocks
+    run_clock<3, 8, 2, 2, false, 4>("ideal 8x64 full", 2, 64, 64, 256, 1024, 1.5);
+    run_clock<3, 8, 2, 2, false, 1>("ideal 8x64 no glds", 2, 64, 64, 256, 1024, 1.5);
+    run_clock<3, 8, 2, 2, false, 2>("ideal 8x64 no glds/ds", 2, 64, 64, 256, 1024, 1.5);
+    run_clock<3, 8, 2, 2, true, 4>("conv1b full", 2, 64, 64, 360, 1176, 1.5);
+    run_clock<3, 8, 1, 2, false, 4>("conv2a 4x64 full", 2, 64, 64, 180, 588, 1.5);
+    run_clock<3, 8, 1, 1, false, 4>("conv4a 4x32 full", 2, 128, 128, 45, 147, 1.5);
+    run_clock<1, 16, 1, 1, false, 4>("convDb 4x32 full", 2, 256, 256, 45, 147, 1.5);
+    return 0;
+  }
+  if (argc > 3 && !strcmp(argv[3], "one")) {   // a single production kernel, for PMC passes
+    run_variant<3, 8, 2, 2, true>("conv1b 8x64 pool ck8", 2, 64, 64, 360, 1176, reps);
+    return 0;
+  }
   // small ragged shapes first (correctness incl. edges)
   run_variant<3, 8, 2, 2, false>("small k3 8x64", 1, 16, 64, 21, 75, 2);
   run_variant<3, 8, 2, 2, true>("small k3 8x64 pool", 2, 16, 70, 22, 74, 2);
@@ -171,8 +261,6 @@ int main(int argc, char **argv) {
   run_variant<3, 8, 2, 1, true, 1, 1>("abl1 8x32p no glds", 2, 64, 64, 256, 1024, reps);
   run_variant<3, 8, 2, 1, true, 1, 2>("abl2 8x32p no glds/ds", 2, 64, 64, 256, 1024, reps);
   run_variant<3, 8, 2, 1, true, 1, 3>("abl3 8x32p stagger", 2, 64, 64, 256, 1024, reps);
-  run_variant<3, 4, 2, 2, false, 2, 0>("abl0 8x64 ck4 w2 full", 2, 64, 64, 256, 1024, reps);
-  run_variant<3, 4, 2, 2, false, 2, 3>("abl3 8x64 ck4 w2 stagger", 2, 64, 64, 256, 1024, reps);
   run_variant<3, 8, 1, 1, false, 1, 0>("abl0 4x32 full", 2, 128, 128, 48, 512, reps);
   run_variant<3, 8, 1, 1, false, 1, 1>("abl1 4x32 no glds", 2, 128, 128, 48, 512, reps);
   run_variant<3, 8, 1, 1, false, 1, 2>("abl2 4x32 no glds/ds", 2, 128, 128, 48, 512, reps);
@@ -191,7 +279,6 @@ int main(int argc, char **argv) {
   run_variant<3, 8, 1, 1, false>("ideal 4x32 128ch (3/CU)", 2, 128, 128, 48, 256, reps);
   // VGG layer shapes at 360x1176, stereo pair (B = 2)
   run_variant<3, 8, 2, 2, true>("conv1b 8x64 pool ck8", 2, 64, 64, 360, 1176, reps);
-  run_variant<3, 4, 2, 2, true, 2>("conv1b 8x64 pool ck4 w2", 2, 64, 64, 360, 1176, reps);
   run_variant<3, 8, 2, 1, true>("conv1b 8x32 pool ck8", 2, 64, 64, 360, 1176, reps);
   run_variant<3, 4, 2, 1, true>("conv1b 8x32 pool ck4", 2, 64, 64, 360, 1176, reps);
   run_variant<3, 8, 2, 2, false>("conv2a 8x64", 2, 64, 64, 180, 588, reps);

@@ -30,7 +30,29 @@ void run(int blocks, int iters, const char *name) {
   printf("%-24s blocks %5d iters %6d: %8.3f ms  %7.2f TFLOP/s\n", name, blocks, iters, ms, fl / ms * 1e-9);
   hipFree(d);
 }
+// back-to-back launches of a short kernel for ~1.5 s: what a kernel of the conv layers' duration can reach
+template <int NACC>
+void run_sustained(int blocks, int iters, const char *name) {
+  float *d; hipMalloc(&d, blocks * 256 * 4);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  double total = 0, last = 0;
+  while (total < 1500) {
+    hipEventRecord(e0);
+    for (int i = 0; i < 200; ++i) k<NACC><<<blocks, 256>>>(d, iters, 0.5f, 0.25f);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    total += ms; last = ms / 200;
+  }
+  double fl = (double)blocks * 4 * iters * NACC * 32 * 32 * 2 * 2;
+  printf("%-24s blocks %5d iters %6d: %8.3f ms/launch sustained  %7.2f TFLOP/s\n", name, blocks, iters, last, fl / last * 1e-9);
+  hipFree(d);
+}
 int main() {
+  run_sustained<8>(256, 50, "8 acc 0.04ms b2b");
+  run_sustained<8>(256, 200, "8 acc 0.15ms b2b");
+  run_sustained<8>(256, 400, "8 acc 0.3ms b2b");
+  run_sustained<8>(256, 800, "8 acc 0.6ms b2b");
+  run_sustained<8>(256, 4000, "8 acc 3ms b2b");
   run<8>(256, 400, "8 acc, 1 blk/CU, 0.3ms");
   run<8>(256, 4000, "8 acc, 1 blk/CU, 3ms");
   run<8>(256, 40000, "8 acc, 1 blk/CU, 30ms");
