@@ -66,7 +66,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
-    ap.add_argument("--no-pipeline", action="store_true", help="do not hand the next stereo pair over early")
+    ap.add_argument("--no-pipeline", action="store_true", help="do not hand the next stereo pairs over early")
+    ap.add_argument("--depth", type=int, default=2, choices=[1, 2], help="stereo pairs handed over ahead of the one being solved")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -107,9 +108,11 @@ def main():
 
     def step(i):
         dl, dr = d_frames[order[i % len(order)]]
-        nl, nr = d_frames[order[(i + 1) % len(order)]]
-        nxt = None if args.no_pipeline else (nl.data_ptr(), nr.data_ptr())   # the next pair is already in HBM
-        res = fe.step_device(dl.data_ptr(), dr.data_ptr(), rows, cols, dl.stride(0), P_l, P_r, nxt)
+        ahead = [None, None]                                                # the next pairs are already in HBM
+        for d in range(0 if args.no_pipeline else args.depth):
+            nl, nr = d_frames[order[(i + 1 + d) % len(order)]]
+            ahead[d] = (nl.data_ptr(), nr.data_ptr())
+        res = fe.step_device(dl.data_ptr(), dr.data_ptr(), rows, cols, dl.stride(0), P_l, P_r, ahead[0], ahead[1])
         if world > 1:                                                       # RCCL all-gather, 56 B per rank
             pg.gather(*(res if res is not None else (None, None)))
         return res

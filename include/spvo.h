@@ -112,8 +112,9 @@ typedef struct {
 /* addStereoImagePair (nn.cpp:449-498), everything but the deque bookkeeping:
  * preprocess both images, run the network, post-process.  P_l/P_r are updated
  * in place (nn.cpp:465-466 clones then mutates).  The device copies of the
- * keypoints/descriptors are kept in feature slots `slot_l`/`slot_r` (0..3, the
- * caller's ring of prevL, prevR, currL, currR; hpp:66-72) for spvo_match_slots.
+ * keypoints/descriptors are kept in feature slots `slot_l`/`slot_r` (0..7: the
+ * caller's ring of prevL, prevR, currL, currR of hpp:66-72, plus the slots of up to
+ * two pairs submitted ahead) for spvo_match_slots.
  * `resized_l`/`resized_r` (net_height*net_width u8, what nn.cpp:154 pushes to
  * images_dq) may be NULL. */
 int spvo_detect(spvo_ctx *ctx, const uint8_t *img_l, const uint8_t *img_r, int rows, int cols,
@@ -127,13 +128,17 @@ int spvo_detect_dev(spvo_ctx *ctx, const void *d_img_l, const void *d_img_r, int
                     size_t stride, double P_l[12], double P_r[12], int slot_l, int slot_r,
                     spvo_features *out_l, spvo_features *out_r);
 
-/* Asynchronous form of spvo_detect_dev (at most one submission in flight): _submit returns as
- * soon as the whole detector chain (and, with spvo_set_prematch, the two standard matches) is
- * enqueued; _wait blocks until it has finished and hands out what spvo_detect_dev would have.
- * Between the two the caller may run spvo_match_slots on precomputed matches and
- * spvo_solve_stereo_odometry for the PREVIOUS pair: the ROS node receives the next image pair
- * while it is still solving the current one.  The slots named here are rewritten while the
- * submission is in flight. */
+/* Asynchronous form of spvo_detect_dev: _submit returns as soon as the whole detector chain (and,
+ * with spvo_set_prematch, the two standard matches) is enqueued; _wait blocks until the OLDEST
+ * submission has finished and hands out what spvo_detect_dev would have.  At most two submissions
+ * may be in flight: the post-processing of one then overlaps with the network of the next.
+ * Meanwhile the caller may run spvo_match_slots on precomputed matches and
+ * spvo_solve_stereo_odometry for pairs already waited for: the ROS node receives the next image
+ * pairs while it is still solving the current one.  The slots named here are rewritten while the
+ * submission is in flight and must differ from those of other submissions in flight; the temporal
+ * partner of a submission is the left slot of the submission before it.  All other entry points
+ * that touch the detector's buffers (spvo_detect, spvo_forward, spvo_nms, ...) return
+ * SPVO_ERR_STATE while a submission is in flight. */
 int spvo_detect_dev_submit(spvo_ctx *ctx, const void *d_img_l, const void *d_img_r, int rows, int cols,
                            size_t stride, int slot_l, int slot_r);
 int spvo_detect_wait(spvo_ctx *ctx, double P_l[12], double P_r[12], spvo_features *out_l,

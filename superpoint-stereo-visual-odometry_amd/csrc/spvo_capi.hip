@@ -12,6 +12,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <deque>
 
 #include "../../include/spvo.h"
 #include "conv_mfma.hip.h"
@@ -25,10 +26,15 @@ namespace {
 
 thread_local std::string g_error;  // for calls without a context
 
+constexpr int RING = 4;          // buffer sets a detector submission owns (network outputs, heat map, NMS state, counters, host mirrors)
+constexpr int MAX_INFLIGHT = 2;  // detector submissions that may be queued at once
+constexpr int N_SLOTS = 8;       // feature slots: 4 stereo pairs (previous, current and two in flight)
+
 struct Tensor {
   int ch = 0, level = 0, H = 0, W = 0, hp = 0, wp = 0;
   bool nhwc = false;  // dense [B][H][W][C] (descriptor map) instead of padded planes
   float *d = nullptr;
+  float *dr[RING] = {nullptr, nullptr, nullptr, nullptr};  // network outputs only: one buffer per submission set (d == dr[0])
   size_t per_image = 0;  // floats
 };
 
@@ -55,6 +61,7 @@ struct Pending { int stage; hipEvent_t e0, e1; };
 
 struct FeatureSlot {
   int n = 0;
+  bool filled = false;      // a submission has written (or is writing) this slot
   int *d_xy = nullptr;      // [cap][2] int
   float *d_xyf = nullptr;   // [cap][2] float
   float *d_desc = nullptr;  // [cap][256]
@@ -88,19 +95,24 @@ struct NmsImage {
 struct CropGeomS { int row_off = 0, col_off = 0, crop_rows = 0, crop_cols = 0; float scale = 1.f; };
 
 struct PendingDetect {           // one spvo_detect*_submit in flight
-  bool active = false;
   CropGeomS g;
-  int rows = 0, cols = 0, slot_l = 0, slot_r = 0, prev_l = -1, parity = 0;
+  int rows = 0, cols = 0, slot_l = 0, slot_r = 0, prev_l = -1, ring = 0;
+  bool rematch = false;          // the temporal partner's keypoints were redone after this submission matched against them
 };
+
 
 struct spvo_ctx {
   spvo_config cfg;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // fused solve: overlaps with a detector submission in flight
+  hipStream_t stream_t = nullptr;  // detector tail (heat map, NMS, sampling, matching): overlaps with the NEXT submission's network
+  hipStream_t post = nullptr;      // where post-processing is enqueued right now: `stream`, or `stream_t` for a submission
   hipStream_t stream3 = nullptr;   // second image of the pair through the small layers
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int split_level = 99;   // measured: no gain from per-image streams on MI355X (kernels of two streams do not backfill); off
-  PendingDetect pend;
+  std::deque<PendingDetect> pendq;
+  int cur_ring = 0;                // set whose network outputs the running forward pass writes
+  unsigned submit_count = 0;
   std::string error;
   bool weights = false;
   int H = 0, W = 0, Hc = 0, Wc = 0, B = 0;
@@ -124,23 +136,28 @@ struct spvo_ctx {
   uint8_t *d_resized = nullptr;  // [2][H][W]
   int *d_tab = nullptr;          // resize tables: xi,xa0,xa1 [W] ; yi,yb0,yb1 [H]
   int tab_rows = -1, tab_cols = -1;
-  FeatureSlot slots[4];
+  FeatureSlot slots[N_SLOTS];
   int *d_xy_tmp = nullptr;       // [cap][2] for spvo_sample_descriptors
   float *d_desc_tmp = nullptr;   // [cap][256]
   float *h_xy = nullptr;         // pinned [2][cap][2]
-  int last_slot_l = -1;          // left slot of the previous spvo_detect* call (temporal partner)
+  int last_slot_l = -1;          // left slot of the previous submission (temporal partner)
 
   // matching scratch
   int match_cap = 0;
   float *d_ma = nullptr, *d_mb = nullptr;
   MatchScratch ms[2];
   int2 *d_match_out = nullptr;   // [2][cap]: both jobs' results leave in one copy
-  int2 *h_match_out[2] = {nullptr, nullptr};   // pinned [2][cap] per submission parity
+  int2 *h_match_out[RING] = {nullptr, nullptr, nullptr, nullptr};   // pinned [2][cap] per submission set
   int2 *h_match_tmp = nullptr;   // pinned [cap] for the synchronous entry points
-  int *d_counters_all = nullptr; // [2 parities + 1 stand-alone set][2 images][NMS_COUNTER_INTS]
-  float *d_xy_stage = nullptr;   // [2][cap][2] keypoints of both images as floats: one copy
-  MatchCache mcache[2][2];       // [submission parity][stereo, temporal]
-  int det_parity = 0;
+  int *d_counters_all = nullptr; // [RING sets + 1 stand-alone set][2 images][NMS_COUNTER_INTS]
+  float *d_xy_stage = nullptr;   // [RING][2][cap][2] keypoints of both images as floats: one copy per submission
+  MatchCache mcache[RING][2];    // [submission set][stereo, temporal]
+  // per submission set (index 0 doubles as the stand-alone entry points' set)
+  NmsImage nms_r[RING][2];
+  float *d_heat_r[RING] = {nullptr, nullptr, nullptr, nullptr}, *d_heat_base_r[RING] = {nullptr, nullptr, nullptr, nullptr};
+  int *h_counters_r[RING] = {nullptr, nullptr, nullptr, nullptr};
+  float *h_xy_r[RING] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_net[RING] = {nullptr, nullptr, nullptr, nullptr}, ev_tail[RING] = {nullptr, nullptr, nullptr, nullptr};
   bool prematch = false;
   int pm_selector = SPVO_SELECT_KNN, pm_cross = 0;
   float pm_ratio = 0.8f;
@@ -237,7 +254,7 @@ struct ScopedStage {
   ScopedStage(spvo_ctx *ctx, int stage, double flops = 0, double bytes = 0, hipStream_t stream = nullptr) : c(ctx) {
     if (!c->prof || stage < 0) return;
     id = stage;
-    st = stream ? stream : c->stream;
+    st = stream ? stream : (c->post ? c->post : c->stream);
     if (flops > 0) c->stages[id].flops = flops;
     if (bytes > 0) c->stages[id].bytes = bytes;
     e0 = get_event(c);
@@ -318,8 +335,8 @@ void choose_tile(int H, int W, int co_tiles, int batch, bool pool, int *wr, int 
 int launch_conv(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream) {
   const Tensor &ti = c->tensors[op.in];
   const Tensor &to = c->tensors[op.out];
-  const float *tin = ti.d + (size_t)img0 * ti.per_image;
-  float *tout = to.d + (size_t)img0 * to.per_image;
+  const float *tin = (ti.dr[c->cur_ring] ? ti.dr[c->cur_ring] : ti.d) + (size_t)img0 * ti.per_image;
+  float *tout = (to.dr[c->cur_ring] ? to.dr[c->cur_ring] : to.d) + (size_t)img0 * to.per_image;
   const bool relu = op.flags & FLAG_RELU, pool = op.flags & FLAG_POOL;
   const int epi = (op.flags & FLAG_BN) ? 1 : (op.flags & FLAG_ADD) ? 2 : 0;
   if (op.type == OP_DWCONV) {
@@ -384,8 +401,8 @@ int launch_op(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream
     ScopedStage st(c, op.stage, op.flops_per_image * batch, 0, stream);
     return launch_conv(c, op, img0, batch, stream);
   }
-  const float *tin = ti.d + (size_t)img0 * ti.per_image;
-  float *tout = to.d + (size_t)img0 * to.per_image;
+  const float *tin = (ti.dr[c->cur_ring] ? ti.dr[c->cur_ring] : ti.d) + (size_t)img0 * ti.per_image;
+  float *tout = (to.dr[c->cur_ring] ? to.dr[c->cur_ring] : to.d) + (size_t)img0 * to.per_image;
   ScopedStage st(c, op.stage, 0, 0, stream);
   if (op.type == OP_MAXPOOL) {
     dim3 grid((to.W + 63) / 64, (to.H + 3) / 4, batch * to.ch);
@@ -521,31 +538,35 @@ int launch_preprocess(spvo_ctx *c, const uint8_t *d_src, int rows, int cols, siz
 constexpr int NMS_INNER = 4;
 constexpr int NMS_GRID = 128;
 
-// NMS counter blocks are double-buffered by submission parity: the last NMS kernel of one
+// NMS counter blocks rotate through RING sets with the submissions: the last NMS kernel of one
 // submission zeroes the block of the next one, so the steady state needs no memset.
-NmsPair nms_pair(spvo_ctx *c, int parity) {
+// `set` < RING: a detector submission's buffers and counters; set == RING: the stand-alone entry
+// points (buffers of set 0, counters of their own so that the submissions' blocks stay zeroed).
+NmsPair nms_pair(spvo_ctx *c, int set) {
   NmsPair p;
   for (int i = 0; i < 2; ++i) {
-    p.b[i] = c->nms[i].b;
-    p.b[i].counters = c->d_counters_all + (size_t)(parity * 2 + i) * NMS_COUNTER_INTS;
+    p.b[i] = c->nms_r[set % RING][i].b;
+    p.b[i].counters = c->d_counters_all + (size_t)(set * 2 + i) * NMS_COUNTER_INTS;
   }
   return p;
 }
 
 // `n_launch` round launches + collect + rank + write for `nimg` images, then the counters travel
 // to the host in one copy.  Launch 0 of a batch never exits early.
-int launch_nms_rounds(spvo_ctx *c, int nimg, const NmsPair &np, int n_launch, int *zero_next) {
+int launch_nms_rounds(spvo_ctx *c, int nimg, const NmsPair &np, int set, int n_launch, int *zero_next) {
+  hipStream_t st = c->post;
+  const float *heat = c->d_heat_r[set % RING];
   for (int l = 0; l < n_launch; ++l) {
     if (c->cfg.dist_thresh == 4)
-      hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 4>), dim3(NMS_GRID, nimg), dim3(256), 0, c->stream, c->d_heat, c->H, c->W, 4, np, l);
+      hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 4>), dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, 4, np, l);
     else
-      hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 0>), dim3(NMS_GRID, nimg), dim3(256), 0, c->stream, c->d_heat, c->H, c->W, c->cfg.dist_thresh, np, l);
+      hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 0>), dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, c->cfg.dist_thresh, np, l);
   }
-  hipLaunchKernelGGL(nms_collect_kernel, dim3(NMS_GRID, nimg), dim3(256), 0, c->stream, c->d_heat, c->H, c->W, c->cfg.border_remove, c->surv_cap, np);
-  hipLaunchKernelGGL(nms_rank_kernel, dim3((c->surv_cap + 255) / 256, (c->surv_cap + RANK_TILE - 1) / RANK_TILE, nimg), dim3(256), 0, c->stream, c->surv_cap, np);
-  hipLaunchKernelGGL(nms_write_kernel, dim3((c->surv_cap + 255) / 256, nimg), dim3(256), 0, c->stream, c->H, c->cfg.max_keypoints, c->surv_cap, np, zero_next);
+  hipLaunchKernelGGL(nms_collect_kernel, dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, c->cfg.border_remove, c->surv_cap, np);
+  hipLaunchKernelGGL(nms_rank_kernel, dim3((c->surv_cap + 255) / 256, (c->surv_cap + RANK_TILE - 1) / RANK_TILE, nimg), dim3(256), 0, st, c->surv_cap, np);
+  hipLaunchKernelGGL(nms_write_kernel, dim3((c->surv_cap + 255) / 256, nimg), dim3(256), 0, st, c->H, c->cfg.max_keypoints, c->surv_cap, np, zero_next);
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemcpyAsync(c->h_counters, np.b[0].counters, (size_t)nimg * NMS_COUNTER_INTS * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_counters_r[set % RING], np.b[0].counters, (size_t)nimg * NMS_COUNTER_INTS * sizeof(int), hipMemcpyDeviceToHost, st));
   return SPVO_OK;
 }
 
@@ -557,37 +578,38 @@ int launch_nms_rounds(spvo_ctx *c, int nimg, const NmsPair &np, int n_launch, in
 constexpr int NMS_FIRST = 3;
 
 // more rounds for the (rare) submissions whose first batch left candidates undecided
-int nms_settle(spvo_ctx *c, int nimg, const NmsPair &np, bool *redone) {
+int nms_settle(spvo_ctx *c, int nimg, const NmsPair &np, int set, bool *redone) {
   int last = NMS_FIRST;
   *redone = false;
+  const int *hc = c->h_counters_r[set % RING];
   for (;;) {
     bool pending = false;
-    for (int i = 0; i < nimg; ++i) pending |= c->h_counters[i * NMS_COUNTER_INTS + 8 + last - 1] != 0;
+    for (int i = 0; i < nimg; ++i) pending |= hc[i * NMS_COUNTER_INTS + 8 + last - 1] != 0;
     if (!pending) break;
     *redone = true;
     last = NMS_MAX_LAUNCH;
     for (int i = 0; i < nimg; ++i)   // keep n_cand, clear the rest of the block
-      HIP_TRY(c, hipMemsetAsync(np.b[i].counters + 1, 0, (NMS_COUNTER_INTS - 1) * sizeof(int), c->stream));
-    int rc = launch_nms_rounds(c, nimg, np, last, nullptr);
+      HIP_TRY(c, hipMemsetAsync(np.b[i].counters + 1, 0, (NMS_COUNTER_INTS - 1) * sizeof(int), c->post));
+    int rc = launch_nms_rounds(c, nimg, np, set, last, nullptr);
     if (rc) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->post));
   }
   for (int i = 0; i < nimg; ++i)
-    if (c->h_counters[i * NMS_COUNTER_INTS + 3]) return fail(c, SPVO_ERR_CAPACITY, "NMS survivor buffer overflow");
+    if (hc[i * NMS_COUNTER_INTS + 3]) return fail(c, SPVO_ERR_CAPACITY, "NMS survivor buffer overflow");
   return SPVO_OK;
 }
 
 // stand-alone entry (heat map already in d_heat): threshold + rounds, synchronous
 int run_nms(spvo_ctx *c, int nimg) {
-  const NmsPair np = nms_pair(c, 2);   // its own counter set: the detector's two stay clean
+  const NmsPair np = nms_pair(c, RING);   // its own counter set: the submissions' blocks stay clean
   for (int i = 0; i < nimg; ++i) HIP_TRY(c, hipMemsetAsync(np.b[i].counters, 0, NMS_COUNTER_INTS * sizeof(int), c->stream));
   dim3 grid((c->W + 63) / 64, (c->H + 3) / 4, nimg);
   hipLaunchKernelGGL(nms_threshold_kernel, grid, dim3(256), 0, c->stream, c->d_heat, c->H, c->W, c->cfg.conf_thresh, np);
-  int rc = launch_nms_rounds(c, nimg, np, NMS_FIRST, nullptr);
+  int rc = launch_nms_rounds(c, nimg, np, RING, NMS_FIRST, nullptr);
   if (rc) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   bool redone;
-  return nms_settle(c, nimg, np, &redone);
+  return nms_settle(c, nimg, np, RING, &redone);
 }
 
 int ensure_match(spvo_ctx *c, int na, int nb) {
@@ -600,8 +622,8 @@ int ensure_match(spvo_ctx *c, int na, int nb) {
   for (auto &m : c->ms)
     for (void *p : {(void *)m.d_na, (void *)m.d_nb, (void *)m.d_best_d2, (void *)m.d_short, (void *)m.d_best_idx, (void *)m.d_train_best})
       if (p) (void)hipFree(p);
-  for (void *p : {(void *)c->h_match_out[0], (void *)c->h_match_out[1], (void *)c->h_match_tmp})
-    if (p) (void)hipHostFree(p);
+  for (auto &p : c->h_match_out) { if (p) (void)hipHostFree(p); p = nullptr; }
+  if (c->h_match_tmp) (void)hipHostFree(c->h_match_tmp);
   const int groups = (cap + MATCH_TT - 1) / MATCH_TT;
   int rc;
   if ((rc = dev_alloc(c, &c->d_ma, (size_t)cap * MATCH_D))) return rc;
@@ -616,10 +638,10 @@ int ensure_match(spvo_ctx *c, int na, int nb) {
     if ((rc = dev_alloc(c, &m.d_best_idx, (size_t)cap * 2))) return rc;
     if ((rc = dev_alloc(c, &m.d_train_best, cap))) return rc;
     m.d_out = c->d_match_out + (size_t)k * cap;
-    HIP_TRY(c, hipHostMalloc((void **)&c->h_match_out[k], (size_t)2 * cap * sizeof(int2)));
   }
+  for (int r = 0; r < RING; ++r) HIP_TRY(c, hipHostMalloc((void **)&c->h_match_out[r], (size_t)2 * cap * sizeof(int2)));
   HIP_TRY(c, hipHostMalloc((void **)&c->h_match_tmp, (size_t)cap * sizeof(int2)));
-  for (int par = 0; par < 2; ++par)
+  for (int par = 0; par < RING; ++par)
     for (int k = 0; k < 2; ++k) {
       c->mcache[par][k].h_out = c->h_match_out[par] + (size_t)k * cap;
       c->mcache[par][k].valid = false;
@@ -652,10 +674,10 @@ int enqueue_matches(spvo_ctx *c, const MatchReq *req, int njobs, int selector, i
     j.shortlist = m.d_short; j.best_d2 = m.d_best_d2; j.best_idx = m.d_best_idx; j.train_best = m.d_train_best; j.out = m.d_out;
     na_max = std::max(na_max, req[k].na);
     nb_max = std::max(nb_max, req[k].nb);
-    if (!req[k].sqA) hipLaunchKernelGGL(row_sqnorm_kernel, dim3((req[k].na + 3) / 4), dim3(256), 0, c->stream, req[k].dA, req[k].na, req[k].na_ptr, m.d_na);
-    if (!req[k].sqB) hipLaunchKernelGGL(row_sqnorm_kernel, dim3((req[k].nb + 3) / 4), dim3(256), 0, c->stream, req[k].dB, req[k].nb, req[k].nb_ptr, m.d_nb);
+    if (!req[k].sqA) hipLaunchKernelGGL(row_sqnorm_kernel, dim3((req[k].na + 3) / 4), dim3(256), 0, c->post, req[k].dA, req[k].na, req[k].na_ptr, m.d_na);
+    if (!req[k].sqB) hipLaunchKernelGGL(row_sqnorm_kernel, dim3((req[k].nb + 3) / 4), dim3(256), 0, c->post, req[k].dB, req[k].nb, req[k].nb_ptr, m.d_nb);
     if (selector == SPVO_SELECT_NN && cross_check)
-      HIP_TRY(c, hipMemsetAsync(m.d_train_best, 0xFF, (size_t)req[k].nb * sizeof(unsigned long long), c->stream));
+      HIP_TRY(c, hipMemsetAsync(m.d_train_best, 0xFF, (size_t)req[k].nb * sizeof(unsigned long long), c->post));
   }
   if (njobs == 1) jobs.j[1] = jobs.j[0];
   const int groups = (nb_max + MATCH_TT - 1) / MATCH_TT;
@@ -669,15 +691,15 @@ int enqueue_matches(spvo_ctx *c, const MatchReq *req, int njobs, int selector, i
   }
   {
     ScopedStage sg(c, stage_id(c, "match_gemm"), fl, 4.0 * (na_max + nb_max) * MATCH_D * njobs);
-    hipLaunchKernelGGL(match_gemm_kernel, dim3(groups, (na_max + MATCH_QT - 1) / MATCH_QT, njobs), dim3(256), lds, c->stream, jobs, groups);
+    hipLaunchKernelGGL(match_gemm_kernel, dim3(groups, (na_max + MATCH_QT - 1) / MATCH_QT, njobs), dim3(256), lds, c->post, jobs, groups);
   }
-  hipLaunchKernelGGL(match_rerank_kernel, dim3((na_max + 3) / 4, njobs), dim3(256), 0, c->stream, jobs, groups, selector, cross_check, ratio);
+  hipLaunchKernelGGL(match_rerank_kernel, dim3((na_max + 3) / 4, njobs), dim3(256), 0, c->post, jobs, groups, selector, cross_check, ratio);
   if (selector == SPVO_SELECT_NN && cross_check)
-    hipLaunchKernelGGL(match_select_cross_kernel, dim3((na_max + 255) / 256, njobs), dim3(256), 0, c->stream, jobs);
+    hipLaunchKernelGGL(match_select_cross_kernel, dim3((na_max + 255) / 256, njobs), dim3(256), 0, c->post, jobs);
   HIP_TRY(c, hipGetLastError());
   // jobs' outputs are adjacent in d_match_out (stride match_cap): one copy
   const size_t count = (njobs == 2) ? (size_t)c->match_cap + req[1].na : (size_t)req[0].na;
-  HIP_TRY(c, hipMemcpyAsync(host_out, c->d_match_out, count * sizeof(int2), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(host_out, c->d_match_out, count * sizeof(int2), hipMemcpyDeviceToHost, c->post));
   return SPVO_OK;
 }
 
@@ -696,7 +718,7 @@ int run_match(spvo_ctx *c, const MatchReq &r, int selector, int cross_check, flo
   }
   int rc = enqueue_matches(c, &r, 1, selector, cross_check, ratio, c->h_match_tmp);
   if (rc) return rc;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->post));
   unpack_match(c->h_match_tmp, r.na, train_idx, distance);
   return SPVO_OK;
 }
@@ -733,6 +755,23 @@ int ensure_odometry(spvo_ctx *c, int n, int iterations, int n_obs) {
     c->obs_cap = cap;
   }
   return SPVO_OK;
+}
+
+// post-processing issued by a synchronous entry point while submissions are queued goes behind them
+struct PostScope {
+  spvo_ctx *c;
+  explicit PostScope(spvo_ctx *ctx) : c(ctx) { c->post = c->pendq.empty() ? c->stream : c->stream_t; }
+  ~PostScope() { c->post = c->stream; }
+};
+
+void free_plan(spvo_ctx *c) {
+  for (auto &t : c->tensors) {
+    if (t.d) (void)hipFree(t.d);
+    for (int r = 1; r < RING; ++r) if (t.dr[r]) (void)hipFree(t.dr[r]);
+  }
+  for (auto &o : c->ops)
+    for (float *p : {o.d_w, o.d_b, o.d_bn_scale, o.d_bn_shift}) if (p) (void)hipFree(p);
+  c->tensors.clear(); c->ops.clear(); c->weights = false;
 }
 
 }  // namespace
@@ -778,11 +817,18 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
   if (const char *e = std::getenv("SPVO_SPLIT_LEVEL")) c->split_level = std::atoi(e);
   c->H = cfg->net_height; c->W = cfg->net_width; c->Hc = c->H / 8; c->Wc = c->W / 8; c->B = 2;
   if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess ||
-      hipStreamCreate(&c->stream3) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipStreamCreate(&c->stream3) != hipSuccess || hipStreamCreate(&c->stream_t) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
     delete c;
     return fail(nullptr, SPVO_ERR_DEVICE, "cannot create a stream on device %d", cfg->device);
   }
+  c->post = c->stream;
+  for (int r = 0; r < RING; ++r)
+    if (hipEventCreateWithFlags(&c->ev_net[r], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_tail[r], hipEventDisableTiming) != hipSuccess ) {
+      spvo_destroy(c);
+      return fail(nullptr, SPVO_ERR_DEVICE, "cannot create events on device %d", cfg->device);
+    }
   int rc = SPVO_OK;
   const size_t hw = (size_t)c->H * c->W;
   const int cap = cfg->max_keypoints;
@@ -792,23 +838,30 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
   do {
     if ((rc = dev_alloc(c, &c->d_dense_in, 2 * hw))) break;
     if ((rc = dev_alloc(c, &c->d_det_dense, (size_t)2 * 65 * c->Hc * c->Wc))) break;
-    if ((rc = dev_alloc(c, &c->d_counters_all, (size_t)6 * NMS_COUNTER_INTS))) break;   // parity 0, parity 1, stand-alone
-    if ((rc = dev_alloc(c, &c->d_xy_stage, (size_t)2 * cfg->max_keypoints * 2))) break;
-    if ((rc = dev_alloc(c, &c->d_heat_base, 2 * hw + 128))) break;
-    c->d_heat = c->d_heat_base + 64;   // K10 reads aligned float4 rows that may start left of column 0
-    if ((rc = dev_alloc(c, &c->d_resized, 2 * hw))) break;
-    if ((rc = dev_alloc(c, &c->d_tab, (size_t)3 * (c->H + c->W)))) break;
-    for (int i = 0; i < 2 && !rc; ++i) {
-      NmsBuffers &b = c->nms[i].b;
-      if ((rc = dev_alloc(c, &b.state, (size_t)(c->H + 2 * NMS_PAD) * nms_state_pitch(c->W)))) break;
-      if ((rc = dev_alloc(c, &b.cand, hw))) break;
-      b.counters = nullptr;   // set per submission parity (nms_pair)
-      if ((rc = dev_alloc(c, &b.surv_key, c->surv_cap))) break;
-      if ((rc = dev_alloc(c, &b.rank, c->surv_cap))) break;
-      if ((rc = dev_alloc(c, &b.out_xy, (size_t)cap * 2))) break;
+    if ((rc = dev_alloc(c, &c->d_counters_all, (size_t)(RING + 1) * 2 * NMS_COUNTER_INTS))) break;   // RING submission sets, stand-alone
+    if ((rc = dev_alloc(c, &c->d_xy_stage, (size_t)RING * 2 * cfg->max_keypoints * 2))) break;
+    for (int r = 0; r < RING && !rc; ++r) {
+      if ((rc = dev_alloc(c, &c->d_heat_base_r[r], 2 * hw + 128))) break;
+      c->d_heat_r[r] = c->d_heat_base_r[r] + 64;   // K10 reads aligned float4 rows that may start left of column 0
     }
     if (rc) break;
-    for (int i = 0; i < 4 && !rc; ++i) {
+    c->d_heat_base = c->d_heat_base_r[0];
+    c->d_heat = c->d_heat_r[0];
+    if ((rc = dev_alloc(c, &c->d_resized, 2 * hw))) break;
+    if ((rc = dev_alloc(c, &c->d_tab, (size_t)3 * (c->H + c->W)))) break;
+    for (int r = 0; r < RING && !rc; ++r)
+      for (int i = 0; i < 2 && !rc; ++i) {
+        NmsBuffers &b = c->nms_r[r][i].b;
+        if ((rc = dev_alloc(c, &b.state, (size_t)(c->H + 2 * NMS_PAD) * nms_state_pitch(c->W)))) break;
+        if ((rc = dev_alloc(c, &b.cand, hw))) break;
+        b.counters = nullptr;   // set per submission (nms_pair)
+        if ((rc = dev_alloc(c, &b.surv_key, c->surv_cap))) break;
+        if ((rc = dev_alloc(c, &b.rank, c->surv_cap))) break;
+        if ((rc = dev_alloc(c, &b.out_xy, (size_t)cap * 2))) break;
+      }
+    if (rc) break;
+    for (int i = 0; i < 2; ++i) c->nms[i] = c->nms_r[0][i];   // the stand-alone entry points work in set 0
+    for (int i = 0; i < N_SLOTS && !rc; ++i) {
       if ((rc = dev_alloc(c, &c->slots[i].d_xy, (size_t)cap * 2))) break;
       if ((rc = dev_alloc(c, &c->slots[i].d_xyf, (size_t)cap * 2))) break;
       if ((rc = dev_alloc(c, &c->slots[i].d_desc, (size_t)cap * 256))) break;
@@ -818,9 +871,12 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
     if (rc) break;
     if ((rc = dev_alloc(c, &c->d_xy_tmp, (size_t)cap * 2))) break;
     if ((rc = dev_alloc(c, &c->d_desc_tmp, (size_t)cap * 256))) break;
-    if (hipHostMalloc((void **)&c->h_counters, 2 * NMS_COUNTER_INTS * sizeof(int)) != hipSuccess ||
-        hipHostMalloc((void **)&c->h_xy, (size_t)2 * cap * 2 * sizeof(float)) != hipSuccess) { rc = fail(c, SPVO_ERR_DEVICE, "hipHostMalloc failed"); break; }
+    for (int r = 0; r < RING && !rc; ++r)
+      if (hipHostMalloc((void **)&c->h_counters_r[r], 2 * NMS_COUNTER_INTS * sizeof(int)) != hipSuccess ||
+          hipHostMalloc((void **)&c->h_xy_r[r], (size_t)2 * cap * 2 * sizeof(float)) != hipSuccess) rc = fail(c, SPVO_ERR_DEVICE, "hipHostMalloc failed");
     if (rc) break;
+    c->h_counters = c->h_counters_r[0];
+    c->h_xy = c->h_xy_r[0];
     if ((rc = ensure_match(c, cap, cap))) break;
   } while (0);
   if (rc) {
@@ -839,31 +895,36 @@ void spvo_destroy(spvo_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   if (c->stream3) (void)hipStreamSynchronize(c->stream3);
+  if (c->stream_t) (void)hipStreamSynchronize(c->stream_t);
   resolve_pending(c);
   for (auto e : c->free_events) (void)hipEventDestroy(e);
-  for (auto &t : c->tensors) if (t.d) (void)hipFree(t.d);
-  for (auto &o : c->ops)
-    for (float *p : {o.d_w, o.d_b, o.d_bn_scale, o.d_bn_shift}) if (p) (void)hipFree(p);
-  void *ptrs[] = {c->d_dense_in, c->d_det_dense, c->d_heat_base, c->d_resized, c->d_tab, c->d_img[0], c->d_img[1], c->d_xy_tmp, c->d_desc_tmp,
+  free_plan(c);
+  void *ptrs[] = {c->d_dense_in, c->d_det_dense, c->d_resized, c->d_tab, c->d_img[0], c->d_img[1], c->d_xy_tmp, c->d_desc_tmp,
                   c->d_ma, c->d_mb, c->d_match_out, c->d_counters_all, c->d_xy_stage,
                   c->ms[0].d_na, c->ms[0].d_nb, c->ms[0].d_best_d2, c->ms[0].d_short, c->ms[0].d_best_idx, c->ms[0].d_train_best,
                   c->ms[1].d_na, c->ms[1].d_nb, c->ms[1].d_best_d2, c->ms[1].d_short, c->ms[1].d_best_idx, c->ms[1].d_train_best,
                   c->d_P, c->d_pts_a, c->d_pts_b, c->d_xyz, c->rw.counts, c->rw.poses, c->rw.result, c->rw.inliers, c->d_obs, c->d_refine};
   for (void *p : ptrs) if (p) (void)hipFree(p);
-  for (int i = 0; i < 2; ++i) {
-    NmsBuffers &b = c->nms[i].b;
-    void *q[] = {b.state, b.cand, b.surv_key, b.rank, b.out_xy};
-    for (void *p : q) if (p) (void)hipFree(p);
+  for (int r = 0; r < RING; ++r) {
+    for (int i = 0; i < 2; ++i) {
+      NmsBuffers &b = c->nms_r[r][i].b;
+      void *q[] = {b.state, b.cand, b.surv_key, b.rank, b.out_xy};
+      for (void *p : q) if (p) (void)hipFree(p);
+    }
+    if (c->d_heat_base_r[r]) (void)hipFree(c->d_heat_base_r[r]);
+    if (c->h_counters_r[r]) (void)hipHostFree(c->h_counters_r[r]);
+    if (c->h_xy_r[r]) (void)hipHostFree(c->h_xy_r[r]);
+    for (hipEvent_t e : {c->ev_net[r], c->ev_tail[r]}) if (e) (void)hipEventDestroy(e);
   }
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < N_SLOTS; ++i) {
     void *q[] = {c->slots[i].d_xy, c->slots[i].d_xyf, c->slots[i].d_desc, c->slots[i].d_n, c->slots[i].d_sqn};
     for (void *p : q) if (p) (void)hipFree(p);
   }
-  if (c->h_counters) (void)hipHostFree(c->h_counters);
-  if (c->h_xy) (void)hipHostFree(c->h_xy);
   for (void *hp : {(void *)c->h_solve_in, (void *)c->h_solve_res, (void *)c->h_solve_o}) if (hp) (void)hipHostFree(hp);
   for (void *dp : {(void *)c->d_solve_in, (void *)c->d_solve_res, (void *)c->d_solve_o, (void *)c->d_ctl}) if (dp) (void)hipFree(dp);
-  for (void *hp : {(void *)c->h_match_out[0], (void *)c->h_match_out[1], (void *)c->h_match_tmp}) if (hp) (void)hipHostFree(hp);
+  for (auto hp : c->h_match_out) if (hp) (void)hipHostFree(hp);
+  if (c->h_match_tmp) (void)hipHostFree(c->h_match_tmp);
+  if (c->stream_t) (void)hipStreamDestroy(c->stream_t);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
@@ -890,10 +951,8 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
   size_t pos = 40;
   if (buf.size() < pos + (size_t)nt * 8 + (size_t)no * 72 + 8) return fail(c, SPVO_ERR_IO, "%s: truncated", path);
   // drop a previously loaded plan
-  for (auto &t : c->tensors) if (t.d) (void)hipFree(t.d);
-  for (auto &o : c->ops)
-    for (float *p : {o.d_w, o.d_b, o.d_bn_scale, o.d_bn_shift}) if (p) (void)hipFree(p);
-  c->tensors.clear(); c->ops.clear(); c->weights = false;
+  if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "detector submissions are in flight");
+  free_plan(c);
   c->t_input = hdr[2]; c->t_det = hdr[3]; c->t_desc = hdr[4];
   for (uint32_t i = 0; i < nt; ++i) {
     const uint32_t *r = (const uint32_t *)(buf.data() + pos);
@@ -927,10 +986,16 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
     c->ops.push_back(op);
   }
   // allocate activations (padded planes stay zero outside the interior for ever)
-  for (auto &t : c->tensors) {
+  for (size_t ti = 0; ti < c->tensors.size(); ++ti) {
+    Tensor &t = c->tensors[ti];
     t.per_image = t.nhwc ? (size_t)t.H * t.W * t.ch : (size_t)t.ch * t.hp * t.wp;
     int rc = dev_alloc(c, &t.d, t.per_image * c->B);
     if (rc) return rc;
+    if ((int)ti == c->t_det || (int)ti == c->t_desc) {   // what a submission's tail reads while the next network pass already runs
+      t.dr[0] = t.d;
+      for (int r = 1; r < RING; ++r)
+        if ((rc = dev_alloc(c, &t.dr[r], t.per_image * c->B))) return rc;
+    }
   }
   for (uint32_t i = 0; i < no; ++i) {
     Op &op = c->ops[i];
@@ -1036,6 +1101,7 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
 
 int spvo_preprocess(spvo_ctx *c, const uint8_t *img, int rows, int cols, size_t stride, double P[12], uint8_t *resized_u8) {
   if (!c || !img || !P || rows <= 0 || cols <= 0 || stride < (size_t)cols) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "detector submissions are in flight: complete them with spvo_detect_wait first");
   if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
   HIP_TRY(c, hipSetDevice(c->cfg.device));
   const size_t bytes = (size_t)rows * stride;
@@ -1056,6 +1122,7 @@ int spvo_preprocess(spvo_ctx *c, const uint8_t *img, int rows, int cols, size_t 
 
 int spvo_forward(spvo_ctx *c, const float *input, int batch, float *det, float *desc_nhwc) {
   if (!c || !input) return fail(c, SPVO_ERR_INVALID, "null argument");
+  if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "detector submissions are in flight: complete them with spvo_detect_wait first");
   if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
   if (batch < 1 || batch > c->B) return fail(c, SPVO_ERR_INVALID, "batch %d out of range", batch);
   HIP_TRY(c, hipSetDevice(c->cfg.device));
@@ -1081,6 +1148,7 @@ int spvo_forward(spvo_ctx *c, const float *input, int batch, float *det, float *
 
 int spvo_debug_tensor(spvo_ctx *c, int tensor_id, int batch, float *out, size_t out_floats) {
   if (!c || !out) return fail(c, SPVO_ERR_INVALID, "null argument");
+  if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "detector submissions are in flight: complete them with spvo_detect_wait first");
   if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
   if (tensor_id < 0 || tensor_id >= (int)c->tensors.size() || batch < 1 || batch > c->B) return fail(c, SPVO_ERR_INVALID, "bad tensor id / batch");
   const Tensor &t = c->tensors[tensor_id];
@@ -1103,6 +1171,7 @@ int spvo_debug_tensor(spvo_ctx *c, int tensor_id, int batch, float *out, size_t 
 
 int spvo_heatmap(spvo_ctx *c, const float *det, float *heat) {
   if (!c || !det || !heat) return fail(c, SPVO_ERR_INVALID, "null argument");
+  if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "detector submissions are in flight: complete them with spvo_detect_wait first");
   HIP_TRY(c, hipSetDevice(c->cfg.device));
   HIP_TRY(c, hipMemcpyAsync(c->d_det_dense, det, (size_t)65 * c->Hc * c->Wc * sizeof(float), hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(heatmap_kernel<false>, dim3((c->Wc + 63) / 64, (c->Hc + 3) / 4, 1), dim3(256), 0, c->stream, c->d_det_dense, c->d_heat, c->Hc, c->Wc, 0, 0);
@@ -1114,6 +1183,7 @@ int spvo_heatmap(spvo_ctx *c, const float *det, float *heat) {
 
 int spvo_nms(spvo_ctx *c, const float *heat, int32_t *xy, int *n) {
   if (!c || !heat || !xy || !n) return fail(c, SPVO_ERR_INVALID, "null argument");
+  if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "detector submissions are in flight: complete them with spvo_detect_wait first");
   HIP_TRY(c, hipSetDevice(c->cfg.device));
   HIP_TRY(c, hipMemcpyAsync(c->d_heat, heat, (size_t)c->H * c->W * sizeof(float), hipMemcpyHostToDevice, c->stream));
   int rc = run_nms(c, 1);
@@ -1125,6 +1195,7 @@ int spvo_nms(spvo_ctx *c, const float *heat, int32_t *xy, int *n) {
 
 int spvo_sample_descriptors(spvo_ctx *c, const float *desc_nhwc, const int32_t *xy, int n, float *out) {
   if (!c || !desc_nhwc || (n > 0 && (!xy || !out))) return fail(c, SPVO_ERR_INVALID, "null argument");
+  if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "detector submissions are in flight: complete them with spvo_detect_wait first");
   if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
   if (n < 0 || n > c->cfg.max_keypoints) return fail(c, SPVO_ERR_CAPACITY, "n = %d exceeds max_keypoints", n);
   if (n == 0) return SPVO_OK;
@@ -1142,130 +1213,169 @@ int spvo_sample_descriptors(spvo_ctx *c, const float *desc_nhwc, const int32_t *
   return SPVO_OK;
 }
 
-static int enqueue_sample(spvo_ctx *c, const int slots[2], const NmsPair &np) {
+static int enqueue_sample(spvo_ctx *c, const int slots[2], const NmsPair &np, int ring) {
   const Tensor &ts = c->tensors[c->t_desc];
+  const float *desc = ts.dr[ring] ? ts.dr[ring] : ts.d;
   ScopedStage ss(c, stage_id(c, "sample"));
   const int cap = c->cfg.max_keypoints;
+  float *stage = c->d_xy_stage + (size_t)ring * 2 * cap * 2;
   SampleJobs sj;
   for (int i = 0; i < 2; ++i) {
     FeatureSlot &s = c->slots[slots[i]];
     // the keypoint count is read from the NMS counters on the device: no host round trip
-    sj.j[i] = SampleJob{ts.d + (size_t)i * ts.per_image, np.b[i].out_xy, (const int *)(np.b[i].counters + 2), 0, s.d_desc, s.d_sqn,
-                        c->d_xy_stage + (size_t)i * cap * 2, s.d_xy, s.d_n};
+    sj.j[i] = SampleJob{desc + (size_t)i * ts.per_image, np.b[i].out_xy, (const int *)(np.b[i].counters + 2), 0, s.d_desc, s.d_sqn,
+                        stage + (size_t)i * cap * 2, s.d_xy, s.d_n};
   }
-  hipLaunchKernelGGL(sample_desc_kernel, dim3((cap + 3) / 4, 2), dim3(256), 0, c->stream, sj, c->H, c->W, c->Hc, c->Wc);
+  hipLaunchKernelGGL(sample_desc_kernel, dim3((cap + 3) / 4, 2), dim3(256), 0, c->post, sj, c->H, c->W, c->Hc, c->Wc);
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemcpyAsync(c->h_xy, c->d_xy_stage, (size_t)2 * cap * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_xy_r[ring], stage, (size_t)2 * cap * 2 * sizeof(float), hipMemcpyDeviceToHost, c->post));
   return SPVO_OK;
 }
 
-static int enqueue_prematch(spvo_ctx *c, int slot_l, int slot_r, int prev_l, int parity) {
+static int enqueue_prematch(spvo_ctx *c, int slot_l, int slot_r, int prev_l, int ring) {
   const int cap = c->cfg.max_keypoints;
   const int partner[2] = {slot_r, prev_l};
   MatchReq req[2];
   int nj = 0;
   for (int k = 0; k < 2; ++k) {
-    MatchCache &mc = c->mcache[parity][k];
+    MatchCache &mc = c->mcache[ring][k];
     mc.valid = false;
     if (partner[k] < 0) continue;
     FeatureSlot &a = c->slots[slot_l], &b = c->slots[partner[k]];
     req[nj] = MatchReq{a.d_desc, b.d_desc, cap, cap, a.d_n, b.d_n, a.d_sqn, b.d_sqn};
-    MatchCache &dst = c->mcache[parity][nj];   // job nj's result lands in cache entry nj
+    MatchCache &dst = c->mcache[ring][nj];   // job nj's result lands in cache entry nj
     dst.slot_a = slot_l; dst.slot_b = partner[k];
     dst.selector = c->pm_selector; dst.cross = c->pm_cross; dst.ratio = c->pm_ratio;
     dst.valid = true;   // generations are stamped after the slots' counts are known
     ++nj;
   }
   if (nj == 0) return SPVO_OK;
-  return enqueue_matches(c, req, nj, c->pm_selector, c->pm_cross, c->pm_ratio, c->h_match_out[parity]);
+  return enqueue_matches(c, req, nj, c->pm_selector, c->pm_cross, c->pm_ratio, c->h_match_out[ring]);
 }
 
+// Submission = network on `stream`, then the tail (heat map + NMS, sampling, the two matches and
+// their copies to pinned memory) on `stream_t` behind an event.  Up to MAX_INFLIGHT submissions may
+// be queued: the tail of one overlaps with the network of the next, whose kernels leave CUs idle at
+// their ragged ends.  Every buffer a tail touches belongs to the submission's set (RING of them), so
+// a later submission -- or the rare host-driven NMS redo of an earlier one -- never meets it.
 static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, int rows, int cols, size_t stride, int slot_l, int slot_r) {
-  if (c->pend.active) return fail(c, SPVO_ERR_STATE, "a detector submission is already in flight");
-  if (slot_l < 0 || slot_l > 3 || slot_r < 0 || slot_r > 3 || slot_l == slot_r) return fail(c, SPVO_ERR_INVALID, "bad feature slots %d, %d", slot_l, slot_r);
+  if ((int)c->pendq.size() >= MAX_INFLIGHT) return fail(c, SPVO_ERR_STATE, "%d detector submissions are already in flight", MAX_INFLIGHT);
+  if (slot_l < 0 || slot_l >= N_SLOTS || slot_r < 0 || slot_r >= N_SLOTS || slot_l == slot_r) return fail(c, SPVO_ERR_INVALID, "bad feature slots %d, %d", slot_l, slot_r);
+  for (const auto &q : c->pendq)
+    if (q.slot_l == slot_l || q.slot_r == slot_l || q.slot_l == slot_r || q.slot_r == slot_r || q.prev_l == slot_l || q.prev_l == slot_r)
+      return fail(c, SPVO_ERR_STATE, "feature slots %d, %d are used by a submission in flight", slot_l, slot_r);
   if (c->cfg.max_batch != 2) return fail(c, SPVO_ERR_INVALID, "max_batch == 1 detect path is not built yet; use max_batch = 2");
   const CropGeom g = crop_geometry(rows, cols, c->H, c->W);
   const Tensor &td = c->tensors[c->t_det];
   const uint8_t *srcs[2] = {d_l, d_r};
   const int slots[2] = {slot_l, slot_r};
-  // temporal partner = the left slot of the previous call, if it survives this call
+  // temporal partner = the left slot of the previous submission, if it survives this one
   int prev_l = c->last_slot_l;
-  if (prev_l == slot_l || prev_l == slot_r || (prev_l >= 0 && c->slots[prev_l].gen == 0)) prev_l = -1;
-  c->det_parity ^= 1;
-  const int parity = c->det_parity;
-  for (auto &mc : c->mcache[parity]) mc.valid = false;
+  if (prev_l == slot_l || prev_l == slot_r || (prev_l >= 0 && !c->slots[prev_l].filled)) prev_l = -1;
+  const int ring = (int)(c->submit_count++ % RING);
+  for (auto &mc : c->mcache[ring]) mc.valid = false;
   // ---- everything below is enqueued without a host round trip
+  c->cur_ring = ring;
+  c->post = c->stream;
+  hipEvent_t det_e0 = nullptr;
+  if (c->prof) { det_e0 = get_event(c); (void)hipEventRecord(det_e0, c->stream); }
   {
-    ScopedStage st(c, stage_id(c, "detect"));
-    {
-      ScopedStage sp(c, stage_id(c, "preprocess"));
-      for (int i = 0; i < 2; ++i) { int rc = launch_preprocess(c, srcs[i], rows, cols, stride, g, i); if (rc) return rc; }
-    }
-    int rc = run_network(c, 2);
-    if (rc) return rc;
-    const NmsPair np = nms_pair(c, parity);
-    {
-      // heat map + threshold + candidate list in one kernel; the counter block of this parity was
-      // zeroed by the previous submission's last NMS kernel (or at allocation)
-      ScopedStage sh(c, stage_id(c, "heatmap"));
-      hipLaunchKernelGGL(heatmap_nms_kernel, dim3((c->Wc + 63) / 64, (c->Hc + 3) / 4, 2), dim3(256), 0, c->stream, td.d, c->d_heat, c->Hc, c->Wc, td.hp, td.wp,
-                         c->cfg.conf_thresh, np);
-      HIP_TRY(c, hipGetLastError());
-    }
-    {
-      ScopedStage sn(c, stage_id(c, "nms"));
-      if ((rc = launch_nms_rounds(c, 2, np, NMS_FIRST, c->d_counters_all + (size_t)((parity ^ 1) * 2) * NMS_COUNTER_INTS))) return rc;
-    }
-    if ((rc = enqueue_sample(c, slots, np))) return rc;
+    ScopedStage sp(c, stage_id(c, "preprocess"));
+    for (int i = 0; i < 2; ++i) { int rc = launch_preprocess(c, srcs[i], rows, cols, stride, g, i); if (rc) return rc; }
   }
-  if (c->prematch) { int rc = enqueue_prematch(c, slot_l, slot_r, prev_l, parity); if (rc) return rc; }
-  c->pend.active = true;
-  c->pend.g = CropGeomS{g.row_off, g.col_off, g.crop_rows, g.crop_cols, g.scale};
-  c->pend.rows = rows; c->pend.cols = cols;
-  c->pend.slot_l = slot_l; c->pend.slot_r = slot_r; c->pend.prev_l = prev_l; c->pend.parity = parity;
+  int rc = run_network(c, 2);
+  c->cur_ring = 0;
+  if (rc) return rc;
+  HIP_TRY(c, hipEventRecord(c->ev_net[ring], c->stream));
+  HIP_TRY(c, hipStreamWaitEvent(c->stream_t, c->ev_net[ring], 0));
+  c->post = c->stream_t;
+  const NmsPair np = nms_pair(c, ring);
+  {
+    // heat map + threshold + candidate list in one kernel; the counter block of this set was
+    // zeroed by the previous submission's last NMS kernel (or at allocation)
+    ScopedStage sh(c, stage_id(c, "heatmap"));
+    hipLaunchKernelGGL(heatmap_nms_kernel, dim3((c->Wc + 63) / 64, (c->Hc + 3) / 4, 2), dim3(256), 0, c->post, td.dr[ring], c->d_heat_r[ring], c->Hc, c->Wc, td.hp, td.wp,
+                       c->cfg.conf_thresh, np);
+    HIP_TRY(c, hipGetLastError());
+  }
+  {
+    ScopedStage sn(c, stage_id(c, "nms"));
+    rc = launch_nms_rounds(c, 2, np, ring, NMS_FIRST, c->d_counters_all + (size_t)(((ring + 1) % RING) * 2) * NMS_COUNTER_INTS);
+  }
+  if (!rc) rc = enqueue_sample(c, slots, np, ring);
+  if (!rc && c->prematch) rc = enqueue_prematch(c, slot_l, slot_r, prev_l, ring);
+  if (!rc && c->prof) {   // "detect" spans both streams: first kernel on `stream` .. last copy on `stream_t`
+    hipEvent_t e1 = get_event(c);
+    (void)hipEventRecord(e1, c->stream_t);
+    c->pending.push_back({stage_id(c, "detect"), det_e0, e1});
+  }
+  if (!rc) rc = (hipEventRecord(c->ev_tail[ring], c->stream_t) == hipSuccess) ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");
+  c->post = c->stream;
+  if (rc) return rc;
+  for (int i = 0; i < 2; ++i) c->slots[slots[i]].filled = true;
+  c->last_slot_l = slot_l;
+  PendingDetect pd;
+  pd.g = CropGeomS{g.row_off, g.col_off, g.crop_rows, g.crop_cols, g.scale};
+  pd.rows = rows; pd.cols = cols;
+  pd.slot_l = slot_l; pd.slot_r = slot_r; pd.prev_l = prev_l; pd.ring = ring;
+  c->pendq.push_back(pd);
   return SPVO_OK;
 }
 
+// completes the OLDEST submission
 static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_features *out_l, spvo_features *out_r, uint8_t *resized_l, uint8_t *resized_r) {
-  if (!c->pend.active) return fail(c, SPVO_ERR_STATE, "no detector submission in flight");
-  const PendingDetect pd = c->pend;
-  c->pend.active = false;
+  if (c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "no detector submission in flight");
+  const PendingDetect pd = c->pendq.front();
+  c->pendq.pop_front();
   const int slots[2] = {pd.slot_l, pd.slot_r};
   const int cap = c->cfg.max_keypoints;
   uint8_t *res[2] = {resized_l, resized_r};
   spvo_features *outs[2] = {out_l, out_r};
+  const bool extras = resized_l || resized_r || (out_l && out_l->desc) || (out_r && out_r->desc);
+  if (extras && !c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "resized images / host descriptors can only be fetched with one submission in flight");
+  c->post = c->stream_t;
   auto copy_extras = [&]() -> int {
     for (int i = 0; i < 2; ++i)
-      if (res[i]) HIP_TRY(c, hipMemcpyAsync(res[i], c->d_resized + (size_t)i * c->H * c->W, (size_t)c->H * c->W, hipMemcpyDeviceToHost, c->stream));
+      if (res[i]) HIP_TRY(c, hipMemcpyAsync(res[i], c->d_resized + (size_t)i * c->H * c->W, (size_t)c->H * c->W, hipMemcpyDeviceToHost, c->post));
     // descriptors: copy the full slot (1000 x 256 floats); rows >= n are stale
     for (int i = 0; i < 2; ++i)
-      if (outs[i] && outs[i]->desc) HIP_TRY(c, hipMemcpyAsync(outs[i]->desc, c->slots[slots[i]].d_desc, (size_t)cap * 256 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+      if (outs[i] && outs[i]->desc) HIP_TRY(c, hipMemcpyAsync(outs[i]->desc, c->slots[slots[i]].d_desc, (size_t)cap * 256 * sizeof(float), hipMemcpyDeviceToHost, c->post));
     return SPVO_OK;
   };
-  int rc = copy_extras();
-  if (rc) return rc;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  bool redone = false;
-  const NmsPair np = nms_pair(c, pd.parity);
-  if ((rc = nms_settle(c, 2, np, &redone))) return rc;
-  if (redone) {   // rare: the keypoints changed after the first batch -> redo what depends on them
-    if ((rc = enqueue_sample(c, slots, np))) return rc;
-    if (c->prematch && (rc = enqueue_prematch(c, pd.slot_l, pd.slot_r, pd.prev_l, pd.parity))) return rc;
-    if ((rc = copy_extras())) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int rc = SPVO_OK;
+  if (extras) {
+    if ((rc = copy_extras())) { c->post = c->stream; return rc; }
+    rc = hipStreamSynchronize(c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "stream synchronisation failed");
+  } else {
+    // only this submission's tail: a younger one may be queued behind it on both streams
+    rc = hipEventSynchronize(c->ev_tail[pd.ring]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");
   }
+  bool redone = false;
+  const NmsPair np = nms_pair(c, pd.ring);
+  if (!rc) rc = nms_settle(c, 2, np, pd.ring, &redone);
+  if (!rc && (redone || pd.rematch)) {   // rare: keypoints changed after the first batch -> redo what depends on them
+    if (redone) rc = enqueue_sample(c, slots, np, pd.ring);
+    if (!rc && c->prematch) rc = enqueue_prematch(c, pd.slot_l, pd.slot_r, pd.prev_l, pd.ring);
+    if (!rc && extras) rc = copy_extras();
+    if (!rc) rc = hipStreamSynchronize(c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "stream synchronisation failed");
+    if (redone)
+      for (auto &q : c->pendq)
+        if (q.prev_l == pd.slot_l) q.rematch = true;   // it matched against keypoints that have just been replaced
+  }
+  c->post = c->stream;
+  if (rc) return rc;
+  const int *hc = c->h_counters_r[pd.ring];
   for (int i = 0; i < 2; ++i) {
     FeatureSlot &s = c->slots[slots[i]];
-    s.n = c->h_counters[i * NMS_COUNTER_INTS + 2];
+    s.n = hc[i * NMS_COUNTER_INTS + 2];
     s.gen += 1;
     if (outs[i]) {
       outs[i]->n = s.n;
-      if (outs[i]->xy && s.n > 0) std::memcpy(outs[i]->xy, c->h_xy + (size_t)i * cap * 2, (size_t)s.n * 2 * sizeof(float));
+      if (outs[i]->xy && s.n > 0) std::memcpy(outs[i]->xy, c->h_xy_r[pd.ring] + (size_t)i * cap * 2, (size_t)s.n * 2 * sizeof(float));
     }
   }
-  for (auto &mc : c->mcache[pd.parity])
+  for (auto &mc : c->mcache[pd.ring])
     if (mc.valid) { mc.gen_a = c->slots[mc.slot_a].gen; mc.gen_b = c->slots[mc.slot_b].gen; }
-  c->last_slot_l = pd.slot_l;
   const CropGeom g{pd.g.row_off, pd.g.col_off, pd.g.crop_rows, pd.g.crop_cols, pd.g.scale};
   if (P_l) fix_projection(P_l, g, pd.rows, pd.cols, c->cfg.bug_compat_p);
   if (P_r) fix_projection(P_r, g, pd.rows, pd.cols, c->cfg.bug_compat_p);
@@ -1282,6 +1392,7 @@ static int detect_common(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
 int spvo_detect(spvo_ctx *c, const uint8_t *img_l, const uint8_t *img_r, int rows, int cols, size_t stride, double P_l[12], double P_r[12],
                 int slot_l, int slot_r, spvo_features *out_l, spvo_features *out_r, uint8_t *resized_l, uint8_t *resized_r) {
   if (!c || !img_l || !img_r || !P_l || !P_r || rows <= 0 || cols <= 0 || stride < (size_t)cols) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "detector submissions are in flight: complete them with spvo_detect_wait first");
   if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
   HIP_TRY(c, hipSetDevice(c->cfg.device));
   const size_t bytes = (size_t)rows * stride;
@@ -1298,6 +1409,7 @@ int spvo_detect(spvo_ctx *c, const uint8_t *img_l, const uint8_t *img_r, int row
 int spvo_detect_dev(spvo_ctx *c, const void *d_img_l, const void *d_img_r, int rows, int cols, size_t stride, double P_l[12], double P_r[12],
                     int slot_l, int slot_r, spvo_features *out_l, spvo_features *out_r) {
   if (!c || !d_img_l || !d_img_r || !P_l || !P_r || rows <= 0 || cols <= 0 || stride < (size_t)cols) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "detector submissions are in flight: complete them with spvo_detect_wait first");
   if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
   HIP_TRY(c, hipSetDevice(c->cfg.device));
   return detect_common(c, (const uint8_t *)d_img_l, (const uint8_t *)d_img_r, rows, cols, stride, P_l, P_r, slot_l, slot_r, out_l, out_r, nullptr, nullptr);
@@ -1322,18 +1434,21 @@ int spvo_match(spvo_ctx *c, const float *desc_a, int na, const float *desc_b, in
   HIP_TRY(c, hipSetDevice(c->cfg.device));
   int rc = ensure_match(c, na, nb);
   if (rc) return rc;
-  if (na) HIP_TRY(c, hipMemcpyAsync(c->d_ma, desc_a, (size_t)na * MATCH_D * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  if (nb) HIP_TRY(c, hipMemcpyAsync(c->d_mb, desc_b, (size_t)nb * MATCH_D * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  PostScope ps(c);   // behind the queued tails: they share the matcher's scratch
+  if (na) HIP_TRY(c, hipMemcpyAsync(c->d_ma, desc_a, (size_t)na * MATCH_D * sizeof(float), hipMemcpyHostToDevice, c->post));
+  if (nb) HIP_TRY(c, hipMemcpyAsync(c->d_mb, desc_b, (size_t)nb * MATCH_D * sizeof(float), hipMemcpyHostToDevice, c->post));
   return run_match(c, MatchReq{c->d_ma, c->d_mb, na, nb, nullptr, nullptr, nullptr, nullptr}, selector, cross_check ? 1 : 0, ratio, train_idx, distance);
 }
 
 int spvo_match_slots(spvo_ctx *c, int slot_a, int slot_b, int selector, int cross_check, float ratio, int32_t *train_idx, float *distance) {
-  if (!c || slot_a < 0 || slot_a > 3 || slot_b < 0 || slot_b > 3) return fail(c, SPVO_ERR_INVALID, "bad slot");
+  if (!c || slot_a < 0 || slot_a >= N_SLOTS || slot_b < 0 || slot_b >= N_SLOTS) return fail(c, SPVO_ERR_INVALID, "bad slot");
   if (selector != SPVO_SELECT_NN && selector != SPVO_SELECT_KNN) return fail(c, SPVO_ERR_INVALID, "bad selector");
   const FeatureSlot &a = c->slots[slot_a], &b = c->slots[slot_b];
   if (a.n > 0 && (!train_idx || !distance)) return fail(c, SPVO_ERR_INVALID, "null output");
-  for (int set = 0; set < 2; ++set) {   // already computed alongside the detector (spvo_set_prematch)?
-    if (c->pend.active && set == c->pend.parity) continue;   // that set belongs to the submission in flight
+  for (int set = 0; set < RING; ++set) {   // already computed alongside the detector (spvo_set_prematch)?
+    bool inflight = false;
+    for (const auto &q : c->pendq) inflight |= q.ring == set;
+    if (inflight) continue;   // that set belongs to a submission in flight
     for (const auto &mc : c->mcache[set])
       if (mc.valid && mc.slot_a == slot_a && mc.slot_b == slot_b && mc.gen_a == a.gen && mc.gen_b == b.gen && mc.selector == selector &&
           mc.cross == (cross_check ? 1 : 0) && mc.ratio == ratio) {
@@ -1341,7 +1456,10 @@ int spvo_match_slots(spvo_ctx *c, int slot_a, int slot_b, int selector, int cros
         return SPVO_OK;
       }
   }
-  if (c->pend.active) return fail(c, SPVO_ERR_STATE, "match not precomputed and a detector submission is rewriting the feature slots");
+  for (const auto &q : c->pendq)
+    if (q.slot_l == slot_a || q.slot_r == slot_a || q.slot_l == slot_b || q.slot_r == slot_b)
+      return fail(c, SPVO_ERR_STATE, "match not precomputed and a detector submission is rewriting the feature slots");
+  PostScope ps(c);   // behind the queued tails: they share the matcher's scratch
   HIP_TRY(c, hipSetDevice(c->cfg.device));
   int rc = ensure_match(c, a.n, b.n);
   if (rc) return rc;
@@ -1562,6 +1680,8 @@ void *spvo_stream(spvo_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int spvo_synchronize(spvo_ctx *c) {
   if (!c) return fail(c, SPVO_ERR_INVALID, "null context");
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream_t));
+  HIP_TRY(c, hipStreamSynchronize(c->stream2));
   return SPVO_OK;
 }
 

@@ -283,10 +283,7 @@ SuperPointFeatureFrontEnd::SuperPointFeatureFrontEnd(const MatcherType matcher_t
 }
 
 SuperPointFeatureFrontEnd::~SuperPointFeatureFrontEnd() {
-  if (ctx_ && prefetch_.active) {
-    spvo_features dl{0, nullptr, nullptr}, dr{0, nullptr, nullptr};
-    spvo_detect_wait(ctx_, nullptr, nullptr, &dl, &dr);
-  }
+  drainPrefetch();
   if (ctx_) spvo_destroy(ctx_);
   ctx_ = nullptr;
 }
@@ -355,6 +352,7 @@ void SuperPointFeatureFrontEnd::addStereoImagePair(cv::Mat &img_l, cv::Mat &img_
   projection_matrix_l_ = projection_matrix_l.clone();  // nn.cpp:465-466
   projection_matrix_r_ = projection_matrix_r.clone();
 
+  drainPrefetch();   // the synchronous path shares the detector's buffers with submissions in flight
   int slot_l, slot_r;
   pickSlots(&slot_l, &slot_r);
   spvo_features fl{0, xy_buf_[0].data(), desc_buf_[0].data()}, fr{0, xy_buf_[1].data(), desc_buf_[1].data()};
@@ -393,18 +391,16 @@ void SuperPointFeatureFrontEnd::addStereoImagePairDevice(const void *d_img_l, co
   spvo_features fl{0, xy_buf_[0].data(), host_descriptors ? desc_buf_[0].data() : nullptr};
   spvo_features fr{0, xy_buf_[1].data(), host_descriptors ? desc_buf_[1].data() : nullptr};
   int rc;
-  const bool hit = prefetch_.active && prefetch_.l == d_img_l && prefetch_.r == d_img_r && prefetch_.rows == rows && prefetch_.cols == cols &&
-                   prefetch_.stride == stride;
-  if (prefetch_.active && !hit) {  // a different pair was announced: drain and drop it
-    spvo_features dl{0, nullptr, nullptr}, dr{0, nullptr, nullptr};
-    spvo_detect_wait(ctx_, nullptr, nullptr, &dl, &dr);
-    prefetch_.active = false;
+  const bool hit = !prefetch_q_.empty() && prefetch_q_.front().l == d_img_l && prefetch_q_.front().r == d_img_r && prefetch_q_.front().rows == rows &&
+                   prefetch_q_.front().cols == cols && prefetch_q_.front().stride == stride;
+  if (!prefetch_q_.empty() && !hit) {  // a different pair was announced: drain and drop what is in flight
+    drainPrefetch();
     logError("addStereoImagePairDevice: the prefetched pair was not the one passed in; prefetch discarded");
   }
   if (hit) {
-    slot_l = prefetch_.slot_l;
-    slot_r = prefetch_.slot_r;
-    prefetch_.active = false;
+    slot_l = prefetch_q_.front().slot_l;
+    slot_r = prefetch_q_.front().slot_r;
+    prefetch_q_.pop_front();
     rc = spvo_detect_wait(ctx_, projection_matrix_l_.ptr<double>(0), projection_matrix_r_.ptr<double>(0), &fl, &fr);
   } else {
     pickSlots(&slot_l, &slot_r);
@@ -423,27 +419,33 @@ void SuperPointFeatureFrontEnd::addStereoImagePairDevice(const void *d_img_l, co
 }
 
 void SuperPointFeatureFrontEnd::prefetchStereoImagePairDevice(const void *d_img_l, const void *d_img_r, int rows, int cols, size_t stride) {
-  if (!engine_loaded_ || prefetch_.active) return;
-  int slot_l, slot_r;
-  pickSlots(&slot_l, &slot_r);  // the slots of the oldest pair: its matches are already cached
-  if (spvo_detect_dev_submit(ctx_, d_img_l, d_img_r, rows, cols, stride, slot_l, slot_r) != SPVO_OK) {
+  if (!engine_loaded_ || prefetch_q_.size() >= 2) return;
+  for (const auto &q : prefetch_q_)   // already announced
+    if (q.l == d_img_l && q.r == d_img_r && q.rows == rows && q.cols == cols && q.stride == stride) return;
+  Prefetch pf;
+  pickSlots(&pf.slot_l, &pf.slot_r);
+  if (spvo_detect_dev_submit(ctx_, d_img_l, d_img_r, rows, cols, stride, pf.slot_l, pf.slot_r) != SPVO_OK) {
     logError(std::string("spvo_detect_dev_submit: ") + spvo_last_error(ctx_));
     return;
   }
-  prefetch_.active = true;
-  prefetch_.l = d_img_l; prefetch_.r = d_img_r;
-  prefetch_.rows = rows; prefetch_.cols = cols; prefetch_.stride = stride;
-  prefetch_.slot_l = slot_l; prefetch_.slot_r = slot_r;
+  pf.l = d_img_l; pf.r = d_img_r;
+  pf.rows = rows; pf.cols = cols; pf.stride = stride;
+  prefetch_q_.push_back(pf);
 }
 
-void SuperPointFeatureFrontEnd::pickSlots(int *slot_l, int *slot_r) const {
-  // device slots: the two oldest entries of the ring are recycled
-  *slot_l = 0;
-  if (!slots_dq_.empty()) {
-    const bool used01 = std::find(slots_dq_.end() - std::min<size_t>(2, slots_dq_.size()), slots_dq_.end(), 0) != slots_dq_.end();
-    *slot_l = used01 ? 2 : 0;
+void SuperPointFeatureFrontEnd::drainPrefetch() {
+  while (ctx_ && !prefetch_q_.empty()) {
+    spvo_features dl{0, nullptr, nullptr}, dr{0, nullptr, nullptr};
+    spvo_detect_wait(ctx_, nullptr, nullptr, &dl, &dr);
+    prefetch_q_.pop_front();
   }
+}
+
+void SuperPointFeatureFrontEnd::pickSlots(int *slot_l, int *slot_r) {
+  // device slots: a ring of 4 pairs -- the previous and the current pair plus up to two pairs in flight
+  *slot_l = 2 * next_pair_;
   *slot_r = *slot_l + 1;
+  next_pair_ = (next_pair_ + 1) % 4;
 }
 
 void SuperPointFeatureFrontEnd::pushFeatures(const spvo_features *f[2], const cv::Mat *images[2], const int slots[2], bool host_descriptors) {

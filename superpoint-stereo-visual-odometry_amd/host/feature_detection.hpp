@@ -271,11 +271,13 @@ private:
   bool engine_loaded_ = false;
   std::vector<float> xy_buf_[2], desc_buf_[2];
   struct Prefetch {
-    bool active = false;
     const void *l = nullptr, *r = nullptr;
     int rows = 0, cols = 0, slot_l = 0, slot_r = 0;
     size_t stride = 0;
-  } prefetch_;
-  void pickSlots(int *slot_l, int *slot_r) const;
+  };
+  std::deque<Prefetch> prefetch_q_;   // pairs announced ahead (at most 2), oldest first
+  int next_pair_ = 0;                 // ring of 4 slot pairs: previous, current and two in flight
+  void drainPrefetch();
+  void pickSlots(int *slot_l, int *slot_r);
   void pushFeatures(const spvo_features *f[2], const cv::Mat *images[2], const int slots[2], bool host_descriptors);
 };

@@ -147,12 +147,14 @@ class FrontEnd:
     def prefetch_device(self, d_l: int, d_r: int, rows: int, cols: int, stride: int):
         self.lib.spvo_host_prefetch_dev(self.h, C.c_void_p(d_l), C.c_void_p(d_r), rows, cols, stride)
 
-    def step_device(self, d_l, d_r, rows, cols, stride, P_l, P_r, next_pair=None):
-        """One stereoCallback on a device-resident pair; `next_pair` = (d_l, d_r) of the following
-        frame, handed over early so that its detector overlaps this frame's matching / solving."""
+    def step_device(self, d_l, d_r, rows, cols, stride, P_l, P_r, next_pair=None, next2_pair=None):
+        """One stereoCallback on a device-resident pair; `next_pair` / `next2_pair` = (d_l, d_r) of the
+        following two frames, handed over early: their detector runs while this frame is matched and
+        solved, and the post-processing of one overlaps with the network of the other."""
         self.add_stereo_image_pair_device(d_l, d_r, rows, cols, stride, P_l, P_r)
-        if next_pair is not None:
-            self.prefetch_device(next_pair[0], next_pair[1], rows, cols, stride)
+        for nxt in (next_pair, next2_pair):
+            if nxt is not None:
+                self.prefetch_device(nxt[0], nxt[1], rows, cols, stride)   # no-op if already announced
         if self.dq_size() < 4:
             self.match_descriptors(CURR_LEFT_CURR_RIGHT)
             return None

@@ -95,24 +95,26 @@ def test_host_error_conventions(models_dir, tmp_path):
 
 
 def test_prefetch_pipeline_is_transparent(models_dir, sequence):
-    """Handing the next pair over early (detector overlapped with matching/solving) changes nothing."""
+    """Handing the next one or two pairs over early (their detector overlapped with this frame's matching
+    and solving, the tail of one submission overlapped with the network of the next) changes nothing."""
     import torch
     frames, poses, P_l, P_r = sequence
     dev = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
     rows, cols = frames[0][0].shape
     out = {}
-    for pipelined in (False, True):
+    for depth in (0, 1, 2):
         fe = host.FrontEnd(models_dir, prefix="sp_squeeze")
         res = []
         for k, (dl, dr) in enumerate(dev):
-            nxt = (dev[k + 1][0].data_ptr(), dev[k + 1][1].data_ptr()) if pipelined and k + 1 < len(dev) else None
-            r = fe.step_device(dl.data_ptr(), dr.data_ptr(), rows, cols, dl.stride(0), P_l, P_r, nxt)
+            ahead = [(dev[k + d][0].data_ptr(), dev[k + d][1].data_ptr()) if d <= depth and k + d < len(dev) else None for d in (1, 2)]
+            r = fe.step_device(dl.data_ptr(), dr.data_ptr(), rows, cols, dl.stride(0), P_l, P_r, ahead[0], ahead[1])
             res.append((r, fe.keypoints(host.CURR_LEFT), fe.map_of_indices(0), fe.map_of_indices(1) if k else None, fe.inliers("pnp")))
-        out[pipelined] = res
+        out[depth] = res
         fe.close()
-    for a, b in zip(out[False], out[True]):
-        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4])
-        if a[3] is not None:
-            assert np.array_equal(a[3], b[3])
-        if a[0] is not None:
-            assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1])      # poses: bit-identical
+    for depth in (1, 2):
+        for a, b in zip(out[0], out[depth]):
+            assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4])
+            if a[3] is not None:
+                assert np.array_equal(a[3], b[3])
+            if a[0] is not None:
+                assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1])      # poses: bit-identical
