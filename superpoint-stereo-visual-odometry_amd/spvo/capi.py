@@ -247,6 +247,18 @@ class Context:
         return dict(xy_l=xyl[:fl.n], xy_r=xyr[:fr.n], desc_l=None if dl is None else dl[:fl.n],
                     desc_r=None if dr is None else dr[:fr.n], P_l=Pl.reshape(3, 4), P_r=Pr.reshape(3, 4))
 
+    def detect_dev_submit(self, d_img_l: int, d_img_r: int, rows: int, cols: int, stride: int, slot_l: int, slot_r: int):
+        """Enqueue a detector pass (at most two may be in flight); complete them oldest-first with detect_wait."""
+        self._check(self.lib.spvo_detect_dev_submit(self.h, C.c_void_p(d_img_l), C.c_void_p(d_img_r), rows, cols, stride, slot_l, slot_r))
+
+    def detect_wait(self, P_l, P_r):
+        Pl = np.ascontiguousarray(P_l, np.float64).reshape(12).copy()
+        Pr = np.ascontiguousarray(P_r, np.float64).reshape(12).copy()
+        fl, xyl, _ = self._features(False)
+        fr, xyr, _ = self._features(False)
+        self._check(self.lib.spvo_detect_wait(self.h, _dptr(Pl), _dptr(Pr), C.byref(fl), C.byref(fr)))
+        return dict(xy_l=xyl[:fl.n], xy_r=xyr[:fr.n], P_l=Pl.reshape(3, 4), P_r=Pr.reshape(3, 4))
+
     def match(self, a: np.ndarray, b: np.ndarray, selector="KNN", cross_check=False, ratio=0.8):
         a = np.ascontiguousarray(a, np.float32).reshape(-1, 256)
         b = np.ascontiguousarray(b, np.float32).reshape(-1, 256)

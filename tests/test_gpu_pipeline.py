@@ -80,3 +80,42 @@ def test_prematch_is_transparent(ctx_squeeze, stereo_pair):
     for x, y in zip(res[False], res[True]):
         assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
     assert (res[True][1][0] >= 0).sum() > 300                            # temporal matches exist
+
+
+def test_two_submissions_in_flight(ctx_squeeze, stereo_pair):
+    """spvo_detect_dev_submit x2 / spvo_detect_wait x2 through the C ABI: same keypoints and matches as the
+    synchronous calls, oldest-first completion, and the documented SPVO_ERR_STATE refusals."""
+    import torch
+    from spvo import capi
+    frames, _, P_l, P_r = stereo_pair
+    dev = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
+    rows, cols = frames[0][0].shape
+    args = lambda k: (dev[k][0].data_ptr(), dev[k][1].data_ptr(), rows, cols, dev[k][0].stride(0))
+    ctx_squeeze.set_prematch(True, "KNN", False, 0.8)
+    ref = [ctx_squeeze.detect_dev(*args(0), P_l, P_r, 0, 1), ctx_squeeze.detect_dev(*args(1), P_l, P_r, 2, 3)]
+    ref = [{k: (None if v is None else v.copy()) for k, v in r.items()} for r in ref]
+    ref_m = (ctx_squeeze.match_slots(2, 3, len(ref[1]["xy_l"])), ctx_squeeze.match_slots(2, 0, len(ref[1]["xy_l"])))
+    with pytest.raises(capi.SpvoError) as e:
+        ctx_squeeze.detect_wait(P_l, P_r)                                     # nothing in flight
+    assert e.value.code == -4
+    ctx_squeeze.detect_dev_submit(*args(0), 4, 5)
+    ctx_squeeze.detect_dev_submit(*args(1), 6, 7)
+    with pytest.raises(capi.SpvoError) as e:
+        ctx_squeeze.detect_dev_submit(*args(0), 0, 1)                         # a third one
+    assert e.value.code == -4
+    with pytest.raises(capi.SpvoError) as e:
+        ctx_squeeze.forward(np.zeros((1, 1, 360, 1176), np.float32))          # would overwrite the activations
+    assert e.value.code == -4
+    a = ctx_squeeze.detect_wait(P_l, P_r)
+    with pytest.raises(capi.SpvoError) as e:
+        ctx_squeeze.detect_dev_submit(*args(0), 6, 7)                         # slots of the submission still in flight
+    assert e.value.code == -4
+    b = ctx_squeeze.detect_wait(P_l, P_r)
+    for got, want in ((a, ref[0]), (b, ref[1])):
+        assert np.array_equal(got["xy_l"], want["xy_l"]) and np.array_equal(got["xy_r"], want["xy_r"])
+        assert np.array_equal(got["P_l"], want["P_l"])
+    n = len(b["xy_l"])
+    got_m = (ctx_squeeze.match_slots(6, 7, n), ctx_squeeze.match_slots(6, 4, n))    # stereo, temporal: from the submission's cache
+    for (gi, gd), (ri, rd) in zip(got_m, ref_m):
+        assert np.array_equal(gi, ri) and np.array_equal(gd, rd)
+    ctx_squeeze.set_prematch(False, "KNN", False, 0.8)
