@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--no-pipeline", action="store_true", help="do not hand the next stereo pairs over early")
+    ap.add_argument("--dump-ops", action="store_true", help="add per-layer network times to the JSON line")
     ap.add_argument("--depth", type=int, default=2, choices=[1, 2], help="stereo pairs handed over ahead of the one being solved")
     args = ap.parse_args()
 
@@ -171,6 +172,9 @@ def main():
             out["stages_ms"] = {k: round(v["total_ms"] / max(v["calls"], 1), 4) for k, v in prof.items()
                                 if not k.startswith(("conv:", "pool:", "l2norm:"))}
             out["stages_ms"]["conv_stack_sum"] = round(conv_ms, 4)
+            if args.dump_ops:   # per-layer times of the network (variant tuning)
+                out["net_ops_ms"] = {k: round(v["total_ms"] / max(v["calls"], 1), 4) for k, v in prof.items()
+                                     if k.startswith(("conv:", "pool:", "l2norm:", "dwconv:"))}
             out["conv_stack_tflops"] = round(conv_fl / (conv_ms * 1e-3) / 1e12, 2)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames, P_l, P_r, plan)

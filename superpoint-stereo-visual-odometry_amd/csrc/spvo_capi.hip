@@ -270,10 +270,10 @@ struct ScopedStage {
 };
 
 // ---------------------------------------------------------------- conv dispatch
-template <int KS, int CK, int WR, int WC, bool POOL, bool RELU, int EPI = 0>
+template <int KS, int CK, int WR, int WC, bool POOL, bool RELU, int EPI = 0, int MINW = 1>
 int launch_conv_instance(spvo_ctx *c, ConvArgs args, hipStream_t stream) {
   using T = ConvTile<KS, CK, WR, WC>;
-  auto k = conv_mfma_kernel<KS, CK, WR, WC, POOL, RELU, 1, 0, EPI>;
+  auto k = conv_mfma_kernel<KS, CK, WR, WC, POOL, RELU, MINW, 0, EPI>;
   static int per_cu[64] = {};   // resident workgroups per CU of this instance, per device
   const int dev = c->cfg.device & 63;
   if (!per_cu[dev]) {
@@ -290,15 +290,15 @@ int launch_conv_instance(spvo_ctx *c, ConvArgs args, hipStream_t stream) {
   return SPVO_OK;
 }
 
-template <int KS, int CK, int WR, int WC, bool POOL>
+template <int KS, int CK, int WR, int WC, bool POOL, int MINW = 1>
 int launch_conv_variant(spvo_ctx *c, const ConvArgs &a, int batch, bool relu, hipStream_t stream) {
   using T = ConvTile<KS, CK, WR, WC>;
   ConvArgs args = a;
   args.tiles_x = (a.W + T::TW - 1) / T::TW;
   args.tiles_y = (a.H + T::TH - 1) / T::TH;
   args.batch = batch;
-  return relu ? launch_conv_instance<KS, CK, WR, WC, POOL, true>(c, args, stream)
-              : launch_conv_instance<KS, CK, WR, WC, POOL, false>(c, args, stream);
+  return relu ? launch_conv_instance<KS, CK, WR, WC, POOL, true, 0, MINW>(c, args, stream)
+              : launch_conv_instance<KS, CK, WR, WC, POOL, false, 0, MINW>(c, args, stream);
 }
 
 // MobileNet 1x1 layers: EPI 1 = ReLU, BatchNorm, ReLU (mbv1); EPI 2 = residual add, ReLU (mbv2)
@@ -313,21 +313,32 @@ int launch_conv_epi(spvo_ctx *c, const ConvArgs &a, int batch, int epi, hipStrea
                   : launch_conv_instance<1, 16, WR, WC, POOL, false, 2>(c, args, stream);
 }
 
-// tile choice: minimise padded work / fill, small tiles pay a little for lower operand reuse
-void choose_tile(int H, int W, int co_tiles, int batch, bool pool, int *wr, int *wc) {
-  struct Cand { int wr, wc; double pen; };
-  static const Cand nopool[] = {{2, 2, 1.00}, {1, 2, 1.03}, {1, 1, 1.06}};
-  static const Cand withpool[] = {{2, 2, 1.00}, {2, 1, 1.03}};
-  const Cand *cands = pool ? withpool : nopool;
-  const int nc = pool ? 2 : 3;
+// Variant choice for a layer.  3x3: every tile variant has a measured rate on perfectly divisible shapes
+// (tools/conv_bench sweep, launched back to back; TFLOP/s on 256 CUs) -- the smaller tiles let 2-3 workgroups share
+// a CU, whose staging, barriers and output bursts then hide under each other's matrix instructions -- and the
+// layer's time is that rate applied to the padded work of the busiest CU: ceil(tiles / CUs) tiles of TH x TW pixels
+// (the model reproduces the sweep's times within 4 %).  Chunks of 4 channels (3-4 workgroups per CU) measure a
+// further 2-3 % faster in isolation but 4 % SLOWER inside the pipeline, where the chip is shared with the previous
+// pair's post-processing and the solver (tools/tune_variants.sh), so they are not offered.
+// 1x1: tile by padded work / grid fill.
+void choose_variant(int ks, int H, int W, int co_tiles, int batch, bool pool, int num_cus, int *wr, int *wc, int *ck) {
+  struct Cand { int wr, wc, ck; double rate; };
+  static const Cand k3[] = {{2, 2, 8, 130.0}, {2, 1, 8, 135.0}, {1, 2, 8, 135.0}, {1, 1, 8, 133.0}};
+  static const Cand k1[] = {{2, 2, 16, 1.0 / 1.00}, {1, 2, 16, 1.0 / 1.03}, {2, 1, 16, 1.0 / 1.03}, {1, 1, 16, 1.0 / 1.06}};
+  const Cand *cands = ks == 3 ? k3 : k1;
+  const int nc = 4;
   double best = 1e300;
   for (int i = 0; i < nc; ++i) {
-    const int th = 4 * cands[i].wr, tw = 32 * cands[i].wc;
+    const Cand &v = cands[i];
+    if (pool && v.wr != 2) continue;                 // a 2x2 pooling window lives in one wave
+    if (ks == 1 && !pool && v.wr == 2 && v.wc == 1) continue;
+    const int th = 4 * v.wr, tw = 32 * v.wc;
     const int tx = (W + tw - 1) / tw, ty = (H + th - 1) / th;
-    const double grid = (double)tx * ty * co_tiles * batch;
-    const double work = (double)tx * tw * ty * th;
-    const double cost = work * cands[i].pen / std::min(1.0, grid / 256.0);
-    if (cost < best) { best = cost; *wr = cands[i].wr; *wc = cands[i].wc; }
+    const long tiles = (long)tx * ty * co_tiles * batch;
+    double cost;
+    if (ks == 3) cost = (double)((tiles + num_cus - 1) / num_cus) * th * tw / v.rate;
+    else cost = (double)tx * tw * ty * th / v.rate / std::min(1.0, (double)tiles / num_cus);
+    if (cost < best) { best = cost; *wr = v.wr; *wc = v.wc; *ck = v.ck; }
   }
 }
 
@@ -366,30 +377,31 @@ int launch_conv(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stre
   a.cout = op.cout; a.n_chunks = op.n_chunks; a.co_tiles = op.co_tiles;
   a.tiles_x = a.tiles_y = 0;
   a.batch = batch;
-  const int key = op.ks * 1000 + op.wr * 100 + op.wc * 10 + (pool ? 1 : 0);
+  const int key = op.ks * 10000 + op.ck * 100 + op.wr * 20 + op.wc * 2 + (pool ? 1 : 0);   // ks, ck, wr, wc, pool
   if (epi) {
     a.bn_scale = op.d_bn_scale; a.bn_shift = op.d_bn_shift;
     if (epi == 2) a.residual = c->tensors[op.residual].d + (size_t)img0 * c->tensors[op.residual].per_image;
     switch (key) {
-      case 1220: return launch_conv_epi<2, 2, false>(c, a, batch, epi, stream);
-      case 1120: return launch_conv_epi<1, 2, false>(c, a, batch, epi, stream);
-      case 1110: return launch_conv_epi<1, 1, false>(c, a, batch, epi, stream);
-      case 1221: return launch_conv_epi<2, 2, true>(c, a, batch, epi, stream);
-      case 1211: return launch_conv_epi<2, 1, true>(c, a, batch, epi, stream);
+      case 11644: return launch_conv_epi<2, 2, false>(c, a, batch, epi, stream);
+      case 11624: return launch_conv_epi<1, 2, false>(c, a, batch, epi, stream);
+      case 11622: return launch_conv_epi<1, 1, false>(c, a, batch, epi, stream);
+      case 11645: return launch_conv_epi<2, 2, true>(c, a, batch, epi, stream);
+      case 11643: return launch_conv_epi<2, 1, true>(c, a, batch, epi, stream);
       default: return fail(c, SPVO_ERR_INVALID, "no conv kernel variant for key %d with epilogue %d", key, epi);
     }
   }
-  switch (key) {
-    case 3220: return launch_conv_variant<3, 8, 2, 2, false>(c, a, batch, relu, stream);
-    case 3120: return launch_conv_variant<3, 8, 1, 2, false>(c, a, batch, relu, stream);
-    case 3110: return launch_conv_variant<3, 8, 1, 1, false>(c, a, batch, relu, stream);
-    case 3221: return launch_conv_variant<3, 8, 2, 2, true>(c, a, batch, relu, stream);
-    case 3211: return launch_conv_variant<3, 8, 2, 1, true>(c, a, batch, relu, stream);
-    case 1220: return launch_conv_variant<1, 16, 2, 2, false>(c, a, batch, relu, stream);
-    case 1120: return launch_conv_variant<1, 16, 1, 2, false>(c, a, batch, relu, stream);
-    case 1110: return launch_conv_variant<1, 16, 1, 1, false>(c, a, batch, relu, stream);
-    case 1221: return launch_conv_variant<1, 16, 2, 2, true>(c, a, batch, relu, stream);
-    case 1211: return launch_conv_variant<1, 16, 2, 1, true>(c, a, batch, relu, stream);
+  switch (key) {   // third template argument of the launch helper = waves per SIMD the register budget allows
+    case 30844: return launch_conv_variant<3, 8, 2, 2, false, 1>(c, a, batch, relu, stream);
+    case 30842: return launch_conv_variant<3, 8, 2, 1, false, 2>(c, a, batch, relu, stream);
+    case 30824: return launch_conv_variant<3, 8, 1, 2, false, 2>(c, a, batch, relu, stream);
+    case 30822: return launch_conv_variant<3, 8, 1, 1, false, 4>(c, a, batch, relu, stream);
+    case 30845: return launch_conv_variant<3, 8, 2, 2, true, 1>(c, a, batch, relu, stream);
+    case 30843: return launch_conv_variant<3, 8, 2, 1, true, 2>(c, a, batch, relu, stream);
+    case 11644: return launch_conv_variant<1, 16, 2, 2, false>(c, a, batch, relu, stream);
+    case 11624: return launch_conv_variant<1, 16, 1, 2, false>(c, a, batch, relu, stream);
+    case 11622: return launch_conv_variant<1, 16, 1, 1, false>(c, a, batch, relu, stream);
+    case 11645: return launch_conv_variant<1, 16, 2, 2, true>(c, a, batch, relu, stream);
+    case 11643: return launch_conv_variant<1, 16, 2, 1, true>(c, a, batch, relu, stream);
     default: return fail(c, SPVO_ERR_INVALID, "no conv kernel variant for key %d", key);
   }
 }
@@ -1064,11 +1076,16 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
         HIP_TRY(c, hipMemcpy(op.d_b, b, (size_t)op.cout * 4, hipMemcpyHostToDevice));
         continue;
       }
-      op.ck = (op.ks == 3) ? 8 : 16;
+      op.co_tiles = (op.cout + CO_TILE - 1) / CO_TILE;
+      choose_variant(op.ks, ti.H, ti.W, op.co_tiles, c->cfg.max_batch, pool, c->num_cus, &op.wr, &op.wc, &op.ck);
+      if (const char *force = std::getenv("SPVO_CONV_FORCE")) {   // tuning aid: "op:wr,wc,ck;op:wr,wc,ck"
+        for (const char *q = force; q && *q; q = std::strchr(q, ';') ? std::strchr(q, ';') + 1 : nullptr) {
+          int oi, wr, wc, ck;
+          if (std::sscanf(q, "%d:%d,%d,%d", &oi, &wr, &wc, &ck) == 4 && oi == (int)i) { op.wr = wr; op.wc = wc; op.ck = ck; }
+        }
+      }
       if (op.cin % op.ck) return fail(c, SPVO_ERR_IO, "op %u: cin %d is not a multiple of %d", i, op.cin, op.ck);
       op.n_chunks = op.cin / op.ck;
-      op.co_tiles = (op.cout + CO_TILE - 1) / CO_TILE;
-      choose_tile(ti.H, ti.W, op.co_tiles, c->cfg.max_batch, pool, &op.wr, &op.wc);
       // repack OIHW + bias -> [co_tile][chunk][(tap, ci) rows + bias row][64]
       const std::vector<float> pk = pack_conv_weights(w, b, op.cout, op.cin, op.ks, op.ck);
       std::vector<float> bp((size_t)op.co_tiles * CO_TILE, 0.f);

@@ -144,7 +144,7 @@ static double run_variant(const char *name, int B, int cin, int cout, int H, int
 
 // In-kernel clock of a production variant under sustained load (MI355X_MICROARCH.md, DVFS give-back
 // item 6): >= 2 s of back-to-back launches, then the stamps of the last launch, median over workgroups.
-template <int KS, int CK, int WR, int WC, bool POOL, int ABL = 4>
+template <int KS, int CK, int WR, int WC, bool POOL, int ABL = 4, int MINW = 1>
 static void run_clock(const char *name, int B, int cin, int cout, int H, int W, double seconds) {
   using T = ConvTile<KS, CK, WR, WC>;
   const int hp = padded_h(H), wp = padded_w(W);
@@ -174,7 +174,7 @@ static void run_clock(const char *name, int B, int cin, int cout, int H, int W, 
   a.out_hp = ohp; a.out_wp = owp; a.out_ctot = cout; a.out_coff = 0; a.cout = cout;
   a.n_chunks = cin / CK;
   a.tiles_x = (W + T::TW - 1) / T::TW; a.tiles_y = (H + T::TH - 1) / T::TH; a.co_tiles = co_tiles; a.batch = B;
-  auto kern = conv_mfma_kernel<KS, CK, WR, WC, POOL, true, 1, ABL>;
+  auto kern = conv_mfma_kernel<KS, CK, WR, WC, POOL, true, MINW, ABL>;
   CK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
   int per_cu = 1;
   CK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, 256, T::LDS_BYTES));
@@ -231,6 +231,41 @@ int main(int argc, char **argv) {
     run_clock<3, 8, 2, 2, false>("ideal 8x64", 2, 64, 64, 256, 1024, 2.5);
     run_clock<3, 8, 1, 2, false>("conv2a 4x64", 2, 64, 64, 180, 588, 2.0);
     run_clock<3, 8, 1, 1, false>("conv4a 4x32", 2, 128, 128, 45, 147, 2.0);
+    return 0;
+  }
+  if (argc > 3 && !strcmp(argv[3], "sweep")) {   // tile / chunk / occupancy variants per VGG layer shape, sustained
+#define SW(KS, CK, WR, WC, POOL, MINW, NAME, CI, CO, H, W) run_clock<KS, CK, WR, WC, POOL, 4, MINW>(NAME " k" #KS " ck" #CK " " #WR "x" #WC " w" #MINW, 2, CI, CO, H, W, 0.6)
+#define SW_POOL(NAME, CI, CO, H, W) \
+    SW(3, 8, 2, 2, true, 1, NAME, CI, CO, H, W); SW(3, 4, 2, 2, true, 2, NAME, CI, CO, H, W); \
+    SW(3, 8, 2, 1, true, 2, NAME, CI, CO, H, W); SW(3, 4, 2, 1, true, 2, NAME, CI, CO, H, W); SW(3, 4, 2, 1, true, 4, NAME, CI, CO, H, W)
+#define SW_PLAIN(NAME, CI, CO, H, W) \
+    SW(3, 8, 2, 2, false, 1, NAME, CI, CO, H, W); SW(3, 4, 2, 2, false, 2, NAME, CI, CO, H, W); \
+    SW(3, 8, 2, 1, false, 2, NAME, CI, CO, H, W); SW(3, 4, 2, 1, false, 4, NAME, CI, CO, H, W); \
+    SW(3, 8, 1, 2, false, 2, NAME, CI, CO, H, W); SW(3, 4, 1, 2, false, 4, NAME, CI, CO, H, W); \
+    SW(3, 8, 1, 1, false, 2, NAME, CI, CO, H, W); SW(3, 8, 1, 1, false, 4, NAME, CI, CO, H, W); SW(3, 4, 1, 1, false, 4, NAME, CI, CO, H, W)
+    SW_POOL("conv1b", 64, 64, 360, 1176);
+    SW_PLAIN("conv2a", 64, 64, 180, 588);
+    SW_POOL("conv2b", 64, 64, 180, 588);
+    SW_PLAIN("conv3a", 64, 128, 90, 294);
+    SW_POOL("conv3b", 128, 128, 90, 294);
+    SW_PLAIN("conv4a", 128, 128, 45, 147);
+    SW_PLAIN("convPa", 128, 256, 45, 147);
+    return 0;
+  }
+  if (argc > 3 && !strcmp(argv[3], "occ")) {   // one big workgroup per CU vs two / three smaller-chunk ones
+    run_clock<3, 8, 2, 2, false, 4, 1>("ideal 8x64 ck8 1/CU", 2, 64, 64, 256, 1024, 1.5);
+    run_clock<3, 4, 2, 2, false, 4, 2>("ideal 8x64 ck4 2/CU", 2, 64, 64, 256, 1024, 1.5);
+    run_clock<3, 8, 2, 1, false, 4, 1>("ideal 8x32 ck8", 2, 64, 64, 256, 1024, 1.5);
+    run_clock<3, 4, 2, 1, false, 4, 2>("ideal 8x32 ck4 w2", 2, 64, 64, 256, 1024, 1.5);
+    run_clock<3, 8, 2, 2, true, 4, 1>("conv1b 8x64 ck8 1/CU", 2, 64, 64, 360, 1176, 1.5);
+    run_clock<3, 4, 2, 2, true, 4, 2>("conv1b 8x64 ck4 2/CU", 2, 64, 64, 360, 1176, 1.5);
+    run_clock<3, 8, 2, 1, true, 4, 1>("conv1b 8x32 ck8", 2, 64, 64, 360, 1176, 1.5);
+    run_clock<3, 4, 2, 1, true, 4, 2>("conv1b 8x32 ck4 w2", 2, 64, 64, 360, 1176, 1.5);
+    run_clock<3, 8, 1, 2, false, 4, 1>("conv2a 4x64 ck8", 2, 64, 64, 180, 588, 1.5);
+    run_clock<3, 4, 1, 2, false, 4, 2>("conv2a 4x64 ck4 w2", 2, 64, 64, 180, 588, 1.5);
+    run_clock<3, 8, 1, 1, false, 4, 1>("conv2a 4x32 ck8", 2, 64, 64, 180, 588, 1.5);
+    run_clock<3, 8, 1, 1, false, 4, 1>("conv4a 4x32 ck8", 2, 128, 128, 45, 147, 1.5);
+    run_clock<3, 4, 1, 1, false, 4, 1>("conv4a 4x32 ck4", 2, 128, 128, 45, 147, 1.5);
     return 0;
   }
   if (argc > 3 && !strcmp(argv[3], "abl")) {   // what each part of the kernel costs, at sustained clocks
