@@ -33,6 +33,7 @@ import numpy as np  # noqa: E402
 NET_H, NET_W = 360, 1176
 SEQ_LEN = 8
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+F16_MFMA_PEAK_TFLOPS = 2500.0   # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense" (the FP16 engines of config 3)
 
 
 def cpu_baseline(frames, P_l, P_r, plan):
@@ -67,9 +68,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--no-pipeline", action="store_true", help="do not hand the next stereo pairs over early")
+    ap.add_argument("--net-size", default="360x1176", help="network input HxW: 360x1176 (the reference's, default = the headline workload) or 376x1240 (native, SURVEY.md section 8)")
+    ap.add_argument("--precision", default="FP32", choices=["FP32", "FP16"],
+                    help="FP32 = the headline workload (BASELINE config 2); FP16 = the half-precision engine of config 3 (use with --net-size 192x640)")
     ap.add_argument("--dump-ops", action="store_true", help="add per-layer network times to the JSON line")
     ap.add_argument("--depth", type=int, default=2, choices=[1, 2], help="stereo pairs handed over ahead of the one being solved")
     args = ap.parse_args()
+    global NET_H, NET_W
+    NET_H, NET_W = (int(v) for v in args.net_size.lower().split("x"))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,9 +94,10 @@ def main():
     from spvo import host, posegather, synth, weights
 
     plan = weights.vgg_plan(seed=0)
+    plan.precision = args.precision
     tmp = tempfile.mkdtemp(prefix=f"spvo_bench_{rank}_")
     os.makedirs(os.path.join(tmp, "laptop"))
-    weights.save(plan, os.path.join(tmp, "laptop", weights.engine_name("superpoint_pretrained", 2, NET_H, NET_W, "FP32")))
+    weights.save(plan, os.path.join(tmp, "laptop", weights.engine_name("superpoint_pretrained", 2, NET_H, NET_W, args.precision)))
 
     # every rank renders its own stream (different seed = different ego-motion); sample-image texture
     tex = os.path.join(ROOT, "tests", "golden", "images", "0000000000.png")
@@ -101,7 +108,7 @@ def main():
 
     fe = host.FrontEnd(tmp, prefix="superpoint_pretrained", selector="KNN", cross_check=True, batch=2,
                        height=NET_H, width=NET_W, conf_thresh=0.015, dist_thresh=4, border_remove=4,
-                       stereo_threshold=2.0, min_disparity=0.25, refinement_degree=4)
+                       stereo_threshold=2.0, min_disparity=0.25, refinement_degree=4, precision=args.precision)
     if not fe.engine_loaded:
         raise SystemExit("engine load failed: " + fe.last_error)
     ctx = fe.context()
@@ -148,9 +155,9 @@ def main():
         out = {
             "metric": "stereo frames/sec (1241x376 KITTI)", "value": round(total_frames / elapsed, 2), "unit": "stereo frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "SuperPoint VGG fp32 (seeded synthetic weights, 1300865 params), 1241x376 stereo pairs, "
-                                   "net 360x1176, 1000 kp cap, BF+KNN 0.8, P3P-style RANSAC 500 it, LM refinement degree 4; "
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "FP32" else "f16", "data": "synthetic",
+            "config": {"workload": f"SuperPoint VGG {args.precision.lower()} (seeded synthetic weights, 1300865 params), 1241x376 stereo pairs, "
+                                   f"net {NET_H}x{NET_W}, 1000 kp cap, BF+KNN 0.8, P3P-style RANSAC 500 it, LM refinement degree 4; "
                                    "one stereo stream per GPU, RCCL all-gather of poses",
                        "net_size": [NET_H, NET_W], "input_size": [rows, cols], "streams": world},
         }
@@ -160,11 +167,13 @@ def main():
             achieved = dom["flops"] / (avg_ms * 1e-3) / 1e12
             traffic = None                                                 # HBM bytes per launch from the committed PMC pass
             pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")
-            if os.path.exists(pmc):
+            if os.path.exists(pmc) and (NET_H, NET_W) == (360, 1176) and args.precision == "FP32":
                 traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel<KS=3,...,POOL,RELU> instance of op 1 = conv1b 64->64 @360x1176, 2 images",
-                               "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "FP32" else F16_MFMA_PEAK_TFLOPS
+            kname = "conv_mfma_kernel<KS=3,...,POOL,RELU>" if args.precision == "FP32" else "conv_f16_kernel<KS=3,...,POOL,RELU>"
+            out["roofline"] = {"bound": "mfma", "kernel": kname + " instance of op 1 = conv1b 64->64 @" + f"{NET_H}x{NET_W}, 2 images",
+                               "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(achieved / peak, 4), "traffic": traffic,
                                "traffic_source": "profiles/r01_pmc_conv_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 per gfx950 note)",
                                "avg_kernel_ms": round(avg_ms, 5), "flops_per_launch": dom["flops"]}
             conv_ms = sum(v["total_ms"] for k, v in prof.items() if k.startswith("conv:")) / max(dom["calls"], 1)

@@ -17,19 +17,34 @@ import torch.nn.functional as F
 from spvo import weights as W
 
 
+def _h(t: torch.Tensor) -> torch.Tensor:
+    """round to fp16 (nearest even) and back: the storage precision of an FP16 engine"""
+    return t.half().float()
+
+
 def forward(plan: W.Plan, x: np.ndarray, return_all: bool = False):
-    """x: float32 [B,1,H,W].  Returns (det, desc) as float32 numpy NCHW."""
+    """x: float32 [B,1,H,W].  Returns (det, desc) as float32 numpy NCHW.
+
+    plan.precision == "FP16" restates an engine built by engine_generation.py:13-56 with --fp16: the bindings stay
+    fp32 (nn.cpp:117) and everything between them is half precision.  TensorRT's internal choices (which layers it
+    keeps in fp32, its accumulation width) are not observable, so the restatement fixes the simplest consistent
+    reading: weights rounded to fp16, products accumulated in fp32 together with an fp32 bias, every intermediate
+    tensor rounded to fp16 when it is stored; the two heads' last convolutions, the L2 normalisation and the
+    outputs are fp32."""
     assert x.dtype == np.float32 and x.ndim == 4 and x.shape[1] == 1
     torch.set_grad_enabled(False)
     B, _, H, Wd = x.shape
     vals = {}
     vals[plan.input_tensor] = torch.from_numpy(x)
+    fp16 = plan.precision == "FP16"
+    keep_f32 = {plan.input_tensor, plan.det_tensor, plan.desc_tensor} | {op.inp for op in plan.ops if op.type == W.OP_L2NORM}
     for op in plan.ops:
         src = vals[op.inp]
         in_off = getattr(op, "in_c_off", 0)
         if op.type in (W.OP_CONV, W.OP_DWCONV):
             xin = src[:, in_off:in_off + op.cin]
-            y = F.conv2d(xin, torch.from_numpy(op.weight), torch.from_numpy(op.bias),
+            wt = torch.from_numpy(op.weight)
+            y = F.conv2d(xin, _h(wt) if fp16 else wt, torch.from_numpy(op.bias),
                          stride=1, padding=op.ksize // 2,
                          groups=op.cin if op.type == W.OP_DWCONV else 1)
             if op.flags & W.FLAG_RELU:
@@ -46,7 +61,7 @@ def forward(plan: W.Plan, x: np.ndarray, return_all: bool = False):
             ch, lvl = plan.tensors[op.out]
             if op.out not in vals:
                 vals[op.out] = torch.zeros((B, ch, H >> lvl, Wd >> lvl), dtype=torch.float32)
-            vals[op.out][:, op.out_c_off:op.out_c_off + op.cout] = y
+            vals[op.out][:, op.out_c_off:op.out_c_off + op.cout] = _h(y) if fp16 and op.out not in keep_f32 else y
         elif op.type == W.OP_MAXPOOL:
             vals[op.out] = F.max_pool2d(src, 2, 2)
         elif op.type == W.OP_L2NORM:

@@ -18,6 +18,7 @@
 #include "conv_mfma.hip.h"
 #include "match.hip.h"
 #include "odometry.hip.h"
+#include "conv_f16.hip.h"
 #include "post.hip.h"
 
 using namespace spvo;
@@ -33,6 +34,7 @@ constexpr int N_SLOTS = 8;       // feature slots: 4 stereo pairs (previous, cur
 struct Tensor {
   int ch = 0, level = 0, H = 0, W = 0, hp = 0, wp = 0;
   bool nhwc = false;  // dense [B][H][W][C] (descriptor map) instead of padded planes
+  bool f16 = false;   // FP16 engines: C8 fp16 [C/8][Hp][Wp][8] instead of fp32 planes (per_image still counts floats = 4 bytes)
   float *d = nullptr;
   float *dr[RING] = {nullptr, nullptr, nullptr, nullptr};  // network outputs only: one buffer per submission set (d == dr[0])
   size_t per_image = 0;  // floats
@@ -46,6 +48,7 @@ struct Op {
   int ck = 0, n_chunks = 0, co_tiles = 0, wr = 0, wc = 0;
   int residual = 0;  // tensor added before the last ReLU (FLAG_ADD)
   float *d_w = nullptr, *d_b = nullptr, *d_bn_scale = nullptr, *d_bn_shift = nullptr;
+  _Float16 *d_w16 = nullptr;   // FP16 engines: pack_conv_weights_f16()
   double flops_per_image = 0;
   int stage = -1;
 };
@@ -115,6 +118,7 @@ struct spvo_ctx {
   unsigned submit_count = 0;
   std::string error;
   bool weights = false;
+  bool fp16 = false;               // the loaded engine's precision
   int H = 0, W = 0, Hc = 0, Wc = 0, B = 0;
   int num_cus = 256;
 
@@ -406,17 +410,93 @@ int launch_conv(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stre
   }
 }
 
+// ---------------------------------------------------------------- FP16 engines
+template <int KS, int CKG, int WR, int WC, bool POOL, bool RELU, bool OUT_F32>
+int launch_conv16_instance(spvo_ctx *c, ConvArgs16 args, hipStream_t stream) {
+  using T = ConvTile16<KS, CKG, WR, WC>;
+  auto k = conv_f16_kernel<KS, CKG, WR, WC, POOL, RELU, OUT_F32>;
+  static int per_cu[64] = {};
+  const int dev = c->cfg.device & 63;
+  if (!per_cu[dev]) {
+    HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+    int n = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k, 256, T::LDS_BYTES));
+    per_cu[dev] = std::max(n, 1);
+  }
+  args.tiles_x = (args.W + T::TW - 1) / T::TW;
+  args.tiles_y = (args.H + T::TH - 1) / T::TH;
+  const int n_tiles = args.tiles_x * args.tiles_y * args.co_tiles * args.batch;
+  hipLaunchKernelGGL(k, dim3(std::min(n_tiles, c->num_cus * per_cu[dev])), dim3(256), T::LDS_BYTES, stream, args);
+  HIP_TRY(c, hipGetLastError());
+  return SPVO_OK;
+}
+
+template <int KS, int CKG, int WR, int WC, bool POOL>
+int launch_conv16_variant(spvo_ctx *c, const ConvArgs16 &a, bool relu, bool out_f32, hipStream_t stream) {
+  if constexpr (!POOL) {
+    if (out_f32) return relu ? launch_conv16_instance<KS, CKG, WR, WC, false, true, true>(c, a, stream) : launch_conv16_instance<KS, CKG, WR, WC, false, false, true>(c, a, stream);
+  }
+  return relu ? launch_conv16_instance<KS, CKG, WR, WC, POOL, true, false>(c, a, stream) : launch_conv16_instance<KS, CKG, WR, WC, POOL, false, false>(c, a, stream);
+}
+
+int launch_conv16(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream) {
+  const Tensor &ti = c->tensors[op.in];
+  const Tensor &to = c->tensors[op.out];
+  const float *tin = (ti.dr[c->cur_ring] ? ti.dr[c->cur_ring] : ti.d) + (size_t)img0 * ti.per_image;
+  float *tout = (to.dr[c->cur_ring] ? to.dr[c->cur_ring] : to.d) + (size_t)img0 * to.per_image;
+  const bool relu = op.flags & FLAG_RELU, pool = op.flags & FLAG_POOL;
+  if (op.cin == 1) {
+    dim3 grid((ti.W + 63) / 64, (ti.H + 3) / 4, batch);
+    if (relu) hipLaunchKernelGGL(conv_first_f16_kernel<true>, grid, dim3(256), 0, stream, tin, (_Float16 *)tout, op.d_w, op.d_b, ti.H, ti.W, ti.hp, ti.wp, to.ch / 8, op.out_c_off / 8, op.cout);
+    else hipLaunchKernelGGL(conv_first_f16_kernel<false>, grid, dim3(256), 0, stream, tin, (_Float16 *)tout, op.d_w, op.d_b, ti.H, ti.W, ti.hp, ti.wp, to.ch / 8, op.out_c_off / 8, op.cout);
+    HIP_TRY(c, hipGetLastError());
+    return SPVO_OK;
+  }
+  ConvArgs16 a;
+  a.in = (const _Float16 *)tin; a.out = tout; a.wpack = op.d_w16;
+  a.H = ti.H; a.W = ti.W;
+  a.in_hp = ti.hp; a.in_wp = ti.wp; a.in_gtot = ti.ch / 8; a.in_goff = op.in_c_off / 8;
+  a.out_hp = to.hp; a.out_wp = to.wp; a.out_ctot = to.ch; a.out_coff = op.out_c_off;
+  a.cout = op.cout; a.n_chunks = op.n_chunks; a.co_tiles = op.co_tiles;
+  a.tiles_x = a.tiles_y = 0;
+  a.batch = batch;
+  const bool out_f32 = !to.f16;
+  const int key = op.ks * 10000 + (op.ck / 8) * 1000 + op.wr * 100 + op.wc * 10 + (pool ? 1 : 0);   // ks, groups per chunk, wr, wc, pool
+  switch (key) {
+    case 32220: return launch_conv16_variant<3, 2, 2, 2, false>(c, a, relu, out_f32, stream);
+    case 32210: return launch_conv16_variant<3, 2, 2, 1, false>(c, a, relu, out_f32, stream);
+    case 32120: return launch_conv16_variant<3, 2, 1, 2, false>(c, a, relu, out_f32, stream);
+    case 32110: return launch_conv16_variant<3, 2, 1, 1, false>(c, a, relu, out_f32, stream);
+    case 32221: return launch_conv16_variant<3, 2, 2, 2, true>(c, a, relu, out_f32, stream);
+    case 32211: return launch_conv16_variant<3, 2, 2, 1, true>(c, a, relu, out_f32, stream);
+    case 14220: return launch_conv16_variant<1, 4, 2, 2, false>(c, a, relu, out_f32, stream);
+    case 14120: return launch_conv16_variant<1, 4, 1, 2, false>(c, a, relu, out_f32, stream);
+    case 14110: return launch_conv16_variant<1, 4, 1, 1, false>(c, a, relu, out_f32, stream);
+    case 14221: return launch_conv16_variant<1, 4, 2, 2, true>(c, a, relu, out_f32, stream);
+    case 14211: return launch_conv16_variant<1, 4, 2, 1, true>(c, a, relu, out_f32, stream);
+    case 12220: return launch_conv16_variant<1, 2, 2, 2, false>(c, a, relu, out_f32, stream);
+    case 12120: return launch_conv16_variant<1, 2, 1, 2, false>(c, a, relu, out_f32, stream);
+    case 12110: return launch_conv16_variant<1, 2, 1, 1, false>(c, a, relu, out_f32, stream);
+    case 12221: return launch_conv16_variant<1, 2, 2, 2, true>(c, a, relu, out_f32, stream);
+    case 12211: return launch_conv16_variant<1, 2, 2, 1, true>(c, a, relu, out_f32, stream);
+    default: return fail(c, SPVO_ERR_INVALID, "no fp16 conv kernel variant for key %d", key);
+  }
+}
+
 int launch_op(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream) {
   const Tensor &ti = c->tensors[op.in];
   const Tensor &to = c->tensors[op.out];
   if (op.type == OP_CONV || op.type == OP_DWCONV) {
     ScopedStage st(c, op.stage, op.flops_per_image * batch, 0, stream);
-    return launch_conv(c, op, img0, batch, stream);
+    return c->fp16 ? launch_conv16(c, op, img0, batch, stream) : launch_conv(c, op, img0, batch, stream);
   }
   const float *tin = (ti.dr[c->cur_ring] ? ti.dr[c->cur_ring] : ti.d) + (size_t)img0 * ti.per_image;
   float *tout = (to.dr[c->cur_ring] ? to.dr[c->cur_ring] : to.d) + (size_t)img0 * to.per_image;
   ScopedStage st(c, op.stage, 0, 0, stream);
-  if (op.type == OP_MAXPOOL) {
+  if (op.type == OP_MAXPOOL && ti.f16) {
+    dim3 grid((to.W + 63) / 64, (to.H + 3) / 4, batch * (to.ch / 8));
+    hipLaunchKernelGGL(maxpool2_f16_kernel, grid, dim3(256), 0, stream, (const _Float16 *)tin, (_Float16 *)tout, to.H, to.W, ti.hp, ti.wp, to.hp, to.wp);
+  } else if (op.type == OP_MAXPOOL) {
     dim3 grid((to.W + 63) / 64, (to.H + 3) / 4, batch * to.ch);
     hipLaunchKernelGGL(maxpool2_kernel, grid, dim3(256), 0, stream, tin, tout, to.ch, to.H, to.W, ti.hp, ti.wp, to.hp, to.wp);
   } else if (op.type == OP_L2NORM) {
@@ -782,8 +862,11 @@ void free_plan(spvo_ctx *c) {
     for (int r = 1; r < RING; ++r) if (t.dr[r]) (void)hipFree(t.dr[r]);
   }
   for (auto &o : c->ops)
+  {
     for (float *p : {o.d_w, o.d_b, o.d_bn_scale, o.d_bn_shift}) if (p) (void)hipFree(p);
-  c->tensors.clear(); c->ops.clear(); c->weights = false;
+    if (o.d_w16) (void)hipFree(o.d_w16);
+  }
+  c->tensors.clear(); c->ops.clear(); c->weights = false; c->fp16 = false;
 }
 
 }  // namespace
@@ -966,6 +1049,8 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
   if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "detector submissions are in flight");
   free_plan(c);
   c->t_input = hdr[2]; c->t_det = hdr[3]; c->t_desc = hdr[4];
+  if (hdr[5] > 1) return fail(c, SPVO_ERR_IO, "%s: unknown precision %u", path, hdr[5]);
+  c->fp16 = hdr[5] == 1;   // engine built for FP16 (engine_generation.py's --fp16; the file name says FP16, nn.cpp:44-49)
   for (uint32_t i = 0; i < nt; ++i) {
     const uint32_t *r = (const uint32_t *)(buf.data() + pos);
     pos += 8;
@@ -997,10 +1082,23 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
     if (op.type == OP_L2NORM) c->tensors[op.out].nhwc = true;
     c->ops.push_back(op);
   }
+  if (c->fp16) {
+    // half precision between the fp32 network input and the fp32 outputs (nn.cpp:117): every tensor but the input,
+    // output_det, the raw descriptor map and output_desc is C8 fp16
+    for (auto &t : c->tensors) t.f16 = true;
+    c->tensors[c->t_input].f16 = c->tensors[c->t_det].f16 = c->tensors[c->t_desc].f16 = false;
+    for (const auto &op : c->ops) {
+      if (op.type == OP_L2NORM) c->tensors[op.in].f16 = false;
+      if (op.type == OP_DWCONV || (op.flags & (FLAG_BN | FLAG_ADD)))
+        return fail(c, SPVO_ERR_IO, "%s: FP16 engines run the VGG and squeeze graphs; MobileNet layers (depthwise, BatchNorm, residual) are FP32 only", path);
+    }
+    for (size_t ti = 0; ti < c->tensors.size(); ++ti)
+      if (c->tensors[ti].f16 && c->tensors[ti].ch % 8) return fail(c, SPVO_ERR_IO, "%s: tensor %zu has %d channels, not a multiple of 8", path, ti, c->tensors[ti].ch);
+  }
   // allocate activations (padded planes stay zero outside the interior for ever)
   for (size_t ti = 0; ti < c->tensors.size(); ++ti) {
     Tensor &t = c->tensors[ti];
-    t.per_image = t.nhwc ? (size_t)t.H * t.W * t.ch : (size_t)t.ch * t.hp * t.wp;
+    t.per_image = t.nhwc ? (size_t)t.H * t.W * t.ch : (size_t)t.ch * t.hp * t.wp / (t.f16 ? 2 : 1);
     int rc = dev_alloc(c, &t.d, t.per_image * c->B);
     if (rc) return rc;
     if ((int)ti == c->t_det || (int)ti == c->t_desc) {   // what a submission's tail reads while the next network pass already runs
@@ -1067,6 +1165,34 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
       op.flops_per_image = 2.0 * ti.H * ti.W * op.cout * op.cin * taps;
       const float *w = payload + r.w_off;
       const float *b = payload + r.b_off;
+      if (c->fp16) {
+        if (ti.f16 != (op.cin != 1)) return fail(c, SPVO_ERR_IO, "op %u: FP16 engine with an fp32 intermediate tensor", i);
+        if (op.cin == 1) {   // first layer: fp32 arithmetic on fp16-rounded weights, fp16 output
+          if (op.ks != 3 || pool || !to.f16 || (op.cout % 8) || (op.out_c_off % 8)) return fail(c, SPVO_ERR_IO, "op %u: unsupported first layer for FP16", i);
+          std::vector<float> wr((size_t)op.cout * 9);
+          for (size_t q = 0; q < wr.size(); ++q) wr[q] = (float)(_Float16)w[q];
+          int rc = dev_alloc(c, &op.d_w, wr.size(), false);
+          if (rc) return rc;
+          if ((rc = dev_alloc(c, &op.d_b, op.cout, false))) return rc;
+          HIP_TRY(c, hipMemcpy(op.d_w, wr.data(), wr.size() * 4, hipMemcpyHostToDevice));
+          HIP_TRY(c, hipMemcpy(op.d_b, b, (size_t)op.cout * 4, hipMemcpyHostToDevice));
+          continue;
+        }
+        const int ckg = (op.ks == 3 || op.cin % 32) ? 2 : 4;   // 16 channels per chunk; 32 for 1x1 layers when they divide
+        if (op.cin % (8 * ckg) || op.in_c_off % 8) return fail(c, SPVO_ERR_IO, "op %u: cin %d / channel offset %d do not fit the FP16 chunking (%d)", i, op.cin, op.in_c_off, 8 * ckg);
+        if (to.f16 && ((op.cout % 8) || (op.out_c_off % 8))) return fail(c, SPVO_ERR_IO, "op %u: cout %d / channel offset %d are not multiples of 8", i, op.cout, op.out_c_off);
+        if (!to.f16 && pool) return fail(c, SPVO_ERR_IO, "op %u: pooled fp32 output", i);
+        op.ck = 8 * ckg;
+        op.n_chunks = op.cin / op.ck;
+        op.co_tiles = (op.cout + CO_TILE - 1) / CO_TILE;
+        int ck_unused;
+        choose_variant(op.ks, ti.H, ti.W, op.co_tiles, c->cfg.max_batch, pool, c->num_cus, &op.wr, &op.wc, &ck_unused);
+        const std::vector<_Float16> pk = pack_conv_weights_f16(w, b, op.cout, op.cin, op.ks, ckg);
+        int rc = dev_alloc(c, &op.d_w16, pk.size(), false);
+        if (rc) return rc;
+        HIP_TRY(c, hipMemcpy(op.d_w16, pk.data(), pk.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+        continue;
+      }
       if (op.cin == 1) {
         if (pool || add) return fail(c, SPVO_ERR_IO, "op %u: single-channel-input layers have no pooling / residual form", i);
         int rc = dev_alloc(c, &op.d_w, (size_t)op.cout * taps, false);
@@ -1114,6 +1240,11 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->weights = true;
   return SPVO_OK;
+}
+
+int spvo_engine_precision(const spvo_ctx *c) {
+  if (!c || !c->weights) return SPVO_ERR_STATE;
+  return c->fp16 ? 1 : 0;
 }
 
 int spvo_preprocess(spvo_ctx *c, const uint8_t *img, int rows, int cols, size_t stride, double P[12], uint8_t *resized_u8) {
@@ -1178,7 +1309,8 @@ int spvo_debug_tensor(spvo_ctx *c, int tensor_id, int batch, float *out, size_t 
   }
   float *tmp = nullptr;
   HIP_TRY(c, hipMalloc((void **)&tmp, need * sizeof(float)));
-  hipLaunchKernelGGL(unpad_kernel, dim3((t.W + 63) / 64, (t.H + 3) / 4, batch * t.ch), dim3(256), 0, c->stream, t.d, tmp, t.ch, t.H, t.W, t.hp, t.wp);
+  if (t.f16) hipLaunchKernelGGL(unpad_c8_kernel, dim3((t.W + 63) / 64, t.H, batch * t.ch), dim3(64), 0, c->stream, (const _Float16 *)t.d, tmp, t.ch, t.H, t.W, t.hp, t.wp);
+  else hipLaunchKernelGGL(unpad_kernel, dim3((t.W + 63) / 64, (t.H + 3) / 4, batch * t.ch), dim3(256), 0, c->stream, t.d, tmp, t.ch, t.H, t.W, t.hp, t.wp);
   hipError_t e = hipMemcpyAsync(out, tmp, need * sizeof(float), hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   (void)hipFree(tmp);

@@ -306,10 +306,6 @@ void SuperPointFeatureFrontEnd::loadEngine() {
     logError("Wrong batch size (" + std::to_string(model_batch_size_) + ")");  // nn.cpp:490
     return;
   }
-  if (trt_precision_ != TRT_FP32) {
-    logError("only FP32 engines are built so far");
-    return;
-  }
   if (spvo_create(&cfg, &ctx_) != SPVO_OK) {
     logError(std::string("spvo_create: ") + spvo_last_error(nullptr));
     ctx_ = nullptr;
@@ -323,6 +319,10 @@ void SuperPointFeatureFrontEnd::loadEngine() {
                                       trt_precision_enum2string.at(trt_precision_) + ".spvw";
   if (spvo_load_weights(ctx_, model_name_full.c_str()) != SPVO_OK) {
     logError(spvo_last_error(ctx_));  // "no such engine file: ..." (nn.cpp:53-55): object stays half-initialised
+    return;
+  }
+  if (spvo_engine_precision(ctx_) != (trt_precision_ == TRT_FP16 ? 1 : 0)) {   // the name promises what trtexec was told (--fp16 or not)
+    logError("engine file `" + model_name_full + "` was not built for " + trt_precision_enum2string.at(trt_precision_));
     return;
   }
   logInfo("engine file `" + model_name_full + "` loaded");

@@ -56,7 +56,7 @@ OBS_DTYPE = np.dtype([("X", np.float32, 3), ("uv", np.float32, 2), ("cam", np.in
 
 # every symbol include/spvo.h declares
 SYMBOLS = [
-    "spvo_default_config", "spvo_create", "spvo_destroy", "spvo_last_error", "spvo_load_weights",
+    "spvo_default_config", "spvo_create", "spvo_destroy", "spvo_last_error", "spvo_load_weights", "spvo_engine_precision",
     "spvo_preprocess", "spvo_forward", "spvo_debug_tensor", "spvo_heatmap", "spvo_nms",
     "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_detect_dev_submit", "spvo_detect_wait", "spvo_match", "spvo_match_slots", "spvo_set_prematch",
     "spvo_triangulate", "spvo_pnp_ransac", "spvo_pnp_refine", "spvo_solve_stereo_odometry", "spvo_stream", "spvo_synchronize",
@@ -246,6 +246,12 @@ class Context:
                                              _dptr(Pl), _dptr(Pr), slot_l, slot_r, C.byref(fl), C.byref(fr)))
         return dict(xy_l=xyl[:fl.n], xy_r=xyr[:fr.n], desc_l=None if dl is None else dl[:fl.n],
                     desc_r=None if dr is None else dr[:fr.n], P_l=Pl.reshape(3, 4), P_r=Pr.reshape(3, 4))
+
+    def engine_precision(self) -> str:
+        rc = self.lib.spvo_engine_precision(self.h)
+        if rc < 0:
+            raise SpvoError(rc, "no weights loaded")
+        return "FP16" if rc == 1 else "FP32"
 
     def detect_dev_submit(self, d_img_l: int, d_img_r: int, rows: int, cols: int, stride: int, slot_l: int, slot_r: int):
         """Enqueue a detector pass (at most two may be in flight); complete them oldest-first with detect_wait."""

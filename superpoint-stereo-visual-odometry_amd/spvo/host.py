@@ -24,7 +24,7 @@ def load():
         vp = C.c_void_p
         lib.spvo_host_create.restype = vp
         lib.spvo_host_create.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                         C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int]
+                                         C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]
         lib.spvo_host_destroy.argtypes = [vp]
         lib.spvo_host_destroy.restype = None
         lib.spvo_host_last_error.argtypes = [vp]
@@ -92,12 +92,12 @@ class FrontEnd:
 
     def __init__(self, models_dir, prefix="superpoint_pretrained", machine="laptop", selector="KNN", cross_check=True,
                  batch=2, height=360, width=1176, conf_thresh=0.015, dist_thresh=4, border_remove=4,
-                 stereo_threshold=2.0, min_disparity=0.25, refinement_degree=4, verbose=False):
+                 stereo_threshold=2.0, min_disparity=0.25, refinement_degree=4, verbose=False, precision="FP32"):
         self.lib = load()
         self.h = self.lib.spvo_host_create(models_dir.encode(), prefix.encode(), machine.encode(),
                                            1 if selector == "KNN" else 0, int(cross_check), batch, height, width,
                                            conf_thresh, dist_thresh, border_remove, stereo_threshold, min_disparity,
-                                           refinement_degree, int(verbose))
+                                           refinement_degree, int(verbose), 1 if precision == "FP16" else 0)
         self.H, self.W = height, width
 
     def close(self):

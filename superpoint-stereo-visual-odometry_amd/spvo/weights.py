@@ -10,7 +10,7 @@ own layout, so the file stays canonical and human-checkable.
 
 File layout (little endian):
     char  magic[8]  = b"SPVW0003"
-    u32   n_tensors, n_ops, input_tensor, det_tensor, desc_tensor, reserved[3]
+    u32   n_tensors, n_ops, input_tensor, det_tensor, desc_tensor, precision (0 = FP32, 1 = FP16), reserved[2]
     n_tensors x { u32 channels, u32 level }          level = log2(downscale)
     n_ops     x { u32 type, in, out, out_c_off, cin | in_c_off << 16, cout, ksize, flags,
                   residual_tensor, reserved[3]; u64 w_off, b_off, bn_off }   offsets in floats
@@ -67,6 +67,7 @@ class Plan:
     input_tensor: int = 0
     det_tensor: int = 0
     desc_tensor: int = 0
+    precision: str = "FP32"   # "FP16": the library keeps fp16 between the fp32 network input and the fp32 outputs
 
     def add_tensor(self, channels: int, level: int) -> int:
         self.tensors.append((channels, level))
@@ -306,7 +307,13 @@ def onnx_plan(path: str) -> Plan:
 
 
 # --------------------------------------------------------------------------
-def save(plan: Plan, path: str) -> None:
+PRECISIONS = {"FP32": 0, "FP16": 1}
+
+
+def save(plan: Plan, path: str, precision: Optional[str] = None) -> None:
+    """Weights stay canonical fp32 in the file for every precision (the library rounds them at load, to nearest even);
+    `precision` (default: the plan's) only selects the engine the library builds, like trtexec's --fp16."""
+    precision = precision or plan.precision
     payload: List[np.ndarray] = []
     off = 0
     recs = []
@@ -327,7 +334,7 @@ def save(plan: Plan, path: str) -> None:
     with open(path, "wb") as fh:
         fh.write(MAGIC)
         fh.write(struct.pack("<8I", len(plan.tensors), len(plan.ops), plan.input_tensor,
-                             plan.det_tensor, plan.desc_tensor, 0, 0, 0))
+                             plan.det_tensor, plan.desc_tensor, PRECISIONS[precision], 0, 0))
         for ch, lvl in plan.tensors:
             fh.write(struct.pack("<2I", ch, lvl))
         for r in recs:
@@ -341,9 +348,9 @@ def load(path: str) -> Plan:
     with open(path, "rb") as fh:
         buf = fh.read()
     assert buf[:8] == MAGIC, "not a .spvw file of this version"
-    nt, no, it, dt, st, _, _, _ = struct.unpack_from("<8I", buf, 8)
+    nt, no, it, dt, st, prec, _, _ = struct.unpack_from("<8I", buf, 8)
     pos = 40
-    p = Plan(input_tensor=it, det_tensor=dt, desc_tensor=st)
+    p = Plan(input_tensor=it, det_tensor=dt, desc_tensor=st, precision={v: k for k, v in PRECISIONS.items()}[prec])
     for _ in range(nt):
         ch, lvl = struct.unpack_from("<2I", buf, pos)
         pos += 8

@@ -126,3 +126,26 @@ def test_oracle_runs_mobilenet_graphs(name):
     if op.flags & weights.FLAG_POOL:
         y = y.reshape(1, op.cout, y.shape[2] // 2, 2, y.shape[3] // 2, 2).max(axis=(3, 5))
     assert np.abs(vals[op.out] - y).max() < 1e-4
+
+
+def test_fp16_engine_file_and_oracle(tmp_path):
+    """The precision travels in the engine file (weights stay canonical fp32) and the oracle's FP16 restatement rounds
+    what an FP16 engine stores: weights and intermediate activations, not the bindings."""
+    import copy
+    from oracle import net
+    from spvo import weights
+    plan = weights.vgg_plan(seed=0)
+    p16 = copy.copy(plan)
+    p16.precision = "FP16"
+    path = str(tmp_path / weights.engine_name("superpoint_pretrained", 2, 32, 48, "FP16"))
+    weights.save(p16, path)
+    back = weights.load(path)
+    assert back.precision == "FP16" and weights.load(os.path.join(GOLDEN, "sp_squeeze.spvw")).precision == "FP32"
+    assert all(np.array_equal(a.weight, b.weight) for a, b in zip(plan.ops, back.ops) if a.weight is not None)
+    x = np.random.RandomState(1).rand(1, 1, 32, 48).astype(np.float32)
+    det32, desc32 = net.forward(plan, x)
+    det16, desc16, vals = net.forward(back, x, return_all=True)
+    mid = vals[3]                                     # an intermediate activation: exactly representable in fp16
+    assert np.array_equal(mid, mid.astype(np.float16).astype(np.float32))
+    assert not np.array_equal(det16, det16.astype(np.float16).astype(np.float32))     # outputs stay fp32
+    assert 0 < np.abs(det16 - det32).max() < 2e-2 * np.abs(det32).max()

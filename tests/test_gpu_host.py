@@ -118,3 +118,36 @@ def test_prefetch_pipeline_is_transparent(models_dir, sequence):
                 assert np.array_equal(a[3], b[3])
             if a[0] is not None:
                 assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1])      # poses: bit-identical
+
+
+def test_fp16_engine_through_the_host_class(tmp_path, squeeze_weights_path, sequence):
+    """TensorRtPrecision::FP16 (hpp:124-126): the front end loads `<prefix>_<B>_<H>_<W>_FP16.spvw`, refuses a file
+    of the other precision, and tracks the synthetic ego-motion like the FP32 engine (the trained squeeze weights;
+    < 5 cm per 0.8 m step), with most keypoints in common."""
+    frames, poses, P_l, P_r = sequence
+    d = tmp_path / "models"
+    os.makedirs(d / "laptop")
+    plan = weights.load(squeeze_weights_path)
+    weights.save(plan, str(d / "laptop" / weights.engine_name("sp_squeeze", 2, 360, 1176, "FP16")), precision="FP16")
+    weights.save(plan, str(d / "laptop" / weights.engine_name("sp_squeeze", 2, 360, 1176, "FP32")))
+    weights.save(plan, str(d / "laptop" / weights.engine_name("mislabelled", 2, 360, 1176, "FP16")))     # an FP32 engine under an FP16 name
+    bad = host.FrontEnd(str(d), prefix="mislabelled", precision="FP16")
+    assert not bad.engine_loaded and "was not built for FP16" in bad.last_error
+    bad.close()
+    out = {}
+    for prec in ("FP32", "FP16"):
+        fe = host.FrontEnd(str(d), prefix="sp_squeeze", precision=prec)
+        assert fe.engine_loaded, fe.last_error
+        res = []
+        for L, R in frames:
+            r = fe.step(L, R, P_l, P_r)
+            res.append((r, fe.keypoints(host.CURR_LEFT)))
+        out[prec] = res
+        fe.close()
+    for k in range(1, len(frames)):
+        (q16, t16), kp16 = out["FP16"][k]
+        (q32, t32), kp32 = out["FP32"][k]
+        q_true, t_true = synth.relative_pose(poses[k - 1], poses[k])
+        assert np.linalg.norm(t16 - t_true) < 0.05 and np.linalg.norm(t16 - t32) < 0.05
+        a, b = set(map(tuple, kp16.tolist())), set(map(tuple, kp32.tolist()))
+        assert len(a & b) / len(a | b) > 0.8

@@ -22,11 +22,13 @@ def _input(sample_images, H, W, batch):
     xs = []
     for b in range(batch):
         img = sample_images[b % len(sample_images)]
+        if img.shape[0] < H + 5 or img.shape[1] < W + 20 + 3 * b:            # 376 x 1240 does not fit a 375 x 1242 frame: wrap
+            img = np.pad(img, ((0, max(0, H + 5 - img.shape[0])), (0, max(0, W + 20 + 3 * b - img.shape[1]))), mode="wrap")
         xs.append(img[5:5 + H, 20 + 3 * b:20 + 3 * b + W].astype(np.float32) / 255.0)
     return np.stack(xs)[:, None]
 
 
-@pytest.mark.parametrize("H,W,batch", [(120, 392, 2), (360, 1176, 2), (192, 640, 1)])
+@pytest.mark.parametrize("H,W,batch", [(120, 392, 2), (360, 1176, 2), (192, 640, 1), (376, 1240, 2)])
 def test_vgg_forward_matches_oracle(vgg_weights_path, vgg_plan, sample_images, H, W, batch):
     ctx = make_ctx(vgg_weights_path, net_height=H, net_width=W)
     x = _input(sample_images, H, W, batch)
@@ -73,6 +75,41 @@ def test_mobilenet_forward_matches_oracle(name, H, W, batch, sample_images):
         assert np.abs(got - vals[tid]).max() <= _tol(vals[tid]), f"{name} tensor {tid}"
     assert np.abs(det - rdet).max() <= _tol(rdet)
     assert np.abs(desc - rdesc.transpose(0, 2, 3, 1)).max() <= 1e-4
+    ctx.close()
+
+
+@pytest.mark.parametrize("graph,H,W,batch", [("vgg", 192, 640, 2), ("vgg", 360, 1176, 2), ("squeeze", 192, 640, 2), ("vgg", 120, 392, 1)])
+def test_fp16_engine_matches_fp16_oracle(graph, H, W, batch, vgg_plan, squeeze_plan, sample_images, tmp_path):
+    """BASELINE config 3: FP16 engines (fp16 storage, fp32 accumulation, fp32 bindings) against the oracle's restatement
+    of the same engine.  Tolerance: both sides round every stored activation to fp16 (relative step 2^-11 = 4.9e-4);
+    their fp32 sums differ in order, so a value next to a rounding boundary may land one fp16 step apart and the
+    difference propagates through the following layers: |gpu - oracle| <= 4e-3 * max(1, max|oracle|) per tensor
+    (a handful of steps), and <= 4e-3 on the unit-norm descriptors."""
+    import copy
+    from spvo import weights
+    plan = copy.copy(vgg_plan if graph == "vgg" else squeeze_plan)
+    plan.precision = "FP16"
+    path = str(tmp_path / weights.engine_name(graph, 2, H, W, "FP16"))
+    weights.save(plan, path)
+    ctx = make_ctx(path, net_height=H, net_width=W)
+    assert ctx.engine_precision() == "FP16"
+    x = _input(sample_images, H, W, batch)
+    det, desc = ctx.forward(x)
+    rdet, rdesc, vals = net.forward(plan, x, return_all=True)
+    for tid, (ch, lvl) in enumerate(plan.tensors):
+        if tid in (plan.input_tensor, plan.desc_tensor):
+            continue
+        got = ctx.debug_tensor(tid, batch, ch, lvl)
+        tol = 4e-3 * max(1.0, float(np.abs(vals[tid]).max()))
+        assert np.abs(got - vals[tid]).max() <= tol, f"tensor {tid}: {np.abs(got - vals[tid]).max()} > {tol}"
+    assert np.abs(det - rdet).max() <= 4e-3 * max(1.0, float(np.abs(rdet).max()))
+    assert np.abs(desc - rdesc.transpose(0, 2, 3, 1)).max() <= 4e-3
+    assert np.allclose(np.linalg.norm(desc, axis=-1), 1.0, atol=1e-5)
+    # and the half-precision engine stays close to the fp32 one (sanity of the whole path, not a parity bar)
+    plan32 = copy.copy(plan)
+    plan32.precision = "FP32"
+    d32, _ = net.forward(plan32, x)
+    assert np.abs(det - d32).max() <= 2e-2 * max(1.0, float(np.abs(d32).max()))
     ctx.close()
 
 

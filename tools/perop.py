@@ -4,13 +4,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "superpoint-stereo-visual-odometry_amd"))
 import numpy as np
 from spvo import capi, weights
-if len(sys.argv) > 1:   # a committed fixture: squeeze | mbv1 | mbv2
-    p = os.path.join(ROOT, "tests", "golden", f"sp_{sys.argv[1]}.spvw")
-else:
-    plan = weights.vgg_plan()
-    p = os.path.join(tempfile.mkdtemp(), "w.spvw"); weights.save(plan, p)
-ctx = capi.Context(); ctx.load_weights(p)
-x = np.random.RandomState(0).rand(2, 1, 360, 1176).astype(np.float32)
+# usage: perop.py [vgg|squeeze|mbv1|mbv2] [FP32|FP16] [HxW]
+graph = sys.argv[1] if len(sys.argv) > 1 else "vgg"
+prec = sys.argv[2] if len(sys.argv) > 2 else "FP32"
+H, Wd = (int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "360x1176").split("x"))
+plan = weights.vgg_plan() if graph == "vgg" else weights.load(os.path.join(ROOT, "tests", "golden", f"sp_{graph}.spvw"))
+plan.precision = prec
+p = os.path.join(tempfile.mkdtemp(), "w.spvw"); weights.save(plan, p)
+ctx = capi.Context(net_height=H, net_width=Wd); ctx.load_weights(p)
+x = np.random.RandomState(0).rand(2, 1, H, Wd).astype(np.float32)
 for _ in range(20): ctx.forward(x)
 ctx.profile_enable(True); ctx.profile_reset()
 for _ in range(50): ctx.forward(x)
