@@ -414,6 +414,41 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
   }
 }
 
+// K1 for 3x3 without BatchNorm (conv1a of every graph): one thread = 4 consecutive pixels, so each output channel
+// leaves as one aligned 16-byte store per lane (1 KiB per wave instruction) instead of four 4-byte ones; the layer
+// writes cout planes and is bound by that.
+template <bool RELU>
+__global__ __launch_bounds__(256) void conv_first4_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                          const float *__restrict__ w,  // [cout][9]
+                                                          const float *__restrict__ bias, int H, int W, int hp, int wp,
+                                                          int out_ctot, int out_coff, int cout) {
+  const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int img = blockIdx.z;
+  if (x >= W || y >= H) return;   // W is a multiple of 8: a thread's 4 pixels are all inside or all outside
+  const size_t plane = (size_t)hp * wp;
+  const float *ip = in + (size_t)img * plane + (size_t)(y + PADY - 1) * wp + (x + PADX);
+  float v[3][6];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const float *rp = ip + (size_t)ky * wp;
+    const float4 m = *reinterpret_cast<const float4 *>(rp);
+    v[ky][0] = rp[-1]; v[ky][1] = m.x; v[ky][2] = m.y; v[ky][3] = m.z; v[ky][4] = m.w; v[ky][5] = rp[4];
+  }
+  float *op = out + ((size_t)img * out_ctot + out_coff) * plane + (size_t)(y + PADY) * wp + (x + PADX);
+  for (int co = 0; co < cout; ++co) {
+    float s[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s[i] = bias[co];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) s[i] = fmaf(w[co * 9 + t], v[t / 3][i + t % 3], s[i]);   // same tap order as the 1-pixel kernel
+      if (RELU) s[i] = fmaxf(s[i], 0.f);
+    }
+    *reinterpret_cast<float4 *>(op + (size_t)co * plane) = make_float4(s[0], s[1], s[2], s[3]);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // K1b: depthwise 3x3 convolution (+ bias, ReLU) of the MobileNet graphs: 9 MACs per output, so the
 // layer is HBM-bound (read a plane, write a plane).  One thread = 4 consecutive pixels of one row of

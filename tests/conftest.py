@@ -23,6 +23,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """PyTorch ships its own HIP runtime; libspvo.so links the system one.  Both work in one process when torch
+    initialises the device FIRST (the order bench.py uses); the reverse order leaves torch without a device
+    ("No HIP GPUs are available").  Some GPU tests hand torch device buffers to the library, so fix the order here."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:   # no torch / no GPU: the CPU suite does not need it
+        pass
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -119,3 +119,30 @@ def test_two_submissions_in_flight(ctx_squeeze, stereo_pair):
     for (gi, gd), (ri, rd) in zip(got_m, ref_m):
         assert np.array_equal(gi, ri) and np.array_equal(gd, rd)
     ctx_squeeze.set_prematch(False, "KNN", False, 0.8)
+
+
+def test_keypoint_cap_2048(vgg_weights_path, vgg_plan, stereo_pair):
+    """BASELINE config 5 raises the reference's static cap of 1000 keypoints (hpp:368) to 2048: the cap is a
+    context parameter; NMS (on the same heat map) stays bit-exact against the oracle and the matcher handles 2048 x 2048."""
+    from tests.conftest import make_ctx
+    frames, _, P_l, P_r = stereo_pair
+    L, R = frames[0]
+    ctx = make_ctx(vgg_weights_path, max_keypoints=2048)
+    out = ctx.detect(L, R, P_l, P_r, 0, 1)
+    assert len(out["xy_l"]) == 2048 and len(out["xy_r"]) == 2048            # the seeded VGG yields ~13 k candidates
+    x = fe.preprocess(L, P_l, 360, 1176, True)[0].astype(np.float32)[None, None] / 255.0
+    det, _ = ctx.forward(x)
+    heat = ctx.heatmap(det[0])
+    assert np.array_equal(ctx.nms(heat), fe.nms(heat, 0.015, 4, 4, 2048))   # same heat map -> bit-exact keypoints, 2048 of them
+    idx, d = ctx.match_slots(0, 1, 2048)
+    ridx, rd = matching.bf_match(out["desc_l"], out["desc_r"], "KNN", False, 0.8)
+    # The seeded (untrained) VGG produces clusters of numerically identical descriptors: squared distances of 1e-10
+    # and below, under the ~1e-7 resolution of the distance GEMM that builds the matcher's shortlist (|a|^2 + |b|^2 -
+    # 2ab in fp32).  Rows whose 6 nearest candidates lie within 1e-6 of each other are therefore not resolvable by
+    # the shortlist; every other row must be bit-exact (with trained weights no such row exists: test above).
+    d2 = np.sort(matching.sq_distances(out["desc_l"], out["desc_r"]), axis=1)
+    resolvable = (d2[:, 5] - d2[:, 0]) > 1e-6
+    assert resolvable.mean() > 0.95
+    assert np.array_equal(idx[resolvable], ridx[resolvable]) and np.array_equal(d[resolvable], rd[resolvable])
+    assert (idx != ridx).sum() <= 0.02 * len(idx)
+    ctx.close()
