@@ -263,6 +263,9 @@ int spvo_synchronize(spvo_ctx *ctx);
  * Stage names: "conv:<op index>", "net", "post", "match", ...; see DESIGN.md. */
 int spvo_profile_enable(spvo_ctx *ctx, int on);
 int spvo_profile_reset(spvo_ctx *ctx);
+/* Restrict the timing to ONE stage (e.g. "conv:1"); NULL or "" = every stage again.  Two event records per step
+ * instead of two per kernel: the way to time a kernel inside a throughput measurement without slowing it down. */
+int spvo_profile_only(spvo_ctx *ctx, const char *stage);
 int spvo_profile_count(spvo_ctx *ctx);
 int spvo_profile_get(spvo_ctx *ctx, int i, char *name, size_t name_cap, double *total_ms,
                      long long *calls, double *flops_per_call, double *bytes_per_call);

@@ -182,6 +182,7 @@ struct spvo_ctx {
 
   // profiling
   bool prof = false;
+  int prof_only = -1;            // >= 0: only this stage is timed (spvo_profile_only)
   std::vector<Stage> stages;
   std::vector<Pending> pending;
   std::vector<hipEvent_t> free_events;
@@ -256,7 +257,7 @@ struct ScopedStage {
   hipEvent_t e0 = nullptr;
   hipStream_t st = nullptr;
   ScopedStage(spvo_ctx *ctx, int stage, double flops = 0, double bytes = 0, hipStream_t stream = nullptr) : c(ctx) {
-    if (!c->prof || stage < 0) return;
+    if (!c->prof || stage < 0 || (c->prof_only >= 0 && stage != c->prof_only)) return;
     id = stage;
     st = stream ? stream : (c->post ? c->post : c->stream);
     if (flops > 0) c->stages[id].flops = flops;
@@ -1431,7 +1432,8 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   c->cur_ring = ring;
   c->post = c->stream;
   hipEvent_t det_e0 = nullptr;
-  if (c->prof) { det_e0 = get_event(c); (void)hipEventRecord(det_e0, c->stream); }
+  const bool prof_detect = c->prof && (c->prof_only < 0 || c->prof_only == stage_id(c, "detect"));
+  if (prof_detect) { det_e0 = get_event(c); (void)hipEventRecord(det_e0, c->stream); }
   {
     ScopedStage sp(c, stage_id(c, "preprocess"));
     for (int i = 0; i < 2; ++i) { int rc = launch_preprocess(c, srcs[i], rows, cols, stride, g, i); if (rc) return rc; }
@@ -1457,7 +1459,7 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   }
   if (!rc) rc = enqueue_sample(c, slots, np, ring);
   if (!rc && c->prematch) rc = enqueue_prematch(c, slot_l, slot_r, prev_l, ring);
-  if (!rc && c->prof) {   // "detect" spans both streams: first kernel on `stream` .. last copy on `stream_t`
+  if (!rc && prof_detect) {   // "detect" spans both streams: first kernel on `stream` .. last copy on `stream_t`
     hipEvent_t e1 = get_event(c);
     (void)hipEventRecord(e1, c->stream_t);
     c->pending.push_back({stage_id(c, "detect"), det_e0, e1});
@@ -1842,6 +1844,13 @@ int spvo_profile_enable(spvo_ctx *c, int on) {
   if (!c) return fail(c, SPVO_ERR_INVALID, "null context");
   if (!on) resolve_pending(c);
   c->prof = on != 0;
+  return SPVO_OK;
+}
+
+int spvo_profile_only(spvo_ctx *c, const char *stage) {
+  if (!c) return fail(c, SPVO_ERR_INVALID, "null context");
+  resolve_pending(c);
+  c->prof_only = (stage && *stage) ? stage_id(c, stage) : -1;
   return SPVO_OK;
 }
 

@@ -60,7 +60,7 @@ SYMBOLS = [
     "spvo_preprocess", "spvo_forward", "spvo_debug_tensor", "spvo_heatmap", "spvo_nms",
     "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_detect_dev_submit", "spvo_detect_wait", "spvo_match", "spvo_match_slots", "spvo_set_prematch",
     "spvo_triangulate", "spvo_pnp_ransac", "spvo_pnp_refine", "spvo_solve_stereo_odometry", "spvo_stream", "spvo_synchronize",
-    "spvo_profile_enable", "spvo_profile_reset", "spvo_profile_count", "spvo_profile_get",
+    "spvo_profile_enable", "spvo_profile_reset", "spvo_profile_only", "spvo_profile_count", "spvo_profile_get",
 ]
 
 _lib = None
@@ -108,6 +108,7 @@ def load() -> C.CDLL:
     lib.spvo_synchronize.argtypes = [vp]
     lib.spvo_profile_enable.argtypes = [vp, C.c_int]
     lib.spvo_profile_reset.argtypes = [vp]
+    lib.spvo_profile_only.argtypes = [vp, C.c_char_p]
     lib.spvo_profile_count.argtypes = [vp]
     lib.spvo_profile_get.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t, dp, C.POINTER(C.c_longlong), dp, dp]
     _lib = lib
@@ -356,6 +357,10 @@ class Context:
 
     def profile_reset(self):
         self._check(self.lib.spvo_profile_reset(self.h))
+
+    def profile_only(self, stage=None):
+        """Time one stage only (e.g. "conv:1"); None = every stage."""
+        self._check(self.lib.spvo_profile_only(self.h, stage.encode() if stage else None))
 
     def profile(self):
         out = {}
