@@ -110,9 +110,6 @@ struct spvo_ctx {
   hipStream_t stream2 = nullptr;   // fused solve: overlaps with a detector submission in flight
   hipStream_t stream_t = nullptr;  // detector tail (heat map, NMS, sampling, matching): overlaps with the NEXT submission's network
   hipStream_t post = nullptr;      // where post-processing is enqueued right now: `stream`, or `stream_t` for a submission
-  hipStream_t stream3 = nullptr;   // second image of the pair through the small layers
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  int split_level = 99;   // measured: no gain from per-image streams on MI355X (kernels of two streams do not backfill); off
   std::deque<PendingDetect> pendq;
   int cur_ring = 0;                // set whose network outputs the running forward pass writes
   unsigned submit_count = 0;
@@ -512,31 +509,14 @@ int launch_op(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream
   return SPVO_OK;
 }
 
-// The two images of a stereo pair are independent through the whole network.  Big layers run as
-// one launch over both images; from `split_level` on (small maps: the grid no longer fills the
-// chip evenly) each image gets its own stream, so that the ragged tail of one image's layer is
-// filled by the other image's kernels.
+// Both images of a stereo pair go through every layer in ONE launch (they are independent, the batch index is part
+// of the tile id).  Per-image streams for the small layers were measured and gave nothing: two persistent
+// kernels do not backfill each other's ragged ends.
 int run_network(spvo_ctx *c, int batch) {
   ScopedStage net(c, stage_id(c, "net"));
-  bool forked = false;
   for (auto &op : c->ops) {
-    const bool split = batch == 2 && c->tensors[op.in].level >= c->split_level;
-    if (split && !forked) {
-      HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
-      HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
-      forked = true;
-    }
-    int rc;
-    if (forked) {
-      if ((rc = launch_op(c, op, 0, 1, c->stream))) return rc;
-      if ((rc = launch_op(c, op, 1, 1, c->stream3))) return rc;
-    } else {
-      if ((rc = launch_op(c, op, 0, batch, c->stream))) return rc;
-    }
-  }
-  if (forked) {
-    HIP_TRY(c, hipEventRecord(c->ev_join, c->stream3));
-    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    int rc = launch_op(c, op, 0, batch, c->stream);
+    if (rc) return rc;
   }
   c->last_batch = batch;
   return SPVO_OK;
@@ -914,12 +894,9 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
   spvo_ctx *c = new spvo_ctx();
   c->cfg = *cfg;
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (const char *e = std::getenv("SPVO_SPLIT_LEVEL")) c->split_level = std::atoi(e);
   c->H = cfg->net_height; c->W = cfg->net_width; c->Hc = c->H / 8; c->Wc = c->W / 8; c->B = 2;
   if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess ||
-      hipStreamCreate(&c->stream3) != hipSuccess || hipStreamCreate(&c->stream_t) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+      hipStreamCreate(&c->stream_t) != hipSuccess) {
     delete c;
     return fail(nullptr, SPVO_ERR_DEVICE, "cannot create a stream on device %d", cfg->device);
   }
@@ -994,7 +971,6 @@ void spvo_destroy(spvo_ctx *c) {
   (void)hipSetDevice(c->cfg.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
-  if (c->stream3) (void)hipStreamSynchronize(c->stream3);
   if (c->stream_t) (void)hipStreamSynchronize(c->stream_t);
   resolve_pending(c);
   for (auto e : c->free_events) (void)hipEventDestroy(e);
@@ -1027,9 +1003,6 @@ void spvo_destroy(spvo_ctx *c) {
   if (c->stream_t) (void)hipStreamDestroy(c->stream_t);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
-  if (c->stream3) (void)hipStreamDestroy(c->stream3);
-  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   delete c;
 }
 
@@ -1509,6 +1482,8 @@ static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_feature
   const NmsPair np = nms_pair(c, pd.ring);
   if (!rc) rc = nms_settle(c, 2, np, pd.ring, &redone);
   if (!rc && (redone || pd.rematch)) {   // rare: keypoints changed after the first batch -> redo what depends on them
+    if (redone) c->stages[stage_id(c, "nms_redo")].calls += 1;       // counted even with profiling off (tests, diagnostics)
+    if (pd.rematch) c->stages[stage_id(c, "rematch")].calls += 1;
     if (redone) rc = enqueue_sample(c, slots, np, pd.ring);
     if (!rc && c->prematch) rc = enqueue_prematch(c, pd.slot_l, pd.slot_r, pd.prev_l, pd.ring);
     if (!rc && extras) rc = copy_extras();

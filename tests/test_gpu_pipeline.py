@@ -146,3 +146,41 @@ def test_keypoint_cap_2048(vgg_weights_path, vgg_plan, stereo_pair):
     assert np.array_equal(idx[resolvable], ridx[resolvable]) and np.array_equal(d[resolvable], rd[resolvable])
     assert (idx != ridx).sum() <= 0.02 * len(idx)
     ctx.close()
+
+
+def test_nms_redo_with_two_submissions_in_flight(vgg_plan, tmp_path):
+    """The rare path of spvo_detect_wait: the first batch of NMS rounds leaves candidates undecided, so the host
+    enqueues more rounds, re-samples the descriptors and redoes the matches of that submission AND the temporal
+    match of the younger submission that had already matched against the replaced keypoints.  Forced here with
+    all-zero images and a threshold below the uniform response (every pixel is a candidate and ties with its
+    neighbours: one decision chain across the whole picture)."""
+    import torch
+    from spvo import weights
+    from tests.conftest import make_ctx
+    H, W = 120, 392
+    path = str(tmp_path / weights.engine_name("superpoint_pretrained", 2, H, W, "FP32"))
+    weights.save(vgg_plan, path)
+    ctx = make_ctx(path, net_height=H, net_width=W, conf_thresh=0.001)
+    P_l, P_r = synth.projection_matrices()
+    z = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+    args = (z.data_ptr(), z.data_ptr(), H, W, z.stride(0))
+    ctx.set_prematch(True, "NN", False, 0.8)
+    a = ctx.detect_dev(*args, P_l, P_r, 0, 1)
+    n = len(a["xy_l"])
+    assert n > 100                                                          # one keypoint per 5x5 cell of the interior
+    ref_xy = a["xy_l"].copy()
+    ref_b = ctx.detect_dev(*args, P_l, P_r, 2, 3)
+    ref_m = (ctx.match_slots(2, 3, n, "NN", False), ctx.match_slots(2, 0, n, "NN", False))
+    ref_m = tuple((i.copy(), d.copy()) for i, d in ref_m)
+    assert np.array_equal(ref_b["xy_l"], ref_xy)
+    ctx.detect_dev_submit(*args, 4, 5)
+    ctx.detect_dev_submit(*args, 6, 7)
+    r1 = ctx.detect_wait(P_l, P_r)
+    r2 = ctx.detect_wait(P_l, P_r)
+    assert np.array_equal(r1["xy_l"], ref_xy) and np.array_equal(r2["xy_l"], ref_xy) and np.array_equal(r2["xy_r"], ref_xy)
+    got = (ctx.match_slots(6, 7, n, "NN", False), ctx.match_slots(6, 4, n, "NN", False))
+    for (gi, gd), (ri, rd) in zip(got, ref_m):
+        assert np.array_equal(gi, ri) and np.array_equal(gd, rd)
+    prof = ctx.profile()
+    assert prof["nms_redo"]["calls"] >= 4 and prof["rematch"]["calls"] >= 1      # the path under test really ran
+    ctx.close()
