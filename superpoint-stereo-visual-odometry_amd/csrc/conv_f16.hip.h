@@ -44,6 +44,10 @@ struct ConvArgs16 {
   int n_chunks;           // cin / (8 * CKG)
   int tiles_x, tiles_y, co_tiles;
   int batch;
+  // MobileNet epilogues (EPI template parameter), applied per element in fp32 BEFORE pooling and the fp16 rounding
+  const float *bn_scale = nullptr, *bn_shift = nullptr;  // EPI 1: v = relu(v * scale[co] + shift[co]), [co_tiles*64]
+  const _Float16 *residual = nullptr;                    // EPI 2: v = relu(v + residual[co][y][x]); C8 tensor of the input's
+                                                         //        geometry (in_hp x in_wp) with cout channels, image 0
 };
 
 template <int KS, int CKG_, int WR, int WC>
@@ -81,7 +85,7 @@ inline std::vector<_Float16> pack_conv_weights_f16(const float *w, const float *
   return out;
 }
 
-template <int KS, int CKG_, int WR, int WC, bool POOL, bool RELU, bool OUT_F32>
+template <int KS, int CKG_, int WR, int WC, bool POOL, bool RELU, bool OUT_F32, int EPI = 0>
 __global__ __launch_bounds__(256) void conv_f16_kernel(const ConvArgs16 a) {
   using T = ConvTile16<KS, CKG_, WR, WC>;
   constexpr int NT = WR * WC, CKG = T::CKG, LW = T::LW, LH = T::LH, NSTEP = T::NSTEP;
@@ -89,6 +93,7 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const ConvArgs16 a) {
   constexpr int NIT = (TOT_P + 255) / 256;
   static_assert(!POOL || WR == 2, "fused pooling needs both rows of a 2x2 window in one wave");
   static_assert(!(POOL && OUT_F32), "the fp32-output layers are the unpooled heads");
+  static_assert(EPI == 0 || !OUT_F32, "BatchNorm / residual epilogues write C8");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];   // 2 buffers of BUF_P 16-byte pieces
 
@@ -248,6 +253,22 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const ConvArgs16 a) {
       _Float16 *g_base = reinterpret_cast<_Float16 *>(a.out) + ((size_t)cur.img * (a.out_ctot / 8) + a.out_coff / 8 + (size_t)cur.ct * (CO_TILE / 8)) * out_plane * 8;
       const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(g_base, 0, 0x7FFFFFFF, 0x00020000);
       const int groups_valid = (a.cout - cur.ct * CO_TILE + 7) / 8;   // groups of this co tile that exist
+      // element-wise tail in graph order: ReLU, then (EPI 1) BatchNorm + ReLU or (EPI 2) residual + ReLU; register r of
+      // accumulator row block m is channel ct*64 + 32m + (r&3) + 8(r>>2) + 4*half of pixel (y, x) of the INPUT resolution
+      const size_t res_plane = (size_t)a.in_hp * a.in_wp;
+      auto tail = [&](float v, int m, int r, int y, int x) -> float {
+        v = relu(v);
+        if constexpr (EPI != 0) {
+          const int co = cur.ct * CO_TILE + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if constexpr (EPI == 1) v = __builtin_amdgcn_fmed3f(fmaf(v, a.bn_scale[co], a.bn_shift[co]), 0.f, __builtin_inff());
+          if constexpr (EPI == 2) {
+            // the padded plane covers the whole tile (zeros outside the image); channels past cout do not exist
+            const float rv = co < a.cout ? (float)a.residual[((((size_t)cur.img * (a.cout / 8) + co / 8) * res_plane + (size_t)(y + PADY) * a.in_wp + (x + PADX)) * 8) + (co & 7)] : 0.f;
+            v = __builtin_amdgcn_fmed3f(v + rv, 0.f, __builtin_inff());
+          }
+        }
+        return v;
+      };
       auto store_tile = [&](const float (&v)[16], int m, unsigned voff) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -270,7 +291,7 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const ConvArgs16 a) {
               const unsigned voff = ((y < a.H) && (x < a.W)) ? (unsigned)(((y + PADY) * a.out_wp + (x + PADX)) * 16 + 8 * half) : OOB;
               float v[16];
 #pragma unroll
-              for (int r = 0; r < 16; ++r) v[r] = relu(acc[m][rr * WC + cc][r]);
+              for (int r = 0; r < 16; ++r) v[r] = tail(acc[m][rr * WC + cc][r], m, r, y, x);
               store_tile(v, m, voff);
             }
       } else {
@@ -284,9 +305,16 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const ConvArgs16 a) {
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              float q = fmaxf(acc[m][0 * WC + cc][r], acc[m][1 * WC + cc][r]);   // ReLU commutes with max
-              q = fmaxf(q, __shfl_xor(q, 1));
-              v[r] = relu(q);
+              float q;
+              if constexpr (EPI == 0) {
+                q = fmaxf(acc[m][0 * WC + cc][r], acc[m][1 * WC + cc][r]);   // ReLU commutes with max
+                q = relu(fmaxf(q, __shfl_xor(q, 1)));
+              } else {
+                const int yi = cur.y0 + wave * 2, xi = cur.x0 + cc * 32 + j;
+                q = fmaxf(tail(acc[m][0 * WC + cc][r], m, r, yi, xi), tail(acc[m][1 * WC + cc][r], m, r, yi + 1, xi));
+                q = fmaxf(q, __shfl_xor(q, 1));
+              }
+              v[r] = q;
             }
             store_tile(v, m, voff);
           }
@@ -296,24 +324,27 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const ConvArgs16 a) {
   }
 }
 
-// First layer of an FP16 engine: Cin = 1 fp32 plane in (the network input stays fp32, nn.cpp:117), C8 fp16 out.
-// fp32 arithmetic on fp16-rounded weights; one thread = one pixel, 8 channels = one 16-byte store.
-template <bool RELU>
+// Layers of an FP16 engine with Cin = 1 (fp32 plane in: the network input, nn.cpp:117, or mbv's one-channel
+// stem) and a C8 fp16 output: fp32 arithmetic on fp16-rounded weights; one thread = one pixel, 8 channels = one
+// 16-byte store.  bn_scale != nullptr: BatchNorm + ReLU after the activation (mbv1's second layer).
+template <int KS, bool RELU>
 __global__ __launch_bounds__(256) void conv_first_f16_kernel(const float *__restrict__ in, _Float16 *__restrict__ out,
-                                                              const float *__restrict__ w,     // [cout][9], already fp16-rounded values
-                                                              const float *__restrict__ bias, int H, int W, int hp, int wp, int out_gtot,
+                                                              const float *__restrict__ w,     // [cout][KS*KS], already fp16-rounded values
+                                                              const float *__restrict__ bias, const float *__restrict__ bn_scale,
+                                                              const float *__restrict__ bn_shift, int H, int W, int hp, int wp, int out_gtot,
                                                               int out_goff, int cout) {
+  constexpr int TAPS = KS * KS, HALO = KS / 2;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int img = blockIdx.z;
   if (x >= W || y >= H) return;
   const size_t plane = (size_t)hp * wp;
-  const float *ip = in + (size_t)img * plane + (size_t)(y + PADY - 1) * wp + (x + PADX - 1);
-  float v[9];
+  const float *ip = in + (size_t)img * plane + (size_t)(y + PADY - HALO) * wp + (x + PADX - HALO);
+  float v[TAPS];
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky)
+  for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) v[ky * 3 + kx] = ip[ky * wp + kx];
+    for (int kx = 0; kx < KS; ++kx) v[ky * KS + kx] = ip[ky * wp + kx];
   half8 *op = reinterpret_cast<half8 *>(out) + ((size_t)img * out_gtot + out_goff) * plane + (size_t)(y + PADY) * wp + (x + PADX);
   for (int g = 0; g < cout / 8; ++g) {
     half8 hv;
@@ -322,12 +353,43 @@ __global__ __launch_bounds__(256) void conv_first_f16_kernel(const float *__rest
       const int co = g * 8 + e;
       float s = bias[co];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) s = fmaf(w[co * 9 + t], v[t], s);
+      for (int t = 0; t < TAPS; ++t) s = fmaf(w[co * TAPS + t], v[t], s);
       if (RELU) s = fmaxf(s, 0.f);
+      if (bn_scale) s = fmaxf(fmaf(s, bn_scale[co], bn_shift[co]), 0.f);
       hv[e] = (_Float16)s;
     }
     op[(size_t)g * plane] = hv;
   }
+}
+
+// Depthwise 3x3 (+ bias, ReLU) on C8: one thread = one pixel x 8 channels, nine 16-byte loads, fp32 accumulation on
+// fp16-rounded weights, one 16-byte store.  The group is blockIdx.z, so its 72 weights and 8 biases are scalar loads.
+template <bool RELU>
+__global__ __launch_bounds__(256) void dwconv3x3_f16_kernel(const _Float16 *__restrict__ in, _Float16 *__restrict__ out,
+                                                             const float *__restrict__ w,  // [C][9], fp16-rounded values
+                                                             const float *__restrict__ bias, int G, int H, int W, int hp, int wp) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int pg = blockIdx.z;   // image * G + group
+  const int g = pg % G;
+  if (x >= W || y >= H) return;
+  const size_t plane = (size_t)hp * wp;
+  const half8 *ip = reinterpret_cast<const half8 *>(in) + (size_t)pg * plane + (size_t)(y + PADY - 1) * wp + (x + PADX - 1);
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = bias[g * 8 + e];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const half8 v = ip[(size_t)ky * wp + kx];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] = fmaf(w[(g * 8 + e) * 9 + ky * 3 + kx], (float)v[e], s[e]);
+    }
+  half8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (_Float16)(RELU ? fmaxf(s[e], 0.f) : s[e]);
+  reinterpret_cast<half8 *>(out)[(size_t)pg * plane + (size_t)(y + PADY) * wp + (x + PADX)] = r;
 }
 
 // Stand-alone 2x2/2 max-pool on C8 (squeeze graph: pool after a Concat).  One thread = one output pixel of one group.

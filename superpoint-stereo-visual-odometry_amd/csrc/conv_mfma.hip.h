@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
                                                          const float *__restrict__ bn_scale,
                                                          const float *__restrict__ bn_shift, int H,
                                                          int W, int hp, int wp, int out_ctot,
-                                                         int out_coff, int cout) {
+                                                         int out_coff, int cout, int round16 = 0) {
   constexpr int TAPS = KS * KS, HALO = KS / 2;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -410,6 +410,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
     for (int t = 0; t < TAPS; ++t) s = fmaf(w[co * TAPS + t], v[t], s);
     if (RELU) s = fmaxf(s, 0.f);
     if (bn_scale) s = fmaxf(fmaf(s, bn_scale[co], bn_shift[co]), 0.f);
+    if (round16) s = (float)(_Float16)s;   // an fp32-stored tensor inside an FP16 engine holds fp16 values
     op[(size_t)co * plane] = s;
   }
 }

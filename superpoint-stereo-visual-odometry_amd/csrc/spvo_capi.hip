@@ -413,10 +413,10 @@ int launch_conv(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stre
 }
 
 // ---------------------------------------------------------------- FP16 engines
-template <int KS, int CKG, int WR, int WC, bool POOL, bool RELU, bool OUT_F32>
+template <int KS, int CKG, int WR, int WC, bool POOL, bool RELU, bool OUT_F32, int EPI = 0>
 int launch_conv16_instance(spvo_ctx *c, ConvArgs16 args, hipStream_t stream) {
   using T = ConvTile16<KS, CKG, WR, WC>;
-  auto k = conv_f16_kernel<KS, CKG, WR, WC, POOL, RELU, OUT_F32>;
+  auto k = conv_f16_kernel<KS, CKG, WR, WC, POOL, RELU, OUT_F32, EPI>;
   static int per_cu[64] = {};
   const int dev = c->cfg.device & 63;
   if (!per_cu[dev]) {
@@ -441,16 +441,41 @@ int launch_conv16_variant(spvo_ctx *c, const ConvArgs16 &a, bool relu, bool out_
   return relu ? launch_conv16_instance<KS, CKG, WR, WC, POOL, true, false>(c, a, stream) : launch_conv16_instance<KS, CKG, WR, WC, POOL, false, false>(c, a, stream);
 }
 
+// MobileNet 1x1 layers of an FP16 engine: EPI 1 = ReLU, BatchNorm, ReLU (mbv1); EPI 2 = residual add, ReLU (mbv2)
+template <int CKG, int WR, int WC, bool POOL>
+int launch_conv16_epi(spvo_ctx *c, const ConvArgs16 &a, int epi, hipStream_t stream) {
+  return epi == 1 ? launch_conv16_instance<1, CKG, WR, WC, POOL, true, false, 1>(c, a, stream)
+                  : launch_conv16_instance<1, CKG, WR, WC, POOL, false, false, 2>(c, a, stream);
+}
+
 int launch_conv16(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream) {
   const Tensor &ti = c->tensors[op.in];
   const Tensor &to = c->tensors[op.out];
   const float *tin = (ti.dr[c->cur_ring] ? ti.dr[c->cur_ring] : ti.d) + (size_t)img0 * ti.per_image;
   float *tout = (to.dr[c->cur_ring] ? to.dr[c->cur_ring] : to.d) + (size_t)img0 * to.per_image;
   const bool relu = op.flags & FLAG_RELU, pool = op.flags & FLAG_POOL;
+  if (op.type == OP_DWCONV) {
+    dim3 grid((ti.W + 63) / 64, (ti.H + 3) / 4, batch * (op.cout / 8));
+    if (relu) hipLaunchKernelGGL(dwconv3x3_f16_kernel<true>, grid, dim3(256), 0, stream, (const _Float16 *)tin, (_Float16 *)tout, op.d_w, op.d_b, op.cout / 8, ti.H, ti.W, ti.hp, ti.wp);
+    else hipLaunchKernelGGL(dwconv3x3_f16_kernel<false>, grid, dim3(256), 0, stream, (const _Float16 *)tin, (_Float16 *)tout, op.d_w, op.d_b, op.cout / 8, ti.H, ti.W, ti.hp, ti.wp);
+    HIP_TRY(c, hipGetLastError());
+    return SPVO_OK;
+  }
   if (op.cin == 1) {
     dim3 grid((ti.W + 63) / 64, (ti.H + 3) / 4, batch);
-    if (relu) hipLaunchKernelGGL(conv_first_f16_kernel<true>, grid, dim3(256), 0, stream, tin, (_Float16 *)tout, op.d_w, op.d_b, ti.H, ti.W, ti.hp, ti.wp, to.ch / 8, op.out_c_off / 8, op.cout);
-    else hipLaunchKernelGGL(conv_first_f16_kernel<false>, grid, dim3(256), 0, stream, tin, (_Float16 *)tout, op.d_w, op.d_b, ti.H, ti.W, ti.hp, ti.wp, to.ch / 8, op.out_c_off / 8, op.cout);
+    if (to.f16) {
+#define SPVO_FIRST16(KS, RELU) hipLaunchKernelGGL((conv_first_f16_kernel<KS, RELU>), grid, dim3(256), 0, stream, tin, (_Float16 *)tout, op.d_w, op.d_b, \
+                                                  op.d_bn_scale, op.d_bn_shift, ti.H, ti.W, ti.hp, ti.wp, to.ch / 8, op.out_c_off / 8, op.cout)
+      if (op.ks == 3) { if (relu) SPVO_FIRST16(3, true); else SPVO_FIRST16(3, false); }
+      else            { if (relu) SPVO_FIRST16(1, true); else SPVO_FIRST16(1, false); }
+#undef SPVO_FIRST16
+    } else {   // a stem with fewer than 8 channels stays an fp32 plane that holds fp16 values
+#define SPVO_FIRST(KS, RELU) hipLaunchKernelGGL((conv_first_kernel<KS, RELU>), grid, dim3(256), 0, stream, tin, tout, op.d_w, op.d_b, \
+                                                op.d_bn_scale, op.d_bn_shift, ti.H, ti.W, ti.hp, ti.wp, to.ch, op.out_c_off, op.cout, 1)
+      if (op.ks == 3) { if (relu) SPVO_FIRST(3, true); else SPVO_FIRST(3, false); }
+      else            { if (relu) SPVO_FIRST(1, true); else SPVO_FIRST(1, false); }
+#undef SPVO_FIRST
+    }
     HIP_TRY(c, hipGetLastError());
     return SPVO_OK;
   }
@@ -464,6 +489,24 @@ int launch_conv16(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t st
   a.batch = batch;
   const bool out_f32 = !to.f16;
   const int key = op.ks * 10000 + (op.ck / 8) * 1000 + op.wr * 100 + op.wc * 10 + (pool ? 1 : 0);   // ks, groups per chunk, wr, wc, pool
+  const int epi = (op.flags & FLAG_BN) ? 1 : (op.flags & FLAG_ADD) ? 2 : 0;
+  if (epi) {
+    a.bn_scale = op.d_bn_scale; a.bn_shift = op.d_bn_shift;
+    if (epi == 2) a.residual = (const _Float16 *)(c->tensors[op.residual].d + (size_t)img0 * c->tensors[op.residual].per_image);
+    switch (key) {
+      case 14220: return launch_conv16_epi<4, 2, 2, false>(c, a, epi, stream);
+      case 14120: return launch_conv16_epi<4, 1, 2, false>(c, a, epi, stream);
+      case 14110: return launch_conv16_epi<4, 1, 1, false>(c, a, epi, stream);
+      case 14221: return launch_conv16_epi<4, 2, 2, true>(c, a, epi, stream);
+      case 14211: return launch_conv16_epi<4, 2, 1, true>(c, a, epi, stream);
+      case 12220: return launch_conv16_epi<2, 2, 2, false>(c, a, epi, stream);
+      case 12120: return launch_conv16_epi<2, 1, 2, false>(c, a, epi, stream);
+      case 12110: return launch_conv16_epi<2, 1, 1, false>(c, a, epi, stream);
+      case 12221: return launch_conv16_epi<2, 2, 2, true>(c, a, epi, stream);
+      case 12211: return launch_conv16_epi<2, 2, 1, true>(c, a, epi, stream);
+      default: return fail(c, SPVO_ERR_INVALID, "no fp16 conv kernel variant for key %d with epilogue %d", key, epi);
+    }
+  }
   switch (key) {
     case 32220: return launch_conv16_variant<3, 2, 2, 2, false>(c, a, relu, out_f32, stream);
     case 32210: return launch_conv16_variant<3, 2, 2, 1, false>(c, a, relu, out_f32, stream);
@@ -1063,15 +1106,12 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
   if (c->fp16) {
     // half precision between the fp32 network input and the fp32 outputs (nn.cpp:117): every tensor but the input,
     // output_det, the raw descriptor map and output_desc is C8 fp16
-    for (auto &t : c->tensors) t.f16 = true;
+    // (a tensor whose channel count is not a multiple of 8 -- mbv's one-channel stem -- stays an fp32 plane that
+    // holds fp16 values)
+    for (auto &t : c->tensors) t.f16 = (t.ch % 8) == 0;
     c->tensors[c->t_input].f16 = c->tensors[c->t_det].f16 = c->tensors[c->t_desc].f16 = false;
-    for (const auto &op : c->ops) {
+    for (const auto &op : c->ops)
       if (op.type == OP_L2NORM) c->tensors[op.in].f16 = false;
-      if (op.type == OP_DWCONV || (op.flags & (FLAG_BN | FLAG_ADD)))
-        return fail(c, SPVO_ERR_IO, "%s: FP16 engines run the VGG and squeeze graphs; MobileNet layers (depthwise, BatchNorm, residual) are FP32 only", path);
-    }
-    for (size_t ti = 0; ti < c->tensors.size(); ++ti)
-      if (c->tensors[ti].f16 && c->tensors[ti].ch % 8) return fail(c, SPVO_ERR_IO, "%s: tensor %zu has %d channels, not a multiple of 8", path, ti, c->tensors[ti].ch);
   }
   // allocate activations (padded planes stay zero outside the interior for ever)
   for (size_t ti = 0; ti < c->tensors.size(); ++ti) {
@@ -1099,10 +1139,13 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
         return fail(c, SPVO_ERR_IO, "op %u: unsupported depthwise convolution", i);
       if (r.w_off + (uint64_t)op.cout * 9 > nfl || r.b_off + op.cout > nfl) return fail(c, SPVO_ERR_IO, "op %u: weights out of range", i);
       op.flops_per_image = 2.0 * ti.H * ti.W * op.cout * 9;
+      if (c->fp16 && (!ti.f16 || !to.f16)) return fail(c, SPVO_ERR_IO, "op %u: depthwise convolution of an FP16 engine needs channel counts that are multiples of 8", i);
+      std::vector<float> wdw(payload + r.w_off, payload + r.w_off + (size_t)op.cout * 9);
+      if (c->fp16) for (auto &q : wdw) q = (float)(_Float16)q;
       int rc = dev_alloc(c, &op.d_w, (size_t)op.cout * 9, false);
       if (rc) return rc;
       if ((rc = dev_alloc(c, &op.d_b, op.cout, false))) return rc;
-      HIP_TRY(c, hipMemcpy(op.d_w, payload + r.w_off, (size_t)op.cout * 9 * 4, hipMemcpyHostToDevice));
+      HIP_TRY(c, hipMemcpy(op.d_w, wdw.data(), (size_t)op.cout * 9 * 4, hipMemcpyHostToDevice));
       HIP_TRY(c, hipMemcpy(op.d_b, payload + r.b_off, (size_t)op.cout * 4, hipMemcpyHostToDevice));
     } else if (op.type == OP_CONV) {
       std::snprintf(name, sizeof name, "conv:%u", i);
@@ -1144,10 +1187,10 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
       const float *w = payload + r.w_off;
       const float *b = payload + r.b_off;
       if (c->fp16) {
-        if (ti.f16 != (op.cin != 1)) return fail(c, SPVO_ERR_IO, "op %u: FP16 engine with an fp32 intermediate tensor", i);
-        if (op.cin == 1) {   // first layer: fp32 arithmetic on fp16-rounded weights, fp16 output
-          if (op.ks != 3 || pool || !to.f16 || (op.cout % 8) || (op.out_c_off % 8)) return fail(c, SPVO_ERR_IO, "op %u: unsupported first layer for FP16", i);
-          std::vector<float> wr((size_t)op.cout * 9);
+        if (ti.f16 != (op.cin != 1)) return fail(c, SPVO_ERR_IO, "op %u: FP16 engine: a %d-channel input tensor stored as %s", i, op.cin, ti.f16 ? "fp16" : "fp32");
+        if (op.cin == 1) {   // fp32 plane in: fp32 arithmetic on fp16-rounded weights, fp16 values out
+          if (pool || add || (to.f16 && (op.out_c_off % 8))) return fail(c, SPVO_ERR_IO, "op %u: unsupported single-channel-input layer for FP16", i);
+          std::vector<float> wr((size_t)op.cout * taps);
           for (size_t q = 0; q < wr.size(); ++q) wr[q] = (float)(_Float16)w[q];
           int rc = dev_alloc(c, &op.d_w, wr.size(), false);
           if (rc) return rc;
@@ -1159,6 +1202,8 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
         const int ckg = (op.ks == 3 || op.cin % 32) ? 2 : 4;   // 16 channels per chunk; 32 for 1x1 layers when they divide
         if (op.cin % (8 * ckg) || op.in_c_off % 8) return fail(c, SPVO_ERR_IO, "op %u: cin %d / channel offset %d do not fit the FP16 chunking (%d)", i, op.cin, op.in_c_off, 8 * ckg);
         if (to.f16 && ((op.cout % 8) || (op.out_c_off % 8))) return fail(c, SPVO_ERR_IO, "op %u: cout %d / channel offset %d are not multiples of 8", i, op.cout, op.out_c_off);
+        if ((bn || add) && !to.f16) return fail(c, SPVO_ERR_IO, "op %u: BatchNorm / residual epilogue with an fp32 output", i);
+        if (add && (!c->tensors[op.residual].f16 || c->tensors[op.residual].ch != op.cout)) return fail(c, SPVO_ERR_IO, "op %u: residual tensor is not a %d-channel fp16 tensor", i, op.cout);
         if (!to.f16 && pool) return fail(c, SPVO_ERR_IO, "op %u: pooled fp32 output", i);
         op.ck = 8 * ckg;
         op.n_chunks = op.cin / op.ck;

@@ -78,7 +78,8 @@ def test_mobilenet_forward_matches_oracle(name, H, W, batch, sample_images):
     ctx.close()
 
 
-@pytest.mark.parametrize("graph,H,W,batch", [("vgg", 192, 640, 2), ("vgg", 360, 1176, 2), ("squeeze", 192, 640, 2), ("vgg", 120, 392, 1)])
+@pytest.mark.parametrize("graph,H,W,batch", [("vgg", 192, 640, 2), ("vgg", 360, 1176, 2), ("squeeze", 192, 640, 2), ("vgg", 120, 392, 1),
+                                             ("mbv1", 192, 640, 2), ("mbv2", 192, 640, 2), ("mbv2", 360, 1176, 2)])
 def test_fp16_engine_matches_fp16_oracle(graph, H, W, batch, vgg_plan, squeeze_plan, sample_images, tmp_path):
     """BASELINE config 3: FP16 engines (fp16 storage, fp32 accumulation, fp32 bindings) against the oracle's restatement
     of the same engine.  Tolerance: both sides round every stored activation to fp16 (relative step 2^-11 = 4.9e-4);
@@ -87,7 +88,12 @@ def test_fp16_engine_matches_fp16_oracle(graph, H, W, batch, vgg_plan, squeeze_p
     (a handful of steps), and <= 4e-3 on the unit-norm descriptors."""
     import copy
     from spvo import weights
-    plan = copy.copy(vgg_plan if graph == "vgg" else squeeze_plan)
+    if graph in ("vgg", "squeeze"):
+        plan = copy.copy(vgg_plan if graph == "vgg" else squeeze_plan)
+    else:                                                            # depthwise, BatchNorm-after-ReLU, residual layers
+        import os
+        from tests.conftest import GOLDEN
+        plan = weights.load(os.path.join(GOLDEN, f"sp_{graph}.spvw"))
     plan.precision = "FP16"
     path = str(tmp_path / weights.engine_name(graph, 2, H, W, "FP16"))
     weights.save(plan, path)
@@ -96,14 +102,17 @@ def test_fp16_engine_matches_fp16_oracle(graph, H, W, batch, vgg_plan, squeeze_p
     x = _input(sample_images, H, W, batch)
     det, desc = ctx.forward(x)
     rdet, rdesc, vals = net.forward(plan, x, return_all=True)
+    # the MobileNet graphs are 20-27 layers deep (VGG: 12) and their BatchNorm scales amplify a one-step difference:
+    # the same kind of divergence reaches 5e-3 at their outputs, so their bar is 8e-3
+    rel = 4e-3 if graph in ("vgg", "squeeze") else 8e-3
     for tid, (ch, lvl) in enumerate(plan.tensors):
         if tid in (plan.input_tensor, plan.desc_tensor):
             continue
         got = ctx.debug_tensor(tid, batch, ch, lvl)
-        tol = 4e-3 * max(1.0, float(np.abs(vals[tid]).max()))
+        tol = rel * max(1.0, float(np.abs(vals[tid]).max()))
         assert np.abs(got - vals[tid]).max() <= tol, f"tensor {tid}: {np.abs(got - vals[tid]).max()} > {tol}"
-    assert np.abs(det - rdet).max() <= 4e-3 * max(1.0, float(np.abs(rdet).max()))
-    assert np.abs(desc - rdesc.transpose(0, 2, 3, 1)).max() <= 4e-3
+    assert np.abs(det - rdet).max() <= rel * max(1.0, float(np.abs(rdet).max()))
+    assert np.abs(desc - rdesc.transpose(0, 2, 3, 1)).max() <= rel
     assert np.allclose(np.linalg.norm(desc, axis=-1), 1.0, atol=1e-5)
     # and the half-precision engine stays close to the fp32 one (sanity of the whole path, not a parity bar)
     plan32 = copy.copy(plan)
