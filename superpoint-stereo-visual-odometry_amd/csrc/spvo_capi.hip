@@ -47,6 +47,7 @@ struct Op {
   int type = 0, in = 0, out = 0, out_c_off = 0, in_c_off = 0, cin = 0, cout = 0, ks = 0, flags = 0;
   int ck = 0, n_chunks = 0, co_tiles = 0, wr = 0, wc = 0;
   int residual = 0;  // tensor added before the last ReLU (FLAG_ADD)
+  bool dominant = false;   // the op with the most FLOPs: launched under its own kernel name (TAG = 1)
   float *d_w = nullptr, *d_b = nullptr, *d_bn_scale = nullptr, *d_bn_shift = nullptr;
   _Float16 *d_w16 = nullptr;   // FP16 engines: pack_conv_weights_f16()
   double flops_per_image = 0;
@@ -272,10 +273,10 @@ struct ScopedStage {
 };
 
 // ---------------------------------------------------------------- conv dispatch
-template <int KS, int CK, int WR, int WC, bool POOL, bool RELU, int EPI = 0, int MINW = 1>
+template <int KS, int CK, int WR, int WC, bool POOL, bool RELU, int EPI = 0, int MINW = 1, int TAG = 0>
 int launch_conv_instance(spvo_ctx *c, ConvArgs args, hipStream_t stream) {
   using T = ConvTile<KS, CK, WR, WC>;
-  auto k = conv_mfma_kernel<KS, CK, WR, WC, POOL, RELU, MINW, 0, EPI>;
+  auto k = conv_mfma_kernel<KS, CK, WR, WC, POOL, RELU, MINW, 0, EPI, TAG>;
   static int per_cu[64] = {};   // resident workgroups per CU of this instance, per device
   const int dev = c->cfg.device & 63;
   if (!per_cu[dev]) {
@@ -293,12 +294,15 @@ int launch_conv_instance(spvo_ctx *c, ConvArgs args, hipStream_t stream) {
 }
 
 template <int KS, int CK, int WR, int WC, bool POOL, int MINW = 1>
-int launch_conv_variant(spvo_ctx *c, const ConvArgs &a, int batch, bool relu, hipStream_t stream) {
+int launch_conv_variant(spvo_ctx *c, const ConvArgs &a, int batch, bool relu, hipStream_t stream, bool dominant = false) {
   using T = ConvTile<KS, CK, WR, WC>;
   ConvArgs args = a;
   args.tiles_x = (a.W + T::TW - 1) / T::TW;
   args.tiles_y = (a.H + T::TH - 1) / T::TH;
   args.batch = batch;
+  if constexpr (KS == 3) {
+    if (dominant && relu) return launch_conv_instance<KS, CK, WR, WC, POOL, true, 0, MINW, 1>(c, args, stream);   // own kernel name
+  }
   return relu ? launch_conv_instance<KS, CK, WR, WC, POOL, true, 0, MINW>(c, args, stream)
               : launch_conv_instance<KS, CK, WR, WC, POOL, false, 0, MINW>(c, args, stream);
 }
@@ -397,12 +401,12 @@ int launch_conv(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stre
     }
   }
   switch (key) {   // third template argument of the launch helper = waves per SIMD the register budget allows
-    case 30844: return launch_conv_variant<3, 8, 2, 2, false, 1>(c, a, batch, relu, stream);
-    case 30842: return launch_conv_variant<3, 8, 2, 1, false, 2>(c, a, batch, relu, stream);
-    case 30824: return launch_conv_variant<3, 8, 1, 2, false, 2>(c, a, batch, relu, stream);
-    case 30822: return launch_conv_variant<3, 8, 1, 1, false, 4>(c, a, batch, relu, stream);
-    case 30845: return launch_conv_variant<3, 8, 2, 2, true, 1>(c, a, batch, relu, stream);
-    case 30843: return launch_conv_variant<3, 8, 2, 1, true, 2>(c, a, batch, relu, stream);
+    case 30844: return launch_conv_variant<3, 8, 2, 2, false, 1>(c, a, batch, relu, stream, op.dominant);
+    case 30842: return launch_conv_variant<3, 8, 2, 1, false, 2>(c, a, batch, relu, stream, op.dominant);
+    case 30824: return launch_conv_variant<3, 8, 1, 2, false, 2>(c, a, batch, relu, stream, op.dominant);
+    case 30822: return launch_conv_variant<3, 8, 1, 1, false, 4>(c, a, batch, relu, stream, op.dominant);
+    case 30845: return launch_conv_variant<3, 8, 2, 2, true, 1>(c, a, batch, relu, stream, op.dominant);
+    case 30843: return launch_conv_variant<3, 8, 2, 1, true, 2>(c, a, batch, relu, stream, op.dominant);
     case 11644: return launch_conv_variant<1, 16, 2, 2, false>(c, a, batch, relu, stream);
     case 11624: return launch_conv_variant<1, 16, 1, 2, false>(c, a, batch, relu, stream);
     case 11622: return launch_conv_variant<1, 16, 1, 1, false>(c, a, batch, relu, stream);
@@ -1255,6 +1259,11 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
     } else {
       return fail(c, SPVO_ERR_IO, "op %u: unknown type %d", i, op.type);
     }
+  }
+  {   // mark the dominant layer
+    Op *best = nullptr;
+    for (auto &o : c->ops) if (o.type == OP_CONV && (!best || o.flops_per_image > best->flops_per_image)) best = &o;
+    if (best) best->dominant = true;
   }
   const Tensor &td = c->tensors[c->t_det];
   const Tensor &ts = c->tensors[c->t_desc];

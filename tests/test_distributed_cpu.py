@@ -29,6 +29,13 @@ def _worker(rank, world, port, q):
     first = pg.gather(None, None)                                   # frame 0: no pose yet
     mine = np.array([0.0, 0.01 * (rank + 1), 0.0, 1.0])
     allp = pg.gather(mine, t)
+    # non-blocking form (what bench.py uses): three steps enqueued, read back once, in order
+    pg.gather_async(None, None)
+    pg.gather_async(mine, t)
+    pg.gather_async(mine, 2 * t)
+    seq = pg.collect()
+    assert seq.shape == (3, world, 7) and np.allclose(seq[0], posegather.IDENTITY_POSE) and np.allclose(seq[1], allp)
+    assert np.allclose(seq[2][rank, 4:], 2 * t) and pg.collect().shape == (0, world, 7)
     q.put((rank, first, allp, t))
     dist.barrier()
     dist.destroy_process_group()
@@ -58,3 +65,5 @@ def test_single_process_gather_is_identity_passthrough():
     pg = posegather.PoseGather()
     out = pg.gather([0, 0, 0, 1], [1, 2, 3])
     assert out.shape == (1, 7) and np.allclose(out[0], [0, 0, 0, 1, 1, 2, 3])
+    pg.gather_async([0, 0, 0, 1], [1, 2, 3])
+    assert np.allclose(pg.collect(), out[None])
