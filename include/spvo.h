@@ -154,8 +154,11 @@ typedef enum { SPVO_SELECT_NN = 0, SPVO_SELECT_KNN = 1 } spvo_selector;
 /* matchDescriptors (base.cpp:434-491) = cv::BFMatcher(NORM_L2) match / knnMatch
  * k=2 + ratio test.  For every query row i: train_idx[i] = matched train row or
  * -1 (this is maps_of_indices, base.cpp:483-491) and distance[i] = L2 distance
- * of the best neighbour (valid where train_idx[i] >= 0).  NN + cross_check
- * keeps mutual nearest neighbours only (base.cpp:27-28).  KNN keeps i iff
+ * of the matched pair (valid where train_idx[i] >= 0).  NN + cross_check
+ * (base.cpp:27-28) is cv::batchDistance's crosscheck as BFMatcher runs it:
+ * every train row votes for its nearest query row and a query row keeps the
+ * nearest of its voters -- every mutual nearest-neighbour pair plus the pairs
+ * that procedure adds; unmatched rows get -1.  KNN keeps i iff
  * d0 < ratio*d1 (base.cpp:469); with nb < 2 nothing is kept. */
 int spvo_match(spvo_ctx *ctx, const float *desc_a, int na, const float *desc_b, int nb,
                int selector, int cross_check, float ratio, int32_t *train_idx, float *distance);

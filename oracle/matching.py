@@ -46,7 +46,9 @@ def best_two(d2: np.ndarray):
 
 def bf_match(desc_a: np.ndarray, desc_b: np.ndarray, selector: str = "KNN", cross_check: bool = False,
              ratio: float = 0.8):
-    """Returns (train_idx int32 [na] with -1 = no match, distance f32 [na]).
+    """Returns (train_idx int32 [na] with -1 = no match, distance f32 [na]: the matched pair's distance where
+    train_idx >= 0; for NN without cross-check and KNN the nearest neighbour's distance everywhere; 0 for rows a
+    cross-check left unmatched).
 
     train_idx is exactly maps_of_indices[match_type] of base.cpp:483-491; the
     DMatch list of the reference is {(i, train_idx[i], distance[i]) : train_idx[i] >= 0}
@@ -60,17 +62,25 @@ def bf_match(desc_a: np.ndarray, desc_b: np.ndarray, selector: str = "KNN", cros
     d0 = np.sqrt(v0.astype(np.float32))
     d1 = np.sqrt(v1.astype(np.float32))
     out = np.full(na, -1, np.int32)
-    if selector == "NN":
+    if selector == "NN" and cross_check:
+        # cv::batchDistance(..., K = 1, crosscheck = true) as BFMatcher::knnMatchImpl calls it (base.cpp:27-28, 463):
+        # every TRAIN row looks up its nearest query row (lowest index on ties); a query row keeps, among the train rows
+        # that chose it, the nearest one (the first such train row on ties: `if (d < d0)` while i runs upwards) and is
+        # unmatched (-1) if no train row chose it.  [third-party semantics restated from memory of
+        # modules/core/src/batch_distance.cpp; OpenCV's documentation describes the result as "mutual nearest
+        # neighbours", which this procedure contains but does not equal.]
+        v0t, _, q_of_t, _ = best_two(d2.T.copy())
+        dt = np.sqrt(v0t.astype(np.float32))
+        best = np.full(na, np.inf, np.float32)
+        d0 = np.zeros(na, np.float32)                  # distance of the kept pair; 0 where unmatched
+        for t in range(nb):
+            q = int(q_of_t[t])
+            if dt[t] < best[q]:
+                best[q] = dt[t]
+                out[q] = t
+                d0[q] = dt[t]
+    elif selector == "NN":
         out[:] = i0
-        if cross_check:                                # base.cpp:27-28
-            best_q = {}
-            for q in range(na):
-                t = int(i0[q])
-                if t not in best_q or d0[q] < d0[best_q[t]]:
-                    best_q[t] = q
-            for q in range(na):
-                if best_q[int(i0[q])] != q:
-                    out[q] = -1
     elif selector == "KNN":
         if nb >= 2:
             keep = d0 < np.float32(ratio) * d1          # base.cpp:469

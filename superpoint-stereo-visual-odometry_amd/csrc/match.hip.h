@@ -11,7 +11,7 @@
 //         i.e. bit-identical to the oracle) for the <= 4*groups shortlisted rows
 //         and picks the best two under (distance, train index) order -- strict
 //         '<' so the lowest train index wins ties, as BFMatcher does
-//   K13   selector: NN (+ OpenCV's crossCheck rule) or KNN ratio test
+//   K13   selector: NN (+ cv::batchDistance's crosscheck: train rows vote for their nearest query row) or KNN ratio test
 // Integer outputs (train indices) are therefore independent of the MFMA
 // rounding; the MFMA only prunes.
 #pragma once
@@ -38,8 +38,8 @@ struct MatchJob {
   int *shortlist;                 // [na][groups][MATCH_KEEP]
   float *best_d2;                 // [na][2]
   int *best_idx;                  // [na][2]
-  unsigned long long *train_best; // [nb] (cross-check only)
-  int2 *out;                      // [na] packed {train_idx, float bits of the distance}
+  unsigned long long *train_best; // [nb] (cross-check only: the sides are swapped, nb = query rows; {distance bits, train row})
+  int2 *out;                      // [na] packed {train_idx, float bits of the distance} ([nb] with cross-check)
 };
 struct MatchJobs { MatchJob j[2]; };   // blockIdx.z selects the job (stereo / temporal match)
 
@@ -238,6 +238,9 @@ __global__ __launch_bounds__(256) void match_rerank_kernel(MatchJobs jobs, int g
     best_idx[2 * q] = i0; best_idx[2 * q + 1] = i1;
     const float s0 = sqrtf(d0), s1 = sqrtf(d1);   // BFMatcher L2 returns sqrt(sum of squares)
     if (selector == 0 && cross_check) {
+      // sides swapped by the host: row q is a TRAIN row, i0 its nearest query row (lowest index on ties).  The query
+      // keeps the nearest of the train rows that chose it, the lowest train row on ties (cv::batchDistance: `d < d0`
+      // while the train index runs upwards) = the minimum of {distance bits, train row}
       if (i0 >= 0) atomicMin(&jb.train_best[i0], ((unsigned long long)__float_as_uint(s0) << 32) | (unsigned)q);
     } else {
       int out = -1;
@@ -248,20 +251,18 @@ __global__ __launch_bounds__(256) void match_rerank_kernel(MatchJobs jobs, int g
   }
 }
 
-// OpenCV crossCheck (batchDistance, crosscheck=true, K=1): for every train row the query with
-// the smallest distance among those that chose it (lowest query index on ties) wins; other
-// queries that chose the same train row are dropped.  The scatter (atomicMin on
-// {distance bits, query}) is done by match_rerank_kernel; this kernel applies it.
+// OpenCV crossCheck (cv::batchDistance, crosscheck = true, K = 1, as BFMatcher::knnMatchImpl calls it): every train
+// row votes for its nearest query row; a query row is matched to the nearest train row among its voters and stays
+// unmatched when nobody voted for it.  The vote (atomicMin on {distance bits, train row}) is cast by
+// match_rerank_kernel, which ran with the two sides swapped; this kernel reads it out per query row.
 __global__ __launch_bounds__(256) void match_select_cross_kernel(MatchJobs jobs) {
   const MatchJob jb = jobs.j[blockIdx.y];
-  const int na = dev_count(jb.na, jb.na_ptr);
+  const int nq = dev_count(jb.nb, jb.nb_ptr);   // swapped: the B side holds the query rows
   const int q = blockIdx.x * 256 + threadIdx.x;
-  if (q >= na) return;
-  const int i0 = jb.best_idx[2 * q];
-  const float d0 = sqrtf(jb.best_d2[2 * q]);
-  int out = -1;
-  if (i0 >= 0 && (int)(jb.train_best[i0] & 0xFFFFFFFFull) == q) out = i0;
-  jb.out[q] = make_int2(out, __float_as_int(d0));
+  if (q >= nq) return;
+  const unsigned long long key = jb.train_best[q];
+  const bool hit = key != ~0ull;
+  jb.out[q] = make_int2(hit ? (int)(key & 0xFFFFFFFFull) : -1, hit ? (int)(key >> 32) : 0);
 }
 
 }  // namespace spvo

@@ -784,10 +784,20 @@ struct MatchReq {
 
 // Enqueue 1 or 2 matches as ONE set of launches (blockIdx.z / .y = job) and one result copy:
 // packed {train_idx, distance bits} for job k lands at host_out + k*match_cap.
-int enqueue_matches(spvo_ctx *c, const MatchReq *req, int njobs, int selector, int cross_check, float ratio, int2 *host_out) {
+int enqueue_matches(spvo_ctx *c, const MatchReq *req_in, int njobs, int selector, int cross_check, float ratio, int2 *host_out) {
   MatchJobs jobs;
   int na_max = 0, nb_max = 0;
+  // NN + cross-check is cv::batchDistance's crosscheck: the search runs from the TRAIN rows to the query rows, so the
+  // two sides change places for the distance GEMM and the re-rank; match_select_cross_kernel writes one entry per
+  // query row again
+  const bool swap = selector == SPVO_SELECT_NN && cross_check;
+  MatchReq req[2];
   for (int k = 0; k < njobs; ++k) {
+    req[k] = req_in[k];
+    if (swap) {
+      std::swap(req[k].dA, req[k].dB); std::swap(req[k].na, req[k].nb);
+      std::swap(req[k].na_ptr, req[k].nb_ptr); std::swap(req[k].sqA, req[k].sqB);
+    }
     MatchScratch &m = c->ms[k];
     MatchJob &j = jobs.j[k];
     j.A = req[k].dA; j.B = req[k].dB;
@@ -800,8 +810,7 @@ int enqueue_matches(spvo_ctx *c, const MatchReq *req, int njobs, int selector, i
     nb_max = std::max(nb_max, req[k].nb);
     if (!req[k].sqA) hipLaunchKernelGGL(row_sqnorm_kernel, dim3((req[k].na + 3) / 4), dim3(256), 0, c->post, req[k].dA, req[k].na, req[k].na_ptr, m.d_na);
     if (!req[k].sqB) hipLaunchKernelGGL(row_sqnorm_kernel, dim3((req[k].nb + 3) / 4), dim3(256), 0, c->post, req[k].dB, req[k].nb, req[k].nb_ptr, m.d_nb);
-    if (selector == SPVO_SELECT_NN && cross_check)
-      HIP_TRY(c, hipMemsetAsync(m.d_train_best, 0xFF, (size_t)req[k].nb * sizeof(unsigned long long), c->post));
+    if (swap) HIP_TRY(c, hipMemsetAsync(m.d_train_best, 0xFF, (size_t)req[k].nb * sizeof(unsigned long long), c->post));
   }
   if (njobs == 1) jobs.j[1] = jobs.j[0];
   const int groups = (nb_max + MATCH_TT - 1) / MATCH_TT;
@@ -818,11 +827,10 @@ int enqueue_matches(spvo_ctx *c, const MatchReq *req, int njobs, int selector, i
     hipLaunchKernelGGL(match_gemm_kernel, dim3(groups, (na_max + MATCH_QT - 1) / MATCH_QT, njobs), dim3(256), lds, c->post, jobs, groups);
   }
   hipLaunchKernelGGL(match_rerank_kernel, dim3((na_max + 3) / 4, njobs), dim3(256), 0, c->post, jobs, groups, selector, cross_check, ratio);
-  if (selector == SPVO_SELECT_NN && cross_check)
-    hipLaunchKernelGGL(match_select_cross_kernel, dim3((na_max + 255) / 256, njobs), dim3(256), 0, c->post, jobs);
+  if (swap) hipLaunchKernelGGL(match_select_cross_kernel, dim3((nb_max + 255) / 256, njobs), dim3(256), 0, c->post, jobs);
   HIP_TRY(c, hipGetLastError());
   // jobs' outputs are adjacent in d_match_out (stride match_cap): one copy
-  const size_t count = (njobs == 2) ? (size_t)c->match_cap + req[1].na : (size_t)req[0].na;
+  const size_t count = (njobs == 2) ? (size_t)c->match_cap + req_in[1].na : (size_t)req_in[0].na;
   HIP_TRY(c, hipMemcpyAsync(host_out, c->d_match_out, count * sizeof(int2), hipMemcpyDeviceToHost, c->post));
   return SPVO_OK;
 }
