@@ -39,6 +39,7 @@ def test_host_sequence_matches_oracle_state_machine(models_dir, sequence, select
     assert fe.engine_loaded, fe.last_error
     st = od.FrontEndState()
     errs = []
+    traj_gpu, traj_cpu = [np.eye(4)], [np.eye(4)]
     for k, (L, R) in enumerate(frames):
         res = fe.step(L, R, P_l, P_r)
         # identical upstream for the oracle: the GPU's own keypoints / descriptors / P
@@ -67,7 +68,14 @@ def test_host_sequence_matches_oracle_state_machine(models_dir, sequence, select
         # ground truth (reported): relative pose error of this synthetic step
         Rgt, tgt = synth.relative_pose(poses[k - 1], poses[k])
         errs.append(np.linalg.norm(gt - tgt))
+        for traj, (q_, t_) in ((traj_gpu, (gq, gt)), (traj_cpu, (oq, ot))):   # integrate world_T_curr = world_T_prev * (curr_T_prev)^-1
+            S = np.eye(4)
+            S[:3, :3], S[:3, 3] = od.quat_to_rot(np.asarray(q_)), t_
+            traj.append(traj[-1] @ np.linalg.inv(S))
     assert max(errs) < 0.05, errs                                   # metres per ~0.8 m step
+    # SURVEY.md section 8d parity gate: ATE(GPU trajectory, CPU trajectory) <= 1e-3 m
+    ate = np.sqrt(np.mean([np.sum((a[:3, 3] - b[:3, 3]) ** 2) for a, b in zip(traj_gpu, traj_cpu)]))
+    assert ate <= 1e-3, ate
     fe.clear()
     assert fe.dq_size() == 0 and fe.frame_count() == 0
     fe.close()
