@@ -515,11 +515,11 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const float *__restrict__
 // consecutive pixels of one row; each thread first walks channels for "its"
 // pixel (coalesced along x), the tile goes through LDS and leaves as
 // [pixel][256] rows (coalesced along channels).
-template <int C>
+template <int C, int PX = 32>
 __global__ __launch_bounds__(256) void l2norm_nhwc_kernel(const float *__restrict__ in,
                                                           float *__restrict__ out, int H, int W,
                                                           int hp, int wp) {
-  constexpr int PX = 32, CG = 256 / PX;
+  constexpr int CG = 256 / PX;
   __shared__ float tile[PX][C + 1];
   __shared__ float part[CG][PX];
   __shared__ float nrm[PX];

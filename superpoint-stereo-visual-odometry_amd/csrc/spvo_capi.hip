@@ -549,8 +549,8 @@ int launch_op(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream
     dim3 grid((to.W + 63) / 64, (to.H + 3) / 4, batch * to.ch);
     hipLaunchKernelGGL(maxpool2_kernel, grid, dim3(256), 0, stream, tin, tout, to.ch, to.H, to.W, ti.hp, ti.wp, to.hp, to.wp);
   } else if (op.type == OP_L2NORM) {
-    dim3 grid((ti.W + 31) / 32, ti.H, batch);
-    hipLaunchKernelGGL(l2norm_nhwc_kernel<256>, grid, dim3(256), 0, stream, tin, tout, ti.H, ti.W, ti.hp, ti.wp);
+    // 16 pixels per block: 3-4 blocks per CU hide each other's latency (measured 15 us vs 21 us with 32 pixels)
+    hipLaunchKernelGGL((l2norm_nhwc_kernel<256, 16>), dim3((ti.W + 15) / 16, ti.H, batch), dim3(256), 0, stream, tin, tout, ti.H, ti.W, ti.hp, ti.wp);
   }
   HIP_TRY(c, hipGetLastError());
   return SPVO_OK;
