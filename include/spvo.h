@@ -71,8 +71,9 @@ int spvo_load_weights(spvo_ctx *ctx, const char *path);
  * is synchronous (copies in, runs on the context's stream, copies out).      */
 
 /* Precision of the loaded engine: 0 = FP32, 1 = FP16 (what engine_generation.py:13-56 selects with trtexec --fp16
- * and the engine file name carries, nn.cpp:44-49); SPVO_ERR_STATE (negative) before spvo_load_weights.  An FP16
- * engine keeps fp32 bindings (nn.cpp:117): every entry point takes and returns the same types. */
+ * and the engine file name carries, nn.cpp:44-49), 2 = INT8 (an extension: calibrated activation scales travel in
+ * the engine file); SPVO_ERR_STATE (negative) before spvo_load_weights.  FP16 and INT8 engines keep fp32 bindings
+ * (nn.cpp:117): every entry point takes and returns the same types. */
 int spvo_engine_precision(const spvo_ctx *ctx);
 
 /* preprocessImageImpl (base.cpp:68-121) + preprocessImage (nn.cpp:139-161):

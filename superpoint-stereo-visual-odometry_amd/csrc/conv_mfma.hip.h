@@ -44,6 +44,24 @@ __host__ __device__ inline int padded_w(int w) { return ((w + 63) / 64) * 64 + 2
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Separately rounded fp32 operations.  hipcc compiles device code with -ffp-contract=fast and HIP's __fmul_rn /
+// __fadd_rn are plain `x * y` / `x + y`, so a multiply feeding an add may become one fused multiply-add -- a
+// different rounding.  Results that must be bit-identical to a CPU restatement (match distances, softmax sums, the
+// INT8 requantisation) go through these: instructions emitted under `contract(off)` carry no contract flag and are
+// never fused, also after inlining.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+
 struct ConvArgs {
   const float *in;     // padded planes of the input tensor (batch 0, channel 0)
   float *out;          // padded planes of the output tensor

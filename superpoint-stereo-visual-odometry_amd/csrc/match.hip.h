@@ -205,10 +205,10 @@ __global__ __launch_bounds__(256) void match_rerank_kernel(MatchJobs jobs, int g
         const float4 av = *(const float4 *)(a + k);
         const float4 bv = *(const float4 *)(b + k);
         float t;
-        t = __fsub_rn(av.x, bv.x); s = __fadd_rn(s, __fmul_rn(t, t));
-        t = __fsub_rn(av.y, bv.y); s = __fadd_rn(s, __fmul_rn(t, t));
-        t = __fsub_rn(av.z, bv.z); s = __fadd_rn(s, __fmul_rn(t, t));
-        t = __fsub_rn(av.w, bv.w); s = __fadd_rn(s, __fmul_rn(t, t));
+        t = sub_rn(av.x, bv.x); s = add_rn(s, mul_rn(t, t));
+        t = sub_rn(av.y, bv.y); s = add_rn(s, mul_rn(t, t));
+        t = sub_rn(av.z, bv.z); s = add_rn(s, mul_rn(t, t));
+        t = sub_rn(av.w, bv.w); s = add_rn(s, mul_rn(t, t));
       }
       d = s;
     }
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void match_rerank_kernel(MatchJobs jobs, int g
     } else {
       int out = -1;
       if (selector == 0) out = i0;
-      else if (i0 >= 0 && i1 >= 0 && s0 < __fmul_rn(ratio, s1)) out = i0;   // base.cpp:469
+      else if (i0 >= 0 && i1 >= 0 && s0 < mul_rn(ratio, s1)) out = i0;   // base.cpp:469
       jb.out[q] = make_int2(out, __float_as_int(s0));
     }
   }

@@ -160,9 +160,9 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const double *__restri
     h[r] = (float)v;
   }
   const float scale = (h[3] != 0.f) ? __fdiv_rn(1.0f, h[3]) : 1.0f;
-  xyz[3 * i + 0] = __fmul_rn(h[0], scale);
-  xyz[3 * i + 1] = __fmul_rn(h[1], scale);
-  xyz[3 * i + 2] = __fmul_rn(h[2], scale);
+  xyz[3 * i + 0] = mul_rn(h[0], scale);
+  xyz[3 * i + 1] = mul_rn(h[1], scale);
+  xyz[3 * i + 2] = mul_rn(h[2], scale);
 }
 
 // ------------------------------------------------------------------------- K15

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t *__restri
     v = min(max(v, 0), 255);
   }
   if (out_u8) out_u8[(size_t)y * W + x] = (uint8_t)v;
-  out_plane[(size_t)(y + PADY) * wp + (x + PADX)] = __fmul_rn((float)v, 1.0f / 255.0f);
+  out_plane[(size_t)(y + PADY) * wp + (x + PADX)] = mul_rn((float)v, 1.0f / 255.0f);
 }
 
 // Dense f32 [B,1,H,W] -> padded input planes (spvo_forward's host-input path).
@@ -100,9 +100,9 @@ __global__ __launch_bounds__(256) void heatmap_kernel(const float *__restrict__ 
 #pragma unroll
   for (int c = 0; c < 65; ++c) {
     e[c] = expf(p[(size_t)c * plane]);
-    s = __fadd_rn(s, e[c]);
+    s = add_rn(s, e[c]);
   }
-  s = __fadd_rn(s, 0.00001f);
+  s = add_rn(s, 0.00001f);
   const int W = Wc * 8;
   float *h = heat + (size_t)img * (Hc * 8) * W + (size_t)(i * 8) * W + j * 8;
 #pragma unroll
@@ -222,9 +222,9 @@ __global__ __launch_bounds__(256) void heatmap_nms_kernel(const float *__restric
 #pragma unroll
     for (int c = 0; c < 65; ++c) {
       e[c] = expf(p[(size_t)c * plane]);
-      s = __fadd_rn(s, e[c]);
+      s = add_rn(s, e[c]);
     }
-    s = __fadd_rn(s, 0.00001f);
+    s = add_rn(s, 0.00001f);
     float *h = heat + (size_t)img * H * W + (size_t)(i * 8) * W + j * 8;
     uint8_t *st = nb.state + (size_t)(i * 8 + NMS_PAD) * pitch + j * 8 + NMS_PAD;
 #pragma unroll
@@ -498,23 +498,23 @@ __global__ __launch_bounds__(256) void sample_desc_kernel(SampleJobs jobs, int H
     jb.out_xy_i32[2 * k + 1] = row;
   }
   float *out = jb.out;
-  const float row8 = __fmul_rn(__fdiv_rn((float)row, (float)(H - 1)), (float)(Hc - 1));
-  const float col8 = __fmul_rn(__fdiv_rn((float)col, (float)(W - 1)), (float)(Wc - 1));
+  const float row8 = mul_rn(__fdiv_rn((float)row, (float)(H - 1)), (float)(Hc - 1));
+  const float col8 = mul_rn(__fdiv_rn((float)col, (float)(W - 1)), (float)(Wc - 1));
   const int r0 = (int)floorf(row8), c0 = (int)floorf(col8);
-  const float rr = __fsub_rn(1.0f, __fsub_rn(row8, (float)r0));
-  const float cr = __fsub_rn(1.0f, __fsub_rn(col8, (float)c0));
-  const float rr1 = __fsub_rn(1.0f, rr), cr1 = __fsub_rn(1.0f, cr);
+  const float rr = sub_rn(1.0f, sub_rn(row8, (float)r0));
+  const float cr = sub_rn(1.0f, sub_rn(col8, (float)c0));
+  const float rr1 = sub_rn(1.0f, rr), cr1 = sub_rn(1.0f, cr);
   const int r1 = min(r0 + 1, Hc - 1), c1 = min(c0 + 1, Wc - 1);
   const float4 tl = *(const float4 *)(desc_nhwc + ((size_t)r0 * Wc + c0) * 256 + lane * 4);
   const float4 tr = *(const float4 *)(desc_nhwc + ((size_t)r0 * Wc + c1) * 256 + lane * 4);
   const float4 bl = *(const float4 *)(desc_nhwc + ((size_t)r1 * Wc + c0) * 256 + lane * 4);
   const float4 br = *(const float4 *)(desc_nhwc + ((size_t)r1 * Wc + c1) * 256 + lane * 4);
   auto blend = [&](float a, float b, float c, float d) {
-    const float t0 = __fmul_rn(__fmul_rn(a, rr), cr);
-    const float t1 = __fmul_rn(__fmul_rn(b, rr), cr1);
-    const float t2 = __fmul_rn(__fmul_rn(c, rr1), cr);
-    const float t3 = __fmul_rn(__fmul_rn(d, rr1), cr1);
-    return __fadd_rn(__fadd_rn(__fadd_rn(t0, t1), t2), t3);
+    const float t0 = mul_rn(mul_rn(a, rr), cr);
+    const float t1 = mul_rn(mul_rn(b, rr), cr1);
+    const float t2 = mul_rn(mul_rn(c, rr1), cr);
+    const float t3 = mul_rn(mul_rn(d, rr1), cr1);
+    return add_rn(add_rn(add_rn(t0, t1), t2), t3);
   };
   float4 v;
   v.x = blend(tl.x, tr.x, bl.x, br.x);

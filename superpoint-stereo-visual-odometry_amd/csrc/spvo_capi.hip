@@ -19,6 +19,7 @@
 #include "match.hip.h"
 #include "odometry.hip.h"
 #include "conv_f16.hip.h"
+#include "conv_i8.hip.h"
 #include "post.hip.h"
 
 using namespace spvo;
@@ -35,6 +36,8 @@ struct Tensor {
   int ch = 0, level = 0, H = 0, W = 0, hp = 0, wp = 0;
   bool nhwc = false;  // dense [B][H][W][C] (descriptor map) instead of padded planes
   bool f16 = false;   // FP16 engines: C8 fp16 [C/8][Hp][Wp][8] instead of fp32 planes (per_image still counts floats = 4 bytes)
+  bool i8 = false;    // INT8 engines: C16 int8 [C/16][Hp][Wp][16]
+  float scale = 0.f;  // INT8 engines: real value = q * scale (calibrated)
   float *d = nullptr;
   float *dr[RING] = {nullptr, nullptr, nullptr, nullptr};  // network outputs only: one buffer per submission set (d == dr[0])
   size_t per_image = 0;  // floats
@@ -50,6 +53,10 @@ struct Op {
   bool dominant = false;   // the op with the most FLOPs: launched under its own kernel name (TAG = 1)
   float *d_w = nullptr, *d_b = nullptr, *d_bn_scale = nullptr, *d_bn_shift = nullptr;
   _Float16 *d_w16 = nullptr;   // FP16 engines: pack_conv_weights_f16()
+  int8_t *d_w8 = nullptr;      // INT8 engines: pack_conv_weights_i8()
+  int *d_wq32 = nullptr;       // INT8 engines, depthwise: quantised weights [C][9] as int32
+  float *d_qm = nullptr;       // INT8 engines: weight scale * input scale per output channel
+  float inv_s_out = 0.f, s_res = 0.f;
   double flops_per_image = 0;
   int stage = -1;
 };
@@ -117,6 +124,7 @@ struct spvo_ctx {
   std::string error;
   bool weights = false;
   bool fp16 = false;               // the loaded engine's precision
+  bool int8 = false;
   int H = 0, W = 0, Hc = 0, Wc = 0, B = 0;
   int num_cus = 256;
 
@@ -532,12 +540,108 @@ int launch_conv16(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t st
   }
 }
 
+// ---------------------------------------------------------------- INT8 engines
+template <int KS, int CKG, int WR, int WC, bool POOL, bool RELU, bool OUT_F32, int EPI = 0>
+int launch_conv8_instance(spvo_ctx *c, ConvArgs8 args, hipStream_t stream) {
+  using T = ConvTile8<KS, CKG, WR, WC>;
+  auto k = conv_i8_kernel<KS, CKG, WR, WC, POOL, RELU, OUT_F32, EPI>;
+  static int per_cu[64] = {};
+  const int dev = c->cfg.device & 63;
+  if (!per_cu[dev]) {
+    HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+    int n = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k, 256, T::LDS_BYTES));
+    per_cu[dev] = std::max(n, 1);
+  }
+  args.tiles_x = (args.W + T::TW - 1) / T::TW;
+  args.tiles_y = (args.H + T::TH - 1) / T::TH;
+  const int n_tiles = args.tiles_x * args.tiles_y * args.co_tiles * args.batch;
+  hipLaunchKernelGGL(k, dim3(std::min(n_tiles, c->num_cus * per_cu[dev])), dim3(256), T::LDS_BYTES, stream, args);
+  HIP_TRY(c, hipGetLastError());
+  return SPVO_OK;
+}
+
+template <int KS, int CKG, int WR, int WC, bool POOL>
+int launch_conv8_variant(spvo_ctx *c, const ConvArgs8 &a, bool relu, bool out_f32, int epi, hipStream_t stream) {
+  if constexpr (KS == 1) {
+    if (epi == 1) return launch_conv8_instance<1, CKG, WR, WC, POOL, true, false, 1>(c, a, stream);
+    if (epi == 2) return launch_conv8_instance<1, CKG, WR, WC, POOL, false, false, 2>(c, a, stream);
+  }
+  if constexpr (!POOL) {
+    if (out_f32) return relu ? launch_conv8_instance<KS, CKG, WR, WC, false, true, true>(c, a, stream) : launch_conv8_instance<KS, CKG, WR, WC, false, false, true>(c, a, stream);
+  }
+  return relu ? launch_conv8_instance<KS, CKG, WR, WC, POOL, true, false>(c, a, stream) : launch_conv8_instance<KS, CKG, WR, WC, POOL, false, false>(c, a, stream);
+}
+
+int launch_conv8(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream) {
+  const Tensor &ti = c->tensors[op.in];
+  const Tensor &to = c->tensors[op.out];
+  const float *tin = (ti.dr[c->cur_ring] ? ti.dr[c->cur_ring] : ti.d) + (size_t)img0 * ti.per_image;
+  float *tout = (to.dr[c->cur_ring] ? to.dr[c->cur_ring] : to.d) + (size_t)img0 * to.per_image;
+  const bool relu = op.flags & FLAG_RELU, pool = op.flags & FLAG_POOL;
+  if (op.type == OP_DWCONV) {
+    dim3 grid((ti.W + 63) / 64, (ti.H + 3) / 4, batch * (op.cout / 16));
+    if (relu) hipLaunchKernelGGL(dwconv3x3_i8_kernel<true>, grid, dim3(256), 0, stream, (const int8_t *)tin, (int8_t *)tout, op.d_wq32, op.d_qm, op.d_b, op.inv_s_out, op.cout / 16, ti.H, ti.W, ti.hp, ti.wp);
+    else hipLaunchKernelGGL(dwconv3x3_i8_kernel<false>, grid, dim3(256), 0, stream, (const int8_t *)tin, (int8_t *)tout, op.d_wq32, op.d_qm, op.d_b, op.inv_s_out, op.cout / 16, ti.H, ti.W, ti.hp, ti.wp);
+    HIP_TRY(c, hipGetLastError());
+    return SPVO_OK;
+  }
+  if (op.cin == 1) {   // fp32 stem
+    dim3 grid((ti.W + 63) / 64, (ti.H + 3) / 4, batch);
+#define SPVO_STEM8(KS, RELU, OUTQ) hipLaunchKernelGGL((conv_first_i8_kernel<KS, RELU, OUTQ>), grid, dim3(256), 0, stream, tin, (void *)tout, op.d_w, op.d_b, \
+                                                      op.d_bn_scale, op.d_bn_shift, op.inv_s_out, ti.H, ti.W, ti.hp, ti.wp, to.ch, op.out_c_off, op.cout)
+    if (to.i8) {
+      if (op.ks == 3) { if (relu) SPVO_STEM8(3, true, true); else SPVO_STEM8(3, false, true); }
+      else            { if (relu) SPVO_STEM8(1, true, true); else SPVO_STEM8(1, false, true); }
+    } else {
+      if (op.ks == 3) { if (relu) SPVO_STEM8(3, true, false); else SPVO_STEM8(3, false, false); }
+      else            { if (relu) SPVO_STEM8(1, true, false); else SPVO_STEM8(1, false, false); }
+    }
+#undef SPVO_STEM8
+    HIP_TRY(c, hipGetLastError());
+    return SPVO_OK;
+  }
+  ConvArgs8 a;
+  a.in = (const int8_t *)tin; a.out = tout; a.wpack = op.d_w8; a.qm = op.d_qm; a.bias = op.d_b;
+  a.bn_scale = op.d_bn_scale; a.bn_shift = op.d_bn_shift;
+  a.inv_s_out = op.inv_s_out; a.s_res = op.s_res;
+  a.H = ti.H; a.W = ti.W;
+  a.in_hp = ti.hp; a.in_wp = ti.wp; a.in_gtot = ti.ch / 16; a.in_goff = op.in_c_off / 16;
+  a.out_hp = to.hp; a.out_wp = to.wp; a.out_ctot = to.ch; a.out_coff = op.out_c_off;
+  a.cout = op.cout; a.n_chunks = op.n_chunks; a.co_tiles = op.co_tiles;
+  a.tiles_x = a.tiles_y = 0;
+  a.batch = batch;
+  const int epi = (op.flags & FLAG_BN) ? 1 : (op.flags & FLAG_ADD) ? 2 : 0;
+  if (epi == 2) a.residual = (const int8_t *)(c->tensors[op.residual].d + (size_t)img0 * c->tensors[op.residual].per_image);
+  const bool out_f32 = !to.i8;
+  const int key = op.ks * 10000 + (op.ck / 16) * 1000 + op.wr * 100 + op.wc * 10 + (pool ? 1 : 0);   // ks, groups per chunk, wr, wc, pool
+  switch (key) {
+    case 32220: return launch_conv8_variant<3, 2, 2, 2, false>(c, a, relu, out_f32, epi, stream);
+    case 32210: return launch_conv8_variant<3, 2, 2, 1, false>(c, a, relu, out_f32, epi, stream);
+    case 32120: return launch_conv8_variant<3, 2, 1, 2, false>(c, a, relu, out_f32, epi, stream);
+    case 32110: return launch_conv8_variant<3, 2, 1, 1, false>(c, a, relu, out_f32, epi, stream);
+    case 32221: return launch_conv8_variant<3, 2, 2, 2, true>(c, a, relu, out_f32, epi, stream);
+    case 32211: return launch_conv8_variant<3, 2, 2, 1, true>(c, a, relu, out_f32, epi, stream);
+    case 14220: return launch_conv8_variant<1, 4, 2, 2, false>(c, a, relu, out_f32, epi, stream);
+    case 14120: return launch_conv8_variant<1, 4, 1, 2, false>(c, a, relu, out_f32, epi, stream);
+    case 14110: return launch_conv8_variant<1, 4, 1, 1, false>(c, a, relu, out_f32, epi, stream);
+    case 14221: return launch_conv8_variant<1, 4, 2, 2, true>(c, a, relu, out_f32, epi, stream);
+    case 14211: return launch_conv8_variant<1, 4, 2, 1, true>(c, a, relu, out_f32, epi, stream);
+    case 12220: return launch_conv8_variant<1, 2, 2, 2, false>(c, a, relu, out_f32, epi, stream);
+    case 12120: return launch_conv8_variant<1, 2, 1, 2, false>(c, a, relu, out_f32, epi, stream);
+    case 12110: return launch_conv8_variant<1, 2, 1, 1, false>(c, a, relu, out_f32, epi, stream);
+    case 12221: return launch_conv8_variant<1, 2, 2, 2, true>(c, a, relu, out_f32, epi, stream);
+    case 12211: return launch_conv8_variant<1, 2, 2, 1, true>(c, a, relu, out_f32, epi, stream);
+    default: return fail(c, SPVO_ERR_INVALID, "no int8 conv kernel variant for key %d", key);
+  }
+}
+
 int launch_op(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream) {
   const Tensor &ti = c->tensors[op.in];
   const Tensor &to = c->tensors[op.out];
   if (op.type == OP_CONV || op.type == OP_DWCONV) {
     ScopedStage st(c, op.stage, op.flops_per_image * batch, 0, stream);
-    return c->fp16 ? launch_conv16(c, op, img0, batch, stream) : launch_conv(c, op, img0, batch, stream);
+    return c->int8 ? launch_conv8(c, op, img0, batch, stream) : c->fp16 ? launch_conv16(c, op, img0, batch, stream) : launch_conv(c, op, img0, batch, stream);
   }
   const float *tin = (ti.dr[c->cur_ring] ? ti.dr[c->cur_ring] : ti.d) + (size_t)img0 * ti.per_image;
   float *tout = (to.dr[c->cur_ring] ? to.dr[c->cur_ring] : to.d) + (size_t)img0 * to.per_image;
@@ -905,8 +1009,11 @@ void free_plan(spvo_ctx *c) {
   {
     for (float *p : {o.d_w, o.d_b, o.d_bn_scale, o.d_bn_shift}) if (p) (void)hipFree(p);
     if (o.d_w16) (void)hipFree(o.d_w16);
+    if (o.d_w8) (void)hipFree(o.d_w8);
+    if (o.d_wq32) (void)hipFree(o.d_wq32);
+    if (o.d_qm) (void)hipFree(o.d_qm);
   }
-  c->tensors.clear(); c->ops.clear(); c->weights = false; c->fp16 = false;
+  c->tensors.clear(); c->ops.clear(); c->weights = false; c->fp16 = false; c->int8 = false;
 }
 
 }  // namespace
@@ -1082,8 +1189,10 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
   if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "detector submissions are in flight");
   free_plan(c);
   c->t_input = hdr[2]; c->t_det = hdr[3]; c->t_desc = hdr[4];
-  if (hdr[5] > 1) return fail(c, SPVO_ERR_IO, "%s: unknown precision %u", path, hdr[5]);
+  if (hdr[5] > 2) return fail(c, SPVO_ERR_IO, "%s: unknown precision %u", path, hdr[5]);
   c->fp16 = hdr[5] == 1;   // engine built for FP16 (engine_generation.py's --fp16; the file name says FP16, nn.cpp:44-49)
+  c->int8 = hdr[5] == 2;   // INT8 engine (BASELINE config 5; no counterpart in the reference): calibrated activation scales in the file
+  const uint32_t act_scale_off = hdr[6];
   for (uint32_t i = 0; i < nt; ++i) {
     const uint32_t *r = (const uint32_t *)(buf.data() + pos);
     pos += 8;
@@ -1115,6 +1224,19 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
     if (op.type == OP_L2NORM) c->tensors[op.out].nhwc = true;
     c->ops.push_back(op);
   }
+  if (c->int8) {
+    if (act_scale_off + (uint64_t)nt > nfl) return fail(c, SPVO_ERR_IO, "%s: activation scales out of range", path);
+    for (uint32_t t = 0; t < nt; ++t) {
+      c->tensors[t].scale = payload[act_scale_off + t];
+      c->tensors[t].i8 = (c->tensors[t].ch % 16) == 0;   // fewer channels (mbv's stem): an fp32 plane
+      if (!(c->tensors[t].scale > 0.f)) return fail(c, SPVO_ERR_IO, "%s: tensor %u has no activation scale", path, t);
+    }
+    c->tensors[c->t_input].i8 = c->tensors[c->t_det].i8 = c->tensors[c->t_desc].i8 = false;   // fp32 bindings
+    for (const auto &op : c->ops) {
+      if (op.type == OP_L2NORM) c->tensors[op.in].i8 = false;
+      if (op.type == OP_MAXPOOL) return fail(c, SPVO_ERR_IO, "%s: INT8 engines have no stand-alone max-pool (squeeze graph)", path);
+    }
+  }
   if (c->fp16) {
     // half precision between the fp32 network input and the fp32 outputs (nn.cpp:117): every tensor but the input,
     // output_det, the raw descriptor map and output_desc is C8 fp16
@@ -1128,7 +1250,7 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
   // allocate activations (padded planes stay zero outside the interior for ever)
   for (size_t ti = 0; ti < c->tensors.size(); ++ti) {
     Tensor &t = c->tensors[ti];
-    t.per_image = t.nhwc ? (size_t)t.H * t.W * t.ch : (size_t)t.ch * t.hp * t.wp / (t.f16 ? 2 : 1);
+    t.per_image = t.nhwc ? (size_t)t.H * t.W * t.ch : (size_t)t.ch * t.hp * t.wp / (t.f16 ? 2 : t.i8 ? 4 : 1);
     int rc = dev_alloc(c, &t.d, t.per_image * c->B);
     if (rc) return rc;
     if ((int)ti == c->t_det || (int)ti == c->t_desc) {   // what a submission's tail reads while the next network pass already runs
@@ -1152,6 +1274,24 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
       if (r.w_off + (uint64_t)op.cout * 9 > nfl || r.b_off + op.cout > nfl) return fail(c, SPVO_ERR_IO, "op %u: weights out of range", i);
       op.flops_per_image = 2.0 * ti.H * ti.W * op.cout * 9;
       if (c->fp16 && (!ti.f16 || !to.f16)) return fail(c, SPVO_ERR_IO, "op %u: depthwise convolution of an FP16 engine needs channel counts that are multiples of 8", i);
+      if (c->int8) {
+        if (!ti.i8 || !to.i8) return fail(c, SPVO_ERR_IO, "op %u: depthwise convolution of an INT8 engine needs channel counts that are multiples of 16", i);
+        std::vector<int8_t> wq;
+        std::vector<float> ws;
+        quantize_conv_weights(payload + r.w_off, op.cout, 9, wq, ws);
+        std::vector<int> wq32(wq.begin(), wq.end());
+        std::vector<float> qm(op.cout);
+        for (int o = 0; o < op.cout; ++o) qm[o] = ws[o] * ti.scale;
+        op.inv_s_out = 1.f / to.scale;
+        int rc = dev_alloc(c, &op.d_wq32, wq32.size(), false);
+        if (rc) return rc;
+        if ((rc = dev_alloc(c, &op.d_qm, op.cout, false))) return rc;
+        if ((rc = dev_alloc(c, &op.d_b, op.cout, false))) return rc;
+        HIP_TRY(c, hipMemcpy(op.d_wq32, wq32.data(), wq32.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(op.d_qm, qm.data(), qm.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(op.d_b, payload + r.b_off, (size_t)op.cout * 4, hipMemcpyHostToDevice));
+        continue;
+      }
       std::vector<float> wdw(payload + r.w_off, payload + r.w_off + (size_t)op.cout * 9);
       if (c->fp16) for (auto &q : wdw) q = (float)(_Float16)q;
       int rc = dev_alloc(c, &op.d_w, (size_t)op.cout * 9, false);
@@ -1198,6 +1338,47 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
       op.flops_per_image = 2.0 * ti.H * ti.W * op.cout * op.cin * taps;
       const float *w = payload + r.w_off;
       const float *b = payload + r.b_off;
+      if (c->int8) {
+        if (ti.i8 != (op.cin != 1)) return fail(c, SPVO_ERR_IO, "op %u: INT8 engine: a %d-channel input tensor stored as %s", i, op.cin, ti.i8 ? "int8" : "fp32");
+        op.inv_s_out = to.i8 ? 1.f / to.scale : 0.f;
+        if (op.cin == 1) {   // fp32 stem
+          if (pool || add || (to.i8 && ((op.out_c_off % 16) || (op.cout % 16)))) return fail(c, SPVO_ERR_IO, "op %u: unsupported single-channel-input layer for INT8", i);
+          int rc = dev_alloc(c, &op.d_w, (size_t)op.cout * taps, false);
+          if (rc) return rc;
+          if ((rc = dev_alloc(c, &op.d_b, op.cout, false))) return rc;
+          HIP_TRY(c, hipMemcpy(op.d_w, w, (size_t)op.cout * taps * 4, hipMemcpyHostToDevice));
+          HIP_TRY(c, hipMemcpy(op.d_b, b, (size_t)op.cout * 4, hipMemcpyHostToDevice));
+          continue;
+        }
+        const int ckg = (op.ks == 3 || op.cin % 64) ? 2 : 4;   // 32 channels per chunk; 64 for 1x1 layers when they divide
+        if (op.cin % (16 * ckg) || op.in_c_off % 16) return fail(c, SPVO_ERR_IO, "op %u: cin %d / channel offset %d do not fit the INT8 chunking (%d)", i, op.cin, op.in_c_off, 16 * ckg);
+        if (to.i8 && ((op.cout % 16) || (op.out_c_off % 16))) return fail(c, SPVO_ERR_IO, "op %u: cout %d / channel offset %d are not multiples of 16", i, op.cout, op.out_c_off);
+        if (!to.i8 && (pool || bn || add)) return fail(c, SPVO_ERR_IO, "op %u: pooled / BatchNorm / residual layer with an fp32 output", i);
+        if (add) {
+          const Tensor &tr = c->tensors[op.residual];
+          if (!tr.i8 || tr.ch != op.cout) return fail(c, SPVO_ERR_IO, "op %u: residual tensor is not a %d-channel int8 tensor", i, op.cout);
+          op.s_res = tr.scale;
+        }
+        op.ck = 16 * ckg;
+        op.n_chunks = op.cin / op.ck;
+        op.co_tiles = (op.cout + CO_TILE - 1) / CO_TILE;
+        int ck_unused;
+        choose_variant(op.ks, ti.H, ti.W, op.co_tiles, c->cfg.max_batch, pool, c->num_cus, &op.wr, &op.wc, &ck_unused);
+        std::vector<int8_t> wq;
+        std::vector<float> ws;
+        quantize_conv_weights(w, op.cout, op.cin * taps, wq, ws);
+        const std::vector<int8_t> pk = pack_conv_weights_i8(wq.data(), op.cout, op.cin, op.ks, ckg);
+        std::vector<float> qm((size_t)op.co_tiles * CO_TILE, 0.f), bp((size_t)op.co_tiles * CO_TILE, 0.f);
+        for (int o = 0; o < op.cout; ++o) { qm[o] = ws[o] * ti.scale; bp[o] = b[o]; }
+        int rc = dev_alloc(c, &op.d_w8, pk.size(), false);
+        if (rc) return rc;
+        if ((rc = dev_alloc(c, &op.d_qm, qm.size(), false))) return rc;
+        if ((rc = dev_alloc(c, &op.d_b, bp.size(), false))) return rc;
+        HIP_TRY(c, hipMemcpy(op.d_w8, pk.data(), pk.size(), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(op.d_qm, qm.data(), qm.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(op.d_b, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+        continue;
+      }
       if (c->fp16) {
         if (ti.f16 != (op.cin != 1)) return fail(c, SPVO_ERR_IO, "op %u: FP16 engine: a %d-channel input tensor stored as %s", i, op.cin, ti.f16 ? "fp16" : "fp32");
         if (op.cin == 1) {   // fp32 plane in: fp32 arithmetic on fp16-rounded weights, fp16 values out
@@ -1284,7 +1465,7 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
 
 int spvo_engine_precision(const spvo_ctx *c) {
   if (!c || !c->weights) return SPVO_ERR_STATE;
-  return c->fp16 ? 1 : 0;
+  return c->int8 ? 2 : c->fp16 ? 1 : 0;
 }
 
 int spvo_preprocess(spvo_ctx *c, const uint8_t *img, int rows, int cols, size_t stride, double P[12], uint8_t *resized_u8) {
@@ -1349,7 +1530,8 @@ int spvo_debug_tensor(spvo_ctx *c, int tensor_id, int batch, float *out, size_t 
   }
   float *tmp = nullptr;
   HIP_TRY(c, hipMalloc((void **)&tmp, need * sizeof(float)));
-  if (t.f16) hipLaunchKernelGGL(unpad_c8_kernel, dim3((t.W + 63) / 64, t.H, batch * t.ch), dim3(64), 0, c->stream, (const _Float16 *)t.d, tmp, t.ch, t.H, t.W, t.hp, t.wp);
+  if (t.i8) hipLaunchKernelGGL(unpad_c16_kernel, dim3((t.W + 63) / 64, t.H, batch * t.ch), dim3(64), 0, c->stream, (const int8_t *)t.d, tmp, t.ch, t.H, t.W, t.hp, t.wp);
+  else if (t.f16) hipLaunchKernelGGL(unpad_c8_kernel, dim3((t.W + 63) / 64, t.H, batch * t.ch), dim3(64), 0, c->stream, (const _Float16 *)t.d, tmp, t.ch, t.H, t.W, t.hp, t.wp);
   else hipLaunchKernelGGL(unpad_kernel, dim3((t.W + 63) / 64, (t.H + 3) / 4, batch * t.ch), dim3(256), 0, c->stream, t.d, tmp, t.ch, t.H, t.W, t.hp, t.wp);
   hipError_t e = hipMemcpyAsync(out, tmp, need * sizeof(float), hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

@@ -321,7 +321,7 @@ void SuperPointFeatureFrontEnd::loadEngine() {
     logError(spvo_last_error(ctx_));  // "no such engine file: ..." (nn.cpp:53-55): object stays half-initialised
     return;
   }
-  if (spvo_engine_precision(ctx_) != (trt_precision_ == TRT_FP16 ? 1 : 0)) {   // the name promises what trtexec was told (--fp16 or not)
+  if (spvo_engine_precision(ctx_) != (int)trt_precision_) {   // the name promises what trtexec was told (--fp16 or not)
     logError("engine file `" + model_name_full + "` was not built for " + trt_precision_enum2string.at(trt_precision_));
     return;
   }

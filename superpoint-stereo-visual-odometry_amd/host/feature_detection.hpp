@@ -121,9 +121,10 @@ const std::array<std::pair<int, int>, MATCH_TYPE_NUM> match_type_to_positions = 
     std::pair<int, int>(CURR_LEFT, CURR_RIGHT), std::pair<int, int>(CURR_LEFT, PREV_LEFT),
     std::pair<int, int>(PREV_LEFT, PREV_RIGHT)};
 
-enum TensorRtPrecision { TRT_FP32 = 0, TRT_FP16 = 1, NUM_TRT_PRECISION_CHOICES = 2 };
-const std::unordered_map<std::string, TensorRtPrecision> trt_precision_string2enum = {{"FP32", TRT_FP32}, {"FP16", TRT_FP16}};
-const std::array<std::string, NUM_TRT_PRECISION_CHOICES> trt_precision_enum2string = {"FP32", "FP16"};
+// FP32 and FP16 as in the reference (hpp:124-126); INT8 is an extension (BASELINE config 5)
+enum TensorRtPrecision { TRT_FP32 = 0, TRT_FP16 = 1, TRT_INT8 = 2, NUM_TRT_PRECISION_CHOICES = 3 };
+const std::unordered_map<std::string, TensorRtPrecision> trt_precision_string2enum = {{"FP32", TRT_FP32}, {"FP16", TRT_FP16}, {"INT8", TRT_INT8}};
+const std::array<std::string, NUM_TRT_PRECISION_CHOICES> trt_precision_enum2string = {"FP32", "FP16", "INT8"};
 
 ///////////////////////////////////////////////////////////////////////////////////////
 //////////////////////////////// Abstract class (hpp:96-178) //////////////////////////

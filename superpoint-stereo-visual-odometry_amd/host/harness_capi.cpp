@@ -10,10 +10,10 @@ extern "C" {
 
 void *spvo_host_create(const char *models_dir, const char *prefix, const char *machine, int selector_knn, int cross_check, int batch,
                        int height, int width, float conf_thresh, int dist_thresh, int border_remove, float stereo_threshold,
-                       float min_disparity, int refinement_degree, int verbose, int fp16) {
+                       float min_disparity, int refinement_degree, int verbose, int precision) {
   SuperPointFeatureFrontEnd::setModelsDir(models_dir ? models_dir : "");
   auto *fe = new SuperPointFeatureFrontEnd(MatcherType::BF, selector_knn ? SelectorType::KNN : SelectorType::NN, cross_check != 0, prefix, batch,
-                                           machine, fp16 ? TRT_FP16 : TRT_FP32, height, width, conf_thresh, dist_thresh, /*num_threads=*/6, border_remove,
+                                           machine, precision == 2 ? TRT_INT8 : precision == 1 ? TRT_FP16 : TRT_FP32, height, width, conf_thresh, dist_thresh, /*num_threads=*/6, border_remove,
                                            stereo_threshold, min_disparity, refinement_degree, verbose != 0);
   return fe;
 }

@@ -252,7 +252,7 @@ class Context:
         rc = self.lib.spvo_engine_precision(self.h)
         if rc < 0:
             raise SpvoError(rc, "no weights loaded")
-        return "FP16" if rc == 1 else "FP32"
+        return {0: "FP32", 1: "FP16", 2: "INT8"}[rc]
 
     def detect_dev_submit(self, d_img_l: int, d_img_r: int, rows: int, cols: int, stride: int, slot_l: int, slot_r: int):
         """Enqueue a detector pass (at most two may be in flight); complete them oldest-first with detect_wait."""

@@ -97,7 +97,7 @@ class FrontEnd:
         self.h = self.lib.spvo_host_create(models_dir.encode(), prefix.encode(), machine.encode(),
                                            1 if selector == "KNN" else 0, int(cross_check), batch, height, width,
                                            conf_thresh, dist_thresh, border_remove, stereo_threshold, min_disparity,
-                                           refinement_degree, int(verbose), 1 if precision == "FP16" else 0)
+                                           refinement_degree, int(verbose), {"FP32": 0, "FP16": 1, "INT8": 2}[precision])
         self.H, self.W = height, width
 
     def close(self):

@@ -10,7 +10,8 @@ own layout, so the file stays canonical and human-checkable.
 
 File layout (little endian):
     char  magic[8]  = b"SPVW0003"
-    u32   n_tensors, n_ops, input_tensor, det_tensor, desc_tensor, precision (0 = FP32, 1 = FP16), reserved[2]
+    u32   n_tensors, n_ops, input_tensor, det_tensor, desc_tensor, precision (0 = FP32, 1 = FP16, 2 = INT8),
+          act_scale_off (INT8: offset in floats of n_tensors activation scales in the payload), reserved
     n_tensors x { u32 channels, u32 level }          level = log2(downscale)
     n_ops     x { u32 type, in, out, out_c_off, cin | in_c_off << 16, cout, ksize, flags,
                   residual_tensor, reserved[3]; u64 w_off, b_off, bn_off }   offsets in floats
@@ -68,6 +69,7 @@ class Plan:
     det_tensor: int = 0
     desc_tensor: int = 0
     precision: str = "FP32"   # "FP16": the library keeps fp16 between the fp32 network input and the fp32 outputs
+    act_scales: Optional[np.ndarray] = None   # "INT8": one symmetric scale per tensor from calibration (real = q * scale)
 
     def add_tensor(self, channels: int, level: int) -> int:
         self.tensors.append((channels, level))
@@ -307,7 +309,7 @@ def onnx_plan(path: str) -> Plan:
 
 
 # --------------------------------------------------------------------------
-PRECISIONS = {"FP32": 0, "FP16": 1}
+PRECISIONS = {"FP32": 0, "FP16": 1, "INT8": 2}
 
 
 def save(plan: Plan, path: str, precision: Optional[str] = None) -> None:
@@ -331,10 +333,15 @@ def save(plan: Plan, path: str, precision: Optional[str] = None) -> None:
             payload.append(bn)
         recs.append(struct.pack("<12I3Q", op.type, op.inp, op.out, op.out_c_off, op.cin | (op.in_c_off << 16), op.cout,
                                 op.ksize, op.flags, op.residual, 0, 0, 0, w_off, b_off, bn_off))
+    act_off = 0
+    if precision == "INT8":
+        assert plan.act_scales is not None and len(plan.act_scales) == len(plan.tensors), "INT8 engines need calibrated activation scales"
+        act_off, off = off, off + len(plan.tensors)
+        payload.append(np.ascontiguousarray(plan.act_scales, np.float32))
     with open(path, "wb") as fh:
         fh.write(MAGIC)
         fh.write(struct.pack("<8I", len(plan.tensors), len(plan.ops), plan.input_tensor,
-                             plan.det_tensor, plan.desc_tensor, PRECISIONS[precision], 0, 0))
+                             plan.det_tensor, plan.desc_tensor, PRECISIONS[precision], act_off, 0))
         for ch, lvl in plan.tensors:
             fh.write(struct.pack("<2I", ch, lvl))
         for r in recs:
@@ -348,7 +355,7 @@ def load(path: str) -> Plan:
     with open(path, "rb") as fh:
         buf = fh.read()
     assert buf[:8] == MAGIC, "not a .spvw file of this version"
-    nt, no, it, dt, st, prec, _, _ = struct.unpack_from("<8I", buf, 8)
+    nt, no, it, dt, st, prec, act_off, _ = struct.unpack_from("<8I", buf, 8)
     pos = 40
     p = Plan(input_tensor=it, det_tensor=dt, desc_tensor=st, precision={v: k for k, v in PRECISIONS.items()}[prec])
     for _ in range(nt):
@@ -376,6 +383,8 @@ def load(path: str) -> Plan:
         if fl & FLAG_BN:
             op.bn = payload[bno:bno + 4 * cout + 1].copy()
         p.ops.append(op)
+    if p.precision == "INT8":
+        p.act_scales = payload[act_off:act_off + nt].copy()
     return p
 
 

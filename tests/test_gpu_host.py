@@ -159,3 +159,41 @@ def test_fp16_engine_through_the_host_class(tmp_path, squeeze_weights_path, sequ
         assert np.linalg.norm(t16 - t_true) < 0.05 and np.linalg.norm(t16 - t32) < 0.05
         a, b = set(map(tuple, kp16.tolist())), set(map(tuple, kp32.tolist()))
         assert len(a & b) / len(a | b) > 0.8
+
+
+def test_int8_engine_through_the_host_class(tmp_path, sequence):
+    """BASELINE config 5 end to end: an INT8 sp_mbv1 engine, calibrated on the device (spvo/quant.py) with the first
+    stereo pair, loaded by the host class under the reference's engine naming rule, tracks the synthetic ego-motion;
+    and the device calibration agrees with the oracle's."""
+    from oracle import frontend as ofe, net_int8
+    from spvo import quant
+    from tests.conftest import GOLDEN
+    frames, poses, P_l, P_r = sequence
+    plan = weights.load(os.path.join(GOLDEN, "sp_mbv1.spvw"))
+    x = np.stack([ofe.to_network_input(ofe.preprocess(img, P_l, 360, 1176, True)[0]) for img in frames[0]])[:, None]
+    scales = quant.calibrate(plan, [x], 360, 1176)
+    ref = net_int8.calibrate(plan, [x])
+    assert np.allclose(scales, ref, rtol=2e-3)                       # percentiles of activations that agree to 1e-4
+    plan.act_scales = scales
+    d = tmp_path / "models"
+    os.makedirs(d / "laptop")
+    weights.save(plan, str(d / "laptop" / weights.engine_name("sp_mbv1", 2, 360, 1176, "INT8")), precision="INT8")
+    weights.save(plan, str(d / "laptop" / weights.engine_name("sp_mbv1", 2, 360, 1176, "FP32")), precision="FP32")
+    out = {}
+    for prec in ("FP32", "INT8"):
+        fe = host.FrontEnd(str(d), prefix="sp_mbv1", precision=prec)
+        assert fe.engine_loaded, fe.last_error
+        res = []
+        for L, R in frames:
+            r = fe.step(L, R, P_l, P_r)
+            res.append((r, fe.keypoints(host.CURR_LEFT)))
+        out[prec] = res
+        fe.close()
+    for k in range(1, len(frames)):
+        (q8, t8), kp8 = out["INT8"][k]
+        (q32, t32), kp32 = out["FP32"][k]
+        _, t_true = synth.relative_pose(poses[k - 1], poses[k])
+        assert np.linalg.norm(t32 - t_true) < 0.05
+        assert np.linalg.norm(t8 - t_true) < 0.10                    # naive post-training quantisation: still tracks
+        a, b = set(map(tuple, kp8.tolist())), set(map(tuple, kp32.tolist()))
+        assert len(a & b) / len(a | b) > 0.4

@@ -122,6 +122,39 @@ def test_fp16_engine_matches_fp16_oracle(graph, H, W, batch, vgg_plan, squeeze_p
     ctx.close()
 
 
+@pytest.mark.parametrize("graph,H,W,batch", [("mbv1", 192, 640, 2), ("mbv2", 192, 640, 2), ("mbv1", 360, 1176, 2), ("vgg", 120, 392, 2)])
+def test_int8_engine_is_bit_exact(graph, H, W, batch, vgg_plan, sample_images, tmp_path):
+    """BASELINE config 5: INT8 engines.  The arithmetic is defined by oracle/net_int8.py (exact int32 accumulation,
+    separately rounded fp32 multiply / add in the requantisation), so every int8 tensor and the fp32 detector
+    output must agree with the oracle BIT FOR BIT; only the L2-normalised descriptors (a float reduction whose
+    order differs) carry a tolerance, 1e-5."""
+    import copy, os
+    from oracle import net_int8
+    from spvo import weights
+    from tests.conftest import GOLDEN
+    plan = copy.copy(vgg_plan) if graph == "vgg" else weights.load(os.path.join(GOLDEN, f"sp_{graph}.spvw"))
+    x = _input(sample_images, H, W, batch)
+    plan.act_scales = net_int8.calibrate(plan, [x[:1]])                    # calibrated on the first image only
+    plan.precision = "INT8"
+    path = str(tmp_path / weights.engine_name(graph, 2, H, W, "INT8"))
+    weights.save(plan, path)
+    ctx = make_ctx(path, net_height=H, net_width=W)
+    assert ctx.engine_precision() == "INT8"
+    det, desc = ctx.forward(x)
+    rdet, rdesc, vals = net_int8.forward(plan, x, return_all=True)
+    for tid, (ch, lvl) in enumerate(plan.tensors):
+        if tid in (plan.input_tensor, plan.desc_tensor):
+            continue
+        got = ctx.debug_tensor(tid, batch, ch, lvl)
+        if vals[tid].dtype == np.int8:
+            assert np.array_equal(got, vals[tid].astype(np.float32)), f"int8 tensor {tid}: {(got != vals[tid]).sum()} of {got.size} values differ"
+        else:
+            assert np.array_equal(got, vals[tid]), f"fp32 tensor {tid}: max diff {np.abs(got - vals[tid]).max()}"
+    assert np.array_equal(det, rdet)
+    assert np.abs(desc - rdesc.transpose(0, 2, 3, 1)).max() <= 1e-5
+    ctx.close()
+
+
 def test_forward_is_deterministic_and_batch_independent(ctx_vgg, sample_images):
     x = _input(sample_images, 360, 1176, 2)
     d1, s1 = ctx_vgg.forward(x)

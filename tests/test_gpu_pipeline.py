@@ -60,9 +60,17 @@ def test_detect_properties_full_size(ctx_vgg, stereo_pair):
     # swapping left and right swaps the outputs
     c = ctx_vgg.detect(R, L, P_r, P_l, 0, 1)
     assert np.array_equal(c["xy_l"], a["xy_r"]) and np.array_equal(c["desc_r"], a["desc_l"])
-    # a stereo pair matched against itself: every keypoint finds itself at distance 0 (NN)
+    # a slot matched against itself (NN + crossCheck): every keypoint finds itself at distance 0 -- except where the
+    # seeded, untrained network produced (near-)duplicate descriptors, squared distance below the 1e-6 the distance GEMM
+    # of the shortlist resolves: of such a group one row collects the votes and the others stay unmatched
     idx, dist = ctx_vgg.match_slots(0, 0, len(c["xy_l"]), "NN", True)
-    assert np.array_equal(idx, np.arange(len(idx))) and np.all(dist == 0)
+    hit = idx >= 0
+    assert np.array_equal(idx[hit], np.arange(len(idx))[hit]) and np.all(dist[hit] == 0) and hit.mean() > 0.97
+    desc = c["desc_l"].astype(np.float64)
+    for i in np.nonzero(~hit)[0]:
+        d2 = ((desc - desc[i]) ** 2).sum(1)
+        d2[i] = np.inf
+        assert d2.min() < 1e-6
 
 
 def test_prematch_is_transparent(ctx_squeeze, stereo_pair):
