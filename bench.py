@@ -82,14 +82,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ["SPVO_DEVICE"] = str(local_rank)
+    os.environ.setdefault("SPVO_QUIET", "1")    # the seeded (untrained) weights make the reference's gating message fire on every frame
 
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    # Test hook: SPVO_BENCH_SHARED_GPU=1 lets several ranks share the visible GPU(s) over the gloo backend, so the N > 1
+    # code path (pose gather, barrier, max-over-ranks timing) can be exercised on a one-GPU box.  RCCL refuses two ranks
+    # on one device; a real run uses one GPU per rank and backend "nccl" (= RCCL).
+    shared = os.environ.get("SPVO_BENCH_SHARED_GPU") == "1"
+    if shared:
+        local_rank = local_rank % torch.cuda.device_count()
+        os.environ["SPVO_DEVICE"] = str(local_rank)
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from spvo import host, posegather, synth, weights
 

@@ -54,7 +54,8 @@ Transform Transform::operator*(const Transform &o) const {
 // ------------------------------------------------------------------------- logging
 void FeatureFrontEnd::logError(const std::string &msg) {
   last_error_ = msg;
-  std::fprintf(stderr, "[ERROR] %s\n", msg.c_str());  // ROS_ERROR stand-in
+  static const bool quiet = std::getenv("SPVO_QUIET") != nullptr;   // benchmarks with untrained weights trip the gating message every frame
+  if (!quiet) std::fprintf(stderr, "[ERROR] %s\n", msg.c_str());  // ROS_ERROR stand-in
 }
 void FeatureFrontEnd::logInfo(const std::string &msg) const {
   if (verbose_) std::fprintf(stderr, "[ INFO] %s\n", msg.c_str());
