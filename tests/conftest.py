@@ -33,6 +33,13 @@ def pytest_sessionstart(session):
             torch.cuda.init()
     except Exception:   # no torch / no GPU: the CPU suite does not need it
         pass
+    # a fresh checkout has no built libraries (they are git-ignored): build them once (hipcc cross-compiles without a GPU)
+    pkg = os.path.join(ROOT, "superpoint-stereo-visual-odometry_amd")
+    if not (os.path.exists(os.path.join(pkg, "libspvo.so")) and os.path.exists(os.path.join(pkg, "libspvo_host.so"))):
+        import shutil
+        import subprocess
+        if shutil.which("hipcc") and shutil.which("make"):
+            subprocess.run(["make", "-C", pkg, "all"], check=False)
 
 
 @pytest.fixture(scope="session")
