@@ -27,16 +27,20 @@ struct ResizeTab {  // device arrays
   const int *yi, *yb0, *yb1;  // [H]
 };
 
-__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t *__restrict__ src,
+// blockIdx.z selects the image of a stereo pair (src0 / src1; output slot z of out_u8 and of the input tensor)
+__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t *__restrict__ src0, const uint8_t *__restrict__ src1,
                                                          size_t stride, int src_rows, int src_cols,
                                                          int row_off, int col_off, int crop_rows,
                                                          int crop_cols, ResizeTab tab, int H, int W,
                                                          uint8_t *__restrict__ out_u8,
-                                                         float *__restrict__ out_plane, int hp,
+                                                         float *__restrict__ out_plane, size_t plane_per_image, int hp,
                                                          int wp, int identity) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= W || y >= H) return;
+  const uint8_t *src = blockIdx.z ? src1 : src0;
+  if (out_u8) out_u8 += (size_t)blockIdx.z * H * W;
+  out_plane += (size_t)blockIdx.z * plane_per_image;
   int v;
   if (identity) {  // cv::resize copies when the sizes already match
     v = src[(size_t)(row_off + y) * stride + col_off + x];

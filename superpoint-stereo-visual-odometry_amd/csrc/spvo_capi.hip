@@ -747,7 +747,8 @@ int ensure_tables(spvo_ctx *c, const CropGeom &g) {
   return SPVO_OK;
 }
 
-int launch_preprocess(spvo_ctx *c, const uint8_t *d_src, int rows, int cols, size_t stride, const CropGeom &g, int slot) {
+// one launch for `count` images (d_src0, d_src1) into slots slot0, slot0 + 1 of the resized-image buffer and the input tensor
+int launch_preprocess(spvo_ctx *c, const uint8_t *d_src0, const uint8_t *d_src1, int count, int rows, int cols, size_t stride, const CropGeom &g, int slot0) {
   int rc = ensure_tables(c, g);
   if (rc) return rc;
   ResizeTab tab;
@@ -755,9 +756,9 @@ int launch_preprocess(spvo_ctx *c, const uint8_t *d_src, int rows, int cols, siz
   tab.yi = c->d_tab + 3 * c->W; tab.yb0 = tab.yi + c->H; tab.yb1 = tab.yi + 2 * c->H;
   const Tensor &tin = c->tensors[c->t_input];
   const int identity = (g.crop_rows == c->H && g.crop_cols == c->W) ? 1 : 0;
-  dim3 grid((c->W + 63) / 64, (c->H + 3) / 4);
-  hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, c->stream, d_src, stride, rows, cols, g.row_off, g.col_off, g.crop_rows, g.crop_cols, tab, c->H, c->W,
-                     c->d_resized + (size_t)slot * c->H * c->W, tin.d + (size_t)slot * tin.per_image, tin.hp, tin.wp, identity);
+  dim3 grid((c->W + 63) / 64, (c->H + 3) / 4, count);
+  hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, c->stream, d_src0, d_src1, stride, rows, cols, g.row_off, g.col_off, g.crop_rows, g.crop_cols, tab, c->H, c->W,
+                     c->d_resized + (size_t)slot0 * c->H * c->W, tin.d + (size_t)slot0 * tin.per_image, tin.per_image, tin.hp, tin.wp, identity);
   HIP_TRY(c, hipGetLastError());
   return SPVO_OK;
 }
@@ -1481,7 +1482,7 @@ int spvo_preprocess(spvo_ctx *c, const uint8_t *img, int rows, int cols, size_t 
   }
   const CropGeom g = crop_geometry(rows, cols, c->H, c->W);
   HIP_TRY(c, hipMemcpyAsync(c->d_img[0], img, bytes, hipMemcpyHostToDevice, c->stream));
-  int rc = launch_preprocess(c, c->d_img[0], rows, cols, stride, g, 0);
+  int rc = launch_preprocess(c, c->d_img[0], c->d_img[0], 1, rows, cols, stride, g, 0);
   if (rc) return rc;
   fix_projection(P, g, rows, cols, c->cfg.bug_compat_p);
   if (resized_u8) HIP_TRY(c, hipMemcpyAsync(resized_u8, c->d_resized, (size_t)c->H * c->W, hipMemcpyDeviceToHost, c->stream));
@@ -1653,7 +1654,8 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   if (prof_detect) { det_e0 = get_event(c); (void)hipEventRecord(det_e0, c->stream); }
   {
     ScopedStage sp(c, stage_id(c, "preprocess"));
-    for (int i = 0; i < 2; ++i) { int rc = launch_preprocess(c, srcs[i], rows, cols, stride, g, i); if (rc) return rc; }
+    int rc = launch_preprocess(c, srcs[0], srcs[1], 2, rows, cols, stride, g, 0);
+    if (rc) return rc;
   }
   int rc = run_network(c, 2);
   c->cur_ring = 0;
