@@ -176,6 +176,11 @@ int spvo_match_slots(spvo_ctx *ctx, int slot_a, int slot_b, int selector, int cr
  * are identical with it on or off. */
 int spvo_set_prematch(spvo_ctx *ctx, int enable, int selector, int cross_check, float ratio);
 
+/* Extension (BASELINE config 5): build the matcher's candidate shortlist with an fp8 (e4m3) distance GEMM instead of
+ * the fp32 one.  The exact re-rank still yields exact distances for the candidates it is given, but the shortlist --
+ * and therefore a borderline ratio-test decision or a near-tie -- is approximate; off by default. */
+int spvo_set_match_fp8(spvo_ctx *ctx, int enable);
+
 /* cv::triangulatePoints + convertPointsFromHomogeneous (base.cpp:211-223):
  * DLT null vector of the 4x4 system in f64, stored f32, then x/w.
  * xy_l, xy_r: [n][2] f32; xyz: [n][3] f32. */

@@ -38,6 +38,7 @@ struct MatchJob {
   int *shortlist;                 // [na][groups][MATCH_KEEP]
   float *best_d2;                 // [na][2]
   int *best_idx;                  // [na][2]
+  const unsigned char *A8, *B8;   // fp8 (e4m3) copies [n][256] of A * 16 and B * 16 for the fp8 shortlist GEMM, or NULL
   unsigned long long *train_best; // [nb] (cross-check only: the sides are swapped, nb = query rows; {distance bits, train row})
   int2 *out;                      // [na] packed {train_idx, float bits of the distance} ([nb] with cross-check)
 };
@@ -55,6 +56,22 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float *__restrict
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
   if (lane == 0) out[r] = s;
+}
+
+// fp8 copy of descriptor rows for the fp8 shortlist GEMM (BASELINE config 5): x * 16 rounded to OCP e4m3 (unit-norm
+// descriptors have entries around 1/16, so the scale puts them in the format's normal range).  One wave per row.
+constexpr float MATCH_FP8_SCALE = 16.f;
+__global__ __launch_bounds__(256) void desc_to_fp8_kernel(const float *__restrict__ x, int n_host, const int *__restrict__ n_ptr,
+                                                          unsigned char *__restrict__ out) {
+  const int n = dev_count(n_host, n_ptr);
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= n) return;
+  const float4 v = *(const float4 *)(x + (size_t)r * MATCH_D + lane * 4);
+  int pk = 0;
+  pk = __builtin_amdgcn_cvt_pk_fp8_f32(v.x * MATCH_FP8_SCALE, v.y * MATCH_FP8_SCALE, pk, false);
+  pk = __builtin_amdgcn_cvt_pk_fp8_f32(v.z * MATCH_FP8_SCALE, v.w * MATCH_FP8_SCALE, pk, true);
+  reinterpret_cast<int *>(out + (size_t)r * MATCH_D)[lane] = pk;
 }
 
 // K12a. grid = (ceil(nb/128), ceil(na/32), jobs).  shortlist[q][group][MATCH_KEEP] (train idx, -1 = none)
@@ -78,6 +95,11 @@ __device__ __forceinline__ void shortlist_insert(float (&bd)[MATCH_KEEP], int (&
   }
 }
 
+// FP8 = true: the dot products of the shortlist come from v_mfma_f32_32x32x16_fp8_fp8 on the fp8 copies (operands straight
+// from global memory: a lane's 8 consecutive dimensions of one row are 8 contiguous bytes); the shortlist is then
+// APPROXIMATE -- the exact re-rank (K12b) still produces exact distances for whatever it contains -- so this mode is an
+// opt-in (spvo_set_match_fp8) and the default keeps the fp32 GEMM whose shortlist error is 1e-7.
+template <bool FP8>
 __global__ __launch_bounds__(256) void match_gemm_kernel(MatchJobs jobs, int groups) {
   const MatchJob jb = jobs.j[blockIdx.z];
   const float *__restrict__ A = jb.A;
@@ -101,7 +123,17 @@ __global__ __launch_bounds__(256) void match_gemm_kernel(MatchJobs jobs, int gro
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  for (int k0 = 0; k0 < MATCH_D; k0 += MATCH_KS) {
+  if constexpr (FP8) {
+    const int q = min(q0 + j, na - 1), t = min(t0 + wave * 32 + j, nb - 1);       // clamped rows are masked out below
+    const long *pa8 = reinterpret_cast<const long *>(jb.A8 + (size_t)q * MATCH_D) + half;
+    const long *pb8 = reinterpret_cast<const long *>(jb.B8 + (size_t)t * MATCH_D) + half;
+#pragma unroll
+    for (int s = 0; s < MATCH_D / 16; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(pa8[2 * s], pb8[2 * s], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] *= 1.f / (MATCH_FP8_SCALE * MATCH_FP8_SCALE);
+  }
+  for (int k0 = 0; k0 < (FP8 ? 0 : MATCH_D); k0 += MATCH_KS) {
     __syncthreads();
     // 160 rows x 16 float4: consecutive threads walk along k (coalesced 256-byte runs)
 #pragma unroll

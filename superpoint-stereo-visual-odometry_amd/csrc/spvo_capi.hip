@@ -94,6 +94,7 @@ struct MatchScratch {         // one set per concurrently enqueued match
   float *d_na = nullptr, *d_nb = nullptr, *d_best_d2 = nullptr;
   int *d_short = nullptr, *d_best_idx = nullptr;
   unsigned long long *d_train_best = nullptr;
+  unsigned char *d_a8 = nullptr, *d_b8 = nullptr;   // fp8 copies of both sides (spvo_set_match_fp8)
   int2 *d_out = nullptr;      // packed result, points into spvo_ctx::d_match_out
 };
 
@@ -168,6 +169,7 @@ struct spvo_ctx {
   int *h_counters_r[RING] = {nullptr, nullptr, nullptr, nullptr};
   float *h_xy_r[RING] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_net[RING] = {nullptr, nullptr, nullptr, nullptr}, ev_tail[RING] = {nullptr, nullptr, nullptr, nullptr};
+  bool match_fp8 = false;        // fp8 shortlist GEMM (approximate; spvo_set_match_fp8)
   bool prematch = false;
   int pm_selector = SPVO_SELECT_KNN, pm_cross = 0;
   float pm_ratio = 0.8f;
@@ -849,7 +851,7 @@ int ensure_match(spvo_ctx *c, int na, int nb) {
   for (void *p : {(void *)c->d_ma, (void *)c->d_mb, (void *)c->d_match_out})
     if (p) (void)hipFree(p);
   for (auto &m : c->ms)
-    for (void *p : {(void *)m.d_na, (void *)m.d_nb, (void *)m.d_best_d2, (void *)m.d_short, (void *)m.d_best_idx, (void *)m.d_train_best})
+    for (void *p : {(void *)m.d_na, (void *)m.d_nb, (void *)m.d_best_d2, (void *)m.d_short, (void *)m.d_best_idx, (void *)m.d_train_best, (void *)m.d_a8, (void *)m.d_b8})
       if (p) (void)hipFree(p);
   for (auto &p : c->h_match_out) { if (p) (void)hipHostFree(p); p = nullptr; }
   if (c->h_match_tmp) (void)hipHostFree(c->h_match_tmp);
@@ -866,6 +868,8 @@ int ensure_match(spvo_ctx *c, int na, int nb) {
     if ((rc = dev_alloc(c, &m.d_short, (size_t)cap * groups * MATCH_KEEP))) return rc;
     if ((rc = dev_alloc(c, &m.d_best_idx, (size_t)cap * 2))) return rc;
     if ((rc = dev_alloc(c, &m.d_train_best, cap))) return rc;
+    if ((rc = dev_alloc(c, &m.d_a8, (size_t)cap * MATCH_D))) return rc;
+    if ((rc = dev_alloc(c, &m.d_b8, (size_t)cap * MATCH_D))) return rc;
     m.d_out = c->d_match_out + (size_t)k * cap;
   }
   for (int r = 0; r < RING; ++r) HIP_TRY(c, hipHostMalloc((void **)&c->h_match_out[r], (size_t)2 * cap * sizeof(int2)));
@@ -911,6 +915,12 @@ int enqueue_matches(spvo_ctx *c, const MatchReq *req_in, int njobs, int selector
     j.nA = req[k].sqA ? req[k].sqA : m.d_na;
     j.nB = req[k].sqB ? req[k].sqB : m.d_nb;
     j.shortlist = m.d_short; j.best_d2 = m.d_best_d2; j.best_idx = m.d_best_idx; j.train_best = m.d_train_best; j.out = m.d_out;
+    j.A8 = j.B8 = nullptr;
+    if (c->match_fp8) {
+      hipLaunchKernelGGL(desc_to_fp8_kernel, dim3((req[k].na + 3) / 4), dim3(256), 0, c->post, req[k].dA, req[k].na, req[k].na_ptr, m.d_a8);
+      hipLaunchKernelGGL(desc_to_fp8_kernel, dim3((req[k].nb + 3) / 4), dim3(256), 0, c->post, req[k].dB, req[k].nb, req[k].nb_ptr, m.d_b8);
+      j.A8 = m.d_a8; j.B8 = m.d_b8;
+    }
     na_max = std::max(na_max, req[k].na);
     nb_max = std::max(nb_max, req[k].nb);
     if (!req[k].sqA) hipLaunchKernelGGL(row_sqnorm_kernel, dim3((req[k].na + 3) / 4), dim3(256), 0, c->post, req[k].dA, req[k].na, req[k].na_ptr, m.d_na);
@@ -924,12 +934,14 @@ int enqueue_matches(spvo_ctx *c, const MatchReq *req_in, int njobs, int selector
   const size_t lds = MATCH_LDS_BYTES;
   static bool attr[64] = {};
   if (!attr[c->cfg.device & 63]) {
-    HIP_TRY(c, hipFuncSetAttribute((const void *)match_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(c, hipFuncSetAttribute((const void *)match_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(c, hipFuncSetAttribute((const void *)match_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr[c->cfg.device & 63] = true;
   }
   {
     ScopedStage sg(c, stage_id(c, "match_gemm"), fl, 4.0 * (na_max + nb_max) * MATCH_D * njobs);
-    hipLaunchKernelGGL(match_gemm_kernel, dim3(groups, (na_max + MATCH_QT - 1) / MATCH_QT, njobs), dim3(256), lds, c->post, jobs, groups);
+    if (c->match_fp8) hipLaunchKernelGGL(match_gemm_kernel<true>, dim3(groups, (na_max + MATCH_QT - 1) / MATCH_QT, njobs), dim3(256), lds, c->post, jobs, groups);
+    else hipLaunchKernelGGL(match_gemm_kernel<false>, dim3(groups, (na_max + MATCH_QT - 1) / MATCH_QT, njobs), dim3(256), lds, c->post, jobs, groups);
   }
   hipLaunchKernelGGL(match_rerank_kernel, dim3((na_max + 3) / 4, njobs), dim3(256), 0, c->post, jobs, groups, selector, cross_check, ratio);
   if (swap) hipLaunchKernelGGL(match_select_cross_kernel, dim3((nb_max + 255) / 256, njobs), dim3(256), 0, c->post, jobs);
@@ -1140,8 +1152,8 @@ void spvo_destroy(spvo_ctx *c) {
   free_plan(c);
   void *ptrs[] = {c->d_dense_in, c->d_det_dense, c->d_resized, c->d_tab, c->d_img[0], c->d_img[1], c->d_xy_tmp, c->d_desc_tmp,
                   c->d_ma, c->d_mb, c->d_match_out, c->d_counters_all, c->d_xy_stage,
-                  c->ms[0].d_na, c->ms[0].d_nb, c->ms[0].d_best_d2, c->ms[0].d_short, c->ms[0].d_best_idx, c->ms[0].d_train_best,
-                  c->ms[1].d_na, c->ms[1].d_nb, c->ms[1].d_best_d2, c->ms[1].d_short, c->ms[1].d_best_idx, c->ms[1].d_train_best,
+                  c->ms[0].d_na, c->ms[0].d_nb, c->ms[0].d_best_d2, c->ms[0].d_short, c->ms[0].d_best_idx, c->ms[0].d_train_best, c->ms[0].d_a8, c->ms[0].d_b8,
+                  c->ms[1].d_na, c->ms[1].d_nb, c->ms[1].d_best_d2, c->ms[1].d_short, c->ms[1].d_best_idx, c->ms[1].d_train_best, c->ms[1].d_a8, c->ms[1].d_b8,
                   c->d_P, c->d_pts_a, c->d_pts_b, c->d_xyz, c->rw.counts, c->rw.poses, c->rw.result, c->rw.inliers, c->d_obs, c->d_refine};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (int r = 0; r < RING; ++r) {
@@ -1849,6 +1861,14 @@ int spvo_set_prematch(spvo_ctx *c, int enable, int selector, int cross_check, fl
   c->pm_selector = selector;
   c->pm_cross = cross_check ? 1 : 0;
   c->pm_ratio = ratio;
+  for (auto &set : c->mcache)
+    for (auto &mc : set) mc.valid = false;
+  return SPVO_OK;
+}
+
+int spvo_set_match_fp8(spvo_ctx *c, int enable) {
+  if (!c) return fail(c, SPVO_ERR_INVALID, "null context");
+  c->match_fp8 = enable != 0;
   for (auto &set : c->mcache)
     for (auto &mc : set) mc.valid = false;
   return SPVO_OK;

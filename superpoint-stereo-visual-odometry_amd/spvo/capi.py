@@ -58,7 +58,7 @@ OBS_DTYPE = np.dtype([("X", np.float32, 3), ("uv", np.float32, 2), ("cam", np.in
 SYMBOLS = [
     "spvo_default_config", "spvo_create", "spvo_destroy", "spvo_last_error", "spvo_load_weights", "spvo_engine_precision",
     "spvo_preprocess", "spvo_forward", "spvo_debug_tensor", "spvo_heatmap", "spvo_nms",
-    "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_detect_dev_submit", "spvo_detect_wait", "spvo_match", "spvo_match_slots", "spvo_set_prematch",
+    "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_detect_dev_submit", "spvo_detect_wait", "spvo_match", "spvo_match_slots", "spvo_set_prematch", "spvo_set_match_fp8",
     "spvo_triangulate", "spvo_pnp_ransac", "spvo_pnp_refine", "spvo_solve_stereo_odometry", "spvo_stream", "spvo_synchronize",
     "spvo_profile_enable", "spvo_profile_reset", "spvo_profile_only", "spvo_profile_count", "spvo_profile_get",
 ]
@@ -247,6 +247,9 @@ class Context:
                                              _dptr(Pl), _dptr(Pr), slot_l, slot_r, C.byref(fl), C.byref(fr)))
         return dict(xy_l=xyl[:fl.n], xy_r=xyr[:fr.n], desc_l=None if dl is None else dl[:fl.n],
                     desc_r=None if dr is None else dr[:fr.n], P_l=Pl.reshape(3, 4), P_r=Pr.reshape(3, 4))
+
+    def set_match_fp8(self, enable: bool):
+        self._check(self.lib.spvo_set_match_fp8(self.h, int(enable)))
 
     def engine_precision(self) -> str:
         rc = self.lib.spvo_engine_precision(self.h)

@@ -192,3 +192,29 @@ def test_nms_redo_with_two_submissions_in_flight(vgg_plan, tmp_path):
     prof = ctx.profile()
     assert prof["nms_redo"]["calls"] >= 4 and prof["rematch"]["calls"] >= 1      # the path under test really ran
     ctx.close()
+
+
+def test_fp8_shortlist_matcher(ctx_squeeze, stereo_pair):
+    """BASELINE config 5: the shortlist of the matcher from an fp8 (e4m3) distance GEMM.  The shortlist is approximate,
+    the re-rank exact: every CONFIDENT match (best / second-best distance below 0.7) is found with bit-identical index
+    and distance, and on trained descriptors the borderline rows that may differ are a fraction of a percent."""
+    frames, _, P_l, P_r = stereo_pair
+    L, R = frames[0]
+    out = ctx_squeeze.detect(L, R, P_l, P_r, 0, 1)
+    n = len(out["xy_l"])
+    ridx, rd = matching.bf_match(out["desc_l"], out["desc_r"], "KNN", False, 0.8)
+    d2 = np.sort(matching.sq_distances(out["desc_l"], out["desc_r"]), axis=1)
+    confident = np.sqrt(d2[:, 0]) < 0.7 * np.sqrt(d2[:, 1])
+    try:
+        ctx_squeeze.set_match_fp8(True)
+        idx, d = ctx_squeeze.match_slots(0, 1, n)
+        nn_idx, nn_d = ctx_squeeze.match_slots(0, 1, n, "NN", False)
+    finally:
+        ctx_squeeze.set_match_fp8(False)
+    assert confident.sum() > 300
+    assert np.array_equal(idx[confident], ridx[confident]) and np.array_equal(d[confident], rd[confident])
+    assert (idx != ridx).mean() < 0.01
+    r_nn, r_nnd = matching.bf_match(out["desc_l"], out["desc_r"], "NN", False, 0.8)
+    assert (nn_idx != r_nn).mean() < 0.01 and np.array_equal(nn_d[nn_idx == r_nn], r_nnd[nn_idx == r_nn])
+    idx2, d2_ = ctx_squeeze.match_slots(0, 1, n)                              # back to the fp32 shortlist: exact again
+    assert np.array_equal(idx2, ridx) and np.array_equal(d2_, rd)
