@@ -69,11 +69,23 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--no-pipeline", action="store_true", help="do not hand the next stereo pairs over early")
     ap.add_argument("--net-size", default="360x1176", help="network input HxW: 360x1176 (the reference's, default = the headline workload) or 376x1240 (native, SURVEY.md section 8)")
-    ap.add_argument("--precision", default="FP32", choices=["FP32", "FP16"],
-                    help="FP32 = the headline workload (BASELINE config 2); FP16 = the half-precision engine of config 3 (use with --net-size 192x640)")
+    ap.add_argument("--precision", default="FP32", choices=["FP32", "FP16", "INT8"],
+                    help="FP32 = the headline workload (BASELINE config 2); FP16 = the half-precision engine of config 3 (use with --net-size 192x640); "
+                         "INT8 = post-training-quantised engine, calibrated on the device on the bench's own frames (config 5)")
+    ap.add_argument("--graph", default="vgg", choices=["vgg", "sp_mbv1", "sp_mbv2", "sp_squeeze"],
+                    help="network: vgg (seeded, the headline) or one of the reference's ONNX graphs (tests/golden/<graph>.spvw)")
+    ap.add_argument("--max-keypoints", type=int, default=1000, help="keypoint cap per image (reference: 1000; config 5: 2048)")
+    ap.add_argument("--match-fp8", action="store_true", help="fp8 (e4m3) shortlist GEMM in the matcher, exact fp32 re-rank (config 5)")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 5],
+                    help="BASELINE.json config shortcut: 2 = default; 3 = FP16 192x640; 5 = sp_mbv1 INT8, 2048 keypoints, fp8 shortlist")
     ap.add_argument("--dump-ops", action="store_true", help="add per-layer network times to the JSON line")
     ap.add_argument("--depth", type=int, default=2, choices=[1, 2], help="stereo pairs handed over ahead of the one being solved")
     args = ap.parse_args()
+    if args.config == 3:
+        args.precision, args.net_size = "FP16", "192x640"
+    elif args.config == 5:
+        args.precision, args.graph, args.max_keypoints, args.match_fp8 = "INT8", "sp_mbv1", 2048, True
+    headline = args.precision == "FP32" and args.graph == "vgg" and args.max_keypoints == 1000 and not args.match_fp8
     global NET_H, NET_W
     NET_H, NET_W = (int(v) for v in args.net_size.lower().split("x"))
 
@@ -83,6 +95,10 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ["SPVO_DEVICE"] = str(local_rank)
     os.environ.setdefault("SPVO_QUIET", "1")    # the seeded (untrained) weights make the reference's gating message fire on every frame
+    if args.max_keypoints != 1000:
+        os.environ["SPVO_MAX_KEYPOINTS"] = str(args.max_keypoints)
+    if args.match_fp8:
+        os.environ["SPVO_MATCH_FP8"] = "1"
 
     import torch
     import torch.distributed as dist
@@ -104,15 +120,20 @@ def main():
 
     from spvo import host, posegather, synth, weights
 
-    plan = weights.vgg_plan(seed=0)
-    plan.precision = args.precision
+    plan = weights.vgg_plan(seed=0) if args.graph == "vgg" else weights.load(os.path.join(ROOT, "tests", "golden", args.graph + ".spvw"))
+    n_params = int(sum(op.weight.size + op.bias.size for op in plan.ops if op.weight is not None))
     tmp = tempfile.mkdtemp(prefix=f"spvo_bench_{rank}_")
     os.makedirs(os.path.join(tmp, "laptop"))
-    weights.save(plan, os.path.join(tmp, "laptop", weights.engine_name("superpoint_pretrained", 2, NET_H, NET_W, args.precision)))
 
     # every rank renders its own stream (different seed = different ego-motion); sample-image texture
     tex = os.path.join(ROOT, "tests", "golden", "images", "0000000000.png")
     frames, poses, P_l, P_r = synth.stereo_sequence(SEQ_LEN, tex, seed=posegather.stream_seed(rank))
+    if args.precision == "INT8":       # activation scales from the fp32 engine of the same plan on this stream's own frames (on the device)
+        from spvo import quant
+        calib = [quant.calibration_inputs(plan, frames[k], NET_H, NET_W) for k in (0, SEQ_LEN // 2, SEQ_LEN - 1)]
+        plan.act_scales = quant.calibrate(plan, calib, NET_H, NET_W)
+    plan.precision = args.precision
+    weights.save(plan, os.path.join(tmp, "laptop", weights.engine_name("superpoint_pretrained", 2, NET_H, NET_W, args.precision)))
     d_frames = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
     rows, cols = frames[0][0].shape
     order = list(range(SEQ_LEN)) + list(range(SEQ_LEN - 2, 0, -1))       # ping-pong: every step is a real motion
@@ -151,7 +172,7 @@ def main():
     # context's stream: two event records per step.  Timing every stage costs 2 records per kernel and 7 % of the
     # throughput, so the stage breakdown comes from a separate, untimed pass below.
     if not args.no_profile:
-        ctx.profile_only("conv:1")
+        ctx.profile_only("conv:1" if args.graph == "vgg" else "detect")
         ctx.profile_enable(True)
         ctx.profile_reset()
     barrier()
@@ -184,13 +205,15 @@ def main():
         out = {
             "metric": "stereo frames/sec (1241x376 KITTI)", "value": round(total_frames / elapsed, 2), "unit": "stereo frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "FP32" else "f16", "data": "synthetic",
-            "config": {"workload": f"SuperPoint VGG {args.precision.lower()} (seeded synthetic weights, 1300865 params), 1241x376 stereo pairs, "
-                                   f"net {NET_H}x{NET_W}, 1000 kp cap, BF+KNN 0.8, P3P-style RANSAC 500 it, LM refinement degree 4; "
-                                   "one stereo stream per GPU, RCCL all-gather of poses",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"FP32": "f32", "FP16": "f16", "INT8": "i8"}[args.precision], "data": "synthetic",
+            "config": {"workload": (f"SuperPoint VGG {args.precision.lower()} (seeded synthetic weights, {n_params} params)" if args.graph == "vgg" else
+                                    f"SuperPoint {args.graph} {args.precision.lower()} (the reference's ONNX graph, seeded weights, {n_params} params)")
+                                   + f", 1241x376 stereo pairs, net {NET_H}x{NET_W}, {args.max_keypoints} kp cap, "
+                                   + ("fp8 shortlist + exact re-rank, " if args.match_fp8 else "")
+                                   + "BF+KNN 0.8, P3P-style RANSAC 500 it, LM refinement degree 4; one stereo stream per GPU, RCCL all-gather of poses",
                        "net_size": [NET_H, NET_W], "input_size": [rows, cols], "streams": world},
         }
-        dom = prof.get("conv:1")                                           # conv1b: 43 % of all CNN FLOPs
+        dom = prof.get("conv:1") if args.graph == "vgg" and args.precision != "INT8" else None     # conv1b: 43 % of all CNN FLOPs
         if dom and dom["calls"]:
             avg_ms = dom["total_ms"] / dom["calls"]
             achieved = dom["flops"] / (avg_ms * 1e-3) / 1e12
@@ -218,7 +241,7 @@ def main():
                 out["net_ops_ms"] = {k: round(v["total_ms"] / max(v["calls"], 1), 4) for k, v in prof_all.items()
                                      if k.startswith(("conv:", "pool:", "l2norm:", "dwconv:"))}
             out["conv_stack_tflops"] = round(conv_fl / (conv_ms * 1e-3) / 1e12, 2)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and headline:
             out["cpu_baseline"] = cpu_baseline(frames, P_l, P_r, plan)
         print(json.dumps(out), flush=True)
     fe.close()

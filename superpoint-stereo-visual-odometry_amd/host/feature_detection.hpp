@@ -267,7 +267,7 @@ private:
   const float conf_thresh_;
   const int dist_thresh_;
   const int border_remove_;
-  static constexpr int max_keypoints_ = 1000;
+  int max_keypoints_ = 1000;   // hpp:368 (static constexpr there); env SPVO_MAX_KEYPOINTS raises it (BASELINE config 5: 2048)
   const int num_threads_;  // kept for signature parity; the work runs on the GPU
   bool engine_loaded_ = false;
   std::vector<float> xy_buf_[2], desc_buf_[2];

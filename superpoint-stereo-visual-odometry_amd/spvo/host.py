@@ -99,6 +99,7 @@ class FrontEnd:
                                            conf_thresh, dist_thresh, border_remove, stereo_threshold, min_disparity,
                                            refinement_degree, int(verbose), {"FP32": 0, "FP16": 1, "INT8": 2}[precision])
         self.H, self.W = height, width
+        self.cap = max(1000, int(os.environ.get("SPVO_MAX_KEYPOINTS", "1000")))
 
     def close(self):
         if self.h:
@@ -181,13 +182,13 @@ class FrontEnd:
         return self.lib.spvo_host_frame_count(self.h)
 
     def keypoints(self, position):
-        xy = np.zeros((1000, 2), np.float32)
-        n = self.lib.spvo_host_keypoints(self.h, position, _p(xy), 1000)
+        xy = np.zeros((self.cap, 2), np.float32)
+        n = self.lib.spvo_host_keypoints(self.h, position, _p(xy), self.cap)
         return xy[:max(n, 0)].copy()
 
     def descriptors(self, position):
-        d = np.zeros((1000, 256), np.float32)
-        n = self.lib.spvo_host_descriptors(self.h, position, _p(d), 1000)
+        d = np.zeros((self.cap, 256), np.float32)
+        n = self.lib.spvo_host_descriptors(self.h, position, _p(d), self.cap)
         return d[:max(n, 0)].copy()
 
     def image(self, position):
@@ -196,10 +197,10 @@ class FrontEnd:
         return out if n == out.size else None
 
     def matches(self, match_type):
-        q = np.zeros(1000, np.int32)
-        t = np.zeros(1000, np.int32)
-        d = np.zeros(1000, np.float32)
-        n = self.lib.spvo_host_matches(self.h, match_type, _p(q), _p(t), _p(d), 1000)
+        q = np.zeros(self.cap, np.int32)
+        t = np.zeros(self.cap, np.int32)
+        d = np.zeros(self.cap, np.float32)
+        n = self.lib.spvo_host_matches(self.h, match_type, _p(q), _p(t), _p(d), self.cap)
         return q[:n].copy(), t[:n].copy(), d[:n].copy()
 
     def map_of_indices(self, match_type):

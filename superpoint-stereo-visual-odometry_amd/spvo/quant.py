@@ -20,13 +20,30 @@ import numpy as np
 from . import capi, weights
 
 
-def calibrate(plan: weights.Plan, inputs: Iterable[np.ndarray], height: int, width: int, percentile: float = 99.999) -> np.ndarray:
-    """Per-tensor activation scales = percentile(|activation|) / 127 over the calibration inputs (fp32 engine on the GPU)."""
+def _fp32_context(plan: weights.Plan, height: int, width: int) -> capi.Context:
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "calib_FP32.spvw")
         weights.save(plan, path, precision="FP32")
         ctx = capi.Context(net_height=height, net_width=width)
         ctx.load_weights(path)
+    return ctx
+
+
+def calibration_inputs(plan: weights.Plan, images: Iterable[np.ndarray], height: int, width: int) -> np.ndarray:
+    """uint8 grey images -> the network's fp32 input [N, 1, H, W] through the library's own preprocess (crop + resize on
+    the device, then x * (1/255) as csrc/post.hip.h does it)."""
+    ctx = _fp32_context(plan, height, width)
+    try:
+        P = np.eye(3, 4)
+        out = [ctx.preprocess(im, P)[0].astype(np.float32) * np.float32(1.0 / 255.0) for im in images]
+    finally:
+        ctx.close()
+    return np.stack(out)[:, None]
+
+
+def calibrate(plan: weights.Plan, inputs: Iterable[np.ndarray], height: int, width: int, percentile: float = 99.999) -> np.ndarray:
+    """Per-tensor activation scales = percentile(|activation|) / 127 over the calibration inputs (fp32 engine on the GPU)."""
+    ctx = _fp32_context(plan, height, width)
     amax = np.zeros(len(plan.tensors), np.float64)
     try:
         for x in inputs:
