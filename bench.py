@@ -76,6 +76,9 @@ def main():
                     help="network: vgg (seeded, the headline) or one of the reference's ONNX graphs (tests/golden/<graph>.spvw)")
     ap.add_argument("--max-keypoints", type=int, default=1000, help="keypoint cap per image (reference: 1000; config 5: 2048)")
     ap.add_argument("--match-fp8", action="store_true", help="fp8 (e4m3) shortlist GEMM in the matcher, exact fp32 re-rank (config 5)")
+    ap.add_argument("--fp32-split", action="store_true",
+                    help="evaluate the FP32 engine on the bf16 matrix pipe (3 bf16 pieces per operand, 6 partial products, fp32 accumulation; "
+                         "spvo_set_fp32_split) -- opt-in, not the headline")
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 5],
                     help="BASELINE.json config shortcut: 2 = default; 3 = FP16 192x640; 5 = sp_mbv1 INT8, 2048 keypoints, fp8 shortlist")
     ap.add_argument("--dump-ops", action="store_true", help="add per-layer network times to the JSON line")
@@ -85,7 +88,7 @@ def main():
         args.precision, args.net_size = "FP16", "192x640"
     elif args.config == 5:
         args.precision, args.graph, args.max_keypoints, args.match_fp8 = "INT8", "sp_mbv1", 2048, True
-    headline = args.precision == "FP32" and args.graph == "vgg" and args.max_keypoints == 1000 and not args.match_fp8
+    headline = args.precision == "FP32" and args.graph == "vgg" and args.max_keypoints == 1000 and not args.match_fp8 and not args.fp32_split
     global NET_H, NET_W
     NET_H, NET_W = (int(v) for v in args.net_size.lower().split("x"))
 
@@ -99,6 +102,10 @@ def main():
         os.environ["SPVO_MAX_KEYPOINTS"] = str(args.max_keypoints)
     if args.match_fp8:
         os.environ["SPVO_MATCH_FP8"] = "1"
+    if args.fp32_split:
+        if args.precision != "FP32":
+            raise SystemExit("--fp32-split applies to FP32 engines")
+        os.environ["SPVO_FP32_SPLIT"] = "1"
 
     import torch
     import torch.distributed as dist
@@ -205,7 +212,7 @@ def main():
         out = {
             "metric": "stereo frames/sec (1241x376 KITTI)", "value": round(total_frames / elapsed, 2), "unit": "stereo frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"FP32": "f32", "FP16": "f16", "INT8": "i8"}[args.precision], "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 as 3 x bf16 (split operands, fp32 accumulate)" if args.fp32_split else {"FP32": "f32", "FP16": "f16", "INT8": "i8"}[args.precision], "data": "synthetic",
             "config": {"workload": (f"SuperPoint VGG {args.precision.lower()} (seeded synthetic weights, {n_params} params)" if args.graph == "vgg" else
                                     f"SuperPoint {args.graph} {args.precision.lower()} (the reference's ONNX graph, seeded weights, {n_params} params)")
                                    + f", 1241x376 stereo pairs, net {NET_H}x{NET_W}, {args.max_keypoints} kp cap, "
@@ -213,16 +220,20 @@ def main():
                                    + "BF+KNN 0.8, P3P-style RANSAC 500 it, LM refinement degree 4; one stereo stream per GPU, RCCL all-gather of poses",
                        "net_size": [NET_H, NET_W], "input_size": [rows, cols], "streams": world},
         }
-        dom = prof.get("conv:1") if args.graph == "vgg" and args.precision != "INT8" else None     # conv1b: 43 % of all CNN FLOPs
+        dom = prof.get("conv:1") if args.graph == "vgg" and args.precision != "INT8" else None
+        if args.fp32_split:
+            out["config"]["workload"] = out["config"]["workload"].replace(" fp32 ", " fp32 [split mode: bf16x3 operands, 6 partial products] ")     # conv1b: 43 % of all CNN FLOPs
         if dom and dom["calls"]:
             avg_ms = dom["total_ms"] / dom["calls"]
             achieved = dom["flops"] / (avg_ms * 1e-3) / 1e12
             traffic = None                                                 # HBM bytes per launch from the committed PMC pass
             pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")
-            if os.path.exists(pmc) and (NET_H, NET_W) == (360, 1176) and args.precision == "FP32":
+            if os.path.exists(pmc) and (NET_H, NET_W) == (360, 1176) and args.precision == "FP32" and not args.fp32_split:
                 traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
-            peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "FP32" else F16_MFMA_PEAK_TFLOPS
-            kname = "conv_mfma_kernel<KS=3,...,POOL,RELU>" if args.precision == "FP32" else "conv_f16_kernel<KS=3,...,POOL,RELU>"
+            peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "FP32" and not args.fp32_split else F16_MFMA_PEAK_TFLOPS
+            kname = "conv_s3_kernel<KS=3,...,POOL,RELU>" if args.fp32_split else "conv_mfma_kernel<KS=3,...,POOL,RELU>" if args.precision == "FP32" else "conv_f16_kernel<KS=3,...,POOL,RELU>"
+            if args.fp32_split:
+                achieved *= 6.0                                            # executed matrix flops: six bf16 partial products per fp32 product
             out["roofline"] = {"bound": "mfma", "kernel": kname + " instance of op 1 = conv1b 64->64 @" + f"{NET_H}x{NET_W}, 2 images",
                                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(achieved / peak, 4), "traffic": traffic,

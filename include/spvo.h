@@ -76,6 +76,14 @@ int spvo_load_weights(spvo_ctx *ctx, const char *path);
  * (nn.cpp:117): every entry point takes and returns the same types. */
 int spvo_engine_precision(const spvo_ctx *ctx);
 
+/* Opt-in evaluation mode for FP32 engines loaded AFTER the call (environment default: SPVO_FP32_SPLIT=1): every fp32
+ * operand of the convolutions is carried as three bf16 pieces (exact: 3 x 8 = 24 significand bits) and every product is
+ * the sum of its six leading partial products on the bf16 matrix pipe with fp32 accumulation
+ * (csrc/conv_bf16x3.hip.h).  Results agree with the native fp32 engine to fp32 rounding level; the engine file, the
+ * bindings and spvo_engine_precision (0) do not change.  Covers convolution + L2-norm graphs (the VGG SuperPoint of
+ * nn.cpp:43-137); other graphs fail at spvo_load_weights. */
+int spvo_set_fp32_split(spvo_ctx *ctx, int enable);
+
 /* preprocessImageImpl (base.cpp:68-121) + preprocessImage (nn.cpp:139-161):
  * centre-crop to the network aspect ratio, cv::resize(INTER_LINEAR) 8-bit
  * fixed-point semantics, scale P rows 0-1.  `P` (3x4 row-major, f64) is

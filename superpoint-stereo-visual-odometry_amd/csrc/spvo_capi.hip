@@ -19,6 +19,7 @@
 #include "match.hip.h"
 #include "odometry.hip.h"
 #include "conv_f16.hip.h"
+#include "conv_bf16x3.hip.h"
 #include "conv_i8.hip.h"
 #include "post.hip.h"
 
@@ -37,6 +38,7 @@ struct Tensor {
   bool nhwc = false;  // dense [B][H][W][C] (descriptor map) instead of padded planes
   bool f16 = false;   // FP16 engines: C8 fp16 [C/8][Hp][Wp][8] instead of fp32 planes (per_image still counts floats = 4 bytes)
   bool i8 = false;    // INT8 engines: C16 int8 [C/16][Hp][Wp][16]
+  bool s3 = false;    // FP32 engines in split mode: C8x3 bf16 pieces [C/8][3][Hp][Wp][8] (conv_bf16x3.hip.h)
   float scale = 0.f;  // INT8 engines: real value = q * scale (calibrated)
   float *d = nullptr;
   float *dr[RING] = {nullptr, nullptr, nullptr, nullptr};  // network outputs only: one buffer per submission set (d == dr[0])
@@ -54,6 +56,7 @@ struct Op {
   float *d_w = nullptr, *d_b = nullptr, *d_bn_scale = nullptr, *d_bn_shift = nullptr;
   _Float16 *d_w16 = nullptr;   // FP16 engines: pack_conv_weights_f16()
   int8_t *d_w8 = nullptr;      // INT8 engines: pack_conv_weights_i8()
+  unsigned short *d_ws3 = nullptr;   // FP32 engines in split mode: pack_conv_weights_s3()
   int *d_wq32 = nullptr;       // INT8 engines, depthwise: quantised weights [C][9] as int32
   float *d_qm = nullptr;       // INT8 engines: weight scale * input scale per output channel
   float inv_s_out = 0.f, s_res = 0.f;
@@ -125,6 +128,8 @@ struct spvo_ctx {
   std::string error;
   bool weights = false;
   bool fp16 = false;               // the loaded engine's precision
+  bool split_req = false;          // spvo_set_fp32_split / SPVO_FP32_SPLIT: FP32 engines loaded from now on run on the bf16x3 kernels
+  bool s3 = false;                 // the loaded FP32 engine runs in split mode
   bool int8 = false;
   int H = 0, W = 0, Hc = 0, Wc = 0, B = 0;
   int num_cus = 256;
@@ -337,9 +342,13 @@ int launch_conv_epi(spvo_ctx *c, const ConvArgs &a, int batch, int epi, hipStrea
 // further 2-3 % faster in isolation but 4 % SLOWER inside the pipeline, where the chip is shared with the previous
 // pair's post-processing and the solver (tools/tune_variants.sh), so they are not offered.
 // 1x1: tile by padded work / grid fill.
-void choose_variant(int ks, int H, int W, int co_tiles, int batch, bool pool, int num_cus, int *wr, int *wc, int *ck) {
+void choose_variant(int ks, int H, int W, int co_tiles, int batch, bool pool, int num_cus, int *wr, int *wc, int *ck, bool split = false) {
   struct Cand { int wr, wc, ck; double rate; };
-  static const Cand k3[] = {{2, 2, 8, 130.0}, {2, 1, 8, 135.0}, {1, 2, 8, 135.0}, {1, 1, 8, 133.0}};
+  static const Cand k3_f32[] = {{2, 2, 8, 130.0}, {2, 1, 8, 135.0}, {1, 2, 8, 135.0}, {1, 1, 8, 133.0}};
+  // split (bf16x3) kernels: the 8x64 tile reads the fewest operands per matrix instruction (14 ds_read_b128 per 24) and
+  // measures 4-9 % faster per pixel than the others (conv1b 263 vs 281 us, conv2b 76 vs 83 us)
+  static const Cand k3_s3[] = {{2, 2, 8, 108.0}, {2, 1, 8, 100.0}, {1, 2, 8, 97.0}, {1, 1, 8, 97.0}};
+  const Cand *k3 = split ? k3_s3 : k3_f32;
   static const Cand k1[] = {{2, 2, 16, 1.0 / 1.00}, {1, 2, 16, 1.0 / 1.03}, {2, 1, 16, 1.0 / 1.03}, {1, 1, 16, 1.0 / 1.06}};
   const Cand *cands = ks == 3 ? k3 : k1;
   const int nc = 4;
@@ -542,6 +551,77 @@ int launch_conv16(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t st
   }
 }
 
+// ---------------------------------------------------------------- FP32 engines in split mode (bf16x3)
+template <int KS, int CKG, int WR, int WC, bool POOL, bool RELU, bool OUT_F32>
+int launch_conv_s3_instance(spvo_ctx *c, ConvArgsS3 args, hipStream_t stream) {
+  using T = ConvTileS3<KS, CKG, WR, WC>;
+  auto k = conv_s3_kernel<KS, CKG, WR, WC, POOL, RELU, OUT_F32>;
+  static int per_cu[64] = {};
+  const int dev = c->cfg.device & 63;
+  if (!per_cu[dev]) {
+    HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+    int n = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k, 256, T::LDS_BYTES));
+    per_cu[dev] = std::max(n, 1);
+  }
+  args.tiles_x = (args.W + T::TW - 1) / T::TW;
+  args.tiles_y = (args.H + T::TH - 1) / T::TH;
+  const int n_tiles = args.tiles_x * args.tiles_y * args.co_tiles * args.batch;
+  hipLaunchKernelGGL(k, dim3(std::min(n_tiles, c->num_cus * per_cu[dev])), dim3(256), T::LDS_BYTES, stream, args);
+  HIP_TRY(c, hipGetLastError());
+  return SPVO_OK;
+}
+
+template <int KS, int CKG, int WR, int WC, bool POOL>
+int launch_conv_s3_variant(spvo_ctx *c, const ConvArgsS3 &a, bool relu, bool out_f32, hipStream_t stream) {
+  if constexpr (!POOL) {
+    if (out_f32) return relu ? launch_conv_s3_instance<KS, CKG, WR, WC, false, true, true>(c, a, stream) : launch_conv_s3_instance<KS, CKG, WR, WC, false, false, true>(c, a, stream);
+  }
+  return relu ? launch_conv_s3_instance<KS, CKG, WR, WC, POOL, true, false>(c, a, stream) : launch_conv_s3_instance<KS, CKG, WR, WC, POOL, false, false>(c, a, stream);
+}
+
+int launch_conv_s3(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream) {
+  const Tensor &ti = c->tensors[op.in];
+  const Tensor &to = c->tensors[op.out];
+  const float *tin = (ti.dr[c->cur_ring] ? ti.dr[c->cur_ring] : ti.d) + (size_t)img0 * ti.per_image;
+  float *tout = (to.dr[c->cur_ring] ? to.dr[c->cur_ring] : to.d) + (size_t)img0 * to.per_image;
+  const bool relu = op.flags & FLAG_RELU, pool = op.flags & FLAG_POOL;
+  if (op.cin == 1) {
+    dim3 grid((ti.W + 63) / 64, (ti.H + 3) / 4, batch);
+#define SPVO_FIRST_S3(KS, RELU) hipLaunchKernelGGL((conv_first_s3_kernel<KS, RELU>), grid, dim3(256), 0, stream, tin, (unsigned short *)tout, op.d_w, op.d_b, \
+                                                   ti.H, ti.W, ti.hp, ti.wp, to.ch / 8, op.out_c_off / 8, op.cout)
+    if (op.ks == 3) { if (relu) SPVO_FIRST_S3(3, true); else SPVO_FIRST_S3(3, false); }
+    else            { if (relu) SPVO_FIRST_S3(1, true); else SPVO_FIRST_S3(1, false); }
+#undef SPVO_FIRST_S3
+    HIP_TRY(c, hipGetLastError());
+    return SPVO_OK;
+  }
+  ConvArgsS3 a;
+  a.in = (const unsigned short *)tin; a.out = tout; a.wpack = op.d_ws3;
+  a.H = ti.H; a.W = ti.W;
+  a.in_hp = ti.hp; a.in_wp = ti.wp; a.in_gtot = ti.ch / 8; a.in_goff = op.in_c_off / 8;
+  a.out_hp = to.hp; a.out_wp = to.wp; a.out_ctot = to.ch; a.out_coff = op.out_c_off;
+  a.cout = op.cout; a.n_chunks = op.n_chunks; a.co_tiles = op.co_tiles;
+  a.tiles_x = a.tiles_y = 0;
+  a.batch = batch;
+  const bool out_f32 = !to.s3;
+  const int key = op.ks * 1000 + op.wr * 100 + op.wc * 10 + (pool ? 1 : 0);
+  switch (key) {
+    case 3220: return launch_conv_s3_variant<3, 1, 2, 2, false>(c, a, relu, out_f32, stream);
+    case 3210: return launch_conv_s3_variant<3, 1, 2, 1, false>(c, a, relu, out_f32, stream);
+    case 3120: return launch_conv_s3_variant<3, 1, 1, 2, false>(c, a, relu, out_f32, stream);
+    case 3110: return launch_conv_s3_variant<3, 1, 1, 1, false>(c, a, relu, out_f32, stream);
+    case 3221: return launch_conv_s3_variant<3, 1, 2, 2, true>(c, a, relu, out_f32, stream);
+    case 3211: return launch_conv_s3_variant<3, 1, 2, 1, true>(c, a, relu, out_f32, stream);
+    case 1220: return launch_conv_s3_variant<1, 2, 2, 2, false>(c, a, relu, out_f32, stream);
+    case 1120: return launch_conv_s3_variant<1, 2, 1, 2, false>(c, a, relu, out_f32, stream);
+    case 1110: return launch_conv_s3_variant<1, 2, 1, 1, false>(c, a, relu, out_f32, stream);
+    case 1221: return launch_conv_s3_variant<1, 2, 2, 2, true>(c, a, relu, out_f32, stream);
+    case 1211: return launch_conv_s3_variant<1, 2, 2, 1, true>(c, a, relu, out_f32, stream);
+    default: return fail(c, SPVO_ERR_INVALID, "no split-fp32 conv kernel variant for key %d", key);
+  }
+}
+
 // ---------------------------------------------------------------- INT8 engines
 template <int KS, int CKG, int WR, int WC, bool POOL, bool RELU, bool OUT_F32, int EPI = 0>
 int launch_conv8_instance(spvo_ctx *c, ConvArgs8 args, hipStream_t stream) {
@@ -643,7 +723,8 @@ int launch_op(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream
   const Tensor &to = c->tensors[op.out];
   if (op.type == OP_CONV || op.type == OP_DWCONV) {
     ScopedStage st(c, op.stage, op.flops_per_image * batch, 0, stream);
-    return c->int8 ? launch_conv8(c, op, img0, batch, stream) : c->fp16 ? launch_conv16(c, op, img0, batch, stream) : launch_conv(c, op, img0, batch, stream);
+    return c->int8 ? launch_conv8(c, op, img0, batch, stream) : c->fp16 ? launch_conv16(c, op, img0, batch, stream)
+           : c->s3 ? launch_conv_s3(c, op, img0, batch, stream) : launch_conv(c, op, img0, batch, stream);
   }
   const float *tin = (ti.dr[c->cur_ring] ? ti.dr[c->cur_ring] : ti.d) + (size_t)img0 * ti.per_image;
   float *tout = (to.dr[c->cur_ring] ? to.dr[c->cur_ring] : to.d) + (size_t)img0 * to.per_image;
@@ -1023,10 +1104,11 @@ void free_plan(spvo_ctx *c) {
     for (float *p : {o.d_w, o.d_b, o.d_bn_scale, o.d_bn_shift}) if (p) (void)hipFree(p);
     if (o.d_w16) (void)hipFree(o.d_w16);
     if (o.d_w8) (void)hipFree(o.d_w8);
+    if (o.d_ws3) (void)hipFree(o.d_ws3);
     if (o.d_wq32) (void)hipFree(o.d_wq32);
     if (o.d_qm) (void)hipFree(o.d_qm);
   }
-  c->tensors.clear(); c->ops.clear(); c->weights = false; c->fp16 = false; c->int8 = false;
+  c->tensors.clear(); c->ops.clear(); c->weights = false; c->fp16 = false; c->int8 = false; c->s3 = false;
 }
 
 }  // namespace
@@ -1076,6 +1158,7 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
     return fail(nullptr, SPVO_ERR_DEVICE, "cannot create a stream on device %d", cfg->device);
   }
   c->post = c->stream;
+  if (const char *e = std::getenv("SPVO_FP32_SPLIT")) c->split_req = std::atoi(e) != 0;
   for (int r = 0; r < RING; ++r)
     if (hipEventCreateWithFlags(&c->ev_net[r], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_tail[r], hipEventDisableTiming) != hipSuccess ) {
       spvo_destroy(c);
@@ -1260,10 +1343,21 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
     for (const auto &op : c->ops)
       if (op.type == OP_L2NORM) c->tensors[op.in].f16 = false;
   }
+  c->s3 = c->split_req && !c->fp16 && !c->int8;
+  if (c->s3) {
+    // split mode: every tensor between the fp32 network input and the fp32 outputs holds bf16 triples
+    for (auto &t : c->tensors) t.s3 = true;
+    c->tensors[c->t_input].s3 = c->tensors[c->t_det].s3 = c->tensors[c->t_desc].s3 = false;
+    for (const auto &op : c->ops) {
+      if (op.type == OP_L2NORM) c->tensors[op.in].s3 = false;
+      if (op.type != OP_CONV && op.type != OP_L2NORM) return fail(c, SPVO_ERR_IO, "%s: the split-fp32 mode covers convolution + L2-norm graphs (VGG SuperPoint) only", path);
+    }
+    for (const auto &t : c->tensors) if (t.s3 && (t.ch % 8)) return fail(c, SPVO_ERR_IO, "%s: split-fp32 mode: a %d-channel tensor", path, t.ch);
+  }
   // allocate activations (padded planes stay zero outside the interior for ever)
   for (size_t ti = 0; ti < c->tensors.size(); ++ti) {
     Tensor &t = c->tensors[ti];
-    t.per_image = t.nhwc ? (size_t)t.H * t.W * t.ch : (size_t)t.ch * t.hp * t.wp / (t.f16 ? 2 : t.i8 ? 4 : 1);
+    t.per_image = t.nhwc ? (size_t)t.H * t.W * t.ch : t.s3 ? (size_t)t.ch * t.hp * t.wp * 3 / 2 : (size_t)t.ch * t.hp * t.wp / (t.f16 ? 2 : t.i8 ? 4 : 1);
     int rc = dev_alloc(c, &t.d, t.per_image * c->B);
     if (rc) return rc;
     if ((int)ti == c->t_det || (int)ti == c->t_desc) {   // what a submission's tail reads while the next network pass already runs
@@ -1422,6 +1516,39 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
         HIP_TRY(c, hipMemcpy(op.d_w16, pk.data(), pk.size() * sizeof(_Float16), hipMemcpyHostToDevice));
         continue;
       }
+      if (c->s3) {
+        if (bn || add) return fail(c, SPVO_ERR_IO, "op %u: split-fp32 mode has no BatchNorm / residual epilogue", i);
+        if (ti.s3 != (op.cin != 1)) return fail(c, SPVO_ERR_IO, "op %u: split-fp32 mode: unexpected storage of the input tensor", i);
+        if (to.s3 && ((op.cout % 8) || (op.out_c_off % 8))) return fail(c, SPVO_ERR_IO, "op %u: cout %d / channel offset %d are not multiples of 8", i, op.cout, op.out_c_off);
+        if (!to.s3 && pool) return fail(c, SPVO_ERR_IO, "op %u: pooled fp32 output", i);
+        if (op.cin == 1) {
+          if (pool || !to.s3) return fail(c, SPVO_ERR_IO, "op %u: unsupported single-channel-input layer for split-fp32 mode", i);
+          int rc = dev_alloc(c, &op.d_w, (size_t)op.cout * taps, false);
+          if (rc) return rc;
+          if ((rc = dev_alloc(c, &op.d_b, op.cout, false))) return rc;
+          HIP_TRY(c, hipMemcpy(op.d_w, w, (size_t)op.cout * taps * 4, hipMemcpyHostToDevice));
+          HIP_TRY(c, hipMemcpy(op.d_b, b, (size_t)op.cout * 4, hipMemcpyHostToDevice));
+          continue;
+        }
+        const int ckg = op.ks == 3 ? 1 : 2;
+        if (op.cin % (8 * ckg) || op.in_c_off % 8) return fail(c, SPVO_ERR_IO, "op %u: cin %d / channel offset %d do not fit the split-fp32 chunking (%d)", i, op.cin, op.in_c_off, 8 * ckg);
+        op.ck = 8 * ckg;
+        op.n_chunks = op.cin / op.ck;
+        op.co_tiles = (op.cout + CO_TILE - 1) / CO_TILE;
+        int ck_unused;
+        choose_variant(op.ks, ti.H, ti.W, op.co_tiles, c->cfg.max_batch, pool, c->num_cus, &op.wr, &op.wc, &ck_unused, true);
+        if (const char *force = std::getenv("SPVO_CONV_FORCE")) {   // tuning aid: "op:wr,wc,ck;op:wr,wc,ck" (ck ignored here)
+          for (const char *q = force; q && *q; q = std::strchr(q, ';') ? std::strchr(q, ';') + 1 : nullptr) {
+            int oi, wr, wc, ck;
+            if (std::sscanf(q, "%d:%d,%d,%d", &oi, &wr, &wc, &ck) == 4 && oi == (int)i) { op.wr = wr; op.wc = wc; }
+          }
+        }
+        const std::vector<unsigned short> pk = pack_conv_weights_s3(w, b, op.cout, op.cin, op.ks, ckg);
+        int rc = dev_alloc(c, &op.d_ws3, pk.size(), false);
+        if (rc) return rc;
+        HIP_TRY(c, hipMemcpy(op.d_ws3, pk.data(), pk.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+        continue;
+      }
       if (op.cin == 1) {
         if (pool || add) return fail(c, SPVO_ERR_IO, "op %u: single-channel-input layers have no pooling / residual form", i);
         int rc = dev_alloc(c, &op.d_w, (size_t)op.cout * taps, false);
@@ -1473,6 +1600,12 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
     return fail(c, SPVO_ERR_IO, "%s: unexpected output tensors", path);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->weights = true;
+  return SPVO_OK;
+}
+
+int spvo_set_fp32_split(spvo_ctx *c, int enable) {
+  if (!c) return SPVO_ERR_INVALID;
+  c->split_req = enable != 0;
   return SPVO_OK;
 }
 
@@ -1544,6 +1677,7 @@ int spvo_debug_tensor(spvo_ctx *c, int tensor_id, int batch, float *out, size_t 
   float *tmp = nullptr;
   HIP_TRY(c, hipMalloc((void **)&tmp, need * sizeof(float)));
   if (t.i8) hipLaunchKernelGGL(unpad_c16_kernel, dim3((t.W + 63) / 64, t.H, batch * t.ch), dim3(64), 0, c->stream, (const int8_t *)t.d, tmp, t.ch, t.H, t.W, t.hp, t.wp);
+  else if (t.s3) hipLaunchKernelGGL(unpad_s3_kernel, dim3((t.W + 63) / 64, t.H, batch * t.ch), dim3(64), 0, c->stream, (const unsigned short *)t.d, tmp, t.ch, t.H, t.W, t.hp, t.wp);
   else if (t.f16) hipLaunchKernelGGL(unpad_c8_kernel, dim3((t.W + 63) / 64, t.H, batch * t.ch), dim3(64), 0, c->stream, (const _Float16 *)t.d, tmp, t.ch, t.H, t.W, t.hp, t.wp);
   else hipLaunchKernelGGL(unpad_kernel, dim3((t.W + 63) / 64, (t.H + 3) / 4, batch * t.ch), dim3(256), 0, c->stream, t.d, tmp, t.ch, t.H, t.W, t.hp, t.wp);
   hipError_t e = hipMemcpyAsync(out, tmp, need * sizeof(float), hipMemcpyDeviceToHost, c->stream);

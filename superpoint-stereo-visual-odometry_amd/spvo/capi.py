@@ -56,7 +56,7 @@ OBS_DTYPE = np.dtype([("X", np.float32, 3), ("uv", np.float32, 2), ("cam", np.in
 
 # every symbol include/spvo.h declares
 SYMBOLS = [
-    "spvo_default_config", "spvo_create", "spvo_destroy", "spvo_last_error", "spvo_load_weights", "spvo_engine_precision",
+    "spvo_default_config", "spvo_create", "spvo_destroy", "spvo_last_error", "spvo_load_weights", "spvo_engine_precision", "spvo_set_fp32_split",
     "spvo_preprocess", "spvo_forward", "spvo_debug_tensor", "spvo_heatmap", "spvo_nms",
     "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_detect_dev_submit", "spvo_detect_wait", "spvo_match", "spvo_match_slots", "spvo_set_prematch", "spvo_set_match_fp8",
     "spvo_triangulate", "spvo_pnp_ransac", "spvo_pnp_refine", "spvo_solve_stereo_odometry", "spvo_stream", "spvo_synchronize",
@@ -247,6 +247,10 @@ class Context:
                                              _dptr(Pl), _dptr(Pr), slot_l, slot_r, C.byref(fl), C.byref(fr)))
         return dict(xy_l=xyl[:fl.n], xy_r=xyr[:fr.n], desc_l=None if dl is None else dl[:fl.n],
                     desc_r=None if dr is None else dr[:fr.n], P_l=Pl.reshape(3, 4), P_r=Pr.reshape(3, 4))
+
+    def set_fp32_split(self, enable: bool):
+        """FP32 engines loaded after this call evaluate their convolutions on the bf16x3 split kernels (include/spvo.h)."""
+        self._check(self.lib.spvo_set_fp32_split(self.h, int(enable)))
 
     def set_match_fp8(self, enable: bool):
         self._check(self.lib.spvo_set_match_fp8(self.h, int(enable)))

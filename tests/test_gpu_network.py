@@ -46,6 +46,77 @@ def test_vgg_forward_matches_oracle(vgg_weights_path, vgg_plan, sample_images, H
     ctx.close()
 
 
+def _vgg_forward_f64(plan, x):
+    """the same graph in float64 (torch CPU): the yardstick for "fp32 rounding level" below"""
+    import torch
+    import torch.nn.functional as F
+    from spvo import weights as Wm
+    vals = {plan.input_tensor: torch.from_numpy(x.astype(np.float64))}
+    for op in plan.ops:
+        src = vals[op.inp]
+        if op.type == Wm.OP_CONV:
+            in_off = getattr(op, "in_c_off", 0)
+            y = F.conv2d(src[:, in_off:in_off + op.cin], torch.from_numpy(op.weight.astype(np.float64)), torch.from_numpy(op.bias.astype(np.float64)),
+                         padding=op.ksize // 2)
+            if op.flags & Wm.FLAG_RELU:
+                y = F.relu(y)
+            if op.flags & Wm.FLAG_POOL:
+                y = F.max_pool2d(y, 2, 2)
+            if op.out not in vals:
+                vals[op.out] = torch.zeros((y.shape[0], plan.tensors[op.out][0], y.shape[2], y.shape[3]), dtype=torch.float64)
+            vals[op.out][:, op.out_c_off:op.out_c_off + op.cout] = y
+        else:
+            assert op.type == Wm.OP_L2NORM
+            vals[op.out] = src / torch.sqrt((src * src).sum(dim=1, keepdim=True))
+    return {k: v.numpy() for k, v in vals.items()}
+
+
+@pytest.mark.parametrize("H,W,batch", [(120, 392, 2), (360, 1176, 2), (192, 640, 1), (376, 1240, 2)])
+def test_fp32_split_mode_matches_oracle_at_fp32_rounding_level(vgg_weights_path, vgg_plan, sample_images, H, W, batch):
+    """spvo_set_fp32_split: the FP32 engine evaluated on the bf16 matrix pipe (three bf16 pieces per fp32 operand, six
+    partial products per product, fp32 accumulation; csrc/conv_bf16x3.hip.h).  Same bar against the oracle as the native
+    engine (1e-4, every intermediate tensor), AND its distance to a float64 evaluation of the graph stays within a small
+    factor of the native fp32 engine's own distance: it is a re-ordered fp32 evaluation, not a lower precision."""
+    from spvo import capi
+    x = _input(sample_images, H, W, batch)
+    rdet, rdesc, vals = net.forward(vgg_plan, x, return_all=True)
+    ref64 = _vgg_forward_f64(vgg_plan, x)
+    errs = {}
+    for mode in ("native", "split"):
+        ctx = capi.Context(net_height=H, net_width=W)
+        ctx.set_fp32_split(mode == "split")
+        ctx.load_weights(vgg_weights_path)
+        assert ctx.engine_precision() == "FP32"
+        det, desc = ctx.forward(x)
+        e = {}
+        for tid, (ch, lvl) in enumerate(vgg_plan.tensors):
+            if tid in (vgg_plan.input_tensor, vgg_plan.desc_tensor):
+                continue
+            got = ctx.debug_tensor(tid, batch, ch, lvl)
+            assert np.abs(got - vals[tid]).max() <= _tol(vals[tid]), f"{mode}: tensor {tid}"
+            e[tid] = float(np.abs(got - ref64[tid]).max() / max(1.0, np.abs(ref64[tid]).max()))
+        assert np.abs(det - rdet).max() <= _tol(rdet)
+        assert np.abs(desc - rdesc.transpose(0, 2, 3, 1)).max() <= 1e-4
+        assert np.allclose(np.linalg.norm(desc, axis=-1), 1.0, atol=1e-5)
+        e["desc"] = float(np.abs(desc - ref64[vgg_plan.desc_tensor].transpose(0, 2, 3, 1)).max())
+        errs[mode] = e
+        ctx.close()
+    print("max relative error against float64, native vs split:", {k: (errs["native"][k], errs["split"][k]) for k in errs["native"]})
+    for k in errs["native"]:
+        assert errs["split"][k] <= 4 * errs["native"][k] + 2e-7, (k, errs["native"][k], errs["split"][k])
+
+
+def test_fp32_split_mode_rejects_other_graphs(squeeze_weights_path):
+    from spvo import capi
+    ctx = capi.Context()
+    ctx.set_fp32_split(True)
+    with pytest.raises(capi.SpvoError):
+        ctx.load_weights(squeeze_weights_path)
+    ctx.set_fp32_split(False)
+    ctx.load_weights(squeeze_weights_path)
+    ctx.close()
+
+
 def test_squeeze_forward_matches_oracle(ctx_squeeze, squeeze_plan, sample_images):
     x = _input(sample_images, 360, 1176, 2)
     det, desc = ctx_squeeze.forward(x)

@@ -73,6 +73,29 @@ def test_detect_properties_full_size(ctx_vgg, stereo_pair):
         assert d2.min() < 1e-6
 
 
+def test_detect_in_fp32_split_mode_matches_oracle(vgg_weights_path, vgg_plan, stereo_pair):
+    """the whole detector with the FP32 engine evaluated on the bf16x3 split kernels (spvo_set_fp32_split): same bars as
+    the native engine -- keypoint sets agree with the oracle (threshold / sort outcomes of floats that agree to ~1e-6),
+    descriptors of the common keypoints to 1e-4"""
+    from spvo import capi
+    frames, _, P_l, P_r = stereo_pair
+    L, R = frames[0]
+    ctx = capi.Context()
+    ctx.set_fp32_split(True)
+    ctx.load_weights(vgg_weights_path)
+    out = ctx.detect(L, R, P_l, P_r, 2, 3)
+    for side, img, P in (("l", L, P_l), ("r", R, P_r)):
+        ref = fe.detect(vgg_plan, img, P, 360, 1176)
+        xy = out["xy_" + side].astype(np.int32)
+        a, b = set(map(tuple, xy.tolist())), set(map(tuple, ref["xy"].tolist()))
+        assert len(a & b) / len(a | b) > 0.97, len(a & b)
+        pos = {tuple(p): i for i, p in enumerate(ref["xy"].tolist())}
+        common = [(i, pos[tuple(p)]) for i, p in enumerate(xy.tolist()) if tuple(p) in pos]
+        gi, ri = map(np.array, zip(*common))
+        assert np.abs(out["desc_" + side][gi] - ref["descriptors"][ri]).max() <= 1e-4
+    ctx.close()
+
+
 def test_prematch_is_transparent(ctx_squeeze, stereo_pair):
     """spvo_set_prematch only moves the two standard matches into the detector's submission."""
     frames, _, P_l, P_r = stereo_pair
