@@ -11,7 +11,7 @@ reference's exact 1 300 865-parameter layout: the real ones are missing from the
 tree), 1241x376 KITTI-sized synthetic stereo pairs, network size 360x1176 (the reference's
 largest), reference launch-file parameters.  Input images are resident in HBM before the timed
 region.  N GPUs = N independent stereo streams, one rank per GPU (weak scaling); the only
-collective is the per-step all-gather of the 7-double pose over RCCL.
+collective is the all-gather of the 7-double poses over RCCL (batches of 64 frames, off the critical path).
 
 Prints ONE JSON line (rank 0).
 """
@@ -120,7 +120,12 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
         os.environ["SPVO_DEVICE"] = str(local_rank)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # Test hook: SPVO_BENCH_FORCE_DIST=1 runs the collective path (RCCL process group, pose all-gather, barrier, max-reduce) in a
+    # single-rank job too, so that it can be exercised on a one-GPU box.
+    dist_on = world > 1 or os.environ.get("SPVO_BENCH_FORCE_DIST") == "1"
+    if dist_on and "RANK" not in os.environ:
+        os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": os.environ.get("MASTER_PORT", "29533")})
+    if dist_on:
         if shared:
             dist.init_process_group("gloo")
         else:
@@ -152,7 +157,7 @@ def main():
     if not fe.engine_loaded:
         raise SystemExit("engine load failed: " + fe.last_error)
     ctx = fe.context()
-    pg = posegather.PoseGather(torch.device("cuda", local_rank))
+    pg = posegather.PoseGather(torch.device("cuda", local_rank), force=dist_on)
 
     def step(i):
         dl, dr = d_frames[order[i % len(order)]]
@@ -161,20 +166,20 @@ def main():
             nl, nr = d_frames[order[(i + 1 + d) % len(order)]]
             ahead[d] = (nl.data_ptr(), nr.data_ptr())
         res = fe.step_device(dl.data_ptr(), dr.data_ptr(), rows, cols, dl.stride(0), P_l, P_r, ahead[0], ahead[1])
-        if world > 1:                                                       # RCCL all-gather, 56 B per rank, not waited for here
+        if dist_on:                                                       # pose staged; RCCL all-gather per 64 frames on a side stream
             pg.gather_async(*(res if res is not None else (None, None)))
             if (i + 1) % 1024 == 0:
                 pg.collect()
         return res
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
         step(i)
-    if world > 1:
+    if dist_on:
         pg.collect()
     # Inside the timed region only the dominant kernel (conv1b = stage "conv:1") is bracketed by HIP events on the
     # context's stream: two event records per step.  Timing every stage costs 2 records per kernel and 7 % of the
@@ -187,7 +192,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
-    if world > 1:
+    if dist_on:
         gathered = pg.collect()                                             # every pose of every rank has arrived: inside the timed region
         assert gathered.shape[1:] == (world, 7)
     barrier()
@@ -203,7 +208,7 @@ def main():
         barrier()
         prof_all = ctx.profile()
         ctx.profile_enable(False)
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -279,7 +284,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(frames, P_l, P_r, plan)
         print(json.dumps(out), flush=True)
     fe.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -137,7 +137,11 @@ int spvo_detect(spvo_ctx *ctx, const uint8_t *img_l, const uint8_t *img_r, int r
                 uint8_t *resized_r);
 
 /* Same, with both images already resident in device memory (u8, `stride` bytes
- * per row) and no host copies of descriptors (out_*->desc may be NULL). */
+ * per row) and no host copies of descriptors (out_*->desc may be NULL).  The context
+ * works on its own NON-BLOCKING streams: the images must be complete in device memory
+ * when the call is made (it does not order itself behind work the caller queued on the
+ * NULL stream or any other stream), and must stay untouched until the call -- for the
+ * asynchronous form, the matching spvo_detect_wait -- has returned. */
 int spvo_detect_dev(spvo_ctx *ctx, const void *d_img_l, const void *d_img_r, int rows, int cols,
                     size_t stride, double P_l[12], double P_r[12], int slot_l, int slot_r,
                     spvo_features *out_l, spvo_features *out_r);

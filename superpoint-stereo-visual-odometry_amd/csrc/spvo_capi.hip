@@ -1152,8 +1152,11 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
   c->cfg = *cfg;
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c->H = cfg->net_height; c->W = cfg->net_width; c->Hc = c->H / 8; c->Wc = c->W / 8; c->B = 2;
-  if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess ||
-      hipStreamCreate(&c->stream_t) != hipSuccess) {
+  // Non-blocking streams: work the caller puts on the NULL stream (a framework's default stream, a blocking hipMemcpy) must not
+  // serialise the three streams of the pipeline against each other.  Device pointers handed to the *_dev entry points
+  // have to be complete when the call is made (include/spvo.h).
+  if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->stream_t, hipStreamNonBlocking) != hipSuccess) {
     delete c;
     return fail(nullptr, SPVO_ERR_DEVICE, "cannot create a stream on device %d", cfg->device);
   }

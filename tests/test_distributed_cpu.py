@@ -36,6 +36,15 @@ def _worker(rank, world, port, q):
     seq = pg.collect()
     assert seq.shape == (3, world, 7) and np.allclose(seq[0], posegather.IDENTITY_POSE) and np.allclose(seq[1], allp)
     assert np.allclose(seq[2][rank, 4:], 2 * t) and pg.collect().shape == (0, world, 7)
+    # more steps than one batch (64) and more batches than staging slots (4): 5 full batches + a ragged one, in order
+    n = 5 * posegather.PoseGather.BATCH + 17
+    for k in range(n):
+        pg.gather_async(mine, (k + 1) * t)
+    seq = pg.collect()
+    assert seq.shape == (n, world, 7)
+    for k in (0, 63, 64, 200, n - 1):
+        assert np.allclose(seq[k][rank, 4:], (k + 1) * t) and np.allclose(seq[k][rank, :4], mine)
+        assert np.allclose(seq[k][1 - rank, :4], [0.0, 0.01 * (2 - rank), 0.0, 1.0])
     q.put((rank, first, allp, t))
     dist.barrier()
     dist.destroy_process_group()
@@ -67,3 +76,7 @@ def test_single_process_gather_is_identity_passthrough():
     assert out.shape == (1, 7) and np.allclose(out[0], [0, 0, 0, 1, 1, 2, 3])
     pg.gather_async([0, 0, 0, 1], [1, 2, 3])
     assert np.allclose(pg.collect(), out[None])
+    for k in range(130):
+        pg.gather_async([0, 0, 0, 1], [k, 2, 3])
+    seq = pg.collect()
+    assert seq.shape == (130, 1, 7) and np.allclose(seq[:, 0, 4], np.arange(130))
