@@ -131,6 +131,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    if world > 1:   # several ranks share the host: do not let each of them spin up one CPU thread per core
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     from spvo import host, posegather, synth, weights
 
     plan = weights.vgg_plan(seed=0) if args.graph == "vgg" else weights.load(os.path.join(ROOT, "tests", "golden", args.graph + ".spvw"))

@@ -20,6 +20,7 @@
 #include "odometry.hip.h"
 #include "conv_f16.hip.h"
 #include "conv_bf16x3.hip.h"
+#include "conv_wino.hip.h"
 #include "conv_i8.hip.h"
 #include "post.hip.h"
 
@@ -52,6 +53,7 @@ struct Op {
   int type = 0, in = 0, out = 0, out_c_off = 0, in_c_off = 0, cin = 0, cout = 0, ks = 0, flags = 0;
   int ck = 0, n_chunks = 0, co_tiles = 0, wr = 0, wc = 0;
   int residual = 0;  // tensor added before the last ReLU (FLAG_ADD)
+  bool wino = false;       // FP32 engines: this 3x3 layer runs the Winograd F(2x2,3x3) kernel (conv_wino.hip.h)
   bool dominant = false;   // the op with the most FLOPs: launched under its own kernel name (TAG = 1)
   float *d_w = nullptr, *d_b = nullptr, *d_bn_scale = nullptr, *d_bn_shift = nullptr;
   _Float16 *d_w16 = nullptr;   // FP16 engines: pack_conv_weights_f16()
@@ -334,6 +336,32 @@ int launch_conv_epi(spvo_ctx *c, const ConvArgs &a, int batch, int epi, hipStrea
                   : launch_conv_instance<1, 16, WR, WC, POOL, false, 2>(c, args, stream);
 }
 
+// Winograd F(2x2, 3x3) instance of a 3x3 layer (conv_wino.hip.h): one tile shape, one workgroup per CU (124 KB of LDS)
+template <bool POOL, bool RELU, int TAG>
+int launch_conv_wino_instance(spvo_ctx *c, const ConvArgs &args, hipStream_t stream) {
+  auto k = conv_wino_kernel<POOL, RELU, TAG>;
+  static bool ready[64] = {};
+  const int dev = c->cfg.device & 63;
+  if (!ready[dev]) {
+    HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, WinoTile::LDS_BYTES));
+    ready[dev] = true;
+  }
+  const int n_tiles = args.tiles_x * args.tiles_y * args.co_tiles * args.batch;
+  hipLaunchKernelGGL(k, dim3(std::min(n_tiles, c->num_cus)), dim3(256), WinoTile::LDS_BYTES, stream, args);
+  HIP_TRY(c, hipGetLastError());
+  return SPVO_OK;
+}
+
+int launch_conv_wino(spvo_ctx *c, const ConvArgs &a, int batch, bool relu, bool pool, bool dominant, hipStream_t stream) {
+  ConvArgs args = a;
+  args.tiles_x = (a.W + WinoTile::TW - 1) / WinoTile::TW;
+  args.tiles_y = (a.H + WinoTile::TH - 1) / WinoTile::TH;
+  args.batch = batch;
+  if (dominant && relu) return pool ? launch_conv_wino_instance<true, true, 1>(c, args, stream) : launch_conv_wino_instance<false, true, 1>(c, args, stream);
+  if (pool) return relu ? launch_conv_wino_instance<true, true, 0>(c, args, stream) : launch_conv_wino_instance<true, false, 0>(c, args, stream);
+  return relu ? launch_conv_wino_instance<false, true, 0>(c, args, stream) : launch_conv_wino_instance<false, false, 0>(c, args, stream);
+}
+
 // Variant choice for a layer.  3x3: every tile variant has a measured rate on perfectly divisible shapes
 // (tools/conv_bench sweep, launched back to back; TFLOP/s on 256 CUs) -- the smaller tiles let 2-3 workgroups share
 // a CU, whose staging, barriers and output bursts then hide under each other's matrix instructions -- and the
@@ -406,6 +434,7 @@ int launch_conv(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stre
   a.cout = op.cout; a.n_chunks = op.n_chunks; a.co_tiles = op.co_tiles;
   a.tiles_x = a.tiles_y = 0;
   a.batch = batch;
+  if (op.wino) return launch_conv_wino(c, a, batch, relu, pool, op.dominant, stream);
   const int key = op.ks * 10000 + op.ck * 100 + op.wr * 20 + op.wc * 2 + (pool ? 1 : 0);   // ks, ck, wr, wc, pool
   if (epi) {
     a.bn_scale = op.d_bn_scale; a.bn_shift = op.d_bn_shift;
@@ -1568,6 +1597,23 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
           int oi, wr, wc, ck;
           if (std::sscanf(q, "%d:%d,%d,%d", &oi, &wr, &wc, &ck) == 4 && oi == (int)i) { op.wr = wr; op.wc = wc; op.ck = ck; }
         }
+      }
+      // Winograd F(2x2,3x3) where it pays: plain 3x3 layers (no BatchNorm / residual epilogue) on even-sized maps with enough
+      // 8x32 tiles to fill the chip twice; the small maps (45x147 and below) stay on the direct kernel, whose 4x32 tiles fill
+      // the CUs better.  SPVO_WINOGRAD=0 switches it off (A/B measurements, parity debugging).
+      {
+        static const bool wino_on = !(std::getenv("SPVO_WINOGRAD") && std::atoi(std::getenv("SPVO_WINOGRAD")) == 0);
+        const long wtiles = (long)((ti.W + WinoTile::TW - 1) / WinoTile::TW) * ((ti.H + WinoTile::TH - 1) / WinoTile::TH) * op.co_tiles * c->cfg.max_batch;
+        op.wino = wino_on && op.ks == 3 && !bn && !add && (op.cin % WinoTile::CK) == 0 && (ti.H % 2) == 0 && (ti.W % 2) == 0 && wtiles >= 2L * c->num_cus;
+      }
+      if (op.wino) {
+        op.ck = WinoTile::CK;
+        op.n_chunks = op.cin / op.ck;
+        const std::vector<float> pk = pack_conv_weights_wino(w, b, op.cout, op.cin);
+        int rc = dev_alloc(c, &op.d_w, pk.size(), false);
+        if (rc) return rc;
+        HIP_TRY(c, hipMemcpy(op.d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+        continue;
       }
       if (op.cin % op.ck) return fail(c, SPVO_ERR_IO, "op %u: cin %d is not a multiple of %d", i, op.cin, op.ck);
       op.n_chunks = op.cin / op.ck;
