@@ -13,11 +13,16 @@
 //
 // Workgroup = 4 waves = 64 output channels x 64 tiles (8 rows x 32 columns of output, the direct kernel's 8x32 tile):
 // wave (cb, tb) owns channels [32 cb, 32 cb + 32) and the 32 tiles of tile rows {2 tb, 2 tb + 1} (lane j: tile row j >> 4,
-// tile column j & 15), one 32x32 accumulator block per xi = 16 blocks = 256 registers.  Per chunk of 8 input channels:
-//   1. the raw halo tile (8 x 10 x 40 floats, the direct kernel's LDS layout) and the host-transformed filters
-//      U[16][8][64] arrive by global_load_lds into a 2-deep ring, prefetched one chunk (and one tile) ahead;
-//   2. the 4 waves transform the raw tile to V[16][8][64] in LDS (each thread 2 patches: 16 reads, 32 adds, 16 writes);
-//   3. 64 matrix instructions per wave (4 channel pairs x 16 positions), operands by conflict-free ds_read_b32.
+// tile column j & 15), one 32x32 accumulator block per xi = 16 blocks = 256 registers.  The work of a workgroup is a linear
+// sequence of items k = (tile, chunk of 8 input channels), software-pipelined three deep:
+//   * LDS-DMA (global_load_lds): the host-transformed filters U[16][8][64] of item k+1 and the raw halo tile (8 x 10 x 40
+//     floats, the direct kernel's layout) of item k+2 go out from inside the matrix stream of item k;
+//   * input transform: raw tile of item k+1 -> V[16][8][64] (each thread 2 patches: 16 reads, 32 adds, 16 writes), its
+//     instructions spread one or a few per matrix instruction of item k;
+//   * 64 matrix instructions of item k per wave (4 channel pairs x 16 positions), operands by conflict-free ds_read_b32
+//     four instructions ahead.
+// One barrier per item; the matrix pipe idles only there and in the epilogue.  (A first version with a separate transform
+// phase and the DMA issued in front of it ran conv1b in 572 us, slower than the direct kernel's 490.)
 // Epilogue: the inverse transform runs in registers (the 16 values of an output channel x tile sit in the same register of
 // the 16 accumulator blocks), the bias enters through position (1,1), whose inverse-transform weight is +1 for all four
 // outputs, and a 2x2 max-pool is the maximum of the tile's own four outputs: no cross-lane traffic at all.
@@ -37,12 +42,14 @@ struct WinoTile {
   static constexpr int IN_FLOATS = CK * LH * LW;            // 3200: raw halo tile, row = x0-4 .. x0+35
   static constexpr int U_FLOATS = 16 * CK * CO_TILE;        // 8192
   static constexpr int W_FLOATS = U_FLOATS + CO_TILE;       // + the bias row (chunk 0's slab)
-  static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;   // one ring buffer (LDS-DMA target)
-  static constexpr int V_FLOATS = 16 * CK * 64;             // transformed input, single buffer
-  static constexpr int LDS_BYTES = (2 * BUF_FLOATS + V_FLOATS) * 4;   // 124 416
+  static constexpr int V_FLOATS = 16 * CK * 64;             // transformed input
+  // LDS: two raw tiles, two filter slabs, two transformed tiles (everything double-buffered)
+  static constexpr int RAW_OFF = 0, U_OFF = 2 * IN_FLOATS, V_OFF = U_OFF + 2 * W_FLOATS;
+  static constexpr int LDS_BYTES = (V_OFF + 2 * V_FLOATS) * 4;   // 157 184
 };
 
-// OIHW weights + bias -> slabs [co_tile][chunk][xi 16][ci 8][co 64] of U = G g G^T (computed in double) + a bias row.
+// OIHW weights + bias -> slabs [co_tile][chunk][xi 16][half 2][co 64][kk 4] of U = G g G^T (computed in double; input
+// channel ci = 2 kk + half: a lane's four channel pairs sit in one 16-byte piece) + a bias row.
 inline std::vector<float> pack_conv_weights_wino(const float *w, const float *bias, int cout, int cin) {
   constexpr int CK = WinoTile::CK;
   const int co_tiles = (cout + CO_TILE - 1) / CO_TILE, nch = cin / CK;
@@ -61,7 +68,7 @@ inline std::vector<float> pack_conv_weights_wino(const float *w, const float *bi
             for (int k = 0; k < 3; ++k) t[a][k] = G[a][0] * g[0 * 3 + k] + G[a][1] * g[1 * 3 + k] + G[a][2] * g[2 * 3 + k];
           for (int a = 0; a < 4; ++a)
             for (int b = 0; b < 4; ++b)
-              slab[((a * 4 + b) * CK + c) * CO_TILE + o] = (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
+              slab[(((a * 4 + b) * 2 + (c & 1)) * CO_TILE + o) * 4 + (c >> 1)] = (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
         }
         if (ch == 0) slab[WinoTile::U_FLOATS + o] = bias[co];
       }
@@ -73,11 +80,10 @@ template <bool POOL, bool RELU, int TAG = 0>
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
   using T = WinoTile;
   constexpr int CK = T::CK, LW = T::LW, LH = T::LH, LW4 = LW / 4;
-  constexpr int IN_V4 = T::IN_FLOATS / 4, W_V4 = T::W_FLOATS / 4, TOT_V4 = IN_V4 + W_V4;
-  constexpr int NIT = (TOT_V4 + 255) / 256;
+  constexpr int IN_V4 = T::IN_FLOATS / 4, W_V4 = T::W_FLOATS / 4;
+  constexpr int NIT_R = (IN_V4 + 255) / 256, NIT_U = (W_V4 + 255) / 256;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *const vbuf = smem + 2 * T::BUF_FLOATS;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -105,50 +111,106 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
     return t;
   };
 
-  int piece_off[NIT];
+  // staging plans: this thread's 16-byte pieces of a raw tile / of a filter slab
+  // Addresses are a wave-uniform 64-bit base (SGPRs) + an unsigned 32-bit byte offset per lane: the per-lane state of the
+  // DMA is NIT_R + 1 registers.  (64-bit per-lane pointers spilled, and a scratch reload's vmcnt(0) between two LDS-DMA
+  // instructions waits for the DMA itself.)
+  unsigned roff[NIT_R];
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int idx = it * 256 + tid;
-    if (idx < IN_V4) {
-      const int ci = idx / (LH * LW4);
-      const int rem = idx - ci * (LH * LW4);
-      const int r = rem / LW4;
-      const int q = rem - r * LW4;
-      piece_off[it] = ci * (int)in_plane + r * a.in_wp + q * 4;
-    } else {
-      piece_off[it] = (min(idx, TOT_V4 - 1) - IN_V4) * 4;
-    }
+  for (int it = 0; it < NIT_R; ++it) {
+    const int idx = min(it * 256 + tid, IN_V4 - 1);
+    const int ci = idx / (LH * LW4);
+    const int rem = idx - ci * (LH * LW4);
+    const int r = rem / LW4;
+    const int q = rem - r * LW4;
+    roff[it] = 4u * (unsigned)(ci * (int)in_plane + r * a.in_wp + q * 4);
   }
-  auto issue = [&](const TileRef &t, int chunk, float *buf) {
-    const float *inb = t.in_base + (size_t)chunk * CK * in_plane;
-    const float *wb = t.w_base + (size_t)chunk * T::W_FLOATS;
+  auto issue_raw = [&](const TileRef &t, int chunk, float *buf) {
+    const char *inb = reinterpret_cast<const char *>(t.in_base + (size_t)chunk * CK * in_plane);
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int idx = it * 256 + tid;
-      const float *src = ((idx < IN_V4) ? inb : wb) + piece_off[it];
-      if (it < NIT - 1 || idx < TOT_V4) glds16(src, buf + (it * 256 + wave * 64) * 4);
+    for (int it = 0; it < NIT_R; ++it)
+      if (it < NIT_R - 1 || it * 256 + tid < IN_V4) glds16(reinterpret_cast<const float *>(inb + roff[it]), buf + (it * 256 + wave * 64) * 4);
+  };
+  const unsigned uoff = 16u * (unsigned)tid;
+  auto issue_u = [&](const TileRef &t, int chunk, float *buf) {
+    const char *wb = reinterpret_cast<const char *>(t.w_base + (size_t)chunk * T::W_FLOATS);
+#pragma unroll
+    for (int it = 0; it < NIT_U; ++it)
+      if (it < NIT_U - 1 || it * 256 + tid < W_V4) glds16(reinterpret_cast<const float *>(wb + (uoff + 4096u * it)), buf + (it * 256 + wave * 64) * 4);
+  };
+
+  // input transform: this thread's two patches of a chunk = one tile, channels ci = half_t + 2 kk for kk = 2 p_t, 2 p_t + 1
+  // (the pair shares one 8-byte piece of V[xi][half][tile][kk 4])
+  const int t_tile = tid & 63, t_half = (tid >> 6) & 1, t_p = tid >> 7;
+  int raw_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ci = t_half + 2 * (2 * t_p + i);
+    const int trow = t_tile >> 4, tcol = t_tile & 15;              // tile row 0..3 (= 2 tb + (j >> 4)), tile column 0..15
+    raw_off[i] = ci * (LH * LW) + (2 * trow) * LW + 3 + 2 * tcol;  // LDS row 0 = output row y0 - 1, LDS column 4 = output column x0
+  }
+  const int v_off = (t_half * 64 + t_tile) * 4 + 2 * t_p;          // + xi * 512
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  auto transform = [&](const float *raw, float *vb) {
+    float v0[16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float *d = raw + raw_off[i];
+      float t[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float d0 = d[0 * LW + q], d1 = d[1 * LW + q], d2 = d[2 * LW + q], d3 = d[3 * LW + q];
+        t[0][q] = d0 - d2; t[1][q] = d1 + d2; t[2][q] = d2 - d1; t[3][q] = d1 - d3;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float w0 = t[r][0] - t[r][2], w1 = t[r][1] + t[r][2], w2 = t[r][2] - t[r][1], w3 = t[r][1] - t[r][3];
+        if (i == 0) {
+          v0[r * 4 + 0] = w0; v0[r * 4 + 1] = w1; v0[r * 4 + 2] = w2; v0[r * 4 + 3] = w3;
+        } else {
+          f32x2 *v = reinterpret_cast<f32x2 *>(vb + v_off);
+          v[(r * 4 + 0) * 256] = f32x2{v0[r * 4 + 0], w0};
+          v[(r * 4 + 1) * 256] = f32x2{v0[r * 4 + 1], w1};
+          v[(r * 4 + 2) * 256] = f32x2{v0[r * 4 + 2], w2};
+          v[(r * 4 + 3) * 256] = f32x2{v0[r * 4 + 3], w3};
+        }
+      }
     }
   };
 
-  // input transform: this thread's two (tile, channel) patches of a chunk
-  int raw_off[2], v_off[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int p = tid + 256 * i;
-    const int tile = p & 63, ci = p >> 6;
-    const int trow = tile >> 4, tcol = tile & 15;                 // tile row 0..3 (= 2 tb + (j >> 4)), tile column 0..15
-    raw_off[i] = ci * (LH * LW) + (2 * trow) * LW + 3 + 2 * tcol;  // LDS row 0 = output row y0 - 1, LDS column 4 = output column x0
-    v_off[i] = ci * 64 + tile;
-  }
-  const int a_lane = T::IN_FLOATS + half * CO_TILE + cb * 32 + j;   // + (xi * CK + 2 kk) * 64
-  const int b_lane = half * 64 + tb * 32 + j;                        // + (xi * CK + 2 kk) * 64
+  const int a_lane = half * CO_TILE + cb * 32 + j;   // 16-byte pieces in a filter slab: + xi * 128
+  const int b_lane = half * 64 + tb * 32 + j;        // 16-byte pieces in a V buffer:    + xi * 128
 
   int tile_id = blockIdx.x;
   if (tile_id >= n_tiles) return;
   TileRef cur = decode(tile_id);
-  issue(cur, 0, smem);
-  int ring = 0;
-  bool first_landed = false;
+
+  // prefetch cursors over the item sequence: filters one item ahead, raw tiles two items ahead
+  struct Cursor { TileRef t; int chunk, id; };
+  auto advance = [&](Cursor &q) {
+    if (++q.chunk == a.n_chunks) {
+      q.chunk = 0;
+      q.id += gridDim.x;
+      if (q.id < n_tiles) q.t = decode(q.id);
+    }
+  };
+  Cursor cu{cur, 0, tile_id};
+  issue_raw(cu.t, 0, smem + T::RAW_OFF);
+  issue_u(cu.t, 0, smem + T::U_OFF);
+  advance(cu);                                   // item 1
+  if (cu.id < n_tiles) issue_raw(cu.t, cu.chunk, smem + T::RAW_OFF + T::IN_FLOATS);
+  Cursor cr = cu;
+  advance(cr);                                   // item 2
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  // item 0's transform has nothing to hide behind
+  transform(smem + T::RAW_OFF, smem + T::V_OFF);
+
+#ifdef WINO_STAMPS
+  unsigned long long sum_vm = 0, sum_bar = 0, sum_gemm = 0, sum_xf = 0, sum_epi = 0;
+  const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+#endif
+  int k = 0;                    // items done: selects the buffers
+  bool drained = true;          // the LDS-DMA this item needs has been waited for already
   constexpr unsigned OOB = 0xFFFFFFFFu;
 
   for (; tile_id < n_tiles; tile_id += gridDim.x) {
@@ -156,74 +218,90 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
     TileRef nxt = cur;
     if (next_id < n_tiles) nxt = decode(next_id);
 
+    // accumulators start as 0 * 0 + 0 from the matrix pipe itself (C = the inline constant 0): 256 v_mov / v_accvgpr_write
+    // went through 256 live VGPRs, and the spills that caused put scratch reloads -- whose vmcnt(0) also waits for the
+    // LDS-DMA in flight -- into the matrix stream (conv1b 440 us with them)
     f32x16 acc[16];
 #pragma unroll
-    for (int x = 0; x < 16; ++x)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+    for (int x = 0; x < 16; ++x) acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(0.f, 0.f, f32x16{}, 0, 0, 0);
 
-    for (int c = 0; c < a.n_chunks; ++c, ++ring) {
-      // chunk `ring` has landed and every wave is done with the previous chunk's matrix work (V and the other ring buffer
-      // are free).  At a tile's first chunk the DMA wait already happened in front of the previous tile's epilogue.
-      if (c > 0 || !first_landed) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-      else asm volatile("s_barrier" ::: "memory");
-      float *nbuf = smem + ((ring + 1) & 1) * T::BUF_FLOATS;
-      const float *buf = smem + (ring & 1) * T::BUF_FLOATS;
+    for (int c = 0; c < a.n_chunks; ++c, ++k) {
+      // Item k may start: its filters and the raw tile of item k+1 have landed (issued one item ago), every wave has
+      // written its part of V(k) and finished the matrix work of item k-1.
+#ifdef WINO_STAMPS
+      const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
+      if (!drained) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef WINO_STAMPS
+      const unsigned long long st0b = __builtin_amdgcn_s_memtime();
+#endif
+      drained = false;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef WINO_STAMPS
+      const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
+      const float *ub = smem + T::U_OFF + (k & 1) * T::W_FLOATS;
+      const float *vb = smem + T::V_OFF + (k & 1) * T::V_FLOATS;
+      float *u_next = smem + T::U_OFF + ((k + 1) & 1) * T::W_FLOATS;
+      float *raw_next2 = smem + T::RAW_OFF + (k & 1) * T::IN_FLOATS;          // raw(k+2) replaces raw(k), transformed during item k-1
+      const float *raw_next = smem + T::RAW_OFF + ((k + 1) & 1) * T::IN_FLOATS;
+      float *v_next = smem + T::V_OFF + ((k + 1) & 1) * T::V_FLOATS;
 
       if (c == 0) {   // bias through position (1,1): A = (bias, 0), B = (1, 1), C = 0
-        const float bias_a = half ? 0.f : buf[T::IN_FLOATS + T::U_FLOATS + cb * 32 + j];
+        const float bias_a = half ? 0.f : ub[T::U_FLOATS + cb * 32 + j];
         acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a, 1.0f, acc[5], 0, 0, 0);
       }
 
-      // ---- input transform V = B^T d B
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const float *d = buf + raw_off[i];
-        float t[4][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float d0 = d[0 * LW + q], d1 = d[1 * LW + q], d2 = d[2 * LW + q], d3 = d[3 * LW + q];
-          t[0][q] = d0 - d2; t[1][q] = d1 + d2; t[2][q] = d2 - d1; t[3][q] = d1 - d3;
-        }
-        float *v = vbuf + v_off[i];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[((r * 4 + 0) * CK) * 64] = t[r][0] - t[r][2];
-          v[((r * 4 + 1) * CK) * 64] = t[r][1] + t[r][2];
-          v[((r * 4 + 2) * CK) * 64] = t[r][2] - t[r][1];
-          v[((r * 4 + 3) * CK) * 64] = t[r][1] - t[r][3];
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // V is complete; not __syncthreads(): its fence would drain the LDS-DMA
-
-      // ---- 16 GEMMs, 4 channel pairs each.  Operands are read PF instructions ahead (an LDS read takes longer than one
-      // matrix instruction runs); sched_barrier pins the order: one matrix instruction, then the two reads for PF later.
-      constexpr int PF = 4;
-      float av[PF], bv[PF];
-      auto ld = [&](int s) {
-        const int kk = s >> 4, xi = s & 15;
-        av[s % PF] = buf[a_lane + (xi * CK + 2 * kk) * 64];
-        bv[s % PF] = vbuf[b_lane + (xi * CK + 2 * kk) * 64];
+      // 64 matrix instructions in 4 groups of 4 positions.  A group's operands are 8 ds_read_b128 (a lane's four channel
+      // pairs of one position sit in one 16-byte piece of U and of V), read while the previous group multiplies; inside a
+      // group the order is channel pair outer, position inner, so an accumulator is revisited after 3 other instructions.
+      // The LDS-DMA of the following items goes out from inside the matrix stream.  sched_barrier pins the order.
+      typedef float f32x4v __attribute__((ext_vector_type(4)));
+      const f32x4v *ub4 = reinterpret_cast<const f32x4v *>(ub), *vb4 = reinterpret_cast<const f32x4v *>(vb);
+      f32x4v av[4], bv[4];   // one register set: position x of the next group is read right after its last use in this one
+      auto ld = [&](int g, int x) {
+        av[x] = ub4[a_lane + (4 * g + x) * 128];
+        bv[x] = vb4[b_lane + (4 * g + x) * 128];
       };
 #pragma unroll
-      for (int s = 0; s < PF - 1; ++s) ld(s);
+      for (int x = 0; x < 4; ++x) ld(0, x);
 #pragma unroll
-      for (int s = 0; s < 64; ++s) {
-        if (s + PF - 1 < 64) ld(s + PF - 1);
-        if (s == 1) {   // the next chunk's LDS-DMA goes out from inside the matrix stream (issued in front of the transform
-                        // it stalls the LDS instructions behind it: 572 -> 450 us on conv1b)
-          if (c + 1 < a.n_chunks) issue(cur, c + 1, nbuf);
-          else if (next_id < n_tiles) issue(nxt, 0, nbuf);      // first chunk of the NEXT tile
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int kk = q >> 2, x = q & 3;
+          acc[4 * g + x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][kk], bv[x][kk], acc[4 * g + x], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#ifndef WINO_NODMA
+          if (g == 0 && q == 1 && cu.id < n_tiles) issue_u(cu.t, cu.chunk, u_next);
+          if (g == 0 && q == 3 && cr.id < n_tiles) issue_raw(cr.t, cr.chunk, raw_next2);
+#endif
+          if (g < 3 && q >= 12) ld(g + 1, q - 12);   // 3 matrix instructions (192 cycles) before its first use
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        acc[s & 15] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s % PF], bv[s % PF], acc[s & 15], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
       }
+      // input transform of item k+1 (harmless garbage in -> garbage out when there is no item k+1): a phase of its own --
+      // spread between the matrix instructions it made the item 2.4x longer
+#ifdef WINO_STAMPS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+#endif
+      transform(raw_next, v_next);
+#ifdef WINO_STAMPS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+      sum_vm += st0b - st0; sum_bar += st1 - st0b; sum_gemm += st2 - st1; sum_xf += st3 - st2;
+#endif
+      advance(cu);
+      advance(cr);
     }
 
-    // the next tile's first chunk has landed before this tile's stores queue up behind it
+    // everything in flight for the next item has landed before this tile's stores queue up behind it
+#ifdef WINO_STAMPS
+    const unsigned long long se0 = __builtin_amdgcn_s_memtime();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    first_landed = true;
+    drained = true;
 
     // ---------------------------------------------------------------- epilogue: Y = A^T M A, ReLU, (pool), store
     float *co_base = a.out + (((size_t)cur.img * a.out_ctot + a.out_coff) + (size_t)cur.ct * CO_TILE + cb * 32) * out_plane;
@@ -261,9 +339,19 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
         __builtin_amdgcn_raw_buffer_store_b64(r0, rsrc, vo, k * oplane * 4, 0);
         __builtin_amdgcn_raw_buffer_store_b64(r1, rsrc, vo == OOB ? OOB : vo + 4u * (unsigned)a.out_wp, k * oplane * 4, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);   // one register index at a time: 16 accumulator reads live, not 256
     }
+#ifdef WINO_STAMPS
+    sum_epi += __builtin_amdgcn_s_memtime() - se0;
+#endif
     cur = nxt;
   }
+#ifdef WINO_STAMPS
+  if (a.stamps && tid == 0) {
+    unsigned long long *o = a.stamps + 8 * blockIdx.x;
+    o[0] = sum_vm; o[1] = sum_bar; o[2] = sum_gemm; o[3] = sum_xf; o[4] = sum_epi; o[5] = __builtin_amdgcn_s_memtime() - st_begin; o[6] = k;
+  }
+#endif
 }
 
 }  // namespace spvo

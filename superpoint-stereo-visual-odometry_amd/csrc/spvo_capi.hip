@@ -347,6 +347,25 @@ int launch_conv_wino_instance(spvo_ctx *c, const ConvArgs &args, hipStream_t str
     ready[dev] = true;
   }
   const int n_tiles = args.tiles_x * args.tiles_y * args.co_tiles * args.batch;
+#ifdef WINO_STAMPS
+  static unsigned long long *d_st = nullptr;
+  static int calls = 0;
+  ConvArgs a2 = args;
+  if (TAG == 1) {
+    if (!d_st) (void)hipMalloc(&d_st, 8 * 8 * 1024);
+    a2.stamps = d_st;
+  }
+  hipLaunchKernelGGL(k, dim3(std::min(n_tiles, c->num_cus)), dim3(256), WinoTile::LDS_BYTES, stream, a2);
+  if (TAG == 1 && ++calls == 20) {
+    (void)hipStreamSynchronize(stream);
+    std::vector<unsigned long long> h(8 * 256);
+    (void)hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost);
+    double s[7] = {0};
+    for (int b = 0; b < 256; ++b) for (int q = 0; q < 7; ++q) s[q] += (double)h[8 * b + q] / 256;
+    std::fprintf(stderr, "[wino stamps, 100 MHz ticks per workgroup] items %.0f: vm-wait %.0f barrier %.0f gemm %.0f transform %.0f epilogue %.0f total %.0f\n", s[6], s[0], s[1], s[2], s[3], s[4], s[5]);
+  }
+  return SPVO_OK;
+#endif
   hipLaunchKernelGGL(k, dim3(std::min(n_tiles, c->num_cus)), dim3(256), WinoTile::LDS_BYTES, stream, args);
   HIP_TRY(c, hipGetLastError());
   return SPVO_OK;
