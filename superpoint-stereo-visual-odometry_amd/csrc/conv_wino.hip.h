@@ -21,8 +21,9 @@
 //     instructions spread one or a few per matrix instruction of item k;
 //   * 64 matrix instructions of item k per wave (4 channel pairs x 16 positions), operands by conflict-free ds_read_b32
 //     four instructions ahead.
-// One barrier per item; the matrix pipe idles only there and in the epilogue.  (A first version with a separate transform
-// phase and the DMA issued in front of it ran conv1b in 572 us, slower than the direct kernel's 490.)
+// One barrier per item; the matrix pipe idles only there and in the epilogue.  The kernel must not spill: a scratch reload is a
+// vector-memory load, its s_waitcnt vmcnt(0) also waits for the LDS-DMA in flight, and such waits inside the matrix stream
+// cost 35 % (conv1b 440 us with 21 spilled registers, 296 us without).
 // Epilogue: the inverse transform runs in registers (the 16 values of an output channel x tile sit in the same register of
 // the 16 accumulator blocks), the bias enters through position (1,1), whose inverse-transform weight is +1 for all four
 // outputs, and a 2x2 max-pool is the maximum of the tile's own four outputs: no cross-lane traffic at all.
@@ -32,6 +33,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include <vector>
 #include "conv_mfma.hip.h"
 
@@ -76,7 +78,7 @@ inline std::vector<float> pack_conv_weights_wino(const float *w, const float *bi
   return out;
 }
 
-template <bool POOL, bool RELU, int TAG = 0>
+template <bool POOL, bool RELU, int TAG = 0, bool ODD = false>
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
   using T = WinoTile;
   constexpr int CK = T::CK, LW = T::LW, LH = T::LH, LW4 = LW / 4;
@@ -178,6 +180,37 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
     }
   };
 
+  // The same transform in 40 micro-steps (20 per patch) for the matrix stream: 0..11 read the patch row u / 3 as three aligned
+  // 8-byte pairs (columns c0-1 .. c0+4 of which c0 .. c0+3 are the patch: consecutive lanes read consecutive pairs, no bank
+  // conflicts; 4-byte reads at the odd column c0 use only the 16 odd banks); 12..15 column q of B^T d; 16..19 row r of
+  // (B^T d) B -> kept (patch 0) or written together with patch 0's (patch 1).
+  f32x2 dp[12];
+  float tt[16], v0s[16];
+  auto xf_step = [&](const float *raw, float *vb, int st) {
+    const int i = st / 20, u = st % 20;
+    if (u < 12) {
+      dp[u] = *reinterpret_cast<const f32x2 *>(raw + raw_off[i] - 1 + (u / 3) * LW + 2 * (u % 3));
+    } else if (u < 16) {
+      const int q = u - 12;
+      auto d = [&](int r) { return q == 0 ? dp[3 * r][1] : q == 1 ? dp[3 * r + 1][0] : q == 2 ? dp[3 * r + 1][1] : dp[3 * r + 2][0]; };
+      tt[0 * 4 + q] = d(0) - d(2);
+      tt[1 * 4 + q] = d(1) + d(2);
+      tt[2 * 4 + q] = d(2) - d(1);
+      tt[3 * 4 + q] = d(1) - d(3);
+    } else {
+      const int r = u - 16;
+      const float w0 = tt[r * 4 + 0] - tt[r * 4 + 2], w1 = tt[r * 4 + 1] + tt[r * 4 + 2], w2 = tt[r * 4 + 2] - tt[r * 4 + 1], w3 = tt[r * 4 + 1] - tt[r * 4 + 3];
+      if (i == 0) {
+        v0s[r * 4 + 0] = w0; v0s[r * 4 + 1] = w1; v0s[r * 4 + 2] = w2; v0s[r * 4 + 3] = w3;
+      } else {
+        f32x2 *v = reinterpret_cast<f32x2 *>(vb + v_off);
+        v[(r * 4 + 0) * 256] = f32x2{v0s[r * 4 + 0], w0};
+        v[(r * 4 + 1) * 256] = f32x2{v0s[r * 4 + 1], w1};
+        v[(r * 4 + 2) * 256] = f32x2{v0s[r * 4 + 2], w2};
+        v[(r * 4 + 3) * 256] = f32x2{v0s[r * 4 + 3], w3};
+      }
+    }
+  };
   const int a_lane = half * CO_TILE + cb * 32 + j;   // 16-byte pieces in a filter slab: + xi * 128
   const int b_lane = half * 64 + tb * 32 + j;        // 16-byte pieces in a V buffer:    + xi * 128
 
@@ -205,10 +238,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
   // item 0's transform has nothing to hide behind
   transform(smem + T::RAW_OFF, smem + T::V_OFF);
 
-#ifdef WINO_STAMPS
-  unsigned long long sum_vm = 0, sum_bar = 0, sum_gemm = 0, sum_xf = 0, sum_epi = 0;
-  const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
-#endif
   int k = 0;                    // items done: selects the buffers
   bool drained = true;          // the LDS-DMA this item needs has been waited for already
   constexpr unsigned OOB = 0xFFFFFFFFu;
@@ -219,8 +248,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
     if (next_id < n_tiles) nxt = decode(next_id);
 
     // accumulators start as 0 * 0 + 0 from the matrix pipe itself (C = the inline constant 0): 256 v_mov / v_accvgpr_write
-    // went through 256 live VGPRs, and the spills that caused put scratch reloads -- whose vmcnt(0) also waits for the
-    // LDS-DMA in flight -- into the matrix stream (conv1b 440 us with them)
+    // went through 256 live VGPRs and made the kernel spill (so did a first-chunk variant of the loop with C = 0 operands)
     f32x16 acc[16];
 #pragma unroll
     for (int x = 0; x < 16; ++x) acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(0.f, 0.f, f32x16{}, 0, 0, 0);
@@ -228,18 +256,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
     for (int c = 0; c < a.n_chunks; ++c, ++k) {
       // Item k may start: its filters and the raw tile of item k+1 have landed (issued one item ago), every wave has
       // written its part of V(k) and finished the matrix work of item k-1.
-#ifdef WINO_STAMPS
-      const unsigned long long st0 = __builtin_amdgcn_s_memtime();
-#endif
       if (!drained) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef WINO_STAMPS
-      const unsigned long long st0b = __builtin_amdgcn_s_memtime();
-#endif
       drained = false;
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#ifdef WINO_STAMPS
-      const unsigned long long st1 = __builtin_amdgcn_s_memtime();
-#endif
       const float *ub = smem + T::U_OFF + (k & 1) * T::W_FLOATS;
       const float *vb = smem + T::V_OFF + (k & 1) * T::V_FLOATS;
       float *u_next = smem + T::U_OFF + ((k + 1) & 1) * T::W_FLOATS;
@@ -247,59 +266,45 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
       const float *raw_next = smem + T::RAW_OFF + ((k + 1) & 1) * T::IN_FLOATS;
       float *v_next = smem + T::V_OFF + ((k + 1) & 1) * T::V_FLOATS;
 
-      if (c == 0) {   // bias through position (1,1): A = (bias, 0), B = (1, 1), C = 0
-        const float bias_a = half ? 0.f : ub[T::U_FLOATS + cb * 32 + j];
-        acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a, 1.0f, acc[5], 0, 0, 0);
-      }
-
       // 64 matrix instructions in 4 groups of 4 positions.  A group's operands are 8 ds_read_b128 (a lane's four channel
       // pairs of one position sit in one 16-byte piece of U and of V), read while the previous group multiplies; inside a
       // group the order is channel pair outer, position inner, so an accumulator is revisited after 3 other instructions.
-      // The LDS-DMA of the following items goes out from inside the matrix stream.  sched_barrier pins the order.
+      // The LDS-DMA of the following items and the 40 micro-steps of item k+1's input transform (harmless garbage in ->
+      // garbage out when there is no item k+1) sit between the matrix instructions.  sched_barrier pins the order.
       typedef float f32x4v __attribute__((ext_vector_type(4)));
       const f32x4v *ub4 = reinterpret_cast<const f32x4v *>(ub), *vb4 = reinterpret_cast<const f32x4v *>(vb);
-      f32x4v av[4], bv[4];   // one register set: position x of the next group is read right after its last use in this one
-      auto ld = [&](int g, int x) {
-        av[x] = ub4[a_lane + (4 * g + x) * 128];
-        bv[x] = vb4[b_lane + (4 * g + x) * 128];
-      };
+      if (c == 0) {   // bias through position (1,1), whose inverse-transform weight is +1 for all four outputs: A = (bias, 0), B = (1, 1)
+        const float bias_a = half ? 0.f : ub[T::U_FLOATS + cb * 32 + j];
+        acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a, 1.0f, acc[5], 0, 0, 0);
+      }
+      {
+        f32x4v av[4], bv[4];   // one register set: position x of the next group is read right after its last use in this one
+        auto ld = [&](int g, int x) {
+          av[x] = ub4[a_lane + (4 * g + x) * 128];
+          bv[x] = vb4[b_lane + (4 * g + x) * 128];
+        };
 #pragma unroll
-      for (int x = 0; x < 4; ++x) ld(0, x);
+        for (int x = 0; x < 4; ++x) ld(0, x);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < 4; ++g) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int kk = q >> 2, x = q & 3;
-          acc[4 * g + x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][kk], bv[x][kk], acc[4 * g + x], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-#ifndef WINO_NODMA
-          if (g == 0 && q == 1 && cu.id < n_tiles) issue_u(cu.t, cu.chunk, u_next);
-          if (g == 0 && q == 3 && cr.id < n_tiles) issue_raw(cr.t, cr.chunk, raw_next2);
-#endif
-          if (g < 3 && q >= 12) ld(g + 1, q - 12);   // 3 matrix instructions (192 cycles) before its first use
-          __builtin_amdgcn_sched_barrier(0);
+          for (int q = 0; q < 16; ++q) {
+            const int kk = q >> 2, x = q & 3;
+            acc[4 * g + x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][kk], bv[x][kk], acc[4 * g + x], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g == 0 && q == 1 && cu.id < n_tiles) issue_u(cu.t, cu.chunk, u_next);
+            if (g == 0 && q == 3 && cr.id < n_tiles) issue_raw(cr.t, cr.chunk, raw_next2);
+            if (g < 3 && q >= 12) ld(g + 1, q - 12);   // 3 matrix instructions (192 cycles) before its first use
+            if (16 * g + q >= 8 && 16 * g + q < 48) xf_step(raw_next, v_next, 16 * g + q - 8);   // input transform of item k+1
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
-      // input transform of item k+1 (harmless garbage in -> garbage out when there is no item k+1): a phase of its own --
-      // spread between the matrix instructions it made the item 2.4x longer
-#ifdef WINO_STAMPS
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const unsigned long long st2 = __builtin_amdgcn_s_memtime();
-#endif
-      transform(raw_next, v_next);
-#ifdef WINO_STAMPS
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const unsigned long long st3 = __builtin_amdgcn_s_memtime();
-      sum_vm += st0b - st0; sum_bar += st1 - st0b; sum_gemm += st2 - st1; sum_xf += st3 - st2;
-#endif
       advance(cu);
       advance(cr);
     }
 
     // everything in flight for the next item has landed before this tile's stores queue up behind it
-#ifdef WINO_STAMPS
-    const unsigned long long se0 = __builtin_amdgcn_s_memtime();
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     drained = true;
 
@@ -310,13 +315,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
     const int kmax = a.cout - (cur.ct * CO_TILE + cb * 32 + 4 * half);   // channels k < kmax of this wave's 32 exist for this lane
     const int trow = 2 * tb + (j >> 4), tcol = j & 15;
     auto relu = [](float v) { return RELU ? __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()) : v; };
-    unsigned voff;
+    unsigned voff, voff01 = OOB, voff10 = OOB, voff11 = OOB;
     if constexpr (POOL) {
       const int y = (cur.y0 >> 1) + trow, x = (cur.x0 >> 1) + tcol;
       voff = (y < (a.H >> 1) && x < (a.W >> 1)) ? 4u * (unsigned)(4 * half * oplane + (y + PADY) * a.out_wp + (x + PADX)) : OOB;
     } else {
       const int y = cur.y0 + 2 * trow, x = cur.x0 + 2 * tcol;
       voff = (y < a.H && x < a.W) ? 4u * (unsigned)(4 * half * oplane + (y + PADY) * a.out_wp + (x + PADX)) : OOB;
+      if constexpr (ODD) {
+        voff01 = (voff != OOB && x + 1 < a.W) ? voff + 4u : OOB;
+        voff10 = (voff != OOB && y + 1 < a.H) ? voff + 4u * (unsigned)a.out_wp : OOB;
+        voff11 = (voff01 != OOB && voff10 != OOB) ? voff10 + 4u : OOB;
+      }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -333,25 +343,24 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
       const unsigned vo = k < kmax ? voff : OOB;
       if constexpr (POOL) {
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaxf(fmaxf(y00, y01), fmaxf(y10, y11))), rsrc, vo, k * oplane * 4, 0);
-      } else {
+      } else if constexpr (!ODD) {
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         const u32x2 r0 = {__float_as_uint(y00), __float_as_uint(y01)}, r1 = {__float_as_uint(y10), __float_as_uint(y11)};
         __builtin_amdgcn_raw_buffer_store_b64(r0, rsrc, vo, k * oplane * 4, 0);
         __builtin_amdgcn_raw_buffer_store_b64(r1, rsrc, vo == OOB ? OOB : vo + 4u * (unsigned)a.out_wp, k * oplane * 4, 0);
+      } else {
+        // odd H or W: the second row / column of the last tiles is outside the image and must stay zero (it is the next
+        // layer's halo), so the four outputs leave one by one
+        const unsigned v00 = k < kmax ? voff : OOB, v01 = k < kmax ? voff01 : OOB, v10 = k < kmax ? voff10 : OOB, v11 = k < kmax ? voff11 : OOB;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y00), rsrc, v00, k * oplane * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y01), rsrc, v01, k * oplane * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y10), rsrc, v10, k * oplane * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y11), rsrc, v11, k * oplane * 4, 0);
       }
       __builtin_amdgcn_sched_barrier(0);   // one register index at a time: 16 accumulator reads live, not 256
     }
-#ifdef WINO_STAMPS
-    sum_epi += __builtin_amdgcn_s_memtime() - se0;
-#endif
     cur = nxt;
   }
-#ifdef WINO_STAMPS
-  if (a.stamps && tid == 0) {
-    unsigned long long *o = a.stamps + 8 * blockIdx.x;
-    o[0] = sum_vm; o[1] = sum_bar; o[2] = sum_gemm; o[3] = sum_xf; o[4] = sum_epi; o[5] = __builtin_amdgcn_s_memtime() - st_begin; o[6] = k;
-  }
-#endif
 }
 
 }  // namespace spvo

@@ -337,9 +337,9 @@ int launch_conv_epi(spvo_ctx *c, const ConvArgs &a, int batch, int epi, hipStrea
 }
 
 // Winograd F(2x2, 3x3) instance of a 3x3 layer (conv_wino.hip.h): one tile shape, one workgroup per CU (124 KB of LDS)
-template <bool POOL, bool RELU, int TAG>
+template <bool POOL, bool RELU, int TAG, bool ODD = false>
 int launch_conv_wino_instance(spvo_ctx *c, const ConvArgs &args, hipStream_t stream) {
-  auto k = conv_wino_kernel<POOL, RELU, TAG>;
+  auto k = conv_wino_kernel<POOL, RELU, TAG, ODD>;
   static bool ready[64] = {};
   const int dev = c->cfg.device & 63;
   if (!ready[dev]) {
@@ -347,25 +347,6 @@ int launch_conv_wino_instance(spvo_ctx *c, const ConvArgs &args, hipStream_t str
     ready[dev] = true;
   }
   const int n_tiles = args.tiles_x * args.tiles_y * args.co_tiles * args.batch;
-#ifdef WINO_STAMPS
-  static unsigned long long *d_st = nullptr;
-  static int calls = 0;
-  ConvArgs a2 = args;
-  if (TAG == 1) {
-    if (!d_st) (void)hipMalloc(&d_st, 8 * 8 * 1024);
-    a2.stamps = d_st;
-  }
-  hipLaunchKernelGGL(k, dim3(std::min(n_tiles, c->num_cus)), dim3(256), WinoTile::LDS_BYTES, stream, a2);
-  if (TAG == 1 && ++calls == 20) {
-    (void)hipStreamSynchronize(stream);
-    std::vector<unsigned long long> h(8 * 256);
-    (void)hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost);
-    double s[7] = {0};
-    for (int b = 0; b < 256; ++b) for (int q = 0; q < 7; ++q) s[q] += (double)h[8 * b + q] / 256;
-    std::fprintf(stderr, "[wino stamps, 100 MHz ticks per workgroup] items %.0f: vm-wait %.0f barrier %.0f gemm %.0f transform %.0f epilogue %.0f total %.0f\n", s[6], s[0], s[1], s[2], s[3], s[4], s[5]);
-  }
-  return SPVO_OK;
-#endif
   hipLaunchKernelGGL(k, dim3(std::min(n_tiles, c->num_cus)), dim3(256), WinoTile::LDS_BYTES, stream, args);
   HIP_TRY(c, hipGetLastError());
   return SPVO_OK;
@@ -376,6 +357,7 @@ int launch_conv_wino(spvo_ctx *c, const ConvArgs &a, int batch, bool relu, bool 
   args.tiles_x = (a.W + WinoTile::TW - 1) / WinoTile::TW;
   args.tiles_y = (a.H + WinoTile::TH - 1) / WinoTile::TH;
   args.batch = batch;
+  if (!pool && ((a.H | a.W) & 1)) return relu ? launch_conv_wino_instance<false, true, 0, true>(c, args, stream) : launch_conv_wino_instance<false, false, 0, true>(c, args, stream);
   if (dominant && relu) return pool ? launch_conv_wino_instance<true, true, 1>(c, args, stream) : launch_conv_wino_instance<false, true, 1>(c, args, stream);
   if (pool) return relu ? launch_conv_wino_instance<true, true, 0>(c, args, stream) : launch_conv_wino_instance<true, false, 0>(c, args, stream);
   return relu ? launch_conv_wino_instance<false, true, 0>(c, args, stream) : launch_conv_wino_instance<false, false, 0>(c, args, stream);
@@ -1617,13 +1599,14 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
           if (std::sscanf(q, "%d:%d,%d,%d", &oi, &wr, &wc, &ck) == 4 && oi == (int)i) { op.wr = wr; op.wc = wc; op.ck = ck; }
         }
       }
-      // Winograd F(2x2,3x3) where it pays: plain 3x3 layers (no BatchNorm / residual epilogue) on even-sized maps with enough
-      // 8x32 tiles to fill the chip twice; the small maps (45x147 and below) stay on the direct kernel, whose 4x32 tiles fill
-      // the CUs better.  SPVO_WINOGRAD=0 switches it off (A/B measurements, parity debugging).
+      // Winograd F(2x2,3x3) for the plain 3x3 layers (no BatchNorm / residual epilogue) whose 8x32 tiles give at least
+      // SPVO_WINOGRAD_MIN_TILES workgroups (default: 3/4 of the CUs; below that -- conv4a/4b at 45x147: 120 -- the direct kernel's 4x32 tiles fill the chip better: 47 vs 52 us); a pooled layer needs even sizes (the pooling window is
+      // the Winograd tile).  SPVO_WINOGRAD=0 switches it off (A/B measurements, parity debugging).
       {
         static const bool wino_on = !(std::getenv("SPVO_WINOGRAD") && std::atoi(std::getenv("SPVO_WINOGRAD")) == 0);
         const long wtiles = (long)((ti.W + WinoTile::TW - 1) / WinoTile::TW) * ((ti.H + WinoTile::TH - 1) / WinoTile::TH) * op.co_tiles * c->cfg.max_batch;
-        op.wino = wino_on && op.ks == 3 && !bn && !add && (op.cin % WinoTile::CK) == 0 && (ti.H % 2) == 0 && (ti.W % 2) == 0 && wtiles >= 2L * c->num_cus;
+        static const long min_tiles = std::getenv("SPVO_WINOGRAD_MIN_TILES") ? std::atol(std::getenv("SPVO_WINOGRAD_MIN_TILES")) : 3 * c->num_cus / 4;
+        op.wino = wino_on && op.ks == 3 && !bn && !add && (op.cin % WinoTile::CK) == 0 && (!pool || ((ti.H % 2) == 0 && (ti.W % 2) == 0)) && wtiles >= min_tiles;
       }
       if (op.wino) {
         op.ck = WinoTile::CK;
