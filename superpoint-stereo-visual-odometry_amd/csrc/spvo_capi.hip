@@ -53,6 +53,8 @@ struct Op {
   int type = 0, in = 0, out = 0, out_c_off = 0, in_c_off = 0, cin = 0, cout = 0, ks = 0, flags = 0;
   int ck = 0, n_chunks = 0, co_tiles = 0, wr = 0, wc = 0;
   int residual = 0;  // tensor added before the last ReLU (FLAG_ADD)
+  bool merged = false;     // FP32 engines: this op's output channels are computed by the previous op's launch (sibling layers
+                           // that read the same tensor and write adjacent channel ranges of one tensor: convPa + convDa)
   bool wino = false;       // FP32 engines: this 3x3 layer runs the Winograd F(2x2,3x3) kernel (conv_wino.hip.h)
   bool dominant = false;   // the op with the most FLOPs: launched under its own kernel name (TAG = 1)
   float *d_w = nullptr, *d_b = nullptr, *d_bn_scale = nullptr, *d_bn_shift = nullptr;
@@ -749,6 +751,7 @@ int launch_conv8(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t str
 }
 
 int launch_op(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream) {
+  if (op.merged) return SPVO_OK;
   const Tensor &ti = c->tensors[op.in];
   const Tensor &to = c->tensors[op.out];
   if (op.type == OP_CONV || op.type == OP_DWCONV) {
@@ -1442,6 +1445,7 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
     } else if (op.type == OP_CONV) {
       std::snprintf(name, sizeof name, "conv:%u", i);
       op.stage = stage_id(c, name);
+      if (op.merged) continue;
       const int taps = op.ks * op.ks;
       const bool bn = op.flags & FLAG_BN, add = op.flags & FLAG_ADD;
       if ((bn && (add || !(op.flags & FLAG_RELU))) || (add && (op.flags & FLAG_RELU)))
@@ -1478,6 +1482,28 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
       op.flops_per_image = 2.0 * ti.H * ti.W * op.cout * op.cin * taps;
       const float *w = payload + r.w_off;
       const float *b = payload + r.b_off;
+      // Sibling 3x3 layers (same input slice, same flags, adjacent output channel ranges of one tensor -- the two heads' first
+      // convolutions convPa / convDa write channels 0..255 and 256..511 of one tensor) run as ONE layer with the output
+      // channels concatenated: one launch instead of two, and 480 workgroups on 256 CUs instead of twice 240.
+      std::vector<float> wcat, bcat;
+      if (!c->int8 && !c->fp16 && !c->s3 && op.ks == 3 && op.cin > 1 && !bn && !add && !pool && (op.cout % CO_TILE) == 0 && i + 1 < no &&
+          !(std::getenv("SPVO_MERGE_SIBLINGS") && std::atoi(std::getenv("SPVO_MERGE_SIBLINGS")) == 0)) {
+        Op &nx = c->ops[i + 1];
+        const Raw &rn = raws[i + 1];
+        if (nx.type == OP_CONV && nx.in == op.in && nx.in_c_off == op.in_c_off && nx.cin == op.cin && nx.ks == op.ks && nx.flags == op.flags &&
+            nx.out == op.out && nx.out_c_off == op.out_c_off + op.cout && nx.out_c_off + nx.cout <= to.ch &&
+            rn.w_off + (uint64_t)nx.cout * nx.cin * taps <= nfl && rn.b_off + nx.cout <= nfl) {
+          wcat.assign(w, w + (size_t)op.cout * op.cin * taps);
+          wcat.insert(wcat.end(), payload + rn.w_off, payload + rn.w_off + (size_t)nx.cout * nx.cin * taps);
+          bcat.assign(b, b + op.cout);
+          bcat.insert(bcat.end(), payload + rn.b_off, payload + rn.b_off + nx.cout);
+          w = wcat.data();
+          b = bcat.data();
+          op.cout += nx.cout;
+          op.flops_per_image = 2.0 * ti.H * ti.W * op.cout * op.cin * taps;
+          nx.merged = true;
+        }
+      }
       if (c->int8) {
         if (ti.i8 != (op.cin != 1)) return fail(c, SPVO_ERR_IO, "op %u: INT8 engine: a %d-channel input tensor stored as %s", i, op.cin, ti.i8 ? "int8" : "fp32");
         op.inv_s_out = to.i8 ? 1.f / to.scale : 0.f;
@@ -1603,9 +1629,9 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
       // SPVO_WINOGRAD_MIN_TILES workgroups (default: 3/4 of the CUs; below that -- conv4a/4b at 45x147: 120 -- the direct kernel's 4x32 tiles fill the chip better: 47 vs 52 us); a pooled layer needs even sizes (the pooling window is
       // the Winograd tile).  SPVO_WINOGRAD=0 switches it off (A/B measurements, parity debugging).
       {
-        static const bool wino_on = !(std::getenv("SPVO_WINOGRAD") && std::atoi(std::getenv("SPVO_WINOGRAD")) == 0);
+        const bool wino_on = !(std::getenv("SPVO_WINOGRAD") && std::atoi(std::getenv("SPVO_WINOGRAD")) == 0);
         const long wtiles = (long)((ti.W + WinoTile::TW - 1) / WinoTile::TW) * ((ti.H + WinoTile::TH - 1) / WinoTile::TH) * op.co_tiles * c->cfg.max_batch;
-        static const long min_tiles = std::getenv("SPVO_WINOGRAD_MIN_TILES") ? std::atol(std::getenv("SPVO_WINOGRAD_MIN_TILES")) : 3 * c->num_cus / 4;
+        const long min_tiles = std::getenv("SPVO_WINOGRAD_MIN_TILES") ? std::atol(std::getenv("SPVO_WINOGRAD_MIN_TILES")) : 3 * c->num_cus / 4;
         op.wino = wino_on && op.ks == 3 && !bn && !add && (op.cin % WinoTile::CK) == 0 && (!pool || ((ti.H % 2) == 0 && (ti.W % 2) == 0)) && wtiles >= min_tiles;
       }
       if (op.wino) {

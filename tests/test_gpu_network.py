@@ -106,6 +106,39 @@ def test_fp32_split_mode_matches_oracle_at_fp32_rounding_level(vgg_weights_path,
         assert errs["split"][k] <= 4 * errs["native"][k] + 2e-7, (k, errs["native"][k], errs["split"][k])
 
 
+@pytest.mark.parametrize("H,W,batch", [(360, 1176, 2), (192, 640, 1)])
+def test_winograd_layers_stay_at_fp32_rounding_level(vgg_weights_path, vgg_plan, sample_images, H, W, batch, monkeypatch):
+    """The default FP32 engine runs its 3x3 layers through the Winograd F(2x2,3x3) kernel (csrc/conv_wino.hip.h); with
+    SPVO_WINOGRAD=0 (read when an engine is loaded) they run the direct kernel.  Both meet the 1e-4 bar against the oracle
+    on every tensor, and against a float64 evaluation of the graph the Winograd engine stays within a small factor of the
+    direct one: fp32 throughout, the transforms only use the coefficients 0, +-1 and +-1/2."""
+    from spvo import capi
+    x = _input(sample_images, H, W, batch)
+    rdet, rdesc, vals = net.forward(vgg_plan, x, return_all=True)
+    ref64 = _vgg_forward_f64(vgg_plan, x)
+    errs = {}
+    for mode in ("direct", "winograd"):
+        monkeypatch.setenv("SPVO_WINOGRAD", "0" if mode == "direct" else "1")
+        ctx = capi.Context(net_height=H, net_width=W)
+        ctx.load_weights(vgg_weights_path)
+        det, desc = ctx.forward(x)
+        e = {}
+        for tid, (ch, lvl) in enumerate(vgg_plan.tensors):
+            if tid in (vgg_plan.input_tensor, vgg_plan.desc_tensor):
+                continue
+            got = ctx.debug_tensor(tid, batch, ch, lvl)
+            assert np.abs(got - vals[tid]).max() <= _tol(vals[tid]), f"{mode}: tensor {tid}"
+            e[tid] = float(np.abs(got - ref64[tid]).max() / max(1.0, np.abs(ref64[tid]).max()))
+        e["desc"] = float(np.abs(desc - ref64[vgg_plan.desc_tensor].transpose(0, 2, 3, 1)).max())
+        assert np.abs(det - rdet).max() <= _tol(rdet) and np.abs(desc - rdesc.transpose(0, 2, 3, 1)).max() <= 1e-4
+        errs[mode] = e
+        ctx.close()
+    print("max relative error against float64, direct vs Winograd:", {k: (errs["direct"][k], errs["winograd"][k]) for k in errs["direct"]})
+    assert any(errs["direct"][k] != errs["winograd"][k] for k in errs["direct"])      # the switch did switch kernels
+    for k in errs["direct"]:
+        assert errs["winograd"][k] <= 4 * errs["direct"][k] + 2e-7, (k, errs["direct"][k], errs["winograd"][k])
+
+
 def test_fp32_split_mode_rejects_other_graphs(squeeze_weights_path):
     from spvo import capi
     ctx = capi.Context()

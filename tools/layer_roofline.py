@@ -37,6 +37,17 @@ for i, op in enumerate(plan.ops):
     st = prof.get(key)
     if not st or not st["calls"]:
         continue
+    # the library runs sibling layers (same input, adjacent output channel ranges: convPa + convDa) as one launch under
+    # the first one's name: fold the silent sibling into this row
+    nxt = plan.ops[i + 1] if i + 1 < len(plan.ops) else None
+    nkey = f"conv:{i + 1}"
+    if (nxt is not None and nxt.type == weights.OP_CONV and op.type == weights.OP_CONV and nxt.inp == op.inp and nxt.out == op.out
+            and not (prof.get(nkey) or {}).get("calls")):
+        import copy
+        op = copy.copy(op)
+        op.cout = op.cout + nxt.cout
+        op.weight = np.concatenate([op.weight, nxt.weight])
+        key = f"conv:{i}+{i + 1}"
     us = st["total_ms"] / st["calls"] * 1e3
     tot_us += us
     lvl_in, lvl_out = plan.tensors[op.inp][1], plan.tensors[op.out][1]
