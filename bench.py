@@ -235,8 +235,9 @@ def main():
             avg_ms = dom["total_ms"] / dom["calls"]
             achieved = dom["flops"] / (avg_ms * 1e-3) / 1e12
             traffic = None                                                 # HBM bytes per launch from the committed PMC pass
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")
-            if os.path.exists(pmc) and (NET_H, NET_W) == (360, 1176) and args.precision == "FP32" and not args.fp32_split and os.environ.get("SPVO_WINOGRAD", "1") == "0":
+            wino_on = os.environ.get("SPVO_WINOGRAD", "1") != "0"
+            pmc = os.path.join(ROOT, "profiles", "r01j_pmc_conv_traffic.json" if wino_on else "r01_pmc_conv_traffic.json")
+            if os.path.exists(pmc) and (NET_H, NET_W) == (360, 1176) and args.precision == "FP32" and not args.fp32_split:
                 traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
             peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "FP32" and not args.fp32_split else F16_MFMA_PEAK_TFLOPS
             wino = args.precision == "FP32" and not args.fp32_split and os.environ.get("SPVO_WINOGRAD", "1") != "0"
@@ -247,7 +248,7 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": kname + " instance of op 1 = conv1b 64->64 @" + f"{NET_H}x{NET_W}, 2 images",
                                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(achieved / peak, 4), "traffic": traffic,
-                               "traffic_source": "profiles/r01_pmc_conv_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 per gfx950 note)",
+                               "traffic_source": "profiles/" + os.path.basename(pmc) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 per gfx950 note)",
                                "avg_kernel_ms": round(avg_ms, 5), "flops_per_launch": dom["flops"]}
             if wino:   # `achieved` counts the layer's ALGORITHMIC flops (direct 3x3 convolution); the Winograd
                        # kernel executes 4/9 of them on the matrix pipe (16 multiplies per 2x2 outputs instead of 36)
