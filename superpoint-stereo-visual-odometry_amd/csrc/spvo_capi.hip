@@ -134,6 +134,7 @@ struct spvo_ctx {
   bool fp16 = false;               // the loaded engine's precision
   bool split_req = false;          // spvo_set_fp32_split / SPVO_FP32_SPLIT: FP32 engines loaded from now on run on the bf16x3 kernels
   bool s3 = false;                 // the loaded FP32 engine runs in split mode
+  size_t head_start = 0;           // ops [head_start, end) = the 1x1 heads + L2 norm: a submission runs them on the tail stream
   bool int8 = false;
   int H = 0, W = 0, Hc = 0, Wc = 0, B = 0;
   int num_cus = 256;
@@ -292,6 +293,9 @@ struct ScopedStage {
 };
 
 // ---------------------------------------------------------------- conv dispatch
+// a tensor's buffer for the submission being enqueued (tensors a tail reads have one per submission set)
+inline float *ring_ptr(spvo_ctx *c, const Tensor &t) { return t.dr[c->cur_ring] ? t.dr[c->cur_ring] : t.d; }
+
 template <int KS, int CK, int WR, int WC, bool POOL, bool RELU, int EPI = 0, int MINW = 1, int TAG = 0>
 int launch_conv_instance(spvo_ctx *c, ConvArgs args, hipStream_t stream) {
   using T = ConvTile<KS, CK, WR, WC>;
@@ -441,7 +445,7 @@ int launch_conv(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stre
   const int key = op.ks * 10000 + op.ck * 100 + op.wr * 20 + op.wc * 2 + (pool ? 1 : 0);   // ks, ck, wr, wc, pool
   if (epi) {
     a.bn_scale = op.d_bn_scale; a.bn_shift = op.d_bn_shift;
-    if (epi == 2) a.residual = c->tensors[op.residual].d + (size_t)img0 * c->tensors[op.residual].per_image;
+    if (epi == 2) a.residual = ring_ptr(c, c->tensors[op.residual]) + (size_t)img0 * c->tensors[op.residual].per_image;
     switch (key) {
       case 11644: return launch_conv_epi<2, 2, false>(c, a, batch, epi, stream);
       case 11624: return launch_conv_epi<1, 2, false>(c, a, batch, epi, stream);
@@ -547,7 +551,7 @@ int launch_conv16(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t st
   const int epi = (op.flags & FLAG_BN) ? 1 : (op.flags & FLAG_ADD) ? 2 : 0;
   if (epi) {
     a.bn_scale = op.d_bn_scale; a.bn_shift = op.d_bn_shift;
-    if (epi == 2) a.residual = (const _Float16 *)(c->tensors[op.residual].d + (size_t)img0 * c->tensors[op.residual].per_image);
+    if (epi == 2) a.residual = (const _Float16 *)(ring_ptr(c, c->tensors[op.residual]) + (size_t)img0 * c->tensors[op.residual].per_image);
     switch (key) {
       case 14220: return launch_conv16_epi<4, 2, 2, false>(c, a, epi, stream);
       case 14120: return launch_conv16_epi<4, 1, 2, false>(c, a, epi, stream);
@@ -726,7 +730,7 @@ int launch_conv8(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t str
   a.tiles_x = a.tiles_y = 0;
   a.batch = batch;
   const int epi = (op.flags & FLAG_BN) ? 1 : (op.flags & FLAG_ADD) ? 2 : 0;
-  if (epi == 2) a.residual = (const int8_t *)(c->tensors[op.residual].d + (size_t)img0 * c->tensors[op.residual].per_image);
+  if (epi == 2) a.residual = (const int8_t *)(ring_ptr(c, c->tensors[op.residual]) + (size_t)img0 * c->tensors[op.residual].per_image);
   const bool out_f32 = !to.i8;
   const int key = op.ks * 10000 + (op.ck / 16) * 1000 + op.wr * 100 + op.wc * 10 + (pool ? 1 : 0);   // ks, groups per chunk, wr, wc, pool
   switch (key) {
@@ -779,12 +783,19 @@ int launch_op(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream
 // Both images of a stereo pair go through every layer in ONE launch (they are independent, the batch index is part
 // of the tile id).  Per-image streams for the small layers were measured and gave nothing: two persistent
 // kernels do not backfill each other's ragged ends.
-int run_network(spvo_ctx *c, int batch) {
-  ScopedStage net(c, stage_id(c, "net"));
-  for (auto &op : c->ops) {
-    int rc = launch_op(c, op, 0, batch, c->stream);
+// ops [first, last) on `stream`
+int run_ops(spvo_ctx *c, int batch, size_t first, size_t last, hipStream_t stream) {
+  for (size_t i = first; i < last && i < c->ops.size(); ++i) {
+    int rc = launch_op(c, c->ops[i], 0, batch, stream);
     if (rc) return rc;
   }
+  return SPVO_OK;
+}
+
+int run_network(spvo_ctx *c, int batch) {
+  ScopedStage net(c, stage_id(c, "net"));
+  int rc = run_ops(c, batch, 0, c->ops.size(), c->stream);
+  if (rc) return rc;
   c->last_batch = batch;
   return SPVO_OK;
 }
@@ -1390,13 +1401,26 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
     }
     for (const auto &t : c->tensors) if (t.s3 && (t.ch % 8)) return fail(c, SPVO_ERR_IO, "%s: split-fp32 mode: a %d-channel tensor", path, t.ch);
   }
+  // The network's tail end -- the trailing run of unpooled 1x1 convolutions and the L2 normalisation: convPb, convDb + norm --
+  // is tiny and launch-bound (64 us for 2.2 GFLOP); a submission runs it on the tail stream, where it fills the CUs the next
+  // pair's trunk leaves idle, instead of on the network stream, which is the one that limits the frame rate.
+  c->head_start = c->ops.size();
+  if (!(std::getenv("SPVO_HEADS_ON_TAIL") && std::atoi(std::getenv("SPVO_HEADS_ON_TAIL")) == 0))
+    while (c->head_start > 0) {
+      const Op &o = c->ops[c->head_start - 1];
+      const bool head = o.type == OP_L2NORM || (o.type == OP_CONV && o.ks == 1 && !(o.flags & FLAG_POOL) && o.cin > 1);
+      if (!head) break;
+      --c->head_start;
+    }
   // allocate activations (padded planes stay zero outside the interior for ever)
   for (size_t ti = 0; ti < c->tensors.size(); ++ti) {
     Tensor &t = c->tensors[ti];
     t.per_image = t.nhwc ? (size_t)t.H * t.W * t.ch : t.s3 ? (size_t)t.ch * t.hp * t.wp * 3 / 2 : (size_t)t.ch * t.hp * t.wp / (t.f16 ? 2 : t.i8 ? 4 : 1);
     int rc = dev_alloc(c, &t.d, t.per_image * c->B);
     if (rc) return rc;
-    if ((int)ti == c->t_det || (int)ti == c->t_desc) {   // what a submission's tail reads while the next network pass already runs
+    bool head_input = false;   // read by the head ops, which a submission runs on its tail stream while the next trunk already runs
+    for (size_t q = c->head_start; q < c->ops.size(); ++q) head_input |= c->ops[q].in == (int)ti || ((c->ops[q].flags & FLAG_ADD) && c->ops[q].residual == (int)ti);
+    if ((int)ti == c->t_det || (int)ti == c->t_desc || head_input) {   // what a submission's tail reads while the next network pass already runs
       t.dr[0] = t.d;
       for (int r = 1; r < RING; ++r)
         if ((rc = dev_alloc(c, &t.dr[r], t.per_image * c->B))) return rc;
@@ -1880,12 +1904,19 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
     int rc = launch_preprocess(c, srcs[0], srcs[1], 2, rows, cols, stride, g, 0);
     if (rc) return rc;
   }
-  int rc = run_network(c, 2);
-  c->cur_ring = 0;
-  if (rc) return rc;
+  int rc;
+  {
+    ScopedStage net(c, stage_id(c, "net"));
+    rc = run_ops(c, 2, 0, c->head_start, c->stream);
+  }
+  if (rc) { c->cur_ring = 0; return rc; }
+  c->last_batch = 2;
   HIP_TRY(c, hipEventRecord(c->ev_net[ring], c->stream));
   HIP_TRY(c, hipStreamWaitEvent(c->stream_t, c->ev_net[ring], 0));
   c->post = c->stream_t;
+  rc = run_ops(c, 2, c->head_start, c->ops.size(), c->stream_t);   // heads: on the tail stream, reading this submission's ring buffers
+  c->cur_ring = 0;
+  if (rc) { c->post = c->stream; return rc; }
   const NmsPair np = nms_pair(c, ring);
   {
     // heat map + threshold + candidate list in one kernel; the counter block of this set was
