@@ -331,15 +331,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int k = (r & 3) + 8 * (r >> 2);
-      float s0[4], s1[4];
+      // two-wide (v_pk_add_f32): rows of M in pairs for the column pass, (y00, y01) / (y10, y11) for the row pass
+      f32x2 sa[2], sb[2];   // sa[h] = (s0[2h], s0[2h+1]), sb[h] = (s1[2h], s1[2h+1])
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float m0 = acc[4 * q + 0][r], m1 = acc[4 * q + 1][r], m2 = acc[4 * q + 2][r], m3 = acc[4 * q + 3][r];
-        s0[q] = (m0 + m1) + m2;
-        s1[q] = (m1 - m2) - m3;
+      for (int h = 0; h < 2; ++h) {
+        const f32x2 m0 = {acc[8 * h + 0][r], acc[8 * h + 4][r]}, m1 = {acc[8 * h + 1][r], acc[8 * h + 5][r]};
+        const f32x2 m2 = {acc[8 * h + 2][r], acc[8 * h + 6][r]}, m3 = {acc[8 * h + 3][r], acc[8 * h + 7][r]};
+        sa[h] = (m0 + m1) + m2;
+        sb[h] = (m1 - m2) - m3;
       }
-      const float y00 = relu((s0[0] + s0[1]) + s0[2]), y01 = relu((s1[0] + s1[1]) + s1[2]);
-      const float y10 = relu((s0[1] - s0[2]) - s0[3]), y11 = relu((s1[1] - s1[2]) - s1[3]);
+      const f32x2 q0 = {sa[0][0], sb[0][0]}, q1 = {sa[0][1], sb[0][1]}, q2 = {sa[1][0], sb[1][0]}, q3 = {sa[1][1], sb[1][1]};
+      const f32x2 ya = (q0 + q1) + q2, yb = (q1 - q2) - q3;   // ya = (y00, y01), yb = (y10, y11)
+      const float y00 = relu(ya[0]), y01 = relu(ya[1]), y10 = relu(yb[0]), y11 = relu(yb[1]);
       const unsigned vo = k < kmax ? voff : OOB;
       if constexpr (POOL) {
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaxf(fmaxf(y00, y01), fmaxf(y10, y11))), rsrc, vo, k * oplane * 4, 0);
