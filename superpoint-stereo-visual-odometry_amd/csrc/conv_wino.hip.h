@@ -247,13 +247,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
     TileRef nxt = cur;
     if (next_id < n_tiles) nxt = decode(next_id);
 
-    // accumulators start as 0 * 0 + 0 from the matrix pipe itself (C = the inline constant 0): 256 v_mov / v_accvgpr_write
-    // went through 256 live VGPRs and made the kernel spill (so did a first-chunk variant of the loop with C = 0 operands)
+    // One item (tile, chunk).  FIRST = the tile's first chunk: the first matrix instruction of every accumulator takes C = 0, so
+    // the 256 accumulator registers are never zeroed (v_mov / v_accvgpr_write went through 256 live VGPRs and made the kernel
+    // spill; 16 zeroing matrix instructions cost 2.4 %).  The first chunk is peeled from the loop, not branched inside it, so
+    // that no accumulator is conditionally defined.
     f32x16 acc[16];
-#pragma unroll
-    for (int x = 0; x < 16; ++x) acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(0.f, 0.f, f32x16{}, 0, 0, 0);
-
-    for (int c = 0; c < a.n_chunks; ++c, ++k) {
+    auto item = [&](auto first_tag) {
+      constexpr bool FIRST = decltype(first_tag)::value;
       // Item k may start: its filters and the raw tile of item k+1 have landed (issued one item ago), every wave has
       // written its part of V(k) and finished the matrix work of item k-1.
       if (!drained) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -273,10 +273,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
       // garbage out when there is no item k+1) sit between the matrix instructions.  sched_barrier pins the order.
       typedef float f32x4v __attribute__((ext_vector_type(4)));
       const f32x4v *ub4 = reinterpret_cast<const f32x4v *>(ub), *vb4 = reinterpret_cast<const f32x4v *>(vb);
-      if (c == 0) {   // bias through position (1,1), whose inverse-transform weight is +1 for all four outputs: A = (bias, 0), B = (1, 1)
-        const float bias_a = half ? 0.f : ub[T::U_FLOATS + cb * 32 + j];
-        acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a, 1.0f, acc[5], 0, 0, 0);
-      }
       {
         f32x4v av[4], bv[4];   // one register set: position x of the next group is read right after its last use in this one
         auto ld = [&](int g, int x) {
@@ -290,7 +286,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
             const int kk = q >> 2, x = q & 3;
-            acc[4 * g + x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][kk], bv[x][kk], acc[4 * g + x], 0, 0, 0);
+            if (FIRST && kk == 0) acc[4 * g + x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][kk], bv[x][kk], f32x16{}, 0, 0, 0);
+            else acc[4 * g + x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][kk], bv[x][kk], acc[4 * g + x], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (g == 0 && q == 1 && cu.id < n_tiles) issue_u(cu.t, cu.chunk, u_next);
             if (g == 0 && q == 3 && cr.id < n_tiles) issue_raw(cr.t, cr.chunk, raw_next2);
@@ -300,9 +297,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
           }
         }
       }
+      if (FIRST) {   // bias through position (1,1), whose inverse-transform weight is +1 for all four outputs: A = (bias, 0), B = (1, 1)
+        const float bias_a = half ? 0.f : ub[T::U_FLOATS + cb * 32 + j];
+        acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a, 1.0f, acc[5], 0, 0, 0);
+      }
       advance(cu);
       advance(cr);
-    }
+      ++k;
+    };
+    item(std::true_type{});
+    for (int c = 1; c < a.n_chunks; ++c) item(std::false_type{});
 
     // everything in flight for the next item has landed before this tile's stores queue up behind it
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
