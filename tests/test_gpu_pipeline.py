@@ -96,6 +96,36 @@ def test_detect_in_fp32_split_mode_matches_oracle(vgg_weights_path, vgg_plan, st
     ctx.close()
 
 
+@pytest.mark.parametrize("env", [{"SPVO_WINOGRAD": "0"}, {"SPVO_HEADS_ON_TAIL": "0"}, {"SPVO_MERGE_SIBLINGS": "0"},
+                                 {"SPVO_WINOGRAD": "0", "SPVO_HEADS_ON_TAIL": "0", "SPVO_MERGE_SIBLINGS": "0"}])
+def test_kernel_selection_switches_do_not_change_the_detector(vgg_weights_path, stereo_pair, env, monkeypatch):
+    """The engine-load switches (direct instead of Winograd 3x3 kernels, heads on the network stream, head
+    siblings launched separately) select other kernels / streams for the same arithmetic: keypoints are identical up to
+    threshold outcomes of heat-map values that differ in the last bits, descriptors agree to 1e-5."""
+    from spvo import capi
+    frames, _, P_l, P_r = stereo_pair
+    L, R = frames[1]
+    outs = []
+    for e in ({}, env):
+        for k in ("SPVO_WINOGRAD", "SPVO_HEADS_ON_TAIL", "SPVO_MERGE_SIBLINGS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in e.items():
+            monkeypatch.setenv(k, v)
+        ctx = capi.Context()
+        ctx.load_weights(vgg_weights_path)
+        outs.append(ctx.detect(L, R, P_l, P_r, 2, 3))
+        # two submissions in flight exercise the ring buffers of the head inputs
+        ctx.close()
+    a, b = outs
+    for side in ("l", "r"):
+        sa, sb = set(map(tuple, a["xy_" + side].astype(int).tolist())), set(map(tuple, b["xy_" + side].astype(int).tolist()))
+        assert len(sa & sb) / len(sa | sb) > 0.99
+        pos = {tuple(p): i for i, p in enumerate(b["xy_" + side].astype(int).tolist())}
+        common = [(i, pos[tuple(p)]) for i, p in enumerate(a["xy_" + side].astype(int).tolist()) if tuple(p) in pos]
+        gi, ri = map(np.array, zip(*common))
+        assert np.abs(a["desc_" + side][gi] - b["desc_" + side][ri]).max() <= 1e-5
+
+
 def test_prematch_is_transparent(ctx_squeeze, stereo_pair):
     """spvo_set_prematch only moves the two standard matches into the detector's submission."""
     frames, _, P_l, P_r = stereo_pair
