@@ -271,29 +271,35 @@ def main():
                                      if k.startswith(("conv:", "pool:", "l2norm:", "dwconv:"))}
             out["conv_stack_tflops"] = round(conv_fl / (conv_ms * 1e-3) / 1e12, 2)
         if world == 1 and headline and not args.no_extras:
-            # Informational, never `value`: the same workload with the FP32 engine in its opt-in split mode (every fp32 operand as
-            # three bf16 pieces, six partial products on the bf16 matrix pipe, fp32 accumulation: results agree with the
-            # native engine to fp32 rounding level, tests/test_gpu_network.py::test_fp32_split_mode_*).
-            fe.close()
-            os.environ["SPVO_FP32_SPLIT"] = "1"
-            fe = host.FrontEnd(tmp, prefix="superpoint_pretrained", selector="KNN", cross_check=True, batch=2,
-                               height=NET_H, width=NET_W, conf_thresh=0.015, dist_thresh=4, border_remove=4,
-                               stereo_threshold=2.0, min_disparity=0.25, refinement_degree=4, precision="FP32")
-            del os.environ["SPVO_FP32_SPLIT"]
-            if fe.engine_loaded:
-                for i in range(args.warmup):
-                    step(i)
-                barrier()
-                t1 = time.perf_counter()
-                for i in range(args.warmup, args.warmup + args.steps):
-                    step(i)
-                barrier()
-                e2 = time.perf_counter() - t1
-                out["fp32_split_mode"] = {"value": round(args.steps / e2, 2), "unit": "stereo frames/s", "ms_per_step": round(1e3 * e2 / args.steps, 4),
-                                          "note": "opt-in (spvo_set_fp32_split / bench.py --fp32-split), not the headline: fp32 operands as 3 bf16 pieces, "
-                                                  "6 partial products per product, fp32 accumulate; fp32-equivalent results"}
+            try:
+                # Informational, never `value`: the same workload with the FP32 engine in its opt-in split mode (every fp32 operand as
+                # three bf16 pieces, six partial products on the bf16 matrix pipe, fp32 accumulation: results agree with the
+                # native engine to fp32 rounding level, tests/test_gpu_network.py::test_fp32_split_mode_*).
+                fe.close()
+                os.environ["SPVO_FP32_SPLIT"] = "1"
+                fe = host.FrontEnd(tmp, prefix="superpoint_pretrained", selector="KNN", cross_check=True, batch=2,
+                                   height=NET_H, width=NET_W, conf_thresh=0.015, dist_thresh=4, border_remove=4,
+                                   stereo_threshold=2.0, min_disparity=0.25, refinement_degree=4, precision="FP32")
+                del os.environ["SPVO_FP32_SPLIT"]
+                if fe.engine_loaded:
+                    for i in range(args.warmup):
+                        step(i)
+                    barrier()
+                    t1 = time.perf_counter()
+                    for i in range(args.warmup, args.warmup + args.steps):
+                        step(i)
+                    barrier()
+                    e2 = time.perf_counter() - t1
+                    out["fp32_split_mode"] = {"value": round(args.steps / e2, 2), "unit": "stereo frames/s", "ms_per_step": round(1e3 * e2 / args.steps, 4),
+                                              "note": "opt-in (spvo_set_fp32_split / bench.py --fp32-split), not the headline: fp32 operands as 3 bf16 pieces, "
+                                                      "6 partial products per product, fp32 accumulate; fp32-equivalent results"}
+            except Exception as exc:   # the headline line must survive a failure of this informational part
+                out["fp32_split_mode"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and world == 1 and headline:
-            out["cpu_baseline"] = cpu_baseline(frames, P_l, P_r, plan)
+            try:
+                out["cpu_baseline"] = cpu_baseline(frames, P_l, P_r, plan)
+            except Exception as exc:   # the headline line must survive a failure of this informational part
+                out["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)
     fe.close()
     if dist_on:
