@@ -15,12 +15,12 @@
 // wave (cb, tb) owns channels [32 cb, 32 cb + 32) and the 32 tiles of tile rows {2 tb, 2 tb + 1} (lane j: tile row j >> 4,
 // tile column j & 15), one 32x32 accumulator block per xi = 16 blocks = 256 registers.  The work of a workgroup is a linear
 // sequence of items k = (tile, chunk of 8 input channels), software-pipelined three deep:
-//   * LDS-DMA (global_load_lds): the host-transformed filters U[16][8][64] of item k+1 and the raw halo tile (8 x 10 x 40
-//     floats, the direct kernel's layout) of item k+2 go out from inside the matrix stream of item k;
-//   * input transform: raw tile of item k+1 -> V[16][8][64] (each thread 2 patches: 16 reads, 32 adds, 16 writes), its
-//     instructions spread one or a few per matrix instruction of item k;
-//   * 64 matrix instructions of item k per wave (4 channel pairs x 16 positions), operands by conflict-free ds_read_b32
-//     four instructions ahead.
+//   * LDS-DMA (global_load_lds): the host-transformed filters U[16][half 2][co 64][kk 4] of item k+1 and the raw halo tile
+//     (8 x 10 x 40 floats, the direct kernel's layout) of item k+2 go out from inside the matrix stream of item k;
+//   * input transform: raw tile of item k+1 -> V[16][half 2][tile 64][kk 4] (each thread 2 patches = 2 channels of one tile:
+//     24 ds_read_b64, 64 adds, 16 ds_write_b64), in 40 micro-steps spread between the matrix instructions of item k;
+//   * 64 matrix instructions of item k per wave (16 positions x 4 channel pairs ci = 2 kk + half), operands by conflict-free
+//     ds_read_b128 (a lane's four channel pairs of one position are one 16-byte piece), read 3-4 instructions ahead.
 // One barrier per item; the matrix pipe idles only there and in the epilogue.  The kernel must not spill: a scratch reload is a
 // vector-memory load, its s_waitcnt vmcnt(0) also waits for the LDS-DMA in flight, and such waits inside the matrix stream
 // cost 35 % (conv1b 440 us with 21 spilled registers, 296 us without).
@@ -29,7 +29,8 @@
 // outputs, and a 2x2 max-pool is the maximum of the tile's own four outputs: no cross-lane traffic at all.
 //
 // Numerics: the transforms use coefficients 0, +-1, +-1/2 only; against a float64 evaluation the layer's error is of the
-// same order as the direct kernel's accumulated rounding (tests/test_gpu_network.py, 1e-4 bar on every tensor).
+// same order as the direct kernel's accumulated rounding, in fact smaller (tests/test_gpu_network.py: 1e-4 bar on every tensor
+// against the oracle, and test_winograd_layers_stay_at_fp32_rounding_level against float64).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
