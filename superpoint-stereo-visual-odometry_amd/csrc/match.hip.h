@@ -133,11 +133,13 @@ __global__ __launch_bounds__(256) void match_gemm_kernel(MatchJobs jobs, int gro
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] *= 1.f / (MATCH_FP8_SCALE * MATCH_FP8_SCALE);
   }
-  for (int k0 = 0; k0 < (FP8 ? 0 : MATCH_D); k0 += MATCH_KS) {
-    __syncthreads();
-    // 160 rows x 16 float4: consecutive threads walk along k (coalesced 256-byte runs)
+  // K slabs of 64: the global loads of slab s+1 are issued before the matrix instructions of slab s (registers), so only the
+  // first slab's latency is exposed
+  constexpr int NLD = MATCH_ROWS * (MATCH_KS / 4) / 256;   // float4 per thread and slab: 10
+  float4 pre[NLD];
+  auto load_slab = [&](int k0) {
 #pragma unroll
-    for (int it = 0; it < MATCH_ROWS * (MATCH_KS / 4) / 256; ++it) {
+    for (int it = 0; it < NLD; ++it) {
       const int i = it * 256 + tid;
       const int row = i >> 4, c4 = i & 15;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -146,10 +148,23 @@ __global__ __launch_bounds__(256) void match_gemm_kernel(MatchJobs jobs, int gro
       } else if (t0 + row - MATCH_QT < nb) {
         v = *(const float4 *)(B + (size_t)(t0 + row - MATCH_QT) * MATCH_D + k0 + c4 * 4);
       }
+      pre[it] = v;
+    }
+  };
+  if constexpr (!FP8) load_slab(0);
+  for (int k0 = 0; k0 < (FP8 ? 0 : MATCH_D); k0 += MATCH_KS) {
+    __syncthreads();
+    // 160 rows x 16 float4: consecutive threads walk along k (coalesced 256-byte runs)
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+      const int i = it * 256 + tid;
+      const int row = i >> 4, c4 = i & 15;
+      const float4 v = pre[it];
       float *dst = smem + (c4 * 4) * MATCH_LD + row;
       dst[0] = v.x; dst[MATCH_LD] = v.y; dst[2 * MATCH_LD] = v.z; dst[3 * MATCH_LD] = v.w;
     }
     __syncthreads();
+    if (k0 + MATCH_KS < MATCH_D) load_slab(k0 + MATCH_KS);
     // D[i = query][jj = train]: A operand lane -> A[q = j][k = 2s + half], B operand -> B[t = j][k]
     const float *pa = smem + half * MATCH_LD + j;
     const float *pb = smem + half * MATCH_LD + MATCH_QT + wave * 32 + j;
