@@ -84,17 +84,6 @@ constexpr int MATCH_ROWS = MATCH_QT + MATCH_TT;    // 160
 constexpr int MATCH_LD = MATCH_ROWS + 1;           // 161
 constexpr int MATCH_LDS_BYTES = MATCH_KS * MATCH_LD * 4;
 
-__device__ __forceinline__ void shortlist_insert(float (&bd)[MATCH_KEEP], int (&bi)[MATCH_KEEP], float d, int idx) {
-  // sorted insertion under (distance, index) order: the lower index wins ties, as in BFMatcher's scan
-#pragma unroll
-  for (int k = 0; k < MATCH_KEEP; ++k) {
-    if (d < bd[k] || (d == bd[k] && (unsigned)idx < (unsigned)bi[k])) {
-      const float td = bd[k]; const int ti = bi[k];
-      bd[k] = d; bi[k] = idx; d = td; idx = ti;
-    }
-  }
-}
-
 // FP8 = true: the dot products of the shortlist come from v_mfma_f32_32x32x16_fp8_fp8 on the fp8 copies (operands straight
 // from global memory: a lane's 8 consecutive dimensions of one row are 8 contiguous bytes); the shortlist is then
 // APPROXIMATE -- the exact re-rank (K12b) still produces exact distances for whatever it contains -- so this mode is an
@@ -187,34 +176,42 @@ __global__ __launch_bounds__(256) void match_gemm_kernel(MatchJobs jobs, int gro
     }
   }
   __syncthreads();
-  // per query: 8 lanes each keep the best MATCH_KEEP of 16 columns, then merge by butterfly
+  // Per query the MATCH_KEEP smallest (distance, index) pairs of the 128 columns: 8 lanes hold 16 columns each in registers and
+  // run MATCH_KEEP selection rounds -- lane-local minimum (the lower column wins ties), 3-step butterfly across the 8 lanes
+  // under (distance, index) order (BFMatcher's scan order), the owner masks the winner out.  (Sorted insertion of every
+  // column followed by a serial merge of the 8 lists cost 16 of the kernel's 30 us.)
   {
     const int q = tid >> 3, g = tid & 7;
-    float bd[MATCH_KEEP];
-    int bi[MATCH_KEEP];
-#pragma unroll
-    for (int k = 0; k < MATCH_KEEP; ++k) { bd[k] = __builtin_inff(); bi[k] = 0x7FFFFFFF; }
     const int ncol = min(MATCH_TT, nb - t0);
-    for (int c = g; c < ncol; c += 8) shortlist_insert(bd, bi, sD[q * LDD + c], t0 + c);
-    // merge the 8 partial lists of a query through LDS (behind the distance tile)
-    float *sMd = smem + MATCH_QT * LDD;                       // [32][8][KEEP] distances
-    int *sMi = (int *)(sMd + MATCH_QT * 8 * MATCH_KEEP);      // [32][8][KEEP] indices
+    float dcol[MATCH_TT / 8];
 #pragma unroll
-    for (int k = 0; k < MATCH_KEEP; ++k) {
-      sMd[(q * 8 + g) * MATCH_KEEP + k] = bd[k];
-      sMi[(q * 8 + g) * MATCH_KEEP + k] = bi[k];
+    for (int i = 0; i < MATCH_TT / 8; ++i) {
+      const int c = g + 8 * i;
+      dcol[i] = (c < ncol) ? sD[q * LDD + c] : __builtin_inff();
     }
-    __syncthreads();
-    if (g == 0) {
-      for (int e = MATCH_KEEP; e < 8 * MATCH_KEEP; ++e) {
-        const int oi = sMi[q * 8 * MATCH_KEEP + e];
-        if (oi != 0x7FFFFFFF) shortlist_insert(bd, bi, sMd[q * 8 * MATCH_KEEP + e], oi);
+    int sel[MATCH_KEEP];
+#pragma unroll
+    for (int r = 0; r < MATCH_KEEP; ++r) {
+      float bd = __builtin_inff();
+      int bi = 0x7FFFFFFF;
+#pragma unroll
+      for (int i = 0; i < MATCH_TT / 8; ++i)
+        if (dcol[i] < bd) { bd = dcol[i]; bi = t0 + g + 8 * i; }
+#pragma unroll
+      for (int m = 1; m < 8; m <<= 1) {
+        const float od = __shfl_xor(bd, m);
+        const int oi = __shfl_xor(bi, m);
+        if (od < bd || (od == bd && (unsigned)oi < (unsigned)bi)) { bd = od; bi = oi; }
       }
+      sel[r] = bi;
+#pragma unroll
+      for (int i = 0; i < MATCH_TT / 8; ++i)
+        if (t0 + g + 8 * i == bi) dcol[i] = __builtin_inff();
     }
     if (g == 0 && q0 + q < na) {
       int *o = jb.shortlist + ((size_t)(q0 + q) * groups + blockIdx.x) * MATCH_KEEP;
 #pragma unroll
-      for (int k = 0; k < MATCH_KEEP; ++k) o[k] = (bi[k] == 0x7FFFFFFF) ? -1 : bi[k];
+      for (int k = 0; k < MATCH_KEEP; ++k) o[k] = (sel[k] == 0x7FFFFFFF) ? -1 : sel[k];
     }
   }
 }
