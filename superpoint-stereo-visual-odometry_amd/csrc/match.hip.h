@@ -3,17 +3,20 @@
 // Replaces cv::BFMatcher(NORM_L2)::match / knnMatch(k=2) + ratio test
 // (reference: src/odml_visual_odometry/src/feature_detection_base.cpp:27-28,
 // 462-491).  Structure:
-//   K12a  S = A * B^T on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), tile
-//         32 queries x 128 train rows per workgroup, approximate
-//         d2 = |a|^2 + |b|^2 - 2 S, per-(query, 128-column group) top-4 kept in LDS
-//   K12b  exact re-rank: one wave per query recomputes the canonical distance
-//         sum_k (a_k - b_k)^2 (sequential k, separate multiply and add roundings,
-//         i.e. bit-identical to the oracle) for the <= 4*groups shortlisted rows
-//         and picks the best two under (distance, train index) order -- strict
-//         '<' so the lowest train index wins ties, as BFMatcher does
+//   K12a  S = A * B^T on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), one 64 x 128 tile per
+//         workgroup; the approximate squared distance dt = |a|^2 + |b|^2 - 2 S of EVERY pair goes
+//         to HBM (4 MB for 1000 x 1000)
+//   K12b  exact re-rank, one wave per query row.  |dt - d2| <= E = 2^-14 (|a|^2 + |b|^2) is a
+//         rigorous bound on the distance between dt and the canonical fp32 distance d2 =
+//         sum_k (a_k - b_k)^2 (sequential k, separately rounded multiply and add: bit-identical
+//         to the oracle), derivation at MATCH_ERR_REL.  With U2 = the second smallest dt + E of
+//         the row, every train row that can be among the two nearest under (d2, index) order
+//         has dt - E <= U2: exactly those rows are re-scored with the canonical sum and the best
+//         two picked under (distance, train index) order -- strict '<', so the lowest train
+//         index wins ties, as BFMatcher does.  The number of re-scored rows adapts to the data
+//         (2-4 on trained descriptors, the whole cluster on near-duplicate ones), so the result
+//         is the brute-force result BY CONSTRUCTION: the MFMA only prunes.
 //   K13   selector: NN (+ cv::batchDistance's crosscheck: train rows vote for their nearest query row) or KNN ratio test
-// Integer outputs (train indices) are therefore independent of the MFMA
-// rounding; the MFMA only prunes.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -22,9 +25,18 @@
 namespace spvo {
 
 constexpr int MATCH_D = 256;
-constexpr int MATCH_QT = 32;     // queries per workgroup
-constexpr int MATCH_TT = 128;    // train rows per workgroup (4 waves x 32)
-constexpr int MATCH_KEEP = 4;    // shortlist per (query, column group)
+constexpr int MATCH_QT = 64;     // query rows per workgroup (2 waves x 32)
+constexpr int MATCH_TT = 128;    // train rows per workgroup (2 waves x 2 x 32)
+
+// Error bound between the GEMM's dt and the canonical fp32 distance d2 (u = 2^-24, n = 256, N = |a|^2 + |b|^2, d^2 <= 2N):
+//   canonical sum: |d2 - d^2| <= gamma(n + 2) d^2 <= 2 * 258 u N                                   = 516 u N
+//   dot product on the matrix cores (an fma chain of length n): 2 |S~ - S| <= 2 * 256 u N / 2      = 256 u N
+//   squared norms (any summation order, <= 64 roundings) and the two additions of the epilogue     <=  80 u N
+// together 852 u N < 1024 u N = 2^-14 N.
+constexpr float MATCH_ERR_REL = 6.103515625e-5f;   // 2^-14
+// The same window for the fp8 shortlist GEMM (spvo_set_match_fp8): NOT a bound -- e4m3 operands carry 2^-4 relative
+// rounding errors whose sum over 256 random-sign terms is ~5e-3 N; 2e-2 N covers four standard deviations.
+constexpr float MATCH_ERR_REL_FP8 = 2e-2f;
 
 // Row counts come either from the host (n_host) or, when the call is enqueued before the
 // detector's counts are known on the host, from device memory (n_ptr).
@@ -35,7 +47,7 @@ struct MatchJob {
   int na, nb;                     // host counts (upper bounds when the *_ptr are set)
   const int *na_ptr, *nb_ptr;     // device counts or NULL
   const float *nA, *nB;           // squared row norms
-  int *shortlist;                 // [na][groups][MATCH_KEEP]
+  float *dt;                      // [na][ldt] approximate squared distances (K12a -> K12b)
   float *best_d2;                 // [na][2]
   int *best_idx;                  // [na][2]
   const unsigned char *A8, *B8;   // fp8 (e4m3) copies [n][256] of A * 16 and B * 16 for the fp8 shortlist GEMM, or NULL
@@ -74,212 +86,281 @@ __global__ __launch_bounds__(256) void desc_to_fp8_kernel(const float *__restric
   reinterpret_cast<int *>(out + (size_t)r * MATCH_D)[lane] = pk;
 }
 
-// K12a. grid = (ceil(nb/128), ceil(na/32), jobs).  shortlist[q][group][MATCH_KEEP] (train idx, -1 = none)
-// LDS holds one K-slab (64 of the 256 dimensions) of the 32 query rows and the 128 train rows,
-// K-MAJOR: element (row r, dim k) at [k][r] with a row pitch of 161 floats, so that both MFMA
-// operand reads are consecutive-lane ds_read_b32 (conflict-free) while the staging loads stay
-// coalesced along k.  41 KB per workgroup -> three workgroups per CU overlap load and compute.
+// K12a. grid = (ceil(nb/128), ceil(na/64), jobs): at 1000 x 1000 two jobs are 256 workgroups, one per CU.
+// The K dimension is walked in slabs of 64.  A slab of the tile's 64 query and 128 train rows sits in LDS ROW-major with
+// a pitch of 68 floats; the dot product does not care in which order k is visited as long as both operands agree, so
+// the lane that supplies (row j, k-half h) of v_mfma_f32_32x32x2_f32 reads the 16 contiguous bytes k = 8m + 4h .. + 3
+// of its row with ONE ds_read_b128 and feeds them to four consecutive matrix instructions.  (pitch / 4 = 17 is odd: the
+// 16 lanes of each ds_read_b128 service group fall on 16 different bank quads.)  No transposing scalar LDS stores, 3
+// 16-byte reads per 8 matrix instructions.  Staging goes global -> registers -> ds_write_b128; the loads of slab s + 1
+// are issued before the matrix instructions of slab s, and the two LDS buffers alternate: one barrier per slab.
 constexpr int MATCH_KS = 64;                       // K-slab
-constexpr int MATCH_ROWS = MATCH_QT + MATCH_TT;    // 160
-constexpr int MATCH_LD = MATCH_ROWS + 1;           // 161
-constexpr int MATCH_LDS_BYTES = MATCH_KS * MATCH_LD * 4;
+constexpr int MATCH_ROWS = MATCH_QT + MATCH_TT;    // 192
+constexpr int MATCH_LD = MATCH_KS + 4;             // 68
+constexpr int MATCH_BUF = MATCH_ROWS * MATCH_LD;   // floats per buffer
+constexpr int MATCH_LDS_BYTES = 2 * MATCH_BUF * 4; // 104448
 
-// FP8 = true: the dot products of the shortlist come from v_mfma_f32_32x32x16_fp8_fp8 on the fp8 copies (operands straight
-// from global memory: a lane's 8 consecutive dimensions of one row are 8 contiguous bytes); the shortlist is then
-// APPROXIMATE -- the exact re-rank (K12b) still produces exact distances for whatever it contains -- so this mode is an
-// opt-in (spvo_set_match_fp8) and the default keeps the fp32 GEMM whose shortlist error is 1e-7.
+__host__ __device__ inline int match_ldt(int nb_cap) { return (nb_cap + 31) & ~31; }   // row pitch of dt: 128-byte multiples
+
+// FP8 = true: the dot products come from v_mfma_f32_32x32x16_fp8_fp8 on the fp8 copies (operands straight from global
+// memory: a lane's 8 consecutive dimensions of one row are 8 contiguous bytes); dt is then approximate beyond
+// MATCH_ERR_REL -- K12b runs with the statistical window MATCH_ERR_REL_FP8 and still produces exact distances for
+// whatever falls into it -- so this mode is an opt-in (spvo_set_match_fp8).
 template <bool FP8>
-__global__ __launch_bounds__(256) void match_gemm_kernel(MatchJobs jobs, int groups) {
+__global__ __launch_bounds__(256) void match_gemm_kernel(MatchJobs jobs, int ldt) {
   const MatchJob jb = jobs.j[blockIdx.z];
   const float *__restrict__ A = jb.A;
   const float *__restrict__ B = jb.B;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qh = wave >> 1, th = wave & 1;           // the wave's 32 x 64 piece of the 64 x 128 tile
   const int q0 = blockIdx.y * MATCH_QT, t0 = blockIdx.x * MATCH_TT;
   const int na = dev_count(jb.na, jb.na_ptr), nb = dev_count(jb.nb, jb.nb_ptr);
-  if (q0 >= na) return;
-  if (t0 >= nb) {   // empty column group: the shortlist must still say "none"
-    if (tid < MATCH_QT && q0 + tid < na) {
-      int *o = jb.shortlist + ((size_t)(q0 + tid) * groups + blockIdx.x) * MATCH_KEEP;
-#pragma unroll
-      for (int k = 0; k < MATCH_KEEP; ++k) o[k] = -1;
-    }
-    return;
-  }
+  if (q0 >= na || t0 >= nb) return;
 
-  f32x16 acc;
+  f32x16 acc0, acc1;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 
   if constexpr (FP8) {
-    const int q = min(q0 + j, na - 1), t = min(t0 + wave * 32 + j, nb - 1);       // clamped rows are masked out below
+    const int q = min(q0 + 32 * qh + j, na - 1);       // clamped rows are never stored
+    const int ta = min(t0 + 64 * th + j, nb - 1), tb = min(t0 + 64 * th + 32 + j, nb - 1);
     const long *pa8 = reinterpret_cast<const long *>(jb.A8 + (size_t)q * MATCH_D) + half;
-    const long *pb8 = reinterpret_cast<const long *>(jb.B8 + (size_t)t * MATCH_D) + half;
+    const long *pb8 = reinterpret_cast<const long *>(jb.B8 + (size_t)ta * MATCH_D) + half;
+    const long *pc8 = reinterpret_cast<const long *>(jb.B8 + (size_t)tb * MATCH_D) + half;
 #pragma unroll
-    for (int s = 0; s < MATCH_D / 16; ++s)
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(pa8[2 * s], pb8[2 * s], acc, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] *= 1.f / (MATCH_FP8_SCALE * MATCH_FP8_SCALE);
-  }
-  // K slabs of 64: the global loads of slab s+1 are issued before the matrix instructions of slab s (registers), so only the
-  // first slab's latency is exposed
-  constexpr int NLD = MATCH_ROWS * (MATCH_KS / 4) / 256;   // float4 per thread and slab: 10
-  float4 pre[NLD];
-  auto load_slab = [&](int k0) {
-#pragma unroll
-    for (int it = 0; it < NLD; ++it) {
-      const int i = it * 256 + tid;
-      const int row = i >> 4, c4 = i & 15;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < MATCH_QT) {
-        if (q0 + row < na) v = *(const float4 *)(A + (size_t)(q0 + row) * MATCH_D + k0 + c4 * 4);
-      } else if (t0 + row - MATCH_QT < nb) {
-        v = *(const float4 *)(B + (size_t)(t0 + row - MATCH_QT) * MATCH_D + k0 + c4 * 4);
-      }
-      pre[it] = v;
+    for (int s = 0; s < MATCH_D / 16; ++s) {
+      const long av = pa8[2 * s];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(av, pb8[2 * s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(av, pc8[2 * s], acc1, 0, 0, 0);
     }
-  };
-  if constexpr (!FP8) load_slab(0);
-  for (int k0 = 0; k0 < (FP8 ? 0 : MATCH_D); k0 += MATCH_KS) {
-    __syncthreads();
-    // 160 rows x 16 float4: consecutive threads walk along k (coalesced 256-byte runs)
-#pragma unroll
-    for (int it = 0; it < NLD; ++it) {
-      const int i = it * 256 + tid;
-      const int row = i >> 4, c4 = i & 15;
-      const float4 v = pre[it];
-      float *dst = smem + (c4 * 4) * MATCH_LD + row;
-      dst[0] = v.x; dst[MATCH_LD] = v.y; dst[2 * MATCH_LD] = v.z; dst[3 * MATCH_LD] = v.w;
-    }
-    __syncthreads();
-    if (k0 + MATCH_KS < MATCH_D) load_slab(k0 + MATCH_KS);
-    // D[i = query][jj = train]: A operand lane -> A[q = j][k = 2s + half], B operand -> B[t = j][k]
-    const float *pa = smem + half * MATCH_LD + j;
-    const float *pb = smem + half * MATCH_LD + MATCH_QT + wave * 32 + j;
-#pragma unroll 8
-    for (int s2 = 0; s2 < MATCH_KS / 2; ++s2)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * s2 * MATCH_LD], pb[2 * s2 * MATCH_LD], acc, 0, 0, 0);
-  }
-  __syncthreads();
-  // approximate squared distances -> LDS [32 q][128 t + 1]
-  float *sD = smem;
-  constexpr int LDD = MATCH_TT + 1;
-  {
-    const int t = t0 + wave * 32 + j;
-    const float nbv = (t < nb) ? jb.nB[t] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int q = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const float nav = (q0 + q < na) ? jb.nA[q0 + q] : 0.f;
-      sD[q * LDD + wave * 32 + j] = (t < nb) ? (nav + nbv - 2.f * acc[r]) : __builtin_inff();
+      acc0[r] *= 1.f / (MATCH_FP8_SCALE * MATCH_FP8_SCALE);
+      acc1[r] *= 1.f / (MATCH_FP8_SCALE * MATCH_FP8_SCALE);
+    }
+  } else {
+    constexpr int NLD = MATCH_ROWS * (MATCH_KS / 4) / 256;   // float4 per thread and slab: 12
+    float4 pre[NLD];
+    // 16 consecutive threads fetch the 256 bytes of one row's slab: a wave instruction covers 4 rows
+    const int srow = tid >> 4, sc4 = tid & 15;
+    auto load_slab = [&](int k0) {
+#pragma unroll
+      for (int it = 0; it < NLD; ++it) {
+        const int row = it * 16 + srow;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < MATCH_QT) {
+          if (q0 + row < na) v = *(const float4 *)(A + (size_t)(q0 + row) * MATCH_D + k0 + sc4 * 4);
+        } else if (t0 + row - MATCH_QT < nb) {
+          v = *(const float4 *)(B + (size_t)(t0 + row - MATCH_QT) * MATCH_D + k0 + sc4 * 4);
+        }
+        pre[it] = v;
+      }
+    };
+    load_slab(0);
+    const int off_a = (32 * qh + j) * MATCH_LD + 4 * half;
+    const int off_b = (MATCH_QT + 64 * th + j) * MATCH_LD + 4 * half;
+#pragma unroll 1
+    for (int s = 0; s < MATCH_D / MATCH_KS; ++s) {
+      float *buf = smem + (s & 1) * MATCH_BUF;
+#pragma unroll
+      for (int it = 0; it < NLD; ++it)
+        *(float4 *)(buf + (it * 16 + srow) * MATCH_LD + sc4 * 4) = pre[it];
+      __syncthreads();
+      if (s + 1 < MATCH_D / MATCH_KS) load_slab((s + 1) * MATCH_KS);
+      const float *pa = buf + off_a, *pb = buf + off_b;
+      // operands of step m + 1 are read while the matrix instructions of step m run
+      float4 av = *(const float4 *)pa, bv = *(const float4 *)pb, cv = *(const float4 *)(pb + 32 * MATCH_LD);
+#pragma unroll
+      for (int m = 0; m < MATCH_KS / 8; ++m) {
+        float4 an = av, bn = bv, cn = cv;
+        if (m + 1 < MATCH_KS / 8) {
+          an = *(const float4 *)(pa + 8 * (m + 1));
+          bn = *(const float4 *)(pb + 8 * (m + 1));
+          cn = *(const float4 *)(pb + 32 * MATCH_LD + 8 * (m + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, cv.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, cv.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, cv.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, cv.w, acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        av = an; bv = bn; cv = cn;
+      }
     }
   }
-  __syncthreads();
-  // Per query the MATCH_KEEP smallest (distance, index) pairs of the 128 columns: 8 lanes hold 16 columns each in registers and
-  // run MATCH_KEEP selection rounds -- lane-local minimum (the lower column wins ties), 3-step butterfly across the 8 lanes
-  // under (distance, index) order (BFMatcher's scan order), the owner masks the winner out.  (Sorted insertion of every
-  // column followed by a serial merge of the 8 lists cost 16 of the kernel's 30 us.)
-  {
-    const int q = tid >> 3, g = tid & 7;
-    const int ncol = min(MATCH_TT, nb - t0);
-    float dcol[MATCH_TT / 8];
+  // dt[q][t] = |a|^2 + |b|^2 - 2 S.  Register r of an accumulator holds query row (r & 3) + 8 (r >> 2) + 4 half and the
+  // lanes of a half-wave 32 consecutive train rows: every store instruction writes two 128-byte runs.
+  const int ta = t0 + 64 * th + j, tb = ta + 32;
+  const float nba = (ta < nb) ? jb.nB[ta] : 0.f, nbb = (tb < nb) ? jb.nB[tb] : 0.f;
+  float *__restrict__ D = jb.dt;
 #pragma unroll
-    for (int i = 0; i < MATCH_TT / 8; ++i) {
-      const int c = g + 8 * i;
-      dcol[i] = (c < ncol) ? sD[q * LDD + c] : __builtin_inff();
-    }
-    int sel[MATCH_KEEP];
-#pragma unroll
-    for (int r = 0; r < MATCH_KEEP; ++r) {
-      float bd = __builtin_inff();
-      int bi = 0x7FFFFFFF;
-#pragma unroll
-      for (int i = 0; i < MATCH_TT / 8; ++i)
-        if (dcol[i] < bd) { bd = dcol[i]; bi = t0 + g + 8 * i; }
-#pragma unroll
-      for (int m = 1; m < 8; m <<= 1) {
-        const float od = __shfl_xor(bd, m);
-        const int oi = __shfl_xor(bi, m);
-        if (od < bd || (od == bd && (unsigned)oi < (unsigned)bi)) { bd = od; bi = oi; }
-      }
-      sel[r] = bi;
-#pragma unroll
-      for (int i = 0; i < MATCH_TT / 8; ++i)
-        if (t0 + g + 8 * i == bi) dcol[i] = __builtin_inff();
-    }
-    if (g == 0 && q0 + q < na) {
-      int *o = jb.shortlist + ((size_t)(q0 + q) * groups + blockIdx.x) * MATCH_KEEP;
-#pragma unroll
-      for (int k = 0; k < MATCH_KEEP; ++k) o[k] = (sel[k] == 0x7FFFFFFF) ? -1 : sel[k];
+  for (int r = 0; r < 16; ++r) {
+    const int q = q0 + 32 * qh + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (q < na) {
+      const float nav = jb.nA[q];
+      if (ta < nb) D[(size_t)q * ldt + ta] = nav + nba - 2.f * acc0[r];
+      if (tb < nb) D[(size_t)q * ldt + tb] = nav + nbb - 2.f * acc1[r];
     }
   }
 }
 
-// K12b. One wave per query; lane c re-scores shortlisted candidate c exactly.
-// Handles groups*MATCH_KEEP candidates in passes of 64.
+// K12b. One wave per query row.
+//   pass 1: U2 = second smallest (dt + E) of the row, E = err_rel (|a|^2 + |b|^2)
+//   pass 2: train rows with dt - E <= min(U2, second-best canonical distance found so far) are collected (ballot +
+//           prefix count into a per-wave LDS list) and re-scored 64 at a time, lane c scoring list entry c with the
+//           canonical sum; two rounds of wave arg-min under (distance, index) order merge a batch into the best two.
 // best[q] = {d2_0, d2_1 (f32 bits), idx0, idx1}
-// When `select_here` is set (every mode but NN + cross-check) the selector of K13 runs at the end of
-// this kernel and the packed result is written directly; with cross-check the best-of-train scatter
-// happens here and match_select_kernel finishes the job.
-__global__ __launch_bounds__(256) void match_rerank_kernel(MatchJobs jobs, int groups, int selector,
+// Every mode but NN + cross-check applies the selector at the end and writes the packed result; with cross-check the
+// best-of-train vote is cast here and match_select_cross_kernel finishes the job.
+constexpr int MATCH_LIST = 512;   // per-wave candidate queue (ring): a chunk adds up to 256 entries, fewer than 64 stay behind
+__global__ __launch_bounds__(256) void match_rerank_kernel(MatchJobs jobs, int ldt, float err_rel, int selector,
                                                            int cross_check, float ratio) {
   const MatchJob jb = jobs.j[blockIdx.y];
   const float *__restrict__ A = jb.A;
   const float *__restrict__ B = jb.B;
-  const int *__restrict__ shortlist = jb.shortlist;
-  float *__restrict__ best_d2 = jb.best_d2;
-  int *__restrict__ best_idx = jb.best_idx;
-  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ int s_list[4][MATCH_LIST];
+  __shared__ __attribute__((aligned(16))) float s_a[4][MATCH_D];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = blockIdx.x * 4 + wave;
   const int lane = threadIdx.x & 63;
-  const int na = dev_count(jb.na, jb.na_ptr);
+  const int na = dev_count(jb.na, jb.na_ptr), nb = dev_count(jb.nb, jb.nb_ptr);
   if (q >= na) return;
-  const int ncand = groups * MATCH_KEEP;
-  const float *a = A + (size_t)q * MATCH_D;
-  float d0 = __builtin_inff(), d1 = __builtin_inff();
-  int i0 = -1, i1 = -1;
-  for (int base = 0; base < ncand; base += 64) {
-    const int c = base + lane;
-    const int idx = (c < ncand) ? shortlist[(size_t)q * ncand + c] : -1;
-    float d = __builtin_inff();
-    if (idx >= 0) {
-      const float *b = B + (size_t)idx * MATCH_D;
-      float s = 0.f;
-      for (int k = 0; k < MATCH_D; k += 4) {
-        const float4 av = *(const float4 *)(a + k);
-        const float4 bv = *(const float4 *)(b + k);
-        float t;
-        t = sub_rn(av.x, bv.x); s = add_rn(s, mul_rn(t, t));
-        t = sub_rn(av.y, bv.y); s = add_rn(s, mul_rn(t, t));
-        t = sub_rn(av.z, bv.z); s = add_rn(s, mul_rn(t, t));
-        t = sub_rn(av.w, bv.w); s = add_rn(s, mul_rn(t, t));
+  const float *__restrict__ drow = jb.dt + (size_t)q * ldt;
+  const float *__restrict__ nB = jb.nB;
+  const float naq = jb.nA[q];
+  volatile int *list = s_list[wave];
+
+  // ---- pass 1
+  float u1 = __builtin_inff(), u2 = __builtin_inff();
+  for (int c0 = 0; c0 < nb; c0 += 256) {
+    const int t = c0 + lane * 4;
+    float dv[4], ev[4];
+    if (t + 3 < nb) {
+      const float4 d4 = *(const float4 *)(drow + t);
+      dv[0] = d4.x; dv[1] = d4.y; dv[2] = d4.z; dv[3] = d4.w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ev[e] = nB[t + e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dv[e] = (t + e < nb) ? drow[t + e] : __builtin_inff();
+        ev[e] = (t + e < nb) ? nB[t + e] : 0.f;
       }
-      d = s;
     }
-    // two rounds of wave arg-min under (d, idx) order
 #pragma unroll
-    for (int round = 0; round < 2; ++round) {
-      float md = d;
-      int mi = (idx >= 0) ? idx : 0x7FFFFFFF;
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) {
-        const float od = __shfl_xor(md, o);
-        const int oi = __shfl_xor(mi, o);
-        if (od < md || (od == md && oi < mi)) { md = od; mi = oi; }
-      }
-      if (mi == 0x7FFFFFFF || md == __builtin_inff()) break;
-      // merge (md, mi) into the running best two
-      if (md < d0 || (md == d0 && mi < i0) || i0 < 0) {
-        d1 = d0; i1 = i0; d0 = md; i0 = mi;
-      } else if (md < d1 || (md == d1 && mi < i1) || i1 < 0) {
-        d1 = md; i1 = mi;
-      }
-      if (idx == mi) d = __builtin_inff();  // remove the winner for the second round
+    for (int e = 0; e < 4; ++e) {
+      const float up = dv[e] + err_rel * (naq + ev[e]);
+      if (up < u1) { u2 = u1; u1 = up; } else if (up < u2) u2 = up;
     }
   }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {   // merge the lanes' two smallest
+    const float o1 = __shfl_xor(u1, o), o2 = __shfl_xor(u2, o);
+    const float lo = fminf(u1, o1), hi = fmaxf(u1, o1);
+    u2 = fminf(hi, fminf(u2, o2));
+    u1 = lo;
+  }
+  float thr = u2;   // +inf when the row has fewer than two columns: everything is a candidate
+
+  // ---- pass 2
+  // the query row goes to LDS once (one coalesced 1 KiB load per wave); the re-score loop reads it back with broadcast
+  // ds_read_b128, which are counted apart from the global loads of the train rows it keeps in flight
+  ((float4 *)s_a[wave])[lane] = ((const float4 *)(A + (size_t)q * MATCH_D))[lane];
+  const float4 *a4 = (const float4 *)s_a[wave];
+  float d0 = __builtin_inff(), d1 = __builtin_inff();
+  int i0 = -1, i1 = -1;
+  int head = 0, tail = 0;   // wave-uniform positions in the candidate queue (a ring of MATCH_LIST entries)
+  const int nchunks = (nb + 255) >> 8;
+  for (int step = 0; step <= nchunks; ++step) {
+    const bool last = step == nchunks;
+    if (!last) {
+      const int t = step * 256 + lane * 4;
+      float dv[4], ev[4];
+      if (t + 3 < nb) {
+        const float4 d4 = *(const float4 *)(drow + t);
+        dv[0] = d4.x; dv[1] = d4.y; dv[2] = d4.z; dv[3] = d4.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ev[e] = nB[t + e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dv[e] = (t + e < nb) ? drow[t + e] : __builtin_inff();
+          ev[e] = (t + e < nb) ? nB[t + e] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool cand = (t + e < nb) && (dv[e] - err_rel * (naq + ev[e]) <= thr);
+        const unsigned long long mask = __ballot(cand);
+        if (cand) list[(tail + __popcll(mask & ((1ull << lane) - 1ull))) & (MATCH_LIST - 1)] = t + e;
+        tail += __popcll(mask);
+      }
+    }
+    // re-score the queue 64 entries at a time (whatever is left after the last chunk)
+    while (tail - head >= 64 || (last && tail > head)) {
+      const int n = min(64, tail - head);
+      int idx = (lane < n) ? list[(head + lane) & (MATCH_LIST - 1)] : -1;
+      head += n;
+      // the canonical sum is one dependent chain of 256 additions per row; the train row's 1 KiB streams through two
+      // register blocks of 32 floats so that the loads of block i + 1 are in flight while block i is summed (lanes
+      // without a candidate re-read row 0 and are ignored)
+      const float4 *b4 = (const float4 *)(B + (size_t)max(idx, 0) * MATCH_D);
+      float4 cur[8], nxt[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) cur[i] = b4[i];
+      float s = 0.f;
+#pragma unroll 1
+      for (int blk = 0; blk < MATCH_D / 32; ++blk) {
+        if (blk + 1 < MATCH_D / 32) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) nxt[i] = b4[(blk + 1) * 8 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float4 av = a4[blk * 8 + i];
+          const float4 bv = cur[i];
+          float t;
+          t = sub_rn(av.x, bv.x); s = add_rn(s, mul_rn(t, t));
+          t = sub_rn(av.y, bv.y); s = add_rn(s, mul_rn(t, t));
+          t = sub_rn(av.z, bv.z); s = add_rn(s, mul_rn(t, t));
+          t = sub_rn(av.w, bv.w); s = add_rn(s, mul_rn(t, t));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+      }
+      float d = (idx >= 0) ? s : __builtin_inff();
+      // two rounds of wave arg-min under (distance, index) order merge the batch into the best two
+#pragma unroll
+      for (int round = 0; round < 2; ++round) {
+        float md = d;
+        int mi = (idx >= 0) ? idx : 0x7FFFFFFF;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+          const float od = __shfl_xor(md, o);
+          const int oi = __shfl_xor(mi, o);
+          if (od < md || (od == md && oi < mi)) { md = od; mi = oi; }
+        }
+        if (mi == 0x7FFFFFFF) break;
+        if (i0 < 0 || md < d0 || (md == d0 && mi < i0)) {
+          d1 = d0; i1 = i0; d0 = md; i0 = mi;
+        } else if (i1 < 0 || md < d1 || (md == d1 && mi < i1)) {
+          d1 = md; i1 = mi;
+        }
+        if (idx == mi) { idx = -1; d = __builtin_inff(); }  // the winner leaves before the second round
+      }
+      if (i1 >= 0) thr = fminf(thr, d1);     // no row above the second-best canonical distance can enter any more
+    }
+  }
+
   if (lane == 0) {
-    best_d2[2 * q] = d0; best_d2[2 * q + 1] = d1;
-    best_idx[2 * q] = i0; best_idx[2 * q + 1] = i1;
+    jb.best_d2[2 * q] = d0; jb.best_d2[2 * q + 1] = d1;
+    jb.best_idx[2 * q] = i0; jb.best_idx[2 * q + 1] = i1;
     const float s0 = sqrtf(d0), s1 = sqrtf(d1);   // BFMatcher L2 returns sqrt(sum of squares)
     if (selector == 0 && cross_check) {
       // sides swapped by the host: row q is a TRAIN row, i0 its nearest query row (lowest index on ties).  The query

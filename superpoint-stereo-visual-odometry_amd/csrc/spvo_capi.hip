@@ -99,7 +99,8 @@ struct MatchCache {
 
 struct MatchScratch {         // one set per concurrently enqueued match
   float *d_na = nullptr, *d_nb = nullptr, *d_best_d2 = nullptr;
-  int *d_short = nullptr, *d_best_idx = nullptr;
+  float *d_dt = nullptr;      // [cap][match_ldt(cap)] approximate squared distances of every pair (K12a -> K12b)
+  int *d_best_idx = nullptr;
   unsigned long long *d_train_best = nullptr;
   unsigned char *d_a8 = nullptr, *d_b8 = nullptr;   // fp8 copies of both sides (spvo_set_match_fp8)
   int2 *d_out = nullptr;      // packed result, points into spvo_ctx::d_match_out
@@ -973,14 +974,19 @@ int ensure_match(spvo_ctx *c, int na, int nb) {
   if (need <= c->match_cap) return SPVO_OK;
   const int cap = std::max(need, std::max(c->cfg.max_keypoints, 1024));
   HIP_TRY(c, hipDeviceSynchronize());
-  for (void *p : {(void *)c->d_ma, (void *)c->d_mb, (void *)c->d_match_out})
-    if (p) (void)hipFree(p);
-  for (auto &m : c->ms)
-    for (void *p : {(void *)m.d_na, (void *)m.d_nb, (void *)m.d_best_d2, (void *)m.d_short, (void *)m.d_best_idx, (void *)m.d_train_best, (void *)m.d_a8, (void *)m.d_b8})
-      if (p) (void)hipFree(p);
+  // every pointer is cleared as it is freed and the capacity drops to 0 first: an allocation failure further down leaves a
+  // context that spvo_destroy (and a later, smaller request) can still handle
+  c->match_cap = 0;
+  auto drop = [](auto *&p) { if (p) (void)hipFree(p); p = nullptr; };
+  drop(c->d_ma); drop(c->d_mb); drop(c->d_match_out);
+  for (auto &m : c->ms) {
+    drop(m.d_na); drop(m.d_nb); drop(m.d_best_d2); drop(m.d_dt); drop(m.d_best_idx); drop(m.d_train_best); drop(m.d_a8); drop(m.d_b8);
+    m.d_out = nullptr;
+  }
   for (auto &p : c->h_match_out) { if (p) (void)hipHostFree(p); p = nullptr; }
   if (c->h_match_tmp) (void)hipHostFree(c->h_match_tmp);
-  const int groups = (cap + MATCH_TT - 1) / MATCH_TT;
+  c->h_match_tmp = nullptr;
+  for (auto &set : c->mcache) for (auto &mc : set) { mc.valid = false; mc.h_out = nullptr; }
   int rc;
   if ((rc = dev_alloc(c, &c->d_ma, (size_t)cap * MATCH_D))) return rc;
   if ((rc = dev_alloc(c, &c->d_mb, (size_t)cap * MATCH_D))) return rc;
@@ -990,7 +996,7 @@ int ensure_match(spvo_ctx *c, int na, int nb) {
     if ((rc = dev_alloc(c, &m.d_na, cap))) return rc;
     if ((rc = dev_alloc(c, &m.d_nb, cap))) return rc;
     if ((rc = dev_alloc(c, &m.d_best_d2, (size_t)cap * 2))) return rc;
-    if ((rc = dev_alloc(c, &m.d_short, (size_t)cap * groups * MATCH_KEEP))) return rc;
+    if ((rc = dev_alloc(c, &m.d_dt, (size_t)cap * match_ldt(cap)))) return rc;
     if ((rc = dev_alloc(c, &m.d_best_idx, (size_t)cap * 2))) return rc;
     if ((rc = dev_alloc(c, &m.d_train_best, cap))) return rc;
     if ((rc = dev_alloc(c, &m.d_a8, (size_t)cap * MATCH_D))) return rc;
@@ -1039,7 +1045,7 @@ int enqueue_matches(spvo_ctx *c, const MatchReq *req_in, int njobs, int selector
     j.na_ptr = req[k].na_ptr; j.nb_ptr = req[k].nb_ptr;
     j.nA = req[k].sqA ? req[k].sqA : m.d_na;
     j.nB = req[k].sqB ? req[k].sqB : m.d_nb;
-    j.shortlist = m.d_short; j.best_d2 = m.d_best_d2; j.best_idx = m.d_best_idx; j.train_best = m.d_train_best; j.out = m.d_out;
+    j.dt = m.d_dt; j.best_d2 = m.d_best_d2; j.best_idx = m.d_best_idx; j.train_best = m.d_train_best; j.out = m.d_out;
     j.A8 = j.B8 = nullptr;
     if (c->match_fp8) {
       hipLaunchKernelGGL(desc_to_fp8_kernel, dim3((req[k].na + 3) / 4), dim3(256), 0, c->post, req[k].dA, req[k].na, req[k].na_ptr, m.d_a8);
@@ -1054,6 +1060,7 @@ int enqueue_matches(spvo_ctx *c, const MatchReq *req_in, int njobs, int selector
   }
   if (njobs == 1) jobs.j[1] = jobs.j[0];
   const int groups = (nb_max + MATCH_TT - 1) / MATCH_TT;
+  const int ldt = match_ldt(c->match_cap);
   const double fl = 2.0 * na_max * nb_max * MATCH_D * njobs;
   ScopedStage st(c, stage_id(c, "match"), fl, 4.0 * (na_max + nb_max) * MATCH_D * njobs);
   const size_t lds = MATCH_LDS_BYTES;
@@ -1065,10 +1072,14 @@ int enqueue_matches(spvo_ctx *c, const MatchReq *req_in, int njobs, int selector
   }
   {
     ScopedStage sg(c, stage_id(c, "match_gemm"), fl, 4.0 * (na_max + nb_max) * MATCH_D * njobs);
-    if (c->match_fp8) hipLaunchKernelGGL(match_gemm_kernel<true>, dim3(groups, (na_max + MATCH_QT - 1) / MATCH_QT, njobs), dim3(256), lds, c->post, jobs, groups);
-    else hipLaunchKernelGGL(match_gemm_kernel<false>, dim3(groups, (na_max + MATCH_QT - 1) / MATCH_QT, njobs), dim3(256), lds, c->post, jobs, groups);
+    if (c->match_fp8) hipLaunchKernelGGL(match_gemm_kernel<true>, dim3(groups, (na_max + MATCH_QT - 1) / MATCH_QT, njobs), dim3(256), 0, c->post, jobs, ldt);
+    else hipLaunchKernelGGL(match_gemm_kernel<false>, dim3(groups, (na_max + MATCH_QT - 1) / MATCH_QT, njobs), dim3(256), lds, c->post, jobs, ldt);
   }
-  hipLaunchKernelGGL(match_rerank_kernel, dim3((na_max + 3) / 4, njobs), dim3(256), 0, c->post, jobs, groups, selector, cross_check, ratio);
+  {
+    ScopedStage sr(c, stage_id(c, "match_rerank"));
+    hipLaunchKernelGGL(match_rerank_kernel, dim3((na_max + 3) / 4, njobs), dim3(256), 0, c->post, jobs, ldt,
+                       c->match_fp8 ? MATCH_ERR_REL_FP8 : MATCH_ERR_REL, selector, cross_check, ratio);
+  }
   if (swap) hipLaunchKernelGGL(match_select_cross_kernel, dim3((nb_max + 255) / 256, njobs), dim3(256), 0, c->post, jobs);
   HIP_TRY(c, hipGetLastError());
   // jobs' outputs are adjacent in d_match_out (stride match_cap): one copy
@@ -1282,8 +1293,8 @@ void spvo_destroy(spvo_ctx *c) {
   free_plan(c);
   void *ptrs[] = {c->d_dense_in, c->d_det_dense, c->d_resized, c->d_tab, c->d_img[0], c->d_img[1], c->d_xy_tmp, c->d_desc_tmp,
                   c->d_ma, c->d_mb, c->d_match_out, c->d_counters_all, c->d_xy_stage,
-                  c->ms[0].d_na, c->ms[0].d_nb, c->ms[0].d_best_d2, c->ms[0].d_short, c->ms[0].d_best_idx, c->ms[0].d_train_best, c->ms[0].d_a8, c->ms[0].d_b8,
-                  c->ms[1].d_na, c->ms[1].d_nb, c->ms[1].d_best_d2, c->ms[1].d_short, c->ms[1].d_best_idx, c->ms[1].d_train_best, c->ms[1].d_a8, c->ms[1].d_b8,
+                  c->ms[0].d_na, c->ms[0].d_nb, c->ms[0].d_best_d2, c->ms[0].d_dt, c->ms[0].d_best_idx, c->ms[0].d_train_best, c->ms[0].d_a8, c->ms[0].d_b8,
+                  c->ms[1].d_na, c->ms[1].d_nb, c->ms[1].d_best_d2, c->ms[1].d_dt, c->ms[1].d_best_idx, c->ms[1].d_train_best, c->ms[1].d_a8, c->ms[1].d_b8,
                   c->d_P, c->d_pts_a, c->d_pts_b, c->d_xyz, c->rw.counts, c->rw.poses, c->rw.result, c->rw.inliers, c->d_obs, c->d_refine};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (int r = 0; r < RING; ++r) {

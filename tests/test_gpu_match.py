@@ -64,3 +64,46 @@ def test_match_unnormalised_large_values(ctx_vgg):
     b[:100] = a[:100] + 0.5 * rng.randn(100, 256).astype(np.float32)
     _check(ctx_vgg, a, b, "KNN", False)
     _check(ctx_vgg, a, b, "NN", True)
+
+
+def test_match_near_duplicate_clusters(ctx_vgg):
+    """Clusters of rows that differ by a few ulps (what an untrained network produces): dozens of train rows sit
+    inside the error of the distance GEMM, so the pruning must hand ALL of them to the exact re-rank; ties and
+    near-ties resolve under (canonical distance, index) order exactly as the oracle's scan does."""
+    rng = np.random.RandomState(11)
+    base = _unit(rng, 40)
+    rows = []
+    for i in range(40):
+        reps = 5 + (i * 7) % 90                                            # cluster sizes 5 .. 94: more than one re-score batch
+        pert = (rng.randint(-2, 3, size=(reps, 256)) * 2.0 ** -26).astype(np.float32)
+        rows.append(base[i] + pert)
+    b = np.concatenate(rows + [_unit(rng, 300)])
+    b = b[rng.permutation(len(b))]
+    a = np.concatenate([base, base + (rng.randint(-1, 2, size=base.shape) * 2.0 ** -25).astype(np.float32), _unit(rng, 100)])
+    for selector, cross in (("KNN", False), ("NN", False), ("NN", True)):
+        _check(ctx_vgg, a, b, selector, cross)
+        _check(ctx_vgg, b, a, selector, cross)
+    _check(ctx_vgg, b, b, "NN", True)
+    _check(ctx_vgg, b, b, "KNN", False)
+
+
+def test_match_one_big_cluster_2048(ctx_vgg):
+    """2048 x 2048 with every row within 1e-6 of one point: every pair is inside the error window, every row is
+    re-scored (32 batches per query)."""
+    rng = np.random.RandomState(13)
+    c = _unit(rng, 1)
+    a = (c + rng.randn(2048, 256) * 3e-8).astype(np.float32)
+    b = (c + rng.randn(2048, 256) * 3e-8).astype(np.float32)
+    b[100:200] = a[300:400]
+    for selector, cross in (("KNN", False), ("NN", True)):
+        _check(ctx_vgg, a, b, selector, cross)
+
+
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 37.0, 1e4])
+def test_match_scaled_descriptors(ctx_vgg, scale):
+    """the error window scales with |a|^2 + |b|^2: exactness does not depend on unit norms"""
+    rng = np.random.RandomState(17)
+    a = _unit(rng, 500) * np.float32(scale)
+    b = np.concatenate([a[:250] * (1 + rng.randn(250, 1).astype(np.float32) * 1e-7), _unit(rng, 380) * np.float32(scale)])
+    for selector, cross in (("KNN", False), ("NN", False), ("NN", True)):
+        _check(ctx_vgg, a, b, selector, cross)

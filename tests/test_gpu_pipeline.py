@@ -60,17 +60,17 @@ def test_detect_properties_full_size(ctx_vgg, stereo_pair):
     # swapping left and right swaps the outputs
     c = ctx_vgg.detect(R, L, P_r, P_l, 0, 1)
     assert np.array_equal(c["xy_l"], a["xy_r"]) and np.array_equal(c["desc_r"], a["desc_l"])
-    # a slot matched against itself (NN + crossCheck): every keypoint finds itself at distance 0 -- except where the
-    # seeded, untrained network produced (near-)duplicate descriptors, squared distance below the 1e-6 the distance GEMM
-    # of the shortlist resolves: of such a group one row collects the votes and the others stay unmatched
-    idx, dist = ctx_vgg.match_slots(0, 0, len(c["xy_l"]), "NN", True)
-    hit = idx >= 0
-    assert np.array_equal(idx[hit], np.arange(len(idx))[hit]) and np.all(dist[hit] == 0) and hit.mean() > 0.97
-    desc = c["desc_l"].astype(np.float64)
-    for i in np.nonzero(~hit)[0]:
-        d2 = ((desc - desc[i]) ** 2).sum(1)
-        d2[i] = np.inf
-        assert d2.min() < 1e-6
+    # a slot matched against itself, every selector: the brute-force result, bit for bit, on EVERY row.  The seeded,
+    # untrained network produces clusters of (near-)duplicate descriptors (squared distances of 1e-10 and below, far
+    # under what the fp32 distance GEMM resolves): the re-rank re-scores whole clusters exactly, so ties go to the
+    # lowest index as BFMatcher's scan does (base.cpp:462-473)
+    n = len(c["xy_l"])
+    for selector, cross in (("NN", True), ("NN", False), ("KNN", False)):
+        idx, dist = ctx_vgg.match_slots(0, 0, n, selector, cross)
+        ridx, rdist = matching.bf_match(c["desc_l"], c["desc_l"], selector, cross, 0.8)
+        assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), (selector, cross)
+    idx, dist = ctx_vgg.match_slots(0, 0, n, "NN", False)
+    assert np.all(dist == 0)                                                 # every row finds itself or an exact duplicate
 
 
 def test_detect_in_fp32_split_mode_matches_oracle(vgg_weights_path, vgg_plan, stereo_pair):
@@ -195,18 +195,28 @@ def test_keypoint_cap_2048(vgg_weights_path, vgg_plan, stereo_pair):
     det, _ = ctx.forward(x)
     heat = ctx.heatmap(det[0])
     assert np.array_equal(ctx.nms(heat), fe.nms(heat, 0.015, 4, 4, 2048))   # same heat map -> bit-exact keypoints, 2048 of them
-    idx, d = ctx.match_slots(0, 1, 2048)
-    ridx, rd = matching.bf_match(out["desc_l"], out["desc_r"], "KNN", False, 0.8)
-    # The seeded (untrained) VGG produces clusters of numerically identical descriptors: squared distances of 1e-10
-    # and below, under the ~1e-7 resolution of the distance GEMM that builds the matcher's shortlist (|a|^2 + |b|^2 -
-    # 2ab in fp32).  Rows whose 6 nearest candidates lie within 1e-6 of each other are therefore not resolvable by
-    # the shortlist; every other row must be bit-exact (with trained weights no such row exists: test above).
-    d2 = np.sort(matching.sq_distances(out["desc_l"], out["desc_r"]), axis=1)
-    resolvable = (d2[:, 5] - d2[:, 0]) > 1e-6
-    assert resolvable.mean() > 0.95
-    assert np.array_equal(idx[resolvable], ridx[resolvable]) and np.array_equal(d[resolvable], rd[resolvable])
-    assert (idx != ridx).sum() <= 0.02 * len(idx)
+    # the headline workload's descriptors (seeded VGG: clusters of numerically identical rows) at the raised cap, every
+    # selector, every row: indices and distances equal the brute-force oracle's (base.cpp:462-473)
+    for selector, cross in (("KNN", False), ("NN", False), ("NN", True)):
+        idx, d = ctx.match_slots(0, 1, 2048, selector, cross)
+        ridx, rd = matching.bf_match(out["desc_l"], out["desc_r"], selector, cross, 0.8)
+        assert np.array_equal(idx, ridx) and np.array_equal(d, rd), (selector, cross)
     ctx.close()
+
+
+def test_matches_on_the_headline_workload_are_exact(ctx_vgg, stereo_pair):
+    """What bench.py times: seeded VGG, 360x1176, cap 1000, the stereo and the temporal match.  Every row of every
+    selector equals the oracle's brute-force matcher bit for bit (indices and distances)."""
+    frames, _, P_l, P_r = stereo_pair
+    prev = ctx_vgg.detect(frames[0][0], frames[0][1], P_l, P_r, 0, 1)
+    cur = ctx_vgg.detect(frames[1][0], frames[1][1], P_l, P_r, 2, 3)
+    n = len(cur["xy_l"])
+    assert n == 1000
+    for (sa, sb, da, db) in ((2, 3, cur["desc_l"], cur["desc_r"]), (2, 0, cur["desc_l"], prev["desc_l"])):
+        for selector, cross in (("KNN", False), ("NN", False), ("NN", True)):
+            idx, d = ctx_vgg.match_slots(sa, sb, n, selector, cross)
+            ridx, rd = matching.bf_match(da, db, selector, cross, 0.8)
+            assert np.array_equal(idx, ridx) and np.array_equal(d, rd), (sa, sb, selector, cross)
 
 
 def test_nms_redo_with_two_submissions_in_flight(vgg_plan, tmp_path):
