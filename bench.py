@@ -243,20 +243,20 @@ def main():
             wino = args.precision == "FP32" and not args.fp32_split and os.environ.get("SPVO_WINOGRAD", "1") != "0"
             kname = ("conv_s3_kernel<KS=3,...,POOL,RELU>" if args.fp32_split else "conv_wino_kernel<POOL,RELU,TAG=1> (Winograd F(2x2,3x3), fp32)" if wino
                      else "conv_mfma_kernel<KS=3,...,POOL,RELU>" if args.precision == "FP32" else "conv_f16_kernel<KS=3,...,POOL,RELU>")
-            if args.fp32_split:
-                achieved *= 6.0                                            # executed matrix flops: six bf16 partial products per fp32 product
+            # `achieved` / `frac` count the flops the matrix pipe EXECUTES per launch: the Winograd F(2x2,3x3) kernel runs 16
+            # multiplies per 2x2 outputs and channel pair instead of the direct method's 36 (4/9), the split mode six bf16
+            # partial products per fp32 product (x6).  The layer's ALGORITHMIC rate (direct 3x3 convolution, SURVEY.md
+            # section 8d) is reported beside it under its own name and never enters `frac`.
+            algorithmic = achieved
+            executed_per_launch = dom["flops"] * (6.0 if args.fp32_split else 4.0 / 9.0 if wino else 1.0)
+            achieved = executed_per_launch / (avg_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": kname + " instance of op 1 = conv1b 64->64 @" + f"{NET_H}x{NET_W}, 2 images",
                                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(achieved / peak, 4), "traffic": traffic,
                                "traffic_source": "profiles/" + os.path.basename(pmc) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 per gfx950 note)",
-                               "avg_kernel_ms": round(avg_ms, 5), "flops_per_launch": dom["flops"]}
-            if wino:   # `achieved` counts the layer's ALGORITHMIC flops (direct 3x3 convolution); the Winograd
-                       # kernel executes 4/9 of them on the matrix pipe (16 multiplies per 2x2 outputs instead of 36)
-                out["roofline"]["executed_flops_per_launch"] = dom["flops"] * 4.0 / 9.0
-                out["roofline"]["executed_tflops"] = round(achieved * 4.0 / 9.0, 2)
-                out["roofline"]["executed_frac_of_peak"] = round(achieved * 4.0 / 9.0 / peak, 4)
-                out["roofline"]["note"] = ("achieved / frac use the algorithmic (direct-convolution) flop count as the contract asks, so frac can exceed 1; "
-                                           "executed_* is what the fp32 matrix pipe actually runs (Winograd F(2x2,3x3) = 4/9 of it)")
+                               "avg_kernel_ms": round(avg_ms, 5), "flops_per_launch": executed_per_launch,
+                               "flops_counted": "executed on the matrix pipe" + (" (Winograd F(2x2,3x3): 4/9 of the direct convolution's)" if wino else ""),
+                               "algorithmic_flops_per_launch": dom["flops"], "algorithmic_tflops": round(algorithmic, 2)}
         any_stage = next((v for k, v in prof_all.items() if k.startswith("conv:") and v["calls"]), None)
         if any_stage:   # stage breakdown: the separate pass with every stage timed (it runs ~7 % slower than the timed region)
             calls = any_stage["calls"]

@@ -42,6 +42,8 @@ constexpr float MATCH_ERR_REL_FP8 = 2e-2f;
 // detector's counts are known on the host, from device memory (n_ptr).
 __device__ __forceinline__ int dev_count(int n_host, const int *n_ptr) { return n_ptr ? *n_ptr : n_host; }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 struct MatchJob {
   const float *A, *B;             // [na][256], [nb][256]
   int na, nb;                     // host counts (upper bounds when the *_ptr are set)
@@ -99,6 +101,7 @@ constexpr int MATCH_ROWS = MATCH_QT + MATCH_TT;    // 192
 constexpr int MATCH_LD = MATCH_KS + 4;             // 68
 constexpr int MATCH_BUF = MATCH_ROWS * MATCH_LD;   // floats per buffer
 constexpr int MATCH_LDS_BYTES = 2 * MATCH_BUF * 4; // 104448
+constexpr int MATCH_LDS_BYTES_FP8 = MATCH_QT * (MATCH_TT + 4) * 4;   // the fp8 variant stages only its output tile
 
 __host__ __device__ inline int match_ldt(int nb_cap) { return (nb_cap + 31) & ~31; }   // row pitch of dt: 128-byte multiples
 
@@ -122,6 +125,12 @@ __global__ __launch_bounds__(256) void match_gemm_kernel(MatchJobs jobs, int ldt
   f32x16 acc0, acc1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  // squared norms of the wave's rows: requested now, consumed by the epilogue
+  float nav[16], nbv[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) nav[r] = jb.nA[min(q0 + 32 * qh + (r & 3) + 8 * (r >> 2) + 4 * half, na - 1)];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) nbv[f] = jb.nB[min(t0 + 64 * th + 32 * f + j, nb - 1)];
 
   if constexpr (FP8) {
     const int q = min(q0 + 32 * qh + j, na - 1);       // clamped rows are never stored
@@ -195,169 +204,262 @@ __global__ __launch_bounds__(256) void match_gemm_kernel(MatchJobs jobs, int ldt
     }
   }
   // dt[q][t] = |a|^2 + |b|^2 - 2 S.  Register r of an accumulator holds query row (r & 3) + 8 (r >> 2) + 4 half and the
-  // lanes of a half-wave 32 consecutive train rows: every store instruction writes two 128-byte runs.
-  const int ta = t0 + 64 * th + j, tb = ta + 32;
-  const float nba = (ta < nb) ? jb.nB[ta] : 0.f, nbb = (tb < nb) ? jb.nB[tb] : 0.f;
-  float *__restrict__ D = jb.dt;
+  // lanes of a half-wave 32 consecutive train rows.  32 dword stores per lane would be issue-bound, so the tile is
+  // transposed through LDS (buffer 0 is free: its last readers passed the barrier of the final slab) and leaves as 8
+  // 16-byte stores per lane, a wave instruction covering two 512-byte row pieces.  Columns beyond nb inside the row
+  // pitch receive finite filler (zero-padded operands) that K12b never reads.
+  constexpr int LDD = MATCH_TT + 4;
+  float *sD = smem;
+  {
+    const float nba = nbv[0], nbb = nbv[1];
+    float *w0 = sD + (32 * qh + 4 * half) * LDD + 64 * th + j;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int q = q0 + 32 * qh + (r & 3) + 8 * (r >> 2) + 4 * half;
-    if (q < na) {
-      const float nav = jb.nA[q];
-      if (ta < nb) D[(size_t)q * ldt + ta] = nav + nba - 2.f * acc0[r];
-      if (tb < nb) D[(size_t)q * ldt + tb] = nav + nbb - 2.f * acc1[r];
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2);
+      w0[row * LDD] = nav[r] + nba - 2.f * acc0[r];
+      w0[row * LDD + 32] = nav[r] + nbb - 2.f * acc1[r];
+    }
+  }
+  __syncthreads();
+  float *__restrict__ D = jb.dt;
+  const int c4 = tid & 31, r0 = tid >> 5;
+  const int t = t0 + c4 * 4;
+  if (t < ldt) {
+#pragma unroll
+    for (int it = 0; it < MATCH_QT / 8; ++it) {
+      const int row = it * 8 + r0;
+      if (q0 + row < na) *(float4 *)(D + (size_t)(q0 + row) * ldt + t) = *(const float4 *)(sD + row * LDD + c4 * 4);
     }
   }
 }
 
 // K12b. One wave per query row.
 //   pass 1: U2 = second smallest (dt + E) of the row, E = err_rel (|a|^2 + |b|^2)
-//   pass 2: train rows with dt - E <= min(U2, second-best canonical distance found so far) are collected (ballot +
-//           prefix count into a per-wave LDS list) and re-scored 64 at a time, lane c scoring list entry c with the
-//           canonical sum; two rounds of wave arg-min under (distance, index) order merge a batch into the best two.
+//   pass 2: train rows with dt - E <= U2 are collected (ballot + prefix count into a per-wave LDS queue) and re-scored
+//           in batches of up to 64 with the canonical sum; two rounds of wave arg-min under (distance, index) order
+//           merge a batch into the best two.
+// NCH > 0: the row has at most NCH * 256 columns and stays in registers between the passes (one round of loads, all in
+// flight together); NCH = 0: any length, the row is read twice in chunks of 256 columns and the queue is drained as it
+// fills (the threshold then also drops to the second-best canonical distance found so far).
 // best[q] = {d2_0, d2_1 (f32 bits), idx0, idx1}
 // Every mode but NN + cross-check applies the selector at the end and writes the packed result; with cross-check the
 // best-of-train vote is cast here and match_select_cross_kernel finishes the job.
-constexpr int MATCH_LIST = 512;   // per-wave candidate queue (ring): a chunk adds up to 256 entries, fewer than 64 stay behind
+constexpr int MATCH_COOP = 8;                  // batches of up to 8 rows are fetched by the whole wave (one 1 KiB load per row)
+constexpr int MATCH_COOP_LD = MATCH_D + 4;     // LDS pitch of those rows: lanes reading different rows hit different banks
+template <int NCH> struct MatchRerankLds {
+  static constexpr int LIST = NCH > 0 ? NCH * 256 : 512;   // queue entries per wave (NCH = 0: a ring, < 64 + 256 waiting)
+  int list[4][LIST];
+  __attribute__((aligned(16))) float a[4][MATCH_D];
+  __attribute__((aligned(16))) float b[4][MATCH_COOP][MATCH_COOP_LD];
+};
+
+// Re-scores queue entries [head, head + n), n <= 64, and merges them into the best two.
+struct MatchBest { float d0, d1; int i0, i1; };   // the two nearest so far under (distance, index) order
+struct MatchTwo { float u1, u2; };                // two smallest values
+
+template <int LIST>
+__device__ __forceinline__ MatchBest match_score_batch(volatile int *list, int head, int n, const float *__restrict__ B,
+                                                       const float4 *a4, float (*sb)[MATCH_COOP_LD], int lane, MatchBest best) {
+  float d0 = best.d0, d1 = best.d1;
+  int i0 = best.i0, i1 = best.i1;
+  int idx = (lane < n) ? list[(head + lane) & (LIST - 1)] : -1;
+  float s = 0.f;
+  if (n <= MATCH_COOP) {
+    // few rows (the usual case): the wave fetches each row with ONE coalesced 1 KiB load, all of them in flight together,
+    // and parks them in LDS; lane c then sums row c -- one dependent chain of 256 additions, the canonical order
+    float4 rowv[MATCH_COOP];
+#pragma unroll
+    for (int c = 0; c < MATCH_COOP; ++c) {
+      rowv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < n) {
+        const int ic = __builtin_amdgcn_readfirstlane(list[(head + c) & (LIST - 1)]);
+        rowv[c] = ((const float4 *)(B + (size_t)ic * MATCH_D))[lane];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < MATCH_COOP; ++c)
+      if (c < n) *(float4 *)(&sb[c][lane * 4]) = rowv[c];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the rows are read back by other lanes of this wave
+    if (idx >= 0) {
+      const float4 *b4 = (const float4 *)sb[lane];
+#pragma unroll 8
+      for (int i = 0; i < MATCH_D / 4; ++i) {
+        const float4 av = a4[i];
+        const float4 bv = b4[i];
+        float t;
+        t = sub_rn(av.x, bv.x); s = add_rn(s, mul_rn(t, t));
+        t = sub_rn(av.y, bv.y); s = add_rn(s, mul_rn(t, t));
+        t = sub_rn(av.z, bv.z); s = add_rn(s, mul_rn(t, t));
+        t = sub_rn(av.w, bv.w); s = add_rn(s, mul_rn(t, t));
+      }
+    }
+  } else if (idx >= 0) {
+    // many rows (clusters of near-duplicates): every lane streams its own row through two register blocks of 32 floats,
+    // the loads of block i + 1 in flight while block i is summed
+    const float4 *b4 = (const float4 *)(B + (size_t)idx * MATCH_D);
+    float4 cur[8], nxt[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cur[i] = b4[i];
+#pragma unroll 1
+    for (int blk = 0; blk < MATCH_D / 32; ++blk) {
+      if (blk + 1 < MATCH_D / 32) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) nxt[i] = b4[(blk + 1) * 8 + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float4 av = a4[blk * 8 + i];
+        const float4 bv = cur[i];
+        float t;
+        t = sub_rn(av.x, bv.x); s = add_rn(s, mul_rn(t, t));
+        t = sub_rn(av.y, bv.y); s = add_rn(s, mul_rn(t, t));
+        t = sub_rn(av.z, bv.z); s = add_rn(s, mul_rn(t, t));
+        t = sub_rn(av.w, bv.w); s = add_rn(s, mul_rn(t, t));
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+    }
+  }
+  float d = (idx >= 0) ? s : __builtin_inff();
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    float md = d;
+    int mi = (idx >= 0) ? idx : 0x7FFFFFFF;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const float od = __shfl_xor(md, o);
+      const int oi = __shfl_xor(mi, o);
+      if (od < md || (od == md && oi < mi)) { md = od; mi = oi; }
+    }
+    if (mi == 0x7FFFFFFF) break;
+    if (i0 < 0 || md < d0 || (md == d0 && mi < i0)) {
+      d1 = d0; i1 = i0; d0 = md; i0 = mi;
+    } else if (i1 < 0 || md < d1 || (md == d1 && mi < i1)) {
+      d1 = md; i1 = mi;
+    }
+    if (idx == mi) { idx = -1; d = __builtin_inff(); }  // the winner leaves before the second round
+  }
+  return MatchBest{d0, d1, i0, i1};
+}
+
+__device__ __forceinline__ MatchTwo match_two_smallest(float up, MatchTwo t) {
+  if (up < t.u1) { t.u2 = t.u1; t.u1 = up; } else if (up < t.u2) t.u2 = up;
+  return t;
+}
+
+template <int NCH>
 __global__ __launch_bounds__(256) void match_rerank_kernel(MatchJobs jobs, int ldt, float err_rel, int selector,
                                                            int cross_check, float ratio) {
+  using L = MatchRerankLds<NCH>;
+  constexpr int LIST = L::LIST;
   const MatchJob jb = jobs.j[blockIdx.y];
   const float *__restrict__ A = jb.A;
   const float *__restrict__ B = jb.B;
-  __shared__ int s_list[4][MATCH_LIST];
-  __shared__ __attribute__((aligned(16))) float s_a[4][MATCH_D];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  L &lds = *reinterpret_cast<L *>(smem);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = blockIdx.x * 4 + wave;
   const int lane = threadIdx.x & 63;
   const int na = dev_count(jb.na, jb.na_ptr), nb = dev_count(jb.nb, jb.nb_ptr);
   if (q >= na) return;
   const float *__restrict__ drow = jb.dt + (size_t)q * ldt;
-  const float *__restrict__ nB = jb.nB;
+  const float *__restrict__ nB = jb.nB;     // 16-byte aligned, readable up to the next multiple of 4 rows
   const float naq = jb.nA[q];
-  volatile int *list = s_list[wave];
+  volatile int *list = lds.list[wave];
+  // the query row goes to LDS once (one coalesced 1 KiB load per wave); the re-score loops read it back with broadcast
+  // ds_read_b128, which are counted apart from the global loads of the train rows they keep in flight
+  ((float4 *)lds.a[wave])[lane] = ((const float4 *)(A + (size_t)q * MATCH_D))[lane];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const float4 *a4 = (const float4 *)lds.a[wave];
+  MatchBest best{__builtin_inff(), __builtin_inff(), -1, -1};
+  int head = 0, tail = 0;   // wave-uniform positions in the candidate queue
 
-  // ---- pass 1
-  float u1 = __builtin_inff(), u2 = __builtin_inff();
-  for (int c0 = 0; c0 < nb; c0 += 256) {
-    const int t = c0 + lane * 4;
-    float dv[4], ev[4];
-    if (t + 3 < nb) {
-      const float4 d4 = *(const float4 *)(drow + t);
-      dv[0] = d4.x; dv[1] = d4.y; dv[2] = d4.z; dv[3] = d4.w;
+  // one chunk = 256 columns, 4 consecutive ones per lane; columns beyond nb never qualify
+  auto load_chunk = [&](int t, f32x4 &dv, f32x4 &ev) __attribute__((always_inline)) {
+    if (t < nb) { dv = *(const f32x4 *)(drow + t); ev = *(const f32x4 *)(nB + t); }
+  };
+  auto wave_second_smallest = [&](MatchTwo two) __attribute__((always_inline)) {
+    float u1 = two.u1, u2 = two.u2;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ev[e] = nB[t + e];
-    } else {
+    for (int o = 1; o < 64; o <<= 1) {
+      const float o1 = __shfl_xor(u1, o), o2 = __shfl_xor(u2, o);
+      const float hi = fmaxf(u1, o1);
+      u1 = fminf(u1, o1);
+      u2 = fminf(hi, fminf(u2, o2));
+    }
+    return u2;   // +inf when the row has fewer than two columns: everything is a candidate
+  };
+
+  if constexpr (NCH > 0) {
+    f32x4 dv[NCH], ev[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      dv[c] = f32x4{0.f, 0.f, 0.f, 0.f}; ev[c] = dv[c];
+      load_chunk(c * 256 + lane * 4, dv[c], ev[c]);
+    }
+    float lo[NCH][4];
+    MatchTwo two{__builtin_inff(), __builtin_inff()};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        dv[e] = (t + e < nb) ? drow[t + e] : __builtin_inff();
-        ev[e] = (t + e < nb) ? nB[t + e] : 0.f;
+        const bool in = c * 256 + lane * 4 + e < nb;
+        const float err = err_rel * (naq + ev[c][e]);
+        two = match_two_smallest(in ? dv[c][e] + err : __builtin_inff(), two);
+        lo[c][e] = in ? dv[c][e] - err : __builtin_inff();
       }
     }
+    const float thr = wave_second_smallest(two);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float up = dv[e] + err_rel * (naq + ev[e]);
-      if (up < u1) { u2 = u1; u1 = up; } else if (up < u2) u2 = up;
-    }
-  }
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {   // merge the lanes' two smallest
-    const float o1 = __shfl_xor(u1, o), o2 = __shfl_xor(u2, o);
-    const float lo = fminf(u1, o1), hi = fmaxf(u1, o1);
-    u2 = fminf(hi, fminf(u2, o2));
-    u1 = lo;
-  }
-  float thr = u2;   // +inf when the row has fewer than two columns: everything is a candidate
-
-  // ---- pass 2
-  // the query row goes to LDS once (one coalesced 1 KiB load per wave); the re-score loop reads it back with broadcast
-  // ds_read_b128, which are counted apart from the global loads of the train rows it keeps in flight
-  ((float4 *)s_a[wave])[lane] = ((const float4 *)(A + (size_t)q * MATCH_D))[lane];
-  const float4 *a4 = (const float4 *)s_a[wave];
-  float d0 = __builtin_inff(), d1 = __builtin_inff();
-  int i0 = -1, i1 = -1;
-  int head = 0, tail = 0;   // wave-uniform positions in the candidate queue (a ring of MATCH_LIST entries)
-  const int nchunks = (nb + 255) >> 8;
-  for (int step = 0; step <= nchunks; ++step) {
-    const bool last = step == nchunks;
-    if (!last) {
-      const int t = step * 256 + lane * 4;
-      float dv[4], ev[4];
-      if (t + 3 < nb) {
-        const float4 d4 = *(const float4 *)(drow + t);
-        dv[0] = d4.x; dv[1] = d4.y; dv[2] = d4.z; dv[3] = d4.w;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ev[e] = nB[t + e];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          dv[e] = (t + e < nb) ? drow[t + e] : __builtin_inff();
-          ev[e] = (t + e < nb) ? nB[t + e] : 0.f;
-        }
-      }
+    for (int c = 0; c < NCH; ++c)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const bool cand = (t + e < nb) && (dv[e] - err_rel * (naq + ev[e]) <= thr);
+        const bool cand = (c * 256 + lane * 4 + e < nb) && lo[c][e] <= thr;
         const unsigned long long mask = __ballot(cand);
-        if (cand) list[(tail + __popcll(mask & ((1ull << lane) - 1ull))) & (MATCH_LIST - 1)] = t + e;
+        if (cand) list[tail + __popcll(mask & ((1ull << lane) - 1ull))] = c * 256 + lane * 4 + e;
         tail += __popcll(mask);
       }
-    }
-    // re-score the queue 64 entries at a time (whatever is left after the last chunk)
-    while (tail - head >= 64 || (last && tail > head)) {
+    while (tail > head) {
       const int n = min(64, tail - head);
-      int idx = (lane < n) ? list[(head + lane) & (MATCH_LIST - 1)] : -1;
+      best = match_score_batch<LIST>(list, head, n, B, a4, lds.b[wave], lane, best);
       head += n;
-      // the canonical sum is one dependent chain of 256 additions per row; the train row's 1 KiB streams through two
-      // register blocks of 32 floats so that the loads of block i + 1 are in flight while block i is summed (lanes
-      // without a candidate re-read row 0 and are ignored)
-      const float4 *b4 = (const float4 *)(B + (size_t)max(idx, 0) * MATCH_D);
-      float4 cur[8], nxt[8];
+    }
+  } else {
+    MatchTwo two{__builtin_inff(), __builtin_inff()};
+    for (int c0 = 0; c0 < nb; c0 += 256) {
+      const int t = c0 + lane * 4;
+      f32x4 dv = {0.f, 0.f, 0.f, 0.f}, ev = dv;
+      load_chunk(t, dv, ev);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) cur[i] = b4[i];
-      float s = 0.f;
-#pragma unroll 1
-      for (int blk = 0; blk < MATCH_D / 32; ++blk) {
-        if (blk + 1 < MATCH_D / 32) {
+      for (int e = 0; e < 4; ++e) two = match_two_smallest(t + e < nb ? dv[e] + err_rel * (naq + ev[e]) : __builtin_inff(), two);
+    }
+    float thr = wave_second_smallest(two);
+    const int nchunks = (nb + 255) >> 8;
+    for (int step = 0; step <= nchunks; ++step) {
+      const bool last = step == nchunks;
+      if (!last) {
+        const int t = step * 256 + lane * 4;
+        f32x4 dv = {0.f, 0.f, 0.f, 0.f}, ev = dv;
+        load_chunk(t, dv, ev);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) nxt[i] = b4[(blk + 1) * 8 + i];
+        for (int e = 0; e < 4; ++e) {
+          const bool cand = (t + e < nb) && (dv[e] - err_rel * (naq + ev[e]) <= thr);
+          const unsigned long long mask = __ballot(cand);
+          if (cand) list[(tail + __popcll(mask & ((1ull << lane) - 1ull))) & (LIST - 1)] = t + e;
+          tail += __popcll(mask);
         }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float4 av = a4[blk * 8 + i];
-          const float4 bv = cur[i];
-          float t;
-          t = sub_rn(av.x, bv.x); s = add_rn(s, mul_rn(t, t));
-          t = sub_rn(av.y, bv.y); s = add_rn(s, mul_rn(t, t));
-          t = sub_rn(av.z, bv.z); s = add_rn(s, mul_rn(t, t));
-          t = sub_rn(av.w, bv.w); s = add_rn(s, mul_rn(t, t));
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
       }
-      float d = (idx >= 0) ? s : __builtin_inff();
-      // two rounds of wave arg-min under (distance, index) order merge the batch into the best two
-#pragma unroll
-      for (int round = 0; round < 2; ++round) {
-        float md = d;
-        int mi = (idx >= 0) ? idx : 0x7FFFFFFF;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-          const float od = __shfl_xor(md, o);
-          const int oi = __shfl_xor(mi, o);
-          if (od < md || (od == md && oi < mi)) { md = od; mi = oi; }
-        }
-        if (mi == 0x7FFFFFFF) break;
-        if (i0 < 0 || md < d0 || (md == d0 && mi < i0)) {
-          d1 = d0; i1 = i0; d0 = md; i0 = mi;
-        } else if (i1 < 0 || md < d1 || (md == d1 && mi < i1)) {
-          d1 = md; i1 = mi;
-        }
-        if (idx == mi) { idx = -1; d = __builtin_inff(); }  // the winner leaves before the second round
+      while (tail - head >= 64 || (last && tail > head)) {
+        const int n = min(64, tail - head);
+        best = match_score_batch<LIST>(list, head, n, B, a4, lds.b[wave], lane, best);
+        head += n;
+        if (best.i1 >= 0) thr = fminf(thr, best.d1);   // no row above the second-best canonical distance can enter any more
       }
-      if (i1 >= 0) thr = fminf(thr, d1);     // no row above the second-best canonical distance can enter any more
     }
   }
 
+  const float d0 = best.d0, d1 = best.d1;
+  const int i0 = best.i0, i1 = best.i1;
   if (lane == 0) {
     jb.best_d2[2 * q] = d0; jb.best_d2[2 * q + 1] = d1;
     jb.best_idx[2 * q] = i0; jb.best_idx[2 * q + 1] = i1;

@@ -993,8 +993,8 @@ int ensure_match(spvo_ctx *c, int na, int nb) {
   if ((rc = dev_alloc(c, &c->d_match_out, (size_t)2 * cap))) return rc;
   for (int k = 0; k < 2; ++k) {
     MatchScratch &m = c->ms[k];
-    if ((rc = dev_alloc(c, &m.d_na, cap))) return rc;
-    if ((rc = dev_alloc(c, &m.d_nb, cap))) return rc;
+    if ((rc = dev_alloc(c, &m.d_na, cap + 4))) return rc;   // K12b reads the norms four at a time
+    if ((rc = dev_alloc(c, &m.d_nb, cap + 4))) return rc;
     if ((rc = dev_alloc(c, &m.d_best_d2, (size_t)cap * 2))) return rc;
     if ((rc = dev_alloc(c, &m.d_dt, (size_t)cap * match_ldt(cap)))) return rc;
     if ((rc = dev_alloc(c, &m.d_best_idx, (size_t)cap * 2))) return rc;
@@ -1067,18 +1067,21 @@ int enqueue_matches(spvo_ctx *c, const MatchReq *req_in, int njobs, int selector
   static bool attr[64] = {};
   if (!attr[c->cfg.device & 63]) {
     HIP_TRY(c, hipFuncSetAttribute((const void *)match_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(c, hipFuncSetAttribute((const void *)match_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr[c->cfg.device & 63] = true;
   }
   {
     ScopedStage sg(c, stage_id(c, "match_gemm"), fl, 4.0 * (na_max + nb_max) * MATCH_D * njobs);
-    if (c->match_fp8) hipLaunchKernelGGL(match_gemm_kernel<true>, dim3(groups, (na_max + MATCH_QT - 1) / MATCH_QT, njobs), dim3(256), 0, c->post, jobs, ldt);
+    if (c->match_fp8) hipLaunchKernelGGL(match_gemm_kernel<true>, dim3(groups, (na_max + MATCH_QT - 1) / MATCH_QT, njobs), dim3(256), MATCH_LDS_BYTES_FP8, c->post, jobs, ldt);
     else hipLaunchKernelGGL(match_gemm_kernel<false>, dim3(groups, (na_max + MATCH_QT - 1) / MATCH_QT, njobs), dim3(256), lds, c->post, jobs, ldt);
   }
   {
     ScopedStage sr(c, stage_id(c, "match_rerank"));
-    hipLaunchKernelGGL(match_rerank_kernel, dim3((na_max + 3) / 4, njobs), dim3(256), 0, c->post, jobs, ldt,
-                       c->match_fp8 ? MATCH_ERR_REL_FP8 : MATCH_ERR_REL, selector, cross_check, ratio);
+    const float err = c->match_fp8 ? MATCH_ERR_REL_FP8 : MATCH_ERR_REL;
+    const dim3 gr((na_max + 3) / 4, njobs);
+    // rows of up to 1024 columns stay in registers between the two passes of the re-rank (8 chunks for 2048 columns
+    // measured 2.4x SLOWER than the chunked form: 232 registers, 70 KB of LDS)
+    if (nb_max <= 1024) hipLaunchKernelGGL(match_rerank_kernel<4>, gr, dim3(256), sizeof(MatchRerankLds<4>), c->post, jobs, ldt, err, selector, cross_check, ratio);
+    else hipLaunchKernelGGL(match_rerank_kernel<0>, gr, dim3(256), sizeof(MatchRerankLds<0>), c->post, jobs, ldt, err, selector, cross_check, ratio);
   }
   if (swap) hipLaunchKernelGGL(match_select_cross_kernel, dim3((nb_max + 255) / 256, njobs), dim3(256), 0, c->post, jobs);
   HIP_TRY(c, hipGetLastError());
@@ -1259,7 +1262,7 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
       if ((rc = dev_alloc(c, &c->slots[i].d_xyf, (size_t)cap * 2))) break;
       if ((rc = dev_alloc(c, &c->slots[i].d_desc, (size_t)cap * 256))) break;
       if ((rc = dev_alloc(c, &c->slots[i].d_n, 1))) break;
-      if ((rc = dev_alloc(c, &c->slots[i].d_sqn, cap))) break;
+      if ((rc = dev_alloc(c, &c->slots[i].d_sqn, cap + 4))) break;   // K12b reads the norms four at a time
     }
     if (rc) break;
     if ((rc = dev_alloc(c, &c->d_xy_tmp, (size_t)cap * 2))) break;

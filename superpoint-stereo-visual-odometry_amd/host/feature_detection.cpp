@@ -12,12 +12,13 @@
 #include <cstring>
 
 // ------------------------------------------------------------------------- tf2lite
+#ifndef SPVO_USE_OPENCV
 namespace tf2lite {
-double Vector3::length() const { return std::sqrt(x * x + y * y + z * z); }
+double Vector3::length() const { return std::sqrt(x() * x() + y() * y() + z() * z()); }
 
 static void rotate(const Quaternion &q, const double v[3], double out[3]) {
   // unit quaternion rotation, same polynomial as Eigen's toRotationMatrix
-  const double x = q.x, y = q.y, z = q.z, w = q.w;
+  const double x = q.x(), y = q.y(), z = q.z(), w = q.w();
   const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
   const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x;
   const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
@@ -28,28 +29,29 @@ static void rotate(const Quaternion &q, const double v[3], double out[3]) {
 
 Transform Transform::inverse() const {
   Transform r;
-  const double n = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-  r.q = Quaternion{-q.x / n, -q.y / n, -q.z / n, q.w / n};
-  const double v[3] = {t.x, t.y, t.z};
+  const double n = std::sqrt(q.x() * q.x() + q.y() * q.y() + q.z() * q.z() + q.w() * q.w());
+  r.q = Quaternion(-q.x() / n, -q.y() / n, -q.z() / n, q.w() / n);
+  const double v[3] = {t.x(), t.y(), t.z()};
   double o[3];
   rotate(r.q, v, o);
-  r.t = Vector3{-o[0], -o[1], -o[2]};
+  r.t = Vector3(-o[0], -o[1], -o[2]);
   return r;
 }
 
 Transform Transform::operator*(const Transform &o) const {
   Transform r;
-  r.q.x = q.w * o.q.x + q.x * o.q.w + q.y * o.q.z - q.z * o.q.y;
-  r.q.y = q.w * o.q.y - q.x * o.q.z + q.y * o.q.w + q.z * o.q.x;
-  r.q.z = q.w * o.q.z + q.x * o.q.y - q.y * o.q.x + q.z * o.q.w;
-  r.q.w = q.w * o.q.w - q.x * o.q.x - q.y * o.q.y - q.z * o.q.z;
-  const double v[3] = {o.t.x, o.t.y, o.t.z};
+  r.q = Quaternion(q.w() * o.q.x() + q.x() * o.q.w() + q.y() * o.q.z() - q.z() * o.q.y(),
+                   q.w() * o.q.y() - q.x() * o.q.z() + q.y() * o.q.w() + q.z() * o.q.x(),
+                   q.w() * o.q.z() + q.x() * o.q.y() - q.y() * o.q.x() + q.z() * o.q.w(),
+                   q.w() * o.q.w() - q.x() * o.q.x() - q.y() * o.q.y() - q.z() * o.q.z());
+  const double v[3] = {o.t.x(), o.t.y(), o.t.z()};
   double rv[3];
   rotate(q, v, rv);
-  r.t = Vector3{rv[0] + t.x, rv[1] + t.y, rv[2] + t.z};
+  r.t = Vector3(rv[0] + t.x(), rv[1] + t.y(), rv[2] + t.z());
   return r;
 }
 }  // namespace tf2lite
+#endif
 
 // ------------------------------------------------------------------------- logging
 void FeatureFrontEnd::logError(const std::string &msg) {
@@ -64,17 +66,59 @@ void FeatureFrontEnd::logInfo(const std::string &msg) const {
 // ------------------------------------------------------------------------- base.cpp:10-33
 void FeatureFrontEnd::initMatcher() {
   if (matcher_type_ == MatcherType::BF) {
-    if (descriptor_type_ != DescriptorType::SIFT && descriptor_type_ != DescriptorType::SuperPoint) {
-      // NORM_HAMMING descriptors belong to the classic CPU baseline (classic.cpp), not to this path
-      logError("[initMatcher] only NORM_L2 descriptors (SuperPoint/SIFT) are implemented on the GPU path");
-      return;
-    }
     // cv::BFMatcher::create(norm_type, cross_check_ & (selector_type_ != KNN))   base.cpp:27-28
     matcher_cross_check_ = cross_check_ && (selector_type_ != SelectorType::KNN);
+    if (descriptor_type_ != DescriptorType::SIFT && descriptor_type_ != DescriptorType::SuperPoint) {
+#ifdef SPVO_USE_OPENCV
+      // binary descriptors of the classic CPU baseline (ORB / BRISK / AKAZE ...): NORM_HAMMING on the host through OpenCV
+      matcher_ = cv::BFMatcher::create(cv::NORM_HAMMING, matcher_cross_check_);
+      matcher_ready_ = true;
+#else
+      logError("[initMatcher] only NORM_L2 descriptors (SuperPoint/SIFT) are implemented on the GPU path; NORM_HAMMING needs a build with SPVO_USE_OPENCV");
+#endif
+      return;
+    }
     matcher_ready_ = true;
   } else {
     logError("[initMatcher] FLANN matcher is not implemented on the GPU path (base.cpp:29-32); use BF");
   }
+}
+
+bool FeatureFrontEnd::ensureContext() {
+  if (ctx_) return true;
+  spvo_config cfg;
+  spvo_default_config(&cfg);
+  if (const char *dev = std::getenv("SPVO_DEVICE")) cfg.device = std::atoi(dev);
+  if (input_height_ > 0 && input_width_ > 0) {
+    cfg.net_height = (input_height_ + 7) / 8 * 8;   // only the pre-processing geometry matters to a context without an engine
+    cfg.net_width = (input_width_ + 7) / 8 * 8;
+  }
+  if (const char *bc = std::getenv("SPVO_BUG_COMPAT_P")) cfg.bug_compat_p = std::atoi(bc);
+  if (spvo_create(&cfg, &ctx_) != SPVO_OK) {
+    logError(std::string("spvo_create: ") + spvo_last_error(nullptr));
+    ctx_ = nullptr;
+    return false;
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------------- base.cpp:68-121
+void FeatureFrontEnd::preprocessImageImpl(cv::Mat &img, cv::Mat &projection_matrix) {
+  if (img.type() != CV_8UC1 || projection_matrix.type() != CV_64FC1 || projection_matrix.rows != 3 || projection_matrix.cols != 4) {
+    logError("preprocessImageImpl: expected a CV_8UC1 image and a 3x4 CV_64F projection matrix (node.cpp:91,163-168)");
+    return;
+  }
+  if (input_height_ <= 0 || input_width_ <= 0 || input_height_ % 8 || input_width_ % 8) {
+    logError("preprocessImageImpl: the target size must be a positive multiple of 8 (hpp:296)");
+    return;
+  }
+  if (!ensureContext()) return;
+  cv::Mat out(input_height_, input_width_, CV_8UC1);
+  if (spvo_preprocess(ctx_, img.data, img.rows, img.cols, (size_t)img.step, projection_matrix.ptr<double>(0), out.data) != SPVO_OK) {
+    logError(std::string("spvo_preprocess: ") + spvo_last_error(ctx_));
+    return;
+  }
+  img = out;   // the reference crops and resizes the caller's image in place (base.cpp:89,105,115)
 }
 
 // ------------------------------------------------------------------------- base.cpp:35-66
@@ -100,10 +144,6 @@ void FeatureFrontEnd::clearLagecyData() {
 
 // ------------------------------------------------------------------------- base.cpp:434-500
 void FeatureFrontEnd::matchDescriptors(const MatchType match_type) {
-  if (!ctx_ || !matcher_ready_) {
-    logError("matchDescriptors: front end not initialised");
-    return;
-  }
   const int p0 = match_type_to_positions[match_type].first, p1 = match_type_to_positions[match_type].second;
   const int n_dq = (int)keypoints_dq.size();
   if (n_dq + p0 < 0 || n_dq + p1 < 0) {
@@ -111,6 +151,30 @@ void FeatureFrontEnd::matchDescriptors(const MatchType match_type) {
     return;
   }
   const std::vector<cv::KeyPoint> &keypoints0 = keypoints_dq.end()[p0];
+#ifdef SPVO_USE_OPENCV
+  if (matcher_) {   // classic front end: descriptors are host matrices, the search is OpenCV's (base.cpp:462-473)
+    std::vector<cv::DMatch> &out = cv_DMatches_list[match_type];
+    out.clear();
+    const cv::Mat &query = descriptors_dq.end()[p0], &train_desc = descriptors_dq.end()[p1];
+    if (selector_type_ == SelectorType::NN) {
+      matcher_->match(query, train_desc, out);
+    } else {
+      std::vector<std::vector<cv::DMatch>> two;
+      matcher_->knnMatch(query, train_desc, two, 2);
+      for (const auto &pair : two)
+        if (pair.size() >= 2 && pair[0].distance < knn_threshold_ * pair[1].distance) out.push_back(pair[0]);
+    }
+    if (match_type == MatchType::CURR_LEFT_CURR_RIGHT) maps_of_indices[MatchType::PREV_LEFT_PREV_RIGHT] = maps_of_indices[MatchType::CURR_LEFT_CURR_RIGHT];
+    std::vector<int> &index_map = maps_of_indices.at(match_type);
+    index_map.assign(keypoints0.size(), -1);
+    for (const cv::DMatch &m : out) index_map.at(m.queryIdx) = m.trainIdx;
+    return;
+  }
+#endif
+  if (!ctx_ || !matcher_ready_ || slots_dq_.size() != keypoints_dq.size()) {
+    logError("matchDescriptors: front end not initialised");
+    return;
+  }
   const int slot0 = slots_dq_.end()[p0], slot1 = slots_dq_.end()[p1];
   if (descriptors_dq.end()[p0].rows < 10) std::fprintf(stderr, "[ WARN] descriptors0.rows == %d < 10\n", descriptors_dq.end()[p0].rows);
   if (descriptors_dq.end()[p1].rows < 10) std::fprintf(stderr, "[ WARN] descriptors1.rows == %d < 10\n", descriptors_dq.end()[p1].rows);
@@ -147,7 +211,7 @@ void FeatureFrontEnd::matchDescriptors(const MatchType match_type) {
 
 // ------------------------------------------------------------------------- base.cpp:125-399
 void FeatureFrontEnd::solveStereoOdometry(tf2::Transform &cam0_curr_T_cam0_prev) {
-  if (!ctx_ || keypoints_dq.size() < 4) {
+  if (keypoints_dq.size() < 4 || !ensureContext()) {
     logError("solveStereoOdometry needs two stereo frames");
     return;
   }
@@ -237,8 +301,8 @@ void FeatureFrontEnd::solveStereoOdometry(tf2::Transform &cam0_curr_T_cam0_prev)
   const double t_opt[3] = {so.t[0], so.t[1], so.t[2]};
 
   tf2::Transform cam0_prev_T_cam0_curr;
-  cam0_prev_T_cam0_curr.setRotation(tf2::Quaternion{q_opt[0], q_opt[1], q_opt[2], q_opt[3]});
-  cam0_prev_T_cam0_curr.setOrigin(tf2::Vector3{t_opt[0], t_opt[1], t_opt[2]});
+  cam0_prev_T_cam0_curr.setRotation(tf2::Quaternion(q_opt[0], q_opt[1], q_opt[2], q_opt[3]));
+  cam0_prev_T_cam0_curr.setOrigin(tf2::Vector3(t_opt[0], t_opt[1], t_opt[2]));
   cam0_curr_T_cam0_prev = cam0_prev_T_cam0_curr.inverse();
 
   if (refinement_degree_ >= 3) {  // base.cpp:388-394
@@ -259,6 +323,98 @@ cv::Mat FeatureFrontEnd::visualizeInliers(const ImagePosition image_position) {
   if (images_dq.empty()) return cv::Mat();
   return images_dq.end()[image_position].clone();
 }
+
+// ------------------------------------------------------------------------- classic front end (classic.cpp)
+// The reference's constructor hands `stereo_threshold` to the base class a second time in the place of `min_disparity`
+// (hpp:203-206), so the classic launch file's min_disparity is never used; kept, because the stereo gate of
+// solveStereoOdometry (base.cpp:169-172) then behaves as the reference's does.
+ClassicFeatureFrontEnd::ClassicFeatureFrontEnd()
+    : ClassicFeatureFrontEnd(DetectorType::ShiTomasi, DescriptorType::ORB, MatcherType::BF, SelectorType::NN, true, 2.0f, 1.0f, 4, true, 120, 392) {}
+
+ClassicFeatureFrontEnd::ClassicFeatureFrontEnd(const DetectorType detector_type, const DescriptorType descriptor_type, const MatcherType matcher_type,
+                                               const SelectorType selector_type, const bool cross_check, const float stereo_threshold,
+                                               const float /*min_disparity*/, const int refinement_degree, const bool verbose, const int input_height,
+                                               const int input_width)
+    : FeatureFrontEnd(detector_type, descriptor_type, matcher_type, selector_type, cross_check, stereo_threshold, stereo_threshold, refinement_degree,
+                      verbose, input_height, input_width) {
+  initDetector();
+  initDescriptor();
+  initMatcher();
+}
+
+ClassicFeatureFrontEnd::~ClassicFeatureFrontEnd() {
+  if (ctx_) spvo_destroy(ctx_);
+  ctx_ = nullptr;
+}
+
+#ifdef SPVO_USE_OPENCV
+bool ClassicFeatureFrontEnd::available() { return true; }
+
+void ClassicFeatureFrontEnd::initDetector() {   // parameters: classic.cpp:7-56
+  if (detector_type_ == DetectorType::ORB) detector_ = cv::ORB::create(2000, 1.2f, 8, 31, 0, 2, cv::ORB::FAST_SCORE, 31, 20);
+  else if (detector_type_ == DetectorType::BRISK) detector_ = cv::BRISK::create();
+  else if (detector_type_ == DetectorType::AKAZE) detector_ = cv::AKAZE::create();
+  else if (detector_type_ == DetectorType::SIFT) detector_ = cv::SIFT::create();
+  else if (detector_type_ == DetectorType::FAST) detector_ = cv::FastFeatureDetector::create(10, true);
+  else if (detector_type_ == DetectorType::ShiTomasi) detector_ = cv::GFTTDetector::create(1000, 0.03, 7.5, 5, false, 0.04);
+  else logError("[initDetector] Detector is not implemented");
+}
+
+void ClassicFeatureFrontEnd::initDescriptor() {   // classic.cpp:58-79
+  if (descriptor_type_ == DescriptorType::ORB) extractor_ = cv::ORB::create();
+  else if (descriptor_type_ == DescriptorType::BRISK) extractor_ = cv::BRISK::create(30, 3, 1.0f);
+  else if (descriptor_type_ == DescriptorType::AKAZE) extractor_ = cv::AKAZE::create();
+  else if (descriptor_type_ == DescriptorType::SIFT) extractor_ = cv::SIFT::create();
+  else logError("[initDescriptor] Decscriptor is not implemented");
+}
+
+std::vector<cv::KeyPoint> ClassicFeatureFrontEnd::detectKeypoints(const cv::Mat &img) {
+  std::vector<cv::KeyPoint> keypoints;
+  if (detector_) detector_->detect(img, keypoints);
+  return keypoints;
+}
+
+cv::Mat ClassicFeatureFrontEnd::describeKeypoints(std::vector<cv::KeyPoint> &keypoints, const cv::Mat &img) {
+  cv::Mat descriptors;
+  if (extractor_) extractor_->compute(img, keypoints, descriptors);
+  return descriptors;
+}
+
+void ClassicFeatureFrontEnd::addStereoImagePair(cv::Mat &img_l, cv::Mat &img_r, const cv::Mat &projection_matrix_l, const cv::Mat &projection_matrix_r) {
+  if (img_l.rows != img_r.rows || img_l.cols != img_r.cols) {
+    logError("input images shape doesn't match!");
+    return;
+  }
+  projection_matrix_l_ = projection_matrix_l.clone();
+  projection_matrix_r_ = projection_matrix_r.clone();
+  if (input_height_ > 0 && input_width_ > 0) {   // 0 = native resolution (launch/visual_odometry_classic.launch)
+    preprocessImageImpl(img_l, projection_matrix_l_);
+    preprocessImageImpl(img_r, projection_matrix_r_);
+  }
+  cv::Mat *imgs[2] = {&img_l, &img_r};
+  for (cv::Mat *im : imgs) {
+    images_dq.push_back(*im);
+    keypoints_dq.push_back(detectKeypoints(*im));
+    descriptors_dq.push_back(describeKeypoints(keypoints_dq.back(), *im));
+  }
+  if (verbose_) logInfo(std::to_string(keypoints_dq.end()[-2].size()) + ", " + std::to_string(keypoints_dq.end()[-1].size()) + " keypoints for img_l and img_r");
+  while (images_dq.size() > NUM_IMAGE_POSITIONS) {
+    images_dq.pop_front();
+    keypoints_dq.pop_front();
+    descriptors_dq.pop_front();
+  }
+}
+#else
+bool ClassicFeatureFrontEnd::available() { return false; }
+void ClassicFeatureFrontEnd::initDetector() {}
+void ClassicFeatureFrontEnd::initDescriptor() {}
+std::vector<cv::KeyPoint> ClassicFeatureFrontEnd::detectKeypoints(const cv::Mat &) { return {}; }
+cv::Mat ClassicFeatureFrontEnd::describeKeypoints(std::vector<cv::KeyPoint> &, const cv::Mat &) { return cv::Mat(); }
+void ClassicFeatureFrontEnd::addStereoImagePair(cv::Mat &, cv::Mat &, const cv::Mat &, const cv::Mat &) {
+  logError("ClassicFeatureFrontEnd: the classic detectors (ORB, BRISK, AKAZE, SIFT, FAST, ShiTomasi; classic.cpp:7-79) are OpenCV "
+           "features2d calls -- this library was built without SPVO_USE_OPENCV, the CPU baseline cannot run");
+}
+#endif
 
 // ------------------------------------------------------------------------- SuperPoint front end
 static std::string g_models_dir;
@@ -346,8 +502,8 @@ void SuperPointFeatureFrontEnd::addStereoImagePair(cv::Mat &img_l, cv::Mat &img_
     logError("addStereoImagePair: no engine loaded");
     return;
   }
-  if (img_l.depth != cvlite::CV_8U || img_r.depth != cvlite::CV_8U || img_l.rows != img_r.rows || img_l.cols != img_r.cols ||
-      img_l.step != img_r.step || projection_matrix_l.depth != cvlite::CV_64F || projection_matrix_r.depth != cvlite::CV_64F ||
+  if (img_l.type() != CV_8UC1 || img_r.type() != CV_8UC1 || img_l.rows != img_r.rows || img_l.cols != img_r.cols ||
+      (size_t)img_l.step != (size_t)img_r.step || projection_matrix_l.type() != CV_64FC1 || projection_matrix_r.type() != CV_64FC1 ||
       projection_matrix_l.rows != 3 || projection_matrix_l.cols != 4) {
     logError("addStereoImagePair: expected two equal-sized CV_8UC1 images and 3x4 CV_64F projection matrices (node.cpp:91,163-168)");
     return;
@@ -359,8 +515,8 @@ void SuperPointFeatureFrontEnd::addStereoImagePair(cv::Mat &img_l, cv::Mat &img_
   int slot_l, slot_r;
   pickSlots(&slot_l, &slot_r);
   spvo_features fl{0, xy_buf_[0].data(), desc_buf_[0].data()}, fr{0, xy_buf_[1].data(), desc_buf_[1].data()};
-  cv::Mat res_l(input_height_, input_width_, cvlite::CV_8U), res_r(input_height_, input_width_, cvlite::CV_8U);
-  const int rc = spvo_detect(ctx_, img_l.data, img_r.data, img_l.rows, img_l.cols, img_l.step, projection_matrix_l_.ptr<double>(0),
+  cv::Mat res_l(input_height_, input_width_, CV_8UC1), res_r(input_height_, input_width_, CV_8UC1);
+  const int rc = spvo_detect(ctx_, img_l.data, img_r.data, img_l.rows, img_l.cols, (size_t)img_l.step, projection_matrix_l_.ptr<double>(0),
                              projection_matrix_r_.ptr<double>(0), slot_l, slot_r, &fl, &fr, res_l.data, res_r.data);
   if (rc != SPVO_OK) {
     logError(std::string("spvo_detect: ") + spvo_last_error(ctx_));
@@ -383,7 +539,7 @@ void SuperPointFeatureFrontEnd::addStereoImagePairDevice(const void *d_img_l, co
     logError("addStereoImagePairDevice: no engine loaded");
     return;
   }
-  if (projection_matrix_l.depth != cvlite::CV_64F || projection_matrix_r.depth != cvlite::CV_64F || projection_matrix_l.rows != 3 ||
+  if (projection_matrix_l.type() != CV_64FC1 || projection_matrix_r.type() != CV_64FC1 || projection_matrix_l.rows != 3 ||
       projection_matrix_l.cols != 4) {
     logError("addStereoImagePairDevice: expected 3x4 CV_64F projection matrices");
     return;
@@ -456,16 +612,14 @@ void SuperPointFeatureFrontEnd::pushFeatures(const spvo_features *f[2], const cv
     images_dq.push_back(images[i]->empty() ? cv::Mat() : images[i]->clone());  // nn.cpp:154
     std::vector<cv::KeyPoint> kps;
     kps.reserve(f[i]->n);
-    for (int k = 0; k < f[i]->n; ++k) kps.emplace_back(cv::Point2f{f[i]->xy[2 * k], f[i]->xy[2 * k + 1]}, 1.f);  // nn.cpp:243
+    for (int k = 0; k < f[i]->n; ++k) kps.emplace_back(cv::Point2f(f[i]->xy[2 * k], f[i]->xy[2 * k + 1]), 1.f);  // nn.cpp:243
     keypoints_dq.push_back(std::move(kps));
     cv::Mat d;
     if (host_descriptors) {
-      d.create(f[i]->n, output_desc_channel_, cvlite::CV_32F);
+      d.create(f[i]->n, output_desc_channel_, CV_32FC1);
       if (f[i]->n) std::memcpy(d.data, f[i]->desc, (size_t)f[i]->n * output_desc_channel_ * sizeof(float));
     } else {
-      d.rows = f[i]->n;  // header only: the descriptors live in the device slot
-      d.cols = 0;
-      d.depth = cvlite::CV_32F;
+      d.create(f[i]->n, 0, CV_32FC1);   // n x 0 header: the descriptors live in the device slot
     }
     descriptors_dq.push_back(d);
     slots_dq_.push_back(slots[i]);

@@ -7,8 +7,9 @@
 //   * NvInfer.h / cuda_runtime_api.h / Eigen thread pool members are gone; every heavy call
 //     goes to the C ABI in include/spvo.h (hand-written gfx950 kernels);
 //   * where OpenCV / tf2 / ROS headers are absent (this build image), the few types
-//     the interface mentions are the minimal PODs below (`cvlite`, `tf2lite`), with the same
-//     field names the node touches; INTEGRATION.md shows the adapter for a real ROS build.
+//     the interface mentions are the stand-ins below (`cvlite`, `tf2lite`), API-compatible with
+//     the subset of cv:: / tf2:: that the front end and the node use; a ROS build defines
+//     SPVO_USE_OPENCV and gets the real types.
 #pragma once
 
 #include <array>
@@ -22,39 +23,69 @@
 
 #include "../../include/spvo.h"
 
-// --------------------------------------------------------------------------- POD stand-ins
+// --------------------------------------------------------------------------- OpenCV / tf2 types
+// With SPVO_USE_OPENCV the interface is compiled against the real headers (a ROS build: INTEGRATION.md); without it
+// against the stand-ins below.  The stand-ins expose the SAME API subset the front end and the node use -- rows / cols /
+// data / step, depth(), type(), at<T>(), ptr<T>(), clone(), create(), the CV_8U / CV_32F / CV_64F codes; getRotation().x(),
+// getOrigin().length() ... -- so host/*.cpp is one source for both builds (tests/test_boundary_cpu.py compiles it both ways).
+#ifdef SPVO_USE_OPENCV
+#include <opencv2/core.hpp>
+#include <opencv2/features2d.hpp>
+#include <tf2/LinearMath/Transform.h>
+#else
+#ifndef CV_8U
+#define CV_8U 0
+#define CV_32F 5
+#define CV_64F 6
+#define CV_8UC1 CV_8U
+#define CV_32FC1 CV_32F
+#define CV_64FC1 CV_64F
+#endif
 namespace cvlite {
-enum { CV_8U = 0, CV_32F = 5, CV_64F = 6 };
-
-// minimal dense 2-D matrix with cv::Mat's field names (rows, cols, data, step)
-struct Mat {
-  int rows = 0, cols = 0, depth = CV_8U;
-  size_t step = 0;  // bytes per row
-  std::shared_ptr<std::vector<uint8_t>> buf;
+// dense single-channel 2-D matrix with the part of cv::Mat's API this interface touches
+class Mat {
+public:
+  struct MatStep {   // cv::Mat::step converts to size_t
+    size_t p = 0;
+    operator size_t() const { return p; }
+  };
+  int rows = 0, cols = 0;
   uint8_t *data = nullptr;
+  MatStep step;
 
   Mat() = default;
-  Mat(int r, int c, int d) { create(r, c, d); }
-  static size_t elem(int d) { return d == CV_8U ? 1 : d == CV_32F ? 4 : 8; }
-  void create(int r, int c, int d) {
-    rows = r; cols = c; depth = d; step = (size_t)c * elem(d);
-    buf = std::make_shared<std::vector<uint8_t>>((size_t)r * step, 0);
-    data = buf->data();
+  Mat(int r, int c, int type) { create(r, c, type); }
+  void create(int r, int c, int type) {
+    rows = r; cols = c; type_ = type; step.p = (size_t)c * elemSize();
+    buf_ = std::make_shared<std::vector<uint8_t>>((size_t)r * step.p, 0);
+    data = buf_->empty() ? nullptr : buf_->data();
   }
-  bool empty() const { return rows == 0 || cols == 0; }
+  int type() const { return type_; }
+  int depth() const { return type_; }   // one channel: type == depth
+  int channels() const { return 1; }
+  size_t elemSize() const { return type_ == CV_8U ? 1 : type_ == CV_32F ? 4 : 8; }
+  bool empty() const { return rows == 0 || cols == 0 || data == nullptr; }
   Mat clone() const {
-    Mat m(rows, cols, depth);
-    for (int r = 0; r < rows; ++r) std::copy(data + r * step, data + r * step + m.step, m.data + r * m.step);
+    Mat m(rows, cols, type_);
+    for (int r = 0; r < rows && m.step.p; ++r) std::copy(data + r * step.p, data + r * step.p + m.step.p, m.data + r * m.step.p);
     return m;
   }
   void release() { *this = Mat(); }
-  template <typename T> T &at(int r, int c) { return *reinterpret_cast<T *>(data + r * step + c * sizeof(T)); }
-  template <typename T> const T &at(int r, int c) const { return *reinterpret_cast<const T *>(data + r * step + c * sizeof(T)); }
-  template <typename T> T *ptr(int r) { return reinterpret_cast<T *>(data + r * step); }
-  template <typename T> const T *ptr(int r) const { return reinterpret_cast<const T *>(data + r * step); }
+  template <typename T> T &at(int r, int c) { return *reinterpret_cast<T *>(data + r * step.p + c * sizeof(T)); }
+  template <typename T> const T &at(int r, int c) const { return *reinterpret_cast<const T *>(data + r * step.p + c * sizeof(T)); }
+  template <typename T> T *ptr(int r = 0) { return reinterpret_cast<T *>(data + r * step.p); }
+  template <typename T> const T *ptr(int r = 0) const { return reinterpret_cast<const T *>(data + r * step.p); }
+
+private:
+  int type_ = CV_8U;
+  std::shared_ptr<std::vector<uint8_t>> buf_;
 };
 
-struct Point2f { float x = 0, y = 0; };
+struct Point2f {
+  float x = 0, y = 0;
+  Point2f() = default;
+  Point2f(float x_, float y_) : x(x_), y(y_) {}
+};
 struct KeyPoint {
   Point2f pt;
   float size = 0;
@@ -68,15 +99,33 @@ struct DMatch {
 }  // namespace cvlite
 
 namespace tf2lite {
-// rigid transform with tf2::Transform's accessors the node uses
-struct Quaternion { double x = 0, y = 0, z = 0, w = 1; };
-struct Vector3 {
-  double x = 0, y = 0, z = 0;
-  double length() const;
+// rigid transform with the accessors of tf2::Transform / tf2::Quaternion / tf2::Vector3 the node uses
+class Quaternion {
+public:
+  Quaternion() = default;
+  Quaternion(double x, double y, double z, double w) : v_{x, y, z, w} {}
+  double x() const { return v_[0]; }
+  double y() const { return v_[1]; }
+  double z() const { return v_[2]; }
+  double w() const { return v_[3]; }
+
+private:
+  double v_[4] = {0, 0, 0, 1};
 };
-struct Transform {
-  Quaternion q;
-  Vector3 t;
+class Vector3 {
+public:
+  Vector3() = default;
+  Vector3(double x, double y, double z) : v_{x, y, z} {}
+  double x() const { return v_[0]; }
+  double y() const { return v_[1]; }
+  double z() const { return v_[2]; }
+  double length() const;
+
+private:
+  double v_[3] = {0, 0, 0};
+};
+class Transform {
+public:
   void setRotation(const Quaternion &r) { q = r; }
   void setOrigin(const Vector3 &o) { t = o; }
   const Quaternion &getRotation() const { return q; }
@@ -84,13 +133,15 @@ struct Transform {
   Transform inverse() const;
   Transform operator*(const Transform &o) const;
   void setIdentity() { q = Quaternion(); t = Vector3(); }
+
+private:
+  Quaternion q;
+  Vector3 t;
 };
 }  // namespace tf2lite
-
-#ifndef SPVO_USE_OPENCV
 namespace cv = cvlite;
 namespace tf2 = tf2lite;
-#endif
+#endif  // SPVO_USE_OPENCV
 
 ///////////////////////////////////////////////////////////////////////////////////////
 /////////////////////////// Type and macro definitions (hpp:24-90) ////////////////////
@@ -143,6 +194,9 @@ public:
   virtual ~FeatureFrontEnd() {}
   void initMatcher();
   void clearLagecyData();
+  // base.cpp:68-121: centre-crop to the network aspect ratio, cv::resize(INTER_LINEAR), scale rows 0-1 of P -- on the
+  // GPU (spvo_preprocess).  `img` is replaced by the resized CV_8UC1 image, as the reference does in place.
+  void preprocessImageImpl(cv::Mat &img, cv::Mat &projection_matrix);
   virtual void addStereoImagePair(cv::Mat &img_l, cv::Mat &img_r, const cv::Mat &projection_matrix_l,
                                   const cv::Mat &projection_matrix_r) = 0;
   void matchDescriptors(const MatchType match_type);
@@ -183,9 +237,14 @@ protected:
   const int input_height_;
   const int input_width_;
 
-  // replaces cv::Ptr<cv::DescriptorMatcher> matcher_: the matcher lives behind the C ABI
+  // replaces cv::Ptr<cv::DescriptorMatcher> matcher_: for NORM_L2 descriptors the matcher lives behind the C ABI
   bool matcher_ready_ = false;
   bool matcher_cross_check_ = false;
+#ifdef SPVO_USE_OPENCV
+  cv::Ptr<cv::DescriptorMatcher> matcher_;   // NORM_HAMMING descriptors of the classic front end (base.cpp:13-28): OpenCV, host
+#endif
+  // creates ctx_ without an engine: preprocessImageImpl and solveStereoOdometry of a front end that has no network
+  bool ensureContext();
 
   cv::Mat projection_matrix_l_;
   cv::Mat projection_matrix_r_;
@@ -211,6 +270,40 @@ protected:
   std::string last_error_;
   void logError(const std::string &msg);
   void logInfo(const std::string &msg) const;
+};
+
+///////////////////////////////////////////////////////////////////////////////////////
+//////////////////// Classic front end (hpp:184-235, classic.cpp) /////////////////////
+///////////////////////////////////////////////////////////////////////////////////////
+
+// The CPU baseline of BASELINE config 1 (ORB / BRISK / AKAZE / SIFT / FAST / GFTT through cv::Feature2D).  Detection,
+// description and Hamming / L2 matching are OpenCV calls on the host, so the class does its work only in a build with
+// SPVO_USE_OPENCV; solveStereoOdometry still runs through the C ABI.  Without OpenCV (this image) the class keeps its
+// place in the interface -- visual_odometry_node.cpp:353-360 constructs it when `is_classic` is set -- and
+// addStereoImagePair logs an error and returns, the reference's convention for a front end that cannot run
+// (nn.cpp:53-55).
+class ClassicFeatureFrontEnd : public FeatureFrontEnd {
+public:
+  ClassicFeatureFrontEnd();
+  ClassicFeatureFrontEnd(const DetectorType detector_type, const DescriptorType descriptor_type,
+                         const MatcherType matcher_type, const SelectorType selector_type, const bool cross_check,
+                         const float stereo_threshold, const float min_disparity, const int refinement_degree,
+                         const bool verbose, const int input_height, const int input_width);
+  ~ClassicFeatureFrontEnd();
+
+  void initDetector();
+  void initDescriptor();
+  void addStereoImagePair(cv::Mat &img_l, cv::Mat &img_r, const cv::Mat &projection_matrix_l,
+                          const cv::Mat &projection_matrix_r) override;
+  std::vector<cv::KeyPoint> detectKeypoints(const cv::Mat &img);
+  cv::Mat describeKeypoints(std::vector<cv::KeyPoint> &keypoints, const cv::Mat &img);
+  static bool available();   // false in a build without OpenCV
+
+private:
+#ifdef SPVO_USE_OPENCV
+  cv::Ptr<cv::FeatureDetector> detector_;
+  cv::Ptr<cv::DescriptorExtractor> extractor_;
+#endif
 };
 
 ///////////////////////////////////////////////////////////////////////////////////////

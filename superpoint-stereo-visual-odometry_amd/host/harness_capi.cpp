@@ -29,7 +29,7 @@ void spvo_host_set_seed(void *h, unsigned seed) { static_cast<SuperPointFeatureF
 // node.cpp:163-175
 void spvo_host_add_stereo_pair(void *h, const uint8_t *img_l, const uint8_t *img_r, int rows, int cols, const double *P_l, const double *P_r) {
   auto *fe = static_cast<SuperPointFeatureFrontEnd *>(h);
-  cv::Mat l(rows, cols, cvlite::CV_8U), r(rows, cols, cvlite::CV_8U), pl(3, 4, cvlite::CV_64F), pr(3, 4, cvlite::CV_64F);
+  cv::Mat l(rows, cols, CV_8UC1), r(rows, cols, CV_8UC1), pl(3, 4, CV_64FC1), pr(3, 4, CV_64FC1);
   std::memcpy(l.data, img_l, (size_t)rows * cols);
   std::memcpy(r.data, img_r, (size_t)rows * cols);
   std::memcpy(pl.data, P_l, 12 * sizeof(double));
@@ -40,7 +40,7 @@ void spvo_host_add_stereo_pair(void *h, const uint8_t *img_l, const uint8_t *img
 void spvo_host_add_stereo_pair_dev(void *h, const void *d_l, const void *d_r, int rows, int cols, size_t stride, const double *P_l, const double *P_r,
                                    int host_descriptors) {
   auto *fe = static_cast<SuperPointFeatureFrontEnd *>(h);
-  cv::Mat pl(3, 4, cvlite::CV_64F), pr(3, 4, cvlite::CV_64F);
+  cv::Mat pl(3, 4, CV_64FC1), pr(3, 4, CV_64FC1);
   std::memcpy(pl.data, P_l, 12 * sizeof(double));
   std::memcpy(pr.data, P_r, 12 * sizeof(double));
   fe->addStereoImagePairDevice(d_l, d_r, rows, cols, stride, pl, pr, host_descriptors != 0);
@@ -58,8 +58,8 @@ void spvo_host_match(void *h, int match_type) { static_cast<SuperPointFeatureFro
 void spvo_host_solve(void *h, double *q, double *t) {
   tf2::Transform T;
   static_cast<SuperPointFeatureFrontEnd *>(h)->solveStereoOdometry(T);
-  q[0] = T.getRotation().x; q[1] = T.getRotation().y; q[2] = T.getRotation().z; q[3] = T.getRotation().w;
-  t[0] = T.getOrigin().x; t[1] = T.getOrigin().y; t[2] = T.getOrigin().z;
+  q[0] = T.getRotation().x(); q[1] = T.getRotation().y(); q[2] = T.getRotation().z(); q[3] = T.getRotation().w();
+  t[0] = T.getOrigin().x(); t[1] = T.getOrigin().y(); t[2] = T.getOrigin().z();
 }
 
 void spvo_host_clear(void *h) { static_cast<SuperPointFeatureFrontEnd *>(h)->clearLagecyData(); }
@@ -114,8 +114,8 @@ int spvo_host_inliers(void *h, int which, int *out, int cap) {
 // ---- result files (vo_io.hpp): pure host code, no GPU
 static tf2::Transform make_tf(const double *q, const double *t) {
   tf2::Transform T;
-  T.setRotation(tf2::Quaternion{q[0], q[1], q[2], q[3]});
-  T.setOrigin(tf2::Vector3{t[0], t[1], t[2]});
+  T.setRotation(tf2::Quaternion(q[0], q[1], q[2], q[3]));
+  T.setOrigin(tf2::Vector3(t[0], t[1], t[2]));
   return T;
 }
 
@@ -129,8 +129,8 @@ int spvo_host_write_kitti(const char *dir, int kitti_eval_id, int seq_start, con
   for (int i = 0; i < n; ++i) wr.write(integ.integrate(make_tf(q + 4 * i, t + 3 * i)));
   wr.close();
   const tf2::Transform &P = integ.pose();
-  final_pose[0] = P.getRotation().x; final_pose[1] = P.getRotation().y; final_pose[2] = P.getRotation().z; final_pose[3] = P.getRotation().w;
-  final_pose[4] = P.getOrigin().x; final_pose[5] = P.getOrigin().y; final_pose[6] = P.getOrigin().z;
+  final_pose[0] = P.getRotation().x(); final_pose[1] = P.getRotation().y(); final_pose[2] = P.getRotation().z(); final_pose[3] = P.getRotation().w();
+  final_pose[4] = P.getOrigin().x(); final_pose[5] = P.getOrigin().y(); final_pose[6] = P.getOrigin().z();
   return n - (seq_start < n ? seq_start : n);
 }
 
@@ -144,6 +144,18 @@ int spvo_host_write_latency(const char *dir, const char *prefix, int batch, int 
   std::strncpy(name_out, name.c_str(), name_cap - 1);
   name_out[name_cap - 1] = 0;
   return n;
+}
+
+// constructs the classic front end exactly as visual_odometry_node.cpp:353-360 does and offers it one stereo pair; returns the
+// number of deque entries it produced (0 in a build without OpenCV) and the error it logged
+int spvo_host_classic_probe(char *err, int cap) {
+  ClassicFeatureFrontEnd fe(detector_name_to_type.at("ORB"), descriptor_name_to_type.at("ORB"), matcher_name_to_type.at("BF"),
+                            selector_name_to_type.at("KNN"), true, 2.0f, 2.0f, 4, false, 0, 0);
+  cv::Mat l(16, 16, CV_8UC1), r(16, 16, CV_8UC1), pl(3, 4, CV_64FC1), pr(3, 4, CV_64FC1);
+  fe.addStereoImagePair(l, r, pl, pr);
+  std::strncpy(err, fe.lastError().c_str(), cap - 1);
+  err[cap - 1] = 0;
+  return ClassicFeatureFrontEnd::available() ? (int)fe.keypoints_dq.size() : -(int)fe.keypoints_dq.size();
 }
 
 int spvo_host_frame_count(void *h) { return static_cast<SuperPointFeatureFrontEnd *>(h)->frameCount(); }

@@ -27,8 +27,8 @@ bool KittiPoseWriter::open(const std::string &dir, int kitti_eval_id) {
 }
 
 static void rotation_matrix(const tf2::Quaternion &q, double R[9]) {
-  const double n = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-  const double x = q.x / n, y = q.y / n, z = q.z / n, w = q.w / n;
+  const double n = std::sqrt(q.x() * q.x() + q.y() * q.y() + q.z() * q.z() + q.w() * q.w());
+  const double x = q.x() / n, y = q.y() / n, z = q.z() / n, w = q.w() / n;
   R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
   R[3] = 2 * (x * y + z * w);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
   R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
@@ -47,7 +47,7 @@ void KittiPoseWriter::write(const tf2::Transform &world_T_base_curr) {
   const tf2::Transform cam0_start_T_cam0_curr = base_T_cam0_.inverse() * base_start_T_base_curr * base_T_cam0_;
   double R[9];
   rotation_matrix(cam0_start_T_cam0_curr.getRotation(), R);
-  const double t[3] = {cam0_start_T_cam0_curr.getOrigin().x, cam0_start_T_cam0_curr.getOrigin().y, cam0_start_T_cam0_curr.getOrigin().z};
+  const double t[3] = {cam0_start_T_cam0_curr.getOrigin().x(), cam0_start_T_cam0_curr.getOrigin().y(), cam0_start_T_cam0_curr.getOrigin().z()};
   for (int r = 0; r < 3; ++r) {   // data_processing_node.cpp:181-187
     for (int c = 0; c < 3; ++c) file_ << R[3 * r + c] << " ";
     file_ << t[r] << " ";

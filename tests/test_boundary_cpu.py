@@ -149,3 +149,37 @@ def test_fp16_engine_file_and_oracle(tmp_path):
     assert np.array_equal(mid, mid.astype(np.float16).astype(np.float32))
     assert not np.array_equal(det16, det16.astype(np.float16).astype(np.float32))     # outputs stay fp32
     assert 0 < np.abs(det16 - det32).max() < 2e-2 * np.abs(det32).max()
+
+
+HOST = os.path.join(ROOT, "superpoint-stereo-visual-odometry_amd", "host")
+
+
+@pytest.mark.parametrize("opencv", [False, True])
+def test_host_library_and_a_node_like_caller_compile_against_both_type_sets(opencv):
+    """host/*.cpp (the FeatureFrontEnd mirror) and tests/boundary_node_caller.cpp (the call sequence of
+    visual_odometry_node.cpp:150-262, 316, 330-403: both constructors, addStereoImagePair, matchDescriptors,
+    visualize*, solveStereoOdometry(tf2::Transform&), clearLagecyData, preprocessImageImpl, verbose_, the public
+    deques) are ONE source for two builds: the stand-in types of this image and -- with SPVO_USE_OPENCV -- OpenCV /
+    tf2 shaped headers (tests/mock_ros: methods, not fields).  The second build is what a ROS workspace compiles."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    flags = ["-DSPVO_USE_OPENCV", "-I" + os.path.join(ROOT, "tests", "mock_ros")] if opencv else []
+    for src in ("feature_detection.cpp", "vo_io.cpp", "harness_capi.cpp", os.path.join(ROOT, "tests", "boundary_node_caller.cpp")):
+        path = src if os.path.isabs(src) else os.path.join(HOST, src)
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I" + HOST] + flags + [path],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, (src, r.stderr[-2000:])
+
+
+def test_classic_front_end_is_declared_and_refuses_loudly_without_opencv():
+    """ClassicFeatureFrontEnd (hpp:184-235; constructed at node.cpp:353-360) is part of the interface; in a build without
+    OpenCV its addStereoImagePair logs and returns (nn.cpp:53-55 convention) and leaves the deques empty."""
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(capi.LIB_PATH), "libspvo_host.so"))
+    lib.spvo_host_classic_probe.restype = ctypes.c_int
+    lib.spvo_host_classic_probe.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    buf = ctypes.create_string_buffer(512)
+    rc = lib.spvo_host_classic_probe(buf, 512)
+    assert rc == 0                                        # not available, nothing pushed
+    assert b"SPVO_USE_OPENCV" in buf.value

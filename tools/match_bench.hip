@@ -1,0 +1,67 @@
+// Stand-alone timing of the matcher's kernels (csrc/match.hip.h) in the pipeline's configuration: two jobs (stereo and
+// temporal match) per launch.  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/match_bench.hip -o tools/match_bench
+// usage: match_bench [n = 1000] [jobs = 2] [reps = 200]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <random>
+#include <vector>
+#include "../superpoint-stereo-visual-odometry_amd/csrc/match.hip.h"
+using namespace spvo;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+int main(int argc, char **argv) {
+  const int n = argc > 1 ? atoi(argv[1]) : 1000, njobs = argc > 2 ? atoi(argv[2]) : 2, reps = argc > 3 ? atoi(argv[3]) : 200;
+  const int ldt = match_ldt(n);
+  std::mt19937 rng(1);
+  std::normal_distribution<float> nd;
+  std::vector<float> h((size_t)4 * n * 256);
+  for (int r = 0; r < 4 * n; ++r) {
+    double s = 0;
+    for (int k = 0; k < 256; ++k) { float v = nd(rng); h[(size_t)r * 256 + k] = v; s += (double)v * v; }
+    for (int k = 0; k < 256; ++k) h[(size_t)r * 256 + k] /= (float)std::sqrt(s);
+  }
+  float *d, *sq, *dt, *bd;
+  int *bi;
+  int2 *out;
+  CK(hipMalloc(&d, h.size() * 4)); CK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&sq, 4 * n * 4 + 64)); CK(hipMalloc(&dt, (size_t)2 * n * ldt * 4)); CK(hipMalloc(&bd, 4 * n * 4)); CK(hipMalloc(&bi, 4 * n * 4));
+  CK(hipMalloc(&out, 2 * n * sizeof(int2)));
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3(n), dim3(256), 0, 0, d, 4 * n, nullptr, sq);
+  MatchJobs jobs;
+  for (int k = 0; k < 2; ++k) {
+    MatchJob &j = jobs.j[k];
+    j.A = d + (size_t)(2 * k) * n * 256; j.B = d + (size_t)(2 * k + 1) * n * 256; j.na = j.nb = n; j.na_ptr = j.nb_ptr = nullptr;
+    j.nA = sq + (2 * k) * n; j.nB = sq + (2 * k + 1) * n; j.dt = dt + (size_t)k * n * ldt; j.best_d2 = bd + 2 * k * n; j.best_idx = bi + 2 * k * n;
+    j.A8 = j.B8 = nullptr; j.train_best = nullptr; j.out = out + k * n;
+  }
+  CK(hipFuncSetAttribute((const void *)match_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH_LDS_BYTES));
+  const dim3 gg((n + MATCH_TT - 1) / MATCH_TT, (n + MATCH_QT - 1) / MATCH_QT, njobs), gr((n + 3) / 4, njobs);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float ms;
+  for (int phase = 0; phase < 3; ++phase) {
+    for (int w = 0; w < 2; ++w) {   // w = 0 warms up
+      CK(hipEventRecord(e0));
+      for (int i = 0; i < reps; ++i) {
+        if (phase != 1) hipLaunchKernelGGL(match_gemm_kernel<false>, gg, dim3(256), MATCH_LDS_BYTES, 0, jobs, ldt);
+        if (phase != 0) {
+          if (n <= 1024) hipLaunchKernelGGL(match_rerank_kernel<4>, gr, dim3(256), sizeof(MatchRerankLds<4>), 0, jobs, ldt, MATCH_ERR_REL, 1, 0, 0.8f);
+          else hipLaunchKernelGGL(match_rerank_kernel<0>, gr, dim3(256), sizeof(MatchRerankLds<0>), 0, jobs, ldt, MATCH_ERR_REL, 1, 0, 0.8f);
+        }
+      }
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    const double us = ms * 1e3 / reps, fl = 2.0 * n * n * 256 * njobs;
+    if (phase == 0) printf("n=%d jobs=%d  gemm   %7.2f us  %6.1f TFLOP/s = %.3f of the fp32 MFMA peak (%d workgroups)\n", n, njobs, us, fl / us / 1e6, fl / us / 1e6 / 157.3, gg.x * gg.y * gg.z);
+    if (phase == 1) printf("n=%d jobs=%d  rerank %7.2f us\n", n, njobs, us);
+    if (phase == 2) printf("n=%d jobs=%d  both   %7.2f us\n", n, njobs, us);
+  }
+  std::vector<int2> ho(2 * n);
+  CK(hipMemcpy(ho.data(), out, ho.size() * sizeof(int2), hipMemcpyDeviceToHost));
+  long cs = 0;
+  for (auto &v : ho) cs += v.x;
+  printf("checksum %ld\n", cs);
+  return 0;
+}
