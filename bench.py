@@ -226,7 +226,11 @@ def main():
                                    + f", 1241x376 stereo pairs, net {NET_H}x{NET_W}, {args.max_keypoints} kp cap, "
                                    + ("fp8 shortlist + exact re-rank, " if args.match_fp8 else "")
                                    + "BF+KNN 0.8, P3P-style RANSAC 500 it, LM refinement degree 4; one stereo stream per GPU, RCCL all-gather of poses",
-                       "net_size": [NET_H, NET_W], "input_size": [rows, cols], "streams": world},
+                       "net_size": [NET_H, NET_W], "input_size": [rows, cols], "streams": world,
+                       "pose_gather": {"local": "single stream, no collective", "c:rccl": "spvo_pose_allgather_n (C ABI, RCCL), one collective per 64 frames",
+                                       "c:host": "spvo_pose_allgather_n (C ABI, file transport: test hook)",
+                                       "torch": "torch.distributed all_gather (RCCL), one collective per 64 frames"}.get(pg.transport, pg.transport)
+                                      + (" -- " + pg.transport_note if pg.transport_note else "")},
         }
         dom = prof.get("conv:1") if args.graph == "vgg" and args.precision != "INT8" else None
         if args.fp32_split:
@@ -302,6 +306,7 @@ def main():
                 out["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)
     fe.close()
+    pg.close()
     if dist_on:
         dist.destroy_process_group()
 

@@ -276,6 +276,30 @@ int spvo_solve_stereo_odometry(spvo_ctx *ctx, const spvo_solve_input *in, spvo_s
                                float *xyz /* [n][3] triangulated points */,
                                int32_t *inliers /* [n] RANSAC inliers, ascending */);
 
+/* ------------------------------------------------------- multi-GPU: pose gather
+ * The path shards by stereo stream: one process per GPU, each with its own FeatureFrontEnd
+ * state; nothing but the resulting relative poses -- q (x, y, z, w) + t of cam0_curr_T_cam0_prev, base.cpp:377-385,
+ * 7 doubles -- is ever exchanged.  The communicator is RCCL over xGMI (ncclAllGather on a stream of its own); librccl
+ * is opened when the first communicator is created, not when this library is loaded.  Errors: spvo_last_error(NULL). */
+typedef struct spvo_comm spvo_comm;
+#define SPVO_COMM_ID_BYTES 128
+
+/* Rank 0 creates the id (ncclGetUniqueId) and hands it to the other ranks out of band (ROS parameter server, a file,
+ * MPI, torchrun's store); every rank then calls spvo_comm_create -- collectively, like ncclCommInitRank. */
+int spvo_comm_unique_id(unsigned char id[SPVO_COMM_ID_BYTES]);
+int spvo_comm_create(int device, int rank, int world, const unsigned char id[SPVO_COMM_ID_BYTES], spvo_comm **out);
+/* TEST transport, no GPU: ranks exchange through files in `dir` (world-size-2 CPU tests of the N > 1 code path). */
+int spvo_comm_create_host(const char *dir, int rank, int world, spvo_comm **out);
+int spvo_comm_rank(const spvo_comm *comm);
+int spvo_comm_world(const spvo_comm *comm);
+void spvo_comm_destroy(spvo_comm *comm);
+
+/* all[r][7] = rank r's pose.  Collective and synchronous (host memory in, host memory out). */
+int spvo_pose_allgather(spvo_comm *comm, const double pose[7], double *all /* [world][7] */);
+/* Batched form: n poses per rank (the same n on every rank) in ONE collective; all[r][i][7].  56 bytes per frame are
+ * pure latency, so a throughput-oriented caller gathers once per batch of frames. */
+int spvo_pose_allgather_n(spvo_comm *comm, const double *poses /* [n][7] */, int n, double *all /* [world][n][7] */);
+
 /* ---------------------------------------------------------------- plumbing */
 void *spvo_stream(spvo_ctx *ctx);                 /* hipStream_t of the context */
 int spvo_synchronize(spvo_ctx *ctx);

@@ -1188,6 +1188,7 @@ void spvo_default_config(spvo_config *cfg) {
 }
 
 const char *spvo_last_error(const spvo_ctx *ctx) { return ctx ? ctx->error.c_str() : g_error.c_str(); }
+void spvo_internal_set_error(const char *msg) { g_error = msg ? msg : ""; }   // spvo_comm.hip reports through the same channel
 
 int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
   if (!cfg || !out) return fail(nullptr, SPVO_ERR_INVALID, "null argument");

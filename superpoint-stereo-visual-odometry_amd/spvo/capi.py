@@ -61,6 +61,8 @@ SYMBOLS = [
     "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_detect_dev_submit", "spvo_detect_wait", "spvo_match", "spvo_match_slots", "spvo_set_prematch", "spvo_set_match_fp8",
     "spvo_triangulate", "spvo_pnp_ransac", "spvo_pnp_refine", "spvo_solve_stereo_odometry", "spvo_stream", "spvo_synchronize",
     "spvo_profile_enable", "spvo_profile_reset", "spvo_profile_only", "spvo_profile_count", "spvo_profile_get",
+    "spvo_comm_unique_id", "spvo_comm_create", "spvo_comm_create_host", "spvo_comm_rank", "spvo_comm_world", "spvo_comm_destroy",
+    "spvo_pose_allgather", "spvo_pose_allgather_n",
 ]
 
 _lib = None
@@ -111,6 +113,15 @@ def load() -> C.CDLL:
     lib.spvo_profile_only.argtypes = [vp, C.c_char_p]
     lib.spvo_profile_count.argtypes = [vp]
     lib.spvo_profile_get.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t, dp, C.POINTER(C.c_longlong), dp, dp]
+    lib.spvo_comm_unique_id.argtypes = [vp]
+    lib.spvo_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    lib.spvo_comm_create_host.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.spvo_comm_rank.argtypes = [vp]
+    lib.spvo_comm_world.argtypes = [vp]
+    lib.spvo_comm_destroy.argtypes = [vp]
+    lib.spvo_comm_destroy.restype = None
+    lib.spvo_pose_allgather.argtypes = [vp, dp, dp]
+    lib.spvo_pose_allgather_n.argtypes = [vp, dp, C.c_int, dp]
     _lib = lib
     return lib
 
@@ -379,6 +390,65 @@ class Context:
             self._check(self.lib.spvo_profile_get(self.h, i, name, 64, C.byref(ms), C.byref(calls), C.byref(fl), C.byref(by)))
             out[name.value.decode()] = dict(total_ms=ms.value, calls=calls.value, flops=fl.value, bytes=by.value)
         return out
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """rank 0: the RCCL id every rank passes to Comm.rccl (hand it over out of band)."""
+    lib = load()
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib.spvo_comm_unique_id(buf)
+    if rc:
+        raise SpvoError(rc, lib.spvo_last_error(None).decode())
+    return buf.raw
+
+
+class Comm:
+    """spvo_comm: the pose all-gather of include/spvo.h (RCCL over xGMI; `host` = the file transport of the CPU tests)."""
+
+    def __init__(self, handle, lib):
+        self.h, self.lib = handle, lib
+        self.rank, self.world = lib.spvo_comm_rank(handle), lib.spvo_comm_world(handle)
+
+    @classmethod
+    def rccl(cls, device: int, rank: int, world: int, unique_id: bytes) -> "Comm":
+        lib = load()
+        h = C.c_void_p()
+        rc = lib.spvo_comm_create(device, rank, world, C.create_string_buffer(unique_id, COMM_ID_BYTES), C.byref(h))
+        if rc:
+            raise SpvoError(rc, lib.spvo_last_error(None).decode())
+        return cls(h, lib)
+
+    @classmethod
+    def host(cls, directory: str, rank: int, world: int) -> "Comm":
+        lib = load()
+        h = C.c_void_p()
+        rc = lib.spvo_comm_create_host(directory.encode(), rank, world, C.byref(h))
+        if rc:
+            raise SpvoError(rc, lib.spvo_last_error(None).decode())
+        return cls(h, lib)
+
+    def allgather(self, poses: np.ndarray) -> np.ndarray:
+        """poses [n, 7] (or [7]) float64 -> [world, n, 7]"""
+        p = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+        out = np.empty((self.world, len(p), 7), np.float64)
+        rc = self.lib.spvo_pose_allgather_n(self.h, _dptr(p), len(p), _dptr(out))
+        if rc:
+            raise SpvoError(rc, self.lib.spvo_last_error(None).decode())
+        return out
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.spvo_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def obs_array(X, uv, cam, inverse) -> np.ndarray:

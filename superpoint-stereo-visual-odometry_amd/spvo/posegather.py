@@ -2,12 +2,18 @@
 collective the path needs -- an all-gather of each rank's per-frame relative pose
 (7 doubles: quaternion x, y, z, w + translation; 56 bytes per rank).
 
-torch.distributed is plumbing here: backend "nccl" is RCCL over xGMI on the MI355X node,
-"gloo" is used by the CPU tests.  The message is latency-bound (no bandwidth term), so there is
-nothing to bucket or overlap; streams never exchange image or feature data.
+The collective itself is the C ABI's (include/spvo.h: spvo_comm_create / spvo_pose_allgather_n, RCCL over xGMI on a
+stream of the communicator's own) -- the same entry points a C++ ROS host calls; this module is the thin Python caller
+bench.py and the tests use.  torch.distributed only bootstraps it (hands rank 0's RCCL id to the other ranks) and
+stays available as a second transport (`transport="torch"`: backend "nccl" = RCCL, "gloo" on CPU).  The message is
+latency-bound (no bandwidth term): poses are staged on the host and leave in batches of BATCH frames, one collective
+per batch (a per-frame collective issued from the framework's default stream cost 26 % of the frame rate on one GPU,
+DESIGN.md section 6).  Streams never exchange image or feature data.
 """
 from __future__ import annotations
 
+import os
+import tempfile
 from typing import List, Optional
 
 import numpy as np
@@ -22,15 +28,33 @@ def stream_seed(rank: int, base_seed: int = 0) -> int:
     return base_seed + rank
 
 
-class PoseGather:
-    SLOTS = 4     # batches of the non-blocking form that may be in flight
+def _pose(q_xyzw, t) -> np.ndarray:
+    return IDENTITY_POSE if q_xyzw is None else np.concatenate([np.asarray(q_xyzw, np.float64), np.asarray(t, np.float64)])
 
-    def __init__(self, device: Optional[torch.device] = None, force: bool = False):
-        """force: run the collectives in a one-rank process group as well (test hook)"""
+
+class PoseGather:
+    BATCH = 64    # frames per collective of the non-blocking form
+    SLOTS = 4     # torch transport: batches that may be in flight
+
+    def __init__(self, device: Optional[torch.device] = None, force: bool = False, transport: str = "auto"):
+        """transport: "c" = the C ABI's communicator (RCCL on a GPU rank, the file transport of the CPU tests
+        otherwise), "torch" = torch.distributed collectives, "auto" = "c" with a fall-back to "torch" when the
+        communicator cannot be created.  force: run the collectives in a one-rank process group as well (test hook)."""
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.local_only = self.world == 1 and not (force and dist.is_initialized())
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.device = device or torch.device("cpu")
+        self.comm = None
+        self.transport = "local" if self.local_only else transport
+        self.transport_note = ""
+        if self.transport in ("auto", "c"):
+            try:
+                self.comm = self._make_comm()
+                self.transport = "c:rccl" if self.device.type == "cuda" else "c:host"
+            except Exception as exc:               # noqa: BLE001 -- any failure selects the other transport
+                if transport == "c":
+                    raise
+                self.transport, self.transport_note = "torch", f"C-ABI communicator unavailable ({exc}); torch.distributed used"
         self.buf = torch.zeros(7, dtype=torch.float64, device=self.device)
         self.out: List[torch.Tensor] = [torch.zeros(7, dtype=torch.float64, device=self.device) for _ in range(self.world)]
         self._pending: list = []
@@ -39,29 +63,56 @@ class PoseGather:
         self._stage = self._send = self._ready = None
         self._side = None
 
+    def _make_comm(self):
+        from . import capi
+        box = [None]
+        if self.device.type == "cuda":
+            if self.rank == 0:
+                box[0] = capi.comm_unique_id()
+            if self.world > 1:
+                dist.broadcast_object_list(box, src=0)
+            return capi.Comm.rccl(self.device.index or 0, self.rank, self.world, box[0])
+        if self.rank == 0:
+            box[0] = tempfile.mkdtemp(prefix="spvo_comm_")
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=0)
+        self._host_dir = box[0]
+        return capi.Comm.host(box[0], self.rank, self.world)
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
+            d = getattr(self, "_host_dir", None)
+            if d and self.rank == 0 and os.path.isdir(d):
+                try:
+                    os.rmdir(d)
+                except OSError:
+                    pass
+
     def gather(self, q_xyzw, t) -> np.ndarray:
         """Returns [world, 7]; a rank with no pose yet (first frame) contributes the identity."""
-        pose = IDENTITY_POSE if q_xyzw is None else np.concatenate([np.asarray(q_xyzw, np.float64), np.asarray(t, np.float64)])
+        pose = _pose(q_xyzw, t)
         if self.local_only:
             return pose[None].copy()
+        if self.comm is not None:
+            return self.comm.allgather(pose)[:, 0, :]
         self.buf.copy_(torch.from_numpy(pose))
         dist.all_gather(self.out, self.buf)
         return torch.stack(self.out).cpu().numpy()
 
     # ---- non-blocking form: the poses are only COLLECTED (nothing downstream of the front end waits for the other
-    # streams' poses), so a step need not block on the collective.  Poses are staged on the host and leave in batches of
-    # BATCH steps: one [BATCH, 7] all-gather on a side stream instead of one collective per frame -- a per-frame collective
-    # costs a kernel launch, two stream hand-overs and, issued from the framework's default (NULL) stream, an implicit
-    # synchronisation with every blocking stream of the process (measured: 707 -> 524 frames/s on one GPU).
-    BATCH = 64
-
+    # streams' poses), so a step need not block on the collective: they are staged on the host and leave in batches.
     def _flush(self) -> None:
         n = self._fill
         if n == 0:
             return
         self._fill = 0
         if self.local_only:
-            self._pending.append((torch.from_numpy(self._host[:n].copy())[:, None, :], n))
+            self._pending.append((self._host[:n].copy()[:, None, :], n))
+            return
+        if self.comm is not None:          # one spvo_pose_allgather_n per batch: [world, n, 7] -> [n, world, 7]
+            self._pending.append((self.comm.allgather(self._host[:n]).transpose(1, 0, 2).copy(), n))
             return
         slot = self._slot
         self._slot = (slot + 1) % self.SLOTS
@@ -88,7 +139,7 @@ class PoseGather:
         if self._host is None:
             self._host = np.zeros((self.BATCH, 7), np.float64)
             self._fill = 0
-            if not self.local_only:   # pinned staging + device rows, SLOTS batches may be in flight
+            if not self.local_only and self.comm is None:   # torch transport: pinned staging + device rows, SLOTS batches in flight
                 self._stage = [torch.zeros((self.BATCH, 7), dtype=torch.float64) for _ in range(self.SLOTS)]
                 if self.device.type == "cuda":
                     self._stage = [s.pin_memory() for s in self._stage]
@@ -96,7 +147,7 @@ class PoseGather:
                 self._send = [torch.zeros((self.BATCH, 7), dtype=torch.float64, device=self.device) for _ in range(self.SLOTS)]
                 self._ready = [None] * self.SLOTS
                 self._slot = 0
-        self._host[self._fill, :] = IDENTITY_POSE if q_xyzw is None else np.concatenate([np.asarray(q_xyzw, np.float64), np.asarray(t, np.float64)])
+        self._host[self._fill, :] = _pose(q_xyzw, t)
         self._fill += 1
         if self._fill == self.BATCH:
             self._flush()
@@ -112,7 +163,9 @@ class PoseGather:
             self._side.synchronize()
         rows = []
         for out, n in self._pending:
-            o = out.to("cpu")
-            rows.append(o if self.local_only else o[:, :n, :].permute(1, 0, 2))
+            if isinstance(out, np.ndarray):
+                rows.append(out)
+            else:
+                rows.append(out.to("cpu")[:, :n, :].permute(1, 0, 2).numpy())
         self._pending.clear()
-        return torch.cat(rows).numpy()
+        return np.concatenate(rows)

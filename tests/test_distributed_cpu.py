@@ -1,8 +1,11 @@
-"""world_size-2 gloo test of the multi-GPU layer (one process per GPU, pose all-gather)."""
+"""world_size-2 tests of the multi-GPU layer (one process per GPU, pose all-gather): through the C ABI's communicator
+(spvo_comm_create_host: the file transport that stands in for RCCL where there is no GPU) and through torch.distributed
+(gloo)."""
 import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -18,11 +21,12 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, transport):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    pg = posegather.PoseGather()
+    pg = posegather.PoseGather(transport=transport)
+    assert pg.transport == ("c:host" if transport == "c" else "torch")
     # every rank owns a different stream
     poses = synth.ego_motion(3, seed=posegather.stream_seed(rank))
     R, t = synth.relative_pose(poses[0], poses[1])
@@ -47,14 +51,16 @@ def _worker(rank, world, port, q):
         assert np.allclose(seq[k][1 - rank, :4], [0.0, 0.01 * (2 - rank), 0.0, 1.0])
     q.put((rank, first, allp, t))
     dist.barrier()
+    pg.close()
     dist.destroy_process_group()
 
 
-def test_pose_allgather_world2():
+@pytest.mark.parametrize("transport", ["c", "torch"])
+def test_pose_allgather_world2(transport):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, transport)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
@@ -80,3 +86,24 @@ def test_single_process_gather_is_identity_passthrough():
         pg.gather_async([0, 0, 0, 1], [k, 2, 3])
     seq = pg.collect()
     assert seq.shape == (130, 1, 7) and np.allclose(seq[:, 0, 4], np.arange(130))
+
+
+def test_c_abi_comm_rejects_bad_arguments_and_needs_a_gpu_for_rccl(tmp_path):
+    """spvo_comm_*: argument checks, the loud failure of the RCCL transport without a device, and a one-rank gather
+    through the file transport (what a C++ host calls: include/spvo.h)."""
+    import ctypes as C
+    from spvo import capi
+    lib = capi.load()
+    h = C.c_void_p()
+    assert lib.spvo_comm_create_host(str(tmp_path).encode(), 2, 2, C.byref(h)) == -1          # rank >= world
+    assert lib.spvo_comm_create_host(b"/nonexistent/dir", 0, 1, C.byref(h)) == -3
+    if not torch.cuda.is_available():
+        with pytest.raises(capi.SpvoError) as e:
+            capi.Comm.rccl(0, 0, 1, bytes(128))
+        assert "no CPU path" in str(e.value) or "librccl" in str(e.value)
+    c = capi.Comm.host(str(tmp_path), 0, 1)
+    poses = np.arange(21, dtype=np.float64).reshape(3, 7)
+    assert (c.rank, c.world) == (0, 1) and np.array_equal(c.allgather(poses), poses[None])
+    assert np.array_equal(c.allgather(poses[0]), poses[None, :1])
+    c.close()
+    assert not any(f.startswith("pose_") for f in os.listdir(tmp_path))                        # files cleaned up
