@@ -162,6 +162,18 @@ int spvo_detect_dev_submit(spvo_ctx *ctx, const void *d_img_l, const void *d_img
 int spvo_detect_wait(spvo_ctx *ctx, double P_l[12], double P_r[12], spvo_features *out_l,
                      spvo_features *out_r);
 
+/* The asynchronous form for images in HOST memory -- what a ROS node holds (cv_bridge::toCvCopy, node.cpp:163-168).
+ * _submit copies the two images into pinned staging buffers of the submission (the caller's buffers are free when it
+ * returns), queues the host-to-device copies and the whole detector chain behind them and returns; up to two
+ * submissions may be in flight, exactly as with spvo_detect_dev_submit (same slot rules).  `extras`: bit 0 = the resized
+ * u8 images (nn.cpp:154, images_dq), bit 1 = the descriptors (descriptors_dq) also travel back, into pinned mirrors of
+ * the submission.  _collect completes the OLDEST submission (of either kind) like spvo_detect_wait and hands out what was
+ * requested: results are bit-identical to spvo_detect on the same images. */
+int spvo_detect_submit(spvo_ctx *ctx, const uint8_t *img_l, const uint8_t *img_r, int rows, int cols, size_t stride,
+                       int slot_l, int slot_r, int extras);
+int spvo_detect_collect(spvo_ctx *ctx, double P_l[12], double P_r[12], spvo_features *out_l, spvo_features *out_r,
+                        uint8_t *resized_l, uint8_t *resized_r);
+
 typedef enum { SPVO_SELECT_NN = 0, SPVO_SELECT_KNN = 1 } spvo_selector;
 
 /* matchDescriptors (base.cpp:434-491) = cv::BFMatcher(NORM_L2) match / knnMatch

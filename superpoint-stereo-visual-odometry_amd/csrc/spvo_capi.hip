@@ -118,6 +118,7 @@ struct PendingDetect {           // one spvo_detect*_submit in flight
   CropGeomS g;
   int rows = 0, cols = 0, slot_l = 0, slot_r = 0, prev_l = -1, ring = 0;
   bool rematch = false;          // the temporal partner's keypoints were redone after this submission matched against them
+  int extras = 0;                // spvo_detect_submit: bit 0 resized images, bit 1 descriptors travel to the set's pinned mirrors
 };
 
 
@@ -179,6 +180,12 @@ struct spvo_ctx {
   float *d_heat_r[RING] = {nullptr, nullptr, nullptr, nullptr}, *d_heat_base_r[RING] = {nullptr, nullptr, nullptr, nullptr};
   int *h_counters_r[RING] = {nullptr, nullptr, nullptr, nullptr};
   float *h_xy_r[RING] = {nullptr, nullptr, nullptr, nullptr};
+  // host-image submissions (spvo_detect_submit): per set, pinned staging + device copies of the two input images, a resized-image
+  // buffer of its own and pinned mirrors of the resized images and of the descriptors
+  uint8_t *h_img_r[RING] = {nullptr, nullptr, nullptr, nullptr}, *d_img_r[RING] = {nullptr, nullptr, nullptr, nullptr};
+  size_t img_cap_r = 0;          // bytes per image in those buffers
+  uint8_t *d_resized_r[RING] = {nullptr, nullptr, nullptr, nullptr}, *h_resized_r[RING] = {nullptr, nullptr, nullptr, nullptr};
+  float *h_desc_r[RING] = {nullptr, nullptr, nullptr, nullptr};   // [2][cap][256]
   hipEvent_t ev_net[RING] = {nullptr, nullptr, nullptr, nullptr}, ev_tail[RING] = {nullptr, nullptr, nullptr, nullptr};
   bool match_fp8 = false;        // fp8 shortlist GEMM (approximate; spvo_set_match_fp8)
   bool prematch = false;
@@ -876,7 +883,8 @@ int ensure_tables(spvo_ctx *c, const CropGeom &g) {
 }
 
 // one launch for `count` images (d_src0, d_src1) into slots slot0, slot0 + 1 of the resized-image buffer and the input tensor
-int launch_preprocess(spvo_ctx *c, const uint8_t *d_src0, const uint8_t *d_src1, int count, int rows, int cols, size_t stride, const CropGeom &g, int slot0) {
+int launch_preprocess(spvo_ctx *c, const uint8_t *d_src0, const uint8_t *d_src1, int count, int rows, int cols, size_t stride, const CropGeom &g, int slot0,
+                      uint8_t *resized_dst = nullptr) {
   int rc = ensure_tables(c, g);
   if (rc) return rc;
   ResizeTab tab;
@@ -886,7 +894,7 @@ int launch_preprocess(spvo_ctx *c, const uint8_t *d_src0, const uint8_t *d_src1,
   const int identity = (g.crop_rows == c->H && g.crop_cols == c->W) ? 1 : 0;
   dim3 grid((c->W + 63) / 64, (c->H + 3) / 4, count);
   hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, c->stream, d_src0, d_src1, stride, rows, cols, g.row_off, g.col_off, g.crop_rows, g.crop_cols, tab, c->H, c->W,
-                     c->d_resized + (size_t)slot0 * c->H * c->W, tin.d + (size_t)slot0 * tin.per_image, tin.per_image, tin.hp, tin.wp, identity);
+                     (resized_dst ? resized_dst : c->d_resized) + (size_t)slot0 * c->H * c->W, tin.d + (size_t)slot0 * tin.per_image, tin.per_image, tin.hp, tin.wp, identity);
   HIP_TRY(c, hipGetLastError());
   return SPVO_OK;
 }
@@ -1310,6 +1318,11 @@ void spvo_destroy(spvo_ctx *c) {
     if (c->d_heat_base_r[r]) (void)hipFree(c->d_heat_base_r[r]);
     if (c->h_counters_r[r]) (void)hipHostFree(c->h_counters_r[r]);
     if (c->h_xy_r[r]) (void)hipHostFree(c->h_xy_r[r]);
+    if (c->d_img_r[r]) (void)hipFree(c->d_img_r[r]);
+    if (c->h_img_r[r]) (void)hipHostFree(c->h_img_r[r]);
+    if (c->d_resized_r[r]) (void)hipFree(c->d_resized_r[r]);
+    if (c->h_resized_r[r]) (void)hipHostFree(c->h_resized_r[r]);
+    if (c->h_desc_r[r]) (void)hipHostFree(c->h_desc_r[r]);
     for (hipEvent_t e : {c->ev_net[r], c->ev_tail[r]}) if (e) (void)hipEventDestroy(e);
   }
   for (int i = 0; i < N_SLOTS; ++i) {
@@ -1892,7 +1905,12 @@ static int enqueue_prematch(spvo_ctx *c, int slot_l, int slot_r, int prev_l, int
 // be queued: the tail of one overlaps with the network of the next, whose kernels leave CUs idle at
 // their ragged ends.  Every buffer a tail touches belongs to the submission's set (RING of them), so
 // a later submission -- or the rare host-driven NMS redo of an earlier one -- never meets it.
-static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, int rows, int cols, size_t stride, int slot_l, int slot_r) {
+static int ensure_host_sets(spvo_ctx *c, size_t image_bytes);
+
+// host_l / host_r != NULL: the images are in HOST memory -- they are staged through the set's pinned buffers and copied to the
+// device on the network stream (d_l, d_r are then ignored); extras: see PendingDetect
+static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, int rows, int cols, size_t stride, int slot_l, int slot_r,
+                         const uint8_t *host_l = nullptr, const uint8_t *host_r = nullptr, int extras = 0) {
   if ((int)c->pendq.size() >= MAX_INFLIGHT) return fail(c, SPVO_ERR_STATE, "%d detector submissions are already in flight", MAX_INFLIGHT);
   if (slot_l < 0 || slot_l >= N_SLOTS || slot_r < 0 || slot_r >= N_SLOTS || slot_l == slot_r) return fail(c, SPVO_ERR_INVALID, "bad feature slots %d, %d", slot_l, slot_r);
   for (const auto &q : c->pendq)
@@ -1903,11 +1921,25 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   const Tensor &td = c->tensors[c->t_det];
   const uint8_t *srcs[2] = {d_l, d_r};
   const int slots[2] = {slot_l, slot_r};
+  if (!host_l && (!d_l || !d_r)) return fail(c, SPVO_ERR_INVALID, "null image");
   // temporal partner = the left slot of the previous submission, if it survives this one
   int prev_l = c->last_slot_l;
   if (prev_l == slot_l || prev_l == slot_r || (prev_l >= 0 && !c->slots[prev_l].filled)) prev_l = -1;
+  if (host_l || extras) {
+    const int rc0 = ensure_host_sets(c, (size_t)rows * stride);
+    if (rc0) return rc0;
+  }
   const int ring = (int)(c->submit_count++ % RING);
   for (auto &mc : c->mcache[ring]) mc.valid = false;
+  if (host_l) {   // pageable -> pinned (host copy), pinned -> device (DMA on the network stream): the caller's buffers are free on return
+    const size_t bytes = (size_t)rows * stride;
+    std::memcpy(c->h_img_r[ring], host_l, bytes);
+    std::memcpy(c->h_img_r[ring] + c->img_cap_r, host_r, bytes);
+    HIP_TRY(c, hipMemcpyAsync(c->d_img_r[ring], c->h_img_r[ring], bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_img_r[ring] + c->img_cap_r, c->h_img_r[ring] + c->img_cap_r, bytes, hipMemcpyHostToDevice, c->stream));
+    srcs[0] = c->d_img_r[ring];
+    srcs[1] = c->d_img_r[ring] + c->img_cap_r;
+  }
   // ---- everything below is enqueued without a host round trip
   c->cur_ring = ring;
   c->post = c->stream;
@@ -1916,7 +1948,7 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   if (prof_detect) { det_e0 = get_event(c); (void)hipEventRecord(det_e0, c->stream); }
   {
     ScopedStage sp(c, stage_id(c, "preprocess"));
-    int rc = launch_preprocess(c, srcs[0], srcs[1], 2, rows, cols, stride, g, 0);
+    int rc = launch_preprocess(c, srcs[0], srcs[1], 2, rows, cols, stride, g, 0, (extras & 1) ? c->d_resized_r[ring] : nullptr);
     if (rc) return rc;
   }
   int rc;
@@ -1947,6 +1979,13 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   }
   if (!rc) rc = enqueue_sample(c, slots, np, ring);
   if (!rc && c->prematch) rc = enqueue_prematch(c, slot_l, slot_r, prev_l, ring);
+  if (!rc && (extras & 1))   // resized images (what nn.cpp:154 pushes to images_dq) -> the set's pinned mirror
+    rc = hipMemcpyAsync(c->h_resized_r[ring], c->d_resized_r[ring], (size_t)2 * c->H * c->W, hipMemcpyDeviceToHost, c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipMemcpyAsync failed");
+  if (!rc && (extras & 2)) {   // descriptors of both images: whole slots (the counts are not known on the host yet; rows >= n are stale)
+    const size_t per = (size_t)c->cfg.max_keypoints * 256;
+    for (int i = 0; i < 2 && !rc; ++i)
+      rc = hipMemcpyAsync(c->h_desc_r[ring] + i * per, c->slots[slots[i]].d_desc, per * sizeof(float), hipMemcpyDeviceToHost, c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipMemcpyAsync failed");
+  }
   if (!rc && prof_detect) {   // "detect" spans both streams: first kernel on `stream` .. last copy on `stream_t`
     hipEvent_t e1 = get_event(c);
     (void)hipEventRecord(e1, c->stream_t);
@@ -1960,7 +1999,7 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   PendingDetect pd;
   pd.g = CropGeomS{g.row_off, g.col_off, g.crop_rows, g.crop_cols, g.scale};
   pd.rows = rows; pd.cols = cols;
-  pd.slot_l = slot_l; pd.slot_r = slot_r; pd.prev_l = prev_l; pd.ring = ring;
+  pd.slot_l = slot_l; pd.slot_r = slot_r; pd.prev_l = prev_l; pd.ring = ring; pd.extras = extras;
   c->pendq.push_back(pd);
   return SPVO_OK;
 }
@@ -1969,20 +2008,31 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
 static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_features *out_l, spvo_features *out_r, uint8_t *resized_l, uint8_t *resized_r) {
   if (c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "no detector submission in flight");
   const PendingDetect pd = c->pendq.front();
-  c->pendq.pop_front();
   const int slots[2] = {pd.slot_l, pd.slot_r};
   const int cap = c->cfg.max_keypoints;
   uint8_t *res[2] = {resized_l, resized_r};
   spvo_features *outs[2] = {out_l, out_r};
-  const bool extras = resized_l || resized_r || (out_l && out_l->desc) || (out_r && out_r->desc);
-  if (extras && !c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "resized images / host descriptors can only be fetched with one submission in flight");
+  const bool want_res = resized_l || resized_r, want_desc = (out_l && out_l->desc) || (out_r && out_r->desc);
+  // what the submission staged into its own pinned mirrors is simply read there; anything else has to be copied now, from buffers a
+  // younger submission may already be rewriting -- refused BEFORE the submission is taken off the queue
+  const bool extras = (want_res && !(pd.extras & 1)) || (want_desc && !(pd.extras & 2));
+  if (extras && c->pendq.size() > 1) return fail(c, SPVO_ERR_STATE, "resized images / host descriptors can only be fetched with one submission in flight (or request them at spvo_detect_submit)");
+  c->pendq.pop_front();
   c->post = c->stream_t;
   auto copy_extras = [&]() -> int {
-    for (int i = 0; i < 2; ++i)
-      if (res[i]) HIP_TRY(c, hipMemcpyAsync(res[i], c->d_resized + (size_t)i * c->H * c->W, (size_t)c->H * c->W, hipMemcpyDeviceToHost, c->post));
+    if (!(pd.extras & 1))
+      for (int i = 0; i < 2; ++i)
+        if (res[i]) HIP_TRY(c, hipMemcpyAsync(res[i], c->d_resized + (size_t)i * c->H * c->W, (size_t)c->H * c->W, hipMemcpyDeviceToHost, c->post));
     // descriptors: copy the full slot (1000 x 256 floats); rows >= n are stale
-    for (int i = 0; i < 2; ++i)
-      if (outs[i] && outs[i]->desc) HIP_TRY(c, hipMemcpyAsync(outs[i]->desc, c->slots[slots[i]].d_desc, (size_t)cap * 256 * sizeof(float), hipMemcpyDeviceToHost, c->post));
+    if (!(pd.extras & 2))
+      for (int i = 0; i < 2; ++i)
+        if (outs[i] && outs[i]->desc) HIP_TRY(c, hipMemcpyAsync(outs[i]->desc, c->slots[slots[i]].d_desc, (size_t)cap * 256 * sizeof(float), hipMemcpyDeviceToHost, c->post));
+    return SPVO_OK;
+  };
+  auto restage = [&]() -> int {   // after an NMS redo the set's mirrors are refreshed too
+    if (pd.extras & 2)
+      for (int i = 0; i < 2; ++i)
+        HIP_TRY(c, hipMemcpyAsync(c->h_desc_r[pd.ring] + (size_t)i * cap * 256, c->slots[slots[i]].d_desc, (size_t)cap * 256 * sizeof(float), hipMemcpyDeviceToHost, c->post));
     return SPVO_OK;
   };
   int rc = SPVO_OK;
@@ -2002,6 +2052,7 @@ static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_feature
     if (redone) rc = enqueue_sample(c, slots, np, pd.ring);
     if (!rc && c->prematch) rc = enqueue_prematch(c, pd.slot_l, pd.slot_r, pd.prev_l, pd.ring);
     if (!rc && extras) rc = copy_extras();
+    if (!rc && redone) rc = restage();
     if (!rc) rc = hipStreamSynchronize(c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "stream synchronisation failed");
     if (redone)
       for (auto &q : c->pendq)
@@ -2017,13 +2068,45 @@ static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_feature
     if (outs[i]) {
       outs[i]->n = s.n;
       if (outs[i]->xy && s.n > 0) std::memcpy(outs[i]->xy, c->h_xy_r[pd.ring] + (size_t)i * cap * 2, (size_t)s.n * 2 * sizeof(float));
+      if (outs[i]->desc && (pd.extras & 2) && s.n > 0) std::memcpy(outs[i]->desc, c->h_desc_r[pd.ring] + (size_t)i * cap * 256, (size_t)s.n * 256 * sizeof(float));
     }
+    if (res[i] && (pd.extras & 1)) std::memcpy(res[i], c->h_resized_r[pd.ring] + (size_t)i * c->H * c->W, (size_t)c->H * c->W);
   }
   for (auto &mc : c->mcache[pd.ring])
     if (mc.valid) { mc.gen_a = c->slots[mc.slot_a].gen; mc.gen_b = c->slots[mc.slot_b].gen; }
   const CropGeom g{pd.g.row_off, pd.g.col_off, pd.g.crop_rows, pd.g.crop_cols, pd.g.scale};
   if (P_l) fix_projection(P_l, g, pd.rows, pd.cols, c->cfg.bug_compat_p);
   if (P_r) fix_projection(P_r, g, pd.rows, pd.cols, c->cfg.bug_compat_p);
+  return SPVO_OK;
+}
+
+// buffers of the host-image submissions: allocated on first use, grown when a larger image arrives (never while submissions are in flight)
+static int ensure_host_sets(spvo_ctx *c, size_t image_bytes) {
+  const size_t hw2 = (size_t)2 * c->H * c->W, desc = (size_t)2 * c->cfg.max_keypoints * 256;
+  if (!c->d_resized_r[0]) {
+    for (int r = 0; r < RING; ++r) {
+      int rc = dev_alloc(c, &c->d_resized_r[r], hw2, false);
+      if (rc) return rc;
+      HIP_TRY(c, hipHostMalloc((void **)&c->h_resized_r[r], hw2));
+      HIP_TRY(c, hipHostMalloc((void **)&c->h_desc_r[r], desc * sizeof(float)));
+    }
+  }
+  if (image_bytes > c->img_cap_r) {
+    if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "the image size grew while submissions are in flight");
+    HIP_TRY(c, hipDeviceSynchronize());
+    for (int r = 0; r < RING; ++r) {
+      if (c->d_img_r[r]) (void)hipFree(c->d_img_r[r]);
+      if (c->h_img_r[r]) (void)hipHostFree(c->h_img_r[r]);
+      c->d_img_r[r] = c->h_img_r[r] = nullptr;
+    }
+    c->img_cap_r = 0;
+    for (int r = 0; r < RING; ++r) {
+      int rc = dev_alloc(c, &c->d_img_r[r], 2 * image_bytes, false);
+      if (rc) return rc;
+      HIP_TRY(c, hipHostMalloc((void **)&c->h_img_r[r], 2 * image_bytes));
+    }
+    c->img_cap_r = image_bytes;
+  }
   return SPVO_OK;
 }
 
@@ -2071,6 +2154,19 @@ int spvo_detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_features 
   if (!c) return fail(c, SPVO_ERR_INVALID, "null context");
   HIP_TRY(c, hipSetDevice(c->cfg.device));
   return detect_wait(c, P_l, P_r, out_l, out_r, nullptr, nullptr);
+}
+
+int spvo_detect_submit(spvo_ctx *c, const uint8_t *img_l, const uint8_t *img_r, int rows, int cols, size_t stride, int slot_l, int slot_r, int extras) {
+  if (!c || !img_l || !img_r || rows <= 0 || cols <= 0 || stride < (size_t)cols || (extras & ~3)) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  return detect_submit(c, nullptr, nullptr, rows, cols, stride, slot_l, slot_r, img_l, img_r, extras);
+}
+
+int spvo_detect_collect(spvo_ctx *c, double P_l[12], double P_r[12], spvo_features *out_l, spvo_features *out_r, uint8_t *resized_l, uint8_t *resized_r) {
+  if (!c) return fail(c, SPVO_ERR_INVALID, "null context");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  return detect_wait(c, P_l, P_r, out_l, out_r, resized_l, resized_r);
 }
 
 int spvo_match(spvo_ctx *c, const float *desc_a, int na, const float *desc_b, int nb, int selector, int cross_check, float ratio, int32_t *train_idx, float *distance) {

@@ -511,15 +511,33 @@ void SuperPointFeatureFrontEnd::addStereoImagePair(cv::Mat &img_l, cv::Mat &img_
   projection_matrix_l_ = projection_matrix_l.clone();  // nn.cpp:465-466
   projection_matrix_r_ = projection_matrix_r.clone();
 
-  drainPrefetch();   // the synchronous path shares the detector's buffers with submissions in flight
+  // One code path for the plain call and for a pair announced with prefetchStereoImagePair: the images go through
+  // spvo_detect_submit (pinned staging, asynchronous copies on the network stream; resized images and descriptors come
+  // back in the submission's pinned mirrors) and spvo_detect_collect.  Submissions of OTHER pairs still in flight are
+  // drained first -- the reference processes pairs strictly in call order.
+  const bool hit = !prefetch_q_.empty() && prefetch_q_.front().host && prefetch_q_.front().l == img_l.data && prefetch_q_.front().r == img_r.data &&
+                   prefetch_q_.front().rows == img_l.rows && prefetch_q_.front().cols == img_l.cols;
   int slot_l, slot_r;
-  pickSlots(&slot_l, &slot_r);
+  if (hit) {
+    slot_l = prefetch_q_.front().slot_l;
+    slot_r = prefetch_q_.front().slot_r;
+    prefetch_q_.pop_front();
+  } else {
+    if (!prefetch_q_.empty()) {
+      drainPrefetch();
+      logError("addStereoImagePair: the prefetched pair was not the one passed in; prefetch discarded");
+    }
+    pickSlots(&slot_l, &slot_r);
+    if (spvo_detect_submit(ctx_, img_l.data, img_r.data, img_l.rows, img_l.cols, (size_t)img_l.step, slot_l, slot_r, 3) != SPVO_OK) {
+      logError(std::string("spvo_detect_submit: ") + spvo_last_error(ctx_));
+      return;
+    }
+  }
   spvo_features fl{0, xy_buf_[0].data(), desc_buf_[0].data()}, fr{0, xy_buf_[1].data(), desc_buf_[1].data()};
   cv::Mat res_l(input_height_, input_width_, CV_8UC1), res_r(input_height_, input_width_, CV_8UC1);
-  const int rc = spvo_detect(ctx_, img_l.data, img_r.data, img_l.rows, img_l.cols, (size_t)img_l.step, projection_matrix_l_.ptr<double>(0),
-                             projection_matrix_r_.ptr<double>(0), slot_l, slot_r, &fl, &fr, res_l.data, res_r.data);
+  const int rc = spvo_detect_collect(ctx_, projection_matrix_l_.ptr<double>(0), projection_matrix_r_.ptr<double>(0), &fl, &fr, res_l.data, res_r.data);
   if (rc != SPVO_OK) {
-    logError(std::string("spvo_detect: ") + spvo_last_error(ctx_));
+    logError(std::string("spvo_detect_collect: ") + spvo_last_error(ctx_));
     return;
   }
   // the reference mutates the caller's images in place (crop + resize + convertTo float,
@@ -530,6 +548,22 @@ void SuperPointFeatureFrontEnd::addStereoImagePair(cv::Mat &img_l, cv::Mat &img_
   const cv::Mat *res[2] = {&res_l, &res_r};
   const int slots[2] = {slot_l, slot_r};
   pushFeatures(f, res, slots, true);
+}
+
+void SuperPointFeatureFrontEnd::prefetchStereoImagePair(const cv::Mat &img_l, const cv::Mat &img_r) {
+  if (!engine_loaded_ || prefetch_q_.size() >= 2) return;
+  if (img_l.type() != CV_8UC1 || img_r.type() != CV_8UC1 || img_l.rows != img_r.rows || img_l.cols != img_r.cols || (size_t)img_l.step != (size_t)img_r.step) return;
+  for (const auto &q : prefetch_q_)   // already announced
+    if (q.host && q.l == img_l.data && q.r == img_r.data && q.rows == img_l.rows && q.cols == img_l.cols) return;
+  Prefetch pf;
+  pickSlots(&pf.slot_l, &pf.slot_r);
+  if (spvo_detect_submit(ctx_, img_l.data, img_r.data, img_l.rows, img_l.cols, (size_t)img_l.step, pf.slot_l, pf.slot_r, 3) != SPVO_OK) {
+    logError(std::string("spvo_detect_submit: ") + spvo_last_error(ctx_));
+    return;
+  }
+  pf.l = img_l.data; pf.r = img_r.data;
+  pf.rows = img_l.rows; pf.cols = img_l.cols; pf.stride = (size_t)img_l.step; pf.host = true;
+  prefetch_q_.push_back(pf);
 }
 
 void SuperPointFeatureFrontEnd::addStereoImagePairDevice(const void *d_img_l, const void *d_img_r, int rows, int cols, size_t stride,
@@ -550,8 +584,8 @@ void SuperPointFeatureFrontEnd::addStereoImagePairDevice(const void *d_img_l, co
   spvo_features fl{0, xy_buf_[0].data(), host_descriptors ? desc_buf_[0].data() : nullptr};
   spvo_features fr{0, xy_buf_[1].data(), host_descriptors ? desc_buf_[1].data() : nullptr};
   int rc;
-  const bool hit = !prefetch_q_.empty() && prefetch_q_.front().l == d_img_l && prefetch_q_.front().r == d_img_r && prefetch_q_.front().rows == rows &&
-                   prefetch_q_.front().cols == cols && prefetch_q_.front().stride == stride;
+  const bool hit = !prefetch_q_.empty() && !prefetch_q_.front().host && prefetch_q_.front().l == d_img_l && prefetch_q_.front().r == d_img_r &&
+                   prefetch_q_.front().rows == rows && prefetch_q_.front().cols == cols && prefetch_q_.front().stride == stride;
   if (!prefetch_q_.empty() && !hit) {  // a different pair was announced: drain and drop what is in flight
     drainPrefetch();
     logError("addStereoImagePairDevice: the prefetched pair was not the one passed in; prefetch discarded");
@@ -580,7 +614,7 @@ void SuperPointFeatureFrontEnd::addStereoImagePairDevice(const void *d_img_l, co
 void SuperPointFeatureFrontEnd::prefetchStereoImagePairDevice(const void *d_img_l, const void *d_img_r, int rows, int cols, size_t stride) {
   if (!engine_loaded_ || prefetch_q_.size() >= 2) return;
   for (const auto &q : prefetch_q_)   // already announced
-    if (q.l == d_img_l && q.r == d_img_r && q.rows == rows && q.cols == cols && q.stride == stride) return;
+    if (!q.host && q.l == d_img_l && q.r == d_img_r && q.rows == rows && q.cols == cols && q.stride == stride) return;
   Prefetch pf;
   pickSlots(&pf.slot_l, &pf.slot_r);
   if (spvo_detect_dev_submit(ctx_, d_img_l, d_img_r, rows, cols, stride, pf.slot_l, pf.slot_r) != SPVO_OK) {

@@ -344,6 +344,10 @@ public:
   // addStereoImagePairDevice with the same pointers only collects the result.  Purely a latency-hiding
   // hint: results are identical with or without it.
   void prefetchStereoImagePairDevice(const void *d_img_l, const void *d_img_r, int rows, int cols, size_t stride);
+  // Extension: the same hint for HOST images (the node's message queue holds the next pairs before their turn:
+  // ApproximateTime queue of 20, node.cpp:307-313).  The images are copied to pinned staging at once, so the caller may
+  // reuse them; the following addStereoImagePair with the same images (same data pointers and size) only collects.
+  void prefetchStereoImagePair(const cv::Mat &img_l, const cv::Mat &img_r);
   spvo_ctx *context() const { return ctx_; }
 
   inline int getInputHeight() const { return input_height_; }
@@ -365,9 +369,10 @@ private:
   bool engine_loaded_ = false;
   std::vector<float> xy_buf_[2], desc_buf_[2];
   struct Prefetch {
-    const void *l = nullptr, *r = nullptr;
+    const void *l = nullptr, *r = nullptr;   // device pointers, or the data pointers of host images
     int rows = 0, cols = 0, slot_l = 0, slot_r = 0;
     size_t stride = 0;
+    bool host = false;
   };
   std::deque<Prefetch> prefetch_q_;   // pairs announced ahead (at most 2), oldest first
   int next_pair_ = 0;                 // ring of 4 slot pairs: previous, current and two in flight

@@ -37,6 +37,26 @@ void spvo_host_add_stereo_pair(void *h, const uint8_t *img_l, const uint8_t *img
   fe->addStereoImagePair(l, r, pl, pr);
 }
 
+// Host images kept as cv::Mat objects, like the messages cv_bridge hands to the node: created once, then passed by (shallow) header
+// copy -- addStereoImagePair replaces the caller's header with the resized image, the stored one keeps the original.
+void *spvo_host_make_image(const uint8_t *img, int rows, int cols) {
+  auto *m = new cv::Mat(rows, cols, CV_8UC1);
+  for (int r = 0; r < rows; ++r) std::memcpy(m->ptr<uint8_t>(r), img + (size_t)r * cols, (size_t)cols);
+  return m;
+}
+void spvo_host_free_image(void *m) { delete static_cast<cv::Mat *>(m); }
+
+void spvo_host_add_stereo_pair_mat(void *h, void *img_l, void *img_r, const double *P_l, const double *P_r) {
+  cv::Mat l = *static_cast<cv::Mat *>(img_l), r = *static_cast<cv::Mat *>(img_r), pl(3, 4, CV_64FC1), pr(3, 4, CV_64FC1);
+  std::memcpy(pl.data, P_l, 12 * sizeof(double));
+  std::memcpy(pr.data, P_r, 12 * sizeof(double));
+  static_cast<SuperPointFeatureFrontEnd *>(h)->addStereoImagePair(l, r, pl, pr);
+}
+
+void spvo_host_prefetch_mat(void *h, void *img_l, void *img_r) {
+  static_cast<SuperPointFeatureFrontEnd *>(h)->prefetchStereoImagePair(*static_cast<cv::Mat *>(img_l), *static_cast<cv::Mat *>(img_r));
+}
+
 void spvo_host_add_stereo_pair_dev(void *h, const void *d_l, const void *d_r, int rows, int cols, size_t stride, const double *P_l, const double *P_r,
                                    int host_descriptors) {
   auto *fe = static_cast<SuperPointFeatureFrontEnd *>(h);

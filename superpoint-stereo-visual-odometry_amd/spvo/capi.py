@@ -58,7 +58,7 @@ OBS_DTYPE = np.dtype([("X", np.float32, 3), ("uv", np.float32, 2), ("cam", np.in
 SYMBOLS = [
     "spvo_default_config", "spvo_create", "spvo_destroy", "spvo_last_error", "spvo_load_weights", "spvo_engine_precision", "spvo_set_fp32_split",
     "spvo_preprocess", "spvo_forward", "spvo_debug_tensor", "spvo_heatmap", "spvo_nms",
-    "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_detect_dev_submit", "spvo_detect_wait", "spvo_match", "spvo_match_slots", "spvo_set_prematch", "spvo_set_match_fp8",
+    "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_detect_dev_submit", "spvo_detect_wait", "spvo_detect_submit", "spvo_detect_collect", "spvo_match", "spvo_match_slots", "spvo_set_prematch", "spvo_set_match_fp8",
     "spvo_triangulate", "spvo_pnp_ransac", "spvo_pnp_refine", "spvo_solve_stereo_odometry", "spvo_stream", "spvo_synchronize",
     "spvo_profile_enable", "spvo_profile_reset", "spvo_profile_only", "spvo_profile_count", "spvo_profile_get",
     "spvo_comm_unique_id", "spvo_comm_create", "spvo_comm_create_host", "spvo_comm_rank", "spvo_comm_world", "spvo_comm_destroy",
@@ -97,6 +97,8 @@ def load() -> C.CDLL:
                                     C.POINTER(Features), C.POINTER(Features)]
     lib.spvo_detect_dev_submit.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int]
     lib.spvo_detect_wait.argtypes = [vp, dp, dp, C.POINTER(Features), C.POINTER(Features)]
+    lib.spvo_detect_submit.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int]
+    lib.spvo_detect_collect.argtypes = [vp, dp, dp, C.POINTER(Features), C.POINTER(Features), vp, vp]
     lib.spvo_match.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
     lib.spvo_match_slots.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
     lib.spvo_set_prematch.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float]
@@ -275,6 +277,27 @@ class Context:
     def detect_dev_submit(self, d_img_l: int, d_img_r: int, rows: int, cols: int, stride: int, slot_l: int, slot_r: int):
         """Enqueue a detector pass (at most two may be in flight); complete them oldest-first with detect_wait."""
         self._check(self.lib.spvo_detect_dev_submit(self.h, C.c_void_p(d_img_l), C.c_void_p(d_img_r), rows, cols, stride, slot_l, slot_r))
+
+    def detect_submit(self, img_l: np.ndarray, img_r: np.ndarray, slot_l: int, slot_r: int, extras: int = 3):
+        """Asynchronous detector pass on HOST images (spvo_detect_submit); complete with detect_collect."""
+        img_l = np.ascontiguousarray(img_l, np.uint8)
+        img_r = np.ascontiguousarray(img_r, np.uint8)
+        self._check(self.lib.spvo_detect_submit(self.h, _ptr(img_l), _ptr(img_r), img_l.shape[0], img_l.shape[1], img_l.strides[0], slot_l, slot_r, extras))
+
+    def detect_collect(self, P_l, P_r, want_desc=True, want_resized=True):
+        Pl = np.ascontiguousarray(P_l, np.float64).reshape(12).copy()
+        Pr = np.ascontiguousarray(P_r, np.float64).reshape(12).copy()
+        fl, xyl, dl = self._features(want_desc)
+        fr, xyr, dr = self._features(want_desc)
+        rl = np.empty((self.H, self.W), np.uint8) if want_resized else None
+        rr = np.empty((self.H, self.W), np.uint8) if want_resized else None
+        self._check(self.lib.spvo_detect_collect(self.h, _dptr(Pl), _dptr(Pr), C.byref(fl), C.byref(fr), _ptr(rl), _ptr(rr)))
+        out = dict(xy_l=xyl[:fl.n].copy(), xy_r=xyr[:fr.n].copy(), P_l=Pl.reshape(3, 4), P_r=Pr.reshape(3, 4))
+        if want_desc:
+            out["desc_l"], out["desc_r"] = dl[:fl.n].copy(), dr[:fr.n].copy()
+        if want_resized:
+            out["resized_l"], out["resized_r"] = rl, rr
+        return out
 
     def detect_wait(self, P_l, P_r):
         Pl = np.ascontiguousarray(P_l, np.float64).reshape(12).copy()

@@ -39,6 +39,14 @@ def load():
         lib.spvo_host_add_stereo_pair_dev.restype = None
         lib.spvo_host_prefetch_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t]
         lib.spvo_host_prefetch_dev.restype = None
+        lib.spvo_host_make_image.argtypes = [vp, C.c_int, C.c_int]
+        lib.spvo_host_make_image.restype = vp
+        lib.spvo_host_free_image.argtypes = [vp]
+        lib.spvo_host_free_image.restype = None
+        lib.spvo_host_add_stereo_pair_mat.argtypes = [vp, vp, vp, vp, vp]
+        lib.spvo_host_add_stereo_pair_mat.restype = None
+        lib.spvo_host_prefetch_mat.argtypes = [vp, vp, vp]
+        lib.spvo_host_prefetch_mat.restype = None
         lib.spvo_host_ctx.argtypes = [vp]
         lib.spvo_host_ctx.restype = vp
         lib.spvo_host_match.argtypes = [vp, C.c_int]
@@ -156,6 +164,30 @@ class FrontEnd:
         for nxt in (next_pair, next2_pair):
             if nxt is not None:
                 self.prefetch_device(nxt[0], nxt[1], rows, cols, stride)   # no-op if already announced
+        if self.dq_size() < 4:
+            self.match_descriptors(CURR_LEFT_CURR_RIGHT)
+            return None
+        self.match_descriptors(CURR_LEFT_CURR_RIGHT)
+        self.match_descriptors(CURR_LEFT_PREV_LEFT)
+        return self.solve_stereo_odometry()
+
+    # ---- host images as cv::Mat objects (what cv_bridge hands to the node): the reference's own entry point
+    def make_image(self, img) -> int:
+        img = np.ascontiguousarray(img, np.uint8)
+        return self.lib.spvo_host_make_image(_p(img), img.shape[0], img.shape[1])
+
+    def free_image(self, handle: int):
+        self.lib.spvo_host_free_image(C.c_void_p(handle))
+
+    def step_host(self, mat_l: int, mat_r: int, P_l, P_r, next_pair=None, next2_pair=None):
+        """One stereoCallback through addStereoImagePair(cv::Mat&, ...) (node.cpp:175) on HOST images; `next_pair` /
+        `next2_pair` = (mat_l, mat_r) handles of the following frames, announced with prefetchStereoImagePair."""
+        Pl = np.ascontiguousarray(P_l, np.float64)
+        Pr = np.ascontiguousarray(P_r, np.float64)
+        self.lib.spvo_host_add_stereo_pair_mat(self.h, C.c_void_p(mat_l), C.c_void_p(mat_r), _p(Pl), _p(Pr))
+        for nxt in (next_pair, next2_pair):
+            if nxt is not None:
+                self.lib.spvo_host_prefetch_mat(self.h, C.c_void_p(nxt[0]), C.c_void_p(nxt[1]))
         if self.dq_size() < 4:
             self.match_descriptors(CURR_LEFT_CURR_RIGHT)
             return None

@@ -128,6 +128,52 @@ def test_prefetch_pipeline_is_transparent(models_dir, sequence):
                 assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1])      # poses: bit-identical
 
 
+def test_the_reference_entry_point_with_host_images_equals_the_device_entry(models_dir, sequence):
+    """addStereoImagePair(cv::Mat&, ...) -- the reference's own interface (node.cpp:175): host images in, resized images and
+    descriptors back in images_dq / descriptors_dq -- without look-ahead, with one and with two pairs announced through
+    prefetchStereoImagePair, and the device-resident entry: the same keypoints, descriptors, index maps, inliers and poses,
+    bit for bit."""
+    import torch
+    frames, poses, P_l, P_r = sequence
+    rows, cols = frames[0][0].shape
+    out = {}
+    for mode in ("device", 0, 1, 2):
+        fe = host.FrontEnd(models_dir, prefix="sp_squeeze")
+        res = []
+        if mode == "device":
+            dev = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
+            for k, (dl, dr) in enumerate(dev):
+                fe.add_stereo_image_pair_device(dl.data_ptr(), dr.data_ptr(), rows, cols, dl.stride(0), P_l, P_r, host_descriptors=True)
+                fe.match_descriptors(host.CURR_LEFT_CURR_RIGHT)
+                r = None
+                if k:
+                    fe.match_descriptors(host.CURR_LEFT_PREV_LEFT)
+                    r = fe.solve_stereo_odometry()
+                res.append((r, fe.keypoints(host.CURR_LEFT), fe.descriptors(host.CURR_RIGHT), fe.map_of_indices(0), fe.map_of_indices(1) if k else None,
+                            fe.inliers("pnp"), None))
+        else:
+            mats = [(fe.make_image(L), fe.make_image(R)) for L, R in frames]
+            for k in range(len(frames)):
+                ahead = [mats[k + d] if d <= mode and k + d < len(mats) else None for d in (1, 2)]
+                r = fe.step_host(mats[k][0], mats[k][1], P_l, P_r, ahead[0], ahead[1])
+                res.append((r, fe.keypoints(host.CURR_LEFT), fe.descriptors(host.CURR_RIGHT), fe.map_of_indices(0), fe.map_of_indices(1) if k else None,
+                            fe.inliers("pnp"), fe.image(host.CURR_LEFT)))
+            for m in mats:
+                fe.free_image(m[0]); fe.free_image(m[1])
+        out[mode] = res
+        fe.close()
+    from oracle import frontend as ofe
+    for mode in (0, 1, 2):
+        for k, (a, b) in enumerate(zip(out["device"], out[mode])):
+            for i in (1, 2, 3, 5):
+                assert np.array_equal(a[i], b[i]), (mode, k, i)
+            if a[4] is not None:
+                assert np.array_equal(a[4], b[4])
+            if a[0] is not None:
+                assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1])      # poses: bit-identical
+            assert np.array_equal(b[6], ofe.preprocess(frames[k][0], P_l, 360, 1176)[0])           # images_dq holds the resized u8 image (nn.cpp:154)
+
+
 def test_fp16_engine_through_the_host_class(tmp_path, squeeze_weights_path, sequence):
     """TensorRtPrecision::FP16 (hpp:124-126): the front end loads `<prefix>_<B>_<H>_<W>_FP16.spvw`, refuses a file
     of the other precision, and tracks the synthetic ego-motion like the FP32 engine (the trained squeeze weights;

@@ -281,3 +281,36 @@ def test_fp8_shortlist_matcher(ctx_squeeze, stereo_pair):
     assert (nn_idx != r_nn).mean() < 0.01 and np.array_equal(nn_d[nn_idx == r_nn], r_nnd[nn_idx == r_nn])
     idx2, d2_ = ctx_squeeze.match_slots(0, 1, n)                              # back to the fp32 shortlist: exact again
     assert np.array_equal(idx2, ridx) and np.array_equal(d2_, rd)
+
+
+def test_host_image_submissions_are_bit_identical_to_the_synchronous_entry(ctx_squeeze, stereo_pair):
+    """spvo_detect_submit / spvo_detect_collect (host images through pinned staging, two submissions in flight, resized
+    images and descriptors in the submissions' pinned mirrors) against spvo_detect on the same pairs: every output
+    bit for bit -- keypoints, descriptors, the resized u8 images, the projection matrices -- and the same matches."""
+    frames, _, P_l, P_r = stereo_pair
+    ref = [ctx_squeeze.detect(L, R, P_l, P_r, 2 * k, 2 * k + 1, want_resized=True) for k, (L, R) in enumerate(frames[:2])]
+    n = len(ref[1]["xy_l"])
+    ref_m = (ctx_squeeze.match_slots(2, 3, n), ctx_squeeze.match_slots(2, 0, n))
+    ref_m = tuple((i.copy(), d.copy()) for i, d in ref_m)
+    ctx_squeeze.set_prematch(True, "KNN", False, 0.8)
+    ctx_squeeze.detect_submit(frames[0][0].copy(), frames[0][1].copy(), 4, 5)     # temporaries: the call copies them before it returns
+    ctx_squeeze.detect_submit(frames[1][0].copy(), frames[1][1].copy(), 6, 7)
+    got = [ctx_squeeze.detect_collect(P_l, P_r), ctx_squeeze.detect_collect(P_l, P_r)]
+    for g, r in zip(got, ref):
+        for k in ("xy_l", "xy_r", "desc_l", "desc_r", "resized_l", "resized_r", "P_l", "P_r"):
+            assert np.array_equal(g[k], r[k]), k
+    got_m = (ctx_squeeze.match_slots(6, 7, n), ctx_squeeze.match_slots(6, 4, n))
+    for (gi, gd), (ri, rd) in zip(got_m, ref_m):
+        assert np.array_equal(gi, ri) and np.array_equal(gd, rd)
+    ctx_squeeze.set_prematch(False, "KNN", False, 0.8)
+    # extras not requested at submit time cannot be fetched while a younger submission is in flight -- and the refusal
+    # leaves the queue intact (the oldest submission is still collectable)
+    from spvo import capi
+    ctx_squeeze.detect_submit(frames[0][0], frames[0][1], 0, 1, extras=0)
+    ctx_squeeze.detect_submit(frames[1][0], frames[1][1], 2, 3, extras=0)
+    with pytest.raises(capi.SpvoError) as e:
+        ctx_squeeze.detect_collect(P_l, P_r)
+    assert e.value.code == -4
+    a = ctx_squeeze.detect_collect(P_l, P_r, want_desc=False, want_resized=False)
+    b = ctx_squeeze.detect_collect(P_l, P_r, want_desc=True, want_resized=True)   # the last one in flight may fetch anything
+    assert np.array_equal(a["xy_l"], ref[0]["xy_l"]) and np.array_equal(b["desc_r"], ref[1]["desc_r"]) and np.array_equal(b["resized_l"], ref[1]["resized_l"])
