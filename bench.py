@@ -46,6 +46,19 @@ def cpu_model():
     return "unknown"
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask, cut to the cgroup's CPU quota (a container with `cpu.max` = 16 CPUs
+    on a 256-thread host runs 128 OpenMP threads 6x SLOWER than 16: measured, tools/cpu_scaling.py)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(frames, P_l, P_r, weights_path, order, budget_s=25.0):
     """The CPU restatement of the whole stereoCallback (oracle/cpu: plain C++17 + OpenMP, `-O3 -march=native` rebuilt on THIS
     machine) timed on the host cores: a bounded sample of the same workload -- 5 warm-up frames, then up to 50 timed frames
@@ -60,7 +73,7 @@ def cpu_baseline(frames, P_l, P_r, weights_path, order, budget_s=25.0):
         arch = "native"
     except Exception:   # no compiler on this machine: the library built by __graft_entry__.build()
         pass
-    cpu = cpu_backend.CpuBackend(lib, net_height=NET_H, net_width=NET_W)
+    cpu = cpu_backend.CpuBackend(lib, net_height=NET_H, net_width=NET_W, num_threads=usable_cpus())
     cpu.load_weights(weights_path)
     cpu.frontend_reset("KNN", True, 2.0, 0.25, 4)
     rows, t_start, k = [], time.time(), 0
@@ -78,12 +91,13 @@ def cpu_baseline(frames, P_l, P_r, weights_path, order, budget_s=25.0):
     threads = cpu.threads
     cpu.close()
     return {"value": round(1e3 / float(med[3]), 3), "unit": "stereo frames/s", "cores": int(threads), "kind": "port",
-            "cpu_model": cpu_model(), "host_cpus": os.cpu_count(),
+            "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "cpu_quota": usable_cpus(),
             "stage_median_ms": {"detect": round(float(med[0]), 2), "match": round(float(med[1]), 2), "solve": round(float(med[2]), 2), "total": round(float(med[3]), 2)},
             "refined_rate": round(float(a[:, 5].mean()), 3), "mean_inliers": round(float(a[:, 4].mean()), 1),
             "sample": f"{len(rows)} stereo frames after {warm} warm-ups through oracle/cpu (C++17 + OpenMP restatement of the whole step: "
                       f"crop/resize, VGG fp32 direct convolution, softmax/NMS, descriptor sampling, brute-force L2 matching, triangulation, "
-                      f"RANSAC, LM), g++ -O3 -march={arch}, {threads} OpenMP threads; median of per-frame totals"}
+                      f"RANSAC, LM), g++ -O3 -march={arch}, {threads} OpenMP threads (= the CPUs this process may use: affinity mask and cgroup quota); "
+                      f"median of per-frame totals"}
 
 
 def main():

@@ -40,6 +40,10 @@
 
 namespace spvo {
 
+#ifndef WINO_STORE_AUX
+#define WINO_STORE_AUX 0   // cache policy of the output stores (experiments: 16 = sc1, write-through)
+#endif
+
 struct WinoTile {
   static constexpr int CK = 8, TH = 8, TW = 32, LW = TW + 8, LH = TH + 2;
   static constexpr int IN_FLOATS = CK * LH * LW;            // 3200: raw halo tile, row = x0-4 .. x0+35
@@ -215,6 +219,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
   const int a_lane = half * CO_TILE + cb * 32 + j;   // 16-byte pieces in a filter slab: + xi * 128
   const int b_lane = half * 64 + tb * 32 + j;        // 16-byte pieces in a V buffer:    + xi * 128
 
+#ifdef WINO_STAMPS   // diagnostic build (tools/wino_bench.hip -DWINO_STAMPS): 100 MHz wall-clock stamps per workgroup
+  const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long stamp_epi = 0;
+#endif
   int tile_id = blockIdx.x;
   if (tile_id >= n_tiles) return;
   TileRef cur = decode(tile_id);
@@ -313,6 +321,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     drained = true;
 
+#ifdef WINO_STAMPS
+    stamp_epi = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---------------------------------------------------------------- epilogue: Y = A^T M A, ReLU, (pool), store
     float *co_base = a.out + (((size_t)cur.img * a.out_ctot + a.out_coff) + (size_t)cur.ct * CO_TILE + cb * 32) * out_plane;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(co_base, 0, 0x7FFFFFFF, 0x00020000);
@@ -350,25 +361,33 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
       const float y00 = relu(ya[0]), y01 = relu(ya[1]), y10 = relu(yb[0]), y11 = relu(yb[1]);
       const unsigned vo = k < kmax ? voff : OOB;
       if constexpr (POOL) {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaxf(fmaxf(y00, y01), fmaxf(y10, y11))), rsrc, vo, k * oplane * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaxf(fmaxf(y00, y01), fmaxf(y10, y11))), rsrc, vo, k * oplane * 4, WINO_STORE_AUX);
       } else if constexpr (!ODD) {
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         const u32x2 r0 = {__float_as_uint(y00), __float_as_uint(y01)}, r1 = {__float_as_uint(y10), __float_as_uint(y11)};
-        __builtin_amdgcn_raw_buffer_store_b64(r0, rsrc, vo, k * oplane * 4, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(r1, rsrc, vo == OOB ? OOB : vo + 4u * (unsigned)a.out_wp, k * oplane * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(r0, rsrc, vo, k * oplane * 4, WINO_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(r1, rsrc, vo == OOB ? OOB : vo + 4u * (unsigned)a.out_wp, k * oplane * 4, WINO_STORE_AUX);
       } else {
         // odd H or W: the second row / column of the last tiles is outside the image and must stay zero (it is the next
         // layer's halo), so the four outputs leave one by one
         const unsigned v00 = k < kmax ? voff : OOB, v01 = k < kmax ? voff01 : OOB, v10 = k < kmax ? voff10 : OOB, v11 = k < kmax ? voff11 : OOB;
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y00), rsrc, v00, k * oplane * 4, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y01), rsrc, v01, k * oplane * 4, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y10), rsrc, v10, k * oplane * 4, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y11), rsrc, v11, k * oplane * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y00), rsrc, v00, k * oplane * 4, WINO_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y01), rsrc, v01, k * oplane * 4, WINO_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y10), rsrc, v10, k * oplane * 4, WINO_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y11), rsrc, v11, k * oplane * 4, WINO_STORE_AUX);
       }
       __builtin_amdgcn_sched_barrier(0);   // one register index at a time: 16 accumulator reads live, not 256
     }
     cur = nxt;
   }
+#ifdef WINO_STAMPS
+  if (tid == 0 && a.stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    a.stamps[3 * blockIdx.x] = stamp0;
+    a.stamps[3 * blockIdx.x + 1] = stamp_epi;   // start of the last epilogue
+    a.stamps[3 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 }  // namespace spvo

@@ -1,0 +1,373 @@
+// conv_wino2.hip.h -- K2w, second form: the Winograd F(2x2, 3x3) convolution of conv_wino.hip.h with TWO waves per SIMD.
+//
+// Same algorithm, same tile (64 output channels x 64 Winograd tiles = 8 rows x 32 columns of output per workgroup), same
+// LDS-DMA staging, same interleaved input transform, same in-register epilogue -- see conv_wino.hip.h for all of that and for
+// the reference it replaces (the TensorRT engine enqueued at feature_detection_neural_network.cpp:169).  What changes is who
+// holds the accumulators.  The first form gives each of 4 waves a 32 x 32 block of all 16 transform positions: 256 accumulator
+// registers, so ONE wave per SIMD, and every instruction that wave issues which is not a matrix instruction -- 13 LDS-DMA
+// pieces, 40 transform micro-steps, 32 operand reads, the barrier -- is time the matrix pipe of that SIMD may stand still
+// (measured: ~6000 cycles per item for 4096 cycles of matrix work).  Here the workgroup has 8 waves; wave (cq, tb) owns 16
+// output channels x 32 tiles x 16 positions on v_mfma_f32_16x16x4_f32 (two 16 x 16 blocks per position): 128 accumulator
+// registers, 256 registers per wave, two waves per SIMD.  Each wave issues half the matrix instructions and half of
+// everything else; while one of a SIMD's two waves waits -- on an LDS-DMA issue, a transform step, the barrier -- the other
+// one's matrix instructions keep the pipe busy.
+//
+// LDS images (the staging loads stay lane-linear 16-byte pieces):
+//   U  [xi 16][cq 4][lane 64][s 2]          lane = 16 (ci & 3) + (co & 15), s = ci >> 2: a lane's two k-steps of one position
+//                                           are one 8-byte piece (ds_read_b64, conflict-free)
+//   V  [xi 16][tb 2][lane 64][blk 2][s 2]   lane = 16 (ci & 3) + (tile & 15), blk = (tile >> 4) & 1: both 16-tile blocks and
+//                                           both k-steps of one position are one 16-byte piece (ds_read_b128)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include <vector>
+#include "conv_mfma.hip.h"
+#include "conv_wino.hip.h"
+
+namespace spvo {
+
+// OIHW weights + bias -> slabs [co_tile][chunk][xi 16][cq 4][lane 64][s 2] of U = G g G^T (double) + a bias row
+inline std::vector<float> pack_conv_weights_wino2(const float *w, const float *bias, int cout, int cin) {
+  constexpr int CK = WinoTile::CK;
+  const int co_tiles = (cout + CO_TILE - 1) / CO_TILE, nch = cin / CK;
+  std::vector<float> out((size_t)co_tiles * nch * WinoTile::W_FLOATS, 0.f);
+  static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  for (int ct = 0; ct < co_tiles; ++ct)
+    for (int ch = 0; ch < nch; ++ch) {
+      float *slab = out.data() + ((size_t)ct * nch + ch) * WinoTile::W_FLOATS;
+      for (int o = 0; o < CO_TILE; ++o) {
+        const int co = ct * CO_TILE + o;
+        if (co >= cout) continue;
+        for (int c = 0; c < CK; ++c) {
+          const float *g = w + ((size_t)co * cin + ch * CK + c) * 9;
+          double t[4][3];
+          for (int a = 0; a < 4; ++a)
+            for (int k = 0; k < 3; ++k) t[a][k] = G[a][0] * g[0 * 3 + k] + G[a][1] * g[1 * 3 + k] + G[a][2] * g[2 * 3 + k];
+          const int lane = 16 * (c & 3) + (o & 15), s = c >> 2, cq = o >> 4;
+          for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b)
+              slab[((((a * 4 + b) * 4 + cq) * 64 + lane) * 2) + s] = (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
+        }
+        if (ch == 0) slab[WinoTile::U_FLOATS + o] = bias[co];
+      }
+    }
+  return out;
+}
+
+template <bool POOL, bool RELU, int TAG = 0, bool ODD = false>
+__global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
+  using T = WinoTile;
+  constexpr int CK = T::CK, LW = T::LW, LH = T::LH, LW4 = LW / 4;
+  constexpr int IN_V4 = T::IN_FLOATS / 4, W_V4 = T::W_FLOATS / 4;
+  constexpr int NIT_R = (IN_V4 + 511) / 512, NIT_U = (W_V4 + 511) / 512;   // 2, 5
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cq = wave & 3, tb = wave >> 2;
+  const size_t in_plane = (size_t)a.in_hp * a.in_wp;
+  const size_t out_plane = (size_t)a.out_hp * a.out_wp;
+  const int n_tiles = a.tiles_x * a.tiles_y * a.co_tiles * a.batch;
+
+  struct TileRef { const float *in_base, *w_base; int x0, y0, ct, img; };
+  auto decode = [&](int id) {
+    TileRef t;
+    const int tx = id % a.tiles_x;
+    id /= a.tiles_x;
+    const int ty = id % a.tiles_y;
+    id /= a.tiles_y;
+    t.ct = id % a.co_tiles;
+    t.img = id / a.co_tiles;
+    t.x0 = tx * T::TW;
+    t.y0 = ty * T::TH;
+    t.in_base = a.in + ((size_t)t.img * a.in_ctot + a.in_coff) * in_plane + (size_t)(t.y0 + PADY - 1) * a.in_wp + (t.x0 + PADX - 4);
+    t.w_base = a.wpack + (size_t)t.ct * a.n_chunks * T::W_FLOATS;
+    return t;
+  };
+
+  // staging plans: this thread's 16-byte pieces of a raw tile / of a filter slab (wave-uniform 64-bit base + 32-bit lane offset)
+  unsigned roff[NIT_R];
+#pragma unroll
+  for (int it = 0; it < NIT_R; ++it) {
+    const int idx = min(it * 512 + tid, IN_V4 - 1);
+    const int ci = idx / (LH * LW4);
+    const int rem = idx - ci * (LH * LW4);
+    const int r = rem / LW4;
+    const int q = rem - r * LW4;
+    roff[it] = 4u * (unsigned)(ci * (int)in_plane + r * a.in_wp + q * 4);
+  }
+  auto issue_raw = [&](const TileRef &t, int chunk, float *buf) {
+    const char *inb = reinterpret_cast<const char *>(t.in_base + (size_t)chunk * CK * in_plane);
+#pragma unroll
+    for (int it = 0; it < NIT_R; ++it)
+      if (it < NIT_R - 1 || it * 512 + tid < IN_V4) glds16(reinterpret_cast<const float *>(inb + roff[it]), buf + (it * 512 + wave * 64) * 4);
+  };
+  const unsigned uoff = 16u * (unsigned)tid;
+  auto issue_u = [&](const TileRef &t, int chunk, float *buf) {
+    const char *wb = reinterpret_cast<const char *>(t.w_base + (size_t)chunk * T::W_FLOATS);
+#pragma unroll
+    for (int it = 0; it < NIT_U; ++it)
+      if (it < NIT_U - 1 || it * 512 + tid < W_V4) glds16(reinterpret_cast<const float *>(wb + (uoff + 8192u * it)), buf + (it * 512 + wave * 64) * 4);
+  };
+
+  auto issue_raw_piece = [&](const TileRef &t, int chunk, float *buf, int it) {
+    const char *inb = reinterpret_cast<const char *>(t.in_base + (size_t)chunk * CK * in_plane);
+    if (it < NIT_R - 1 || it * 512 + tid < IN_V4) glds16(reinterpret_cast<const float *>(inb + roff[it]), buf + (it * 512 + wave * 64) * 4);
+  };
+  auto issue_u_piece = [&](const TileRef &t, int chunk, float *buf, int it) {
+    const char *wb = reinterpret_cast<const char *>(t.w_base + (size_t)chunk * T::W_FLOATS);
+    if (it < NIT_U - 1 || it * 512 + tid < W_V4) glds16(reinterpret_cast<const float *>(wb + (uoff + 8192u * it)), buf + (it * 512 + wave * 64) * 4);
+  };
+
+  // input transform: ONE patch per thread -- tile t_tile of input channel `wave` of the chunk
+  const int t_tile = tid & 63;
+  const int t_trow = t_tile >> 4, t_tcol = t_tile & 15;
+  const int raw_off = wave * (LH * LW) + (2 * t_trow) * LW + 3 + 2 * t_tcol;   // LDS row 0 = output row y0 - 1, LDS column 4 = output column x0
+  const int v_off = (((t_tile >> 5) * 64 + 16 * (wave & 3) + t_tcol) * 4) + 2 * ((t_tile >> 4) & 1) + (wave >> 2);   // + xi * 512
+  auto transform = [&](const float *raw, float *vb) {
+    const float *d = raw + raw_off;
+    float t[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float d0 = d[0 * LW + q], d1 = d[1 * LW + q], d2 = d[2 * LW + q], d3 = d[3 * LW + q];
+      t[0][q] = d0 - d2; t[1][q] = d1 + d2; t[2][q] = d2 - d1; t[3][q] = d1 - d3;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float *v = vb + v_off + (r * 4) * 512;
+      v[0 * 512] = t[r][0] - t[r][2];
+      v[1 * 512] = t[r][1] + t[r][2];
+      v[2 * 512] = t[r][2] - t[r][1];
+      v[3 * 512] = t[r][1] - t[r][3];
+    }
+  };
+  // the same in 20 micro-steps for the matrix stream: 0..11 read patch row u / 3 as three aligned 8-byte pairs (columns c0-1 ..
+  // c0+4, of which c0 .. c0+3 are the patch); 12..15 column q of B^T d; 16..19 row r of (B^T d) B, stored
+  f32x2 dp[12];
+  float tt[16];
+  auto xf_step = [&](const float *raw, float *vb, int st) {
+    if (st < 12) {
+      dp[st] = *reinterpret_cast<const f32x2 *>(raw + raw_off - 1 + (st / 3) * LW + 2 * (st % 3));
+    } else if (st < 16) {
+      const int q = st - 12;
+      auto d = [&](int r) { return q == 0 ? dp[3 * r][1] : q == 1 ? dp[3 * r + 1][0] : q == 2 ? dp[3 * r + 1][1] : dp[3 * r + 2][0]; };
+      tt[0 * 4 + q] = d(0) - d(2);
+      tt[1 * 4 + q] = d(1) + d(2);
+      tt[2 * 4 + q] = d(2) - d(1);
+      tt[3 * 4 + q] = d(1) - d(3);
+    } else {
+      const int r = st - 16;
+      float *v = vb + v_off + (r * 4) * 512;
+      v[0 * 512] = tt[r * 4 + 0] - tt[r * 4 + 2];
+      v[1 * 512] = tt[r * 4 + 1] + tt[r * 4 + 2];
+      v[2 * 512] = tt[r * 4 + 2] - tt[r * 4 + 1];
+      v[3 * 512] = tt[r * 4 + 1] - tt[r * 4 + 3];
+    }
+  };
+  const int a_lane = cq * 64 + lane;   // 8-byte pieces in a filter slab:  + xi * 256
+  const int b_lane = tb * 64 + lane;   // 16-byte pieces in a V buffer:    + xi * 128
+
+  int tile_id = blockIdx.x;
+  if (tile_id >= n_tiles) return;
+  TileRef cur = decode(tile_id);
+
+  // prefetch cursors over the item sequence: filters one item ahead, raw tiles two items ahead
+  struct Cursor { TileRef t; int chunk, id; };
+  auto advance = [&](Cursor &q) {
+    if (++q.chunk == a.n_chunks) {
+      q.chunk = 0;
+      q.id += gridDim.x;
+      if (q.id < n_tiles) q.t = decode(q.id);
+    }
+  };
+  Cursor cu{cur, 0, tile_id};
+  issue_raw(cu.t, 0, smem + T::RAW_OFF);
+  issue_u(cu.t, 0, smem + T::U_OFF);
+  advance(cu);                                   // item 1
+  if (cu.id < n_tiles) issue_raw(cu.t, cu.chunk, smem + T::RAW_OFF + T::IN_FLOATS);
+  Cursor cr = cu;
+  advance(cr);                                   // item 2
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  transform(smem + T::RAW_OFF, smem + T::V_OFF);   // item 0's transform has nothing to hide behind
+
+#ifdef WINO_STAMPS   // diagnostic build: shader-clock cycles per wave spent waiting for LDS-DMA, at the barrier, in the matrix stream, in epilogues
+  unsigned long long st_dma = 0, st_bar = 0, st_mfma = 0, st_epi = 0, st_items = 0;
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  int k = 0;                    // items done: selects the buffers
+  bool drained = true;          // the LDS-DMA this item needs has been waited for already
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+
+  for (; tile_id < n_tiles; tile_id += gridDim.x) {
+    const int next_id = tile_id + gridDim.x;
+    TileRef nxt = cur;
+    if (next_id < n_tiles) nxt = decode(next_id);
+
+    // acc[xi][blk]: position xi, tiles 16 blk .. 16 blk + 15 of this wave's 32; register r of a block = output channel 4 g4 + r
+    f32x4v acc[16][2];
+    auto item = [&](auto first_tag) {
+      constexpr bool FIRST = decltype(first_tag)::value;   // the tile's first chunk: C = 0 in every accumulator's first instruction
+#ifdef WINO_STAMPS
+      const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
+      if (!drained) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      drained = false;
+#ifdef WINO_STAMPS
+      const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef WINO_STAMPS
+      const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+      st_dma += ts1 - ts0; st_bar += ts2 - ts1;
+#endif
+      const float *ub = smem + T::U_OFF + (k & 1) * T::W_FLOATS;
+      const float *vb = smem + T::V_OFF + (k & 1) * T::V_FLOATS;
+      float *u_next = smem + T::U_OFF + ((k + 1) & 1) * T::W_FLOATS;
+      float *raw_next2 = smem + T::RAW_OFF + (k & 1) * T::IN_FLOATS;          // raw(k+2) replaces raw(k), transformed during item k-1
+      const float *raw_next = smem + T::RAW_OFF + ((k + 1) & 1) * T::IN_FLOATS;
+      float *v_next = smem + T::V_OFF + ((k + 1) & 1) * T::V_FLOATS;
+      const f32x2 *ub2 = reinterpret_cast<const f32x2 *>(ub);
+      const f32x4v *vb4 = reinterpret_cast<const f32x4v *>(vb);
+      {
+        // 64 matrix instructions in 4 groups of 4 positions; per position one ds_read_b64 (A: two k-steps) and one ds_read_b128
+        // (B: two blocks x two k-steps), read while the previous group multiplies.  Inside a group: k-step outer, position, block
+        // inner -- an accumulator is revisited after 7 other instructions.
+        f32x2 av[4];
+        f32x4v bv[4];
+        auto ld = [&](int g, int x) {
+          av[x] = ub2[a_lane + (4 * g + x) * 256];
+          bv[x] = vb4[b_lane + (4 * g + x) * 128];
+        };
+#pragma unroll
+        for (int x = 0; x < 4; ++x) ld(0, x);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int s = q >> 3, x = (q >> 1) & 3, blk = q & 1;
+            if (FIRST && s == 0) acc[4 * g + x][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[x][s], bv[x][2 * blk + s], f32x4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            else acc[4 * g + x][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[x][s], bv[x][2 * blk + s], acc[4 * g + x][blk], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef WINO2_ABL
+#define WINO2_ABL 0   // timing experiments only (results are wrong when != 0): 1 no transform steps, 2 no LDS-DMA, 4 no operand reads in the loop
+#endif
+#ifndef WINO2_SPREAD
+#define WINO2_SPREAD 0   // 1: one LDS-DMA piece per matrix instruction instead of two bursts
+#endif
+            const int slot = 16 * g + q;
+            if (!(WINO2_ABL & 2)) {
+              if (WINO2_SPREAD) {
+                if (slot >= 1 && slot < 1 + 2 * NIT_U && (slot & 1) && cu.id < n_tiles) issue_u_piece(cu.t, cu.chunk, u_next, (slot - 1) >> 1);
+                if (slot >= 1 + 2 * NIT_U && slot < 1 + 2 * NIT_U + 2 * NIT_R && (slot & 1) && cr.id < n_tiles) issue_raw_piece(cr.t, cr.chunk, raw_next2, (slot - 1 - 2 * NIT_U) >> 1);
+              } else {
+                if (slot == 1 && cu.id < n_tiles) issue_u(cu.t, cu.chunk, u_next);
+                if (slot == 5 && cr.id < n_tiles) issue_raw(cr.t, cr.chunk, raw_next2);
+              }
+            }
+            if (!(WINO2_ABL & 4) && g < 3 && q >= 12) ld(g + 1, q - 12);   // position x's registers were last read by instruction 9 + 2 x
+            // input transform of item k+1: 20 micro-steps on every other instruction slot (staggering them between the two waves of
+            // a SIMD, or packing them densely, measured slower)
+            if (!(WINO2_ABL & 1) && slot >= 16 && slot < 56 && !(slot & 1)) xf_step(raw_next, v_next, (slot - 16) >> 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      if (FIRST) {   // bias through position (1,1) (inverse-transform weight +1 for all four outputs): A = (bias, 0, 0, 0), B = 1
+        const float bias_a = g4 ? 0.f : ub[T::U_FLOATS + cq * 16 + c16];
+        acc[5][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bias_a, 1.0f, acc[5][0], 0, 0, 0);
+        acc[5][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bias_a, 1.0f, acc[5][1], 0, 0, 0);
+      }
+      advance(cu);
+      advance(cr);
+      ++k;
+#ifdef WINO_STAMPS
+      st_mfma += __builtin_amdgcn_s_memtime() - ts2;
+      ++st_items;
+#endif
+    };
+    item(std::true_type{});
+    for (int c = 1; c < a.n_chunks; ++c) item(std::false_type{});
+
+    // everything in flight for the next item has landed before this tile's stores queue up behind it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    drained = true;
+
+#ifdef WINO_STAMPS
+    const unsigned long long te0 = __builtin_amdgcn_s_memtime();
+#endif
+    // ---------------------------------------------------------------- epilogue: Y = A^T M A, ReLU, (pool), store
+    float *co_base = a.out + (((size_t)cur.img * a.out_ctot + a.out_coff) + (size_t)cur.ct * CO_TILE + cq * 16) * out_plane;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(co_base, 0, 0x7FFFFFFF, 0x00020000);
+    const int oplane = (int)out_plane;
+    const int kmax = a.cout - (cur.ct * CO_TILE + cq * 16 + 4 * g4);   // channels r < kmax of this lane's 4 exist
+    auto relu = [](float v) { return RELU ? __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()) : v; };
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const int trow = 2 * tb + blk, tcol = c16;
+      unsigned voff, voff01 = OOB, voff10 = OOB, voff11 = OOB;
+      if constexpr (POOL) {
+        const int y = (cur.y0 >> 1) + trow, x = (cur.x0 >> 1) + tcol;
+        voff = (y < (a.H >> 1) && x < (a.W >> 1)) ? 4u * (unsigned)(4 * g4 * oplane + (y + PADY) * a.out_wp + (x + PADX)) : OOB;
+      } else {
+        const int y = cur.y0 + 2 * trow, x = cur.x0 + 2 * tcol;
+        voff = (y < a.H && x < a.W) ? 4u * (unsigned)(4 * g4 * oplane + (y + PADY) * a.out_wp + (x + PADX)) : OOB;
+        if constexpr (ODD) {
+          voff01 = (voff != OOB && x + 1 < a.W) ? voff + 4u : OOB;
+          voff10 = (voff != OOB && y + 1 < a.H) ? voff + 4u * (unsigned)a.out_wp : OOB;
+          voff11 = (voff01 != OOB && voff10 != OOB) ? voff10 + 4u : OOB;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // two-wide (v_pk_add_f32): rows of M in pairs for the column pass, (y00, y01) / (y10, y11) for the row pass
+        f32x2 sa[2], sb[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x2 m0 = {acc[8 * h + 0][blk][r], acc[8 * h + 4][blk][r]}, m1 = {acc[8 * h + 1][blk][r], acc[8 * h + 5][blk][r]};
+          const f32x2 m2 = {acc[8 * h + 2][blk][r], acc[8 * h + 6][blk][r]}, m3 = {acc[8 * h + 3][blk][r], acc[8 * h + 7][blk][r]};
+          sa[h] = (m0 + m1) + m2;
+          sb[h] = (m1 - m2) - m3;
+        }
+        const f32x2 q0 = {sa[0][0], sb[0][0]}, q1 = {sa[0][1], sb[0][1]}, q2 = {sa[1][0], sb[1][0]}, q3 = {sa[1][1], sb[1][1]};
+        const f32x2 ya = (q0 + q1) + q2, yb = (q1 - q2) - q3;   // ya = (y00, y01), yb = (y10, y11)
+        const float y00 = relu(ya[0]), y01 = relu(ya[1]), y10 = relu(yb[0]), y11 = relu(yb[1]);
+        const unsigned vo = r < kmax ? voff : OOB;
+        if constexpr (POOL) {
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaxf(fmaxf(y00, y01), fmaxf(y10, y11))), rsrc, vo, r * oplane * 4, 0);
+        } else if constexpr (!ODD) {
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          const u32x2 r0 = {__float_as_uint(y00), __float_as_uint(y01)}, r1 = {__float_as_uint(y10), __float_as_uint(y11)};
+          __builtin_amdgcn_raw_buffer_store_b64(r0, rsrc, vo, r * oplane * 4, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(r1, rsrc, vo == OOB ? OOB : vo + 4u * (unsigned)a.out_wp, r * oplane * 4, 0);
+        } else {
+          // odd H or W: the second row / column of the last tiles is outside the image and must stay zero (the next layer's halo)
+          const unsigned v00 = r < kmax ? voff : OOB, v01 = r < kmax ? voff01 : OOB, v10 = r < kmax ? voff10 : OOB, v11 = r < kmax ? voff11 : OOB;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y00), rsrc, v00, r * oplane * 4, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y01), rsrc, v01, r * oplane * 4, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y10), rsrc, v10, r * oplane * 4, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y11), rsrc, v11, r * oplane * 4, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#ifdef WINO_STAMPS
+    st_epi += __builtin_amdgcn_s_memtime() - te0;
+#endif
+    cur = nxt;
+  }
+#ifdef WINO_STAMPS
+  if (lane == 0 && a.stamps) {
+    unsigned long long *o = a.stamps + 8 * (blockIdx.x * 8 + wave);
+    o[0] = st_dma; o[1] = st_bar; o[2] = st_mfma; o[3] = st_epi; o[4] = st_items;
+    o[5] = __builtin_amdgcn_s_memtime() - st_t0; o[6] = __builtin_amdgcn_s_memrealtime() - st_r0;
+  }
+#endif
+}
+
+}  // namespace spvo

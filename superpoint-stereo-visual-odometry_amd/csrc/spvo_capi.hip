@@ -21,6 +21,7 @@
 #include "conv_f16.hip.h"
 #include "conv_bf16x3.hip.h"
 #include "conv_wino.hip.h"
+#include "conv_wino2.hip.h"
 #include "conv_i8.hip.h"
 #include "post.hip.h"
 
@@ -56,6 +57,7 @@ struct Op {
   bool merged = false;     // FP32 engines: this op's output channels are computed by the previous op's launch (sibling layers
                            // that read the same tensor and write adjacent channel ranges of one tensor: convPa + convDa)
   bool wino = false;       // FP32 engines: this 3x3 layer runs the Winograd F(2x2,3x3) kernel (conv_wino.hip.h)
+  bool wino2 = false;      // ... its 8-wave form (conv_wino2.hip.h: two waves per SIMD; the default, SPVO_WINO2=0 keeps the 4-wave form)
   bool dominant = false;   // the op with the most FLOPs: launched under its own kernel name (TAG = 1)
   float *d_w = nullptr, *d_b = nullptr, *d_bn_scale = nullptr, *d_bn_shift = nullptr;
   _Float16 *d_w16 = nullptr;   // FP16 engines: pack_conv_weights_f16()
@@ -350,31 +352,47 @@ int launch_conv_epi(spvo_ctx *c, const ConvArgs &a, int batch, int epi, hipStrea
                   : launch_conv_instance<1, 16, WR, WC, POOL, false, 2>(c, args, stream);
 }
 
-// Winograd F(2x2, 3x3) instance of a 3x3 layer (conv_wino.hip.h): one tile shape, one workgroup per CU (124 KB of LDS)
-template <bool POOL, bool RELU, int TAG, bool ODD = false>
+// Winograd F(2x2, 3x3) instance of a 3x3 layer (conv_wino.hip.h / conv_wino2.hip.h): one tile shape, one workgroup per CU (157 KB of
+// LDS); W2 selects the 8-wave form (two waves per SIMD, 512 threads)
+template <bool POOL, bool RELU, int TAG, bool ODD = false, bool W2 = false>
 int launch_conv_wino_instance(spvo_ctx *c, const ConvArgs &args, hipStream_t stream) {
-  auto k = conv_wino_kernel<POOL, RELU, TAG, ODD>;
   static bool ready[64] = {};
   const int dev = c->cfg.device & 63;
-  if (!ready[dev]) {
-    HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, WinoTile::LDS_BYTES));
-    ready[dev] = true;
-  }
   const int n_tiles = args.tiles_x * args.tiles_y * args.co_tiles * args.batch;
-  hipLaunchKernelGGL(k, dim3(std::min(n_tiles, c->num_cus)), dim3(256), WinoTile::LDS_BYTES, stream, args);
+  if constexpr (W2) {
+    auto k = conv_wino2_kernel<POOL, RELU, TAG, ODD>;
+    if (!ready[dev]) {
+      HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, WinoTile::LDS_BYTES));
+      ready[dev] = true;
+    }
+    hipLaunchKernelGGL(k, dim3(std::min(n_tiles, c->num_cus)), dim3(512), WinoTile::LDS_BYTES, stream, args);
+  } else {
+    auto k = conv_wino_kernel<POOL, RELU, TAG, ODD>;
+    if (!ready[dev]) {
+      HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, WinoTile::LDS_BYTES));
+      ready[dev] = true;
+    }
+    hipLaunchKernelGGL(k, dim3(std::min(n_tiles, c->num_cus)), dim3(256), WinoTile::LDS_BYTES, stream, args);
+  }
   HIP_TRY(c, hipGetLastError());
   return SPVO_OK;
 }
 
-int launch_conv_wino(spvo_ctx *c, const ConvArgs &a, int batch, bool relu, bool pool, bool dominant, hipStream_t stream) {
+template <bool W2>
+int launch_conv_wino_sel(spvo_ctx *c, const ConvArgs &args, bool relu, bool pool, bool dominant, hipStream_t stream) {
+  const ConvArgs &a = args;
+  if (!pool && ((a.H | a.W) & 1)) return relu ? launch_conv_wino_instance<false, true, 0, true, W2>(c, args, stream) : launch_conv_wino_instance<false, false, 0, true, W2>(c, args, stream);
+  if (dominant && relu) return pool ? launch_conv_wino_instance<true, true, 1, false, W2>(c, args, stream) : launch_conv_wino_instance<false, true, 1, false, W2>(c, args, stream);
+  if (pool) return relu ? launch_conv_wino_instance<true, true, 0, false, W2>(c, args, stream) : launch_conv_wino_instance<true, false, 0, false, W2>(c, args, stream);
+  return relu ? launch_conv_wino_instance<false, true, 0, false, W2>(c, args, stream) : launch_conv_wino_instance<false, false, 0, false, W2>(c, args, stream);
+}
+
+int launch_conv_wino(spvo_ctx *c, const ConvArgs &a, int batch, bool relu, bool pool, bool dominant, bool w2, hipStream_t stream) {
   ConvArgs args = a;
   args.tiles_x = (a.W + WinoTile::TW - 1) / WinoTile::TW;
   args.tiles_y = (a.H + WinoTile::TH - 1) / WinoTile::TH;
   args.batch = batch;
-  if (!pool && ((a.H | a.W) & 1)) return relu ? launch_conv_wino_instance<false, true, 0, true>(c, args, stream) : launch_conv_wino_instance<false, false, 0, true>(c, args, stream);
-  if (dominant && relu) return pool ? launch_conv_wino_instance<true, true, 1>(c, args, stream) : launch_conv_wino_instance<false, true, 1>(c, args, stream);
-  if (pool) return relu ? launch_conv_wino_instance<true, true, 0>(c, args, stream) : launch_conv_wino_instance<true, false, 0>(c, args, stream);
-  return relu ? launch_conv_wino_instance<false, true, 0>(c, args, stream) : launch_conv_wino_instance<false, false, 0>(c, args, stream);
+  return w2 ? launch_conv_wino_sel<true>(c, args, relu, pool, dominant, stream) : launch_conv_wino_sel<false>(c, args, relu, pool, dominant, stream);
 }
 
 // Variant choice for a layer.  3x3: every tile variant has a measured rate on perfectly divisible shapes
@@ -449,7 +467,7 @@ int launch_conv(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stre
   a.cout = op.cout; a.n_chunks = op.n_chunks; a.co_tiles = op.co_tiles;
   a.tiles_x = a.tiles_y = 0;
   a.batch = batch;
-  if (op.wino) return launch_conv_wino(c, a, batch, relu, pool, op.dominant, stream);
+  if (op.wino) return launch_conv_wino(c, a, batch, relu, pool, op.dominant, op.wino2, stream);
   const int key = op.ks * 10000 + op.ck * 100 + op.wr * 20 + op.wc * 2 + (pool ? 1 : 0);   // ks, ck, wr, wc, pool
   if (epi) {
     a.bn_scale = op.d_bn_scale; a.bn_shift = op.d_bn_shift;
@@ -1689,7 +1707,8 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
       if (op.wino) {
         op.ck = WinoTile::CK;
         op.n_chunks = op.cin / op.ck;
-        const std::vector<float> pk = pack_conv_weights_wino(w, b, op.cout, op.cin);
+        op.wino2 = !(std::getenv("SPVO_WINO2") && std::atoi(std::getenv("SPVO_WINO2")) == 0);
+        const std::vector<float> pk = op.wino2 ? pack_conv_weights_wino2(w, b, op.cout, op.cin) : pack_conv_weights_wino(w, b, op.cout, op.cin);
         int rc = dev_alloc(c, &op.d_w, pk.size(), false);
         if (rc) return rc;
         HIP_TRY(c, hipMemcpy(op.d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));

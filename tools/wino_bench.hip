@@ -1,0 +1,131 @@
+// Stand-alone run of the Winograd convolution kernel (csrc/conv_wino.hip.h) on one layer shape: timing (HIP events over
+// back-to-back launches) and a check of sampled outputs against a float64 direct convolution on the host.
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/wino_bench.hip -o tools/wino_bench
+// usage: wino_bench H W cin cout pool(0|1) [reps = 50] [grid = CUs]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <random>
+#include <vector>
+#include <algorithm>
+#include "../superpoint-stereo-visual-odometry_amd/csrc/conv_wino.hip.h"
+#include "../superpoint-stereo-visual-odometry_amd/csrc/conv_wino2.hip.h"
+#ifdef WINO2
+#define KERNEL conv_wino2_kernel
+#define PACK pack_conv_weights_wino2
+#define THREADS 512
+#else
+#define KERNEL conv_wino_kernel
+#define PACK pack_conv_weights_wino
+#define THREADS 256
+#endif
+using namespace spvo;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+int main(int argc, char **argv) {
+  if (argc < 6) { printf("usage: wino_bench H W cin cout pool [reps] [grid]\n"); return 1; }
+  const int H = atoi(argv[1]), W = atoi(argv[2]), cin = atoi(argv[3]), cout = atoi(argv[4]), pool = atoi(argv[5]);
+  const int reps = argc > 6 ? atoi(argv[6]) : 50;
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount, batch = 2;
+  const int ihp = padded_h(H), iwp = padded_w(W), OH = pool ? H / 2 : H, OW = pool ? W / 2 : W, ohp = padded_h(OH), owp = padded_w(OW);
+  std::mt19937 rng(1);
+  std::uniform_real_distribution<float> ud(-1.f, 1.f);
+  std::vector<float> in((size_t)batch * cin * ihp * iwp, 0.f), w((size_t)cout * cin * 9), b(cout);
+  for (int n = 0; n < batch; ++n)
+    for (int c = 0; c < cin; ++c)
+      for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) in[(((size_t)n * cin + c) * ihp + y + PADY) * iwp + x + PADX] = ud(rng);
+  const float ws = 1.f / std::sqrt((float)cin * 9);
+  for (auto &v : w) v = ud(rng) * ws * 1.7f;
+  for (auto &v : b) v = ud(rng) * 0.1f;
+  const std::vector<float> pk = PACK(w.data(), b.data(), cout, cin);
+  float *d_in, *d_out, *d_w;
+  const size_t out_n = (size_t)batch * cout * ohp * owp;
+  CK(hipMalloc(&d_in, in.size() * 4)); CK(hipMalloc(&d_out, out_n * 4)); CK(hipMalloc(&d_w, pk.size() * 4));
+  CK(hipMemcpy(d_in, in.data(), in.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemset(d_out, 0, out_n * 4));
+  ConvArgs a{};
+  a.in = d_in; a.out = d_out; a.wpack = d_w; a.bias = nullptr; a.H = H; a.W = W;
+  a.in_hp = ihp; a.in_wp = iwp; a.in_ctot = cin; a.in_coff = 0; a.out_hp = ohp; a.out_wp = owp; a.out_ctot = cout; a.out_coff = 0;
+  a.cout = cout; a.n_chunks = cin / WinoTile::CK; a.tiles_x = (W + WinoTile::TW - 1) / WinoTile::TW; a.tiles_y = (H + WinoTile::TH - 1) / WinoTile::TH;
+  a.co_tiles = (cout + 63) / 64; a.batch = batch;
+  const long n_items = (long)a.tiles_x * a.tiles_y * a.co_tiles * batch * a.n_chunks;
+  const int grid = argc > 7 ? atoi(argv[7]) : (int)std::min<long>(cus, n_items / a.n_chunks);
+  auto launch = [&]() {
+    if (pool) { hipLaunchKernelGGL((KERNEL<true, true, 0, false>), dim3(grid), dim3(THREADS), WinoTile::LDS_BYTES, 0, a); }
+    else if ((H | W) & 1) { hipLaunchKernelGGL((KERNEL<false, true, 0, true>), dim3(grid), dim3(THREADS), WinoTile::LDS_BYTES, 0, a); }
+    else { hipLaunchKernelGGL((KERNEL<false, true, 0, false>), dim3(grid), dim3(THREADS), WinoTile::LDS_BYTES, 0, a); }
+  };
+  CK(hipFuncSetAttribute((const void *)KERNEL<true, true, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WinoTile::LDS_BYTES));
+  CK(hipFuncSetAttribute((const void *)KERNEL<false, true, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WinoTile::LDS_BYTES));
+  CK(hipFuncSetAttribute((const void *)KERNEL<false, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WinoTile::LDS_BYTES));
+  for (int i = 0; i < 5; ++i) launch();
+  CK(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < reps; ++i) launch();
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  const double us = ms * 1e3 / reps, fl = 2.0 * batch * H * W * (double)cout * cin * 9;
+#ifdef WINO_STAMPS
+  {
+    unsigned long long *d_st;
+    const int nw = grid * (THREADS / 64);
+    CK(hipMalloc(&d_st, (size_t)nw * 8 * 8));
+    CK(hipMemset(d_st, 0, (size_t)nw * 8 * 8));
+    a.stamps = d_st;
+    launch(); launch();
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> st((size_t)nw * 8);
+    CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+    a.stamps = nullptr;
+    double sum[7] = {};
+    int n = 0;
+    for (int i = 0; i < nw; ++i) { if (!st[8 * i + 4]) continue; ++n; for (int k = 0; k < 7; ++k) sum[k] += (double)st[8 * i + k]; }
+    const double items = sum[4] / n, clk = sum[5] / sum[6] * 100e6;
+    printf("  per wave: %.1f items, %.0f cycles total at %.2f GHz (100 MHz reference); per item: LDS-DMA wait %.0f, barrier %.0f, matrix stream %.0f, epilogue %.0f (per item share), other %.0f cycles\n",
+           items, sum[5] / n, clk / 1e9, sum[0] / n / items, sum[1] / n / items, sum[2] / n / items, sum[3] / n / items,
+           (sum[5] - sum[0] - sum[1] - sum[2] - sum[3]) / n / items);
+  }
+#endif
+  std::vector<float> out(out_n);
+  CK(hipMemcpy(out.data(), d_out, out_n * 4, hipMemcpyDeviceToHost));
+  // sampled check against a float64 direct convolution (+ bias, ReLU, 2x2 max-pool)
+  auto conv_at = [&](int n, int co, int y, int x) {
+    double s = b[co];
+    for (int c = 0; c < cin; ++c)
+      for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx)
+          s += (double)w[((size_t)co * cin + c) * 9 + ky * 3 + kx] * in[(((size_t)n * cin + c) * ihp + y + ky - 1 + PADY) * iwp + x + kx - 1 + PADX];
+    return s > 0 ? s : 0.0;
+  };
+  double maxerr = 0, maxref = 0;
+  std::uniform_int_distribution<int> rn(0, batch - 1), rc(0, cout - 1), ry(0, OH - 1), rx(0, OW - 1);
+  for (int k = 0; k < 6000; ++k) {
+    const int n = rn(rng), co = rc(rng);
+    int y = ry(rng), x = rx(rng);
+    if (k < 64) { y = (k & 1) ? OH - 1 : 0; x = (k & 2) ? OW - 1 : 0; }   // corners
+    double ref;
+    if (pool) ref = std::max(std::max(conv_at(n, co, 2 * y, 2 * x), conv_at(n, co, 2 * y, 2 * x + 1)), std::max(conv_at(n, co, 2 * y + 1, 2 * x), conv_at(n, co, 2 * y + 1, 2 * x + 1)));
+    else ref = conv_at(n, co, y, x);
+    const double got = out[(((size_t)n * cout + co) * ohp + y + PADY) * owp + x + PADX];
+    maxerr = std::max(maxerr, std::fabs(got - ref));
+    maxref = std::max(maxref, std::fabs(ref));
+  }
+  // the zero border of the output planes must stay zero (it is the next layer's halo)
+  double border = 0;
+  for (int n = 0; n < batch; ++n)
+    for (int co = 0; co < cout; co += 7)
+      for (int y = 0; y < ohp; ++y)
+        for (int x = 0; x < owp; ++x)
+          if (y < PADY || y >= OH + PADY || x < PADX || x >= OW + PADX) border = std::max(border, (double)std::fabs(out[(((size_t)n * cout + co) * ohp + y) * owp + x]));
+  printf("%dx%d %d->%d pool=%d grid=%d items=%ld (%.2f per workgroup): %8.2f us  %6.1f TFLOP/s algorithmic, %5.1f executed = %.3f of peak | max err %.2e (max |ref| %.2f) border %.1e %s\n",
+         H, W, cin, cout, pool, grid, n_items, (double)n_items / grid, us, fl / us / 1e6, fl / us / 1e6 * 4 / 9, fl / us / 1e6 * 4 / 9 / 157.3, maxerr, maxref, border,
+         (maxerr <= 2e-5 * std::max(1.0, maxref) && border == 0) ? "OK" : "MISMATCH");
+  return 0;
+}
