@@ -92,12 +92,15 @@ __device__ inline bool solve_linear(double *A, double *b) {
 // ------------------------------------------------------------------------- K14
 // One thread per point: 4x4 DLT system, one-sided Jacobi SVD (Hestenes) in f64,
 // right-singular vector of the smallest singular value, stored f32, then x/w in f32.
+// Launched with ONE wave per workgroup (64 points): the chain of f64 square roots and divisions is latency-bound, so 1000
+// points are 16 independent waves on 16 CUs rather than 4 workgroups of 4 waves (the solver runs beside the next pair's
+// convolutions, whose waves own most issue slots of a CU).
 __global__ __launch_bounds__(256) void triangulate_kernel(const double *__restrict__ Pl,
                                                           const double *__restrict__ Pr,
                                                           const float *__restrict__ xyl,
                                                           const float *__restrict__ xyr, int n,
                                                           float *__restrict__ xyz) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double A[16], V[16];
   {

@@ -1144,10 +1144,13 @@ int ensure_odometry(spvo_ctx *c, int n, int iterations, int n_obs) {
     if ((rc = dev_alloc(c, &c->rw.result, 8))) return rc;
     if ((rc = dev_alloc(c, &c->d_refine, 1))) return rc;
   }
+  // a buffer is cleared as it is freed and its capacity drops to 0 before the reallocation: a failure half-way leaves a context
+  // that spvo_destroy and a later call can still handle
+  auto drop = [](auto *&p) { if (p) (void)hipFree(p); p = nullptr; };
   if (n > c->odo_cap) {
     const int cap = std::max(n, 2048);
-    for (void *p : {(void *)c->d_pts_a, (void *)c->d_pts_b, (void *)c->d_xyz, (void *)c->rw.inliers})
-      if (p) (void)hipFree(p);
+    c->odo_cap = 0;
+    drop(c->d_pts_a); drop(c->d_pts_b); drop(c->d_xyz); drop(c->rw.inliers);
     if ((rc = dev_alloc(c, &c->d_pts_a, (size_t)cap * 3))) return rc;
     if ((rc = dev_alloc(c, &c->d_pts_b, (size_t)cap * 3))) return rc;
     if ((rc = dev_alloc(c, &c->d_xyz, (size_t)cap * 3))) return rc;
@@ -1156,15 +1159,16 @@ int ensure_odometry(spvo_ctx *c, int n, int iterations, int n_obs) {
   }
   if (iterations > c->ransac_cap) {
     const int cap = std::max(iterations, 512);
-    if (c->rw.counts) (void)hipFree(c->rw.counts);
-    if (c->rw.poses) (void)hipFree(c->rw.poses);
+    c->ransac_cap = 0;
+    drop(c->rw.counts); drop(c->rw.poses);
     if ((rc = dev_alloc(c, &c->rw.counts, cap))) return rc;
     if ((rc = dev_alloc(c, &c->rw.poses, (size_t)cap * 7))) return rc;
     c->ransac_cap = cap;
   }
   if (n_obs > c->obs_cap) {
     const int cap = std::max(n_obs, 8192);
-    if (c->d_obs) (void)hipFree(c->d_obs);
+    c->obs_cap = 0;
+    drop(c->d_obs);
     if ((rc = dev_alloc(c, &c->d_obs, cap))) return rc;
     c->obs_cap = cap;
   }
@@ -1374,11 +1378,29 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
   const uint32_t nt = hdr[0], no = hdr[1];
   size_t pos = 40;
   if (buf.size() < pos + (size_t)nt * 8 + (size_t)no * 72 + 8) return fail(c, SPVO_ERR_IO, "%s: truncated", path);
-  // drop a previously loaded plan
-  if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "detector submissions are in flight");
-  free_plan(c);
-  c->t_input = hdr[2]; c->t_det = hdr[3]; c->t_desc = hdr[4];
+  // Everything that can be checked on the file alone is checked BEFORE the loaded plan is dropped: a missing, truncated or
+  // corrupt file leaves the engine that was loaded before in place.  Ids are compared as unsigned (0xFFFFFFFF is not -1).
   if (hdr[5] > 2) return fail(c, SPVO_ERR_IO, "%s: unknown precision %u", path, hdr[5]);
+  if (nt == 0 || nt > 65536 || no > 65536) return fail(c, SPVO_ERR_IO, "%s: implausible tensor / op count", path);
+  if (hdr[2] >= nt || hdr[3] >= nt || hdr[4] >= nt) return fail(c, SPVO_ERR_IO, "%s: bad binding tensor ids", path);
+  {
+    size_t p = pos;
+    for (uint32_t i = 0; i < nt; ++i, p += 8) {
+      const uint32_t *r = (const uint32_t *)(buf.data() + p);
+      if (r[1] > 3 || ((uint32_t)c->H >> r[1]) << r[1] != (uint32_t)c->H) return fail(c, SPVO_ERR_IO, "%s: bad tensor level", path);
+    }
+    for (uint32_t i = 0; i < no; ++i, p += 72) {
+      const uint32_t *r = (const uint32_t *)(buf.data() + p);
+      if (r[1] >= nt || r[2] >= nt || r[8] >= nt) return fail(c, SPVO_ERR_IO, "%s: op %u: bad tensor id", path, i);
+    }
+    uint64_t n_payload;
+    std::memcpy(&n_payload, buf.data() + p, 8);
+    p += 8;
+    if (n_payload > (buf.size() - p) / 4) return fail(c, SPVO_ERR_IO, "%s: truncated payload", path);
+  }
+  if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "detector submissions are in flight");
+  free_plan(c);   // from here on a failure (device allocation, unsupported layer) leaves the context without an engine
+  c->t_input = (int)hdr[2]; c->t_det = (int)hdr[3]; c->t_desc = (int)hdr[4];
   c->fp16 = hdr[5] == 1;   // engine built for FP16 (engine_generation.py's --fp16; the file name says FP16, nn.cpp:44-49)
   c->int8 = hdr[5] == 2;   // INT8 engine (BASELINE config 5; no counterpart in the reference): calibrated activation scales in the file
   const uint32_t act_scale_off = hdr[6];
@@ -1399,9 +1421,7 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
   uint64_t nfl;
   std::memcpy(&nfl, buf.data() + pos, 8);
   pos += 8;
-  if (buf.size() < pos + nfl * 4) return fail(c, SPVO_ERR_IO, "%s: truncated payload", path);
-  const float *payload = (const float *)(buf.data() + pos);
-  if (c->t_input >= (int)nt || c->t_det >= (int)nt || c->t_desc >= (int)nt) return fail(c, SPVO_ERR_IO, "bad tensor ids");
+  const float *payload = (const float *)(buf.data() + pos);   // nfl was checked against the file size above
 
   for (uint32_t i = 0; i < no; ++i) {
     const Raw &r = raws[i];
@@ -1409,7 +1429,6 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
     op.type = r.v[0]; op.in = r.v[1]; op.out = r.v[2]; op.out_c_off = r.v[3];
     op.cin = r.v[4] & 0xFFFF; op.in_c_off = r.v[4] >> 16; op.cout = r.v[5]; op.ks = r.v[6]; op.flags = r.v[7];
     op.residual = r.v[8];
-    if (op.in >= (int)nt || op.out >= (int)nt || op.residual >= (int)nt) return fail(c, SPVO_ERR_IO, "op %u: bad tensor id", i);
     if (op.type == OP_L2NORM) c->tensors[op.out].nhwc = true;
     c->ops.push_back(op);
   }
@@ -2258,7 +2277,7 @@ int spvo_triangulate(spvo_ctx *c, const double P_l[12], const double P_r[12], co
   HIP_TRY(c, hipMemcpyAsync(c->d_pts_b, xy_r, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
   {
     ScopedStage st(c, stage_id(c, "triangulate"));
-    hipLaunchKernelGGL(triangulate_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_P, c->d_P + 12, c->d_pts_a, c->d_pts_b, n, c->d_xyz);
+    hipLaunchKernelGGL(triangulate_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->d_P, c->d_P + 12, c->d_pts_a, c->d_pts_b, n, c->d_xyz);
   }
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(xyz, c->d_xyz, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -2407,7 +2426,7 @@ int spvo_solve_stereo_odometry(spvo_ctx *c, const spvo_solve_input *in, spvo_sol
   const double thr2 = in->ransac.reproj_error * in->ransac.reproj_error;
   {
     ScopedStage st(c, stage_id(c, "solve"), 0, 0, c->stream2);
-    hipLaunchKernelGGL(triangulate_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream2, dh, dh + 12, df, df + 2 * n, n, d_xyz);
+    hipLaunchKernelGGL(triangulate_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream2, dh, dh + 12, df, df + 2 * n, n, d_xyz);
     if (n >= 4) {
       hipLaunchKernelGGL(ransac_hypothesis_kernel, dim3(in->ransac.iterations), dim3(64), 0, c->stream2, dh + 24, d_xyz, df + 4 * n, n, dh + 33, in->ransac.seed, thr2, rw);
       hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(256), 0, c->stream2, dh + 24, d_xyz, df + 4 * n, n, dh + 33, in->ransac.iterations, thr2, rw);

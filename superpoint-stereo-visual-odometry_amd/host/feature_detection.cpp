@@ -293,6 +293,7 @@ void FeatureFrontEnd::solveStereoOdometry(tf2::Transform &cam0_curr_T_cam0_prev)
     return;
   }
   inliers_pnp.resize(so.n_inliers);
+  last_pnp_ok_ = so.pnp_ok != 0; last_accepted_ = so.accepted != 0; last_refined_ = so.refined != 0; last_lm_iterations_ = so.summary.iterations;
   if (!so.pnp_ok) logError("solvePnPRansac failed! Identity transformation will be applied.");
   else if (!so.accepted) logError("solvePnPRansac succeeded but acceleration is abnormally large!");
   else for (int k = 0; k < 3; ++k) { r_vec_pred[k] = so.rvec[k]; t_vec_pred[k] = so.tvec[k]; }   // base.cpp:269-270

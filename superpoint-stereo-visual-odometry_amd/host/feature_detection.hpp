@@ -219,6 +219,11 @@ public:
   const std::vector<int> &inliersPostmatching() const { return inliers_postmatching; }
   const std::string &lastError() const { return last_error_; }
   int frameCount() const { return frame_count; }
+  // outcome of the last solveStereoOdometry: solvePnPRansac's return value, the gate (base.cpp:243-272), refinement kept (base.cpp:366-374)
+  bool lastPnpOk() const { return last_pnp_ok_; }
+  bool lastAccepted() const { return last_accepted_; }
+  bool lastRefined() const { return last_refined_; }
+  int lastLmIterations() const { return last_lm_iterations_; }
   uint32_t ransac_seed = 0;
 
 protected:
@@ -268,6 +273,8 @@ protected:
   spvo_ctx *ctx_ = nullptr;
   std::deque<int> slots_dq_;
   std::string last_error_;
+  bool last_pnp_ok_ = false, last_accepted_ = false, last_refined_ = false;
+  int last_lm_iterations_ = 0;
   void logError(const std::string &msg);
   void logInfo(const std::string &msg) const;
 };

@@ -178,6 +178,12 @@ int spvo_host_classic_probe(char *err, int cap) {
   return ClassicFeatureFrontEnd::available() ? (int)fe.keypoints_dq.size() : -(int)fe.keypoints_dq.size();
 }
 
+// bit 0 pnp ok, bit 1 accepted by the gate, bit 2 refinement kept; LM iterations in bits 8..
+int spvo_host_last_solve(void *h) {
+  auto *fe = static_cast<SuperPointFeatureFrontEnd *>(h);
+  return (fe->lastPnpOk() ? 1 : 0) | (fe->lastAccepted() ? 2 : 0) | (fe->lastRefined() ? 4 : 0) | (fe->lastLmIterations() << 8);
+}
+
 int spvo_host_frame_count(void *h) { return static_cast<SuperPointFeatureFrontEnd *>(h)->frameCount(); }
 
 }  // extern "C"

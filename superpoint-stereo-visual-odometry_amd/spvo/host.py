@@ -29,7 +29,7 @@ def load():
         lib.spvo_host_destroy.restype = None
         lib.spvo_host_last_error.argtypes = [vp]
         lib.spvo_host_last_error.restype = C.c_char_p
-        for name in ("spvo_host_engine_loaded", "spvo_host_dq_size", "spvo_host_frame_count"):
+        for name in ("spvo_host_engine_loaded", "spvo_host_dq_size", "spvo_host_frame_count", "spvo_host_last_solve"):
             getattr(lib, name).argtypes = [vp]
         lib.spvo_host_set_seed.argtypes = [vp, C.c_uint]
         lib.spvo_host_set_seed.restype = None
@@ -212,6 +212,11 @@ class FrontEnd:
 
     def frame_count(self):
         return self.lib.spvo_host_frame_count(self.h)
+
+    def last_solve(self):
+        """Outcome of the last solveStereoOdometry: dict(pnp_ok, accepted, refined, lm_iterations)."""
+        v = self.lib.spvo_host_last_solve(self.h)
+        return dict(pnp_ok=bool(v & 1), accepted=bool(v & 2), refined=bool(v & 4), lm_iterations=v >> 8)
 
     def keypoints(self, position):
         xy = np.zeros((self.cap, 2), np.float32)

@@ -1,0 +1,33 @@
+"""bench.py's N > 1 code path on ONE GPU: two ranks launched the way the driver launches them (torch.distributed.run), sharing
+the device through the SPVO_BENCH_SHARED_GPU test hook (gloo process group, the C ABI's file transport for the pose gather --
+RCCL refuses two ranks on one device).  Exercises what a multi-GPU run adds to the step loop: per-rank streams, the batched pose
+all-gather inside the timed region, barrier, max-over-ranks timing, rank 0's single JSON line."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_share_one_gpu():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, SPVO_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 prints ONE JSON line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 40 and out["scaling"] == "weak" and out["value"] > 0
+    assert abs(out["value"] - 2 * 40 / (out["ms_per_step"] * 40 / 1e3)) < 0.02 * out["value"]   # whole-job rate = all ranks' frames / max time
+    assert "file transport" in out["config"]["pose_gather"]
+    assert out["config"]["streams"] == 2

@@ -193,3 +193,42 @@ def test_nms_against_a_literal_transcription():
         if len(out) >= cap:
             break
     assert np.array_equal(fe.nms(heat, 0.015, dist, border, cap), np.array(out, np.int32))
+
+
+@pytest.mark.parametrize("name", ["sp_squeeze", "sp_mbv1", "sp_mbv2"])
+def test_plan_evaluations_match_the_direct_onnx_evaluation(name, golden_dir):
+    """oracle/net.py and the C++ restatement execute the product's execution PLAN (ReLU / BatchNorm / Add / MaxPool folded into
+    the producing convolution, Concat as channel offsets).  The fixtures hold what the reference's ONNX graph gives when it is
+    evaluated node by node by an interpreter that shares nothing with the packer (oracle/onnx_direct.py, frozen by
+    tests/golden/make_onnx_direct_golden.py): the plan's semantics -- epsilon and position of BatchNorm, pads, Concat order,
+    the ReduceL2 / Div tail -- are pinned to the graph's."""
+    import os
+    from oracle import cpu_backend, net
+    from spvo import weights
+    g = np.load(os.path.join(golden_dir, f"onnx_direct_{name}_64x96.npz"))
+    path = os.path.join(golden_dir, name + ".spvw")
+    det, desc = net.forward(weights.load(path), g["x"])
+    assert np.abs(det - g["det"]).max() <= 2e-5 * max(1.0, np.abs(g["det"]).max())
+    assert np.abs(desc - g["desc"]).max() <= 2e-5
+    c = cpu_backend.CpuBackend(net_height=64, net_width=96)
+    c.load_weights(path)
+    det2, desc2 = c.forward(g["x"])
+    c.close()
+    assert np.abs(det2 - g["det"]).max() <= 1e-4 * max(1.0, np.abs(g["det"]).max()) and np.abs(desc2 - g["desc"]).max() <= 1e-4
+
+
+def test_direct_onnx_fixtures_are_current():
+    """where the reference tree is present (the build container), the fixtures equal a fresh direct evaluation"""
+    import os
+    models = "/root/reference/src/odml_visual_odometry/models"
+    if not os.path.isdir(models):
+        pytest.skip("reference tree not present")
+    from oracle import onnx_direct
+    from tests.conftest import GOLDEN
+    for name in ("sp_squeeze", "sp_mbv1", "sp_mbv2"):
+        g = np.load(os.path.join(GOLDEN, f"onnx_direct_{name}_64x96.npz"))
+        out = onnx_direct.run(os.path.join(models, name + "_b1.onnx"), g["x"])
+        # (torch's CPU convolution picks its blocking by thread count: bitwise repeatability is not guaranteed)
+        assert np.abs(out["output_det"] - g["det"]).max() <= 2e-5 and np.abs(out["output_desc"] - g["desc"]).max() <= 2e-6
+        out2 = onnx_direct.run(os.path.join(models, name + "_b2.onnx"), np.concatenate([g["x"], g["x"]]))   # b2 graphs: same weights
+        assert np.abs(out2["output_det"][1] - g["det"][0]).max() <= 2e-5
