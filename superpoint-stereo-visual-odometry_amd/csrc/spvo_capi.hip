@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 #include <deque>
+#include <time.h>
 
 #include "../../include/spvo.h"
 #include "conv_mfma.hip.h"
@@ -202,6 +203,7 @@ struct spvo_ctx {
   ObsDev *d_obs = nullptr;
   RefineOut *d_refine = nullptr;
   // fused solve: one packed input, one packed result
+  hipEvent_t ev_solve = nullptr;
   int solve_cap = 0;
   char *d_solve_in = nullptr, *h_solve_in = nullptr;    // 64 doubles + 12*cap words
   double *d_solve_res = nullptr, *h_solve_res = nullptr;  // ransac[8] gate[16] refine[12] + pad
@@ -251,6 +253,24 @@ int stage_id(spvo_ctx *c, const std::string &name) {
   s.name = name;
   c->stages.push_back(s);
   return (int)c->stages.size() - 1;
+}
+
+// SPVO_SPIN_WAIT=1: the waits of the per-frame path poll their event instead of sleeping in the driver (a sleeping host thread
+// pays the wake-up latency of its core at every wait).  Off by default: on the bench box it changed nothing (the waits are
+// dominated by GPU time), and a ROS node should not burn a core while it waits.
+bool spin_wait_enabled() {
+  static const bool on = std::getenv("SPVO_SPIN_WAIT") && std::atoi(std::getenv("SPVO_SPIN_WAIT")) != 0;
+  return on;
+}
+hipError_t wait_event(hipEvent_t ev) {
+  if (spin_wait_enabled()) {
+    for (long spins = 0; spins < 20000000; ++spins) {   // far longer than any wait of this library; then fall back to the blocking form
+      const hipError_t e = hipEventQuery(ev);
+      if (e != hipErrorNotReady) return e;
+      __builtin_ia32_pause();
+    }
+  }
+  return hipEventSynchronize(ev);
 }
 
 hipEvent_t get_event(spvo_ctx *c) {
@@ -359,20 +379,26 @@ int launch_conv_wino_instance(spvo_ctx *c, const ConvArgs &args, hipStream_t str
   static bool ready[64] = {};
   const int dev = c->cfg.device & 63;
   const int n_tiles = args.tiles_x * args.tiles_y * args.co_tiles * args.batch;
+  // One workgroup per CU (157 KB of LDS), each walking ceil(n_tiles / grid) tiles.  The grid is the SMALLEST one that keeps that
+  // number of rounds: 3330 tiles are 14 rounds on 256 CUs and still 14 rounds on 238, and the 18 CUs left over take the
+  // small kernels of the other streams (tail of the previous pair, solver): with all 256 CUs claimed, any of those
+  // kernels sitting on a CU when a layer starts keeps that layer's last workgroup waiting for a CU.
+  const int rounds = (n_tiles + c->num_cus - 1) / c->num_cus;
+  const int grid = (n_tiles + rounds - 1) / rounds;
   if constexpr (W2) {
     auto k = conv_wino2_kernel<POOL, RELU, TAG, ODD>;
     if (!ready[dev]) {
       HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, WinoTile::LDS_BYTES));
       ready[dev] = true;
     }
-    hipLaunchKernelGGL(k, dim3(std::min(n_tiles, c->num_cus)), dim3(512), WinoTile::LDS_BYTES, stream, args);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), WinoTile::LDS_BYTES, stream, args);
   } else {
     auto k = conv_wino_kernel<POOL, RELU, TAG, ODD>;
     if (!ready[dev]) {
       HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, WinoTile::LDS_BYTES));
       ready[dev] = true;
     }
-    hipLaunchKernelGGL(k, dim3(std::min(n_tiles, c->num_cus)), dim3(256), WinoTile::LDS_BYTES, stream, args);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), WinoTile::LDS_BYTES, stream, args);
   }
   HIP_TRY(c, hipGetLastError());
   return SPVO_OK;
@@ -1322,6 +1348,7 @@ void spvo_destroy(spvo_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   if (c->stream_t) (void)hipStreamSynchronize(c->stream_t);
+  if (c->ev_solve) (void)hipEventDestroy(c->ev_solve);
   resolve_pending(c);
   for (auto e : c->free_events) (void)hipEventDestroy(e);
   free_plan(c);
@@ -2079,7 +2106,7 @@ static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_feature
     rc = hipStreamSynchronize(c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "stream synchronisation failed");
   } else {
     // only this submission's tail: a younger one may be queued behind it on both streams
-    rc = hipEventSynchronize(c->ev_tail[pd.ring]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");
+    rc = wait_event(c->ev_tail[pd.ring]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");
   }
   bool redone = false;
   const NmsPair np = nms_pair(c, pd.ring);
@@ -2395,6 +2422,11 @@ int spvo_solve_stereo_odometry(spvo_ctx *c, const spvo_solve_input *in, spvo_sol
     c->solve_cap = cap;
   }
   if (grow) HIP_TRY(c, hipDeviceSynchronize());
+  static const bool solve_timing = std::getenv("SPVO_SOLVE_TIMING") != nullptr;   // diagnostic: host time per phase of this call
+  static double tacc[4] = {0, 0, 0, 0};
+  static long tcalls = 0;
+  auto now_us = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
+  const double tm0 = solve_timing ? now_us() : 0;
   // ---- pack: 64 doubles, then cl cr pl pr [2n each], prev_xyz [3n], prev_valid [n]
   double *hdr = (double *)c->h_solve_in;
   std::memset(hdr, 0, 64 * sizeof(double));
@@ -2415,6 +2447,7 @@ int spvo_solve_stereo_odometry(spvo_ctx *c, const spvo_solve_input *in, spvo_sol
     std::memcpy(fw + 11 * n, in->prev_valid, (size_t)n * 4);
   }
   const size_t used = 64 * sizeof(double) + (size_t)12 * n * 4;
+  const double tm1 = solve_timing ? now_us() : 0;
   HIP_TRY(c, hipMemcpyAsync(c->d_solve_in, c->h_solve_in, used, hipMemcpyHostToDevice, c->stream2));
   const double *dh = (const double *)c->d_solve_in;
   const float *df = (const float *)(c->d_solve_in + 64 * sizeof(double));
@@ -2426,7 +2459,7 @@ int spvo_solve_stereo_odometry(spvo_ctx *c, const spvo_solve_input *in, spvo_sol
   const double thr2 = in->ransac.reproj_error * in->ransac.reproj_error;
   {
     ScopedStage st(c, stage_id(c, "solve"), 0, 0, c->stream2);
-    hipLaunchKernelGGL(triangulate_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream2, dh, dh + 12, df, df + 2 * n, n, d_xyz);
+    hipLaunchKernelGGL(triangulate_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream2, dh, dh + 12, df, df + 2 * n, n, d_xyz);
     if (n >= 4) {
       hipLaunchKernelGGL(ransac_hypothesis_kernel, dim3(in->ransac.iterations), dim3(64), 0, c->stream2, dh + 24, d_xyz, df + 4 * n, n, dh + 33, in->ransac.seed, thr2, rw);
       hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(256), 0, c->stream2, dh + 24, d_xyz, df + 4 * n, n, dh + 33, in->ransac.iterations, thr2, rw);
@@ -2440,7 +2473,18 @@ int spvo_solve_stereo_odometry(spvo_ctx *c, const spvo_solve_input *in, spvo_sol
   }
   HIP_TRY(c, hipMemcpyAsync(c->h_solve_o, c->d_solve_o, (size_t)4 * n * 4, hipMemcpyDeviceToHost, c->stream2));
   if (n >= 4) HIP_TRY(c, hipMemcpyAsync(c->h_solve_res, c->d_solve_res, 40 * sizeof(double), hipMemcpyDeviceToHost, c->stream2));
-  HIP_TRY(c, hipStreamSynchronize(c->stream2));
+  if (!c->ev_solve) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_solve, hipEventDisableTiming));
+  HIP_TRY(c, hipEventRecord(c->ev_solve, c->stream2));
+  const double tm2 = solve_timing ? now_us() : 0;
+  HIP_TRY(c, wait_event(c->ev_solve));
+  if (solve_timing) {
+    const double tm3 = now_us();
+    tacc[0] += tm1 - tm0; tacc[1] += tm2 - tm1; tacc[2] += tm3 - tm2;
+    if (++tcalls % 200 == 0) {
+      std::fprintf(stderr, "[solve timing] pack %.1f us, enqueue %.1f us, wait %.1f us (n = %d)\n", tacc[0] / 200, tacc[1] / 200, tacc[2] / 200, n);
+      tacc[0] = tacc[1] = tacc[2] = 0;
+    }
+  }
   std::memcpy(xyz, c->h_solve_o, (size_t)3 * n * 4);
   if (n < 4) { prior_pose(); return SPVO_OK; }                                      // no model possible: prior is kept
   const double *res = c->h_solve_res, *gate = res + 8, *ref = res + 24;

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <time.h>
 
 // ------------------------------------------------------------------------- tf2lite
 #ifndef SPVO_USE_OPENCV
@@ -210,7 +211,13 @@ void FeatureFrontEnd::matchDescriptors(const MatchType match_type) {
 }
 
 // ------------------------------------------------------------------------- base.cpp:125-399
+static double host_now_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+
 void FeatureFrontEnd::solveStereoOdometry(tf2::Transform &cam0_curr_T_cam0_prev) {
+  static const bool timing = std::getenv("SPVO_SOLVE_TIMING") != nullptr;   // diagnostic
+  static double acc[3] = {0, 0, 0};
+  static long calls = 0;
+  const double th0 = timing ? host_now_us() : 0;
   if (keypoints_dq.size() < 4 || !ensureContext()) {
     logError("solveStereoOdometry needs two stereo frames");
     return;
@@ -288,7 +295,10 @@ void FeatureFrontEnd::solveStereoOdometry(tf2::Transform &cam0_curr_T_cam0_prev)
   si.refine = spvo_refine_opts{40, 1.0};                        // base.cpp:286, 362
   spvo_solve_output so;
   inliers_pnp.assign(std::max(n, 1), 0);
-  if (spvo_solve_stereo_odometry(ctx_, &si, &so, pts3d.data(), inliers_pnp.data()) != SPVO_OK) {
+  const double th1 = timing ? host_now_us() : 0;
+  const int solve_rc = spvo_solve_stereo_odometry(ctx_, &si, &so, pts3d.data(), inliers_pnp.data());
+  const double th2 = timing ? host_now_us() : 0;
+  if (solve_rc != SPVO_OK) {
     logError(std::string("spvo_solve_stereo_odometry: ") + spvo_last_error(ctx_));
     return;
   }
@@ -312,6 +322,14 @@ void FeatureFrontEnd::solveStereoOdometry(tf2::Transform &cam0_curr_T_cam0_prev)
     prev_left_points_3d_inited = true;
   }
   ++frame_count;
+  if (timing) {
+    const double th3 = host_now_us();
+    acc[0] += th1 - th0; acc[1] += th2 - th1; acc[2] += th3 - th2;
+    if (++calls % 200 == 0) {
+      std::fprintf(stderr, "[host solve timing] join %.1f us, C ABI call %.1f us, after %.1f us\n", acc[0] / 200, acc[1] / 200, acc[2] / 200);
+      acc[0] = acc[1] = acc[2] = 0;
+    }
+  }
 }
 
 cv::Mat FeatureFrontEnd::visualizeMatches(const MatchType match_type) {

@@ -24,12 +24,24 @@ plan.precision = prec
 tmp = tempfile.mkdtemp()
 os.makedirs(os.path.join(tmp, "laptop"))
 weights.save(plan, os.path.join(tmp, "laptop", weights.engine_name("superpoint_pretrained", 2, H, W, prec)))
-frames, poses, P_l, P_r = synth.stereo_sequence(8, os.path.join(ROOT, "tests", "golden", "images", "0000000000.png"), seed=0)
+cache = os.path.join(tempfile.gettempdir(), "spvo_hb_cache.npz")
+if os.environ.get("HB_CACHE") == "1" and os.path.exists(cache):   # diagnostic: skip the seconds of rendering (the frame rate depends on it)
+    z = np.load(cache)
+    frames = [(z["L"][k], z["R"][k]) for k in range(8)]
+    P_l, P_r = z["P_l"], z["P_r"]
+else:
+    frames, poses, P_l, P_r = synth.stereo_sequence(8, os.path.join(ROOT, "tests", "golden", "images", "0000000000.png"), seed=0)
+    np.savez(cache, L=np.stack([f[0] for f in frames]), R=np.stack([f[1] for f in frames]), P_l=P_l, P_r=P_r)
 d = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
 rows, cols = frames[0][0].shape
 order = list(range(8)) + list(range(6, 0, -1))
 fe = host.FrontEnd(tmp, prefix="superpoint_pretrained", height=H, width=W, precision=prec)
 assert fe.engine_loaded, fe.last_error
+if os.environ.get("HB_NOGC") == "1":
+    import gc
+    gc.disable()
+import threading
+print("python threads:", [t.name for t in threading.enumerate()])
 acc = np.zeros(5)
 N = 400
 for i in range(N + 20):
