@@ -614,6 +614,8 @@ struct spvo_cpu {
   Act scratch;                // full-resolution output of a conv with a fused pool
   // front-end state (hpp:96-178)
   int selector = 1, cross_check = 0, refinement_degree = 4;
+  bool classic = false;                              // ORB front end (BASELINE config 1): native resolution, Hamming descriptors
+  std::vector<std::vector<uint8_t>> bdesc_dq;        // its 32-byte descriptors, parallel to kp_dq
   float stereo_threshold = 2.f, min_disparity = 0.25f;
   std::vector<std::vector<float>> kp_dq, desc_dq;   // last 4: prevL, prevR, currL, currR
   std::vector<int32_t> maps[3];
@@ -738,6 +740,8 @@ static void linear_coeffs(int dst, int src, std::vector<int> &idx, std::vector<i
     a1[d] = (int)std::nearbyintf(f * 2048.f);
   }
 }
+
+#include "orb_cpu.inc"
 
 int spvo_cpu_preprocess(spvo_cpu *c, const uint8_t *img, int rows, int cols, size_t stride, double P[12], uint8_t *resized) {
   if (!c || !img || !P || rows <= 0 || cols <= 0) return fail(-1, "bad argument");
@@ -1034,7 +1038,8 @@ int spvo_cpu_frontend_reset(spvo_cpu *c, int selector, int cross_check, float st
   if (!c) return fail(-1, "null context");
   c->selector = selector; c->cross_check = cross_check && selector == 0;   // base.cpp:27-28: crossCheck only without KNN
   c->stereo_threshold = stereo_threshold; c->min_disparity = min_disparity; c->refinement_degree = refinement_degree;
-  c->kp_dq.clear(); c->desc_dq.clear();
+  c->kp_dq.clear(); c->desc_dq.clear(); c->bdesc_dq.clear();
+  c->classic = false;
   for (auto &m : c->maps) m.clear();
   for (int k = 0; k < 3; ++k) c->r_pred[k] = c->t_pred[k] = 0;
   c->frame_count = 0;
@@ -1043,9 +1048,39 @@ int spvo_cpu_frontend_reset(spvo_cpu *c, int selector, int cross_check, float st
   return 0;
 }
 
+int spvo_cpu_frontend_reset_classic(spvo_cpu *c, int selector, int cross_check, float stereo_threshold, int refinement_degree) {
+  // ClassicFeatureFrontEnd's constructor hands stereo_threshold to the base class as min_disparity too (hpp:203-206)
+  const int rc = spvo_cpu_frontend_reset(c, selector, cross_check, stereo_threshold, stereo_threshold, refinement_degree);
+  if (!rc) c->classic = true;
+  return rc;
+}
+
+int spvo_cpu_orb(spvo_cpu *c, const uint8_t *img, int rows, int cols, size_t stride, float *xy, float *angle_response_octave, uint8_t *desc, int cap, int *n) {
+  (void)c;
+  if (!img || !n || rows <= 0 || cols <= 0) return fail(-1, "bad argument");
+  std::vector<orb::Kp> kps;
+  std::vector<uint8_t> bd;
+  orb::detect_and_compute(img, rows, cols, stride, kps, bd);
+  *n = (int)kps.size();
+  for (int i = 0; i < *n && i < cap; ++i) {
+    if (xy) { xy[2 * i] = kps[i].x; xy[2 * i + 1] = kps[i].y; }
+    if (angle_response_octave) { angle_response_octave[3 * i] = kps[i].angle; angle_response_octave[3 * i + 1] = kps[i].response; angle_response_octave[3 * i + 2] = (float)kps[i].octave; }
+    if (desc) std::memcpy(desc + (size_t)i * 32, &bd[(size_t)i * 32], 32);
+  }
+  return 0;
+}
+
 static void frontend_match(spvo_cpu *c, int type) {   // base.cpp:434-491
   static const int pos[3][2] = {{-2, -1}, {-2, -4}, {-4, -3}};   // hpp:87-90
   const int nd = (int)c->kp_dq.size();
+  if (c->classic) {
+    const std::vector<uint8_t> &ba = c->bdesc_dq[nd + pos[type][0]], &bb = c->bdesc_dq[nd + pos[type][1]];
+    std::vector<int32_t> idx;
+    orb::hamming_match(ba.data(), (int)ba.size() / 32, bb.data(), (int)bb.size() / 32, c->selector, c->cross_check, 0.8f, idx);
+    if (type == 0) c->maps[2] = c->maps[0];
+    c->maps[type] = idx;
+    return;
+  }
   const std::vector<float> &da = c->desc_dq[nd + pos[type][0]], &db = c->desc_dq[nd + pos[type][1]];
   const int na = (int)da.size() / 256, nb = (int)db.size() / 256;
   std::vector<int32_t> idx(std::max(na, 1));
@@ -1074,15 +1109,25 @@ int spvo_cpu_frontend_step(spvo_cpu *c, const uint8_t *img_l, const uint8_t *img
   for (int side = 0; side < 2; ++side) {
     double *P = side ? c->P_r : c->P_l;
     std::memcpy(P, side ? P_r : P_l, 12 * sizeof(double));
+    if (c->classic) {   // classic.cpp:81-120 with image_height = image_width = 0: native resolution, P unchanged
+      std::vector<orb::Kp> kps;
+      std::vector<uint8_t> bd;
+      orb::detect_and_compute(side ? img_r : img_l, rows, cols, stride, kps, bd);
+      std::vector<float> xy(kps.size() * 2);
+      for (size_t i = 0; i < kps.size(); ++i) { xy[2 * i] = kps[i].x; xy[2 * i + 1] = kps[i].y; }
+      (side ? res->n_kp_r : res->n_kp_l) = (int)kps.size();
+      c->kp_dq.push_back(std::move(xy)); c->desc_dq.emplace_back(); c->bdesc_dq.push_back(std::move(bd));
+      continue;
+    }
     std::vector<float> xy((size_t)cap * 2), desc((size_t)cap * 256);
     int n = 0;
     const int rc = spvo_cpu_detect(c, side ? img_r : img_l, rows, cols, stride, P, xy.data(), desc.data(), &n);
     if (rc) return rc;
     xy.resize((size_t)n * 2); desc.resize((size_t)n * 256);
-    c->kp_dq.push_back(std::move(xy)); c->desc_dq.push_back(std::move(desc));
+    c->kp_dq.push_back(std::move(xy)); c->desc_dq.push_back(std::move(desc)); c->bdesc_dq.emplace_back();
     (side ? res->n_kp_r : res->n_kp_l) = n;
   }
-  while (c->kp_dq.size() > 4) { c->kp_dq.erase(c->kp_dq.begin()); c->desc_dq.erase(c->desc_dq.begin()); }
+  while (c->kp_dq.size() > 4) { c->kp_dq.erase(c->kp_dq.begin()); c->desc_dq.erase(c->desc_dq.begin()); c->bdesc_dq.erase(c->bdesc_dq.begin()); }
   const double t1 = now_ms();
   res->t_detect_ms = (float)(t1 - t0);
   frontend_match(c, 0);

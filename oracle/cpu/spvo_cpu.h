@@ -65,6 +65,12 @@ typedef struct {
 int spvo_cpu_frontend_reset(spvo_cpu *c, int selector, int cross_check, float stereo_threshold, float min_disparity, int refinement_degree);
 int spvo_cpu_frontend_step(spvo_cpu *c, const uint8_t *img_l, const uint8_t *img_r, int rows, int cols, size_t stride,
                            const double P_l[12], const double P_r[12], spvo_cpu_step_result *res);
+/* The classic front end of BASELINE config 1 on the CPU (ClassicFeatureFrontEnd with ORB / ORB / BF, classic.cpp:7-120; parameters of
+ * launch/visual_odometry_classic.launch): the following spvo_cpu_frontend_step calls detect ORB keypoints at the native resolution, match
+ * by Hamming distance and solve as above.  orb_cpu.inc says what is restated and the one thing that cannot be (OpenCV's learned test pairs). */
+int spvo_cpu_frontend_reset_classic(spvo_cpu *c, int selector, int cross_check, float stereo_threshold, int refinement_degree);
+/* ORB alone: xy [cap][2] (level-0 coordinates), angle_response_octave [cap][3], desc [cap][32]; *n = keypoints found */
+int spvo_cpu_orb(spvo_cpu *c, const uint8_t *img, int rows, int cols, size_t stride, float *xy, float *angle_response_octave, uint8_t *desc, int cap, int *n);
 /* introspection for the parity tests: maps_of_indices[match_type] of the last step */
 int spvo_cpu_frontend_map(spvo_cpu *c, int match_type, int32_t *out, int cap);
 

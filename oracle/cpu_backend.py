@@ -79,6 +79,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.spvo_cpu_frontend_reset.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int]
     lib.spvo_cpu_frontend_step.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, dp, dp, C.POINTER(StepResult)]
     lib.spvo_cpu_frontend_map.argtypes = [vp, C.c_int, vp, C.c_int]
+    lib.spvo_cpu_frontend_reset_classic.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_int]
+    lib.spvo_cpu_orb.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, vp, vp, C.c_int, ip]
     return lib
 
 
@@ -212,6 +214,21 @@ class CpuBackend:
         return res
 
     def frontend_map(self, match_type: int) -> np.ndarray:
-        out = np.zeros(self.cap, np.int32)
-        n = self.lib.spvo_cpu_frontend_map(self.h, match_type, _p(out), self.cap)
+        cap = max(self.cap, 4096)
+        out = np.zeros(cap, np.int32)
+        n = self.lib.spvo_cpu_frontend_map(self.h, match_type, _p(out), cap)
         return out[:n].copy()
+
+    def frontend_reset_classic(self, selector="KNN", cross_check=True, stereo_threshold=2.0, refinement_degree=4):
+        """ClassicFeatureFrontEnd(ORB, ORB, BF, ...) of launch/visual_odometry_classic.launch on the CPU (BASELINE config 1)."""
+        self._check(self.lib.spvo_cpu_frontend_reset_classic(self.h, 1 if selector == "KNN" else 0, int(cross_check), stereo_threshold, refinement_degree))
+
+    def orb(self, img, cap=4096):
+        img = np.ascontiguousarray(img, np.uint8)
+        xy = np.zeros((cap, 2), np.float32)
+        aro = np.zeros((cap, 3), np.float32)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        self._check(self.lib.spvo_cpu_orb(self.h, _p(img), img.shape[0], img.shape[1], img.strides[0], _p(xy), _p(aro), _p(desc), cap, C.byref(n)))
+        k = min(n.value, cap)
+        return dict(xy=xy[:k].copy(), angle=aro[:k, 0].copy(), response=aro[:k, 1].copy(), octave=aro[:k, 2].astype(np.int32), desc=desc[:k].copy())

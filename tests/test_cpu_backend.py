@@ -154,3 +154,57 @@ def test_state_machine_agrees_with_the_oracle(golden_dir, pair):
         assert np.abs(np.array(res.q[:]) - q).max() <= 1e-6 and np.abs(np.array(res.t[:]) - t).max() <= 1e-6
         assert res.t_total_ms > 0 and res.t_detect_ms > 0
     c.close()
+
+
+# ---------------------------------------------------------------- BASELINE config 1: the classic (ORB) front end on the CPU
+def test_orb_restatement_properties(cpu, pair):
+    """ORB with the reference's parameters (classic.cpp:13-24: 2000 features, scale 1.2, 8 levels, edge 31, FAST threshold 20): the
+    per-level budget of the ORB formula, the border, FAST scores above the threshold, and orientation-steered descriptors -- the
+    image turned by 180 degrees gives (nearly) the same descriptors at the mirrored keypoints."""
+    frames, _, _ = pair
+    img = frames[0][0]
+    o = cpu.orb(img)
+    assert len(o["xy"]) == 2000
+    f = 1 / 1.2
+    want = [round(2000 * (1 - f) / (1 - f ** 8) * f ** lv) for lv in range(8)]
+    got = np.bincount(o["octave"], minlength=8)
+    assert np.all(np.abs(got[:7] - want[:7]) <= 1) and got.sum() == 2000
+    scale = 1.2 ** o["octave"]
+    rows, cols = img.shape
+    assert np.all(o["xy"][:, 0] >= 31 * scale - 1e-3) and np.all(o["xy"][:, 0] <= cols - 31 * scale + 1.5 * scale)
+    assert o["response"].min() > 20                                  # FAST score above the threshold
+    for lv in range(8):                                              # best-first retention inside a level
+        r = o["response"][o["octave"] == lv]
+        assert np.all(np.diff(r) <= 0)
+    assert 0.35 < np.unpackbits(o["desc"], axis=1).mean() < 0.65     # binary tests are balanced
+    o2 = cpu.orb(np.ascontiguousarray(img[::-1, ::-1]))
+    # level-0 keypoints: the mirrored position exists in the turned image and its descriptor is close (same tests, steered by an
+    # orientation that turned with the image)
+    k0 = np.nonzero(o["octave"] == 0)[0]
+    pos2 = {(int(x), int(y)): i for i, (x, y) in enumerate(o2["xy"]) if o2["octave"][i] == 0}
+    dists = []
+    for i in k0:
+        j = pos2.get((cols - 1 - int(o["xy"][i, 0]), rows - 1 - int(o["xy"][i, 1])))
+        if j is not None:
+            dists.append(int(np.unpackbits(o["desc"][i] ^ o2["desc"][j]).sum()))
+    assert len(dists) > 150 and np.median(dists) < 40                # unrelated descriptors are ~128 bits apart
+
+
+def test_classic_front_end_tracks_the_synthetic_motion(golden_dir):
+    """ClassicFeatureFrontEnd(ORB, ORB, BF, KNN) at the native resolution through the CPU state machine (BASELINE config 1: plumbing
+    and the CPU baseline's workload): Hamming KNN matches, stereo gate with min_disparity = stereo_threshold (hpp:203-206), and a
+    pose close to the synthetic ground truth."""
+    frames, poses, P_l, P_r = synth.stereo_sequence(4, os.path.join(golden_dir, "images", "0000000000.png"), seed=0)
+    c = cpu_backend.CpuBackend(net_height=360, net_width=1176)
+    c.frontend_reset_classic("KNN", True, 2.0, 4)
+    for k, (L, R) in enumerate(frames):
+        r = c.frontend_step(L, R, P_l, P_r)
+        assert r.n_kp_l == 2000 and r.n_stereo > 1000
+        m = c.frontend_map(0)
+        assert len(m) == 2000 and (m >= 0).sum() == r.n_stereo and m.max() < 2000
+        if k == 0:
+            continue
+        assert r.pnp_ok and r.n_inliers > 300 and r.n_temporal > 700
+        Rt, tt = synth.relative_pose(poses[k - 1], poses[k])
+        assert np.abs(np.array(r.t[:]) - tt).max() < 0.1             # metres, per 0.8 m step
+    c.close()
