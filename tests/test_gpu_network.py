@@ -182,6 +182,21 @@ def test_mobilenet_forward_matches_oracle(name, H, W, batch, sample_images):
     ctx.close()
 
 
+@pytest.mark.parametrize("name", ["sp_squeeze", "sp_mbv1", "sp_mbv2"])
+def test_engines_match_the_direct_onnx_evaluation(name):
+    """The HIP engine against what the reference's ONNX graph gives when it is evaluated node by node by an interpreter that
+    shares nothing with the packer (oracle/onnx_direct.py; fixtures frozen by tests/golden/make_onnx_direct_golden.py from
+    models/<name>_b1.onnx): pins the network stage to the reference's own artefact, not to the plan-based oracle."""
+    import os
+    from tests.conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, f"onnx_direct_{name}_64x96.npz"))
+    ctx = make_ctx(os.path.join(GOLDEN, name + ".spvw"), net_height=64, net_width=96)
+    det, desc = ctx.forward(g["x"])
+    ctx.close()
+    assert np.abs(det - g["det"]).max() <= _tol(g["det"])
+    assert np.abs(desc - g["desc"].transpose(0, 2, 3, 1)).max() <= 1e-4
+
+
 @pytest.mark.parametrize("graph,H,W,batch", [("vgg", 192, 640, 2), ("vgg", 360, 1176, 2), ("squeeze", 192, 640, 2), ("vgg", 120, 392, 1),
                                              ("mbv1", 192, 640, 2), ("mbv2", 192, 640, 2), ("mbv2", 360, 1176, 2)])
 def test_fp16_engine_matches_fp16_oracle(graph, H, W, batch, vgg_plan, squeeze_plan, sample_images, tmp_path):
