@@ -27,17 +27,19 @@
 
 namespace spvo {
 
-// OIHW weights + bias -> slabs [co_tile][chunk][xi 16][cq 4][lane 64][s 2] of U = G g G^T (double) + a bias row
-inline std::vector<float> pack_conv_weights_wino2(const float *w, const float *bias, int cout, int cin) {
+// OIHW weights + bias -> slabs [co_tile][chunk][xi 16][cq][lane 64][s 2] of U = G g G^T (double) + a bias row; cot = output
+// channels per workgroup: 64 (cq 4) or, for the narrow form, 32 (cq 2)
+inline std::vector<float> pack_conv_weights_wino2(const float *w, const float *bias, int cout, int cin, int cot = CO_TILE) {
   constexpr int CK = WinoTile::CK;
-  const int co_tiles = (cout + CO_TILE - 1) / CO_TILE, nch = cin / CK;
-  std::vector<float> out((size_t)co_tiles * nch * WinoTile::W_FLOATS, 0.f);
+  const int co_tiles = (cout + cot - 1) / cot, nch = cin / CK, ncq = cot / 16;
+  const int u_floats = 16 * CK * cot, w_floats = u_floats + cot;
+  std::vector<float> out((size_t)co_tiles * nch * w_floats, 0.f);
   static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
   for (int ct = 0; ct < co_tiles; ++ct)
     for (int ch = 0; ch < nch; ++ch) {
-      float *slab = out.data() + ((size_t)ct * nch + ch) * WinoTile::W_FLOATS;
-      for (int o = 0; o < CO_TILE; ++o) {
-        const int co = ct * CO_TILE + o;
+      float *slab = out.data() + ((size_t)ct * nch + ch) * w_floats;
+      for (int o = 0; o < cot; ++o) {
+        const int co = ct * cot + o;
         if (co >= cout) continue;
         for (int c = 0; c < CK; ++c) {
           const float *g = w + ((size_t)co * cin + ch * CK + c) * 9;
@@ -47,20 +49,27 @@ inline std::vector<float> pack_conv_weights_wino2(const float *w, const float *b
           const int lane = 16 * (c & 3) + (o & 15), s = c >> 2, cq = o >> 4;
           for (int a = 0; a < 4; ++a)
             for (int b = 0; b < 4; ++b)
-              slab[((((a * 4 + b) * 4 + cq) * 64 + lane) * 2) + s] = (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
+              slab[((((a * 4 + b) * ncq + cq) * 64 + lane) * 2) + s] = (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
         }
-        if (ch == 0) slab[WinoTile::U_FLOATS + o] = bias[co];
+        if (ch == 0) slab[u_floats + o] = bias[co];
       }
     }
   return out;
 }
 
-template <bool POOL, bool RELU, int TAG = 0, bool ODD = false>
+// NARROW: 32 output channels per workgroup instead of 64 -- wave (cq of 2, tb of 4) owns 16 channels x 16 tiles x 16 positions
+// (64 accumulator registers, 32 matrix instructions per item).  Twice the workgroups for the same layer: for the layers at 1/8
+// resolution (conv4a / conv4b at 45 x 147: 120 workgroups of the wide form on 256 CUs) the chip is filled and a tile's chain
+// of items -- the layer's duration -- is made of items with half the matrix work.  The input transform is done once per
+// 32 instead of once per 64 output channels, which is why the wide form stays the choice wherever it fills the chip.
+template <bool POOL, bool RELU, int TAG = 0, bool ODD = false, bool NARROW = false>
 __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
   using T = WinoTile;
   constexpr int CK = T::CK, LW = T::LW, LH = T::LH, LW4 = LW / 4;
-  constexpr int IN_V4 = T::IN_FLOATS / 4, W_V4 = T::W_FLOATS / 4;
-  constexpr int NIT_R = (IN_V4 + 511) / 512, NIT_U = (W_V4 + 511) / 512;   // 2, 5
+  constexpr int COT = NARROW ? 32 : 64, NCQ = COT / 16, NBLK = NARROW ? 1 : 2;
+  constexpr int U_FL = 16 * CK * COT, W_FL = U_FL + COT;                    // a filter slab in global memory
+  constexpr int IN_V4 = T::IN_FLOATS / 4, W_V4 = W_FL / 4;
+  constexpr int NIT_R = (IN_V4 + 511) / 512, NIT_U = (W_V4 + 511) / 512;   // 2, 5 (narrow: 3)
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef float f32x4v __attribute__((ext_vector_type(4)));
 
@@ -70,7 +79,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
   const int lane = tid & 63;
   const int c16 = lane & 15, g4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cq = wave & 3, tb = wave >> 2;
+  const int cq = wave % NCQ, tb = wave / NCQ;
   const size_t in_plane = (size_t)a.in_hp * a.in_wp;
   const size_t out_plane = (size_t)a.out_hp * a.out_wp;
   const int n_tiles = a.tiles_x * a.tiles_y * a.co_tiles * a.batch;
@@ -87,7 +96,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
     t.x0 = tx * T::TW;
     t.y0 = ty * T::TH;
     t.in_base = a.in + ((size_t)t.img * a.in_ctot + a.in_coff) * in_plane + (size_t)(t.y0 + PADY - 1) * a.in_wp + (t.x0 + PADX - 4);
-    t.w_base = a.wpack + (size_t)t.ct * a.n_chunks * T::W_FLOATS;
+    t.w_base = a.wpack + (size_t)t.ct * a.n_chunks * W_FL;
     return t;
   };
 
@@ -110,7 +119,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
   };
   const unsigned uoff = 16u * (unsigned)tid;
   auto issue_u = [&](const TileRef &t, int chunk, float *buf) {
-    const char *wb = reinterpret_cast<const char *>(t.w_base + (size_t)chunk * T::W_FLOATS);
+    const char *wb = reinterpret_cast<const char *>(t.w_base + (size_t)chunk * W_FL);
 #pragma unroll
     for (int it = 0; it < NIT_U; ++it)
       if (it < NIT_U - 1 || it * 512 + tid < W_V4) glds16(reinterpret_cast<const float *>(wb + (uoff + 8192u * it)), buf + (it * 512 + wave * 64) * 4);
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
     if (it < NIT_R - 1 || it * 512 + tid < IN_V4) glds16(reinterpret_cast<const float *>(inb + roff[it]), buf + (it * 512 + wave * 64) * 4);
   };
   auto issue_u_piece = [&](const TileRef &t, int chunk, float *buf, int it) {
-    const char *wb = reinterpret_cast<const char *>(t.w_base + (size_t)chunk * T::W_FLOATS);
+    const char *wb = reinterpret_cast<const char *>(t.w_base + (size_t)chunk * W_FL);
     if (it < NIT_U - 1 || it * 512 + tid < W_V4) glds16(reinterpret_cast<const float *>(wb + (uoff + 8192u * it)), buf + (it * 512 + wave * 64) * 4);
   };
 
@@ -129,7 +138,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
   const int t_tile = tid & 63;
   const int t_trow = t_tile >> 4, t_tcol = t_tile & 15;
   const int raw_off = wave * (LH * LW) + (2 * t_trow) * LW + 3 + 2 * t_tcol;   // LDS row 0 = output row y0 - 1, LDS column 4 = output column x0
-  const int v_off = (((t_tile >> 5) * 64 + 16 * (wave & 3) + t_tcol) * 4) + 2 * ((t_tile >> 4) & 1) + (wave >> 2);   // + xi * 512
+  const int v_off = NARROW ? (((t_tile >> 4) * 64 + 16 * (wave & 3) + t_tcol) * 2) + (wave >> 2)                              // [xi][tb 4][lane][s]
+                           : (((t_tile >> 5) * 64 + 16 * (wave & 3) + t_tcol) * 4) + 2 * ((t_tile >> 4) & 1) + (wave >> 2);   // + xi * 512
   auto transform = [&](const float *raw, float *vb) {
     const float *d = raw + raw_off;
     float t[4][4];
@@ -170,8 +180,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
       v[3 * 512] = tt[r * 4 + 1] - tt[r * 4 + 3];
     }
   };
-  const int a_lane = cq * 64 + lane;   // 8-byte pieces in a filter slab:  + xi * 256
-  const int b_lane = tb * 64 + lane;   // 16-byte pieces in a V buffer:    + xi * 128
+  const int a_lane = cq * 64 + lane;   // 8-byte pieces in a filter slab:  + xi * 64 NCQ
+  const int b_lane = tb * 64 + lane;   // 16-byte (narrow: 8-byte) pieces in a V buffer:  + xi * 128 (256)
 
   int tile_id = blockIdx.x;
   if (tile_id >= n_tiles) return;
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
     if (next_id < n_tiles) nxt = decode(next_id);
 
     // acc[xi][blk]: position xi, tiles 16 blk .. 16 blk + 15 of this wave's 32; register r of a block = output channel 4 g4 + r
-    f32x4v acc[16][2];
+    f32x4v acc[16][NBLK];
     auto item = [&](auto first_tag) {
       constexpr bool FIRST = decltype(first_tag)::value;   // the tile's first chunk: C = 0 in every accumulator's first instruction
 #ifdef WINO_STAMPS
@@ -241,16 +251,22 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
         f32x2 av[4];
         f32x4v bv[4];
         auto ld = [&](int g, int x) {
-          av[x] = ub2[a_lane + (4 * g + x) * 256];
-          bv[x] = vb4[b_lane + (4 * g + x) * 128];
+          av[x] = ub2[a_lane + (4 * g + x) * (64 * NCQ)];
+          if constexpr (NARROW) {
+            const f32x2 b2 = reinterpret_cast<const f32x2 *>(vb)[b_lane + (4 * g + x) * 256];
+            bv[x][0] = b2[0]; bv[x][1] = b2[1];
+          } else {
+            bv[x] = vb4[b_lane + (4 * g + x) * 128];
+          }
         };
 #pragma unroll
         for (int x = 0; x < 4; ++x) ld(0, x);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+          constexpr int QN = NARROW ? 8 : 16;   // matrix instructions per group of 4 positions
 #pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            const int s = q >> 3, x = (q >> 1) & 3, blk = q & 1;
+          for (int q = 0; q < QN; ++q) {
+            const int s = NARROW ? q >> 2 : q >> 3, x = NARROW ? q & 3 : (q >> 1) & 3, blk = NARROW ? 0 : q & 1;
             if (FIRST && s == 0) acc[4 * g + x][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[x][s], bv[x][2 * blk + s], f32x4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             else acc[4 * g + x][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[x][s], bv[x][2 * blk + s], acc[4 * g + x][blk], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -260,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
 #ifndef WINO2_SPREAD
 #define WINO2_SPREAD 0   // 1: one LDS-DMA piece per matrix instruction instead of two bursts
 #endif
-            const int slot = 16 * g + q;
+            const int slot = QN * g + q;
             if (!(WINO2_ABL & 2)) {
               if (WINO2_SPREAD) {
                 if (slot >= 1 && slot < 1 + 2 * NIT_U && (slot & 1) && cu.id < n_tiles) issue_u_piece(cu.t, cu.chunk, u_next, (slot - 1) >> 1);
@@ -270,18 +286,22 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
                 if (slot == 5 && cr.id < n_tiles) issue_raw(cr.t, cr.chunk, raw_next2);
               }
             }
-            if (!(WINO2_ABL & 4) && g < 3 && q >= 12) ld(g + 1, q - 12);   // position x's registers were last read by instruction 9 + 2 x
+            if (!(WINO2_ABL & 4) && g < 3 && q >= QN - 4) ld(g + 1, q - (QN - 4));   // position x's registers were last read by instruction 9 + 2 x (narrow: 4 + x)
             // input transform of item k+1: 20 micro-steps on every other instruction slot (staggering them between the two waves of
             // a SIMD, or packing them densely, measured slower)
-            if (!(WINO2_ABL & 1) && slot >= 16 && slot < 56 && !(slot & 1)) xf_step(raw_next, v_next, (slot - 16) >> 1);
+            if constexpr (NARROW) {
+              if (!(WINO2_ABL & 1) && slot >= 8 && slot < 28) xf_step(raw_next, v_next, slot - 8);
+            } else {
+              if (!(WINO2_ABL & 1) && slot >= 16 && slot < 56 && !(slot & 1)) xf_step(raw_next, v_next, (slot - 16) >> 1);
+            }
             __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
       if (FIRST) {   // bias through position (1,1) (inverse-transform weight +1 for all four outputs): A = (bias, 0, 0, 0), B = 1
-        const float bias_a = g4 ? 0.f : ub[T::U_FLOATS + cq * 16 + c16];
-        acc[5][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bias_a, 1.0f, acc[5][0], 0, 0, 0);
-        acc[5][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bias_a, 1.0f, acc[5][1], 0, 0, 0);
+        const float bias_a = g4 ? 0.f : ub[U_FL + cq * 16 + c16];
+#pragma unroll
+        for (int blk = 0; blk < NBLK; ++blk) acc[5][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(bias_a, 1.0f, acc[5][blk], 0, 0, 0);
       }
       advance(cu);
       advance(cr);
@@ -302,14 +322,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
     const unsigned long long te0 = __builtin_amdgcn_s_memtime();
 #endif
     // ---------------------------------------------------------------- epilogue: Y = A^T M A, ReLU, (pool), store
-    float *co_base = a.out + (((size_t)cur.img * a.out_ctot + a.out_coff) + (size_t)cur.ct * CO_TILE + cq * 16) * out_plane;
+    float *co_base = a.out + (((size_t)cur.img * a.out_ctot + a.out_coff) + (size_t)cur.ct * COT + cq * 16) * out_plane;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(co_base, 0, 0x7FFFFFFF, 0x00020000);
     const int oplane = (int)out_plane;
-    const int kmax = a.cout - (cur.ct * CO_TILE + cq * 16 + 4 * g4);   // channels r < kmax of this lane's 4 exist
+    const int kmax = a.cout - (cur.ct * COT + cq * 16 + 4 * g4);   // channels r < kmax of this lane's 4 exist
     auto relu = [](float v) { return RELU ? __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()) : v; };
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-      const int trow = 2 * tb + blk, tcol = c16;
+    for (int blk = 0; blk < NBLK; ++blk) {
+      const int trow = NARROW ? tb : 2 * tb + blk, tcol = c16;
       unsigned voff, voff01 = OOB, voff10 = OOB, voff11 = OOB;
       if constexpr (POOL) {
         const int y = (cur.y0 >> 1) + trow, x = (cur.x0 >> 1) + tcol;

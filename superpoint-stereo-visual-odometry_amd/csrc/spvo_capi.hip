@@ -58,6 +58,7 @@ struct Op {
   bool merged = false;     // FP32 engines: this op's output channels are computed by the previous op's launch (sibling layers
                            // that read the same tensor and write adjacent channel ranges of one tensor: convPa + convDa)
   bool wino = false;       // FP32 engines: this 3x3 layer runs the Winograd F(2x2,3x3) kernel (conv_wino.hip.h)
+  bool wino_narrow = false;   // ... with 32 instead of 64 output channels per workgroup (layers whose 64-channel tiles would leave CUs idle)
   bool wino2 = false;      // ... its 8-wave form (conv_wino2.hip.h: two waves per SIMD; the default, SPVO_WINO2=0 keeps the 4-wave form)
   bool dominant = false;   // the op with the most FLOPs: launched under its own kernel name (TAG = 1)
   float *d_w = nullptr, *d_b = nullptr, *d_bn_scale = nullptr, *d_bn_shift = nullptr;
@@ -374,7 +375,7 @@ int launch_conv_epi(spvo_ctx *c, const ConvArgs &a, int batch, int epi, hipStrea
 
 // Winograd F(2x2, 3x3) instance of a 3x3 layer (conv_wino.hip.h / conv_wino2.hip.h): one tile shape, one workgroup per CU (157 KB of
 // LDS); W2 selects the 8-wave form (two waves per SIMD, 512 threads)
-template <bool POOL, bool RELU, int TAG, bool ODD = false, bool W2 = false>
+template <bool POOL, bool RELU, int TAG, bool ODD = false, bool W2 = false, bool NARROW = false>
 int launch_conv_wino_instance(spvo_ctx *c, const ConvArgs &args, hipStream_t stream) {
   static bool ready[64] = {};
   const int dev = c->cfg.device & 63;
@@ -386,7 +387,7 @@ int launch_conv_wino_instance(spvo_ctx *c, const ConvArgs &args, hipStream_t str
   const int rounds = (n_tiles + c->num_cus - 1) / c->num_cus;
   const int grid = (n_tiles + rounds - 1) / rounds;
   if constexpr (W2) {
-    auto k = conv_wino2_kernel<POOL, RELU, TAG, ODD>;
+    auto k = conv_wino2_kernel<POOL, RELU, TAG, ODD, NARROW>;
     if (!ready[dev]) {
       HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, WinoTile::LDS_BYTES));
       ready[dev] = true;
@@ -405,20 +406,26 @@ int launch_conv_wino_instance(spvo_ctx *c, const ConvArgs &args, hipStream_t str
 }
 
 template <bool W2>
-int launch_conv_wino_sel(spvo_ctx *c, const ConvArgs &args, bool relu, bool pool, bool dominant, hipStream_t stream) {
+int launch_conv_wino_sel(spvo_ctx *c, const ConvArgs &args, bool relu, bool pool, bool dominant, bool narrow, hipStream_t stream) {
   const ConvArgs &a = args;
+  if constexpr (W2)
+    if (narrow) {   // 32 output channels per workgroup (layers that would leave CUs idle with 64)
+      if (!pool && ((a.H | a.W) & 1)) return relu ? launch_conv_wino_instance<false, true, 0, true, true, true>(c, args, stream) : launch_conv_wino_instance<false, false, 0, true, true, true>(c, args, stream);
+      if (pool) return relu ? launch_conv_wino_instance<true, true, 0, false, true, true>(c, args, stream) : launch_conv_wino_instance<true, false, 0, false, true, true>(c, args, stream);
+      return relu ? launch_conv_wino_instance<false, true, 0, false, true, true>(c, args, stream) : launch_conv_wino_instance<false, false, 0, false, true, true>(c, args, stream);
+    }
   if (!pool && ((a.H | a.W) & 1)) return relu ? launch_conv_wino_instance<false, true, 0, true, W2>(c, args, stream) : launch_conv_wino_instance<false, false, 0, true, W2>(c, args, stream);
   if (dominant && relu) return pool ? launch_conv_wino_instance<true, true, 1, false, W2>(c, args, stream) : launch_conv_wino_instance<false, true, 1, false, W2>(c, args, stream);
   if (pool) return relu ? launch_conv_wino_instance<true, true, 0, false, W2>(c, args, stream) : launch_conv_wino_instance<true, false, 0, false, W2>(c, args, stream);
   return relu ? launch_conv_wino_instance<false, true, 0, false, W2>(c, args, stream) : launch_conv_wino_instance<false, false, 0, false, W2>(c, args, stream);
 }
 
-int launch_conv_wino(spvo_ctx *c, const ConvArgs &a, int batch, bool relu, bool pool, bool dominant, bool w2, hipStream_t stream) {
+int launch_conv_wino(spvo_ctx *c, const ConvArgs &a, int batch, bool relu, bool pool, bool dominant, bool w2, bool narrow, hipStream_t stream) {
   ConvArgs args = a;
   args.tiles_x = (a.W + WinoTile::TW - 1) / WinoTile::TW;
   args.tiles_y = (a.H + WinoTile::TH - 1) / WinoTile::TH;
   args.batch = batch;
-  return w2 ? launch_conv_wino_sel<true>(c, args, relu, pool, dominant, stream) : launch_conv_wino_sel<false>(c, args, relu, pool, dominant, stream);
+  return w2 ? launch_conv_wino_sel<true>(c, args, relu, pool, dominant, narrow, stream) : launch_conv_wino_sel<false>(c, args, relu, pool, dominant, false, stream);
 }
 
 // Variant choice for a layer.  3x3: every tile variant has a measured rate on perfectly divisible shapes
@@ -493,7 +500,7 @@ int launch_conv(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stre
   a.cout = op.cout; a.n_chunks = op.n_chunks; a.co_tiles = op.co_tiles;
   a.tiles_x = a.tiles_y = 0;
   a.batch = batch;
-  if (op.wino) return launch_conv_wino(c, a, batch, relu, pool, op.dominant, op.wino2, stream);
+  if (op.wino) return launch_conv_wino(c, a, batch, relu, pool, op.dominant, op.wino2, op.wino_narrow, stream);
   const int key = op.ks * 10000 + op.ck * 100 + op.wr * 20 + op.wc * 2 + (pool ? 1 : 0);   // ks, ck, wr, wc, pool
   if (epi) {
     a.bn_scale = op.d_bn_scale; a.bn_shift = op.d_bn_shift;
@@ -1748,13 +1755,19 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
         const bool wino_on = !(std::getenv("SPVO_WINOGRAD") && std::atoi(std::getenv("SPVO_WINOGRAD")) == 0);
         const long wtiles = (long)((ti.W + WinoTile::TW - 1) / WinoTile::TW) * ((ti.H + WinoTile::TH - 1) / WinoTile::TH) * op.co_tiles * c->cfg.max_batch;
         const long min_tiles = std::getenv("SPVO_WINOGRAD_MIN_TILES") ? std::atol(std::getenv("SPVO_WINOGRAD_MIN_TILES")) : 3 * c->num_cus / 4;
-        op.wino = wino_on && op.ks == 3 && !bn && !add && (op.cin % WinoTile::CK) == 0 && (!pool || ((ti.H % 2) == 0 && (ti.W % 2) == 0)) && wtiles >= min_tiles;
+        const bool eligible = wino_on && op.ks == 3 && !bn && !add && (op.cin % WinoTile::CK) == 0 && (!pool || ((ti.H % 2) == 0 && (ti.W % 2) == 0));
+        op.wino2 = !(std::getenv("SPVO_WINO2") && std::atoi(std::getenv("SPVO_WINO2")) == 0);
+        op.wino = eligible && wtiles >= min_tiles;
+        // too few 64-channel tiles (conv4a / conv4b at 45x147: 120 on 256 CUs): 32 channels per workgroup fill the chip, and the
+        // layer -- one tile's chain of items per workgroup -- becomes a chain of half-size items (SPVO_WINO_NARROW=0: direct kernel)
+        const bool narrow_on = !(std::getenv("SPVO_WINO_NARROW") && std::atoi(std::getenv("SPVO_WINO_NARROW")) == 0);
+        if (eligible && !op.wino && op.wino2 && narrow_on && (op.cout % 32) == 0 && 2 * wtiles >= min_tiles) op.wino = op.wino_narrow = true;
       }
       if (op.wino) {
         op.ck = WinoTile::CK;
         op.n_chunks = op.cin / op.ck;
-        op.wino2 = !(std::getenv("SPVO_WINO2") && std::atoi(std::getenv("SPVO_WINO2")) == 0);
-        const std::vector<float> pk = op.wino2 ? pack_conv_weights_wino2(w, b, op.cout, op.cin) : pack_conv_weights_wino(w, b, op.cout, op.cin);
+        if (op.wino_narrow) op.co_tiles = op.cout / 32;
+        const std::vector<float> pk = op.wino2 ? pack_conv_weights_wino2(w, b, op.cout, op.cin, op.wino_narrow ? 32 : CO_TILE) : pack_conv_weights_wino(w, b, op.cout, op.cin);
         int rc = dev_alloc(c, &op.d_w, pk.size(), false);
         if (rc) return rc;
         HIP_TRY(c, hipMemcpy(op.d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
@@ -2008,6 +2021,26 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   // ---- everything below is enqueued without a host round trip
   c->cur_ring = ring;
   c->post = c->stream;
+  // SPVO_TRUNK_TIMING=1 (diagnostic): how long the network stream works per submission and how long it stands idle between two
+  // submissions, from timing events at both ends of the trunk (printed every 200 submissions)
+  static const bool trunk_timing = std::getenv("SPVO_TRUNK_TIMING") != nullptr;
+  static hipEvent_t tt_b[RING], tt_e[RING];
+  static long tt_n = 0;
+  static double tt_busy = 0, tt_idle = 0;
+  if (trunk_timing) {
+    if (tt_n == 0)
+      for (int r = 0; r < RING; ++r) { (void)hipEventCreate(&tt_b[r]); (void)hipEventCreate(&tt_e[r]); }
+    if (tt_n >= RING) {   // the two submissions before the two that may be in flight are complete: ring slots (n-2) and (n-3)
+      const int r2 = (int)((tt_n - 2) % RING), r3 = (int)((tt_n - 3) % RING);
+      float busy = 0, idle = 0;
+      if (hipEventElapsedTime(&busy, tt_b[r2], tt_e[r2]) == hipSuccess && hipEventElapsedTime(&idle, tt_e[r3], tt_b[r2]) == hipSuccess) { tt_busy += busy; tt_idle += idle; }
+      if (tt_n % 200 == 0) {
+        std::fprintf(stderr, "[spvo] trunk timing over 200 submissions: network stream busy %.1f us, idle %.1f us per submission\n", tt_busy * 1e3 / 200, tt_idle * 1e3 / 200);
+        tt_busy = tt_idle = 0;
+      }
+    }
+    (void)hipEventRecord(tt_b[tt_n % RING], c->stream);
+  }
   hipEvent_t det_e0 = nullptr;
   const bool prof_detect = c->prof && (c->prof_only < 0 || c->prof_only == stage_id(c, "detect"));
   if (prof_detect) { det_e0 = get_event(c); (void)hipEventRecord(det_e0, c->stream); }
@@ -2023,6 +2056,7 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   }
   if (rc) { c->cur_ring = 0; return rc; }
   c->last_batch = 2;
+  if (trunk_timing) { (void)hipEventRecord(tt_e[tt_n % RING], c->stream); ++tt_n; }
   HIP_TRY(c, hipEventRecord(c->ev_net[ring], c->stream));
   HIP_TRY(c, hipStreamWaitEvent(c->stream_t, c->ev_net[ring], 0));
   c->post = c->stream_t;

@@ -87,6 +87,33 @@ def test_nms_edge_cases(vgg_weights_path):
     ctx.close()
 
 
+@pytest.mark.parametrize("H,W,dist,border", [(360, 1176, 4, 4), (120, 392, 4, 4), (120, 392, 2, 0), (120, 392, 8, 3), (192, 640, 3, 4)])
+def test_nms_on_sparse_tied_clustered_and_dense_heat_maps(vgg_weights_path, H, W, dist, border):
+    """processOneHeatmap on synthetic heat maps of four kinds -- sparse with distinct confidences, many exact ties and near-ties,
+    blobs that need several rounds of decisions per neighbourhood, every pixel a candidate -- at several sizes, radii and
+    borders: bit-exact keypoints against the oracle's sequential greedy suppression."""
+    ctx = make_ctx(vgg_weights_path, net_height=H, net_width=W, max_keypoints=1000, dist_thresh=dist, border_remove=border)
+    rng = np.random.RandomState(H + dist)
+    heats = []
+    sparse = np.where(rng.rand(H, W) < 0.02, 0.02 + 0.9 * rng.rand(H, W), 0.001).astype(np.float32)
+    heats.append(sparse)                                            # ~2 % candidates, distinct confidences
+    coarse = sparse.copy()
+    m = coarse > 0.015
+    coarse[m] = (np.round(coarse[m] * 64) / 64 + 1e-6 * rng.randint(0, 3, m.sum())).astype(np.float32)   # many ties / near-ties
+    heats.append(coarse)
+    clustered = np.full((H, W), 0.001, np.float32)
+    for _ in range(300):                                            # blobs: several rounds of decisions per neighbourhood
+        cy, cx = rng.randint(0, H), rng.randint(0, W)
+        y0, y1, x0, x1 = max(cy - 6, 0), min(cy + 7, H), max(cx - 6, 0), min(cx + 7, W)
+        clustered[y0:y1, x0:x1] = 0.1 + 0.8 * rng.rand(y1 - y0, x1 - x0).astype(np.float32)
+    heats.append(clustered)
+    heats.append((0.02 + 0.9 * rng.rand(H, W)).astype(np.float32))  # every pixel a candidate
+    for heat in heats:
+        got, ref = _nms_both(ctx, heat)
+        assert np.array_equal(got, ref)
+    ctx.close()
+
+
 def test_sample_descriptors(ctx_squeeze, squeeze_plan, sample_images):
     x = (sample_images[0][:360, :1176].astype(np.float32) / 255)[None, None]
     det, desc = net.forward(squeeze_plan, x)

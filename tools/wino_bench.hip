@@ -11,14 +11,21 @@
 #include <algorithm>
 #include "../superpoint-stereo-visual-odometry_amd/csrc/conv_wino.hip.h"
 #include "../superpoint-stereo-visual-odometry_amd/csrc/conv_wino2.hip.h"
-#ifdef WINO2
-#define KERNEL conv_wino2_kernel
+#if defined(WINO2) && defined(WINO2_NARROW)   // the 8-wave form with 32 output channels per workgroup
+#define KERNEL(P, R, T, O) conv_wino2_kernel<P, R, T, O, true>
+#define PACK(w, b, co, ci) pack_conv_weights_wino2(w, b, co, ci, 32)
+#define THREADS 512
+#define COT 32
+#elif defined(WINO2)
+#define KERNEL(P, R, T, O) conv_wino2_kernel<P, R, T, O>
 #define PACK pack_conv_weights_wino2
 #define THREADS 512
+#define COT 64
 #else
-#define KERNEL conv_wino_kernel
+#define KERNEL(P, R, T, O) conv_wino_kernel<P, R, T, O>
 #define PACK pack_conv_weights_wino
 #define THREADS 256
+#define COT 64
 #endif
 using namespace spvo;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
@@ -51,17 +58,17 @@ int main(int argc, char **argv) {
   a.in = d_in; a.out = d_out; a.wpack = d_w; a.bias = nullptr; a.H = H; a.W = W;
   a.in_hp = ihp; a.in_wp = iwp; a.in_ctot = cin; a.in_coff = 0; a.out_hp = ohp; a.out_wp = owp; a.out_ctot = cout; a.out_coff = 0;
   a.cout = cout; a.n_chunks = cin / WinoTile::CK; a.tiles_x = (W + WinoTile::TW - 1) / WinoTile::TW; a.tiles_y = (H + WinoTile::TH - 1) / WinoTile::TH;
-  a.co_tiles = (cout + 63) / 64; a.batch = batch;
+  a.co_tiles = (cout + COT - 1) / COT; a.batch = batch;
   const long n_items = (long)a.tiles_x * a.tiles_y * a.co_tiles * batch * a.n_chunks;
   const int grid = argc > 7 ? atoi(argv[7]) : (int)std::min<long>(cus, n_items / a.n_chunks);
   auto launch = [&]() {
-    if (pool) { hipLaunchKernelGGL((KERNEL<true, true, 0, false>), dim3(grid), dim3(THREADS), WinoTile::LDS_BYTES, 0, a); }
-    else if ((H | W) & 1) { hipLaunchKernelGGL((KERNEL<false, true, 0, true>), dim3(grid), dim3(THREADS), WinoTile::LDS_BYTES, 0, a); }
-    else { hipLaunchKernelGGL((KERNEL<false, true, 0, false>), dim3(grid), dim3(THREADS), WinoTile::LDS_BYTES, 0, a); }
+    if (pool) { hipLaunchKernelGGL((KERNEL(true, true, 0, false)), dim3(grid), dim3(THREADS), WinoTile::LDS_BYTES, 0, a); }
+    else if ((H | W) & 1) { hipLaunchKernelGGL((KERNEL(false, true, 0, true)), dim3(grid), dim3(THREADS), WinoTile::LDS_BYTES, 0, a); }
+    else { hipLaunchKernelGGL((KERNEL(false, true, 0, false)), dim3(grid), dim3(THREADS), WinoTile::LDS_BYTES, 0, a); }
   };
-  CK(hipFuncSetAttribute((const void *)KERNEL<true, true, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WinoTile::LDS_BYTES));
-  CK(hipFuncSetAttribute((const void *)KERNEL<false, true, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WinoTile::LDS_BYTES));
-  CK(hipFuncSetAttribute((const void *)KERNEL<false, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WinoTile::LDS_BYTES));
+  CK(hipFuncSetAttribute((const void *)KERNEL(true, true, 0, false), hipFuncAttributeMaxDynamicSharedMemorySize, WinoTile::LDS_BYTES));
+  CK(hipFuncSetAttribute((const void *)KERNEL(false, true, 0, false), hipFuncAttributeMaxDynamicSharedMemorySize, WinoTile::LDS_BYTES));
+  CK(hipFuncSetAttribute((const void *)KERNEL(false, true, 0, true), hipFuncAttributeMaxDynamicSharedMemorySize, WinoTile::LDS_BYTES));
   for (int i = 0; i < 5; ++i) launch();
   CK(hipDeviceSynchronize());
   hipEvent_t e0, e1;
