@@ -161,7 +161,7 @@ struct NmsBuffers {   // per image
   int *cand;          // [H*W] row-major pixel index of each candidate
   int *counters;      // [0] n_cand, [1] n_survivors, [2] n_out, [3] overflow, [8 + l] undecided after launch l
   unsigned long long *surv_key;  // [surv_cap]
-  unsigned long long *surv_sorted;  // [surv_cap]: the keys grouped by bucket (nms_order_kernel)
+  int *rank;          // [surv_cap], zero between uses
   int *out_xy;        // [max_kp][2]
 };
 struct NmsPair { NmsBuffers b[2]; };   // blockIdx.y / blockIdx.z selects the image
@@ -424,75 +424,43 @@ __global__ __launch_bounds__(256) void nms_collect_kernel(const float *__restric
   }
 }
 
-// K9: order the survivors and write the first max_kp -- the output position of a survivor is the number of survivors with a
-// smaller key.  Counting that against ALL survivors is n^2 work (6-8 k survivors per image on the headline workload: a
-// launch of 2278 workgroups that filled the chip for 15 us next to the following pair's convolutions); the keys are
-// bucketed instead by a monotone function of the confidence (4096 buckets over the bit patterns of (conf_thresh .. 1]), so that
-// position = survivors in earlier buckets + survivors of the own bucket with a smaller key.  ONE workgroup per image:
-// histogram and its prefix sums in LDS, the keys regrouped by bucket in global memory, the in-bucket count (a few keys) per
-// survivor.  Exact for any input (equal confidences, confidences outside the expected range: the bucket function saturates and
-// stays monotone); a heat map that puts most survivors into one bucket just takes longer.
-constexpr int ORDER_THREADS = 1024, ORDER_BUCKETS = 4096;
-__device__ __forceinline__ int order_bucket(unsigned long long key, unsigned inv_lo, int shift) {
-  const unsigned inv = (unsigned)(key >> 32);          // 0xFFFFFFFF - bits(conf): smaller = more confident
-  return inv <= inv_lo ? 0 : (int)min((inv - inv_lo) >> shift, (unsigned)(ORDER_BUCKETS - 1));
-}
-__global__ __launch_bounds__(ORDER_THREADS) void nms_order_kernel(int H, int max_kp, int surv_cap, float conf_thresh, NmsPair np, int *zero_next) {
-  __shared__ int s_start[ORDER_BUCKETS], s_cur[ORDER_BUCKETS];
-  __shared__ int s_wave[ORDER_THREADS / 64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const NmsBuffers nb = np.b[blockIdx.x];
-  // hand the next submission a clean counter block (it belongs to the other parity)
-  if (zero_next && tid < NMS_COUNTER_INTS) zero_next[blockIdx.x * NMS_COUNTER_INTS + tid] = 0;
+// K9: rank by counting -- the output position of a survivor is the number of survivors with a
+// smaller key.  2-D decomposition: block (bi, bj) counts 256 keys against a 1024-key LDS tile.
+constexpr int RANK_TILE = 1024;
+__global__ __launch_bounds__(256) void nms_rank_kernel(int surv_cap, NmsPair np) {
+  __shared__ __attribute__((aligned(16))) unsigned long long tile[RANK_TILE];
+  const NmsBuffers nb = np.b[blockIdx.z];
   const int n = min(nb.counters[1], surv_cap);
-  if (tid == 0) nb.counters[2] = min(n, max_kp);
-  // buckets: the bit patterns between 1.0 and the threshold, 4096 equal steps (whatever lies outside lands in the end buckets)
-  const unsigned inv_lo = 0xFFFFFFFFu - __float_as_uint(1.0f);
-  const unsigned inv_hi = 0xFFFFFFFFu - __float_as_uint(fmaxf(conf_thresh, 1e-30f));
-  int shift = 0;
-  while (shift < 31 && ((inv_hi > inv_lo ? inv_hi - inv_lo : 0u) >> shift) >= (unsigned)ORDER_BUCKETS) ++shift;
-  for (int b = tid; b < ORDER_BUCKETS; b += ORDER_THREADS) s_cur[b] = 0;
+  const int i = blockIdx.x * 256 + threadIdx.x, j0 = blockIdx.y * RANK_TILE;
+  if (blockIdx.x * 256 >= n || j0 >= n) return;
+  for (int t = threadIdx.x; t < RANK_TILE; t += 256) tile[t] = (j0 + t < n) ? nb.surv_key[j0 + t] : ~0ull;
   __syncthreads();
-  for (int i = tid; i < n; i += ORDER_THREADS) atomicAdd(&s_cur[order_bucket(nb.surv_key[i], inv_lo, shift)], 1);
-  __syncthreads();
-  {   // exclusive prefix over the buckets: 4 consecutive buckets per thread
-    constexpr int PER = ORDER_BUCKETS / ORDER_THREADS;
-    int c[PER], tot = 0;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) { c[k] = s_cur[tid * PER + k]; tot += c[k]; }
-    int incl = tot;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(incl, o);
-      if (lane >= o) incl += t;
-    }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    int run = incl - tot;
-    for (int v = 0; v < wave; ++v) run += s_wave[v];
-#pragma unroll
-    for (int k = 0; k < PER; ++k) { s_start[tid * PER + k] = run; run += c[k]; }
+  if (i >= n) return;
+  const unsigned long long key = nb.surv_key[i];
+  int cnt = 0;
+  const ulonglong2 *t2 = (const ulonglong2 *)tile;
+#pragma unroll 8
+  for (int t = 0; t < RANK_TILE / 2; ++t) {
+    const ulonglong2 v = t2[t];
+    cnt += (v.x < key ? 1 : 0) + (v.y < key ? 1 : 0);
   }
-  __syncthreads();
-  for (int b = tid; b < ORDER_BUCKETS; b += ORDER_THREADS) s_cur[b] = s_start[b];
-  __syncthreads();
-  for (int i = tid; i < n; i += ORDER_THREADS) {
-    const unsigned long long key = nb.surv_key[i];
-    nb.surv_sorted[atomicAdd(&s_cur[order_bucket(key, inv_lo, shift)], 1)] = key;
-  }
-  __threadfence_block();
-  __syncthreads();   // s_cur[b] is now the END of bucket b
-  for (int i = tid; i < n; i += ORDER_THREADS) {
-    const unsigned long long key = ((volatile unsigned long long *)nb.surv_sorted)[i];
-    const int b = order_bucket(key, inv_lo, shift);
-    const int lo = s_start[b], hi = s_cur[b];
-    int rank = lo;
-    for (int j = lo; j < hi; ++j) rank += ((volatile unsigned long long *)nb.surv_sorted)[j] < key ? 1 : 0;
-    if (rank < max_kp) {
-      const unsigned cm = (unsigned)(key & 0xFFFFFFFFull);
-      nb.out_xy[2 * rank + 0] = (int)(cm / (unsigned)H);
-      nb.out_xy[2 * rank + 1] = (int)(cm % (unsigned)H);
-    }
+  if (cnt) atomicAdd(&nb.rank[i], cnt);
+}
+
+__global__ __launch_bounds__(256) void nms_write_kernel(int H, int max_kp, int surv_cap, NmsPair np, int *zero_next) {
+  const NmsBuffers nb = np.b[blockIdx.y];
+  // hand the next submission a clean counter block (it belongs to the other parity)
+  if (zero_next && blockIdx.x == 0 && threadIdx.x < NMS_COUNTER_INTS) zero_next[blockIdx.y * NMS_COUNTER_INTS + threadIdx.x] = 0;
+  const int n = min(nb.counters[1], surv_cap);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) nb.counters[2] = min(n, max_kp);
+  if (i >= n) return;
+  const int rank = nb.rank[i];
+  nb.rank[i] = 0;
+  if (rank < max_kp) {
+    const unsigned cm = (unsigned)(nb.surv_key[i] & 0xFFFFFFFFull);
+    nb.out_xy[2 * rank + 0] = (int)(cm / (unsigned)H);
+    nb.out_xy[2 * rank + 1] = (int)(cm % (unsigned)H);
   }
 }
 

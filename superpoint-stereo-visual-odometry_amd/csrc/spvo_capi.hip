@@ -979,7 +979,8 @@ int launch_nms_rounds(spvo_ctx *c, int nimg, const NmsPair &np, int set, int n_l
       hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 0>), dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, c->cfg.dist_thresh, np, l);
   }
   hipLaunchKernelGGL(nms_collect_kernel, dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, c->cfg.border_remove, c->surv_cap, np);
-  hipLaunchKernelGGL(nms_order_kernel, dim3(nimg), dim3(ORDER_THREADS), 0, st, c->H, c->cfg.max_keypoints, c->surv_cap, c->cfg.conf_thresh, np, zero_next);
+  hipLaunchKernelGGL(nms_rank_kernel, dim3((c->surv_cap + 255) / 256, (c->surv_cap + RANK_TILE - 1) / RANK_TILE, nimg), dim3(256), 0, st, c->surv_cap, np);
+  hipLaunchKernelGGL(nms_write_kernel, dim3((c->surv_cap + 255) / 256, nimg), dim3(256), 0, st, c->H, c->cfg.max_keypoints, c->surv_cap, np, zero_next);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(c->h_counters_r[set % RING], np.b[0].counters, (size_t)nimg * NMS_COUNTER_INTS * sizeof(int), hipMemcpyDeviceToHost, st));
   return SPVO_OK;
@@ -1315,7 +1316,7 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
         if ((rc = dev_alloc(c, &b.cand, hw))) break;
         b.counters = nullptr;   // set per submission (nms_pair)
         if ((rc = dev_alloc(c, &b.surv_key, c->surv_cap))) break;
-        if ((rc = dev_alloc(c, &b.surv_sorted, c->surv_cap))) break;
+        if ((rc = dev_alloc(c, &b.rank, c->surv_cap))) break;
         if ((rc = dev_alloc(c, &b.out_xy, (size_t)cap * 2))) break;
       }
     if (rc) break;
@@ -1367,7 +1368,7 @@ void spvo_destroy(spvo_ctx *c) {
   for (int r = 0; r < RING; ++r) {
     for (int i = 0; i < 2; ++i) {
       NmsBuffers &b = c->nms_r[r][i].b;
-      void *q[] = {b.state, b.cand, b.surv_key, b.surv_sorted, b.out_xy};
+      void *q[] = {b.state, b.cand, b.surv_key, b.rank, b.out_xy};
       for (void *p : q) if (p) (void)hipFree(p);
     }
     if (c->d_heat_base_r[r]) (void)hipFree(c->d_heat_base_r[r]);
