@@ -27,6 +27,8 @@
 
 namespace spvo {
 
+constexpr int WINO2_LDS_BYTES = WinoTile::LDS_BYTES + 16;   // + the slot through which a tile's successor is published (a.sched)
+
 // OIHW weights + bias -> slabs [co_tile][chunk][xi 16][cq][lane 64][s 2] of U = G g G^T (double) + a bias row; cot = output
 // channels per workgroup: 64 (cq 4) or, for the narrow form, 32 (cq 2)
 inline std::vector<float> pack_conv_weights_wino2(const float *w, const float *bias, int cout, int cin, int cot = CO_TILE) {
@@ -188,11 +190,20 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
   TileRef cur = decode(tile_id);
 
   // prefetch cursors over the item sequence: filters one item ahead, raw tiles two items ahead
+  // Which tile comes after the one being computed: blockIdx.x + rounds x gridDim.x (static), or -- a.sched -- whatever the
+  // launch's tile counter hands out next.  A workgroup of this kernel owns its CU; when a small kernel of another stream sits
+  // on that CU as the layer starts, the workgroup starts late, and with equal shares the whole layer ends late.  With the
+  // counter the late workgroup simply takes fewer tiles.  The counter is read (one atomic by thread 0) when a tile begins and
+  // published through LDS at the tile's second item; the prefetch cursors cross into the next tile at the end of item
+  // n_chunks - 3 at the earliest, so the host selects this mode for n_chunks >= 4 only.
+  int nxt_id = tile_id + gridDim.x;
+  int *const sched_slot = reinterpret_cast<int *>(smem + T::LDS_BYTES / 4);   // 16 bytes behind the V buffers (WINO2_LDS_BYTES)
+  int dyn_fetch = 0;
   struct Cursor { TileRef t; int chunk, id; };
   auto advance = [&](Cursor &q) {
     if (++q.chunk == a.n_chunks) {
       q.chunk = 0;
-      q.id += gridDim.x;
+      q.id = a.sched ? nxt_id : q.id + (int)gridDim.x;
       if (q.id < n_tiles) q.t = decode(q.id);
     }
   };
@@ -214,14 +225,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
   bool drained = true;          // the LDS-DMA this item needs has been waited for already
   constexpr unsigned OOB = 0xFFFFFFFFu;
 
-  for (; tile_id < n_tiles; tile_id += gridDim.x) {
-    const int next_id = tile_id + gridDim.x;
-    TileRef nxt = cur;
-    if (next_id < n_tiles) nxt = decode(next_id);
+  while (tile_id < n_tiles) {
+    if (a.sched) {
+      if (tid == 0) dyn_fetch = atomicAdd(a.sched, 1) + (int)gridDim.x;
+    } else {
+      nxt_id = tile_id + gridDim.x;
+    }
 
     // acc[xi][blk]: position xi, tiles 16 blk .. 16 blk + 15 of this wave's 32; register r of a block = output channel 4 g4 + r
     f32x4v acc[16][NBLK];
-    auto item = [&](auto first_tag) {
+    auto item = [&](auto first_tag, bool publish) {
       constexpr bool FIRST = decltype(first_tag)::value;   // the tile's first chunk: C = 0 in every accumulator's first instruction
 #ifdef WINO_STAMPS
       const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
@@ -231,7 +244,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
 #ifdef WINO_STAMPS
       const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
 #endif
+      if (publish && tid == 0) *sched_slot = dyn_fetch;      // (the wait above covered the atomic's return)
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (publish) nxt_id = __builtin_amdgcn_readfirstlane(*sched_slot);
 #ifdef WINO_STAMPS
       const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
       st_dma += ts1 - ts0; st_bar += ts2 - ts1;
@@ -311,8 +326,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
       ++st_items;
 #endif
     };
-    item(std::true_type{});
-    for (int c = 1; c < a.n_chunks; ++c) item(std::false_type{});
+    item(std::true_type{}, false);
+    for (int c = 1; c < a.n_chunks; ++c) item(std::false_type{}, a.sched != nullptr && c == 1);
 
     // everything in flight for the next item has landed before this tile's stores queue up behind it
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -379,8 +394,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
 #ifdef WINO_STAMPS
     st_epi += __builtin_amdgcn_s_memtime() - te0;
 #endif
-    cur = nxt;
+    tile_id = nxt_id;
+    if (tile_id < n_tiles) cur = decode(tile_id);
   }
+  if (a.sched && tid == 0 && atomicAdd(a.sched + 1, 1) == (int)gridDim.x - 1) { a.sched[0] = 0; a.sched[1] = 0; }   // the last workgroup out resets the counters for the next launch
 #ifdef WINO_STAMPS
   if (lane == 0 && a.stamps) {
     unsigned long long *o = a.stamps + 8 * (blockIdx.x * 8 + wave);

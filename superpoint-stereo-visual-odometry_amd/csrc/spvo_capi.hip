@@ -62,6 +62,7 @@ struct Op {
   bool wino2 = false;      // ... its 8-wave form (conv_wino2.hip.h: two waves per SIMD; the default, SPVO_WINO2=0 keeps the 4-wave form)
   bool dominant = false;   // the op with the most FLOPs: launched under its own kernel name (TAG = 1)
   float *d_w = nullptr, *d_b = nullptr, *d_bn_scale = nullptr, *d_bn_shift = nullptr;
+  int *d_sched = nullptr;      // Winograd layers (8-wave form): {tile counter, workgroups done}, zero between launches (SPVO_WINO_DYNAMIC=0: none)
   _Float16 *d_w16 = nullptr;   // FP16 engines: pack_conv_weights_f16()
   int8_t *d_w8 = nullptr;      // INT8 engines: pack_conv_weights_i8()
   unsigned short *d_ws3 = nullptr;   // FP32 engines in split mode: pack_conv_weights_s3()
@@ -389,10 +390,12 @@ int launch_conv_wino_instance(spvo_ctx *c, const ConvArgs &args, hipStream_t str
   if constexpr (W2) {
     auto k = conv_wino2_kernel<POOL, RELU, TAG, ODD, NARROW>;
     if (!ready[dev]) {
-      HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, WinoTile::LDS_BYTES));
+      HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, WINO2_LDS_BYTES));
       ready[dev] = true;
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), WinoTile::LDS_BYTES, stream, args);
+    ConvArgs a2 = args;
+    if (rounds < 2 || args.n_chunks < 4) a2.sched = nullptr;   // one tile per workgroup: nothing to hand out; short K loops: see the kernel
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), WINO2_LDS_BYTES, stream, a2);
   } else {
     auto k = conv_wino_kernel<POOL, RELU, TAG, ODD>;
     if (!ready[dev]) {
@@ -500,6 +503,7 @@ int launch_conv(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stre
   a.cout = op.cout; a.n_chunks = op.n_chunks; a.co_tiles = op.co_tiles;
   a.tiles_x = a.tiles_y = 0;
   a.batch = batch;
+  a.sched = op.d_sched;
   if (op.wino) return launch_conv_wino(c, a, batch, relu, pool, op.dominant, op.wino2, op.wino_narrow, stream);
   const int key = op.ks * 10000 + op.ck * 100 + op.wr * 20 + op.wc * 2 + (pool ? 1 : 0);   // ks, ck, wr, wc, pool
   if (epi) {
@@ -1228,6 +1232,7 @@ void free_plan(spvo_ctx *c) {
     if (o.d_ws3) (void)hipFree(o.d_ws3);
     if (o.d_wq32) (void)hipFree(o.d_wq32);
     if (o.d_qm) (void)hipFree(o.d_qm);
+    if (o.d_sched) (void)hipFree(o.d_sched);
   }
   c->tensors.clear(); c->ops.clear(); c->weights = false; c->fp16 = false; c->int8 = false; c->s3 = false;
 }
@@ -1771,6 +1776,7 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
         int rc = dev_alloc(c, &op.d_w, pk.size(), false);
         if (rc) return rc;
         HIP_TRY(c, hipMemcpy(op.d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+        if (op.wino2 && !(std::getenv("SPVO_WINO_DYNAMIC") && std::atoi(std::getenv("SPVO_WINO_DYNAMIC")) == 0) && (rc = dev_alloc(c, &op.d_sched, 2))) return rc;
         continue;
       }
       if (op.cin % op.ck) return fail(c, SPVO_ERR_IO, "op %u: cin %d is not a multiple of %d", i, op.cin, op.ck);

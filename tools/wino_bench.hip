@@ -28,6 +28,11 @@
 #define COT 64
 #endif
 using namespace spvo;
+#ifdef WINO2
+#define LDSB WINO2_LDS_BYTES
+#else
+#define LDSB WinoTile::LDS_BYTES
+#endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 int main(int argc, char **argv) {
@@ -61,14 +66,19 @@ int main(int argc, char **argv) {
   a.co_tiles = (cout + COT - 1) / COT; a.batch = batch;
   const long n_items = (long)a.tiles_x * a.tiles_y * a.co_tiles * batch * a.n_chunks;
   const int grid = argc > 7 ? atoi(argv[7]) : (int)std::min<long>(cus, n_items / a.n_chunks);
+  if (getenv("WINO_DYNAMIC") && atoi(getenv("WINO_DYNAMIC"))) {   // tiles handed out by a counter instead of blockIdx.x + k gridDim.x (8-wave forms)
+    int *d_sched;
+    CK(hipMalloc(&d_sched, 8)); CK(hipMemset(d_sched, 0, 8));
+    a.sched = d_sched;
+  }
   auto launch = [&]() {
-    if (pool) { hipLaunchKernelGGL((KERNEL(true, true, 0, false)), dim3(grid), dim3(THREADS), WinoTile::LDS_BYTES, 0, a); }
-    else if ((H | W) & 1) { hipLaunchKernelGGL((KERNEL(false, true, 0, true)), dim3(grid), dim3(THREADS), WinoTile::LDS_BYTES, 0, a); }
-    else { hipLaunchKernelGGL((KERNEL(false, true, 0, false)), dim3(grid), dim3(THREADS), WinoTile::LDS_BYTES, 0, a); }
+    if (pool) { hipLaunchKernelGGL((KERNEL(true, true, 0, false)), dim3(grid), dim3(THREADS), LDSB, 0, a); }
+    else if ((H | W) & 1) { hipLaunchKernelGGL((KERNEL(false, true, 0, true)), dim3(grid), dim3(THREADS), LDSB, 0, a); }
+    else { hipLaunchKernelGGL((KERNEL(false, true, 0, false)), dim3(grid), dim3(THREADS), LDSB, 0, a); }
   };
-  CK(hipFuncSetAttribute((const void *)KERNEL(true, true, 0, false), hipFuncAttributeMaxDynamicSharedMemorySize, WinoTile::LDS_BYTES));
-  CK(hipFuncSetAttribute((const void *)KERNEL(false, true, 0, false), hipFuncAttributeMaxDynamicSharedMemorySize, WinoTile::LDS_BYTES));
-  CK(hipFuncSetAttribute((const void *)KERNEL(false, true, 0, true), hipFuncAttributeMaxDynamicSharedMemorySize, WinoTile::LDS_BYTES));
+  CK(hipFuncSetAttribute((const void *)KERNEL(true, true, 0, false), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+  CK(hipFuncSetAttribute((const void *)KERNEL(false, true, 0, false), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+  CK(hipFuncSetAttribute((const void *)KERNEL(false, true, 0, true), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
   for (int i = 0; i < 5; ++i) launch();
   CK(hipDeviceSynchronize());
   hipEvent_t e0, e1;
