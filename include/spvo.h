@@ -288,6 +288,17 @@ int spvo_solve_stereo_odometry(spvo_ctx *ctx, const spvo_solve_input *in, spvo_s
                                float *xyz /* [n][3] triangulated points */,
                                int32_t *inliers /* [n] RANSAC inliers, ascending */);
 
+/* The same call in two halves, for a caller with something else to do in between (collecting the next pair's detector
+ * output, publishing, bookkeeping).  spvo_solve_submit stages the inputs in pinned memory -- the caller's arrays are free
+ * again when it returns -- and enqueues the whole chain on the solver's stream; spvo_solve_wait blocks until it is done and
+ * hands out what spvo_solve_stereo_odometry would have.  ONE solve may be pending; until it has been waited for, the
+ * stand-alone solver entry points (spvo_triangulate, spvo_pnp_ransac, spvo_pnp_refine) and another submit answer
+ * SPVO_ERR_STATE.  The next frame's solve needs this one's pose as its prior (hpp:156-157), so the chain of solves itself
+ * stays sequential; what overlaps is the host's other work.  The reference has no counterpart: solveStereoOdometry
+ * (base.cpp:125-399) is one blocking call. */
+int spvo_solve_submit(spvo_ctx *ctx, const spvo_solve_input *in);
+int spvo_solve_wait(spvo_ctx *ctx, spvo_solve_output *out, float *xyz, int32_t *inliers);
+
 /* ------------------------------------------------------- multi-GPU: pose gather
  * The path shards by stereo stream: one process per GPU, each with its own FeatureFrontEnd
  * state; nothing but the resulting relative poses -- q (x, y, z, w) + t of cam0_curr_T_cam0_prev, base.cpp:377-385,

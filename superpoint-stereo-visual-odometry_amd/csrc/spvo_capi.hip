@@ -205,6 +205,7 @@ struct spvo_ctx {
   ObsDev *d_obs = nullptr;
   RefineOut *d_refine = nullptr;
   // fused solve: one packed input, one packed result
+  struct SolvePending { bool active = false; int n = 0, refinement_degree = 0; double rvec[3] = {0, 0, 0}, tvec[3] = {0, 0, 0}; } solve_pending;   // spvo_solve_submit .. _wait
   hipEvent_t ev_solve = nullptr;
   int solve_cap = 0;
   char *d_solve_in = nullptr, *h_solve_in = nullptr;    // 64 doubles + 12*cap words
@@ -2336,6 +2337,7 @@ int spvo_triangulate(spvo_ctx *c, const double P_l[12], const double P_r[12], co
   if (!c || !P_l || !P_r || n < 0 || (n > 0 && (!xy_l || !xy_r || !xyz))) return fail(c, SPVO_ERR_INVALID, "bad argument");
   if (n == 0) return SPVO_OK;
   HIP_TRY(c, hipSetDevice(c->cfg.device));
+  if (c->solve_pending.active) return fail(c, SPVO_ERR_STATE, "a solve is pending (spvo_solve_submit): complete it with spvo_solve_wait first");
   int rc = ensure_odometry(c, n, 0, 0);
   if (rc) return rc;
   HIP_TRY(c, hipMemcpyAsync(c->d_P, P_l, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -2362,6 +2364,7 @@ int spvo_pnp_ransac(spvo_ctx *c, const double K[9], const float *xyz, const floa
   *n_inliers = 0;
   if (n < 4) return SPVO_OK;  // not enough points for a model: prior is kept
   HIP_TRY(c, hipSetDevice(c->cfg.device));
+  if (c->solve_pending.active) return fail(c, SPVO_ERR_STATE, "a solve is pending (spvo_solve_submit): complete it with spvo_solve_wait first");
   int rc = ensure_odometry(c, n, o.iterations, 0);
   if (rc) return rc;
   double prior[6] = {rvec[0], rvec[1], rvec[2], tvec[0], tvec[1], tvec[2]};
@@ -2393,6 +2396,7 @@ int spvo_pnp_refine(spvo_ctx *c, const double P_l[12], const double P_r[12], con
   if (o.max_iterations < 0 || !(o.huber_delta > 0)) return fail(c, SPVO_ERR_INVALID, "bad refine options");
   static_assert(sizeof(spvo_obs) == sizeof(ObsDev), "spvo_obs layout");
   HIP_TRY(c, hipSetDevice(c->cfg.device));
+  if (c->solve_pending.active) return fail(c, SPVO_ERR_STATE, "a solve is pending (spvo_solve_submit): complete it with spvo_solve_wait first");
   int rc = ensure_odometry(c, 0, 0, n_obs);
   if (rc) return rc;
   double start[7] = {q[0], q[1], q[2], q[3], t[0], t[1], t[2]};
@@ -2420,26 +2424,21 @@ int spvo_pnp_refine(spvo_ctx *c, const double P_l[12], const double P_r[12], con
   return SPVO_OK;
 }
 
-int spvo_solve_stereo_odometry(spvo_ctx *c, const spvo_solve_input *in, spvo_solve_output *out, float *xyz, int32_t *inliers) {
-  if (!c || !in || !out) return fail(c, SPVO_ERR_INVALID, "null argument");
+// Everything of a solve up to the event behind its last copy; the inputs are staged in pinned memory, so the caller's arrays are
+// free again when this returns.  What spvo_solve_wait needs later (the prior, n, the refinement degree) stays in the context.
+int spvo_solve_submit(spvo_ctx *c, const spvo_solve_input *in) {
+  if (!c || !in) return fail(c, SPVO_ERR_INVALID, "null argument");
+  if (c->solve_pending.active) return fail(c, SPVO_ERR_STATE, "a solve is pending: complete it with spvo_solve_wait first");
   const int n = in->n;
-  if (n < 0 || (n > 0 && (!in->xy_cl || !in->xy_cr || !in->xy_pl || !in->xy_pr || !xyz || !inliers))) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  if (n < 0 || (n > 0 && (!in->xy_cl || !in->xy_cr || !in->xy_pl || !in->xy_pr))) return fail(c, SPVO_ERR_INVALID, "bad argument");
   if (in->ransac.iterations <= 0 || in->ransac.iterations > 65536 || !(in->ransac.reproj_error > 0) || in->refine.max_iterations < 0 ||
       !(in->refine.huber_delta > 0))
     return fail(c, SPVO_ERR_INVALID, "bad solver options");
-  std::memset(out, 0, sizeof *out);
   HIP_TRY(c, hipSetDevice(c->cfg.device));
-  // rvec -> quaternion of the prior: the answer when nothing can be estimated (base.cpp:244-250, 274-280)
-  auto prior_pose = [&]() {
-    const double *r = in->rvec_pred;
-    const double a = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
-    double ax[3] = {r[0], r[1], r[2]};
-    if (a > 0) for (int k = 0; k < 3; ++k) ax[k] /= a;
-    const double sn = std::sin(a / 2);
-    out->q[0] = ax[0] * sn; out->q[1] = ax[1] * sn; out->q[2] = ax[2] * sn; out->q[3] = std::cos(a / 2);
-    for (int k = 0; k < 3; ++k) { out->t[k] = in->tvec_pred[k]; out->rvec[k] = in->rvec_pred[k]; out->tvec[k] = in->tvec_pred[k]; }
-  };
-  if (n == 0) { prior_pose(); return SPVO_OK; }
+  spvo_ctx::SolvePending pend;
+  pend.n = n; pend.refinement_degree = in->refinement_degree;
+  for (int k = 0; k < 3; ++k) { pend.rvec[k] = in->rvec_pred[k]; pend.tvec[k] = in->tvec_pred[k]; }
+  if (n == 0) { pend.active = true; c->solve_pending = pend; return SPVO_OK; }   // nothing to enqueue: _wait answers with the prior
   // this call runs on the context's second stream so that it overlaps a detector submission in
   // flight; buffers only grow on first use (then everything is drained once)
   const bool grow = n > c->odo_cap || in->ransac.iterations > c->ransac_cap || 4 * n > c->obs_cap || !c->d_P || n > c->solve_cap;
@@ -2515,16 +2514,40 @@ int spvo_solve_stereo_odometry(spvo_ctx *c, const spvo_solve_input *in, spvo_sol
   if (n >= 4) HIP_TRY(c, hipMemcpyAsync(c->h_solve_res, c->d_solve_res, 40 * sizeof(double), hipMemcpyDeviceToHost, c->stream2));
   if (!c->ev_solve) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_solve, hipEventDisableTiming));
   HIP_TRY(c, hipEventRecord(c->ev_solve, c->stream2));
-  const double tm2 = solve_timing ? now_us() : 0;
-  HIP_TRY(c, wait_event(c->ev_solve));
   if (solve_timing) {
-    const double tm3 = now_us();
-    tacc[0] += tm1 - tm0; tacc[1] += tm2 - tm1; tacc[2] += tm3 - tm2;
+    const double tm2 = now_us();
+    tacc[0] += tm1 - tm0; tacc[1] += tm2 - tm1;
     if (++tcalls % 200 == 0) {
-      std::fprintf(stderr, "[solve timing] pack %.1f us, enqueue %.1f us, wait %.1f us (n = %d)\n", tacc[0] / 200, tacc[1] / 200, tacc[2] / 200, n);
-      tacc[0] = tacc[1] = tacc[2] = 0;
+      std::fprintf(stderr, "[solve timing] pack %.1f us, enqueue %.1f us (n = %d)\n", tacc[0] / 200, tacc[1] / 200, n);
+      tacc[0] = tacc[1] = 0;
     }
   }
+  pend.active = true;
+  c->solve_pending = pend;
+  return SPVO_OK;
+}
+
+int spvo_solve_wait(spvo_ctx *c, spvo_solve_output *out, float *xyz, int32_t *inliers) {
+  if (!c || !out) return fail(c, SPVO_ERR_INVALID, "null argument");
+  if (!c->solve_pending.active) return fail(c, SPVO_ERR_STATE, "no solve pending");
+  const spvo_ctx::SolvePending pend = c->solve_pending;
+  const int n = pend.n;
+  if (n > 0 && (!xyz || !inliers)) return fail(c, SPVO_ERR_INVALID, "bad argument");   // (the solve stays pending)
+  c->solve_pending.active = false;
+  std::memset(out, 0, sizeof *out);
+  // rvec -> quaternion of the prior: the answer when nothing can be estimated (base.cpp:244-250, 274-280)
+  auto prior_pose = [&]() {
+    const double *r = pend.rvec;
+    const double a = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    double ax[3] = {r[0], r[1], r[2]};
+    if (a > 0) for (int k = 0; k < 3; ++k) ax[k] /= a;
+    const double sn = std::sin(a / 2);
+    out->q[0] = ax[0] * sn; out->q[1] = ax[1] * sn; out->q[2] = ax[2] * sn; out->q[3] = std::cos(a / 2);
+    for (int k = 0; k < 3; ++k) { out->t[k] = pend.tvec[k]; out->rvec[k] = pend.rvec[k]; out->tvec[k] = pend.tvec[k]; }
+  };
+  if (n == 0) { prior_pose(); return SPVO_OK; }
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  HIP_TRY(c, wait_event(c->ev_solve));
   std::memcpy(xyz, c->h_solve_o, (size_t)3 * n * 4);
   if (n < 4) { prior_pose(); return SPVO_OK; }                                      // no model possible: prior is kept
   const double *res = c->h_solve_res, *gate = res + 8, *ref = res + 24;
@@ -2533,7 +2556,7 @@ int spvo_solve_stereo_odometry(spvo_ctx *c, const spvo_solve_input *in, spvo_sol
   if (out->n_inliers > 0) std::memcpy(inliers, (const int *)c->h_solve_o + 3 * n, (size_t)out->n_inliers * 4);
   out->accepted = gate[7] != 0;
   for (int k = 0; k < 3; ++k) { out->rvec[k] = gate[10 + k]; out->tvec[k] = gate[13 + k]; }
-  const bool ran = out->accepted && in->refinement_degree > 0;
+  const bool ran = out->accepted && pend.refinement_degree > 0;
   out->summary.iterations = (int)ref[7];
   out->summary.converged = (int)ref[8];
   out->summary.usable = (int)ref[9];
@@ -2544,6 +2567,12 @@ int spvo_solve_stereo_odometry(spvo_ctx *c, const spvo_solve_input *in, spvo_sol
   for (int k = 0; k < 4; ++k) out->q[k] = src[k];
   for (int k = 0; k < 3; ++k) out->t[k] = src[4 + k];
   return SPVO_OK;
+}
+
+int spvo_solve_stereo_odometry(spvo_ctx *c, const spvo_solve_input *in, spvo_solve_output *out, float *xyz, int32_t *inliers) {
+  if (!c || !in || !out || (in->n > 0 && (!xyz || !inliers))) return fail(c, SPVO_ERR_INVALID, "null argument");
+  const int rc = spvo_solve_submit(c, in);
+  return rc ? rc : spvo_solve_wait(c, out, xyz, inliers);
 }
 
 void *spvo_stream(spvo_ctx *c) { return c ? (void *)c->stream : nullptr; }

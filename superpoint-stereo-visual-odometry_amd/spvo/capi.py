@@ -59,7 +59,7 @@ SYMBOLS = [
     "spvo_default_config", "spvo_create", "spvo_destroy", "spvo_last_error", "spvo_load_weights", "spvo_engine_precision", "spvo_set_fp32_split",
     "spvo_preprocess", "spvo_forward", "spvo_debug_tensor", "spvo_heatmap", "spvo_nms",
     "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_detect_dev_submit", "spvo_detect_wait", "spvo_detect_submit", "spvo_detect_collect", "spvo_match", "spvo_match_slots", "spvo_set_prematch", "spvo_set_match_fp8",
-    "spvo_triangulate", "spvo_pnp_ransac", "spvo_pnp_refine", "spvo_solve_stereo_odometry", "spvo_stream", "spvo_synchronize",
+    "spvo_triangulate", "spvo_pnp_ransac", "spvo_pnp_refine", "spvo_solve_stereo_odometry", "spvo_solve_submit", "spvo_solve_wait", "spvo_stream", "spvo_synchronize",
     "spvo_profile_enable", "spvo_profile_reset", "spvo_profile_only", "spvo_profile_count", "spvo_profile_get",
     "spvo_comm_unique_id", "spvo_comm_create", "spvo_comm_create_host", "spvo_comm_rank", "spvo_comm_world", "spvo_comm_destroy",
     "spvo_pose_allgather", "spvo_pose_allgather_n",
@@ -107,6 +107,8 @@ def load() -> C.CDLL:
     lib.spvo_pnp_refine.argtypes = [vp, dp, dp, vp, C.c_int, C.POINTER(RefineOpts), dp, dp,
                                     C.POINTER(RefineSummary)]
     lib.spvo_solve_stereo_odometry.argtypes = [vp, C.POINTER(SolveInput), C.POINTER(SolveOutput), vp, vp]
+    lib.spvo_solve_submit.argtypes = [vp, C.POINTER(SolveInput)]
+    lib.spvo_solve_wait.argtypes = [vp, C.POINTER(SolveOutput), vp, vp]
     lib.spvo_stream.argtypes = [vp]
     lib.spvo_stream.restype = vp
     lib.spvo_synchronize.argtypes = [vp]
@@ -361,7 +363,7 @@ class Context:
         return q, t, s
 
     def solve(self, P_l, P_r, cl, cr, pl, pr, prev_xyz=None, prev_valid=None, rvec_pred=(0, 0, 0), tvec_pred=(0, 0, 0),
-              frame_count=0, refinement_degree=4, seed=0, iterations=500, reproj_error=2.0, max_iterations=40):
+              frame_count=0, refinement_degree=4, seed=0, iterations=500, reproj_error=2.0, max_iterations=40, split=None):
         arrs = [np.ascontiguousarray(a, np.float32).reshape(-1, 2) for a in (cl, cr, pl, pr)]
         n = len(arrs[0])
         si = SolveInput()
@@ -378,10 +380,25 @@ class Context:
         si.frame_count, si.refinement_degree = frame_count, refinement_degree
         si.ransac = RansacOpts(iterations, reproj_error, 0.999, seed)
         si.refine = RefineOpts(max_iterations, 1.0)
+        if split == "submit":      # spvo_solve_submit only: the inputs are staged, complete with solve_wait(n)
+            self._check(self.lib.spvo_solve_submit(self.h, C.byref(si)))
+            return n
         so = SolveOutput()
         xyz = np.zeros((max(n, 1), 3), np.float32)
         inl = np.zeros(max(n, 1), np.int32)
         self._check(self.lib.spvo_solve_stereo_odometry(self.h, C.byref(si), C.byref(so), _ptr(xyz), _ptr(inl)))
+        return self._solve_result(so, xyz, inl, n)
+
+    def solve_wait(self, n):
+        """Second half of solve(..., split="submit")."""
+        so = SolveOutput()
+        xyz = np.zeros((max(n, 1), 3), np.float32)
+        inl = np.zeros(max(n, 1), np.int32)
+        self._check(self.lib.spvo_solve_wait(self.h, C.byref(so), _ptr(xyz), _ptr(inl)))
+        return self._solve_result(so, xyz, inl, n)
+
+    @staticmethod
+    def _solve_result(so, xyz, inl, n):
         return dict(q=np.array(so.q[:]), t=np.array(so.t[:]), rvec=np.array(so.rvec[:]), tvec=np.array(so.tvec[:]),
                     pnp_ok=bool(so.pnp_ok), accepted=bool(so.accepted), refined=bool(so.refined),
                     inliers=inl[:so.n_inliers].copy(), xyz=xyz[:n].copy(), iterations=so.summary.iterations,

@@ -147,3 +147,32 @@ def test_fused_solve_gating_and_small_inputs(ctx_vgg):
         f = ctx_vgg.solve(P_l, P_r, cl[:k], cr[:k], pl[:k], pr[:k], None, None, [0, 0.1, 0], [1, 2, 3])
         assert not f["pnp_ok"] and not f["accepted"] and len(f["inliers"]) == 0 and np.allclose(f["t"], [1, 2, 3])
         assert np.allclose(f["q"], od.rvec_to_quat([0, 0.1, 0]))
+
+
+def test_solve_in_two_halves(ctx_vgg):
+    """spvo_solve_submit + spvo_solve_wait == spvo_solve_stereo_odometry bit for bit; the inputs may be overwritten between the
+    halves (they are staged at submit); one solve may be pending, and the stand-alone solver entry points refuse meanwhile."""
+    P_l, P_r, Xc, cl, cr, pl, pr, rv, tv, bad = _scene(seed=9, n=300, noise=0.3, outliers=0.2)
+    prior_r, prior_t = np.zeros(3), np.array([0.0, 0.0, 0.9])
+    ref = ctx_vgg.solve(P_l, P_r, cl, cr, pl, pr, None, None, prior_r, prior_t, frame_count=3, seed=4)
+    arrs = [a.copy() for a in (cl, cr, pl, pr)]
+    n = ctx_vgg.solve(P_l, P_r, *arrs, None, None, prior_r, prior_t, frame_count=3, seed=4, split="submit")
+    for a in arrs:
+        a[:] = -1.0                                                     # the caller's arrays are free after submit
+    with pytest.raises(capi.SpvoError) as e:
+        ctx_vgg.solve(P_l, P_r, cl, cr, pl, pr, None, None, prior_r, prior_t, split="submit")
+    assert e.value.code == -4
+    with pytest.raises(capi.SpvoError) as e:
+        ctx_vgg.triangulate(P_l, P_r, cl, cr)
+    assert e.value.code == -4
+    got = ctx_vgg.solve_wait(n)
+    for k in ("q", "t", "rvec", "tvec", "inliers", "xyz"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert got["refined"] == ref["refined"] and got["iterations"] == ref["iterations"]
+    with pytest.raises(capi.SpvoError) as e:                            # nothing pending any more
+        ctx_vgg.solve_wait(n)
+    assert e.value.code == -4
+    # no correspondences: nothing is enqueued, the prior comes back from the second half
+    n0 = ctx_vgg.solve(P_l, P_r, cl[:0], cr[:0], pl[:0], pr[:0], None, None, [0, 0.1, 0], [1, 2, 3], split="submit")
+    f = ctx_vgg.solve_wait(n0)
+    assert not f["pnp_ok"] and np.allclose(f["t"], [1, 2, 3]) and np.allclose(f["q"], od.rvec_to_quat([0, 0.1, 0]))
