@@ -2450,6 +2450,8 @@ int spvo_solve_submit(spvo_ctx *c, const spvo_solve_input *in) {
     for (void *hp : {(void *)c->h_solve_in, (void *)c->h_solve_res, (void *)c->h_solve_o}) if (hp) (void)hipHostFree(hp);
     for (void *dp : {(void *)c->d_solve_in, (void *)c->d_solve_res, (void *)c->d_solve_o, (void *)c->d_ctl}) if (dp) (void)hipFree(dp);
     c->h_solve_in = c->h_solve_o = nullptr; c->h_solve_res = nullptr;
+    c->d_solve_in = c->d_solve_o = nullptr; c->d_solve_res = nullptr; c->d_ctl = nullptr;
+    c->solve_cap = 0;   // a failed allocation below leaves a context that spvo_destroy and a later call can still handle
     const size_t in_bytes = 64 * sizeof(double) + (size_t)12 * cap * 4, o_bytes = (size_t)4 * cap * 4;
     if ((rc = dev_alloc(c, &c->d_solve_in, in_bytes))) return rc;
     if ((rc = dev_alloc(c, &c->d_solve_res, 40))) return rc;
