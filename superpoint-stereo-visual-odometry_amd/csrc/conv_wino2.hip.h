@@ -186,7 +186,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
   const int b_lane = tb * 64 + lane;   // 16-byte (narrow: 8-byte) pieces in a V buffer:  + xi * 128 (256)
 
   int tile_id = blockIdx.x;
-  if (tile_id >= n_tiles) return;
+  if (tile_id >= n_tiles) {   // (the product's grids never exceed the tile count; a workgroup without work still counts as done)
+    if (a.sched && tid == 0 && atomicAdd(a.sched + 1, 1) == (int)gridDim.x - 1) { a.sched[0] = 0; a.sched[1] = 0; }
+    return;
+  }
   TileRef cur = decode(tile_id);
 
   // prefetch cursors over the item sequence: filters one item ahead, raw tiles two items ahead
