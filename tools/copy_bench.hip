@@ -8,6 +8,17 @@
 __global__ __launch_bounds__(256) void spvo_copy_calibration_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
+// the same amount read through the LDS-DMA path (global_load_lds_dwordx4), the way the convolution kernels stage their tiles:
+// is FETCH_SIZE halved for these loads too?  (nothing is written back: the data only lands in LDS)
+__global__ __launch_bounds__(512) void spvo_lds_dma_calibration_kernel(const float4 *__restrict__ src, float *__restrict__ sink, size_t n) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // 8 KB: one piece per thread
+  const int wave = threadIdx.x >> 6;
+  for (size_t i = (size_t)blockIdx.x * 512 + threadIdx.x; i < n; i += (size_t)gridDim.x * 512)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i), (__attribute__((address_space(3))) void *)(lds + wave * 256), 16, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (sink && threadIdx.x == 0 && lds[0] == 12345.678f) sink[blockIdx.x] = lds[1];
+}
 int main(int argc, char **argv) {
   const size_t mib = argc > 1 ? atoi(argv[1]) : 1024;
   const int reps = argc > 2 ? atoi(argv[2]) : 5;
@@ -23,6 +34,8 @@ int main(int argc, char **argv) {
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
+  for (int i = 0; i < reps + 1; ++i) hipLaunchKernelGGL(spvo_lds_dma_calibration_kernel, dim3(256 * 4), dim3(512), 8192, 0, a, (float *)b, n);
+  hipDeviceSynchronize();
   printf("copy %zu MiB: %.1f us per launch, %.2f TB/s (read + write), known bytes per launch: read %zu, written %zu\n", mib, ms * 1e3 / reps, 2.0 * n * 16 / (ms * 1e-3 / reps) / 1e12, n * 16, n * 16);
   return 0;
 }

@@ -42,6 +42,14 @@ res["copy_calibration"] = {"kernel": k, "known_read_KB": known_kb, "known_writte
                            "write_reported_over_known": round(mean(w[k]["WRITE_SIZE"]) / known_kb, 4),
                            "conclusion": "FETCH_SIZE reports 1/2 of a 16-byte-per-lane streaming read, WRITE_SIZE the bytes written: traffic = 2 x FETCH_SIZE + WRITE_SIZE"}
 fcorr = 1.0 / res["copy_calibration"]["fetch_reported_over_known"]
+# the same bytes read through the LDS-DMA path (global_load_lds_dwordx4), which is how the convolution kernels read everything
+kd = pick(f, "lds_dma_calibration")
+fcorr_dma = fcorr
+if kd:
+    ratio = mean(f[kd]["FETCH_SIZE"]) / known_kb
+    res["lds_dma_calibration"] = {"kernel": kd, "known_read_KB": known_kb, "FETCH_SIZE_KB": round(mean(f[kd]["FETCH_SIZE"]), 1), "fetch_reported_over_known": round(ratio, 4),
+                                  "conclusion": "correction factor for kernels that read through LDS-DMA = 1 / this ratio"}
+    fcorr_dma = 1.0 / ratio
 # ---- kernels
 H, W = 360, 1176
 alg = {"conv_wino2_kernel<true, true": 2 * (64 * H * W * 4 + 64 * (H // 2) * (W // 2) * 4) + 16 * 64 * 64 * 4,    # input + pooled output planes + transformed filters
@@ -58,7 +66,9 @@ for prog, keys in (("wino", ["conv_wino2_kernel<true, true"]), ("match", ["match
         e = {"kernel": k[:120]}
         fk, wk = mean(f[k]["FETCH_SIZE"]), mean(w[pick(w, key)]["WRITE_SIZE"])
         e["FETCH_SIZE_KB"], e["WRITE_SIZE_KB"] = round(fk, 1), round(wk, 1)
-        e["traffic_bytes_per_launch"] = int((fcorr * fk + wk) * 1024)
+        fc = fcorr_dma if key.startswith("conv_wino2") else fcorr
+        e["fetch_correction"] = round(fc, 3)
+        e["traffic_bytes_per_launch"] = int((fc * fk + wk) * 1024)
         e["algorithmic_bytes_per_launch"] = alg[key]
         e["traffic_over_algorithmic"] = round(e["traffic_bytes_per_launch"] / alg[key], 3)
         k1 = pick(s1, key)
