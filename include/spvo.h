@@ -188,6 +188,14 @@ typedef enum { SPVO_SELECT_NN = 0, SPVO_SELECT_KNN = 1 } spvo_selector;
 int spvo_match(spvo_ctx *ctx, const float *desc_a, int na, const float *desc_b, int nb,
                int selector, int cross_check, float ratio, int32_t *train_idx, float *distance);
 
+/* The same for BINARY descriptors: cv::BFMatcher(NORM_HAMMING), what initMatcher (base.cpp:17-21) builds for the ORB / BRISK /
+ * AKAZE descriptors of ClassicFeatureFrontEnd (classic.cpp:66-79) and matchDescriptors (base.cpp:434-500) runs on them.
+ * Rows of `desc_bytes` bytes (ORB 32, BRISK 64, AKAZE 61; at most 64), distance = number of differing bits (exact), reported
+ * as a float like cv::DMatch::distance; selector / cross_check / ratio and the meaning of train_idx / distance as in
+ * spvo_match. */
+int spvo_match_hamming(spvo_ctx *ctx, const uint8_t *desc_a, int na, const uint8_t *desc_b, int nb, int desc_bytes,
+                       int selector, int cross_check, float ratio, int32_t *train_idx, float *distance);
+
 /* Same on the device-resident descriptors of two feature slots. */
 int spvo_match_slots(spvo_ctx *ctx, int slot_a, int slot_b, int selector, int cross_check,
                      float ratio, int32_t *train_idx, float *distance);

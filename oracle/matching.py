@@ -88,3 +88,48 @@ def bf_match(desc_a: np.ndarray, desc_b: np.ndarray, selector: str = "KNN", cros
     else:
         raise ValueError(selector)
     return out, d0
+
+
+# ------------------------------------------------------------------ binary descriptors (ORB / BRISK / AKAZE: base.cpp:17-21)
+_POPCOUNT8 = np.array([bin(i).count("1") for i in range(256)], np.int32)
+
+
+def hamming_distances(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """int32 [na, nb]: cv::NORM_HAMMING = number of differing bits of the two byte strings."""
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    out = np.zeros((a.shape[0], b.shape[0]), np.int32)
+    for k in range(a.shape[1]):                       # one byte column at a time keeps the temporary at na x nb bytes
+        out += _POPCOUNT8[a[:, k, None] ^ b[None, :, k]]
+    return out
+
+
+def bf_match_hamming(desc_a: np.ndarray, desc_b: np.ndarray, selector: str = "KNN", cross_check: bool = False, ratio: float = 0.8):
+    """bf_match for cv::BFMatcher(NORM_HAMMING) (initMatcher, base.cpp:17-21, 27-28): the same three selection procedures on
+    integer distances; DMatch::distance is the bit count as a float, the ratio test of base.cpp:469 runs in float32."""
+    na, nb = len(desc_a), len(desc_b)
+    if na == 0 or nb == 0:
+        return np.full(na, -1, np.int32), np.zeros(na, np.float32)
+    d = hamming_distances(desc_a, desc_b).astype(np.float32)     # bit counts <= 2040 are exact in float32
+    v0, v1, i0, i1 = best_two(d)
+    out = np.full(na, -1, np.int32)
+    d0 = v0.astype(np.float32)
+    if selector == "NN" and cross_check:
+        v0t, _, q_of_t, _ = best_two(d.T.copy())
+        best = np.full(na, np.inf, np.float32)
+        d0 = np.zeros(na, np.float32)
+        for t in range(nb):
+            q = int(q_of_t[t])
+            if v0t[t] < best[q]:
+                best[q] = v0t[t]
+                out[q] = t
+                d0[q] = v0t[t]
+    elif selector == "NN":
+        out[:] = i0
+    elif selector == "KNN":
+        if nb >= 2:
+            keep = d0 < np.float32(ratio) * v1.astype(np.float32)
+            out[keep] = i0[keep]
+    else:
+        raise ValueError(selector)
+    return out, d0

@@ -492,4 +492,68 @@ __global__ __launch_bounds__(256) void match_select_cross_kernel(MatchJobs jobs)
   jb.out[q] = make_int2(hit ? (int)(key & 0xFFFFFFFFull) : -1, hit ? (int)(key >> 32) : 0);
 }
 
+// ---------------------------------------------------------------------------
+// K12h: cv::BFMatcher(NORM_HAMMING) for the binary descriptors of the classic front end (ORB / BRISK / AKAZE: initMatcher,
+// base.cpp:17-21; matchDescriptors, base.cpp:434-500 -- 49 ms per frame for 2000 ORB keypoints in the reference's own table,
+// VO/README.md:25).  Integer work: distance = popcount(a xor b), exact by nature, so ONE pass: one wave per query row, every
+// lane scans the train rows lane, lane + 64, ... (a row is NW 32-bit words, zero-padded; 64 consecutive rows are one contiguous
+// 2 KB read), keeps its two best under the (distance, index) order of a strict '<' scan, and the wave merges the 64 pairs.
+//   mode 0  NN:  idx = nearest, dist = its distance
+//   mode 1  KNN: dist = nearest distance, idx = nearest if d0 < ratio * d1 (float32, base.cpp:469), else -1
+//   mode 2  the vote of cv::batchDistance's crosscheck: the rows of A are the TRAIN rows, B the queries; each train row casts
+//           (distance << 32 | own index) into vote[its nearest query] with an atomic min -- the query then keeps the nearest
+//           train row that chose it, the lowest one on ties (match_hamming_cross_kernel), as in oracle/matching.py.
+// ---------------------------------------------------------------------------
+struct HamPair { int d0, i0, d1, i1; };
+__device__ __forceinline__ bool ham_less(int da, int ia, int db, int ib) { return da < db || (da == db && (unsigned)ia < (unsigned)ib); }
+__device__ __forceinline__ void ham_insert(HamPair &p, int d, int i) {
+  if (ham_less(d, i, p.d0, p.i0)) { p.d1 = p.d0; p.i1 = p.i0; p.d0 = d; p.i0 = i; }
+  else if (ham_less(d, i, p.d1, p.i1)) { p.d1 = d; p.i1 = i; }
+}
+
+template <int NW>
+__global__ __launch_bounds__(256) void match_hamming_kernel(const uint32_t *__restrict__ A, int na, const uint32_t *__restrict__ B, int nb, int mode, float ratio,
+                                                            int *__restrict__ out_idx, float *__restrict__ out_dist, unsigned long long *__restrict__ vote) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= na) return;
+  uint32_t a[NW];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) a[w] = A[(size_t)q * NW + w];
+  HamPair p{0x7FFFFFFF, -1, 0x7FFFFFFF, -1};
+  for (int t = lane; t < nb; t += 64) {
+    const uint4 *row = reinterpret_cast<const uint4 *>(B + (size_t)t * NW);
+    int d = 0;
+#pragma unroll
+    for (int w4 = 0; w4 < NW / 4; ++w4) {
+      const uint4 v = row[w4];
+      d += __popc(v.x ^ a[4 * w4]) + __popc(v.y ^ a[4 * w4 + 1]) + __popc(v.z ^ a[4 * w4 + 2]) + __popc(v.w ^ a[4 * w4 + 3]);
+    }
+    ham_insert(p, d, t);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const int od0 = __shfl_xor(p.d0, o), oi0 = __shfl_xor(p.i0, o), od1 = __shfl_xor(p.d1, o), oi1 = __shfl_xor(p.i1, o);
+    if (oi0 >= 0) ham_insert(p, od0, oi0);
+    if (oi1 >= 0) ham_insert(p, od1, oi1);
+  }
+  if (lane) return;
+  if (mode == 2) {
+    if (p.i0 >= 0) atomicMin(&vote[p.i0], ((unsigned long long)(unsigned)p.d0 << 32) | (unsigned)q);
+    return;
+  }
+  out_dist[q] = p.i0 >= 0 ? (float)p.d0 : 0.f;
+  if (mode == 0) out_idx[q] = p.i0;
+  else out_idx[q] = (p.i1 >= 0 && (float)p.d0 < ratio * (float)p.d1) ? p.i0 : -1;
+}
+
+__global__ __launch_bounds__(256) void match_hamming_cross_kernel(const unsigned long long *__restrict__ vote, int na, int *__restrict__ out_idx, float *__restrict__ out_dist) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= na) return;
+  const unsigned long long key = vote[q];
+  const bool hit = key != ~0ull;
+  out_idx[q] = hit ? (int)(key & 0xFFFFFFFFull) : -1;
+  out_dist[q] = hit ? (float)(unsigned)(key >> 32) : 0.f;
+}
+
 }  // namespace spvo

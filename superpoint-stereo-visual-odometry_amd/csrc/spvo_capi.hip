@@ -204,6 +204,12 @@ struct spvo_ctx {
   RansacWork rw{};
   ObsDev *d_obs = nullptr;
   RefineOut *d_refine = nullptr;
+  // Hamming matcher (classic front end's binary descriptors): rows padded to 16 words
+  int ham_cap = 0;
+  uint32_t *d_ham_a = nullptr, *d_ham_b = nullptr;
+  int *d_ham_idx = nullptr;
+  float *d_ham_dist = nullptr;
+  unsigned long long *d_ham_vote = nullptr;
   // fused solve: one packed input, one packed result
   struct SolvePending { bool active = false; int n = 0, refinement_degree = 0; double rvec[3] = {0, 0, 0}, tvec[3] = {0, 0, 0}; } solve_pending;   // spvo_solve_submit .. _wait
   hipEvent_t ev_solve = nullptr;
@@ -1393,6 +1399,7 @@ void spvo_destroy(spvo_ctx *c) {
   }
   for (void *hp : {(void *)c->h_solve_in, (void *)c->h_solve_res, (void *)c->h_solve_o}) if (hp) (void)hipHostFree(hp);
   for (void *dp : {(void *)c->d_solve_in, (void *)c->d_solve_res, (void *)c->d_solve_o, (void *)c->d_ctl}) if (dp) (void)hipFree(dp);
+  for (void *dp : {(void *)c->d_ham_a, (void *)c->d_ham_b, (void *)c->d_ham_idx, (void *)c->d_ham_dist, (void *)c->d_ham_vote}) if (dp) (void)hipFree(dp);
   for (auto hp : c->h_match_out) if (hp) (void)hipHostFree(hp);
   if (c->h_match_tmp) (void)hipHostFree(c->h_match_tmp);
   if (c->stream_t) (void)hipStreamDestroy(c->stream_t);
@@ -2285,6 +2292,59 @@ int spvo_match(spvo_ctx *c, const float *desc_a, int na, const float *desc_b, in
   if (na) HIP_TRY(c, hipMemcpyAsync(c->d_ma, desc_a, (size_t)na * MATCH_D * sizeof(float), hipMemcpyHostToDevice, c->post));
   if (nb) HIP_TRY(c, hipMemcpyAsync(c->d_mb, desc_b, (size_t)nb * MATCH_D * sizeof(float), hipMemcpyHostToDevice, c->post));
   return run_match(c, MatchReq{c->d_ma, c->d_mb, na, nb, nullptr, nullptr, nullptr, nullptr}, selector, cross_check ? 1 : 0, ratio, train_idx, distance);
+}
+
+// cv::BFMatcher(NORM_HAMMING): binary descriptors of `desc_bytes` bytes per row (ORB 32, BRISK 64, AKAZE 61), see match.hip.h K12h
+int spvo_match_hamming(spvo_ctx *c, const uint8_t *desc_a, int na, const uint8_t *desc_b, int nb, int desc_bytes, int selector, int cross_check, float ratio,
+                       int32_t *train_idx, float *distance) {
+  if (!c || na < 0 || nb < 0 || (na > 0 && (!desc_a || !train_idx || !distance)) || (nb > 0 && !desc_b)) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  if (selector != SPVO_SELECT_NN && selector != SPVO_SELECT_KNN) return fail(c, SPVO_ERR_INVALID, "bad selector");
+  if (desc_bytes <= 0 || desc_bytes > 64) return fail(c, SPVO_ERR_INVALID, "binary descriptors of 1 .. 64 bytes are supported (got %d)", desc_bytes);
+  if (na == 0) return SPVO_OK;
+  if (nb == 0) {
+    for (int i = 0; i < na; ++i) { train_idx[i] = -1; distance[i] = 0.f; }
+    return SPVO_OK;
+  }
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  const int nw = desc_bytes <= 32 ? 8 : 16;
+  const int need = std::max(na, nb);
+  if (need > c->ham_cap) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream2));
+    for (void *p : {(void *)c->d_ham_a, (void *)c->d_ham_b, (void *)c->d_ham_idx, (void *)c->d_ham_dist, (void *)c->d_ham_vote}) if (p) (void)hipFree(p);
+    c->d_ham_a = c->d_ham_b = nullptr; c->d_ham_idx = nullptr; c->d_ham_dist = nullptr; c->d_ham_vote = nullptr;
+    c->ham_cap = 0;
+    const int cap = std::max(need, 2048);
+    int rc;
+    if ((rc = dev_alloc(c, &c->d_ham_a, (size_t)cap * 16)) || (rc = dev_alloc(c, &c->d_ham_b, (size_t)cap * 16)) || (rc = dev_alloc(c, &c->d_ham_idx, cap)) ||
+        (rc = dev_alloc(c, &c->d_ham_dist, cap)) || (rc = dev_alloc(c, &c->d_ham_vote, cap)))
+      return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // (dev_alloc clears on the network stream)
+    c->ham_cap = cap;
+  }
+  // rows zero-padded to nw words: padding bits are equal on both sides and add nothing to a distance
+  std::vector<uint32_t> pa((size_t)na * nw, 0u), pb((size_t)nb * nw, 0u);
+  for (int i = 0; i < na; ++i) std::memcpy(&pa[(size_t)i * nw], desc_a + (size_t)i * desc_bytes, desc_bytes);
+  for (int i = 0; i < nb; ++i) std::memcpy(&pb[(size_t)i * nw], desc_b + (size_t)i * desc_bytes, desc_bytes);
+  hipStream_t st = c->stream2;   // the solver's stream: overlaps detector submissions in flight
+  HIP_TRY(c, hipMemcpyAsync(c->d_ham_a, pa.data(), pa.size() * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(c->d_ham_b, pb.data(), pb.size() * 4, hipMemcpyHostToDevice, st));
+  const bool cross = cross_check && selector == SPVO_SELECT_NN;   // BFMatcher's crossCheck is off for knnMatch (base.cpp:27-28)
+  auto launch = [&](const uint32_t *A, int n_a, const uint32_t *B, int n_b, int mode) {
+    if (nw == 8) hipLaunchKernelGGL(match_hamming_kernel<8>, dim3((n_a + 3) / 4), dim3(256), 0, st, A, n_a, B, n_b, mode, ratio, c->d_ham_idx, c->d_ham_dist, c->d_ham_vote);
+    else hipLaunchKernelGGL(match_hamming_kernel<16>, dim3((n_a + 3) / 4), dim3(256), 0, st, A, n_a, B, n_b, mode, ratio, c->d_ham_idx, c->d_ham_dist, c->d_ham_vote);
+  };
+  if (cross) {
+    HIP_TRY(c, hipMemsetAsync(c->d_ham_vote, 0xFF, (size_t)na * sizeof(unsigned long long), st));
+    launch(c->d_ham_b, nb, c->d_ham_a, na, 2);   // every train row votes for its nearest query row
+    hipLaunchKernelGGL(match_hamming_cross_kernel, dim3((na + 255) / 256), dim3(256), 0, st, c->d_ham_vote, na, c->d_ham_idx, c->d_ham_dist);
+  } else {
+    launch(c->d_ham_a, na, c->d_ham_b, nb, selector == SPVO_SELECT_KNN ? 1 : 0);
+  }
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(train_idx, c->d_ham_idx, (size_t)na * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipMemcpyAsync(distance, c->d_ham_dist, (size_t)na * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipStreamSynchronize(st));
+  return SPVO_OK;
 }
 
 int spvo_match_slots(spvo_ctx *c, int slot_a, int slot_b, int selector, int cross_check, float ratio, int32_t *train_idx, float *distance) {

@@ -69,16 +69,9 @@ void FeatureFrontEnd::initMatcher() {
   if (matcher_type_ == MatcherType::BF) {
     // cv::BFMatcher::create(norm_type, cross_check_ & (selector_type_ != KNN))   base.cpp:27-28
     matcher_cross_check_ = cross_check_ && (selector_type_ != SelectorType::KNN);
-    if (descriptor_type_ != DescriptorType::SIFT && descriptor_type_ != DescriptorType::SuperPoint) {
-#ifdef SPVO_USE_OPENCV
-      // binary descriptors of the classic CPU baseline (ORB / BRISK / AKAZE ...): NORM_HAMMING on the host through OpenCV
-      matcher_ = cv::BFMatcher::create(cv::NORM_HAMMING, matcher_cross_check_);
-      matcher_ready_ = true;
-#else
-      logError("[initMatcher] only NORM_L2 descriptors (SuperPoint/SIFT) are implemented on the GPU path; NORM_HAMMING needs a build with SPVO_USE_OPENCV");
-#endif
-      return;
-    }
+    // NORM_HAMMING for the binary descriptors of the classic front end (ORB / BRISK / AKAZE, base.cpp:17-21): spvo_match_hamming
+    // on the host matrices of descriptors_dq; NORM_L2 (SuperPoint / SIFT): spvo_match_slots on the device-resident feature slots
+    matcher_hamming_ = descriptor_type_ != DescriptorType::SIFT && descriptor_type_ != DescriptorType::SuperPoint;
     matcher_ready_ = true;
   } else {
     logError("[initMatcher] FLANN matcher is not implemented on the GPU path (base.cpp:29-32); use BF");
@@ -152,31 +145,11 @@ void FeatureFrontEnd::matchDescriptors(const MatchType match_type) {
     return;
   }
   const std::vector<cv::KeyPoint> &keypoints0 = keypoints_dq.end()[p0];
-#ifdef SPVO_USE_OPENCV
-  if (matcher_) {   // classic front end: descriptors are host matrices, the search is OpenCV's (base.cpp:462-473)
-    std::vector<cv::DMatch> &out = cv_DMatches_list[match_type];
-    out.clear();
-    const cv::Mat &query = descriptors_dq.end()[p0], &train_desc = descriptors_dq.end()[p1];
-    if (selector_type_ == SelectorType::NN) {
-      matcher_->match(query, train_desc, out);
-    } else {
-      std::vector<std::vector<cv::DMatch>> two;
-      matcher_->knnMatch(query, train_desc, two, 2);
-      for (const auto &pair : two)
-        if (pair.size() >= 2 && pair[0].distance < knn_threshold_ * pair[1].distance) out.push_back(pair[0]);
-    }
-    if (match_type == MatchType::CURR_LEFT_CURR_RIGHT) maps_of_indices[MatchType::PREV_LEFT_PREV_RIGHT] = maps_of_indices[MatchType::CURR_LEFT_CURR_RIGHT];
-    std::vector<int> &index_map = maps_of_indices.at(match_type);
-    index_map.assign(keypoints0.size(), -1);
-    for (const cv::DMatch &m : out) index_map.at(m.queryIdx) = m.trainIdx;
-    return;
-  }
-#endif
-  if (!ctx_ || !matcher_ready_ || slots_dq_.size() != keypoints_dq.size()) {
+  if (matcher_hamming_ && !ensureContext()) return;
+  if (!ctx_ || !matcher_ready_ || (!matcher_hamming_ && slots_dq_.size() != keypoints_dq.size())) {
     logError("matchDescriptors: front end not initialised");
     return;
   }
-  const int slot0 = slots_dq_.end()[p0], slot1 = slots_dq_.end()[p1];
   if (descriptors_dq.end()[p0].rows < 10) std::fprintf(stderr, "[ WARN] descriptors0.rows == %d < 10\n", descriptors_dq.end()[p0].rows);
   if (descriptors_dq.end()[p1].rows < 10) std::fprintf(stderr, "[ WARN] descriptors1.rows == %d < 10\n", descriptors_dq.end()[p1].rows);
 
@@ -185,10 +158,29 @@ void FeatureFrontEnd::matchDescriptors(const MatchType match_type) {
   const int n0 = (int)keypoints0.size();
   std::vector<int32_t> train(std::max(n0, 1), -1);
   std::vector<float> dist(std::max(n0, 1), 0.f);
-  const int rc = spvo_match_slots(ctx_, slot0, slot1, selector_type_ == SelectorType::KNN ? SPVO_SELECT_KNN : SPVO_SELECT_NN,
-                                  matcher_cross_check_ ? 1 : 0, knn_threshold_, train.data(), dist.data());
+  const int sel = selector_type_ == SelectorType::KNN ? SPVO_SELECT_KNN : SPVO_SELECT_NN;
+  int rc;
+  if (matcher_hamming_) {   // binary descriptors: host matrices (CV_8U, one row per keypoint), packed row by row if they are views
+    const cv::Mat &d0 = descriptors_dq.end()[p0], &d1 = descriptors_dq.end()[p1];
+    const int nbytes = d0.rows ? d0.cols : d1.cols;
+    auto rows_of = [nbytes](const cv::Mat &m, std::vector<uint8_t> &buf) -> const uint8_t * {
+      if (m.rows == 0) return nullptr;
+      if ((size_t)m.step == (size_t)nbytes) return m.ptr<uint8_t>(0);
+      buf.resize((size_t)m.rows * nbytes);
+      for (int r = 0; r < m.rows; ++r) std::memcpy(buf.data() + (size_t)r * nbytes, m.ptr<uint8_t>(r), nbytes);
+      return buf.data();
+    };
+    std::vector<uint8_t> b0, b1;
+    if ((d0.rows && d0.depth() != CV_8U) || (d1.rows && d1.depth() != CV_8U) || (d0.rows && d1.rows && d0.cols != d1.cols) || d0.rows != n0) {
+      logError("matchDescriptors: binary descriptors expected (CV_8U, one row per keypoint, equal widths)");
+      return;
+    }
+    rc = spvo_match_hamming(ctx_, rows_of(d0, b0), d0.rows, rows_of(d1, b1), d1.rows, nbytes, sel, matcher_cross_check_ ? 1 : 0, knn_threshold_, train.data(), dist.data());
+  } else {
+    rc = spvo_match_slots(ctx_, slots_dq_.end()[p0], slots_dq_.end()[p1], sel, matcher_cross_check_ ? 1 : 0, knn_threshold_, train.data(), dist.data());
+  }
   if (rc != SPVO_OK) {
-    logError(std::string("spvo_match_slots: ") + spvo_last_error(ctx_));
+    logError(std::string("matchDescriptors: ") + spvo_last_error(ctx_));
     return;
   }
   for (int i = 0; i < n0; ++i)

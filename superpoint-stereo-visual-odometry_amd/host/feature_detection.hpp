@@ -245,9 +245,7 @@ protected:
   // replaces cv::Ptr<cv::DescriptorMatcher> matcher_: for NORM_L2 descriptors the matcher lives behind the C ABI
   bool matcher_ready_ = false;
   bool matcher_cross_check_ = false;
-#ifdef SPVO_USE_OPENCV
-  cv::Ptr<cv::DescriptorMatcher> matcher_;   // NORM_HAMMING descriptors of the classic front end (base.cpp:13-28): OpenCV, host
-#endif
+  bool matcher_hamming_ = false;   // NORM_HAMMING descriptors of the classic front end (base.cpp:13-28): spvo_match_hamming
   // creates ctx_ without an engine: preprocessImageImpl and solveStereoOdometry of a front end that has no network
   bool ensureContext();
 

@@ -178,6 +178,27 @@ int spvo_host_classic_probe(char *err, int cap) {
   return ClassicFeatureFrontEnd::available() ? (int)fe.keypoints_dq.size() : -(int)fe.keypoints_dq.size();
 }
 
+// The classic front end's matching route without its detectors (which need OpenCV): a ClassicFeatureFrontEnd(ORB, ORB, BF,
+// selector, cross_check) gets the four feature sets of two stereo frames pushed into its public deques -- binary descriptors,
+// `nbytes` per row -- and runs matchDescriptors(match_type) (base.cpp:434-500 with NORM_HAMMING, base.cpp:17-21).
+// sets: prevL, prevR, currL, currR; n[4] rows each, desc[i] = n[i] x nbytes.  Writes maps_of_indices[match_type]; returns its size.
+int spvo_host_classic_match(int knn, int cross_check, int match_type, const uint8_t *const desc[4], const int n[4], int nbytes, int *map_out, int cap) {
+  ClassicFeatureFrontEnd fe(detector_name_to_type.at("ORB"), descriptor_name_to_type.at("ORB"), matcher_name_to_type.at("BF"),
+                            selector_name_to_type.at(knn ? "KNN" : "NN"), cross_check != 0, 2.0f, 2.0f, 4, false, 0, 0);
+  for (int i = 0; i < 4; ++i) {
+    cv::Mat d(n[i], nbytes, CV_8UC1);
+    if (n[i]) std::memcpy(d.data, desc[i], (size_t)n[i] * nbytes);
+    std::vector<cv::KeyPoint> kp((size_t)n[i]);
+    fe.keypoints_dq.push_back(kp);
+    fe.descriptors_dq.push_back(d);
+    fe.images_dq.push_back(cv::Mat());
+  }
+  fe.matchDescriptors((MatchType)match_type);
+  const std::vector<int> &m = fe.mapsOfIndices().at((MatchType)match_type);
+  for (int i = 0; i < (int)m.size() && i < cap; ++i) map_out[i] = m[i];
+  return (int)m.size();
+}
+
 // bit 0 pnp ok, bit 1 accepted by the gate, bit 2 refinement kept; LM iterations in bits 8..
 int spvo_host_last_solve(void *h) {
   auto *fe = static_cast<SuperPointFeatureFrontEnd *>(h);

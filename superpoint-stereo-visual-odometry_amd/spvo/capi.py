@@ -59,7 +59,7 @@ SYMBOLS = [
     "spvo_default_config", "spvo_create", "spvo_destroy", "spvo_last_error", "spvo_load_weights", "spvo_engine_precision", "spvo_set_fp32_split",
     "spvo_preprocess", "spvo_forward", "spvo_debug_tensor", "spvo_heatmap", "spvo_nms",
     "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_detect_dev_submit", "spvo_detect_wait", "spvo_detect_submit", "spvo_detect_collect", "spvo_match", "spvo_match_slots", "spvo_set_prematch", "spvo_set_match_fp8",
-    "spvo_triangulate", "spvo_pnp_ransac", "spvo_pnp_refine", "spvo_solve_stereo_odometry", "spvo_solve_submit", "spvo_solve_wait", "spvo_stream", "spvo_synchronize",
+    "spvo_match_hamming", "spvo_triangulate", "spvo_pnp_ransac", "spvo_pnp_refine", "spvo_solve_stereo_odometry", "spvo_solve_submit", "spvo_solve_wait", "spvo_stream", "spvo_synchronize",
     "spvo_profile_enable", "spvo_profile_reset", "spvo_profile_only", "spvo_profile_count", "spvo_profile_get",
     "spvo_comm_unique_id", "spvo_comm_create", "spvo_comm_create_host", "spvo_comm_rank", "spvo_comm_world", "spvo_comm_destroy",
     "spvo_pose_allgather", "spvo_pose_allgather_n",
@@ -101,6 +101,7 @@ def load() -> C.CDLL:
     lib.spvo_detect_collect.argtypes = [vp, dp, dp, C.POINTER(Features), C.POINTER(Features), vp, vp]
     lib.spvo_match.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
     lib.spvo_match_slots.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
+    lib.spvo_match_hamming.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
     lib.spvo_set_prematch.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float]
     lib.spvo_triangulate.argtypes = [vp, dp, dp, vp, vp, C.c_int, vp]
     lib.spvo_pnp_ransac.argtypes = [vp, dp, vp, vp, C.c_int, C.POINTER(RansacOpts), dp, dp, vp, ip, ip]
@@ -308,6 +309,19 @@ class Context:
         fr, xyr, _ = self._features(False)
         self._check(self.lib.spvo_detect_wait(self.h, _dptr(Pl), _dptr(Pr), C.byref(fl), C.byref(fr)))
         return dict(xy_l=xyl[:fl.n], xy_r=xyr[:fr.n], P_l=Pl.reshape(3, 4), P_r=Pr.reshape(3, 4))
+
+    def match_hamming(self, a: np.ndarray, b: np.ndarray, selector="KNN", cross_check=False, ratio=0.8):
+        """cv::BFMatcher(NORM_HAMMING) on u8 descriptor rows (spvo_match_hamming)."""
+        a = np.ascontiguousarray(a, np.uint8)
+        b = np.ascontiguousarray(b, np.uint8)
+        nbytes = a.shape[1] if a.ndim == 2 and a.shape[1] else (b.shape[1] if b.ndim == 2 and b.shape[1] else 32)
+        a = a.reshape(len(a), nbytes)
+        b = b.reshape(len(b), nbytes)
+        idx = np.full(len(a), -1, np.int32)
+        dist = np.zeros(len(a), np.float32)
+        self._check(self.lib.spvo_match_hamming(self.h, _ptr(a), len(a), _ptr(b), len(b), nbytes, 1 if selector == "KNN" else 0,
+                                                int(cross_check), ratio, _ptr(idx), _ptr(dist)))
+        return idx, dist
 
     def match(self, a: np.ndarray, b: np.ndarray, selector="KNN", cross_check=False, ratio=0.8):
         a = np.ascontiguousarray(a, np.float32).reshape(-1, 256)

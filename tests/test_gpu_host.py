@@ -243,3 +243,30 @@ def test_int8_engine_through_the_host_class(tmp_path, sequence):
         assert np.linalg.norm(t8 - t_true) < 0.10                    # naive post-training quantisation: still tracks
         a, b = set(map(tuple, kp8.tolist())), set(map(tuple, kp32.tolist()))
         assert len(a & b) / len(a | b) > 0.4
+
+
+@pytest.mark.parametrize("knn,cross", [(1, 0), (0, 0), (0, 1)])
+def test_classic_front_end_matches_binary_descriptors_on_the_gpu(knn, cross):
+    """matchDescriptors of a ClassicFeatureFrontEnd(ORB, ORB, BF, ...) -- base.cpp:434-500 with the NORM_HAMMING matcher of
+    base.cpp:17-21 -- runs spvo_match_hamming on the host descriptor matrices of descriptors_dq: the index maps equal the
+    oracle's for both match types of a frame (the detectors themselves need OpenCV and are not part of this test)."""
+    import ctypes
+    from oracle import matching
+    from spvo import host
+    lib = host.load()
+    lib.spvo_host_classic_match.restype = ctypes.c_int
+    lib.spvo_host_classic_match.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+                                            ctypes.c_void_p, ctypes.c_int]
+    rng = np.random.RandomState(3)
+    sets = [rng.randint(0, 256, (n, 32)).astype(np.uint8) for n in (1500, 1400, 1600, 1550)]   # prevL, prevR, currL, currR
+    sets[3][:400] = sets[2][100:500]                                                             # stereo partners
+    sets[0][200:700] = sets[2][300:800]                                                          # temporal partners
+    sets[0][200:300, 1] ^= 3
+    ptrs = (ctypes.c_void_p * 4)(*[s.ctypes.data for s in sets])
+    ns = (ctypes.c_int * 4)(*[len(s) for s in sets])
+    for match_type, (qa, tb) in ((0, (2, 3)), (1, (2, 0))):                                      # CURR_LEFT_CURR_RIGHT, CURR_LEFT_PREV_LEFT
+        out = np.full(len(sets[qa]), -7, np.int32)
+        n = lib.spvo_host_classic_match(knn, cross, match_type, ptrs, ns, 32, out.ctypes.data, len(out))
+        ref, _ = matching.bf_match_hamming(sets[qa], sets[tb], "KNN" if knn else "NN", bool(cross))
+        assert n == len(ref) and np.array_equal(out, ref)
+        assert (ref >= 0).sum() > 300

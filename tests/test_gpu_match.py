@@ -107,3 +107,28 @@ def test_match_scaled_descriptors(ctx_vgg, scale):
     b = np.concatenate([a[:250] * (1 + rng.randn(250, 1).astype(np.float32) * 1e-7), _unit(rng, 380) * np.float32(scale)])
     for selector, cross in (("KNN", False), ("NN", False), ("NN", True)):
         _check(ctx_vgg, a, b, selector, cross)
+
+
+@pytest.mark.parametrize("nbytes", [32, 61, 64])
+@pytest.mark.parametrize("selector,cross", [("KNN", False), ("NN", False), ("NN", True)])
+def test_hamming_matcher_is_bit_exact(ctx_vgg, nbytes, selector, cross):
+    """cv::BFMatcher(NORM_HAMMING) for the classic front end's binary descriptors (ORB 32 bytes, AKAZE 61, BRISK 64) through
+    spvo_match_hamming against oracle/matching.py: indices and distances exact, for random bit strings, planted duplicates
+    (ties between train rows), near-duplicates one bit apart, and the degenerate sizes."""
+    rng = np.random.RandomState(nbytes)
+    a = rng.randint(0, 256, (1900, nbytes)).astype(np.uint8)
+    b = rng.randint(0, 256, (2000, nbytes)).astype(np.uint8)
+    b[100:200] = a[300:400]                                             # exact matches
+    b[250:300] = a[300:350]                                             # ... twice: the lower train index has to win
+    b[400:500] = a[500:600]
+    b[400:500, 0] ^= 1                                                  # one bit apart
+    a[700:720] = a[699]                                                 # several queries with the same nearest train row (cross-check)
+    for aa, bb in ((a, b), (a[:5], b[:1]), (a[:3], b[:2]), (a[:0], b), (a[:7], b[:0])):
+        gi, gd = ctx_vgg.match_hamming(aa, bb, selector, cross)
+        ri, rd = matching.bf_match_hamming(aa, bb, selector, cross)
+        assert np.array_equal(gi, ri) and np.array_equal(gd, rd), (len(aa), len(bb))
+    gi, _ = ctx_vgg.match_hamming(a, b, selector, cross)
+    if selector == "NN" and not cross:
+        assert (gi[300:350] == np.arange(100, 150)).all()              # two identical train rows: the lower index
+    if selector == "KNN":
+        assert (gi[300:350] == -1).all() and (gi[350:400] == np.arange(150, 200)).all()   # 0 < 0.8 * 0 fails; a single exact partner passes

@@ -210,3 +210,21 @@ def test_golden_vgg_and_match_and_odometry(golden_dir, vgg_plan):
     assert ok == bool(o["ok"]) and np.array_equal(inl, o["inliers"])
     assert np.allclose(r, o["rvec"], atol=1e-9) and np.allclose(t, o["tvec"], atol=1e-9)
     assert np.allclose(r, o["true_rvec"], atol=3e-3) and np.allclose(t, o["true_tvec"], atol=3e-2)
+
+
+def test_hamming_matching_known_answers():
+    """bf_match_hamming (cv::BFMatcher(NORM_HAMMING) restated): bit counts, lowest-index ties, the ratio test on integer
+    distances, and the crosscheck procedure, on cases small enough to check by hand."""
+    from oracle import matching
+    a = np.array([[0b00001111, 0], [0xFF, 0xFF], [0, 0]], np.uint8)
+    b = np.array([[0b00001110, 0], [0b00001111, 1], [0xFF, 0x7F], [0, 0]], np.uint8)
+    d = matching.hamming_distances(a, b)
+    assert d.tolist() == [[1, 1, 11, 4], [13, 11, 1, 16], [3, 5, 15, 0]]
+    idx, dist = matching.bf_match_hamming(a, b, "NN")
+    assert idx.tolist() == [0, 2, 3] and dist.tolist() == [1.0, 1.0, 0.0]          # row 0: tie 1 == 1 -> lower train index
+    idx, dist = matching.bf_match_hamming(a, b, "KNN", ratio=0.8)
+    assert idx.tolist() == [-1, 2, 3]                                              # row 0: 1 < 0.8 * 1 fails; row 2: 0 < 0.8 * 3
+    idx, dist = matching.bf_match_hamming(a, b, "NN", cross_check=True)
+    # train rows choose queries: t0 -> q0 (1), t1 -> q0 (1), t2 -> q1 (1), t3 -> q2 (0); q0 keeps the first of its two voters
+    assert idx.tolist() == [0, 2, 3] and dist.tolist() == [1.0, 1.0, 0.0]
+    assert matching.bf_match_hamming(a[:0], b)[0].shape == (0,) and matching.bf_match_hamming(a, b[:0])[0].tolist() == [-1, -1, -1]
