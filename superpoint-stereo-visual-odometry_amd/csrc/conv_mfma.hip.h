@@ -78,8 +78,8 @@ struct ConvArgs {
   const float *bn_scale = nullptr, *bn_shift = nullptr;  // EPI 1: v = relu(v * scale[co] + shift[co]), [co_tiles*64]
   const float *residual = nullptr;                       // EPI 2: v = relu(v + residual[co][y][x]); planes of the
                                                          //        input's geometry (in_hp x in_wp), cout channels
-  int *sched = nullptr;                                  // conv_wino2_kernel: {tile counter, workgroups done} of this layer, both 0 between
-                                                         //        launches: tiles are handed out dynamically (nullptr: blockIdx.x + k gridDim.x)
+  int *sched = nullptr;                                  // conv_wino2_kernel: {8 tile counters (one per XCD band), workgroups done} of this layer,
+                                                         //        all 0 between launches: tiles are handed out dynamically (nullptr: blockIdx.x + k gridDim.x)
   unsigned long long *stamps = nullptr;                  // diagnostic build (ABL 4) only: per workgroup
                                                          //        {shader cycles, 100 MHz ticks} around the tile loop
 };

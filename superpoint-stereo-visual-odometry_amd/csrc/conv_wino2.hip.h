@@ -185,9 +185,45 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
   const int a_lane = cq * 64 + lane;   // 8-byte pieces in a filter slab:  + xi * 64 NCQ
   const int b_lane = tb * 64 + lane;   // 16-byte (narrow: 8-byte) pieces in a V buffer:  + xi * 128 (256)
 
+  // a.sched (dynamic tile assignment, see below): the tiles are cut into 8 contiguous bands, one per group of workgroups that
+  // share an XCD (blockIdx.x % 8: MI355X_MICROARCH.md, workgroup dispatch) -- an XCD's ~30 workgroups then work on ~30
+  // consecutive tiles = most of one row of tiles at a time, and the halo columns / rows and the 128-byte lines that neighbouring
+  // tiles share are fetched into that XCD's L2 once instead of once per XCD.  Bands are sized in proportion to their workgroups
+  // (238 workgroups are 6 groups of 30 and 2 of 29), so all of them run dry together and nobody needs to look into another band
+  // (tried: the futile atomics of 238 workgroups on 8 counters at the end cost more than the balance they bought).  A band's first
+  // tiles go to its workgroups by rank (no start-up atomic), the rest through the band's counter a.sched[band].  a.sched[8]
+  // counts the workgroups that are done; the last one clears all nine.
+  const int band = blockIdx.x & 7;
+  auto wgs_before = [&](int b) { return min(b, (int)gridDim.x & 7) + b * ((int)gridDim.x >> 3); };   // workgroups with blockIdx.x % 8 < b
+  auto band_lo = [&](int b) { return (int)((long)n_tiles * wgs_before(b) / (int)gridDim.x); };
+  auto band_hi = [&](int b) { return band_lo(b + 1); };
+  auto band_wgs = [&](int b) { return wgs_before(b + 1) - wgs_before(b); };
+  auto steal = [&]() {   // thread 0, blocking: a workgroup without a first tile of its own (more workgroups than tiles in its band)
+    for (int k = 1; k < 8; ++k) {
+      const int b = (band + k) & 7;
+      if (band_lo(b) + band_wgs(b) >= band_hi(b)) continue;
+      const int v = band_lo(b) + band_wgs(b) + atomicAdd(a.sched + b, 1);
+      if (v < band_hi(b)) return v;
+    }
+    return n_tiles;
+  };
+  auto all_done = [&]() {
+    if (a.sched && tid == 0 && atomicAdd(a.sched + 8, 1) == (int)gridDim.x - 1)
+      for (int k = 0; k < 9; ++k) a.sched[k] = 0;
+  };
+  int *const sched_slot = reinterpret_cast<int *>(smem + T::LDS_BYTES / 4);   // 16 bytes behind the V buffers (WINO2_LDS_BYTES)
   int tile_id = blockIdx.x;
+  if (a.sched) {
+    tile_id = band_lo(band) + (blockIdx.x >> 3);
+    if (tile_id >= band_hi(band)) {   // (uniform) more workgroups than tiles in this band: look elsewhere before anything starts
+      if (tid == 0) *sched_slot = steal();
+      __syncthreads();
+      tile_id = *sched_slot;
+      __syncthreads();
+    }
+  }
   if (tile_id >= n_tiles) {   // (the product's grids never exceed the tile count; a workgroup without work still counts as done)
-    if (a.sched && tid == 0 && atomicAdd(a.sched + 1, 1) == (int)gridDim.x - 1) { a.sched[0] = 0; a.sched[1] = 0; }
+    all_done();
     return;
   }
   TileRef cur = decode(tile_id);
@@ -200,7 +236,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
   // published through LDS at the tile's second item; the prefetch cursors cross into the next tile at the end of item
   // n_chunks - 3 at the earliest, so the host selects this mode for n_chunks >= 4 only.
   int nxt_id = tile_id + gridDim.x;
-  int *const sched_slot = reinterpret_cast<int *>(smem + T::LDS_BYTES / 4);   // 16 bytes behind the V buffers (WINO2_LDS_BYTES)
   int dyn_fetch = 0;
   struct Cursor { TileRef t; int chunk, id; };
   auto advance = [&](Cursor &q) {
@@ -230,7 +265,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
 
   while (tile_id < n_tiles) {
     if (a.sched) {
-      if (tid == 0) dyn_fetch = atomicAdd(a.sched, 1) + (int)gridDim.x;
+      if (tid == 0) dyn_fetch = band_lo(band) + band_wgs(band) + atomicAdd(a.sched + band, 1);
     } else {
       nxt_id = tile_id + gridDim.x;
     }
@@ -247,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
 #ifdef WINO_STAMPS
       const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
 #endif
-      if (publish && tid == 0) *sched_slot = dyn_fetch;      // (the wait above covered the atomic's return)
+      if (publish && tid == 0) *sched_slot = dyn_fetch < band_hi(band) ? dyn_fetch : n_tiles;   // (the wait above covered the atomic's return)
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (publish) nxt_id = __builtin_amdgcn_readfirstlane(*sched_slot);
 #ifdef WINO_STAMPS
@@ -400,7 +435,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
     tile_id = nxt_id;
     if (tile_id < n_tiles) cur = decode(tile_id);
   }
-  if (a.sched && tid == 0 && atomicAdd(a.sched + 1, 1) == (int)gridDim.x - 1) { a.sched[0] = 0; a.sched[1] = 0; }   // the last workgroup out resets the counters for the next launch
+  all_done();   // the last workgroup out resets the counters for the next launch
 #ifdef WINO_STAMPS
   if (lane == 0 && a.stamps) {
     unsigned long long *o = a.stamps + 8 * (blockIdx.x * 8 + wave);

@@ -62,7 +62,7 @@ struct Op {
   bool wino2 = false;      // ... its 8-wave form (conv_wino2.hip.h: two waves per SIMD; the default, SPVO_WINO2=0 keeps the 4-wave form)
   bool dominant = false;   // the op with the most FLOPs: launched under its own kernel name (TAG = 1)
   float *d_w = nullptr, *d_b = nullptr, *d_bn_scale = nullptr, *d_bn_shift = nullptr;
-  int *d_sched = nullptr;      // Winograd layers (8-wave form): {tile counter, workgroups done}, zero between launches (SPVO_WINO_DYNAMIC=0: none)
+  int *d_sched = nullptr;      // Winograd layers (8-wave form): {8 band counters, workgroups done}, zero between launches (SPVO_WINO_DYNAMIC=0: none)
   _Float16 *d_w16 = nullptr;   // FP16 engines: pack_conv_weights_f16()
   int8_t *d_w8 = nullptr;      // INT8 engines: pack_conv_weights_i8()
   unsigned short *d_ws3 = nullptr;   // FP32 engines in split mode: pack_conv_weights_s3()
@@ -1784,7 +1784,7 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
         int rc = dev_alloc(c, &op.d_w, pk.size(), false);
         if (rc) return rc;
         HIP_TRY(c, hipMemcpy(op.d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
-        if (op.wino2 && !(std::getenv("SPVO_WINO_DYNAMIC") && std::atoi(std::getenv("SPVO_WINO_DYNAMIC")) == 0) && (rc = dev_alloc(c, &op.d_sched, 2))) return rc;
+        if (op.wino2 && !(std::getenv("SPVO_WINO_DYNAMIC") && std::atoi(std::getenv("SPVO_WINO_DYNAMIC")) == 0) && (rc = dev_alloc(c, &op.d_sched, 16))) return rc;
         continue;
       }
       if (op.cin % op.ck) return fail(c, SPVO_ERR_IO, "op %u: cin %d is not a multiple of %d", i, op.cin, op.ck);

@@ -8,7 +8,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/bench.py > $OUT/bench.log 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o st -- python3 $ROOT/bench.py --no-cpu-baseline --no-extras > $OUT/bench_under_rocprof.log 2>&1
-W="$ROOT/tools/wino_bench2 360 1176 64 64 1 20"
+export WINO_DYNAMIC=1   # tools/wino_bench2: tiles through the XCD-banded counters, as the library launches the layer
+W="$ROOT/tools/wino_bench2 360 1176 64 64 1 20 238"
 M="$ROOT/tools/match_bench 1000 2 50"
 C="$ROOT/tools/copy_bench 1024 3"
 for prog in wino match copy; do

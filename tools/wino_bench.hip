@@ -68,7 +68,7 @@ int main(int argc, char **argv) {
   const int grid = argc > 7 ? atoi(argv[7]) : (int)std::min<long>(cus, n_items / a.n_chunks);
   if (getenv("WINO_DYNAMIC") && atoi(getenv("WINO_DYNAMIC"))) {   // tiles handed out by a counter instead of blockIdx.x + k gridDim.x (8-wave forms)
     int *d_sched;
-    CK(hipMalloc(&d_sched, 8)); CK(hipMemset(d_sched, 0, 8));
+    CK(hipMalloc(&d_sched, 64)); CK(hipMemset(d_sched, 0, 64));
     a.sched = d_sched;
   }
   auto launch = [&]() {
