@@ -174,6 +174,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the informational second measurement (FP32 engine in split mode)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--no-pipeline", action="store_true", help="do not hand the next stereo pairs over early")
+    ap.add_argument("--deferred-solve", action="store_true", help="hand every frame's solve over and collect its pose during the next step "
+                                                                  "(solveStereoOdometrySubmit / Collect) instead of solving inside the step; measured: no change of the frame rate")
     ap.add_argument("--net-size", default="360x1176", help="network input HxW: 360x1176 (the reference's, default = the headline workload) or 376x1240 (native, SURVEY.md section 8)")
     ap.add_argument("--precision", default="FP32", choices=["FP32", "FP16", "INT8"],
                     help="FP32 = the headline workload (BASELINE config 2); FP16 = the half-precision engine of config 3 (use with --net-size 192x640); "
@@ -188,7 +190,7 @@ def main():
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 5],
                     help="BASELINE.json config shortcut: 2 = default; 3 = FP16 192x640; 5 = sp_mbv1 INT8, 2048 keypoints, fp8 shortlist")
     ap.add_argument("--dump-ops", action="store_true", help="add per-layer network times to the JSON line")
-    ap.add_argument("--depth", type=int, default=2, choices=[1, 2], help="stereo pairs handed over ahead of the one being solved")
+    ap.add_argument("--depth", type=int, default=2, choices=[1, 2, 3], help="stereo pairs handed over ahead of the one being solved (3 measured no faster than 2)")
     args = ap.parse_args()
     if args.config == 3:
         args.precision, args.net_size = "FP16", "192x640"
@@ -274,13 +276,17 @@ def main():
     # shared-GPU test hook: RCCL refuses two ranks on one device, so the C ABI's file transport carries the poses there
     pg = posegather.PoseGather(torch.device("cpu") if shared else torch.device("cuda", local_rank), force=dist_on)
 
+    deferred = args.deferred_solve and not args.no_pipeline
+
     def step(i, order=order):
         dl, dr = d_frames[order[i % len(order)]]
-        ahead = [None, None]                                                # the next pairs are already in HBM
+        ahead = [None, None, None]                                          # the next pairs are already in HBM
         for d in range(0 if args.no_pipeline else args.depth):
             nl, nr = d_frames[order[(i + 1 + d) % len(order)]]
             ahead[d] = (nl.data_ptr(), nr.data_ptr())
-        res = fe.step_device(dl.data_ptr(), dr.data_ptr(), rows, cols, dl.stride(0), P_l, P_r, ahead[0], ahead[1])
+        # with pairs handed over ahead the solve is handed over too: the pose of frame i is collected in step i + 1 (or by
+        # fe.finish_solve() after the last step), so the solver's latency is never between two hand-overs of images
+        res = fe.step_device(dl.data_ptr(), dr.data_ptr(), rows, cols, dl.stride(0), P_l, P_r, ahead[0], ahead[1], deferred_solve=deferred, next3_pair=ahead[2])
         if dist_on:                                                       # pose staged; RCCL all-gather per 64 frames on a side stream
             pg.gather_async(*(res if res is not None else (None, None)))
             if (i + 1) % 1024 == 0:
@@ -316,6 +322,9 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
+    last = fe.finish_solve()                                                # the last step's pose (deferred solve): inside the timed region
+    if dist_on and last is not None:
+        pg.gather_async(*last)
     if dist_on:
         gathered = pg.collect()                                             # every pose of every rank has arrived: inside the timed region
         assert gathered.shape[1:] == (world, 7)
@@ -349,6 +358,8 @@ def main():
                                    + ("fp8 shortlist + exact re-rank, " if args.match_fp8 else "")
                                    + "BF+KNN 0.8, P3P-style RANSAC 500 it, LM refinement degree 4; one stereo stream per GPU, RCCL all-gather of poses",
                        "net_size": [NET_H, NET_W], "input_size": [rows, cols], "streams": world,
+                       "hand_over": ("images of the next %d pairs handed over ahead (prefetchStereoImagePairDevice)" % args.depth if not args.no_pipeline else "one pair at a time")
+                                    + ("; each frame's solve handed over too, its pose collected during the next step (solveStereoOdometrySubmit / Collect), the last one before the closing barrier" if deferred else ""),
                        "pose_gather": {"local": "single stream, no collective", "c:rccl": "spvo_pose_allgather_n (C ABI, RCCL), one collective per 64 frames",
                                        "c:host": "spvo_pose_allgather_n (C ABI, file transport: test hook)",
                                        "torch": "torch.distributed all_gather (RCCL), one collective per 64 frames"}.get(pg.transport, pg.transport)
@@ -438,15 +449,17 @@ def main():
                 hi = {}
                 for name, depth in (("synchronous", 0), ("lookahead", 2)):
                     def hstep(i, depth=depth):
-                        a = [mats[order[(i + 1 + d) % len(order)]] if d < depth else None for d in range(2)]
+                        a = [mats[order[(i + 1 + d) % len(order)]] if d < depth else None for d in range(3)]
                         m = mats[order[i % len(order)]]
-                        return fe.step_host(m[0], m[1], P_l, P_r, a[0], a[1])
+                        return fe.step_host(m[0], m[1], P_l, P_r, a[0], a[1], deferred_solve=depth > 0 and deferred, next3_pair=a[2])
                     for i in range(args.warmup):
                         hstep(i)
+                    fe.finish_solve()
                     barrier()
                     t1 = time.perf_counter()
                     for i in range(args.warmup, args.warmup + args.steps):
                         hstep(i)
+                    fe.finish_solve()
                     barrier()
                     e3 = time.perf_counter() - t1
                     hi[name] = {"value": round(args.steps / e3, 2), "ms_per_step": round(1e3 * e3 / args.steps, 4)}
@@ -486,6 +499,7 @@ def main():
                     t1 = time.perf_counter()
                     for i in range(args.warmup, args.warmup + args.steps):
                         tstep(i)
+                    fe.finish_solve()
                     barrier()
                     e4 = time.perf_counter() - t1
                     st = np.array(stats, np.float64)

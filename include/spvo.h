@@ -126,9 +126,9 @@ typedef struct {
 /* addStereoImagePair (nn.cpp:449-498), everything but the deque bookkeeping:
  * preprocess both images, run the network, post-process.  P_l/P_r are updated
  * in place (nn.cpp:465-466 clones then mutates).  The device copies of the
- * keypoints/descriptors are kept in feature slots `slot_l`/`slot_r` (0..7: the
+ * keypoints/descriptors are kept in feature slots `slot_l`/`slot_r` (0..9: the
  * caller's ring of prevL, prevR, currL, currR of hpp:66-72, plus the slots of up to
- * two pairs submitted ahead) for spvo_match_slots.
+ * three pairs submitted ahead) for spvo_match_slots.
  * `resized_l`/`resized_r` (net_height*net_width u8, what nn.cpp:154 pushes to
  * images_dq) may be NULL. */
 int spvo_detect(spvo_ctx *ctx, const uint8_t *img_l, const uint8_t *img_r, int rows, int cols,
@@ -148,7 +148,7 @@ int spvo_detect_dev(spvo_ctx *ctx, const void *d_img_l, const void *d_img_r, int
 
 /* Asynchronous form of spvo_detect_dev: _submit returns as soon as the whole detector chain (and,
  * with spvo_set_prematch, the two standard matches) is enqueued; _wait blocks until the OLDEST
- * submission has finished and hands out what spvo_detect_dev would have.  At most two submissions
+ * submission has finished and hands out what spvo_detect_dev would have.  At most three submissions
  * may be in flight: the post-processing of one then overlaps with the network of the next.
  * Meanwhile the caller may run spvo_match_slots on precomputed matches and
  * spvo_solve_stereo_odometry for pairs already waited for: the ROS node receives the next image
@@ -164,7 +164,7 @@ int spvo_detect_wait(spvo_ctx *ctx, double P_l[12], double P_r[12], spvo_feature
 
 /* The asynchronous form for images in HOST memory -- what a ROS node holds (cv_bridge::toCvCopy, node.cpp:163-168).
  * _submit copies the two images into pinned staging buffers of the submission (the caller's buffers are free when it
- * returns), queues the host-to-device copies and the whole detector chain behind them and returns; up to two
+ * returns), queues the host-to-device copies and the whole detector chain behind them and returns; up to three
  * submissions may be in flight, exactly as with spvo_detect_dev_submit (same slot rules).  `extras`: bit 0 = the resized
  * u8 images (nn.cpp:154, images_dq), bit 1 = the descriptors (descriptors_dq) also travel back, into pinned mirrors of
  * the submission.  _collect completes the OLDEST submission (of either kind) like spvo_detect_wait and hands out what was

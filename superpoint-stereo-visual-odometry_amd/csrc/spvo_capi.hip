@@ -33,8 +33,8 @@ namespace {
 thread_local std::string g_error;  // for calls without a context
 
 constexpr int RING = 4;          // buffer sets a detector submission owns (network outputs, heat map, NMS state, counters, host mirrors)
-constexpr int MAX_INFLIGHT = 2;  // detector submissions that may be queued at once
-constexpr int N_SLOTS = 8;       // feature slots: 4 stereo pairs (previous, current and two in flight)
+constexpr int MAX_INFLIGHT = 3;  // detector submissions that may be queued at once (RING - 1: the set of the pair just completed still serves its matches)
+constexpr int N_SLOTS = 10;      // feature slots: 5 stereo pairs (previous, current and three in flight)
 
 struct Tensor {
   int ch = 0, level = 0, H = 0, W = 0, hp = 0, wp = 0;
@@ -228,6 +228,10 @@ struct spvo_ctx {
 };
 
 namespace {
+
+// SPVO_TRUNK_TIMING diagnostics: where the host spends its time between two submissions (maxima over the 200 submissions of a report)
+struct HostDiag { double t_last_submit = 0, max_interval = 0, max_tail_wait = 0, max_solve_wait = 0; int match_miss = 0, late = 0, depth_sum = 0; } g_diag;
+inline double diag_now_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
 
 int fail(spvo_ctx *c, int code, const char *fmt, ...) {
   char buf[512];
@@ -2038,22 +2042,39 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   // SPVO_TRUNK_TIMING=1 (diagnostic): how long the network stream works per submission and how long it stands idle between two
   // submissions, from timing events at both ends of the trunk (printed every 200 submissions)
   static const bool trunk_timing = std::getenv("SPVO_TRUNK_TIMING") != nullptr;
-  static hipEvent_t tt_b[RING], tt_e[RING];
+  constexpr int TT = 8;   // ring of timing events: deeper than the submissions that can be in flight
+  static hipEvent_t tt_b[TT], tt_e[TT];
   static long tt_n = 0;
   static double tt_busy = 0, tt_idle = 0;
   if (trunk_timing) {
+    const double tnow = diag_now_us();
+    if (c->submit_count > 1 && hipEventQuery(c->ev_net[(c->submit_count - 2) % RING]) == hipSuccess) ++g_diag.late;   // the trunk before this one is done already: the stream is idle
+    g_diag.depth_sum += (int)c->pendq.size();
+    if (g_diag.t_last_submit > 0) g_diag.max_interval = std::max(g_diag.max_interval, tnow - g_diag.t_last_submit);
+    g_diag.t_last_submit = tnow;
     if (tt_n == 0)
-      for (int r = 0; r < RING; ++r) { (void)hipEventCreate(&tt_b[r]); (void)hipEventCreate(&tt_e[r]); }
-    if (tt_n >= RING) {   // the two submissions before the two that may be in flight are complete: ring slots (n-2) and (n-3)
-      const int r2 = (int)((tt_n - 2) % RING), r3 = (int)((tt_n - 3) % RING);
+      for (int r = 0; r < TT; ++r) { (void)hipEventCreate(&tt_b[r]); (void)hipEventCreate(&tt_e[r]); }
+    if (tt_n >= TT) {   // the submissions before those that may be in flight are complete: ring slots (n-4) and (n-5)
+      const int r2 = (int)((tt_n - 4) % TT), r3 = (int)((tt_n - 5) % TT);
       float busy = 0, idle = 0;
-      if (hipEventElapsedTime(&busy, tt_b[r2], tt_e[r2]) == hipSuccess && hipEventElapsedTime(&idle, tt_e[r3], tt_b[r2]) == hipSuccess) { tt_busy += busy; tt_idle += idle; }
+      static int tt_late = 0;
+      static float tt_max = 0;
+      if (hipEventElapsedTime(&busy, tt_b[r2], tt_e[r2]) == hipSuccess && hipEventElapsedTime(&idle, tt_e[r3], tt_b[r2]) == hipSuccess) {
+        tt_busy += busy; tt_idle += idle;
+        tt_late += idle > 0.05f ? 1 : 0;
+        tt_max = std::max(tt_max, idle);
+      }
       if (tt_n % 200 == 0) {
-        std::fprintf(stderr, "[spvo] trunk timing over 200 submissions: network stream busy %.1f us, idle %.1f us per submission\n", tt_busy * 1e3 / 200, tt_idle * 1e3 / 200);
-        tt_busy = tt_idle = 0;
+        std::fprintf(stderr, "[spvo] trunk timing over 200 submissions: network stream busy %.1f us, idle %.1f us per submission (%d gaps above 50 us, longest %.0f us)\n",
+                     tt_busy * 1e3 / 200, tt_idle * 1e3 / 200, tt_late, tt_max * 1e3);
+        std::fprintf(stderr, "[spvo]   host: longest interval between submissions %.0f us, longest wait for a tail %.0f us, for a solve %.0f us, matches not served from the cache %d; "
+                             "submissions that found the network stream idle %d, mean submissions in flight at submit %.2f\n",
+                     g_diag.max_interval, g_diag.max_tail_wait, g_diag.max_solve_wait, g_diag.match_miss, g_diag.late, g_diag.depth_sum / 200.0);
+        g_diag.max_interval = g_diag.max_tail_wait = g_diag.max_solve_wait = 0; g_diag.match_miss = 0; g_diag.late = 0; g_diag.depth_sum = 0;
+        tt_busy = tt_idle = 0; tt_late = 0; tt_max = 0;
       }
     }
-    (void)hipEventRecord(tt_b[tt_n % RING], c->stream);
+    (void)hipEventRecord(tt_b[tt_n % TT], c->stream);
   }
   hipEvent_t det_e0 = nullptr;
   const bool prof_detect = c->prof && (c->prof_only < 0 || c->prof_only == stage_id(c, "detect"));
@@ -2070,7 +2091,7 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   }
   if (rc) { c->cur_ring = 0; return rc; }
   c->last_batch = 2;
-  if (trunk_timing) { (void)hipEventRecord(tt_e[tt_n % RING], c->stream); ++tt_n; }
+  if (trunk_timing) { (void)hipEventRecord(tt_e[tt_n % 8], c->stream); ++tt_n; }
   HIP_TRY(c, hipEventRecord(c->ev_net[ring], c->stream));
   HIP_TRY(c, hipStreamWaitEvent(c->stream_t, c->ev_net[ring], 0));
   c->post = c->stream_t;
@@ -2154,7 +2175,9 @@ static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_feature
     rc = hipStreamSynchronize(c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "stream synchronisation failed");
   } else {
     // only this submission's tail: a younger one may be queued behind it on both streams
+    const double tw0 = diag_now_us();
     rc = wait_event(c->ev_tail[pd.ring]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");
+    g_diag.max_tail_wait = std::max(g_diag.max_tail_wait, diag_now_us() - tw0);
   }
   bool redone = false;
   const NmsPair np = nms_pair(c, pd.ring);
@@ -2363,6 +2386,7 @@ int spvo_match_slots(spvo_ctx *c, int slot_a, int slot_b, int selector, int cros
         return SPVO_OK;
       }
   }
+  ++g_diag.match_miss;
   for (const auto &q : c->pendq)
     if (q.slot_l == slot_a || q.slot_r == slot_a || q.slot_l == slot_b || q.slot_r == slot_b)
       return fail(c, SPVO_ERR_STATE, "match not precomputed and a detector submission is rewriting the feature slots");
@@ -2609,7 +2633,11 @@ int spvo_solve_wait(spvo_ctx *c, spvo_solve_output *out, float *xyz, int32_t *in
   };
   if (n == 0) { prior_pose(); return SPVO_OK; }
   HIP_TRY(c, hipSetDevice(c->cfg.device));
-  HIP_TRY(c, wait_event(c->ev_solve));
+  {
+    const double tw0 = diag_now_us();
+    HIP_TRY(c, wait_event(c->ev_solve));
+    g_diag.max_solve_wait = std::max(g_diag.max_solve_wait, diag_now_us() - tw0);
+  }
   std::memcpy(xyz, c->h_solve_o, (size_t)3 * n * 4);
   if (n < 4) { prior_pose(); return SPVO_OK; }                                      // no model possible: prior is kept
   const double *res = c->h_solve_res, *gate = res + 8, *ref = res + 24;

@@ -117,6 +117,13 @@ void FeatureFrontEnd::preprocessImageImpl(cv::Mat &img, cv::Mat &projection_matr
 
 // ------------------------------------------------------------------------- base.cpp:35-66
 void FeatureFrontEnd::clearLagecyData() {
+  if (solve_pending_ && ctx_) {   // a solve handed over and never collected: complete it, its result is dropped with the rest
+    spvo_solve_output so;
+    std::vector<float> xyz((size_t)std::max(solve_n_, 1) * 3);
+    std::vector<int32_t> inl(std::max(solve_n_, 1));
+    (void)spvo_solve_wait(ctx_, &so, xyz.data(), inl.data());
+  }
+  solve_pending_ = false;
   images_dq.clear();
   keypoints_dq.clear();
   descriptors_dq.clear();
@@ -206,13 +213,24 @@ void FeatureFrontEnd::matchDescriptors(const MatchType match_type) {
 static double host_now_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
 
 void FeatureFrontEnd::solveStereoOdometry(tf2::Transform &cam0_curr_T_cam0_prev) {
+  if (solveStereoOdometrySubmit()) solveStereoOdometryCollect(cam0_curr_T_cam0_prev);
+}
+
+// First half (extension): the correspondence join (base.cpp:127-207) and the hand-over of the numeric part to spvo_solve_submit.
+// Nothing of the front end's state changes here except the per-frame maps of the join; the result is taken by
+// solveStereoOdometryCollect, which has to run before the next frame's join (that one needs this frame's points and prior).
+bool FeatureFrontEnd::solveStereoOdometrySubmit() {
   static const bool timing = std::getenv("SPVO_SOLVE_TIMING") != nullptr;   // diagnostic
   static double acc[3] = {0, 0, 0};
   static long calls = 0;
   const double th0 = timing ? host_now_us() : 0;
+  if (solve_pending_) {
+    logError("solveStereoOdometrySubmit: the previous solve has not been collected");
+    return false;
+  }
   if (keypoints_dq.size() < 4 || !ensureContext()) {
     logError("solveStereoOdometry needs two stereo frames");
-    return;
+    return false;
   }
   const std::vector<cv::DMatch> &stereo = cv_DMatches_list[CURR_LEFT_CURR_RIGHT];
   const size_t num_curr_stereo = stereo.size();
@@ -233,13 +251,13 @@ void FeatureFrontEnd::solveStereoOdometry(tf2::Transform &cam0_curr_T_cam0_prev)
   // the reference indexes with .at(): out-of-range would throw there; here it is reported
   for (const auto &m : stereo) {
     const int i_cl = m.queryIdx;
-    if (i_cl >= (int)map_temporal.size()) { logError("maps_of_indices out of range"); return; }
+    if (i_cl >= (int)map_temporal.size()) { logError("maps_of_indices out of range"); return false; }
     if (map_temporal[i_cl] == -1) continue;
     const cv::Point2f &a = keypoints_dq.end()[CURR_LEFT][i_cl].pt;
     const cv::Point2f &b = keypoints_dq.end()[CURR_RIGHT][m.trainIdx].pt;
     if (std::abs(a.y - b.y) > stereo_threshold_ || std::abs(a.x - b.x) < min_disparity_) continue;  // base.cpp:169-172
     const int i_pl = map_temporal[i_cl];
-    if (i_pl >= (int)map_prev.size()) { logError("maps_of_indices out of range"); return; }
+    if (i_pl >= (int)map_prev.size()) { logError("maps_of_indices out of range"); return false; }
     if (map_prev[i_pl] == -1) continue;
     const cv::Point2f &c = keypoints_dq.end()[PREV_LEFT][i_pl].pt;
     const cv::Point2f &d = keypoints_dq.end()[PREV_RIGHT][map_prev[i_pl]].pt;
@@ -259,8 +277,9 @@ void FeatureFrontEnd::solveStereoOdometry(tf2::Transform &cam0_curr_T_cam0_prev)
   // triangulation (base.cpp:211-223), PnP-RANSAC (227-239), gating (241-272), residual blocks
   // (291-356), refinement and the "not converged => keep RANSAC" rule (358-375)
   const double *Pl = projection_matrix_l_.ptr<double>(0), *Pr = projection_matrix_r_.ptr<double>(0);
-  std::vector<float> pts3d((size_t)std::max(n, 1) * 3, 0.f), prev_xyz;
+  std::vector<float> prev_xyz;
   std::vector<int32_t> prev_valid;
+  solve_pts3d_.assign((size_t)std::max(n, 1) * 3, 0.f);
   if (refinement_degree_ >= 3 && prev_left_points_3d_inited) {  // base.cpp:323-332
     prev_xyz.assign((size_t)std::max(n, 1) * 3, 0.f);
     prev_valid.assign(std::max(n, 1), 0);
@@ -285,14 +304,40 @@ void FeatureFrontEnd::solveStereoOdometry(tf2::Transform &cam0_curr_T_cam0_prev)
   si.refinement_degree = refinement_degree_;
   si.ransac = spvo_ransac_opts{500, 2.0, 0.999, ransac_seed};   // base.cpp:239
   si.refine = spvo_refine_opts{40, 1.0};                        // base.cpp:286, 362
-  spvo_solve_output so;
   inliers_pnp.assign(std::max(n, 1), 0);
   const double th1 = timing ? host_now_us() : 0;
-  const int solve_rc = spvo_solve_stereo_odometry(ctx_, &si, &so, pts3d.data(), inliers_pnp.data());
-  const double th2 = timing ? host_now_us() : 0;
+  const int solve_rc = spvo_solve_submit(ctx_, &si);   // the inputs are staged: the vectors above may go
   if (solve_rc != SPVO_OK) {
-    logError(std::string("spvo_solve_stereo_odometry: ") + spvo_last_error(ctx_));
-    return;
+    logError(std::string("spvo_solve_submit: ") + spvo_last_error(ctx_));
+    return false;
+  }
+  solve_pending_ = true;
+  solve_n_ = n;
+  if (timing) {
+    const double th2 = host_now_us();
+    acc[0] += th1 - th0; acc[1] += th2 - th1;
+    if (++calls % 200 == 0) {
+      std::fprintf(stderr, "[host solve timing] join %.1f us, submit %.1f us\n", acc[0] / 200, acc[1] / 200);
+      acc[0] = acc[1] = 0;
+    }
+  }
+  return true;
+}
+
+// Second half (extension): waits for the solve, then base.cpp:241-272 (prior update), 377-396 (output, state roll)
+bool FeatureFrontEnd::solveStereoOdometryCollect(tf2::Transform &cam0_curr_T_cam0_prev) {
+  if (!solve_pending_) {
+    logError("solveStereoOdometryCollect: no solve pending");
+    return false;
+  }
+  solve_pending_ = false;
+  const int n = solve_n_;
+  std::vector<float> &pts3d = solve_pts3d_;
+  spvo_solve_output so;
+  const int solve_rc = spvo_solve_wait(ctx_, &so, pts3d.data(), inliers_pnp.data());
+  if (solve_rc != SPVO_OK) {
+    logError(std::string("spvo_solve_wait: ") + spvo_last_error(ctx_));
+    return false;
   }
   inliers_pnp.resize(so.n_inliers);
   last_pnp_ok_ = so.pnp_ok != 0; last_accepted_ = so.accepted != 0; last_refined_ = so.refined != 0; last_lm_iterations_ = so.summary.iterations;
@@ -314,14 +359,7 @@ void FeatureFrontEnd::solveStereoOdometry(tf2::Transform &cam0_curr_T_cam0_prev)
     prev_left_points_3d_inited = true;
   }
   ++frame_count;
-  if (timing) {
-    const double th3 = host_now_us();
-    acc[0] += th1 - th0; acc[1] += th2 - th1; acc[2] += th3 - th2;
-    if (++calls % 200 == 0) {
-      std::fprintf(stderr, "[host solve timing] join %.1f us, C ABI call %.1f us, after %.1f us\n", acc[0] / 200, acc[1] / 200, acc[2] / 200);
-      acc[0] = acc[1] = acc[2] = 0;
-    }
-  }
+  return true;
 }
 
 cv::Mat FeatureFrontEnd::visualizeMatches(const MatchType match_type) {
@@ -562,7 +600,7 @@ void SuperPointFeatureFrontEnd::addStereoImagePair(cv::Mat &img_l, cv::Mat &img_
 }
 
 void SuperPointFeatureFrontEnd::prefetchStereoImagePair(const cv::Mat &img_l, const cv::Mat &img_r) {
-  if (!engine_loaded_ || prefetch_q_.size() >= 2) return;
+  if (!engine_loaded_ || prefetch_q_.size() >= 3) return;
   if (img_l.type() != CV_8UC1 || img_r.type() != CV_8UC1 || img_l.rows != img_r.rows || img_l.cols != img_r.cols || (size_t)img_l.step != (size_t)img_r.step) return;
   for (const auto &q : prefetch_q_)   // already announced
     if (q.host && q.l == img_l.data && q.r == img_r.data && q.rows == img_l.rows && q.cols == img_l.cols) return;
@@ -623,7 +661,7 @@ void SuperPointFeatureFrontEnd::addStereoImagePairDevice(const void *d_img_l, co
 }
 
 void SuperPointFeatureFrontEnd::prefetchStereoImagePairDevice(const void *d_img_l, const void *d_img_r, int rows, int cols, size_t stride) {
-  if (!engine_loaded_ || prefetch_q_.size() >= 2) return;
+  if (!engine_loaded_ || prefetch_q_.size() >= 3) return;
   for (const auto &q : prefetch_q_)   // already announced
     if (!q.host && q.l == d_img_l && q.r == d_img_r && q.rows == rows && q.cols == cols && q.stride == stride) return;
   Prefetch pf;
@@ -646,10 +684,10 @@ void SuperPointFeatureFrontEnd::drainPrefetch() {
 }
 
 void SuperPointFeatureFrontEnd::pickSlots(int *slot_l, int *slot_r) {
-  // device slots: a ring of 4 pairs -- the previous and the current pair plus up to two pairs in flight
+  // device slots: a ring of 5 pairs -- the previous and the current pair plus up to three pairs in flight
   *slot_l = 2 * next_pair_;
   *slot_r = *slot_l + 1;
-  next_pair_ = (next_pair_ + 1) % 4;
+  next_pair_ = (next_pair_ + 1) % 5;
 }
 
 void SuperPointFeatureFrontEnd::pushFeatures(const spvo_features *f[2], const cv::Mat *images[2], const int slots[2], bool host_descriptors) {

@@ -201,6 +201,12 @@ public:
                                   const cv::Mat &projection_matrix_r) = 0;
   void matchDescriptors(const MatchType match_type);
   void solveStereoOdometry(tf2::Transform &cam0_curr_T_cam0_prev);
+  // Extension: the same call in two halves (spvo_solve_submit / spvo_solve_wait).  A caller that collects the pose of frame k
+  // after it has handed frame k+1's images over keeps the solver off its critical path; results are those of the one-piece
+  // call.  Collect before the next frame's submit (the join needs this frame's points and motion prior).
+  bool solveStereoOdometrySubmit();
+  bool solveStereoOdometryCollect(tf2::Transform &cam0_curr_T_cam0_prev);
+  bool solvePending() const { return solve_pending_; }
   // Drawing only (base.cpp:401-432, 502-553): out of the hot-path scope; they return the
   // stored image untouched so that the node's publish calls keep working.
   cv::Mat visualizeMatches(const MatchType match_type);
@@ -245,6 +251,9 @@ protected:
   // replaces cv::Ptr<cv::DescriptorMatcher> matcher_: for NORM_L2 descriptors the matcher lives behind the C ABI
   bool matcher_ready_ = false;
   bool matcher_cross_check_ = false;
+  bool solve_pending_ = false;     // solveStereoOdometrySubmit .. Collect
+  int solve_n_ = 0;
+  std::vector<float> solve_pts3d_;
   bool matcher_hamming_ = false;   // NORM_HAMMING descriptors of the classic front end (base.cpp:13-28): spvo_match_hamming
   // creates ctx_ without an engine: preprocessImageImpl and solveStereoOdometry of a front end that has no network
   bool ensureContext();
@@ -380,7 +389,7 @@ private:
     bool host = false;
   };
   std::deque<Prefetch> prefetch_q_;   // pairs announced ahead (at most 2), oldest first
-  int next_pair_ = 0;                 // ring of 4 slot pairs: previous, current and two in flight
+  int next_pair_ = 0;                 // ring of 5 slot pairs: previous, current and three in flight
   void drainPrefetch();
   void pickSlots(int *slot_l, int *slot_r);
   void pushFeatures(const spvo_features *f[2], const cv::Mat *images[2], const int slots[2], bool host_descriptors);

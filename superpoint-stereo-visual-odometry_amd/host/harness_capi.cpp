@@ -82,6 +82,17 @@ void spvo_host_solve(void *h, double *q, double *t) {
   t[0] = T.getOrigin().x(); t[1] = T.getOrigin().y(); t[2] = T.getOrigin().z();
 }
 
+// the two halves of spvo_host_solve (solveStereoOdometrySubmit / Collect); both return 1 on success
+int spvo_host_solve_submit(void *h) { return static_cast<SuperPointFeatureFrontEnd *>(h)->solveStereoOdometrySubmit() ? 1 : 0; }
+int spvo_host_solve_collect(void *h, double *q, double *t) {
+  tf2::Transform T;
+  if (!static_cast<SuperPointFeatureFrontEnd *>(h)->solveStereoOdometryCollect(T)) return 0;
+  q[0] = T.getRotation().x(); q[1] = T.getRotation().y(); q[2] = T.getRotation().z(); q[3] = T.getRotation().w();
+  t[0] = T.getOrigin().x(); t[1] = T.getOrigin().y(); t[2] = T.getOrigin().z();
+  return 1;
+}
+int spvo_host_solve_pending(void *h) { return static_cast<SuperPointFeatureFrontEnd *>(h)->solvePending() ? 1 : 0; }
+
 void spvo_host_clear(void *h) { static_cast<SuperPointFeatureFrontEnd *>(h)->clearLagecyData(); }
 
 int spvo_host_dq_size(void *h) { return (int)static_cast<SuperPointFeatureFrontEnd *>(h)->keypoints_dq.size(); }

@@ -53,6 +53,9 @@ def load():
         lib.spvo_host_match.restype = None
         lib.spvo_host_solve.argtypes = [vp, vp, vp]
         lib.spvo_host_solve.restype = None
+        lib.spvo_host_solve_submit.argtypes = [vp]
+        lib.spvo_host_solve_collect.argtypes = [vp, vp, vp]
+        lib.spvo_host_solve_pending.argtypes = [vp]
         lib.spvo_host_clear.argtypes = [vp]
         lib.spvo_host_clear.restype = None
         lib.spvo_host_keypoints.argtypes = [vp, C.c_int, vp, C.c_int]
@@ -156,20 +159,37 @@ class FrontEnd:
     def prefetch_device(self, d_l: int, d_r: int, rows: int, cols: int, stride: int):
         self.lib.spvo_host_prefetch_dev(self.h, C.c_void_p(d_l), C.c_void_p(d_r), rows, cols, stride)
 
-    def step_device(self, d_l, d_r, rows, cols, stride, P_l, P_r, next_pair=None, next2_pair=None):
+    def step_device(self, d_l, d_r, rows, cols, stride, P_l, P_r, next_pair=None, next2_pair=None, deferred_solve=False, next3_pair=None):
         """One stereoCallback on a device-resident pair; `next_pair` / `next2_pair` = (d_l, d_r) of the
         following two frames, handed over early: their detector runs while this frame is matched and
-        solved, and the post-processing of one overlaps with the network of the other."""
+        solved, and the post-processing of one overlaps with the network of the other.
+        deferred_solve: this frame's solve is only handed over (solveStereoOdometrySubmit); its pose is what the NEXT call -- or
+        finish_solve() -- returns, so the solver never keeps the host from handing the next images over."""
         self.add_stereo_image_pair_device(d_l, d_r, rows, cols, stride, P_l, P_r)
-        for nxt in (next_pair, next2_pair):
+        for nxt in (next_pair, next2_pair, next3_pair):
             if nxt is not None:
                 self.prefetch_device(nxt[0], nxt[1], rows, cols, stride)   # no-op if already announced
+        return self._match_and_solve(deferred_solve)
+
+    def _match_and_solve(self, deferred_solve):
         if self.dq_size() < 4:
             self.match_descriptors(CURR_LEFT_CURR_RIGHT)
             return None
         self.match_descriptors(CURR_LEFT_CURR_RIGHT)
         self.match_descriptors(CURR_LEFT_PREV_LEFT)
-        return self.solve_stereo_odometry()
+        if not deferred_solve:
+            return self.solve_stereo_odometry()
+        prev = self.finish_solve()                   # the previous frame's pose: its points and prior enter this frame's join
+        self.lib.spvo_host_solve_submit(self.h)
+        return prev
+
+    def finish_solve(self):
+        """Collects a deferred solve, if one is pending: (q, t) or None."""
+        if not self.lib.spvo_host_solve_pending(self.h):
+            return None
+        q = np.zeros(4)
+        t = np.zeros(3)
+        return (q, t) if self.lib.spvo_host_solve_collect(self.h, _p(q), _p(t)) else None
 
     # ---- host images as cv::Mat objects (what cv_bridge hands to the node): the reference's own entry point
     def make_image(self, img) -> int:
@@ -179,21 +199,16 @@ class FrontEnd:
     def free_image(self, handle: int):
         self.lib.spvo_host_free_image(C.c_void_p(handle))
 
-    def step_host(self, mat_l: int, mat_r: int, P_l, P_r, next_pair=None, next2_pair=None):
+    def step_host(self, mat_l: int, mat_r: int, P_l, P_r, next_pair=None, next2_pair=None, deferred_solve=False, next3_pair=None):
         """One stereoCallback through addStereoImagePair(cv::Mat&, ...) (node.cpp:175) on HOST images; `next_pair` /
         `next2_pair` = (mat_l, mat_r) handles of the following frames, announced with prefetchStereoImagePair."""
         Pl = np.ascontiguousarray(P_l, np.float64)
         Pr = np.ascontiguousarray(P_r, np.float64)
         self.lib.spvo_host_add_stereo_pair_mat(self.h, C.c_void_p(mat_l), C.c_void_p(mat_r), _p(Pl), _p(Pr))
-        for nxt in (next_pair, next2_pair):
+        for nxt in (next_pair, next2_pair, next3_pair):
             if nxt is not None:
                 self.lib.spvo_host_prefetch_mat(self.h, C.c_void_p(nxt[0]), C.c_void_p(nxt[1]))
-        if self.dq_size() < 4:
-            self.match_descriptors(CURR_LEFT_CURR_RIGHT)
-            return None
-        self.match_descriptors(CURR_LEFT_CURR_RIGHT)
-        self.match_descriptors(CURR_LEFT_PREV_LEFT)
-        return self.solve_stereo_odometry()
+        return self._match_and_solve(deferred_solve)
 
     def match_descriptors(self, match_type):
         self.lib.spvo_host_match(self.h, match_type)

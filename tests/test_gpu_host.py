@@ -270,3 +270,34 @@ def test_classic_front_end_matches_binary_descriptors_on_the_gpu(knn, cross):
         ref, _ = matching.bf_match_hamming(sets[qa], sets[tb], "KNN" if knn else "NN", bool(cross))
         assert n == len(ref) and np.array_equal(out, ref)
         assert (ref >= 0).sum() > 300
+
+
+def test_deferred_solve_gives_the_same_poses_one_step_later(models_dir, sequence):
+    """solveStereoOdometrySubmit / Collect (the solve handed over, its pose collected during the next step) against the one-piece
+    solveStereoOdometry on the same sequence: identical poses and state, delivered one call later."""
+    import torch
+    frames, _, P_l, P_r = sequence
+    outs = {}
+    for deferred in (False, True):
+        fe = host.FrontEnd(models_dir, prefix="sp_squeeze", selector="KNN", cross_check=True)
+        assert fe.engine_loaded, fe.last_error
+        dev = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
+        torch.cuda.synchronize()
+        poses = []
+        for k, (L, R) in enumerate(dev):
+            nxt = (dev[k + 1][0].data_ptr(), dev[k + 1][1].data_ptr()) if k + 1 < len(dev) else None
+            r = fe.step_device(L.data_ptr(), R.data_ptr(), L.shape[0], L.shape[1], L.stride(0), P_l, P_r, nxt, None, deferred_solve=deferred)
+            if r is not None:
+                poses.append((r[0].copy(), r[1].copy()))
+        last = fe.finish_solve()
+        if deferred:
+            assert last is not None
+            poses.append((last[0].copy(), last[1].copy()))
+        else:
+            assert last is None
+        outs[deferred] = (poses, fe.frame_count())
+        fe.close()
+    n = len(frames) - 1
+    assert len(outs[False][0]) == len(outs[True][0]) == n and outs[False][1] == outs[True][1] == n
+    for (qa, ta), (qb, tb) in zip(outs[False][0], outs[True][0]):
+        assert np.array_equal(qa, qb) and np.array_equal(ta, tb)

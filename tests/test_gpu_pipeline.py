@@ -143,8 +143,8 @@ def test_prematch_is_transparent(ctx_squeeze, stereo_pair):
     assert (res[True][1][0] >= 0).sum() > 300                            # temporal matches exist
 
 
-def test_two_submissions_in_flight(ctx_squeeze, stereo_pair):
-    """spvo_detect_dev_submit x2 / spvo_detect_wait x2 through the C ABI: same keypoints and matches as the
+def test_submissions_in_flight(ctx_squeeze, stereo_pair):
+    """spvo_detect_dev_submit x3 / spvo_detect_wait x3 through the C ABI: same keypoints and matches as the
     synchronous calls, oldest-first completion, and the documented SPVO_ERR_STATE refusals."""
     import torch
     from spvo import capi
@@ -161,8 +161,9 @@ def test_two_submissions_in_flight(ctx_squeeze, stereo_pair):
     assert e.value.code == -4
     ctx_squeeze.detect_dev_submit(*args(0), 4, 5)
     ctx_squeeze.detect_dev_submit(*args(1), 6, 7)
+    ctx_squeeze.detect_dev_submit(*args(0), 8, 9)                             # a third one: the limit
     with pytest.raises(capi.SpvoError) as e:
-        ctx_squeeze.detect_dev_submit(*args(0), 0, 1)                         # a third one
+        ctx_squeeze.detect_dev_submit(*args(1), 0, 1)                         # a fourth one
     assert e.value.code == -4
     with pytest.raises(capi.SpvoError) as e:
         ctx_squeeze.forward(np.zeros((1, 1, 360, 1176), np.float32))          # would overwrite the activations
@@ -172,6 +173,8 @@ def test_two_submissions_in_flight(ctx_squeeze, stereo_pair):
         ctx_squeeze.detect_dev_submit(*args(0), 6, 7)                         # slots of the submission still in flight
     assert e.value.code == -4
     b = ctx_squeeze.detect_wait(P_l, P_r)
+    c3 = ctx_squeeze.detect_wait(P_l, P_r)
+    assert np.array_equal(c3["xy_l"], ref[0]["xy_l"]) and np.array_equal(c3["xy_r"], ref[0]["xy_r"])
     for got, want in ((a, ref[0]), (b, ref[1])):
         assert np.array_equal(got["xy_l"], want["xy_l"]) and np.array_equal(got["xy_r"], want["xy_r"])
         assert np.array_equal(got["P_l"], want["P_l"])
