@@ -97,6 +97,7 @@ def test_detect_in_fp32_split_mode_matches_oracle(vgg_weights_path, vgg_plan, st
 
 
 @pytest.mark.parametrize("env", [{"SPVO_WINOGRAD": "0"}, {"SPVO_WINO2": "0"}, {"SPVO_HEADS_ON_TAIL": "0"}, {"SPVO_MERGE_SIBLINGS": "0"},
+                                 {"SPVO_WINO_NARROW": "0"}, {"SPVO_WINO_DYNAMIC": "0"},
                                  {"SPVO_WINOGRAD": "0", "SPVO_HEADS_ON_TAIL": "0", "SPVO_MERGE_SIBLINGS": "0"}])
 def test_kernel_selection_switches_do_not_change_the_detector(vgg_weights_path, stereo_pair, env, monkeypatch):
     """The engine-load switches (direct instead of Winograd 3x3 kernels, heads on the network stream, head
@@ -107,7 +108,7 @@ def test_kernel_selection_switches_do_not_change_the_detector(vgg_weights_path, 
     L, R = frames[1]
     outs = []
     for e in ({}, env):
-        for k in ("SPVO_WINOGRAD", "SPVO_WINO2", "SPVO_HEADS_ON_TAIL", "SPVO_MERGE_SIBLINGS"):
+        for k in ("SPVO_WINOGRAD", "SPVO_WINO2", "SPVO_HEADS_ON_TAIL", "SPVO_MERGE_SIBLINGS", "SPVO_WINO_NARROW", "SPVO_WINO_DYNAMIC"):
             monkeypatch.delenv(k, raising=False)
         for k, v in e.items():
             monkeypatch.setenv(k, v)
