@@ -174,8 +174,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the informational second measurement (FP32 engine in split mode)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--no-pipeline", action="store_true", help="do not hand the next stereo pairs over early")
-    ap.add_argument("--deferred-solve", action="store_true", help="hand every frame's solve over and collect its pose during the next step "
-                                                                  "(solveStereoOdometrySubmit / Collect) instead of solving inside the step; measured: no change of the frame rate")
+    ap.add_argument("--sync-solve", action="store_true", help="solve inside the step (solveStereoOdometry in one piece) instead of handing every frame's solve over and "
+                                                              "collecting its pose during the next step (solveStereoOdometrySubmit / Collect: the default whenever pairs are handed over "
+                                                              "ahead; neutral on the fp32 headline, +20..40 %% where the host and the solver bound the step: FP16 / INT8 engines)")
     ap.add_argument("--net-size", default="360x1176", help="network input HxW: 360x1176 (the reference's, default = the headline workload) or 376x1240 (native, SURVEY.md section 8)")
     ap.add_argument("--precision", default="FP32", choices=["FP32", "FP16", "INT8"],
                     help="FP32 = the headline workload (BASELINE config 2); FP16 = the half-precision engine of config 3 (use with --net-size 192x640); "
@@ -276,7 +277,7 @@ def main():
     # shared-GPU test hook: RCCL refuses two ranks on one device, so the C ABI's file transport carries the poses there
     pg = posegather.PoseGather(torch.device("cpu") if shared else torch.device("cuda", local_rank), force=dist_on)
 
-    deferred = args.deferred_solve and not args.no_pipeline
+    deferred = not (args.no_pipeline or args.sync_solve)
 
     def step(i, order=order):
         dl, dr = d_frames[order[i % len(order)]]
