@@ -188,6 +188,25 @@ typedef enum { SPVO_SELECT_NN = 0, SPVO_SELECT_KNN = 1 } spvo_selector;
 int spvo_match(spvo_ctx *ctx, const float *desc_a, int na, const float *desc_b, int nb,
                int selector, int cross_check, float ratio, int32_t *train_idx, float *distance);
 
+/* ------------------------------------------------------- classic front end: ORB
+ * detectKeypoints + describeKeypoints of ClassicFeatureFrontEnd for DetectorType::ORB / DescriptorType::ORB
+ * (feature_detection_classic.cpp:12-25, 66-68: cv::ORB::create(2000, 1.2f, 8, 31, 0, 2, FAST_SCORE, 31, 20)) on one 8-bit
+ * image in host memory: 8-level pyramid, FAST-9 corners with non-maximum suppression, the best `nfeatures` split over the levels,
+ * intensity-centroid direction, 256-bit steered BRIEF on the smoothed level.  OpenCV is not available to this build: the algorithm
+ * is the published one as restated by oracle/cpu/orb_cpu.inc (its header lists the open choices and the one deviation, the
+ * test-pair table) and the kernels reproduce that restatement bit for bit.  Keypoints come level by level, best response first,
+ * in level-0 pixel coordinates; `n` receives their number (<= nfeatures), of which min(n, cap) are written. */
+typedef struct {
+  float x, y;        /* level-0 coordinates                                  */
+  float angle;       /* radians, atan2 of the patch's intensity centroid      */
+  float response;    /* FAST score                                            */
+  int32_t octave;    /* pyramid level                                         */
+} spvo_orb_keypoint;
+int spvo_orb_detect(spvo_ctx *ctx, const uint8_t *img, int rows, int cols, size_t stride, int nfeatures,
+                    spvo_orb_keypoint *keypoints, uint8_t *descriptors /* [cap][32] */, int cap, int *n);
+/* the tables the descriptor uses: 256 x (x1, y1, x2, y2) test pairs and the 7 smoothing taps (either may be NULL) */
+int spvo_orb_tables(float *pattern /* [1024] */, float *taps /* [7] */);
+
 /* The same for BINARY descriptors: cv::BFMatcher(NORM_HAMMING), what initMatcher (base.cpp:17-21) builds for the ORB / BRISK /
  * AKAZE descriptors of ClassicFeatureFrontEnd (classic.cpp:66-79) and matchDescriptors (base.cpp:434-500) runs on them.
  * Rows of `desc_bytes` bytes (ORB 32, BRISK 64, AKAZE 61; at most 64), distance = number of differing bits (exact), reported

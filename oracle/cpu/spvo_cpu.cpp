@@ -1070,6 +1070,14 @@ int spvo_cpu_orb(spvo_cpu *c, const uint8_t *img, int rows, int cols, size_t str
   return 0;
 }
 
+// the 256 test pairs (x1, y1, x2, y2) and the 7 smoothing taps: a second implementation has to use the same tables
+int spvo_cpu_orb_tables(float *pattern /* [1024] */, float *taps /* [7] */) {
+  orb::make_pattern();
+  if (pattern) std::memcpy(pattern, orb::g_pattern.data(), 1024 * sizeof(float));
+  if (taps) orb::gauss_taps(taps);
+  return 0;
+}
+
 static void frontend_match(spvo_cpu *c, int type) {   // base.cpp:434-491
   static const int pos[3][2] = {{-2, -1}, {-2, -4}, {-4, -3}};   // hpp:87-90
   const int nd = (int)c->kp_dq.size();

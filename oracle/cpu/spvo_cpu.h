@@ -70,6 +70,7 @@ int spvo_cpu_frontend_step(spvo_cpu *c, const uint8_t *img_l, const uint8_t *img
  * by Hamming distance and solve as above.  orb_cpu.inc says what is restated and the one thing that cannot be (OpenCV's learned test pairs). */
 int spvo_cpu_frontend_reset_classic(spvo_cpu *c, int selector, int cross_check, float stereo_threshold, int refinement_degree);
 /* ORB alone: xy [cap][2] (level-0 coordinates), angle_response_octave [cap][3], desc [cap][32]; *n = keypoints found */
+int spvo_cpu_orb_tables(float *pattern, float *taps);
 int spvo_cpu_orb(spvo_cpu *c, const uint8_t *img, int rows, int cols, size_t stride, float *xy, float *angle_response_octave, uint8_t *desc, int cap, int *n);
 /* introspection for the parity tests: maps_of_indices[match_type] of the last step */
 int spvo_cpu_frontend_map(spvo_cpu *c, int match_type, int32_t *out, int cap);

@@ -81,6 +81,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.spvo_cpu_frontend_map.argtypes = [vp, C.c_int, vp, C.c_int]
     lib.spvo_cpu_frontend_reset_classic.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_int]
     lib.spvo_cpu_orb.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, vp, vp, C.c_int, ip]
+    lib.spvo_cpu_orb_tables.argtypes = [vp, vp]
     return lib
 
 
@@ -222,6 +223,12 @@ class CpuBackend:
     def frontend_reset_classic(self, selector="KNN", cross_check=True, stereo_threshold=2.0, refinement_degree=4):
         """ClassicFeatureFrontEnd(ORB, ORB, BF, ...) of launch/visual_odometry_classic.launch on the CPU (BASELINE config 1)."""
         self._check(self.lib.spvo_cpu_frontend_reset_classic(self.h, 1 if selector == "KNN" else 0, int(cross_check), stereo_threshold, refinement_degree))
+
+    def orb_tables(self):
+        pat = np.zeros(1024, np.float32)
+        taps = np.zeros(7, np.float32)
+        self._check(self.lib.spvo_cpu_orb_tables(_p(pat), _p(taps)))
+        return pat, taps
 
     def orb(self, img, cap=4096):
         img = np.ascontiguousarray(img, np.uint8)

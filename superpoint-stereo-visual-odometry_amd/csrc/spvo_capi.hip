@@ -19,6 +19,7 @@
 #include "conv_mfma.hip.h"
 #include "match.hip.h"
 #include "odometry.hip.h"
+#include "orb.hip.h"
 #include "conv_f16.hip.h"
 #include "conv_bf16x3.hip.h"
 #include "conv_wino.hip.h"
@@ -204,6 +205,19 @@ struct spvo_ctx {
   RansacWork rw{};
   ObsDev *d_obs = nullptr;
   RefineOut *d_refine = nullptr;
+  // ORB detector / extractor of the classic front end (orb.hip.h): buffers grow on demand
+  struct OrbBufs {
+    size_t px_cap = 0;        // pixels of level 0 the image buffers are sized for
+    int kp_cap = 0;
+    uint8_t *im = nullptr, *score = nullptr, *blur = nullptr, *src = nullptr;   // im: all pyramid levels back to back
+    float *tmp = nullptr, *pattern = nullptr, *taps = nullptr;
+    unsigned long long *keys = nullptr;
+    int *rank = nullptr, *out_xy = nullptr, *counters = nullptr, *tab = nullptr;
+    signed char *disc = nullptr;
+    OrbKeypoint *kps = nullptr;
+    uint8_t *desc = nullptr;
+    size_t src_cap = 0;
+  } orb;
   // Hamming matcher (classic front end's binary descriptors): rows padded to 16 words
   int ham_cap = 0;
   uint32_t *d_ham_a = nullptr, *d_ham_b = nullptr;
@@ -1404,6 +1418,9 @@ void spvo_destroy(spvo_ctx *c) {
   for (void *hp : {(void *)c->h_solve_in, (void *)c->h_solve_res, (void *)c->h_solve_o}) if (hp) (void)hipHostFree(hp);
   for (void *dp : {(void *)c->d_solve_in, (void *)c->d_solve_res, (void *)c->d_solve_o, (void *)c->d_ctl}) if (dp) (void)hipFree(dp);
   for (void *dp : {(void *)c->d_ham_a, (void *)c->d_ham_b, (void *)c->d_ham_idx, (void *)c->d_ham_dist, (void *)c->d_ham_vote}) if (dp) (void)hipFree(dp);
+  for (void *dp : {(void *)c->orb.im, (void *)c->orb.score, (void *)c->orb.blur, (void *)c->orb.src, (void *)c->orb.tmp, (void *)c->orb.pattern, (void *)c->orb.taps, (void *)c->orb.keys,
+                   (void *)c->orb.rank, (void *)c->orb.out_xy, (void *)c->orb.counters, (void *)c->orb.tab, (void *)c->orb.disc, (void *)c->orb.kps, (void *)c->orb.desc})
+    if (dp) (void)hipFree(dp);
   for (auto hp : c->h_match_out) if (hp) (void)hipHostFree(hp);
   if (c->h_match_tmp) (void)hipHostFree(c->h_match_tmp);
   if (c->stream_t) (void)hipStreamDestroy(c->stream_t);
@@ -2315,6 +2332,156 @@ int spvo_match(spvo_ctx *c, const float *desc_a, int na, const float *desc_b, in
   if (na) HIP_TRY(c, hipMemcpyAsync(c->d_ma, desc_a, (size_t)na * MATCH_D * sizeof(float), hipMemcpyHostToDevice, c->post));
   if (nb) HIP_TRY(c, hipMemcpyAsync(c->d_mb, desc_b, (size_t)nb * MATCH_D * sizeof(float), hipMemcpyHostToDevice, c->post));
   return run_match(c, MatchReq{c->d_ma, c->d_mb, na, nb, nullptr, nullptr, nullptr, nullptr}, selector, cross_check ? 1 : 0, ratio, train_idx, distance);
+}
+
+// ---------------------------------------------------------------- ORB (classic front end, orb.hip.h)
+namespace {
+uint32_t host_hash32(uint32_t x) { x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16; return x; }
+// the 256 test pairs: isotropic Gaussian of the original BRIEF (sigma = patch / 5), fixed seed, rounded, kept inside the patch
+// (the same construction as oracle/cpu/orb_cpu.inc; tests/test_gpu_orb.py compares the two tables)
+void orb_host_tables(std::vector<float> &pattern, float taps[7], std::vector<signed char> &disc) {
+  constexpr int PATCH = 31, HALF = ORB_HALF;
+  pattern.resize(1024);
+  uint32_t state = 0x9E3779B9u;
+  auto uni = [&]() { state = host_hash32(state + 0x6D2B79F5u); return ((state >> 8) + 0.5f) / 16777216.0f; };
+  auto gauss = [&]() { const float u1 = uni(), u2 = uni(); return std::sqrt(-2.0f * std::log(u1)) * std::cos(6.2831853f * u2); };
+  for (int i = 0; i < 1024; ++i) {
+    float v = gauss() * (PATCH / 5.0f);
+    v = std::min(std::max(v, -(float)(HALF - 2)), (float)(HALF - 2));
+    pattern[i] = std::round(v);
+  }
+  float sum = 0;
+  for (int i = 0; i < 7; ++i) { taps[i] = std::exp(-0.5f * (i - 3) * (i - 3) / 4.0f); sum += taps[i]; }
+  for (int i = 0; i < 7; ++i) taps[i] /= sum;
+  disc.clear();
+  for (int dy = -HALF; dy <= HALF; ++dy) {
+    const int lim = (int)std::floor(std::sqrt((double)HALF * HALF - dy * dy));
+    for (int dx = -lim; dx <= lim; ++dx) { disc.push_back((signed char)dx); disc.push_back((signed char)dy); }
+  }
+}
+}  // namespace
+
+int spvo_orb_tables(float *pattern, float *taps) {
+  std::vector<float> p;
+  std::vector<signed char> d;
+  float t[7];
+  orb_host_tables(p, t, d);
+  if (pattern) std::memcpy(pattern, p.data(), 1024 * sizeof(float));
+  if (taps) std::memcpy(taps, t, sizeof t);
+  return SPVO_OK;
+}
+
+int spvo_orb_detect(spvo_ctx *c, const uint8_t *img, int rows, int cols, size_t stride, int nfeatures, spvo_orb_keypoint *kps, uint8_t *desc, int cap, int *n_out) {
+  if (!c || !img || !n_out || rows <= 0 || cols <= 0 || stride < (size_t)cols || nfeatures <= 0 || cap < 0 || (cap > 0 && (!kps || !desc)))
+    return fail(c, SPVO_ERR_INVALID, "bad argument");
+  static_assert(sizeof(spvo_orb_keypoint) == sizeof(OrbKeypoint), "keypoint records differ");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  *n_out = 0;
+  hipStream_t st = c->stream2;
+  auto &o = c->orb;
+  // ---- level geometry and per-level quota (the reference's parameters: 8 levels, scale 1.2)
+  constexpr float SCALE = 1.2f;
+  int ph[ORB_LEVELS], pw[ORB_LEVELS], want[ORB_LEVELS];
+  float lscale[ORB_LEVELS];
+  size_t off[ORB_LEVELS + 1];
+  {
+    float scale = 1.f;
+    const float f = 1.0f / SCALE;
+    float n_level = nfeatures * (1 - f) / (1 - std::pow(f, (float)ORB_LEVELS));
+    int assigned = 0;
+    off[0] = 0;
+    for (int l = 0; l < ORB_LEVELS; ++l, scale *= SCALE) {
+      ph[l] = (int)std::lround(rows / scale); pw[l] = (int)std::lround(cols / scale);
+      lscale[l] = scale;
+      want[l] = l == ORB_LEVELS - 1 ? std::max(nfeatures - assigned, 0) : (int)std::lround(n_level);
+      assigned += want[l];
+      n_level *= f;
+      off[l + 1] = off[l] + (((size_t)ph[l] * pw[l] + 255) & ~(size_t)255);
+    }
+  }
+  const size_t px0 = (size_t)rows * cols;
+  const int surv_cap = (rows / 2 + 1) * (cols / 2 + 1);   // 3x3 suppression: at most one survivor per 2x2 block
+  const int kp_cap = nfeatures;
+  if (px0 > o.px_cap || kp_cap > o.kp_cap) {
+    HIP_TRY(c, hipStreamSynchronize(st));
+    for (void *p : {(void *)o.im, (void *)o.score, (void *)o.blur, (void *)o.tmp, (void *)o.keys, (void *)o.rank, (void *)o.out_xy, (void *)o.counters, (void *)o.tab,
+                    (void *)o.kps, (void *)o.desc}) if (p) (void)hipFree(p);
+    o.im = o.score = o.blur = nullptr; o.tmp = nullptr; o.keys = nullptr; o.rank = o.out_xy = o.counters = o.tab = nullptr; o.kps = nullptr; o.desc = nullptr;
+    o.px_cap = 0; o.kp_cap = 0;
+    int rc;
+    if ((rc = dev_alloc(c, &o.im, off[ORB_LEVELS] + 256)) || (rc = dev_alloc(c, &o.score, px0)) || (rc = dev_alloc(c, &o.blur, px0)) || (rc = dev_alloc(c, &o.tmp, px0)) ||
+        (rc = dev_alloc(c, &o.keys, surv_cap)) || (rc = dev_alloc(c, &o.rank, surv_cap)) || (rc = dev_alloc(c, &o.out_xy, (size_t)2 * surv_cap)) ||
+        (rc = dev_alloc(c, &o.counters, NMS_COUNTER_INTS)) || (rc = dev_alloc(c, &o.tab, (size_t)3 * (rows + cols))) || (rc = dev_alloc(c, &o.kps, kp_cap)) ||
+        (rc = dev_alloc(c, &o.desc, (size_t)kp_cap * 32)))
+      return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // (dev_alloc clears on the network stream)
+    o.px_cap = px0; o.kp_cap = kp_cap;
+  }
+  if (!o.pattern) {
+    std::vector<float> pat;
+    std::vector<signed char> disc;
+    float taps[7];
+    orb_host_tables(pat, taps, disc);
+    int rc;
+    if ((rc = dev_alloc(c, &o.pattern, 1024)) || (rc = dev_alloc(c, &o.taps, 8)) || (rc = dev_alloc(c, &o.disc, disc.size()))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(o.pattern, pat.data(), 1024 * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(o.taps, taps, 7 * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(o.disc, disc.data(), disc.size(), hipMemcpyHostToDevice));
+  }
+  if ((size_t)rows * stride > o.src_cap) {
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (o.src) (void)hipFree(o.src);
+    o.src = nullptr; o.src_cap = 0;
+    int rc = dev_alloc(c, &o.src, (size_t)rows * stride, false);
+    if (rc) return rc;
+    o.src_cap = (size_t)rows * stride;
+  }
+  HIP_TRY(c, hipMemcpyAsync(o.src, img, (size_t)rows * stride, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpy2DAsync(o.im, cols, o.src, stride, cols, rows, hipMemcpyDeviceToDevice, st));   // level 0: the image, rows packed
+  NmsPair np;
+  np.b[0].state = nullptr; np.b[0].cand = nullptr; np.b[0].counters = o.counters; np.b[0].surv_key = o.keys; np.b[0].rank = o.rank; np.b[0].out_xy = o.out_xy;
+  np.b[1] = np.b[0];
+  int base = 0;
+  for (int l = 0; l < ORB_LEVELS; ++l) {
+    const int h = ph[l], w = pw[l];
+    uint8_t *im = o.im + off[l];
+    const dim3 grid((w + 63) / 64, (h + 3) / 4);
+    if (l > 0) {
+      std::vector<int> xi, xa0, xa1, yi, yb0, yb1, all;
+      linear_coeffs(w, pw[l - 1], xi, xa0, xa1);
+      linear_coeffs(h, ph[l - 1], yi, yb0, yb1);
+      for (auto *v : {&xi, &xa0, &xa1, &yi, &yb0, &yb1}) all.insert(all.end(), v->begin(), v->end());
+      HIP_TRY(c, hipMemcpyAsync(o.tab, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice, st));
+      HIP_TRY(c, hipStreamSynchronize(st));   // `all` is a stack-lifetime buffer (7 small copies per image)
+      hipLaunchKernelGGL(orb_resize_kernel, grid, dim3(256), 0, st, o.im + off[l - 1], ph[l - 1], pw[l - 1], pw[l - 1], im, h, w, o.tab);
+    }
+    if (h <= 2 * ORB_EDGE + 2 || w <= 2 * ORB_EDGE + 2 || want[l] <= 0) continue;
+    const int lcap = std::min(surv_cap, (h / 2 + 1) * (w / 2 + 1));
+    HIP_TRY(c, hipMemsetAsync(o.counters, 0, NMS_COUNTER_INTS * sizeof(int), st));
+    hipLaunchKernelGGL(orb_fast_kernel, grid, dim3(256), 0, st, im, h, w, ORB_FAST_T, o.score);
+    hipLaunchKernelGGL(orb_collect_kernel, grid, dim3(256), 0, st, o.score, h, w, o.keys, o.counters, lcap);
+    hipLaunchKernelGGL(nms_rank_kernel, dim3((lcap + 255) / 256, (lcap + RANK_TILE - 1) / RANK_TILE, 1), dim3(256), 0, st, lcap, np);
+    hipLaunchKernelGGL(nms_write_kernel, dim3((lcap + 255) / 256, 1), dim3(256), 0, st, h, want[l], lcap, np, (int *)nullptr);
+    hipLaunchKernelGGL(orb_blur_h_kernel, grid, dim3(256), 0, st, im, h, w, o.taps, o.tmp);
+    hipLaunchKernelGGL(orb_blur_v_kernel, grid, dim3(256), 0, st, o.tmp, h, w, o.taps, o.blur);
+    hipLaunchKernelGGL(orb_describe_kernel, dim3((want[l] + 3) / 4), dim3(256), 0, st, im, o.blur, o.score, h, w, o.out_xy, o.counters, o.disc, o.pattern, lscale[l], l,
+                       o.kps, o.desc, base, kp_cap);
+    HIP_TRY(c, hipGetLastError());
+    int cnt[4];
+    HIP_TRY(c, hipMemcpyAsync(cnt, o.counters, sizeof cnt, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (cnt[3]) return fail(c, SPVO_ERR_CAPACITY, "ORB: corner buffer overflow at level %d", l);
+    base += std::min(cnt[2], kp_cap - base);
+  }
+  *n_out = base;
+  const int ncopy = std::min(base, cap);
+  if (ncopy > 0) {
+    HIP_TRY(c, hipMemcpyAsync(kps, o.kps, (size_t)ncopy * sizeof(OrbKeypoint), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(desc, o.desc, (size_t)ncopy * 32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+  }
+  return SPVO_OK;
 }
 
 // cv::BFMatcher(NORM_HAMMING): binary descriptors of `desc_bytes` bytes per row (ORB 32, BRISK 64, AKAZE 61), see match.hip.h K12h

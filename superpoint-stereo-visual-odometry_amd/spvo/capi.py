@@ -59,7 +59,7 @@ SYMBOLS = [
     "spvo_default_config", "spvo_create", "spvo_destroy", "spvo_last_error", "spvo_load_weights", "spvo_engine_precision", "spvo_set_fp32_split",
     "spvo_preprocess", "spvo_forward", "spvo_debug_tensor", "spvo_heatmap", "spvo_nms",
     "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_detect_dev_submit", "spvo_detect_wait", "spvo_detect_submit", "spvo_detect_collect", "spvo_match", "spvo_match_slots", "spvo_set_prematch", "spvo_set_match_fp8",
-    "spvo_match_hamming", "spvo_triangulate", "spvo_pnp_ransac", "spvo_pnp_refine", "spvo_solve_stereo_odometry", "spvo_solve_submit", "spvo_solve_wait", "spvo_stream", "spvo_synchronize",
+    "spvo_match_hamming", "spvo_orb_detect", "spvo_orb_tables", "spvo_triangulate", "spvo_pnp_ransac", "spvo_pnp_refine", "spvo_solve_stereo_odometry", "spvo_solve_submit", "spvo_solve_wait", "spvo_stream", "spvo_synchronize",
     "spvo_profile_enable", "spvo_profile_reset", "spvo_profile_only", "spvo_profile_count", "spvo_profile_get",
     "spvo_comm_unique_id", "spvo_comm_create", "spvo_comm_create_host", "spvo_comm_rank", "spvo_comm_world", "spvo_comm_destroy",
     "spvo_pose_allgather", "spvo_pose_allgather_n",
@@ -102,6 +102,8 @@ def load() -> C.CDLL:
     lib.spvo_match.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
     lib.spvo_match_slots.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
     lib.spvo_match_hamming.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
+    lib.spvo_orb_detect.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_int, vp, vp, C.c_int, ip]
+    lib.spvo_orb_tables.argtypes = [vp, vp]
     lib.spvo_set_prematch.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float]
     lib.spvo_triangulate.argtypes = [vp, dp, dp, vp, vp, C.c_int, vp]
     lib.spvo_pnp_ransac.argtypes = [vp, dp, vp, vp, C.c_int, C.POINTER(RansacOpts), dp, dp, vp, ip, ip]
@@ -309,6 +311,22 @@ class Context:
         fr, xyr, _ = self._features(False)
         self._check(self.lib.spvo_detect_wait(self.h, _dptr(Pl), _dptr(Pr), C.byref(fl), C.byref(fr)))
         return dict(xy_l=xyl[:fl.n], xy_r=xyr[:fr.n], P_l=Pl.reshape(3, 4), P_r=Pr.reshape(3, 4))
+
+    def orb(self, img: np.ndarray, nfeatures=2000):
+        """ORB keypoints + descriptors of one u8 image (spvo_orb_detect): dict of xy [n,2], angle, response, octave, desc [n,32]."""
+        img = np.ascontiguousarray(img, np.uint8)
+        kp = np.zeros((nfeatures, 5), np.float32)          # x, y, angle, response, octave (int32 bits)
+        desc = np.zeros((nfeatures, 32), np.uint8)
+        n = C.c_int(0)
+        self._check(self.lib.spvo_orb_detect(self.h, _ptr(img), img.shape[0], img.shape[1], img.strides[0], nfeatures, _ptr(kp), _ptr(desc), nfeatures, C.byref(n)))
+        k = min(n.value, nfeatures)
+        return dict(xy=kp[:k, :2].copy(), angle=kp[:k, 2].copy(), response=kp[:k, 3].copy(), octave=kp[:k, 4].copy().view(np.int32), desc=desc[:k].copy())
+
+    def orb_tables(self):
+        pat = np.zeros(1024, np.float32)
+        taps = np.zeros(7, np.float32)
+        self._check(self.lib.spvo_orb_tables(_ptr(pat), _ptr(taps)))
+        return pat, taps
 
     def match_hamming(self, a: np.ndarray, b: np.ndarray, selector="KNN", cross_check=False, ratio=0.8):
         """cv::BFMatcher(NORM_HAMMING) on u8 descriptor rows (spvo_match_hamming)."""
