@@ -454,14 +454,91 @@ void ClassicFeatureFrontEnd::addStereoImagePair(cv::Mat &img_l, cv::Mat &img_r, 
   }
 }
 #else
-bool ClassicFeatureFrontEnd::available() { return false; }
-void ClassicFeatureFrontEnd::initDetector() {}
-void ClassicFeatureFrontEnd::initDescriptor() {}
-std::vector<cv::KeyPoint> ClassicFeatureFrontEnd::detectKeypoints(const cv::Mat &) { return {}; }
-cv::Mat ClassicFeatureFrontEnd::describeKeypoints(std::vector<cv::KeyPoint> &, const cv::Mat &) { return cv::Mat(); }
-void ClassicFeatureFrontEnd::addStereoImagePair(cv::Mat &, cv::Mat &, const cv::Mat &, const cv::Mat &) {
-  logError("ClassicFeatureFrontEnd: the classic detectors (ORB, BRISK, AKAZE, SIFT, FAST, ShiTomasi; classic.cpp:7-79) are OpenCV "
-           "features2d calls -- this library was built without SPVO_USE_OPENCV, the CPU baseline cannot run");
+// Without OpenCV: ORB + ORB (the reference's baseline configuration, launch/visual_odometry_classic.launch) runs on the GPU
+// through spvo_orb_detect -- detection and description are one pass there, so detectKeypoints keeps the descriptors for the
+// describeKeypoints call that follows on the same image; the other detector / descriptor types are OpenCV features2d calls and
+// stay unavailable.
+bool ClassicFeatureFrontEnd::available() { return true; }
+void ClassicFeatureFrontEnd::initDetector() {
+  if (detector_type_ != DetectorType::ORB) logError("[initDetector] only ORB runs without OpenCV (build with SPVO_USE_OPENCV for the other detectors of classic.cpp:7-56)");
+}
+void ClassicFeatureFrontEnd::initDescriptor() {
+  if (descriptor_type_ != DescriptorType::ORB) logError("[initDescriptor] only ORB runs without OpenCV (build with SPVO_USE_OPENCV for the other descriptors of classic.cpp:58-79)");
+}
+
+std::vector<cv::KeyPoint> ClassicFeatureFrontEnd::detectKeypoints(const cv::Mat &img) {
+  std::vector<cv::KeyPoint> keypoints;
+  orb_desc_ = cv::Mat();
+  if (detector_type_ != DetectorType::ORB || descriptor_type_ != DescriptorType::ORB) {
+    logError("ClassicFeatureFrontEnd: this detector / descriptor pair is an OpenCV features2d call (classic.cpp:7-79) -- built without SPVO_USE_OPENCV, only ORB + ORB runs");
+    return keypoints;
+  }
+  if (!ensureContext()) return keypoints;
+  if (img.depth() != CV_8U || img.rows <= 0) {
+    logError("detectKeypoints: 8-bit single-channel image expected");
+    return keypoints;
+  }
+  constexpr int NFEATURES = 2000;   // classic.cpp:13
+  std::vector<spvo_orb_keypoint> kp(NFEATURES);
+  cv::Mat desc(NFEATURES, 32, CV_8UC1);
+  int n = 0;
+  if (spvo_orb_detect(ctx_, img.ptr<uint8_t>(0), img.rows, img.cols, (size_t)img.step, NFEATURES, kp.data(), desc.ptr<uint8_t>(0), NFEATURES, &n) != SPVO_OK) {
+    logError(std::string("spvo_orb_detect: ") + spvo_last_error(ctx_));
+    return keypoints;
+  }
+  keypoints.reserve(n);
+  float level_scale[8];
+  level_scale[0] = 1.f;
+  for (int l = 1; l < 8; ++l) level_scale[l] = level_scale[l - 1] * 1.2f;
+  for (int i = 0; i < n; ++i) {
+    cv::KeyPoint k(cv::Point2f(kp[i].x, kp[i].y), 31.f * level_scale[kp[i].octave & 7]);
+    k.angle = kp[i].angle * 57.29577951308232f;   // cv::KeyPoint::angle is in degrees
+    if (k.angle < 0) k.angle += 360.f;
+    k.response = kp[i].response;
+    k.octave = kp[i].octave;
+    keypoints.push_back(k);
+  }
+  orb_desc_ = cv::Mat(n, 32, CV_8UC1);
+  if (n) std::memcpy(orb_desc_.ptr<uint8_t>(0), desc.ptr<uint8_t>(0), (size_t)n * 32);
+  return keypoints;
+}
+
+cv::Mat ClassicFeatureFrontEnd::describeKeypoints(std::vector<cv::KeyPoint> &keypoints, const cv::Mat &) {
+  if (orb_desc_.rows != (int)keypoints.size()) {
+    logError("describeKeypoints: call detectKeypoints on the same image first (ORB detects and describes in one pass here)");
+    return cv::Mat();
+  }
+  return orb_desc_;
+}
+
+void ClassicFeatureFrontEnd::addStereoImagePair(cv::Mat &img_l, cv::Mat &img_r, const cv::Mat &projection_matrix_l, const cv::Mat &projection_matrix_r) {
+  if (img_l.rows != img_r.rows || img_l.cols != img_r.cols) {
+    logError("input images shape doesn't match!");
+    return;
+  }
+  if (detector_type_ != DetectorType::ORB || descriptor_type_ != DescriptorType::ORB) {
+    logError("ClassicFeatureFrontEnd: this detector / descriptor pair is an OpenCV features2d call (classic.cpp:7-79) -- built without SPVO_USE_OPENCV, only ORB + ORB runs");
+    return;
+  }
+  if (!ensureContext()) return;   // no device: logged, nothing pushed (nn.cpp:53-55 convention)
+  projection_matrix_l_ = projection_matrix_l.clone();
+  projection_matrix_r_ = projection_matrix_r.clone();
+  if (input_height_ > 0 && input_width_ > 0) {   // 0 = native resolution (launch/visual_odometry_classic.launch)
+    preprocessImageImpl(img_l, projection_matrix_l_);
+    preprocessImageImpl(img_r, projection_matrix_r_);
+  }
+  cv::Mat *imgs[2] = {&img_l, &img_r};
+  for (cv::Mat *im : imgs) {
+    images_dq.push_back(*im);
+    keypoints_dq.push_back(detectKeypoints(*im));
+    descriptors_dq.push_back(describeKeypoints(keypoints_dq.back(), *im));
+  }
+  if (verbose_) logInfo(std::to_string(keypoints_dq.end()[-2].size()) + ", " + std::to_string(keypoints_dq.end()[-1].size()) + " keypoints for img_l and img_r");
+  while (images_dq.size() > NUM_IMAGE_POSITIONS) {
+    images_dq.pop_front();
+    keypoints_dq.pop_front();
+    descriptors_dq.pop_front();
+  }
 }
 #endif
 

@@ -89,6 +89,9 @@ struct Point2f {
 struct KeyPoint {
   Point2f pt;
   float size = 0;
+  float angle = -1;      // degrees, as in OpenCV; -1 = not applicable
+  float response = 0;
+  int octave = 0;
   KeyPoint() = default;
   KeyPoint(Point2f p, float s) : pt(p), size(s) {}
 };
@@ -317,6 +320,8 @@ private:
 #ifdef SPVO_USE_OPENCV
   cv::Ptr<cv::FeatureDetector> detector_;
   cv::Ptr<cv::DescriptorExtractor> extractor_;
+#else
+  cv::Mat orb_desc_;   // descriptors of the image detectKeypoints saw last (spvo_orb_detect: one pass for both)
 #endif
 };
 

@@ -210,6 +210,47 @@ int spvo_host_classic_match(int knn, int cross_check, int match_type, const uint
   return (int)m.size();
 }
 
+// stereoCallback (node.cpp:150-262) replayed on a ClassicFeatureFrontEnd(ORB, ORB, BF, selector, cross_check, stereo_threshold, ..)
+// exactly as node.cpp:353-360 constructs it, over n stereo pairs in host memory (native resolution, launch/visual_odometry_classic.launch).
+// poses: n x 7 (q xyzw, t of cam0_curr_T_cam0_prev; identity for frame 0); stats: n x 4 (keypoints left, right, stereo matches,
+// PnP inliers); seconds: wall time of frames warm .. n-1.  Returns the number of frames processed, negative on failure.
+int spvo_host_classic_sequence(int n, const uint8_t *const *imgs_l, const uint8_t *const *imgs_r, int rows, int cols, const double *P_l, const double *P_r, int knn,
+                               int cross_check, float stereo_threshold, int refinement_degree, int warm, double *poses, int *stats, double *seconds) {
+  ClassicFeatureFrontEnd fe(detector_name_to_type.at("ORB"), descriptor_name_to_type.at("ORB"), matcher_name_to_type.at("BF"),
+                            selector_name_to_type.at(knn ? "KNN" : "NN"), cross_check != 0, stereo_threshold, stereo_threshold, refinement_degree, false, 0, 0);
+  timespec t0{}, t1{};
+  for (int k = 0; k < n; ++k) {
+    if (k == warm) clock_gettime(CLOCK_MONOTONIC, &t0);
+    cv::Mat l(rows, cols, CV_8UC1), r(rows, cols, CV_8UC1), pl(3, 4, CV_64FC1), pr(3, 4, CV_64FC1);
+    std::memcpy(l.data, imgs_l[k], (size_t)rows * cols);
+    std::memcpy(r.data, imgs_r[k], (size_t)rows * cols);
+    std::memcpy(pl.data, P_l, 12 * sizeof(double));
+    std::memcpy(pr.data, P_r, 12 * sizeof(double));
+    fe.addStereoImagePair(l, r, pl, pr);
+    if (fe.keypoints_dq.size() < 2) return -(k + 1);
+    fe.matchDescriptors(CURR_LEFT_CURR_RIGHT);
+    double *p = poses + 7 * k;
+    p[0] = p[1] = p[2] = 0; p[3] = 1; p[4] = p[5] = p[6] = 0;
+    int inl = 0;
+    if (fe.keypoints_dq.size() >= 4) {
+      fe.matchDescriptors(CURR_LEFT_PREV_LEFT);
+      tf2::Transform T;
+      T.setIdentity();
+      fe.solveStereoOdometry(T);
+      p[0] = T.getRotation().x(); p[1] = T.getRotation().y(); p[2] = T.getRotation().z(); p[3] = T.getRotation().w();
+      p[4] = T.getOrigin().x(); p[5] = T.getOrigin().y(); p[6] = T.getOrigin().z();
+      inl = (int)fe.inliersPnp().size();
+    }
+    if (stats) {
+      stats[4 * k] = (int)fe.keypoints_dq.end()[-2].size(); stats[4 * k + 1] = (int)fe.keypoints_dq.end()[-1].size();
+      stats[4 * k + 2] = (int)fe.cv_DMatches_list[CURR_LEFT_CURR_RIGHT].size(); stats[4 * k + 3] = inl;
+    }
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  if (seconds) *seconds = n > warm ? (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) : 0.0;
+  return n;
+}
+
 // bit 0 pnp ok, bit 1 accepted by the gate, bit 2 refinement kept; LM iterations in bits 8..
 int spvo_host_last_solve(void *h) {
   auto *fe = static_cast<SuperPointFeatureFrontEnd *>(h);

@@ -274,3 +274,29 @@ class FrontEnd:
         self.match_descriptors(CURR_LEFT_CURR_RIGHT)              # node.cpp:196-198
         self.match_descriptors(CURR_LEFT_PREV_LEFT)
         return self.solve_stereo_odometry()                      # node.cpp:218
+
+
+def classic_sequence(frames, P_l, P_r, selector="KNN", cross_check=True, stereo_threshold=2.0, refinement_degree=4, warm=0):
+    """stereoCallback replayed on ClassicFeatureFrontEnd(ORB, ORB, BF, ...) (node.cpp:353-360) over host image pairs at their native
+    resolution: returns (poses [n, 7] = q xyzw + t of cam0_curr_T_cam0_prev, stats [n, 4] = keypoints L, R, stereo matches, PnP
+    inliers, seconds spent on frames warm .. n-1)."""
+    lib = load()
+    lib.spvo_host_classic_sequence.restype = C.c_int
+    lib.spvo_host_classic_sequence.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                               C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+    n = len(frames)
+    ls = [np.ascontiguousarray(f[0], np.uint8) for f in frames]
+    rs = [np.ascontiguousarray(f[1], np.uint8) for f in frames]
+    rows, cols = ls[0].shape
+    pl = (C.c_void_p * n)(*[a.ctypes.data for a in ls])
+    pr = (C.c_void_p * n)(*[a.ctypes.data for a in rs])
+    Pl = np.ascontiguousarray(P_l, np.float64).reshape(12)
+    Pr = np.ascontiguousarray(P_r, np.float64).reshape(12)
+    poses = np.zeros((n, 7), np.float64)
+    stats = np.zeros((n, 4), np.int32)
+    sec = C.c_double(0)
+    rc = lib.spvo_host_classic_sequence(n, pl, pr, rows, cols, Pl.ctypes.data, Pr.ctypes.data, 1 if selector == "KNN" else 0, int(cross_check), stereo_threshold,
+                                        refinement_degree, warm, poses.ctypes.data, stats.ctypes.data, C.byref(sec))
+    if rc != n:
+        raise RuntimeError("classic front end failed at frame %d" % (-rc - 1))
+    return poses, stats, sec.value

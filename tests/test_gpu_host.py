@@ -301,3 +301,27 @@ def test_deferred_solve_gives_the_same_poses_one_step_later(models_dir, sequence
     assert len(outs[False][0]) == len(outs[True][0]) == n and outs[False][1] == outs[True][1] == n
     for (qa, ta), (qb, tb) in zip(outs[False][0], outs[True][0]):
         assert np.array_equal(qa, qb) and np.array_equal(ta, tb)
+
+
+def test_classic_front_end_on_the_gpu_equals_the_cpu_state_machine(sequence):
+    """ClassicFeatureFrontEnd(ORB, ORB, BF, KNN) -- BASELINE config 1's front end, node.cpp:353-360 -- through the mirror class:
+    ORB on the GPU (spvo_orb_detect), Hamming matching on the GPU (spvo_match_hamming), the solver through the C ABI, at the
+    native resolution.  Against the CPU restatement's state machine on the same frames: keypoint counts, stereo matches and PnP
+    inliers identical (bit-exact features and matches upstream), poses within 1e-6; and the poses track the synthetic motion."""
+    from oracle import cpu_backend
+    frames, gt, P_l, P_r = sequence
+    frames = frames[:4]
+    poses, stats, _ = host.classic_sequence(frames, P_l, P_r, "KNN", True, 2.0, 4)
+    c = cpu_backend.CpuBackend(net_height=360, net_width=1176)
+    c.frontend_reset_classic("KNN", True, 2.0, 4)
+    for k, (L, R) in enumerate(frames):
+        r = c.frontend_step(L, R, P_l, P_r)
+        assert stats[k, 0] == r.n_kp_l == 2000 and stats[k, 1] == r.n_kp_r and stats[k, 2] == r.n_stereo
+        if k == 0:
+            continue
+        assert stats[k, 3] == r.n_inliers and r.n_inliers > 300
+        Rc, Rg = od.quat_to_rot(np.array(r.q[:])), od.quat_to_rot(poses[k, :4])       # both: cam0_curr_T_cam0_prev
+        assert np.abs(Rg - Rc).max() <= 1e-6 and np.abs(poses[k, 4:] - np.array(r.t[:])).max() <= 1e-6
+        Rt, tt = synth.relative_pose(gt[k - 1], gt[k])
+        assert np.abs(np.array(r.t[:]) - tt).max() < 0.1
+    c.close()
