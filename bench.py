@@ -511,6 +511,22 @@ def main():
                                                "mean_lm_iterations": round(float(st[:, 2].mean()), 2), "mean_pnp_inliers": round(float(st[:, 3].mean()), 1)}
             except Exception as exc:   # the headline line must survive a failure of this informational part
                 out["trained_workload"] = {"error": repr(exc)}
+        if world == 1 and headline and not args.no_extras:
+            try:
+                # BASELINE config 1's front end on the GPU, never `value`: ClassicFeatureFrontEnd(ORB, ORB, BF, KNN) as node.cpp:353-360
+                # constructs it -- ORB (spvo_orb_detect) and Hamming matching (spvo_match_hamming) as HIP kernels, the same solver --
+                # one pair at a time through the unchanged call sequence, host images in, at the native 376 x 1241.  The CPU
+                # restatement of the same front end is timed in cpu_baseline.config1_orb_front_end.
+                n_c = 5 + min(args.steps, 100)
+                seqc = [frames[order[i % len(order)]] for i in range(n_c)]
+                poses_c, stats_c, sec_c = host.classic_sequence(seqc, P_l, P_r, "KNN", True, 2.0, 4, warm=5)
+                out["classic_front_end_gpu"] = {"value": round((n_c - 5) / sec_c, 2), "unit": "stereo frames/s", "ms_per_step": round(1e3 * sec_c / (n_c - 5), 4),
+                                                "keypoints_per_image": int(np.median(stats_c[5:, 0])), "stereo_matches": int(np.median(stats_c[5:, 2])),
+                                                "pnp_inliers": int(np.median(stats_c[5:, 3])),
+                                                "note": "ORB 2000 features / 8 levels / scale 1.2 / FAST 20 (feature_detection_classic.cpp:13-24) + Hamming BF + KNN 0.8 on the GPU, "
+                                                        "synchronous stereoCallback on host images at 376x1241; bit-exact against the CPU restatement (tests/test_gpu_orb.py)"}
+            except Exception as exc:   # the headline line must survive a failure of this informational part
+                out["classic_front_end_gpu"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and world == 1 and headline:
             try:
                 out["cpu_baseline"] = cpu_baseline(frames, P_l, P_r, engine_path, order)

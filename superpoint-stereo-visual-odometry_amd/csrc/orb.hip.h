@@ -107,12 +107,14 @@ __global__ __launch_bounds__(256) void orb_blur_v_kernel(const float *__restrict
 // One wave per keypoint: moments of the disc (integers), direction, 256 steered tests on the smoothed level, the keypoint record.
 // disc: the 709 (dx, dy) offsets of the disc, int8 pairs; pattern: 256 x (x1, y1, x2, y2) floats.
 __global__ __launch_bounds__(256) void orb_describe_kernel(const uint8_t *__restrict__ im, const uint8_t *__restrict__ blur, const uint8_t *__restrict__ score, int h, int w,
-                                                           const int *__restrict__ out_xy, const int *__restrict__ counters, const signed char *__restrict__ disc,
-                                                           const float *__restrict__ pattern, float scale, int octave, OrbKeypoint *__restrict__ kps,
-                                                           uint8_t *__restrict__ desc, int base, int cap_total) {
+                                                           const int *__restrict__ out_xy, const int *__restrict__ counters /* [levels][NMS_COUNTER_INTS] */,
+                                                           const signed char *__restrict__ disc, const float *__restrict__ pattern, float scale, int octave,
+                                                           OrbKeypoint *__restrict__ kps, uint8_t *__restrict__ desc, int cap_total) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int n = counters[2];
+  const int n = counters[octave * NMS_COUNTER_INTS + 2];
+  int base = 0;   // keypoints of the levels below: those launches are complete (same stream)
+  for (int l = 0; l < octave; ++l) base += counters[l * NMS_COUNTER_INTS + 2];
   if (i >= n || base + i >= cap_total) return;
   const int cx = out_xy[2 * i], cy = out_xy[2 * i + 1];
   int m10 = 0, m01 = 0;

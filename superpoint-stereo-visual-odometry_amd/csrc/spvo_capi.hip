@@ -217,6 +217,7 @@ struct spvo_ctx {
     OrbKeypoint *kps = nullptr;
     uint8_t *desc = nullptr;
     size_t src_cap = 0;
+    int tab_rows = 0, tab_cols = 0;   // image size the resize tables in `tab` belong to
   } orb;
   // Hamming matcher (classic front end's binary descriptors): rows padded to 16 words
   int ham_cap = 0;
@@ -2411,11 +2412,29 @@ int spvo_orb_detect(spvo_ctx *c, const uint8_t *img, int rows, int cols, size_t 
     int rc;
     if ((rc = dev_alloc(c, &o.im, off[ORB_LEVELS] + 256)) || (rc = dev_alloc(c, &o.score, px0)) || (rc = dev_alloc(c, &o.blur, px0)) || (rc = dev_alloc(c, &o.tmp, px0)) ||
         (rc = dev_alloc(c, &o.keys, surv_cap)) || (rc = dev_alloc(c, &o.rank, surv_cap)) || (rc = dev_alloc(c, &o.out_xy, (size_t)2 * surv_cap)) ||
-        (rc = dev_alloc(c, &o.counters, NMS_COUNTER_INTS)) || (rc = dev_alloc(c, &o.tab, (size_t)3 * (rows + cols))) || (rc = dev_alloc(c, &o.kps, kp_cap)) ||
+        (rc = dev_alloc(c, &o.counters, (size_t)ORB_LEVELS * NMS_COUNTER_INTS)) || (rc = dev_alloc(c, &o.tab, (size_t)16 * (rows + cols))) || (rc = dev_alloc(c, &o.kps, kp_cap)) ||
         (rc = dev_alloc(c, &o.desc, (size_t)kp_cap * 32)))
       return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // (dev_alloc clears on the network stream)
     o.px_cap = px0; o.kp_cap = kp_cap;
+    o.tab_rows = o.tab_cols = 0;
+  }
+  // resize tables of all levels, one upload per image size
+  size_t toff[ORB_LEVELS] = {0};
+  {
+    size_t t = 0;
+    for (int l = 1; l < ORB_LEVELS; ++l) { toff[l] = t; t += (size_t)3 * (pw[l] + ph[l]); }
+    if (o.tab_rows != rows || o.tab_cols != cols) {
+      std::vector<int> all, xi, xa0, xa1, yi, yb0, yb1;
+      for (int l = 1; l < ORB_LEVELS; ++l) {
+        linear_coeffs(pw[l], pw[l - 1], xi, xa0, xa1);
+        linear_coeffs(ph[l], ph[l - 1], yi, yb0, yb1);
+        for (auto *v : {&xi, &xa0, &xa1, &yi, &yb0, &yb1}) all.insert(all.end(), v->begin(), v->end());
+      }
+      HIP_TRY(c, hipStreamSynchronize(st));
+      HIP_TRY(c, hipMemcpy(o.tab, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice));
+      o.tab_rows = rows; o.tab_cols = cols;
+    }
   }
   if (!o.pattern) {
     std::vector<float> pat;
@@ -2442,38 +2461,36 @@ int spvo_orb_detect(spvo_ctx *c, const uint8_t *img, int rows, int cols, size_t 
   NmsPair np;
   np.b[0].state = nullptr; np.b[0].cand = nullptr; np.b[0].counters = o.counters; np.b[0].surv_key = o.keys; np.b[0].rank = o.rank; np.b[0].out_xy = o.out_xy;
   np.b[1] = np.b[0];
-  int base = 0;
+  // the whole image is enqueued without a host round trip: one counter block per level, a level's keypoints land behind those of
+  // the levels below (orb_describe_kernel sums their counts)
+  HIP_TRY(c, hipMemsetAsync(o.counters, 0, (size_t)ORB_LEVELS * NMS_COUNTER_INTS * sizeof(int), st));
   for (int l = 0; l < ORB_LEVELS; ++l) {
     const int h = ph[l], w = pw[l];
     uint8_t *im = o.im + off[l];
     const dim3 grid((w + 63) / 64, (h + 3) / 4);
-    if (l > 0) {
-      std::vector<int> xi, xa0, xa1, yi, yb0, yb1, all;
-      linear_coeffs(w, pw[l - 1], xi, xa0, xa1);
-      linear_coeffs(h, ph[l - 1], yi, yb0, yb1);
-      for (auto *v : {&xi, &xa0, &xa1, &yi, &yb0, &yb1}) all.insert(all.end(), v->begin(), v->end());
-      HIP_TRY(c, hipMemcpyAsync(o.tab, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice, st));
-      HIP_TRY(c, hipStreamSynchronize(st));   // `all` is a stack-lifetime buffer (7 small copies per image)
-      hipLaunchKernelGGL(orb_resize_kernel, grid, dim3(256), 0, st, o.im + off[l - 1], ph[l - 1], pw[l - 1], pw[l - 1], im, h, w, o.tab);
-    }
+    if (l > 0) hipLaunchKernelGGL(orb_resize_kernel, grid, dim3(256), 0, st, o.im + off[l - 1], ph[l - 1], pw[l - 1], pw[l - 1], im, h, w, o.tab + toff[l]);
     if (h <= 2 * ORB_EDGE + 2 || w <= 2 * ORB_EDGE + 2 || want[l] <= 0) continue;
     const int lcap = std::min(surv_cap, (h / 2 + 1) * (w / 2 + 1));
-    HIP_TRY(c, hipMemsetAsync(o.counters, 0, NMS_COUNTER_INTS * sizeof(int), st));
+    np.b[0].counters = np.b[1].counters = o.counters + l * NMS_COUNTER_INTS;
     hipLaunchKernelGGL(orb_fast_kernel, grid, dim3(256), 0, st, im, h, w, ORB_FAST_T, o.score);
-    hipLaunchKernelGGL(orb_collect_kernel, grid, dim3(256), 0, st, o.score, h, w, o.keys, o.counters, lcap);
+    hipLaunchKernelGGL(orb_collect_kernel, grid, dim3(256), 0, st, o.score, h, w, o.keys, o.counters + l * NMS_COUNTER_INTS, lcap);
     hipLaunchKernelGGL(nms_rank_kernel, dim3((lcap + 255) / 256, (lcap + RANK_TILE - 1) / RANK_TILE, 1), dim3(256), 0, st, lcap, np);
     hipLaunchKernelGGL(nms_write_kernel, dim3((lcap + 255) / 256, 1), dim3(256), 0, st, h, want[l], lcap, np, (int *)nullptr);
     hipLaunchKernelGGL(orb_blur_h_kernel, grid, dim3(256), 0, st, im, h, w, o.taps, o.tmp);
     hipLaunchKernelGGL(orb_blur_v_kernel, grid, dim3(256), 0, st, o.tmp, h, w, o.taps, o.blur);
     hipLaunchKernelGGL(orb_describe_kernel, dim3((want[l] + 3) / 4), dim3(256), 0, st, im, o.blur, o.score, h, w, o.out_xy, o.counters, o.disc, o.pattern, lscale[l], l,
-                       o.kps, o.desc, base, kp_cap);
+                       o.kps, o.desc, kp_cap);
     HIP_TRY(c, hipGetLastError());
-    int cnt[4];
-    HIP_TRY(c, hipMemcpyAsync(cnt, o.counters, sizeof cnt, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    if (cnt[3]) return fail(c, SPVO_ERR_CAPACITY, "ORB: corner buffer overflow at level %d", l);
-    base += std::min(cnt[2], kp_cap - base);
   }
+  int cnt[ORB_LEVELS * NMS_COUNTER_INTS];
+  HIP_TRY(c, hipMemcpyAsync(cnt, o.counters, sizeof cnt, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipStreamSynchronize(st));
+  int base = 0;
+  for (int l = 0; l < ORB_LEVELS; ++l) {
+    if (cnt[l * NMS_COUNTER_INTS + 3]) return fail(c, SPVO_ERR_CAPACITY, "ORB: corner buffer overflow at level %d", l);
+    base += cnt[l * NMS_COUNTER_INTS + 2];
+  }
+  base = std::min(base, kp_cap);
   *n_out = base;
   const int ncopy = std::min(base, cap);
   if (ncopy > 0) {
