@@ -34,14 +34,29 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(const uint8_t *__restri
   dst[(size_t)y * dw + x] = (uint8_t)min(max(v, 0), 255);
 }
 
+// Everything after the pyramid runs for ALL levels in one launch per stage (blockIdx.z / .y = level; a level's workgroups beyond its
+// size exit at once): an image is 7 resize launches + 7 stage launches instead of 8 x 8 -- the chain is launch-bound, not
+// work-bound (a stage of one level takes 2-13 us).
+struct OrbLevel {
+  uint8_t *im, *score, *blur;
+  float *tmp;
+  unsigned long long *keys;
+  int *rank, *out_xy, *counters;
+  int h, w, want, cap;   // want = 0: the level is skipped (smaller than the border, or no quota)
+  float scale;
+};
+struct OrbLevels { OrbLevel l[ORB_LEVELS]; };
+
 // FAST-9 corner score on the Bresenham circle of radius 3: the largest threshold at which the pixel is still a corner, 0 if it is not
 // one at threshold t (or lies in the border)
-__global__ __launch_bounds__(256) void orb_fast_kernel(const uint8_t *__restrict__ im, int h, int w, int t, uint8_t *__restrict__ score) {
+__global__ __launch_bounds__(256) void orb_fast_kernel(const OrbLevels lv, int t) {
+  const OrbLevel L = lv.l[blockIdx.z];
+  const int h = L.h, w = L.w;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= w || y >= h) return;
+  if (L.want <= 0 || x >= w || y >= h) return;
   int best = 0;
   if (x >= ORB_EDGE && x < w - ORB_EDGE && y >= ORB_EDGE && y < h - ORB_EDGE) {
-    const uint8_t *p = im + (size_t)y * w + x;
+    const uint8_t *p = L.im + (size_t)y * w + x;
     const int c = *p;
     const int off[16] = {-3 * w, -3 * w + 1, -2 * w + 2, -w + 3, 3, w + 3, 2 * w + 2, 3 * w + 1, 3 * w, 3 * w - 1, 2 * w - 2, w - 3, -3, -w - 3, -2 * w - 2, -3 * w - 1};
     int d[25];
@@ -61,62 +76,126 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(const uint8_t *__restrict
       }
     }
   }
-  score[(size_t)y * w + x] = (uint8_t)best;
+  L.score[(size_t)y * w + x] = (uint8_t)best;
 }
 
 // 3x3 non-maximum suppression (of equal neighbours the first in raster order wins) -> rank keys of the survivors
-__global__ __launch_bounds__(256) void orb_collect_kernel(const uint8_t *__restrict__ score, int h, int w, unsigned long long *__restrict__ keys, int *__restrict__ counters,
-                                                          int cap) {
+__global__ __launch_bounds__(256) void orb_collect_kernel(const OrbLevels lv) {
+  const OrbLevel L = lv.l[blockIdx.z];
+  const int h = L.h, w = L.w;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x < ORB_EDGE || x >= w - ORB_EDGE || y < ORB_EDGE || y >= h - ORB_EDGE) return;
-  const int s = score[(size_t)y * w + x];
-  if (!s) return;
-  bool is_max = true;
+  if (L.want <= 0 || y >= h) return;   // (whole waves: a wave is 64 consecutive x of one row)
+  const uint8_t *score = L.score;
+  const bool inside = x >= ORB_EDGE && x < w - ORB_EDGE && y >= ORB_EDGE && y < h - ORB_EDGE;
+  const int s = inside ? score[(size_t)y * w + x] : 0;
+  bool is_max = s != 0;
+  if (is_max) {
 #pragma unroll
-  for (int dy = -1; dy <= 1; ++dy)
+    for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-    for (int dx = -1; dx <= 1; ++dx)
-      if (dy || dx) {
-        const int later = (dy > 0 || (dy == 0 && dx > 0)) ? 1 : 0;
-        if ((int)score[(size_t)(y + dy) * w + x + dx] >= s + later) is_max = false;
-      }
+      for (int dx = -1; dx <= 1; ++dx)
+        if (dy || dx) {
+          const int later = (dy > 0 || (dy == 0 && dx > 0)) ? 1 : 0;
+          if ((int)score[(size_t)(y + dy) * w + x + dx] >= s + later) is_max = false;
+        }
+  }
+  // one atomic per wave: the survivors of a wave take consecutive slots
+  const unsigned long long m = __ballot(is_max);
+  if (!m) return;
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&L.counters[1], __popcll(m));
+  base = __shfl(base, __ffsll((long long)m) - 1);
   if (!is_max) return;
-  const int slot = atomicAdd(&counters[1], 1);
-  if (slot < cap) keys[slot] = rank_key((float)s, x, y, h);   // (0xFFFFFFFF - bits(response)) << 32 | x h + y: smaller = earlier
-  else counters[3] = 1;
+  const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+  if (slot < L.cap) L.keys[slot] = rank_key((float)s, x, y, h);   // (0xFFFFFFFF - bits(response)) << 32 | x h + y: smaller = earlier
+  else L.counters[3] = 1;
+}
+
+// K9's rank-by-counting (nms_rank_kernel) with a grid that does not depend on the buffers' capacity: a level has anything between
+// no corner and one per 2x2 pixels.  A fixed number of workgroups per level walks the (256 keys) x (1024-key tile) blocks that the
+// survivor count on the device calls for.
+__global__ __launch_bounds__(256) void orb_rank_kernel(const OrbLevels lv) {
+  __shared__ __attribute__((aligned(16))) unsigned long long tile[RANK_TILE];
+  const OrbLevel L = lv.l[blockIdx.y];
+  if (L.want <= 0) return;
+  const int n = min(L.counters[1], L.cap);
+  const int nbi = (n + 255) / 256, nbj = (n + RANK_TILE - 1) / RANK_TILE;
+  for (int b = blockIdx.x; b < nbi * nbj; b += gridDim.x) {
+    const int bi = b % nbi, j0 = (b / nbi) * RANK_TILE;
+    __syncthreads();
+    for (int t = threadIdx.x; t < RANK_TILE; t += 256) tile[t] = (j0 + t < n) ? L.keys[j0 + t] : ~0ull;
+    __syncthreads();
+    const int i = bi * 256 + threadIdx.x;
+    if (i >= n) continue;
+    const unsigned long long key = L.keys[i];
+    int cnt = 0;
+    const ulonglong2 *t2 = (const ulonglong2 *)tile;
+#pragma unroll 8
+    for (int t = 0; t < RANK_TILE / 2; ++t) {
+      const ulonglong2 v = t2[t];
+      cnt += (v.x < key ? 1 : 0) + (v.y < key ? 1 : 0);
+    }
+    if (cnt) atomicAdd(&L.rank[i], cnt);
+  }
+}
+
+// positions from ranks: the first `want` of a level in (response, index) order
+__global__ __launch_bounds__(256) void orb_write_kernel(const OrbLevels lv) {
+  const OrbLevel L = lv.l[blockIdx.y];
+  if (L.want <= 0) return;
+  const int n = min(L.counters[1], L.cap);
+  if (blockIdx.x == 0 && threadIdx.x == 0) L.counters[2] = min(n, L.want);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int rank = L.rank[i];
+    L.rank[i] = 0;
+    if (rank < L.want) {
+      const unsigned cm = (unsigned)(L.keys[i] & 0xFFFFFFFFull);
+      L.out_xy[2 * rank + 0] = (int)(cm / (unsigned)L.h);
+      L.out_xy[2 * rank + 1] = (int)(cm % (unsigned)L.h);
+    }
+  }
 }
 
 // 7x7 Gaussian, separable, float32 sums in tap order with separately rounded multiply and add, result = floor(s + 0.5) clamped
-__global__ __launch_bounds__(256) void orb_blur_h_kernel(const uint8_t *__restrict__ src, int h, int w, const float *__restrict__ taps, float *__restrict__ tmp) {
+__global__ __launch_bounds__(256) void orb_blur_h_kernel(const OrbLevels lv, const float *__restrict__ taps) {
+  const OrbLevel L = lv.l[blockIdx.z];
+  const int h = L.h, w = L.w;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= w || y >= h) return;
+  if (L.want <= 0 || x >= w || y >= h) return;
   float s = 0.f;
 #pragma unroll
-  for (int i = -3; i <= 3; ++i) s = add_rn(s, mul_rn(taps[i + 3], (float)src[(size_t)y * w + min(max(x + i, 0), w - 1)]));
-  tmp[(size_t)y * w + x] = s;
+  for (int i = -3; i <= 3; ++i) s = add_rn(s, mul_rn(taps[i + 3], (float)L.im[(size_t)y * w + min(max(x + i, 0), w - 1)]));
+  L.tmp[(size_t)y * w + x] = s;
 }
-__global__ __launch_bounds__(256) void orb_blur_v_kernel(const float *__restrict__ tmp, int h, int w, const float *__restrict__ taps, uint8_t *__restrict__ dst) {
+__global__ __launch_bounds__(256) void orb_blur_v_kernel(const OrbLevels lv, const float *__restrict__ taps) {
+  const OrbLevel L = lv.l[blockIdx.z];
+  const int h = L.h, w = L.w;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= w || y >= h) return;
+  if (L.want <= 0 || x >= w || y >= h) return;
   float s = 0.f;
 #pragma unroll
-  for (int i = -3; i <= 3; ++i) s = add_rn(s, mul_rn(taps[i + 3], tmp[(size_t)min(max(y + i, 0), h - 1) * w + x]));
-  dst[(size_t)y * w + x] = (uint8_t)min(max((int)floorf(add_rn(s, 0.5f)), 0), 255);
+  for (int i = -3; i <= 3; ++i) s = add_rn(s, mul_rn(taps[i + 3], L.tmp[(size_t)min(max(y + i, 0), h - 1) * w + x]));
+  L.blur[(size_t)y * w + x] = (uint8_t)min(max((int)floorf(add_rn(s, 0.5f)), 0), 255);
 }
 
 // One wave per keypoint: moments of the disc (integers), direction, 256 steered tests on the smoothed level, the keypoint record.
-// disc: the 709 (dx, dy) offsets of the disc, int8 pairs; pattern: 256 x (x1, y1, x2, y2) floats.
-__global__ __launch_bounds__(256) void orb_describe_kernel(const uint8_t *__restrict__ im, const uint8_t *__restrict__ blur, const uint8_t *__restrict__ score, int h, int w,
-                                                           const int *__restrict__ out_xy, const int *__restrict__ counters /* [levels][NMS_COUNTER_INTS] */,
-                                                           const signed char *__restrict__ disc, const float *__restrict__ pattern, float scale, int octave,
+// disc: the 709 (dx, dy) offsets of the disc, int8 pairs; pattern: 256 x (x1, y1, x2, y2) floats.  A level's keypoints land behind
+// those of the levels below (their counts are final: the write launch before this one covered every level).
+__global__ __launch_bounds__(256) void orb_describe_kernel(const OrbLevels lv, const signed char *__restrict__ disc, const float *__restrict__ pattern,
                                                            OrbKeypoint *__restrict__ kps, uint8_t *__restrict__ desc, int cap_total) {
+  const int octave = blockIdx.y;
+  const OrbLevel L = lv.l[octave];
+  if (L.want <= 0) return;
+  const int w = L.w;
+  const uint8_t *im = L.im, *blur = L.blur;
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int n = counters[octave * NMS_COUNTER_INTS + 2];
-  int base = 0;   // keypoints of the levels below: those launches are complete (same stream)
-  for (int l = 0; l < octave; ++l) base += counters[l * NMS_COUNTER_INTS + 2];
+  const int n = L.counters[2];
+  int base = 0;
+  for (int l = 0; l < octave; ++l) base += lv.l[l].want > 0 ? lv.l[l].counters[2] : 0;
   if (i >= n || base + i >= cap_total) return;
-  const int cx = out_xy[2 * i], cy = out_xy[2 * i + 1];
+  const int cx = L.out_xy[2 * i], cy = L.out_xy[2 * i + 1];
   int m10 = 0, m01 = 0;
   for (int p = lane; p < ORB_DISC; p += 64) {
     const int dx = disc[2 * p], dy = disc[2 * p + 1];
@@ -141,10 +220,10 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(const uint8_t *__rest
   if (!(lane & 1)) desc[(size_t)(base + i) * 32 + (lane >> 1)] = (uint8_t)(bits | (hi << 4));
   if (lane == 0) {
     OrbKeypoint k;
-    k.x = mul_rn((float)cx, scale);
-    k.y = mul_rn((float)cy, scale);
+    k.x = mul_rn((float)cx, L.scale);
+    k.y = mul_rn((float)cy, L.scale);
     k.angle = atan2f(sa, ca);
-    k.response = (float)score[(size_t)cy * w + cx];
+    k.response = (float)L.score[(size_t)cy * w + cx];
     k.octave = octave;
     kps[base + i] = k;
   }

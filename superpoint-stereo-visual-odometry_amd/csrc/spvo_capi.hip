@@ -2410,8 +2410,9 @@ int spvo_orb_detect(spvo_ctx *c, const uint8_t *img, int rows, int cols, size_t 
     o.im = o.score = o.blur = nullptr; o.tmp = nullptr; o.keys = nullptr; o.rank = o.out_xy = o.counters = o.tab = nullptr; o.kps = nullptr; o.desc = nullptr;
     o.px_cap = 0; o.kp_cap = 0;
     int rc;
-    if ((rc = dev_alloc(c, &o.im, off[ORB_LEVELS] + 256)) || (rc = dev_alloc(c, &o.score, px0)) || (rc = dev_alloc(c, &o.blur, px0)) || (rc = dev_alloc(c, &o.tmp, px0)) ||
-        (rc = dev_alloc(c, &o.keys, surv_cap)) || (rc = dev_alloc(c, &o.rank, surv_cap)) || (rc = dev_alloc(c, &o.out_xy, (size_t)2 * surv_cap)) ||
+    const size_t pyr = off[ORB_LEVELS] + 256, kall = (size_t)5 * surv_cap;   // all levels side by side (sum of 1 / 1.44^l < 3.3)
+    if ((rc = dev_alloc(c, &o.im, pyr)) || (rc = dev_alloc(c, &o.score, pyr)) || (rc = dev_alloc(c, &o.blur, pyr)) || (rc = dev_alloc(c, &o.tmp, pyr)) ||
+        (rc = dev_alloc(c, &o.keys, kall)) || (rc = dev_alloc(c, &o.rank, kall)) || (rc = dev_alloc(c, &o.out_xy, 2 * kall)) ||
         (rc = dev_alloc(c, &o.counters, (size_t)ORB_LEVELS * NMS_COUNTER_INTS)) || (rc = dev_alloc(c, &o.tab, (size_t)16 * (rows + cols))) || (rc = dev_alloc(c, &o.kps, kp_cap)) ||
         (rc = dev_alloc(c, &o.desc, (size_t)kp_cap * 32)))
       return rc;
@@ -2458,30 +2459,35 @@ int spvo_orb_detect(spvo_ctx *c, const uint8_t *img, int rows, int cols, size_t 
   }
   HIP_TRY(c, hipMemcpyAsync(o.src, img, (size_t)rows * stride, hipMemcpyHostToDevice, st));
   HIP_TRY(c, hipMemcpy2DAsync(o.im, cols, o.src, stride, cols, rows, hipMemcpyDeviceToDevice, st));   // level 0: the image, rows packed
-  NmsPair np;
-  np.b[0].state = nullptr; np.b[0].cand = nullptr; np.b[0].counters = o.counters; np.b[0].surv_key = o.keys; np.b[0].rank = o.rank; np.b[0].out_xy = o.out_xy;
-  np.b[1] = np.b[0];
-  // the whole image is enqueued without a host round trip: one counter block per level, a level's keypoints land behind those of
-  // the levels below (orb_describe_kernel sums their counts)
+  // the whole image is enqueued without a host round trip: the pyramid level by level, then every stage once for all levels;
+  // one counter block per level, a level's keypoints land behind those of the levels below (orb_describe_kernel sums their counts)
   HIP_TRY(c, hipMemsetAsync(o.counters, 0, (size_t)ORB_LEVELS * NMS_COUNTER_INTS * sizeof(int), st));
+  OrbLevels lv;
+  size_t koff = 0;
+  int want_max = 0;
   for (int l = 0; l < ORB_LEVELS; ++l) {
-    const int h = ph[l], w = pw[l];
-    uint8_t *im = o.im + off[l];
-    const dim3 grid((w + 63) / 64, (h + 3) / 4);
-    if (l > 0) hipLaunchKernelGGL(orb_resize_kernel, grid, dim3(256), 0, st, o.im + off[l - 1], ph[l - 1], pw[l - 1], pw[l - 1], im, h, w, o.tab + toff[l]);
-    if (h <= 2 * ORB_EDGE + 2 || w <= 2 * ORB_EDGE + 2 || want[l] <= 0) continue;
-    const int lcap = std::min(surv_cap, (h / 2 + 1) * (w / 2 + 1));
-    np.b[0].counters = np.b[1].counters = o.counters + l * NMS_COUNTER_INTS;
-    hipLaunchKernelGGL(orb_fast_kernel, grid, dim3(256), 0, st, im, h, w, ORB_FAST_T, o.score);
-    hipLaunchKernelGGL(orb_collect_kernel, grid, dim3(256), 0, st, o.score, h, w, o.keys, o.counters + l * NMS_COUNTER_INTS, lcap);
-    hipLaunchKernelGGL(nms_rank_kernel, dim3((lcap + 255) / 256, (lcap + RANK_TILE - 1) / RANK_TILE, 1), dim3(256), 0, st, lcap, np);
-    hipLaunchKernelGGL(nms_write_kernel, dim3((lcap + 255) / 256, 1), dim3(256), 0, st, h, want[l], lcap, np, (int *)nullptr);
-    hipLaunchKernelGGL(orb_blur_h_kernel, grid, dim3(256), 0, st, im, h, w, o.taps, o.tmp);
-    hipLaunchKernelGGL(orb_blur_v_kernel, grid, dim3(256), 0, st, o.tmp, h, w, o.taps, o.blur);
-    hipLaunchKernelGGL(orb_describe_kernel, dim3((want[l] + 3) / 4), dim3(256), 0, st, im, o.blur, o.score, h, w, o.out_xy, o.counters, o.disc, o.pattern, lscale[l], l,
-                       o.kps, o.desc, kp_cap);
-    HIP_TRY(c, hipGetLastError());
+    OrbLevel &L = lv.l[l];
+    const int lcap = std::min(surv_cap, (ph[l] / 2 + 1) * (pw[l] / 2 + 1));
+    L.im = o.im + off[l]; L.score = o.score + off[l]; L.blur = o.blur + off[l]; L.tmp = o.tmp + off[l];
+    L.keys = o.keys + koff; L.rank = o.rank + koff; L.out_xy = o.out_xy + 2 * koff; L.counters = o.counters + l * NMS_COUNTER_INTS;
+    L.h = ph[l]; L.w = pw[l]; L.cap = lcap; L.scale = lscale[l];
+    L.want = (ph[l] <= 2 * ORB_EDGE + 2 || pw[l] <= 2 * ORB_EDGE + 2) ? 0 : want[l];
+    want_max = std::max(want_max, L.want);
+    koff += lcap;
+    if (l > 0) hipLaunchKernelGGL(orb_resize_kernel, dim3((pw[l] + 63) / 64, (ph[l] + 3) / 4), dim3(256), 0, st, o.im + off[l - 1], ph[l - 1], pw[l - 1], pw[l - 1], L.im, ph[l], pw[l],
+                                  o.tab + toff[l]);
   }
+  if (want_max > 0) {
+    const dim3 grid((cols + 63) / 64, (rows + 3) / 4, ORB_LEVELS);
+    hipLaunchKernelGGL(orb_fast_kernel, grid, dim3(256), 0, st, lv, ORB_FAST_T);
+    hipLaunchKernelGGL(orb_collect_kernel, grid, dim3(256), 0, st, lv);
+    hipLaunchKernelGGL(orb_rank_kernel, dim3(128, ORB_LEVELS), dim3(256), 0, st, lv);
+    hipLaunchKernelGGL(orb_write_kernel, dim3(32, ORB_LEVELS), dim3(256), 0, st, lv);
+    hipLaunchKernelGGL(orb_blur_h_kernel, grid, dim3(256), 0, st, lv, o.taps);
+    hipLaunchKernelGGL(orb_blur_v_kernel, grid, dim3(256), 0, st, lv, o.taps);
+    hipLaunchKernelGGL(orb_describe_kernel, dim3((want_max + 3) / 4, ORB_LEVELS), dim3(256), 0, st, lv, o.disc, o.pattern, o.kps, o.desc, kp_cap);
+  }
+  HIP_TRY(c, hipGetLastError());
   int cnt[ORB_LEVELS * NMS_COUNTER_INTS];
   HIP_TRY(c, hipMemcpyAsync(cnt, o.counters, sizeof cnt, hipMemcpyDeviceToHost, st));
   HIP_TRY(c, hipStreamSynchronize(st));
