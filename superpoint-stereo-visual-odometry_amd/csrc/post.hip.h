@@ -427,24 +427,31 @@ __global__ __launch_bounds__(256) void nms_collect_kernel(const float *__restric
 // K9: rank by counting -- the output position of a survivor is the number of survivors with a
 // smaller key.  2-D decomposition: block (bi, bj) counts 256 keys against a 1024-key LDS tile.
 constexpr int RANK_TILE = 1024;
+// The grid does not depend on the buffer's capacity (one survivor per 5x5 cell at most: 17 k; a few thousand in practice): a fixed
+// number of workgroups per image walks the blocks the survivor count on the device calls for -- a capacity-sized grid is 2278
+// workgroups per launch, most of which only start and exit, next to convolutions whose workgroups need whole CUs.
 __global__ __launch_bounds__(256) void nms_rank_kernel(int surv_cap, NmsPair np) {
   __shared__ __attribute__((aligned(16))) unsigned long long tile[RANK_TILE];
-  const NmsBuffers nb = np.b[blockIdx.z];
+  const NmsBuffers nb = np.b[blockIdx.y];
   const int n = min(nb.counters[1], surv_cap);
-  const int i = blockIdx.x * 256 + threadIdx.x, j0 = blockIdx.y * RANK_TILE;
-  if (blockIdx.x * 256 >= n || j0 >= n) return;
-  for (int t = threadIdx.x; t < RANK_TILE; t += 256) tile[t] = (j0 + t < n) ? nb.surv_key[j0 + t] : ~0ull;
-  __syncthreads();
-  if (i >= n) return;
-  const unsigned long long key = nb.surv_key[i];
-  int cnt = 0;
-  const ulonglong2 *t2 = (const ulonglong2 *)tile;
+  const int nbi = (n + 255) / 256, nbj = (n + RANK_TILE - 1) / RANK_TILE;
+  for (int b = blockIdx.x; b < nbi * nbj; b += gridDim.x) {
+    const int bi = b % nbi, j0 = (b / nbi) * RANK_TILE;
+    __syncthreads();
+    for (int t = threadIdx.x; t < RANK_TILE; t += 256) tile[t] = (j0 + t < n) ? nb.surv_key[j0 + t] : ~0ull;
+    __syncthreads();
+    const int i = bi * 256 + threadIdx.x;
+    if (i >= n) continue;
+    const unsigned long long key = nb.surv_key[i];
+    int cnt = 0;
+    const ulonglong2 *t2 = (const ulonglong2 *)tile;
 #pragma unroll 8
-  for (int t = 0; t < RANK_TILE / 2; ++t) {
-    const ulonglong2 v = t2[t];
-    cnt += (v.x < key ? 1 : 0) + (v.y < key ? 1 : 0);
+    for (int t = 0; t < RANK_TILE / 2; ++t) {
+      const ulonglong2 v = t2[t];
+      cnt += (v.x < key ? 1 : 0) + (v.y < key ? 1 : 0);
+    }
+    if (cnt) atomicAdd(&nb.rank[i], cnt);
   }
-  if (cnt) atomicAdd(&nb.rank[i], cnt);
 }
 
 __global__ __launch_bounds__(256) void nms_write_kernel(int H, int max_kp, int surv_cap, NmsPair np, int *zero_next) {
@@ -452,15 +459,15 @@ __global__ __launch_bounds__(256) void nms_write_kernel(int H, int max_kp, int s
   // hand the next submission a clean counter block (it belongs to the other parity)
   if (zero_next && blockIdx.x == 0 && threadIdx.x < NMS_COUNTER_INTS) zero_next[blockIdx.y * NMS_COUNTER_INTS + threadIdx.x] = 0;
   const int n = min(nb.counters[1], surv_cap);
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) nb.counters[2] = min(n, max_kp);
-  if (i >= n) return;
-  const int rank = nb.rank[i];
-  nb.rank[i] = 0;
-  if (rank < max_kp) {
-    const unsigned cm = (unsigned)(nb.surv_key[i] & 0xFFFFFFFFull);
-    nb.out_xy[2 * rank + 0] = (int)(cm / (unsigned)H);
-    nb.out_xy[2 * rank + 1] = (int)(cm % (unsigned)H);
+  if (blockIdx.x == 0 && threadIdx.x == 0) nb.counters[2] = min(n, max_kp);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int rank = nb.rank[i];
+    nb.rank[i] = 0;
+    if (rank < max_kp) {
+      const unsigned cm = (unsigned)(nb.surv_key[i] & 0xFFFFFFFFull);
+      nb.out_xy[2 * rank + 0] = (int)(cm / (unsigned)H);
+      nb.out_xy[2 * rank + 1] = (int)(cm % (unsigned)H);
+    }
   }
 }
 

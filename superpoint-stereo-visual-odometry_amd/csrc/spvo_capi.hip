@@ -1009,8 +1009,8 @@ int launch_nms_rounds(spvo_ctx *c, int nimg, const NmsPair &np, int set, int n_l
       hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 0>), dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, c->cfg.dist_thresh, np, l);
   }
   hipLaunchKernelGGL(nms_collect_kernel, dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, c->cfg.border_remove, c->surv_cap, np);
-  hipLaunchKernelGGL(nms_rank_kernel, dim3((c->surv_cap + 255) / 256, (c->surv_cap + RANK_TILE - 1) / RANK_TILE, nimg), dim3(256), 0, st, c->surv_cap, np);
-  hipLaunchKernelGGL(nms_write_kernel, dim3((c->surv_cap + 255) / 256, nimg), dim3(256), 0, st, c->H, c->cfg.max_keypoints, c->surv_cap, np, zero_next);
+  hipLaunchKernelGGL(nms_rank_kernel, dim3(128, nimg), dim3(256), 0, st, c->surv_cap, np);
+  hipLaunchKernelGGL(nms_write_kernel, dim3(32, nimg), dim3(256), 0, st, c->H, c->cfg.max_keypoints, c->surv_cap, np, zero_next);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(c->h_counters_r[set % RING], np.b[0].counters, (size_t)nimg * NMS_COUNTER_INTS * sizeof(int), hipMemcpyDeviceToHost, st));
   return SPVO_OK;
