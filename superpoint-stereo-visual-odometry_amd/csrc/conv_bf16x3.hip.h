@@ -424,6 +424,7 @@ __global__ __launch_bounds__(256) void conv_first_s3_kernel(const float *__restr
 }
 
 // C8x3 -> dense NCHW fp32 (spvo_debug_tensor): the exact sum of the three pieces
+template <int UNUSED = 0>   // (a template so that every translation unit may include this header)
 __global__ void unpad_s3_kernel(const unsigned short *__restrict__ in, float *__restrict__ out, int C, int H, int W, int hp, int wp) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y;

@@ -393,6 +393,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_f16_kernel(const _Float16 *__re
 }
 
 // Stand-alone 2x2/2 max-pool on C8 (squeeze graph: pool after a Concat).  One thread = one output pixel of one group.
+template <int UNUSED = 0>   // (a template so that every translation unit may include this header)
 __global__ __launch_bounds__(256) void maxpool2_f16_kernel(const _Float16 *__restrict__ in, _Float16 *__restrict__ out, int OH, int OW,
                                                             int in_hp, int in_wp, int out_hp, int out_wp) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -408,6 +409,7 @@ __global__ __launch_bounds__(256) void maxpool2_f16_kernel(const _Float16 *__res
 }
 
 // C8 fp16 -> dense NCHW fp32 (spvo_debug_tensor)
+template <int UNUSED = 0>   // (a template so that every translation unit may include this header)
 __global__ void unpad_c8_kernel(const _Float16 *__restrict__ in, float *__restrict__ out, int C, int H, int W, int hp, int wp) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y;

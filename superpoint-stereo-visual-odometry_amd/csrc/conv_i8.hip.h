@@ -404,6 +404,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_i8_kernel(const int8_t *__restr
 }
 
 // C16 int8 -> dense NCHW fp32 holding the integer values q (spvo_debug_tensor)
+template <int UNUSED = 0>   // (a template so that every translation unit may include this header)
 __global__ void unpad_c16_kernel(const int8_t *__restrict__ in, float *__restrict__ out, int C, int H, int W, int hp, int wp) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y;

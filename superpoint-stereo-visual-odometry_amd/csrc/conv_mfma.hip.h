@@ -516,6 +516,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float *__restrict_
 }
 
 // Stand-alone 2x2/2 max-pool (squeeze graph: pool after a Concat).
+template <int UNUSED = 0>   // (a template so that every translation unit may include this header)
 __global__ __launch_bounds__(256) void maxpool2_kernel(const float *__restrict__ in,
                                                        float *__restrict__ out, int C, int OH,
                                                        int OW, int in_hp, int in_wp, int out_hp,

@@ -12,6 +12,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "spvo_types.hip.h"
+#include "conv_mfma.hip.h"   // mul_rn: separately rounded products
 
 namespace spvo {
 
@@ -226,12 +228,7 @@ __device__ __forceinline__ bool reproj_inlier(const double *K, const double *R, 
   return (p2 > 0) && (e2 <= thr2);
 }
 
-struct RansacWork {      // device scratch
-  int *counts;           // [iterations]  (-1 = invalid hypothesis)
-  double *poses;         // [iterations][7]  q(xyzw), t
-  double *result;        // [8]: rvec(3), tvec(3), ok, n_inliers
-  int *inliers;          // [n]
-};
+// (RansacWork: spvo_types.hip.h)
 
 // one wave per hypothesis: lane 0 solves the minimal problem, all lanes score
 __global__ __launch_bounds__(64) void ransac_hypothesis_kernel(const double *__restrict__ Kd,
@@ -454,12 +451,7 @@ __global__ __launch_bounds__(256) void ransac_select_kernel(const double *__rest
 }
 
 // ------------------------------------------------------------------------- K16
-struct ObsDev {   // mirrors spvo_obs (include/spvo.h)
-  float X[3];
-  float uv[2];
-  int32_t cam;
-  int32_t inverse;
-};
+// (ObsDev: spvo_types.hip.h)
 
 // CostFunctor32 (cost.hpp:27-58): residual and analytic Jacobian wrt the
 // EigenQuaternionParameterization tangent (3) and t (3).
@@ -531,9 +523,7 @@ __device__ __forceinline__ void cost32(const double *P /*3x4*/, const double *q,
   }
 }
 
-struct RefineOut {   // device, doubles: q(4) t(3) iterations converged usable initial_cost final_cost
-  double v[12];
-};
+// (RefineOut: spvo_types.hip.h)
 
 // Whole Levenberg-Marquardt loop in ONE workgroup: no host round trips.
 // All threads evaluate residual blocks; thread 0 runs the trust-region logic.

@@ -19,7 +19,7 @@ namespace spvo {
 
 constexpr int ORB_LEVELS = 8, ORB_HALF = 15, ORB_EDGE = 31, ORB_FAST_T = 20, ORB_DISC = 709;   // 709 pixels in the disc of radius 15
 
-struct OrbKeypoint { float x, y, angle, response; int32_t octave; };   // mirrors spvo_orb_keypoint (include/spvo.h)
+// (OrbKeypoint: spvo_types.hip.h)
 
 // pyramid level from the level below: cv::resize(INTER_LINEAR) on 8-bit data, the arithmetic of preprocess_kernel
 __global__ __launch_bounds__(256) void orb_resize_kernel(const uint8_t *__restrict__ src, int sh, int sw, int sstride, uint8_t *__restrict__ dst, int dh, int dw,

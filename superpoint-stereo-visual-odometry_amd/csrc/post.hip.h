@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "conv_mfma.hip.h"
+#include "spvo_types.hip.h"
 
 namespace spvo {
 
@@ -148,23 +149,7 @@ __global__ __launch_bounds__(256) void heatmap_kernel(const float *__restrict__ 
 // ---------------------------------------------------------------------------
 enum : uint8_t { ST_NONE = 0, ST_UNDECIDED = 1, ST_KEPT = 2, ST_SUPPRESSED = 4 };   // one bit each: word-wide tests
 
-// The state map is padded (NMS_PAD rows/columns of ST_NONE on every side, row pitch a multiple
-// of 4) so that a candidate's whole window is read with aligned 32-bit loads and no clipping.
-constexpr int NMS_PAD = 8;           // >= largest supported dist_thresh
-constexpr int NMS_MAX_LAUNCH = 16;   // round launches per host batch
-constexpr int NMS_COUNTER_INTS = 8 + NMS_MAX_LAUNCH;
-
-__host__ __device__ inline int nms_state_pitch(int W) { return ((W + 2 * NMS_PAD + 3) / 4) * 4; }
-
-struct NmsBuffers {   // per image
-  uint8_t *state;     // [(H + 2*NMS_PAD)][pitch]
-  int *cand;          // [H*W] row-major pixel index of each candidate
-  int *counters;      // [0] n_cand, [1] n_survivors, [2] n_out, [3] overflow, [8 + l] undecided after launch l
-  unsigned long long *surv_key;  // [surv_cap]
-  int *rank;          // [surv_cap], zero between uses
-  int *out_xy;        // [max_kp][2]
-};
-struct NmsPair { NmsBuffers b[2]; };   // blockIdx.y / blockIdx.z selects the image
+// (NMS_PAD, NMS_COUNTER_INTS, nms_state_pitch, NmsBuffers, NmsPair: spvo_types.hip.h)
 
 __device__ __forceinline__ unsigned long long rank_key(float conf, int x, int y, int H) {
   return ((unsigned long long)(0xFFFFFFFFu - __float_as_uint(conf)) << 32) | (unsigned)(x * H + y);

@@ -25,7 +25,7 @@
 
 #include "../../include/spvo.h"
 
-extern "C" void spvo_internal_set_error(const char *msg);   // spvo_capi.hip: what spvo_last_error(NULL) returns
+extern "C" void spvo_internal_set_error(const char *msg);   // spvo_core.hip: what spvo_last_error(NULL) returns
 
 namespace {
 

@@ -1,0 +1,822 @@
+// spvo_detect.hip -- preprocess (K0), heat map / NMS / descriptor sampling (K7-K11), the detector submissions (addStereoImagePair,
+// feature_detection_neural_network.cpp:449-498), spvo_forward / spvo_debug_tensor, and the ORB detector of the classic front end.
+#include "spvo_internal.hip.h"
+#include "conv_mfma.hip.h"
+#include "post.hip.h"
+#include "orb.hip.h"
+
+namespace spvo_int {
+
+// ---------------------------------------------------------------- resize tables
+void linear_coeffs(int dst, int src, std::vector<int> &idx, std::vector<int> &a0, std::vector<int> &a1) {
+  // OpenCV resize.cpp, INTER_LINEAR, 8-bit: float32 fractional part, 11-bit coefficients
+  const double scale = (double)src / (double)dst;
+  idx.resize(dst); a0.resize(dst); a1.resize(dst);
+  for (int d = 0; d < dst; ++d) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)std::floor(f);
+    f -= (float)s;
+    if (s < 0) { s = 0; f = 0.f; }
+    if (s >= src - 1) { s = src - 1; f = 0.f; }
+    idx[d] = s;
+    a0[d] = (int)std::nearbyint((1.f - f) * 2048.f);
+    a1[d] = (int)std::nearbyint(f * 2048.f);
+  }
+}
+
+struct CropGeom { int row_off, col_off, crop_rows, crop_cols; float scale; };
+
+CropGeom crop_geometry(int rows, int cols, int net_h, int net_w) {
+  // base.cpp:75-119, float32 arithmetic and int truncation as written there
+  CropGeom g{0, 0, rows, cols, 1.f};
+  const float real = (float)cols / (float)rows;
+  const float expected = (float)net_w / (float)net_h;
+  if (expected > real) {
+    g.crop_rows = (int)((float)cols / expected);
+    g.row_off = (rows - g.crop_rows) / 2;
+  } else if (expected < real) {
+    g.crop_cols = (int)((float)rows * expected);
+    g.col_off = (cols - g.crop_cols) / 2;
+  }
+  g.scale = (float)net_w / (float)g.crop_cols;
+  return g;
+}
+
+void fix_projection(double P[12], const CropGeom &g, int rows, int cols, int bug_compat) {
+  if (bug_compat) {
+    // base.cpp:95,111: at<float>(r, 2) on a CV_64F matrix = low 32 bits of P[r][1]
+    float lo;
+    if (g.crop_rows != rows) {
+      std::memcpy(&lo, (char *)&P[4 + 1], 4);
+      lo -= (float)g.row_off;
+      std::memcpy((char *)&P[4 + 1], &lo, 4);
+    } else if (g.crop_cols != cols) {
+      std::memcpy(&lo, (char *)&P[0 + 1], 4);
+      lo -= (float)g.col_off;
+      std::memcpy((char *)&P[0 + 1], &lo, 4);
+    }
+  } else {
+    if (g.crop_rows != rows) P[4 + 2] -= (double)(float)g.row_off;
+    else if (g.crop_cols != cols) P[0 + 2] -= (double)(float)g.col_off;
+  }
+  for (int k = 0; k < 8; ++k) P[k] *= (double)g.scale;  // base.cpp:120
+}
+
+int ensure_tables(spvo_ctx *c, const CropGeom &g) {
+  if (c->tab_rows == g.crop_rows && c->tab_cols == g.crop_cols) return SPVO_OK;
+  std::vector<int> xi, xa0, xa1, yi, yb0, yb1;
+  linear_coeffs(c->W, g.crop_cols, xi, xa0, xa1);
+  linear_coeffs(c->H, g.crop_rows, yi, yb0, yb1);
+  std::vector<int> all;
+  all.insert(all.end(), xi.begin(), xi.end());
+  all.insert(all.end(), xa0.begin(), xa0.end());
+  all.insert(all.end(), xa1.begin(), xa1.end());
+  all.insert(all.end(), yi.begin(), yi.end());
+  all.insert(all.end(), yb0.begin(), yb0.end());
+  all.insert(all.end(), yb1.begin(), yb1.end());
+  HIP_TRY(c, hipMemcpyAsync(c->d_tab, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // `all` is a stack-lifetime buffer
+  c->tab_rows = g.crop_rows;
+  c->tab_cols = g.crop_cols;
+  return SPVO_OK;
+}
+
+// one launch for `count` images (d_src0, d_src1) into slots slot0, slot0 + 1 of the resized-image buffer and the input tensor
+int launch_preprocess(spvo_ctx *c, const uint8_t *d_src0, const uint8_t *d_src1, int count, int rows, int cols, size_t stride, const CropGeom &g, int slot0,
+                      uint8_t *resized_dst = nullptr) {
+  int rc = ensure_tables(c, g);
+  if (rc) return rc;
+  ResizeTab tab;
+  tab.xi = c->d_tab; tab.xa0 = c->d_tab + c->W; tab.xa1 = c->d_tab + 2 * c->W;
+  tab.yi = c->d_tab + 3 * c->W; tab.yb0 = tab.yi + c->H; tab.yb1 = tab.yi + 2 * c->H;
+  const Tensor &tin = c->tensors[c->t_input];
+  const int identity = (g.crop_rows == c->H && g.crop_cols == c->W) ? 1 : 0;
+  dim3 grid((c->W + 63) / 64, (c->H + 3) / 4, count);
+  hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, c->stream, d_src0, d_src1, stride, rows, cols, g.row_off, g.col_off, g.crop_rows, g.crop_cols, tab, c->H, c->W,
+                     (resized_dst ? resized_dst : c->d_resized) + (size_t)slot0 * c->H * c->W, tin.d + (size_t)slot0 * tin.per_image, tin.per_image, tin.hp, tin.wp, identity);
+  HIP_TRY(c, hipGetLastError());
+  return SPVO_OK;
+}
+
+// ---------------------------------------------------------------- NMS pipeline
+constexpr int NMS_INNER = 4;
+constexpr int NMS_GRID = 128;
+
+// NMS counter blocks rotate through RING sets with the submissions: the last NMS kernel of one
+// submission zeroes the block of the next one, so the steady state needs no memset.
+// `set` < RING: a detector submission's buffers and counters; set == RING: the stand-alone entry
+// points (buffers of set 0, counters of their own so that the submissions' blocks stay zeroed).
+NmsPair nms_pair(spvo_ctx *c, int set) {
+  NmsPair p;
+  for (int i = 0; i < 2; ++i) {
+    p.b[i] = c->nms_r[set % RING][i].b;
+    p.b[i].counters = c->d_counters_all + (size_t)(set * 2 + i) * NMS_COUNTER_INTS;
+  }
+  return p;
+}
+
+// `n_launch` round launches + collect + rank + write for `nimg` images, then the counters travel
+// to the host in one copy.  Launch 0 of a batch never exits early.
+int launch_nms_rounds(spvo_ctx *c, int nimg, const NmsPair &np, int set, int n_launch, int *zero_next) {
+  hipStream_t st = c->post;
+  const float *heat = c->d_heat_r[set % RING];
+  for (int l = 0; l < n_launch; ++l) {
+    if (c->cfg.dist_thresh == 4)
+      hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 4>), dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, 4, np, l);
+    else
+      hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 0>), dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, c->cfg.dist_thresh, np, l);
+  }
+  hipLaunchKernelGGL(nms_collect_kernel, dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, c->cfg.border_remove, c->surv_cap, np);
+  hipLaunchKernelGGL(nms_rank_kernel, dim3(128, nimg), dim3(256), 0, st, c->surv_cap, np);
+  hipLaunchKernelGGL(nms_write_kernel, dim3(32, nimg), dim3(256), 0, st, c->H, c->cfg.max_keypoints, c->surv_cap, np, zero_next);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(c->h_counters_r[set % RING], np.b[0].counters, (size_t)nimg * NMS_COUNTER_INTS * sizeof(int), hipMemcpyDeviceToHost, st));
+  return SPVO_OK;
+}
+
+// processOneHeatmap for images [0, nimg).  Real heat maps settle in 2-3 launches of 4 in-kernel
+// rounds; adversarial ones (e.g. a constant image: one decision chain across the whole picture)
+// simply take more batches -- every launch decides at least the best undecided candidate, so the
+// loop terminates.  nms_enqueue only submits; nms_settle runs after the caller's sync and returns
+// 1 if it had to redo work (the caller then re-runs what depends on the keypoints).
+constexpr int NMS_FIRST = 3;
+
+// more rounds for the (rare) submissions whose first batch left candidates undecided
+int nms_settle(spvo_ctx *c, int nimg, const NmsPair &np, int set, bool *redone) {
+  int last = NMS_FIRST;
+  *redone = false;
+  const int *hc = c->h_counters_r[set % RING];
+  for (;;) {
+    bool pending = false;
+    for (int i = 0; i < nimg; ++i) pending |= hc[i * NMS_COUNTER_INTS + 8 + last - 1] != 0;
+    if (!pending) break;
+    *redone = true;
+    last = NMS_MAX_LAUNCH;
+    for (int i = 0; i < nimg; ++i)   // keep n_cand, clear the rest of the block
+      HIP_TRY(c, hipMemsetAsync(np.b[i].counters + 1, 0, (NMS_COUNTER_INTS - 1) * sizeof(int), c->post));
+    int rc = launch_nms_rounds(c, nimg, np, set, last, nullptr);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->post));
+  }
+  for (int i = 0; i < nimg; ++i)
+    if (hc[i * NMS_COUNTER_INTS + 3]) return fail(c, SPVO_ERR_CAPACITY, "NMS survivor buffer overflow");
+  return SPVO_OK;
+}
+
+// stand-alone entry (heat map already in d_heat): threshold + rounds, synchronous
+int run_nms(spvo_ctx *c, int nimg) {
+  const NmsPair np = nms_pair(c, RING);   // its own counter set: the submissions' blocks stay clean
+  for (int i = 0; i < nimg; ++i) HIP_TRY(c, hipMemsetAsync(np.b[i].counters, 0, NMS_COUNTER_INTS * sizeof(int), c->stream));
+  dim3 grid((c->W + 63) / 64, (c->H + 3) / 4, nimg);
+  hipLaunchKernelGGL(nms_threshold_kernel, grid, dim3(256), 0, c->stream, c->d_heat, c->H, c->W, c->cfg.conf_thresh, np);
+  int rc = launch_nms_rounds(c, nimg, np, RING, NMS_FIRST, nullptr);
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  bool redone;
+  return nms_settle(c, nimg, np, RING, &redone);
+}
+
+}  // namespace spvo_int
+
+// ===========================================================================
+extern "C" {
+
+int spvo_preprocess(spvo_ctx *c, const uint8_t *img, int rows, int cols, size_t stride, double P[12], uint8_t *resized_u8) {
+  if (!c || !img || !P || rows <= 0 || cols <= 0 || stride < (size_t)cols) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "detector submissions are in flight: complete them with spvo_detect_wait first");
+  if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  const size_t bytes = (size_t)rows * stride;
+  if (bytes > c->img_cap) {
+    for (int i = 0; i < 2; ++i) { if (c->d_img[i]) (void)hipFree(c->d_img[i]); c->d_img[i] = nullptr; }
+    for (int i = 0; i < 2; ++i) { int rc = dev_alloc(c, &c->d_img[i], bytes, false); if (rc) return rc; }
+    c->img_cap = bytes;
+  }
+  const CropGeom g = crop_geometry(rows, cols, c->H, c->W);
+  HIP_TRY(c, hipMemcpyAsync(c->d_img[0], img, bytes, hipMemcpyHostToDevice, c->stream));
+  int rc = launch_preprocess(c, c->d_img[0], c->d_img[0], 1, rows, cols, stride, g, 0);
+  if (rc) return rc;
+  fix_projection(P, g, rows, cols, c->cfg.bug_compat_p);
+  if (resized_u8) HIP_TRY(c, hipMemcpyAsync(resized_u8, c->d_resized, (size_t)c->H * c->W, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SPVO_OK;
+}
+
+int spvo_forward(spvo_ctx *c, const float *input, int batch, float *det, float *desc_nhwc) {
+  if (!c || !input) return fail(c, SPVO_ERR_INVALID, "null argument");
+  if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "detector submissions are in flight: complete them with spvo_detect_wait first");
+  if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
+  if (batch < 1 || batch > c->B) return fail(c, SPVO_ERR_INVALID, "batch %d out of range", batch);
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  const size_t hw = (size_t)c->H * c->W;
+  const Tensor &tin = c->tensors[c->t_input];
+  HIP_TRY(c, hipMemcpyAsync(c->d_dense_in, input, batch * hw * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(pad_input_kernel, dim3((c->W + 63) / 64, (c->H + 3) / 4, batch), dim3(256), 0, c->stream, c->d_dense_in, tin.d, c->H, c->W, tin.hp, tin.wp);
+  int rc = run_network(c, batch);
+  if (rc) return rc;
+  const Tensor &td = c->tensors[c->t_det];
+  if (det) {
+    hipLaunchKernelGGL(unpad_kernel, dim3((td.W + 63) / 64, (td.H + 3) / 4, batch * 65), dim3(256), 0, c->stream, td.d, c->d_det_dense, 65, td.H, td.W, td.hp, td.wp);
+    HIP_TRY(c, hipMemcpyAsync(det, c->d_det_dense, (size_t)batch * 65 * td.H * td.W * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  }
+  if (desc_nhwc) {
+    const Tensor &ts = c->tensors[c->t_desc];
+    HIP_TRY(c, hipMemcpyAsync(desc_nhwc, ts.d, (size_t)batch * ts.per_image * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SPVO_OK;
+}
+
+int spvo_debug_tensor(spvo_ctx *c, int tensor_id, int batch, float *out, size_t out_floats) {
+  if (!c || !out) return fail(c, SPVO_ERR_INVALID, "null argument");
+  if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "detector submissions are in flight: complete them with spvo_detect_wait first");
+  if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
+  if (tensor_id < 0 || tensor_id >= (int)c->tensors.size() || batch < 1 || batch > c->B) return fail(c, SPVO_ERR_INVALID, "bad tensor id / batch");
+  const Tensor &t = c->tensors[tensor_id];
+  const size_t need = (size_t)batch * t.ch * t.H * t.W;
+  if (out_floats < need) return fail(c, SPVO_ERR_CAPACITY, "need %zu floats", need);
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  if (t.nhwc) {
+    HIP_TRY(c, hipMemcpy(out, t.d, need * sizeof(float), hipMemcpyDeviceToHost));
+    return SPVO_OK;
+  }
+  float *tmp = nullptr;
+  HIP_TRY(c, hipMalloc((void **)&tmp, need * sizeof(float)));
+  if (t.i8) launch_unpad_c16(t, batch, tmp, c->stream);
+  else if (t.s3) launch_unpad_s3(t, batch, tmp, c->stream);
+  else if (t.f16) launch_unpad_c8(t, batch, tmp, c->stream);
+  else hipLaunchKernelGGL(unpad_kernel, dim3((t.W + 63) / 64, (t.H + 3) / 4, batch * t.ch), dim3(256), 0, c->stream, t.d, tmp, t.ch, t.H, t.W, t.hp, t.wp);
+  hipError_t e = hipMemcpyAsync(out, tmp, need * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) return fail(c, SPVO_ERR_DEVICE, "debug copy failed: %s", hipGetErrorString(e));
+  return SPVO_OK;
+}
+
+int spvo_heatmap(spvo_ctx *c, const float *det, float *heat) {
+  if (!c || !det || !heat) return fail(c, SPVO_ERR_INVALID, "null argument");
+  if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "detector submissions are in flight: complete them with spvo_detect_wait first");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  HIP_TRY(c, hipMemcpyAsync(c->d_det_dense, det, (size_t)65 * c->Hc * c->Wc * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(heatmap_kernel<false>, dim3((c->Wc + 63) / 64, (c->Hc + 3) / 4, 1), dim3(256), 0, c->stream, c->d_det_dense, c->d_heat, c->Hc, c->Wc, 0, 0);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(heat, c->d_heat, (size_t)c->H * c->W * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SPVO_OK;
+}
+
+int spvo_nms(spvo_ctx *c, const float *heat, int32_t *xy, int *n) {
+  if (!c || !heat || !xy || !n) return fail(c, SPVO_ERR_INVALID, "null argument");
+  if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "detector submissions are in flight: complete them with spvo_detect_wait first");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  HIP_TRY(c, hipMemcpyAsync(c->d_heat, heat, (size_t)c->H * c->W * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  int rc = run_nms(c, 1);
+  if (rc) return rc;
+  *n = c->h_counters[2];
+  HIP_TRY(c, hipMemcpy(xy, c->nms[0].b.out_xy, (size_t)(*n) * 2 * sizeof(int), hipMemcpyDeviceToHost));
+  return SPVO_OK;
+}
+
+int spvo_sample_descriptors(spvo_ctx *c, const float *desc_nhwc, const int32_t *xy, int n, float *out) {
+  if (!c || !desc_nhwc || (n > 0 && (!xy || !out))) return fail(c, SPVO_ERR_INVALID, "null argument");
+  if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "detector submissions are in flight: complete them with spvo_detect_wait first");
+  if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
+  if (n < 0 || n > c->cfg.max_keypoints) return fail(c, SPVO_ERR_CAPACITY, "n = %d exceeds max_keypoints", n);
+  if (n == 0) return SPVO_OK;
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  const Tensor &ts = c->tensors[c->t_desc];
+  HIP_TRY(c, hipMemcpyAsync(ts.d, desc_nhwc, ts.per_image * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_xy_tmp, xy, (size_t)n * 2 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  SampleJobs sj;
+  sj.j[0] = SampleJob{ts.d, c->d_xy_tmp, nullptr, n, c->d_desc_tmp, nullptr, nullptr, nullptr, nullptr};
+  sj.j[1] = sj.j[0];
+  hipLaunchKernelGGL(sample_desc_kernel, dim3((n + 3) / 4, 1), dim3(256), 0, c->stream, sj, c->H, c->W, c->Hc, c->Wc);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(out, c->d_desc_tmp, (size_t)n * 256 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SPVO_OK;
+}
+
+static int enqueue_sample(spvo_ctx *c, const int slots[2], const NmsPair &np, int ring) {
+  const Tensor &ts = c->tensors[c->t_desc];
+  const float *desc = ts.dr[ring] ? ts.dr[ring] : ts.d;
+  ScopedStage ss(c, stage_id(c, "sample"));
+  const int cap = c->cfg.max_keypoints;
+  float *stage = c->d_xy_stage + (size_t)ring * 2 * cap * 2;
+  SampleJobs sj;
+  for (int i = 0; i < 2; ++i) {
+    FeatureSlot &s = c->slots[slots[i]];
+    // the keypoint count is read from the NMS counters on the device: no host round trip
+    sj.j[i] = SampleJob{desc + (size_t)i * ts.per_image, np.b[i].out_xy, (const int *)(np.b[i].counters + 2), 0, s.d_desc, s.d_sqn,
+                        stage + (size_t)i * cap * 2, s.d_xy, s.d_n};
+  }
+  hipLaunchKernelGGL(sample_desc_kernel, dim3((cap + 3) / 4, 2), dim3(256), 0, c->post, sj, c->H, c->W, c->Hc, c->Wc);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(c->h_xy_r[ring], stage, (size_t)2 * cap * 2 * sizeof(float), hipMemcpyDeviceToHost, c->post));
+  return SPVO_OK;
+}
+
+static int enqueue_prematch(spvo_ctx *c, int slot_l, int slot_r, int prev_l, int ring) {
+  const int cap = c->cfg.max_keypoints;
+  const int partner[2] = {slot_r, prev_l};
+  MatchReq req[2];
+  int nj = 0;
+  for (int k = 0; k < 2; ++k) {
+    MatchCache &mc = c->mcache[ring][k];
+    mc.valid = false;
+    if (partner[k] < 0) continue;
+    FeatureSlot &a = c->slots[slot_l], &b = c->slots[partner[k]];
+    req[nj] = MatchReq{a.d_desc, b.d_desc, cap, cap, a.d_n, b.d_n, a.d_sqn, b.d_sqn};
+    MatchCache &dst = c->mcache[ring][nj];   // job nj's result lands in cache entry nj
+    dst.slot_a = slot_l; dst.slot_b = partner[k];
+    dst.selector = c->pm_selector; dst.cross = c->pm_cross; dst.ratio = c->pm_ratio;
+    dst.valid = true;   // generations are stamped after the slots' counts are known
+    ++nj;
+  }
+  if (nj == 0) return SPVO_OK;
+  return enqueue_matches(c, req, nj, c->pm_selector, c->pm_cross, c->pm_ratio, c->h_match_out[ring]);
+}
+
+// Submission = network on `stream`, then the tail (heat map + NMS, sampling, the two matches and
+// their copies to pinned memory) on `stream_t` behind an event.  Up to MAX_INFLIGHT submissions may
+// be queued: the tail of one overlaps with the network of the next, whose kernels leave CUs idle at
+// their ragged ends.  Every buffer a tail touches belongs to the submission's set (RING of them), so
+// a later submission -- or the rare host-driven NMS redo of an earlier one -- never meets it.
+static int ensure_host_sets(spvo_ctx *c, size_t image_bytes);
+
+// host_l / host_r != NULL: the images are in HOST memory -- they are staged through the set's pinned buffers and copied to the
+// device on the network stream (d_l, d_r are then ignored); extras: see PendingDetect
+static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, int rows, int cols, size_t stride, int slot_l, int slot_r,
+                         const uint8_t *host_l = nullptr, const uint8_t *host_r = nullptr, int extras = 0) {
+  if ((int)c->pendq.size() >= MAX_INFLIGHT) return fail(c, SPVO_ERR_STATE, "%d detector submissions are already in flight", MAX_INFLIGHT);
+  if (slot_l < 0 || slot_l >= N_SLOTS || slot_r < 0 || slot_r >= N_SLOTS || slot_l == slot_r) return fail(c, SPVO_ERR_INVALID, "bad feature slots %d, %d", slot_l, slot_r);
+  for (const auto &q : c->pendq)
+    if (q.slot_l == slot_l || q.slot_r == slot_l || q.slot_l == slot_r || q.slot_r == slot_r || q.prev_l == slot_l || q.prev_l == slot_r)
+      return fail(c, SPVO_ERR_STATE, "feature slots %d, %d are used by a submission in flight", slot_l, slot_r);
+  if (c->cfg.max_batch != 2) return fail(c, SPVO_ERR_INVALID, "max_batch == 1 detect path is not built yet; use max_batch = 2");
+  const CropGeom g = crop_geometry(rows, cols, c->H, c->W);
+  const Tensor &td = c->tensors[c->t_det];
+  const uint8_t *srcs[2] = {d_l, d_r};
+  const int slots[2] = {slot_l, slot_r};
+  if (!host_l && (!d_l || !d_r)) return fail(c, SPVO_ERR_INVALID, "null image");
+  // temporal partner = the left slot of the previous submission, if it survives this one
+  int prev_l = c->last_slot_l;
+  if (prev_l == slot_l || prev_l == slot_r || (prev_l >= 0 && !c->slots[prev_l].filled)) prev_l = -1;
+  if (host_l || extras) {
+    const int rc0 = ensure_host_sets(c, (size_t)rows * stride);
+    if (rc0) return rc0;
+  }
+  const int ring = (int)(c->submit_count++ % RING);
+  for (auto &mc : c->mcache[ring]) mc.valid = false;
+  if (host_l) {   // pageable -> pinned (host copy), pinned -> device (DMA on the network stream): the caller's buffers are free on return
+    const size_t bytes = (size_t)rows * stride;
+    std::memcpy(c->h_img_r[ring], host_l, bytes);
+    std::memcpy(c->h_img_r[ring] + c->img_cap_r, host_r, bytes);
+    HIP_TRY(c, hipMemcpyAsync(c->d_img_r[ring], c->h_img_r[ring], bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_img_r[ring] + c->img_cap_r, c->h_img_r[ring] + c->img_cap_r, bytes, hipMemcpyHostToDevice, c->stream));
+    srcs[0] = c->d_img_r[ring];
+    srcs[1] = c->d_img_r[ring] + c->img_cap_r;
+  }
+  // ---- everything below is enqueued without a host round trip
+  c->cur_ring = ring;
+  c->post = c->stream;
+  // SPVO_TRUNK_TIMING=1 (diagnostic): how long the network stream works per submission and how long it stands idle between two
+  // submissions, from timing events at both ends of the trunk (printed every 200 submissions)
+  static const bool trunk_timing = std::getenv("SPVO_TRUNK_TIMING") != nullptr;
+  constexpr int TT = 8;   // ring of timing events: deeper than the submissions that can be in flight
+  static hipEvent_t tt_b[TT], tt_e[TT];
+  static long tt_n = 0;
+  static double tt_busy = 0, tt_idle = 0;
+  if (trunk_timing) {
+    const double tnow = diag_now_us();
+    if (c->submit_count > 1 && hipEventQuery(c->ev_net[(c->submit_count - 2) % RING]) == hipSuccess) ++g_diag.late;   // the trunk before this one is done already: the stream is idle
+    g_diag.depth_sum += (int)c->pendq.size();
+    if (g_diag.t_last_submit > 0) g_diag.max_interval = std::max(g_diag.max_interval, tnow - g_diag.t_last_submit);
+    g_diag.t_last_submit = tnow;
+    if (tt_n == 0)
+      for (int r = 0; r < TT; ++r) { (void)hipEventCreate(&tt_b[r]); (void)hipEventCreate(&tt_e[r]); }
+    if (tt_n >= TT) {   // the submissions before those that may be in flight are complete: ring slots (n-4) and (n-5)
+      const int r2 = (int)((tt_n - 4) % TT), r3 = (int)((tt_n - 5) % TT);
+      float busy = 0, idle = 0;
+      static int tt_late = 0;
+      static float tt_max = 0;
+      if (hipEventElapsedTime(&busy, tt_b[r2], tt_e[r2]) == hipSuccess && hipEventElapsedTime(&idle, tt_e[r3], tt_b[r2]) == hipSuccess) {
+        tt_busy += busy; tt_idle += idle;
+        tt_late += idle > 0.05f ? 1 : 0;
+        tt_max = std::max(tt_max, idle);
+      }
+      if (tt_n % 200 == 0) {
+        std::fprintf(stderr, "[spvo] trunk timing over 200 submissions: network stream busy %.1f us, idle %.1f us per submission (%d gaps above 50 us, longest %.0f us)\n",
+                     tt_busy * 1e3 / 200, tt_idle * 1e3 / 200, tt_late, tt_max * 1e3);
+        std::fprintf(stderr, "[spvo]   host: longest interval between submissions %.0f us, longest wait for a tail %.0f us, for a solve %.0f us, matches not served from the cache %d; "
+                             "submissions that found the network stream idle %d, mean submissions in flight at submit %.2f\n",
+                     g_diag.max_interval, g_diag.max_tail_wait, g_diag.max_solve_wait, g_diag.match_miss, g_diag.late, g_diag.depth_sum / 200.0);
+        g_diag.max_interval = g_diag.max_tail_wait = g_diag.max_solve_wait = 0; g_diag.match_miss = 0; g_diag.late = 0; g_diag.depth_sum = 0;
+        tt_busy = tt_idle = 0; tt_late = 0; tt_max = 0;
+      }
+    }
+    (void)hipEventRecord(tt_b[tt_n % TT], c->stream);
+  }
+  hipEvent_t det_e0 = nullptr;
+  const bool prof_detect = c->prof && (c->prof_only < 0 || c->prof_only == stage_id(c, "detect"));
+  if (prof_detect) { det_e0 = get_event(c); (void)hipEventRecord(det_e0, c->stream); }
+  {
+    ScopedStage sp(c, stage_id(c, "preprocess"));
+    int rc = launch_preprocess(c, srcs[0], srcs[1], 2, rows, cols, stride, g, 0, (extras & 1) ? c->d_resized_r[ring] : nullptr);
+    if (rc) return rc;
+  }
+  int rc;
+  {
+    ScopedStage net(c, stage_id(c, "net"));
+    rc = run_ops(c, 2, 0, c->head_start, c->stream);
+  }
+  if (rc) { c->cur_ring = 0; return rc; }
+  c->last_batch = 2;
+  if (trunk_timing) { (void)hipEventRecord(tt_e[tt_n % 8], c->stream); ++tt_n; }
+  HIP_TRY(c, hipEventRecord(c->ev_net[ring], c->stream));
+  HIP_TRY(c, hipStreamWaitEvent(c->stream_t, c->ev_net[ring], 0));
+  c->post = c->stream_t;
+  rc = run_ops(c, 2, c->head_start, c->ops.size(), c->stream_t);   // heads: on the tail stream, reading this submission's ring buffers
+  c->cur_ring = 0;
+  if (rc) { c->post = c->stream; return rc; }
+  const NmsPair np = nms_pair(c, ring);
+  {
+    // heat map + threshold + candidate list in one kernel; the counter block of this set was
+    // zeroed by the previous submission's last NMS kernel (or at allocation)
+    ScopedStage sh(c, stage_id(c, "heatmap"));
+    hipLaunchKernelGGL(heatmap_nms_kernel, dim3((c->Wc + 63) / 64, (c->Hc + 3) / 4, 2), dim3(256), 0, c->post, td.dr[ring], c->d_heat_r[ring], c->Hc, c->Wc, td.hp, td.wp,
+                       c->cfg.conf_thresh, np);
+    HIP_TRY(c, hipGetLastError());
+  }
+  {
+    ScopedStage sn(c, stage_id(c, "nms"));
+    rc = launch_nms_rounds(c, 2, np, ring, NMS_FIRST, c->d_counters_all + (size_t)(((ring + 1) % RING) * 2) * NMS_COUNTER_INTS);
+  }
+  if (!rc) rc = enqueue_sample(c, slots, np, ring);
+  if (!rc && c->prematch) rc = enqueue_prematch(c, slot_l, slot_r, prev_l, ring);
+  if (!rc && (extras & 1))   // resized images (what nn.cpp:154 pushes to images_dq) -> the set's pinned mirror
+    rc = hipMemcpyAsync(c->h_resized_r[ring], c->d_resized_r[ring], (size_t)2 * c->H * c->W, hipMemcpyDeviceToHost, c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipMemcpyAsync failed");
+  if (!rc && (extras & 2)) {   // descriptors of both images: whole slots (the counts are not known on the host yet; rows >= n are stale)
+    const size_t per = (size_t)c->cfg.max_keypoints * 256;
+    for (int i = 0; i < 2 && !rc; ++i)
+      rc = hipMemcpyAsync(c->h_desc_r[ring] + i * per, c->slots[slots[i]].d_desc, per * sizeof(float), hipMemcpyDeviceToHost, c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipMemcpyAsync failed");
+  }
+  if (!rc && prof_detect) {   // "detect" spans both streams: first kernel on `stream` .. last copy on `stream_t`
+    hipEvent_t e1 = get_event(c);
+    (void)hipEventRecord(e1, c->stream_t);
+    c->pending.push_back({stage_id(c, "detect"), det_e0, e1});
+  }
+  if (!rc) rc = (hipEventRecord(c->ev_tail[ring], c->stream_t) == hipSuccess) ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");
+  c->post = c->stream;
+  if (rc) return rc;
+  for (int i = 0; i < 2; ++i) c->slots[slots[i]].filled = true;
+  c->last_slot_l = slot_l;
+  PendingDetect pd;
+  pd.g = CropGeomS{g.row_off, g.col_off, g.crop_rows, g.crop_cols, g.scale};
+  pd.rows = rows; pd.cols = cols;
+  pd.slot_l = slot_l; pd.slot_r = slot_r; pd.prev_l = prev_l; pd.ring = ring; pd.extras = extras;
+  c->pendq.push_back(pd);
+  return SPVO_OK;
+}
+
+// completes the OLDEST submission
+static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_features *out_l, spvo_features *out_r, uint8_t *resized_l, uint8_t *resized_r) {
+  if (c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "no detector submission in flight");
+  const PendingDetect pd = c->pendq.front();
+  const int slots[2] = {pd.slot_l, pd.slot_r};
+  const int cap = c->cfg.max_keypoints;
+  uint8_t *res[2] = {resized_l, resized_r};
+  spvo_features *outs[2] = {out_l, out_r};
+  const bool want_res = resized_l || resized_r, want_desc = (out_l && out_l->desc) || (out_r && out_r->desc);
+  // what the submission staged into its own pinned mirrors is simply read there; anything else has to be copied now, from buffers a
+  // younger submission may already be rewriting -- refused BEFORE the submission is taken off the queue
+  const bool extras = (want_res && !(pd.extras & 1)) || (want_desc && !(pd.extras & 2));
+  if (extras && c->pendq.size() > 1) return fail(c, SPVO_ERR_STATE, "resized images / host descriptors can only be fetched with one submission in flight (or request them at spvo_detect_submit)");
+  c->pendq.pop_front();
+  c->post = c->stream_t;
+  auto copy_extras = [&]() -> int {
+    if (!(pd.extras & 1))
+      for (int i = 0; i < 2; ++i)
+        if (res[i]) HIP_TRY(c, hipMemcpyAsync(res[i], c->d_resized + (size_t)i * c->H * c->W, (size_t)c->H * c->W, hipMemcpyDeviceToHost, c->post));
+    // descriptors: copy the full slot (1000 x 256 floats); rows >= n are stale
+    if (!(pd.extras & 2))
+      for (int i = 0; i < 2; ++i)
+        if (outs[i] && outs[i]->desc) HIP_TRY(c, hipMemcpyAsync(outs[i]->desc, c->slots[slots[i]].d_desc, (size_t)cap * 256 * sizeof(float), hipMemcpyDeviceToHost, c->post));
+    return SPVO_OK;
+  };
+  auto restage = [&]() -> int {   // after an NMS redo the set's mirrors are refreshed too
+    if (pd.extras & 2)
+      for (int i = 0; i < 2; ++i)
+        HIP_TRY(c, hipMemcpyAsync(c->h_desc_r[pd.ring] + (size_t)i * cap * 256, c->slots[slots[i]].d_desc, (size_t)cap * 256 * sizeof(float), hipMemcpyDeviceToHost, c->post));
+    return SPVO_OK;
+  };
+  int rc = SPVO_OK;
+  if (extras) {
+    if ((rc = copy_extras())) { c->post = c->stream; return rc; }
+    rc = hipStreamSynchronize(c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "stream synchronisation failed");
+  } else {
+    // only this submission's tail: a younger one may be queued behind it on both streams
+    const double tw0 = diag_now_us();
+    rc = wait_event(c->ev_tail[pd.ring]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");
+    g_diag.max_tail_wait = std::max(g_diag.max_tail_wait, diag_now_us() - tw0);
+  }
+  bool redone = false;
+  const NmsPair np = nms_pair(c, pd.ring);
+  if (!rc) rc = nms_settle(c, 2, np, pd.ring, &redone);
+  if (!rc && (redone || pd.rematch)) {   // rare: keypoints changed after the first batch -> redo what depends on them
+    if (redone) c->stages[stage_id(c, "nms_redo")].calls += 1;       // counted even with profiling off (tests, diagnostics)
+    if (pd.rematch) c->stages[stage_id(c, "rematch")].calls += 1;
+    if (redone) rc = enqueue_sample(c, slots, np, pd.ring);
+    if (!rc && c->prematch) rc = enqueue_prematch(c, pd.slot_l, pd.slot_r, pd.prev_l, pd.ring);
+    if (!rc && extras) rc = copy_extras();
+    if (!rc && redone) rc = restage();
+    if (!rc) rc = hipStreamSynchronize(c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "stream synchronisation failed");
+    if (redone)
+      for (auto &q : c->pendq)
+        if (q.prev_l == pd.slot_l) q.rematch = true;   // it matched against keypoints that have just been replaced
+  }
+  c->post = c->stream;
+  if (rc) return rc;
+  const int *hc = c->h_counters_r[pd.ring];
+  for (int i = 0; i < 2; ++i) {
+    FeatureSlot &s = c->slots[slots[i]];
+    s.n = hc[i * NMS_COUNTER_INTS + 2];
+    s.gen += 1;
+    if (outs[i]) {
+      outs[i]->n = s.n;
+      if (outs[i]->xy && s.n > 0) std::memcpy(outs[i]->xy, c->h_xy_r[pd.ring] + (size_t)i * cap * 2, (size_t)s.n * 2 * sizeof(float));
+      if (outs[i]->desc && (pd.extras & 2) && s.n > 0) std::memcpy(outs[i]->desc, c->h_desc_r[pd.ring] + (size_t)i * cap * 256, (size_t)s.n * 256 * sizeof(float));
+    }
+    if (res[i] && (pd.extras & 1)) std::memcpy(res[i], c->h_resized_r[pd.ring] + (size_t)i * c->H * c->W, (size_t)c->H * c->W);
+  }
+  for (auto &mc : c->mcache[pd.ring])
+    if (mc.valid) { mc.gen_a = c->slots[mc.slot_a].gen; mc.gen_b = c->slots[mc.slot_b].gen; }
+  const CropGeom g{pd.g.row_off, pd.g.col_off, pd.g.crop_rows, pd.g.crop_cols, pd.g.scale};
+  if (P_l) fix_projection(P_l, g, pd.rows, pd.cols, c->cfg.bug_compat_p);
+  if (P_r) fix_projection(P_r, g, pd.rows, pd.cols, c->cfg.bug_compat_p);
+  return SPVO_OK;
+}
+
+// buffers of the host-image submissions: allocated on first use, grown when a larger image arrives (never while submissions are in flight)
+static int ensure_host_sets(spvo_ctx *c, size_t image_bytes) {
+  const size_t hw2 = (size_t)2 * c->H * c->W, desc = (size_t)2 * c->cfg.max_keypoints * 256;
+  if (!c->d_resized_r[0]) {
+    for (int r = 0; r < RING; ++r) {
+      int rc = dev_alloc(c, &c->d_resized_r[r], hw2, false);
+      if (rc) return rc;
+      HIP_TRY(c, hipHostMalloc((void **)&c->h_resized_r[r], hw2));
+      HIP_TRY(c, hipHostMalloc((void **)&c->h_desc_r[r], desc * sizeof(float)));
+    }
+  }
+  if (image_bytes > c->img_cap_r) {
+    if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "the image size grew while submissions are in flight");
+    HIP_TRY(c, hipDeviceSynchronize());
+    for (int r = 0; r < RING; ++r) {
+      if (c->d_img_r[r]) (void)hipFree(c->d_img_r[r]);
+      if (c->h_img_r[r]) (void)hipHostFree(c->h_img_r[r]);
+      c->d_img_r[r] = c->h_img_r[r] = nullptr;
+    }
+    c->img_cap_r = 0;
+    for (int r = 0; r < RING; ++r) {
+      int rc = dev_alloc(c, &c->d_img_r[r], 2 * image_bytes, false);
+      if (rc) return rc;
+      HIP_TRY(c, hipHostMalloc((void **)&c->h_img_r[r], 2 * image_bytes));
+    }
+    c->img_cap_r = image_bytes;
+  }
+  return SPVO_OK;
+}
+
+static int detect_common(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, int rows, int cols, size_t stride, double P_l[12], double P_r[12],
+                         int slot_l, int slot_r, spvo_features *out_l, spvo_features *out_r, uint8_t *resized_l, uint8_t *resized_r) {
+  int rc = detect_submit(c, d_l, d_r, rows, cols, stride, slot_l, slot_r);
+  if (rc) return rc;
+  return detect_wait(c, P_l, P_r, out_l, out_r, resized_l, resized_r);
+}
+
+int spvo_detect(spvo_ctx *c, const uint8_t *img_l, const uint8_t *img_r, int rows, int cols, size_t stride, double P_l[12], double P_r[12],
+                int slot_l, int slot_r, spvo_features *out_l, spvo_features *out_r, uint8_t *resized_l, uint8_t *resized_r) {
+  if (!c || !img_l || !img_r || !P_l || !P_r || rows <= 0 || cols <= 0 || stride < (size_t)cols) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "detector submissions are in flight: complete them with spvo_detect_wait first");
+  if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  const size_t bytes = (size_t)rows * stride;
+  if (bytes > c->img_cap) {
+    for (int i = 0; i < 2; ++i) { if (c->d_img[i]) (void)hipFree(c->d_img[i]); c->d_img[i] = nullptr; }
+    for (int i = 0; i < 2; ++i) { int rc = dev_alloc(c, &c->d_img[i], bytes, false); if (rc) return rc; }
+    c->img_cap = bytes;
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->d_img[0], img_l, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_img[1], img_r, bytes, hipMemcpyHostToDevice, c->stream));
+  return detect_common(c, c->d_img[0], c->d_img[1], rows, cols, stride, P_l, P_r, slot_l, slot_r, out_l, out_r, resized_l, resized_r);
+}
+
+int spvo_detect_dev(spvo_ctx *c, const void *d_img_l, const void *d_img_r, int rows, int cols, size_t stride, double P_l[12], double P_r[12],
+                    int slot_l, int slot_r, spvo_features *out_l, spvo_features *out_r) {
+  if (!c || !d_img_l || !d_img_r || !P_l || !P_r || rows <= 0 || cols <= 0 || stride < (size_t)cols) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "detector submissions are in flight: complete them with spvo_detect_wait first");
+  if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  return detect_common(c, (const uint8_t *)d_img_l, (const uint8_t *)d_img_r, rows, cols, stride, P_l, P_r, slot_l, slot_r, out_l, out_r, nullptr, nullptr);
+}
+
+int spvo_detect_dev_submit(spvo_ctx *c, const void *d_img_l, const void *d_img_r, int rows, int cols, size_t stride, int slot_l, int slot_r) {
+  if (!c || !d_img_l || !d_img_r || rows <= 0 || cols <= 0 || stride < (size_t)cols) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  return detect_submit(c, (const uint8_t *)d_img_l, (const uint8_t *)d_img_r, rows, cols, stride, slot_l, slot_r);
+}
+
+int spvo_detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_features *out_l, spvo_features *out_r) {
+  if (!c) return fail(c, SPVO_ERR_INVALID, "null context");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  return detect_wait(c, P_l, P_r, out_l, out_r, nullptr, nullptr);
+}
+
+int spvo_detect_submit(spvo_ctx *c, const uint8_t *img_l, const uint8_t *img_r, int rows, int cols, size_t stride, int slot_l, int slot_r, int extras) {
+  if (!c || !img_l || !img_r || rows <= 0 || cols <= 0 || stride < (size_t)cols || (extras & ~3)) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  return detect_submit(c, nullptr, nullptr, rows, cols, stride, slot_l, slot_r, img_l, img_r, extras);
+}
+
+int spvo_detect_collect(spvo_ctx *c, double P_l[12], double P_r[12], spvo_features *out_l, spvo_features *out_r, uint8_t *resized_l, uint8_t *resized_r) {
+  if (!c) return fail(c, SPVO_ERR_INVALID, "null context");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  return detect_wait(c, P_l, P_r, out_l, out_r, resized_l, resized_r);
+}
+
+// ---------------------------------------------------------------- ORB (classic front end, orb.hip.h)
+namespace {
+uint32_t host_hash32(uint32_t x) { x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16; return x; }
+// the 256 test pairs: isotropic Gaussian of the original BRIEF (sigma = patch / 5), fixed seed, rounded, kept inside the patch
+// (the same construction as oracle/cpu/orb_cpu.inc; tests/test_gpu_orb.py compares the two tables)
+void orb_host_tables(std::vector<float> &pattern, float taps[7], std::vector<signed char> &disc) {
+  constexpr int PATCH = 31, HALF = ORB_HALF;
+  pattern.resize(1024);
+  uint32_t state = 0x9E3779B9u;
+  auto uni = [&]() { state = host_hash32(state + 0x6D2B79F5u); return ((state >> 8) + 0.5f) / 16777216.0f; };
+  auto gauss = [&]() { const float u1 = uni(), u2 = uni(); return std::sqrt(-2.0f * std::log(u1)) * std::cos(6.2831853f * u2); };
+  for (int i = 0; i < 1024; ++i) {
+    float v = gauss() * (PATCH / 5.0f);
+    v = std::min(std::max(v, -(float)(HALF - 2)), (float)(HALF - 2));
+    pattern[i] = std::round(v);
+  }
+  float sum = 0;
+  for (int i = 0; i < 7; ++i) { taps[i] = std::exp(-0.5f * (i - 3) * (i - 3) / 4.0f); sum += taps[i]; }
+  for (int i = 0; i < 7; ++i) taps[i] /= sum;
+  disc.clear();
+  for (int dy = -HALF; dy <= HALF; ++dy) {
+    const int lim = (int)std::floor(std::sqrt((double)HALF * HALF - dy * dy));
+    for (int dx = -lim; dx <= lim; ++dx) { disc.push_back((signed char)dx); disc.push_back((signed char)dy); }
+  }
+}
+}  // namespace
+
+int spvo_orb_tables(float *pattern, float *taps) {
+  std::vector<float> p;
+  std::vector<signed char> d;
+  float t[7];
+  orb_host_tables(p, t, d);
+  if (pattern) std::memcpy(pattern, p.data(), 1024 * sizeof(float));
+  if (taps) std::memcpy(taps, t, sizeof t);
+  return SPVO_OK;
+}
+
+int spvo_orb_detect(spvo_ctx *c, const uint8_t *img, int rows, int cols, size_t stride, int nfeatures, spvo_orb_keypoint *kps, uint8_t *desc, int cap, int *n_out) {
+  if (!c || !img || !n_out || rows <= 0 || cols <= 0 || stride < (size_t)cols || nfeatures <= 0 || cap < 0 || (cap > 0 && (!kps || !desc)))
+    return fail(c, SPVO_ERR_INVALID, "bad argument");
+  static_assert(sizeof(spvo_orb_keypoint) == sizeof(OrbKeypoint), "keypoint records differ");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  *n_out = 0;
+  hipStream_t st = c->stream2;
+  auto &o = c->orb;
+  // ---- level geometry and per-level quota (the reference's parameters: 8 levels, scale 1.2)
+  constexpr float SCALE = 1.2f;
+  int ph[ORB_LEVELS], pw[ORB_LEVELS], want[ORB_LEVELS];
+  float lscale[ORB_LEVELS];
+  size_t off[ORB_LEVELS + 1];
+  {
+    float scale = 1.f;
+    const float f = 1.0f / SCALE;
+    float n_level = nfeatures * (1 - f) / (1 - std::pow(f, (float)ORB_LEVELS));
+    int assigned = 0;
+    off[0] = 0;
+    for (int l = 0; l < ORB_LEVELS; ++l, scale *= SCALE) {
+      ph[l] = (int)std::lround(rows / scale); pw[l] = (int)std::lround(cols / scale);
+      lscale[l] = scale;
+      want[l] = l == ORB_LEVELS - 1 ? std::max(nfeatures - assigned, 0) : (int)std::lround(n_level);
+      assigned += want[l];
+      n_level *= f;
+      off[l + 1] = off[l] + (((size_t)ph[l] * pw[l] + 255) & ~(size_t)255);
+    }
+  }
+  const size_t px0 = (size_t)rows * cols;
+  const int surv_cap = (rows / 2 + 1) * (cols / 2 + 1);   // 3x3 suppression: at most one survivor per 2x2 block
+  const int kp_cap = nfeatures;
+  if (px0 > o.px_cap || kp_cap > o.kp_cap) {
+    HIP_TRY(c, hipStreamSynchronize(st));
+    for (void *p : {(void *)o.im, (void *)o.score, (void *)o.blur, (void *)o.tmp, (void *)o.keys, (void *)o.rank, (void *)o.out_xy, (void *)o.counters, (void *)o.tab,
+                    (void *)o.kps, (void *)o.desc}) if (p) (void)hipFree(p);
+    o.im = o.score = o.blur = nullptr; o.tmp = nullptr; o.keys = nullptr; o.rank = o.out_xy = o.counters = o.tab = nullptr; o.kps = nullptr; o.desc = nullptr;
+    o.px_cap = 0; o.kp_cap = 0;
+    int rc;
+    const size_t pyr = off[ORB_LEVELS] + 256, kall = (size_t)5 * surv_cap;   // all levels side by side (sum of 1 / 1.44^l < 3.3)
+    if ((rc = dev_alloc(c, &o.im, pyr)) || (rc = dev_alloc(c, &o.score, pyr)) || (rc = dev_alloc(c, &o.blur, pyr)) || (rc = dev_alloc(c, &o.tmp, pyr)) ||
+        (rc = dev_alloc(c, &o.keys, kall)) || (rc = dev_alloc(c, &o.rank, kall)) || (rc = dev_alloc(c, &o.out_xy, 2 * kall)) ||
+        (rc = dev_alloc(c, &o.counters, (size_t)ORB_LEVELS * NMS_COUNTER_INTS)) || (rc = dev_alloc(c, &o.tab, (size_t)16 * (rows + cols))) || (rc = dev_alloc(c, &o.kps, kp_cap)) ||
+        (rc = dev_alloc(c, &o.desc, (size_t)kp_cap * 32)))
+      return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // (dev_alloc clears on the network stream)
+    o.px_cap = px0; o.kp_cap = kp_cap;
+    o.tab_rows = o.tab_cols = 0;
+  }
+  // resize tables of all levels, one upload per image size
+  size_t toff[ORB_LEVELS] = {0};
+  {
+    size_t t = 0;
+    for (int l = 1; l < ORB_LEVELS; ++l) { toff[l] = t; t += (size_t)3 * (pw[l] + ph[l]); }
+    if (o.tab_rows != rows || o.tab_cols != cols) {
+      std::vector<int> all, xi, xa0, xa1, yi, yb0, yb1;
+      for (int l = 1; l < ORB_LEVELS; ++l) {
+        linear_coeffs(pw[l], pw[l - 1], xi, xa0, xa1);
+        linear_coeffs(ph[l], ph[l - 1], yi, yb0, yb1);
+        for (auto *v : {&xi, &xa0, &xa1, &yi, &yb0, &yb1}) all.insert(all.end(), v->begin(), v->end());
+      }
+      HIP_TRY(c, hipStreamSynchronize(st));
+      HIP_TRY(c, hipMemcpy(o.tab, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice));
+      o.tab_rows = rows; o.tab_cols = cols;
+    }
+  }
+  if (!o.pattern) {
+    std::vector<float> pat;
+    std::vector<signed char> disc;
+    float taps[7];
+    orb_host_tables(pat, taps, disc);
+    int rc;
+    if ((rc = dev_alloc(c, &o.pattern, 1024)) || (rc = dev_alloc(c, &o.taps, 8)) || (rc = dev_alloc(c, &o.disc, disc.size()))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(o.pattern, pat.data(), 1024 * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(o.taps, taps, 7 * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(o.disc, disc.data(), disc.size(), hipMemcpyHostToDevice));
+  }
+  if ((size_t)rows * stride > o.src_cap) {
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (o.src) (void)hipFree(o.src);
+    o.src = nullptr; o.src_cap = 0;
+    int rc = dev_alloc(c, &o.src, (size_t)rows * stride, false);
+    if (rc) return rc;
+    o.src_cap = (size_t)rows * stride;
+  }
+  HIP_TRY(c, hipMemcpyAsync(o.src, img, (size_t)rows * stride, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpy2DAsync(o.im, cols, o.src, stride, cols, rows, hipMemcpyDeviceToDevice, st));   // level 0: the image, rows packed
+  // the whole image is enqueued without a host round trip: the pyramid level by level, then every stage once for all levels;
+  // one counter block per level, a level's keypoints land behind those of the levels below (orb_describe_kernel sums their counts)
+  HIP_TRY(c, hipMemsetAsync(o.counters, 0, (size_t)ORB_LEVELS * NMS_COUNTER_INTS * sizeof(int), st));
+  OrbLevels lv;
+  size_t koff = 0;
+  int want_max = 0;
+  for (int l = 0; l < ORB_LEVELS; ++l) {
+    OrbLevel &L = lv.l[l];
+    const int lcap = std::min(surv_cap, (ph[l] / 2 + 1) * (pw[l] / 2 + 1));
+    L.im = o.im + off[l]; L.score = o.score + off[l]; L.blur = o.blur + off[l]; L.tmp = o.tmp + off[l];
+    L.keys = o.keys + koff; L.rank = o.rank + koff; L.out_xy = o.out_xy + 2 * koff; L.counters = o.counters + l * NMS_COUNTER_INTS;
+    L.h = ph[l]; L.w = pw[l]; L.cap = lcap; L.scale = lscale[l];
+    L.want = (ph[l] <= 2 * ORB_EDGE + 2 || pw[l] <= 2 * ORB_EDGE + 2) ? 0 : want[l];
+    want_max = std::max(want_max, L.want);
+    koff += lcap;
+    if (l > 0) hipLaunchKernelGGL(orb_resize_kernel, dim3((pw[l] + 63) / 64, (ph[l] + 3) / 4), dim3(256), 0, st, o.im + off[l - 1], ph[l - 1], pw[l - 1], pw[l - 1], L.im, ph[l], pw[l],
+                                  o.tab + toff[l]);
+  }
+  if (want_max > 0) {
+    const dim3 grid((cols + 63) / 64, (rows + 3) / 4, ORB_LEVELS);
+    hipLaunchKernelGGL(orb_fast_kernel, grid, dim3(256), 0, st, lv, ORB_FAST_T);
+    hipLaunchKernelGGL(orb_collect_kernel, grid, dim3(256), 0, st, lv);
+    hipLaunchKernelGGL(orb_rank_kernel, dim3(128, ORB_LEVELS), dim3(256), 0, st, lv);
+    hipLaunchKernelGGL(orb_write_kernel, dim3(32, ORB_LEVELS), dim3(256), 0, st, lv);
+    hipLaunchKernelGGL(orb_blur_h_kernel, grid, dim3(256), 0, st, lv, o.taps);
+    hipLaunchKernelGGL(orb_blur_v_kernel, grid, dim3(256), 0, st, lv, o.taps);
+    hipLaunchKernelGGL(orb_describe_kernel, dim3((want_max + 3) / 4, ORB_LEVELS), dim3(256), 0, st, lv, o.disc, o.pattern, o.kps, o.desc, kp_cap);
+  }
+  HIP_TRY(c, hipGetLastError());
+  int cnt[ORB_LEVELS * NMS_COUNTER_INTS];
+  HIP_TRY(c, hipMemcpyAsync(cnt, o.counters, sizeof cnt, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipStreamSynchronize(st));
+  int base = 0;
+  for (int l = 0; l < ORB_LEVELS; ++l) {
+    if (cnt[l * NMS_COUNTER_INTS + 3]) return fail(c, SPVO_ERR_CAPACITY, "ORB: corner buffer overflow at level %d", l);
+    base += cnt[l * NMS_COUNTER_INTS + 2];
+  }
+  base = std::min(base, kp_cap);
+  *n_out = base;
+  const int ncopy = std::min(base, cap);
+  if (ncopy > 0) {
+    HIP_TRY(c, hipMemcpyAsync(kps, o.kps, (size_t)ncopy * sizeof(OrbKeypoint), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(desc, o.desc, (size_t)ncopy * 32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+  }
+  return SPVO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,298 @@
+// spvo_solve.hip -- solveStereoOdometry (feature_detection_base.cpp:125-399) on the device: K14 triangulation, K15 PnP-RANSAC, gating, K16 LM.
+#include "spvo_internal.hip.h"
+#include "odometry.hip.h"
+
+namespace spvo_int {
+
+int ensure_odometry(spvo_ctx *c, int n, int iterations, int n_obs) {
+  int rc;
+  if (!c->d_P) {
+    if ((rc = dev_alloc(c, &c->d_P, 64))) return rc;
+    if ((rc = dev_alloc(c, &c->rw.result, 8))) return rc;
+    if ((rc = dev_alloc(c, &c->d_refine, 1))) return rc;
+  }
+  // a buffer is cleared as it is freed and its capacity drops to 0 before the reallocation: a failure half-way leaves a context
+  // that spvo_destroy and a later call can still handle
+  auto drop = [](auto *&p) { if (p) (void)hipFree(p); p = nullptr; };
+  if (n > c->odo_cap) {
+    const int cap = std::max(n, 2048);
+    c->odo_cap = 0;
+    drop(c->d_pts_a); drop(c->d_pts_b); drop(c->d_xyz); drop(c->rw.inliers);
+    if ((rc = dev_alloc(c, &c->d_pts_a, (size_t)cap * 3))) return rc;
+    if ((rc = dev_alloc(c, &c->d_pts_b, (size_t)cap * 3))) return rc;
+    if ((rc = dev_alloc(c, &c->d_xyz, (size_t)cap * 3))) return rc;
+    if ((rc = dev_alloc(c, &c->rw.inliers, cap))) return rc;
+    c->odo_cap = cap;
+  }
+  if (iterations > c->ransac_cap) {
+    const int cap = std::max(iterations, 512);
+    c->ransac_cap = 0;
+    drop(c->rw.counts); drop(c->rw.poses);
+    if ((rc = dev_alloc(c, &c->rw.counts, cap))) return rc;
+    if ((rc = dev_alloc(c, &c->rw.poses, (size_t)cap * 7))) return rc;
+    c->ransac_cap = cap;
+  }
+  if (n_obs > c->obs_cap) {
+    const int cap = std::max(n_obs, 8192);
+    c->obs_cap = 0;
+    drop(c->d_obs);
+    if ((rc = dev_alloc(c, &c->d_obs, cap))) return rc;
+    c->obs_cap = cap;
+  }
+  return SPVO_OK;
+}
+
+}  // namespace spvo_int
+
+// ===========================================================================
+extern "C" {
+
+int spvo_triangulate(spvo_ctx *c, const double P_l[12], const double P_r[12], const float *xy_l, const float *xy_r, int n, float *xyz) {
+  if (!c || !P_l || !P_r || n < 0 || (n > 0 && (!xy_l || !xy_r || !xyz))) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  if (n == 0) return SPVO_OK;
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  if (c->solve_pending.active) return fail(c, SPVO_ERR_STATE, "a solve is pending (spvo_solve_submit): complete it with spvo_solve_wait first");
+  int rc = ensure_odometry(c, n, 0, 0);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->d_P, P_l, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_P + 12, P_r, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_pts_a, xy_l, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_pts_b, xy_r, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  {
+    ScopedStage st(c, stage_id(c, "triangulate"));
+    hipLaunchKernelGGL(triangulate_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->d_P, c->d_P + 12, c->d_pts_a, c->d_pts_b, n, c->d_xyz);
+  }
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(xyz, c->d_xyz, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SPVO_OK;
+}
+
+int spvo_pnp_ransac(spvo_ctx *c, const double K[9], const float *xyz, const float *xy, int n, const spvo_ransac_opts *opts, double rvec[3], double tvec[3],
+                    int32_t *inliers, int *n_inliers, int *ok) {
+  if (!c || !K || !rvec || !tvec || !n_inliers || !ok || n < 0 || (n > 0 && (!xyz || !xy || !inliers))) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  spvo_ransac_opts o = {500, 2.0, 0.999, 0};
+  if (opts) o = *opts;
+  if (o.iterations <= 0 || o.iterations > 65536 || !(o.reproj_error > 0)) return fail(c, SPVO_ERR_INVALID, "bad RANSAC options");
+  *ok = 0;
+  *n_inliers = 0;
+  if (n < 4) return SPVO_OK;  // not enough points for a model: prior is kept
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  if (c->solve_pending.active) return fail(c, SPVO_ERR_STATE, "a solve is pending (spvo_solve_submit): complete it with spvo_solve_wait first");
+  int rc = ensure_odometry(c, n, o.iterations, 0);
+  if (rc) return rc;
+  double prior[6] = {rvec[0], rvec[1], rvec[2], tvec[0], tvec[1], tvec[2]};
+  HIP_TRY(c, hipMemcpyAsync(c->d_P + 24, K, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_P + 33, prior, 6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_pts_a, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_pts_b, xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  {
+    ScopedStage st(c, stage_id(c, "ransac"));
+    hipLaunchKernelGGL(ransac_hypothesis_kernel, dim3(o.iterations), dim3(64), 0, c->stream, c->d_P + 24, c->d_pts_a, c->d_pts_b, n, c->d_P + 33, o.seed, o.reproj_error * o.reproj_error, c->rw);
+    hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(256), 0, c->stream, c->d_P + 24, c->d_pts_a, c->d_pts_b, n, c->d_P + 33, o.iterations, o.reproj_error * o.reproj_error, c->rw);
+  }
+  HIP_TRY(c, hipGetLastError());
+  double res[8];
+  HIP_TRY(c, hipMemcpyAsync(res, c->rw.result, sizeof res, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  *ok = res[6] != 0;
+  *n_inliers = (int)res[7];
+  for (int k = 0; k < 3; ++k) { rvec[k] = res[k]; tvec[k] = res[3 + k]; }
+  if (*n_inliers > 0) HIP_TRY(c, hipMemcpy(inliers, c->rw.inliers, (size_t)(*n_inliers) * sizeof(int), hipMemcpyDeviceToHost));
+  return SPVO_OK;
+}
+
+int spvo_pnp_refine(spvo_ctx *c, const double P_l[12], const double P_r[12], const spvo_obs *obs, int n_obs, const spvo_refine_opts *opts, double q[4], double t[3],
+                    spvo_refine_summary *summary) {
+  if (!c || !P_l || !P_r || !q || !t || n_obs < 0 || (n_obs > 0 && !obs)) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  spvo_refine_opts o = {40, 1.0};
+  if (opts) o = *opts;
+  if (o.max_iterations < 0 || !(o.huber_delta > 0)) return fail(c, SPVO_ERR_INVALID, "bad refine options");
+  static_assert(sizeof(spvo_obs) == sizeof(ObsDev), "spvo_obs layout");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  if (c->solve_pending.active) return fail(c, SPVO_ERR_STATE, "a solve is pending (spvo_solve_submit): complete it with spvo_solve_wait first");
+  int rc = ensure_odometry(c, 0, 0, n_obs);
+  if (rc) return rc;
+  double start[7] = {q[0], q[1], q[2], q[3], t[0], t[1], t[2]};
+  HIP_TRY(c, hipMemcpyAsync(c->d_P, P_l, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_P + 12, P_r, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_P + 40, start, sizeof start, hipMemcpyHostToDevice, c->stream));
+  if (n_obs) HIP_TRY(c, hipMemcpyAsync(c->d_obs, obs, (size_t)n_obs * sizeof(spvo_obs), hipMemcpyHostToDevice, c->stream));
+  {
+    ScopedStage st(c, stage_id(c, "refine"));
+    hipLaunchKernelGGL(pnp_refine_kernel<512>, dim3(1), dim3(512), 0, c->stream, c->d_P, c->d_P + 12, c->d_obs, n_obs, (const int *)nullptr, c->d_P + 40, o.max_iterations, o.huber_delta, c->d_refine);
+  }
+  HIP_TRY(c, hipGetLastError());
+  RefineOut r;
+  HIP_TRY(c, hipMemcpyAsync(&r, c->d_refine, sizeof r, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int k = 0; k < 4; ++k) q[k] = r.v[k];
+  for (int k = 0; k < 3; ++k) t[k] = r.v[4 + k];
+  if (summary) {
+    summary->iterations = (int)r.v[7];
+    summary->converged = (int)r.v[8];
+    summary->usable = (int)r.v[9];
+    summary->initial_cost = r.v[10];
+    summary->final_cost = r.v[11];
+  }
+  return SPVO_OK;
+}
+
+// Everything of a solve up to the event behind its last copy; the inputs are staged in pinned memory, so the caller's arrays are
+// free again when this returns.  What spvo_solve_wait needs later (the prior, n, the refinement degree) stays in the context.
+int spvo_solve_submit(spvo_ctx *c, const spvo_solve_input *in) {
+  if (!c || !in) return fail(c, SPVO_ERR_INVALID, "null argument");
+  if (c->solve_pending.active) return fail(c, SPVO_ERR_STATE, "a solve is pending: complete it with spvo_solve_wait first");
+  const int n = in->n;
+  if (n < 0 || (n > 0 && (!in->xy_cl || !in->xy_cr || !in->xy_pl || !in->xy_pr))) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  if (in->ransac.iterations <= 0 || in->ransac.iterations > 65536 || !(in->ransac.reproj_error > 0) || in->refine.max_iterations < 0 ||
+      !(in->refine.huber_delta > 0))
+    return fail(c, SPVO_ERR_INVALID, "bad solver options");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  spvo_ctx::SolvePending pend;
+  pend.n = n; pend.refinement_degree = in->refinement_degree;
+  for (int k = 0; k < 3; ++k) { pend.rvec[k] = in->rvec_pred[k]; pend.tvec[k] = in->tvec_pred[k]; }
+  if (n == 0) { pend.active = true; c->solve_pending = pend; return SPVO_OK; }   // nothing to enqueue: _wait answers with the prior
+  // this call runs on the context's second stream so that it overlaps a detector submission in
+  // flight; buffers only grow on first use (then everything is drained once)
+  const bool grow = n > c->odo_cap || in->ransac.iterations > c->ransac_cap || 4 * n > c->obs_cap || !c->d_P || n > c->solve_cap;
+  if (grow) HIP_TRY(c, hipDeviceSynchronize());
+  int rc = ensure_odometry(c, n, in->ransac.iterations, 4 * n);
+  if (rc) return rc;
+  if (n > c->solve_cap) {
+    const int cap = std::max(n, 2048);
+    for (void *hp : {(void *)c->h_solve_in, (void *)c->h_solve_res, (void *)c->h_solve_o}) if (hp) (void)hipHostFree(hp);
+    for (void *dp : {(void *)c->d_solve_in, (void *)c->d_solve_res, (void *)c->d_solve_o, (void *)c->d_ctl}) if (dp) (void)hipFree(dp);
+    c->h_solve_in = c->h_solve_o = nullptr; c->h_solve_res = nullptr;
+    c->d_solve_in = c->d_solve_o = nullptr; c->d_solve_res = nullptr; c->d_ctl = nullptr;
+    c->solve_cap = 0;   // a failed allocation below leaves a context that spvo_destroy and a later call can still handle
+    const size_t in_bytes = 64 * sizeof(double) + (size_t)12 * cap * 4, o_bytes = (size_t)4 * cap * 4;
+    if ((rc = dev_alloc(c, &c->d_solve_in, in_bytes))) return rc;
+    if ((rc = dev_alloc(c, &c->d_solve_res, 40))) return rc;
+    if ((rc = dev_alloc(c, &c->d_solve_o, o_bytes))) return rc;
+    if ((rc = dev_alloc(c, &c->d_ctl, 4))) return rc;
+    HIP_TRY(c, hipHostMalloc((void **)&c->h_solve_in, in_bytes));
+    HIP_TRY(c, hipHostMalloc((void **)&c->h_solve_res, 40 * sizeof(double)));
+    HIP_TRY(c, hipHostMalloc((void **)&c->h_solve_o, o_bytes));
+    c->solve_cap = cap;
+  }
+  if (grow) HIP_TRY(c, hipDeviceSynchronize());
+  static const bool solve_timing = std::getenv("SPVO_SOLVE_TIMING") != nullptr;   // diagnostic: host time per phase of this call
+  static double tacc[4] = {0, 0, 0, 0};
+  static long tcalls = 0;
+  auto now_us = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
+  const double tm0 = solve_timing ? now_us() : 0;
+  // ---- pack: 64 doubles, then cl cr pl pr [2n each], prev_xyz [3n], prev_valid [n]
+  double *hdr = (double *)c->h_solve_in;
+  std::memset(hdr, 0, 64 * sizeof(double));
+  for (int k = 0; k < 12; ++k) { hdr[k] = in->P_l[k]; hdr[12 + k] = in->P_r[k]; }
+  const int kidx[9] = {0, 1, 2, 4, 5, 6, 8, 9, 10};
+  for (int k = 0; k < 9; ++k) hdr[24 + k] = in->P_l[kidx[k]];                      // K = P_l[:, :3]  (base.cpp:227)
+  for (int k = 0; k < 3; ++k) { hdr[33 + k] = in->rvec_pred[k]; hdr[36 + k] = in->tvec_pred[k]; }
+  hdr[39] = in->frame_count; hdr[40] = in->refinement_degree;
+  hdr[41] = 8.0; hdr[42] = 0.1; hdr[43] = 10;                                      // hpp:145-147
+  float *fw = (float *)(c->h_solve_in + 64 * sizeof(double));
+  std::memcpy(fw, in->xy_cl, (size_t)2 * n * 4);
+  std::memcpy(fw + 2 * n, in->xy_cr, (size_t)2 * n * 4);
+  std::memcpy(fw + 4 * n, in->xy_pl, (size_t)2 * n * 4);
+  std::memcpy(fw + 6 * n, in->xy_pr, (size_t)2 * n * 4);
+  const bool have_prev = in->prev_xyz && in->prev_valid;
+  if (have_prev) {
+    std::memcpy(fw + 8 * n, in->prev_xyz, (size_t)3 * n * 4);
+    std::memcpy(fw + 11 * n, in->prev_valid, (size_t)n * 4);
+  }
+  const size_t used = 64 * sizeof(double) + (size_t)12 * n * 4;
+  const double tm1 = solve_timing ? now_us() : 0;
+  HIP_TRY(c, hipMemcpyAsync(c->d_solve_in, c->h_solve_in, used, hipMemcpyHostToDevice, c->stream2));
+  const double *dh = (const double *)c->d_solve_in;
+  const float *df = (const float *)(c->d_solve_in + 64 * sizeof(double));
+  float *d_xyz = (float *)c->d_solve_o;
+  int *d_inl = (int *)(c->d_solve_o) + 3 * n;
+  RansacWork rw = c->rw;
+  rw.result = c->d_solve_res;
+  rw.inliers = d_inl;
+  const double thr2 = in->ransac.reproj_error * in->ransac.reproj_error;
+  {
+    ScopedStage st(c, stage_id(c, "solve"), 0, 0, c->stream2);
+    hipLaunchKernelGGL(triangulate_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream2, dh, dh + 12, df, df + 2 * n, n, d_xyz);
+    if (n >= 4) {
+      hipLaunchKernelGGL(ransac_hypothesis_kernel, dim3(in->ransac.iterations), dim3(64), 0, c->stream2, dh + 24, d_xyz, df + 4 * n, n, dh + 33, in->ransac.seed, thr2, rw);
+      hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(256), 0, c->stream2, dh + 24, d_xyz, df + 4 * n, n, dh + 33, in->ransac.iterations, thr2, rw);
+      hipLaunchKernelGGL(solve_gate_build_kernel, dim3(1), dim3(256), 0, c->stream2, dh, c->d_solve_res, d_inl, d_xyz, df, df + 2 * n, df + 4 * n, df + 6 * n,
+                         have_prev ? df + 8 * n : (const float *)nullptr, have_prev ? (const int *)(df + 11 * n) : (const int *)nullptr, c->d_obs, c->d_ctl,
+                         c->d_solve_res + 8);
+      hipLaunchKernelGGL(pnp_refine_kernel<512>, dim3(1), dim3(512), 0, c->stream2, dh, dh + 12, c->d_obs, 0, (const int *)c->d_ctl, c->d_solve_res + 8,
+                         in->refine.max_iterations, in->refine.huber_delta, (RefineOut *)(c->d_solve_res + 24));
+    }
+    HIP_TRY(c, hipGetLastError());
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->h_solve_o, c->d_solve_o, (size_t)4 * n * 4, hipMemcpyDeviceToHost, c->stream2));
+  if (n >= 4) HIP_TRY(c, hipMemcpyAsync(c->h_solve_res, c->d_solve_res, 40 * sizeof(double), hipMemcpyDeviceToHost, c->stream2));
+  if (!c->ev_solve) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_solve, hipEventDisableTiming));
+  HIP_TRY(c, hipEventRecord(c->ev_solve, c->stream2));
+  if (solve_timing) {
+    const double tm2 = now_us();
+    tacc[0] += tm1 - tm0; tacc[1] += tm2 - tm1;
+    if (++tcalls % 200 == 0) {
+      std::fprintf(stderr, "[solve timing] pack %.1f us, enqueue %.1f us (n = %d)\n", tacc[0] / 200, tacc[1] / 200, n);
+      tacc[0] = tacc[1] = 0;
+    }
+  }
+  pend.active = true;
+  c->solve_pending = pend;
+  return SPVO_OK;
+}
+
+int spvo_solve_wait(spvo_ctx *c, spvo_solve_output *out, float *xyz, int32_t *inliers) {
+  if (!c || !out) return fail(c, SPVO_ERR_INVALID, "null argument");
+  if (!c->solve_pending.active) return fail(c, SPVO_ERR_STATE, "no solve pending");
+  const spvo_ctx::SolvePending pend = c->solve_pending;
+  const int n = pend.n;
+  if (n > 0 && (!xyz || !inliers)) return fail(c, SPVO_ERR_INVALID, "bad argument");   // (the solve stays pending)
+  c->solve_pending.active = false;
+  std::memset(out, 0, sizeof *out);
+  // rvec -> quaternion of the prior: the answer when nothing can be estimated (base.cpp:244-250, 274-280)
+  auto prior_pose = [&]() {
+    const double *r = pend.rvec;
+    const double a = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    double ax[3] = {r[0], r[1], r[2]};
+    if (a > 0) for (int k = 0; k < 3; ++k) ax[k] /= a;
+    const double sn = std::sin(a / 2);
+    out->q[0] = ax[0] * sn; out->q[1] = ax[1] * sn; out->q[2] = ax[2] * sn; out->q[3] = std::cos(a / 2);
+    for (int k = 0; k < 3; ++k) { out->t[k] = pend.tvec[k]; out->rvec[k] = pend.rvec[k]; out->tvec[k] = pend.tvec[k]; }
+  };
+  if (n == 0) { prior_pose(); return SPVO_OK; }
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  {
+    const double tw0 = diag_now_us();
+    HIP_TRY(c, wait_event(c->ev_solve));
+    g_diag.max_solve_wait = std::max(g_diag.max_solve_wait, diag_now_us() - tw0);
+  }
+  std::memcpy(xyz, c->h_solve_o, (size_t)3 * n * 4);
+  if (n < 4) { prior_pose(); return SPVO_OK; }                                      // no model possible: prior is kept
+  const double *res = c->h_solve_res, *gate = res + 8, *ref = res + 24;
+  out->pnp_ok = res[6] != 0;
+  out->n_inliers = (int)res[7];
+  if (out->n_inliers > 0) std::memcpy(inliers, (const int *)c->h_solve_o + 3 * n, (size_t)out->n_inliers * 4);
+  out->accepted = gate[7] != 0;
+  for (int k = 0; k < 3; ++k) { out->rvec[k] = gate[10 + k]; out->tvec[k] = gate[13 + k]; }
+  const bool ran = out->accepted && pend.refinement_degree > 0;
+  out->summary.iterations = (int)ref[7];
+  out->summary.converged = (int)ref[8];
+  out->summary.usable = (int)ref[9];
+  out->summary.initial_cost = ref[10];
+  out->summary.final_cost = ref[11];
+  out->refined = ran && out->summary.usable && out->summary.converged;             // base.cpp:366-374
+  const double *src = out->refined ? ref : gate;
+  for (int k = 0; k < 4; ++k) out->q[k] = src[k];
+  for (int k = 0; k < 3; ++k) out->t[k] = src[4 + k];
+  return SPVO_OK;
+}
+
+int spvo_solve_stereo_odometry(spvo_ctx *c, const spvo_solve_input *in, spvo_solve_output *out, float *xyz, int32_t *inliers) {
+  if (!c || !in || !out || (in->n > 0 && (!xyz || !inliers))) return fail(c, SPVO_ERR_INVALID, "null argument");
+  const int rc = spvo_solve_submit(c, in);
+  return rc ? rc : spvo_solve_wait(c, out, xyz, inliers);
+}
+
+}  // extern "C"
