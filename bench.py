@@ -165,11 +165,50 @@ def pin_to_gpu_numa_node(torch, local_rank):
         return None
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script, one per GPU, exactly as
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` would (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment).  The children are fresh interpreters started BEFORE this process has touched the GPU or imported torch (never
+    re-exec a process that has initialised HIP); rank 0 inherits stdout and prints the one JSON line."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
+
+
+def repeats_for(first_elapsed, target_s=1.0):
+    """How often a timed block of K steps is repeated: so that the blocks add up to about `target_s` seconds (the driver's 20 steps
+    are an 18 ms block: one sample of that says little), at least 5, at most 200."""
+    return int(min(200, max(5, -(-target_s // max(first_elapsed, 1e-4)))))
+
+
+def spread(times, steps):
+    """median / min / max of the per-block times as a dict fragment"""
+    a = np.sort(np.asarray(times, np.float64))
+    med = float(np.median(a))
+    return med, {"repeats": int(a.size), "ms_per_step_min": round(1e3 * float(a[0]) / steps, 4), "ms_per_step_max": round(1e3 * float(a[-1]) / steps, 4),
+                 "spread_pct": round(100.0 * float(a[-1] - a[0]) / med, 2)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=0, help="timed blocks of --steps steps (default 0: as many as make about one second, 5..200); the line reports the median block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational second measurement (FP32 engine in split mode)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
@@ -201,6 +240,8 @@ def main():
     global NET_H, NET_W
     NET_H, NET_W = (int(v) for v in args.net_size.lower().split("x"))
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:   # no launcher: be one (before anything touches the GPU)
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -227,6 +268,8 @@ def main():
     if shared:
         local_rank = local_rank % torch.cuda.device_count()
         os.environ["SPVO_DEVICE"] = str(local_rank)
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, {torch.cuda.device_count()} visible (one rank per GPU; --gpus {args.gpus})")
     torch.cuda.set_device(local_rank)
     # Test hook: SPVO_BENCH_FORCE_DIST=1 runs the collective path (RCCL process group, pose all-gather, barrier, max-reduce) in a
     # single-rank job too, so that it can be exercised on a one-GPU box.
@@ -319,39 +362,72 @@ def main():
         ctx.profile_only("conv:1" if args.graph == "vgg" else "detect")
         ctx.profile_enable(True)
         ctx.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        step(i)
-    last = fe.finish_solve()                                                # the last step's pose (deferred solve): inside the timed region
-    if dist_on and last is not None:
-        pg.gather_async(*last)
-    if dist_on:
-        gathered = pg.collect()                                             # every pose of every rank has arrived: inside the timed region
-        assert gathered.shape[1:] == (world, 7)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # A timed block = EXACTLY args.steps steps between two barriers (+ device synchronisation).  The block is repeated -- a block
+    # of the driver's 20 steps lasts 18 ms, one such sample is thin -- and `value` is the MEDIAN block (max over ranks per block);
+    # the number of repeats follows from the first block's duration and is the same on every rank.
+    cursor = [args.warmup]
+
+    def timed_block():
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(cursor[0], cursor[0] + args.steps):
+            step(i)
+        last = fe.finish_solve()                                            # the last step's pose (deferred solve): inside the timed region
+        if dist_on and last is not None:
+            pg.gather_async(*last)
+        if dist_on:
+            gathered = pg.collect()                                         # every pose of every rank has arrived: inside the timed region
+            assert gathered.shape[1:] == (world, 7)
+        barrier()
+        cursor[0] += args.steps
+        return time.perf_counter() - t0
+
+    def over_ranks(ts):
+        if not dist_on:
+            return list(ts)
+        t = torch.tensor(list(ts), dtype=torch.float64, device="cpu" if shared else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
+
+    block_times = over_ranks([timed_block()])
+    n_rep = args.repeats if args.repeats > 0 else repeats_for(block_times[0])
+    block_times += over_ranks([timed_block() for _ in range(n_rep - 1)])
+    elapsed, headline_spread = spread(block_times, args.steps)
     prof, prof_all = {}, {}
     if not args.no_profile:
         prof = ctx.profile()
         ctx.profile_only(None)
         ctx.profile_reset()
-        n_extra = min(args.steps, 100)
-        for i in range(args.warmup + args.steps, args.warmup + args.steps + n_extra):
+        n_extra = min(max(args.steps, 50), 100)
+        for i in range(cursor[0], cursor[0] + n_extra):
             step(i)
         barrier()
         prof_all = ctx.profile()
         ctx.profile_enable(False)
-    if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    def leg(step_fn, finish, start=args.warmup):
+        """an extra leg timed like the headline: blocks of args.steps steps, the median block"""
+        cur = [start]
+
+        def block():
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(cur[0], cur[0] + args.steps):
+                step_fn(i)
+            finish()
+            barrier()
+            cur[0] += args.steps
+            return time.perf_counter() - t1
+        ts = [block()]
+        ts += [block() for _ in range((args.repeats if args.repeats > 0 else repeats_for(ts[0], 0.6)) - 1)]
+        return spread(ts, args.steps)
 
     if rank == 0:
         total_frames = args.steps * world
         out = {
             "metric": "stereo frames/sec (1241x376 KITTI)", "value": round(total_frames / elapsed, 2), "unit": "stereo frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            **headline_spread, "timing": "median of `repeats` timed blocks of `steps` steps each (barrier + synchronize on both sides, max over ranks per block)",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 as 3 x bf16 (split operands, fp32 accumulate)" if args.fp32_split else {"FP32": "f32", "FP16": "f16", "INT8": "i8"}[args.precision], "data": "synthetic",
             "config": {"workload": (f"SuperPoint VGG {args.precision.lower()} (seeded synthetic weights, {n_params} params)" if args.graph == "vgg" else
                                     f"SuperPoint {args.graph} {args.precision.lower()} (the reference's ONNX graph, seeded weights, {n_params} params)")
@@ -424,13 +500,8 @@ def main():
                 if fe.engine_loaded:
                     for i in range(args.warmup):
                         step(i)
-                    barrier()
-                    t1 = time.perf_counter()
-                    for i in range(args.warmup, args.warmup + args.steps):
-                        step(i)
-                    barrier()
-                    e2 = time.perf_counter() - t1
-                    out["fp32_split_mode"] = {"value": round(args.steps / e2, 2), "unit": "stereo frames/s", "ms_per_step": round(1e3 * e2 / args.steps, 4),
+                    e2, sp2 = leg(lambda i: step(i), lambda: fe.finish_solve())
+                    out["fp32_split_mode"] = {"value": round(args.steps / e2, 2), "unit": "stereo frames/s", "ms_per_step": round(1e3 * e2 / args.steps, 4), **sp2,
                                               "note": "opt-in (spvo_set_fp32_split / bench.py --fp32-split), not the headline: fp32 operands as 3 bf16 pieces, "
                                                       "6 partial products per product, fp32 accumulate; fp32-equivalent results"}
             except Exception as exc:   # the headline line must survive a failure of this informational part
@@ -456,14 +527,8 @@ def main():
                     for i in range(args.warmup):
                         hstep(i)
                     fe.finish_solve()
-                    barrier()
-                    t1 = time.perf_counter()
-                    for i in range(args.warmup, args.warmup + args.steps):
-                        hstep(i)
-                    fe.finish_solve()
-                    barrier()
-                    e3 = time.perf_counter() - t1
-                    hi[name] = {"value": round(args.steps / e3, 2), "ms_per_step": round(1e3 * e3 / args.steps, 4)}
+                    e3, sp3 = leg(hstep, lambda: fe.finish_solve())
+                    hi[name] = {"value": round(args.steps / e3, 2), "ms_per_step": round(1e3 * e3 / args.steps, 4), **sp3}
                 out["host_interface"] = {"unit": "stereo frames/s", **hi,
                                          "note": "addStereoImagePair(cv::Mat&, ...): 2 x 0.47 MB host images in, 2 x 0.42 MB resized images + 2 x 1 MB "
                                                  "descriptors out per pair (PCIe inclusive); the headline `value` has the images resident in HBM"}
@@ -496,17 +561,11 @@ def main():
                     for i in range(args.warmup):
                         tstep(i)
                     stats.clear()
-                    barrier()
-                    t1 = time.perf_counter()
-                    for i in range(args.warmup, args.warmup + args.steps):
-                        tstep(i)
-                    fe.finish_solve()
-                    barrier()
-                    e4 = time.perf_counter() - t1
+                    e4, sp4 = leg(tstep, lambda: fe.finish_solve())
                     st = np.array(stats, np.float64)
                     out["trained_workload"] = {"graph": "sp_squeeze (the reference's trained ONNX graph, 844353 params), FP32, net %dx%d; frames 0..7 cyclically "
                                                         "(one jump back per cycle, which the gate rejects)" % (NET_H, NET_W),
-                                               "value": round(args.steps / e4, 2), "unit": "stereo frames/s", "ms_per_step": round(1e3 * e4 / args.steps, 4),
+                                               "value": round(args.steps / e4, 2), "unit": "stereo frames/s", "ms_per_step": round(1e3 * e4 / args.steps, 4), **sp4,
                                                "accepted_rate": round(float(st[:, 0].mean()), 3), "refined_rate": round(float(st[:, 1].mean()), 3),
                                                "mean_lm_iterations": round(float(st[:, 2].mean()), 2), "mean_pnp_inliers": round(float(st[:, 3].mean()), 1)}
             except Exception as exc:   # the headline line must survive a failure of this informational part

@@ -126,7 +126,10 @@ int spvo_comm_unique_id(unsigned char id[SPVO_COMM_ID_BYTES]) {
   static_assert(SPVO_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
   if (!id) return comm_fail(SPVO_ERR_INVALID, "null id");
   Rccl *r = rccl();
-  if (!r) return comm_fail(SPVO_ERR_DEVICE, "librccl.so.1 not found (set SPVO_RCCL_LIB or ROCM_PATH): %s", dlerror() ? dlerror() : "");
+  if (!r) {
+    const char *why = dlerror();   // (a second call would return NULL: the message is cleared by the first)
+    return comm_fail(SPVO_ERR_DEVICE, "librccl.so.1 not found (set SPVO_RCCL_LIB or ROCM_PATH): %s", why ? why : "");
+  }
   ncclUniqueId u;
   COMM_NCCL(r->GetUniqueId(&u));
   std::memcpy(id, u.internal, SPVO_COMM_ID_BYTES);
@@ -227,6 +230,20 @@ int spvo_pose_allgather(spvo_comm *c, const double pose[7], double *all) { retur
 void spvo_comm_destroy(spvo_comm *c) {
   if (!c) return;
   if (c->host) {
+    // A peer may still be reading this rank's last file (seeing a peer's file for gather s only proves that the peer has finished
+    // s - 1).  So: publish done_<rank>, wait until every peer has published its own -- a rank does that after its last gather
+    // returned, i.e. after its last read -- and only then remove this rank's pose files.  The markers stay for whoever removes
+    // the directory; a directory that has vanished means the others are gone.  Bounded: a peer that died must not hang this one.
+    const std::string mark = c->dir + "/done_" + std::to_string(c->rank);
+    if (FILE *f = std::fopen(mark.c_str(), "wb")) std::fclose(f);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < c->world; ++r) {
+      if (r == c->rank) continue;
+      const std::string peer = c->dir + "/done_" + std::to_string(r);
+      struct stat st;
+      while (stat(peer.c_str(), &st) != 0 && stat(c->dir.c_str(), &st) == 0 && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(30))
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
     for (long s = c->seq > 2 ? c->seq - 2 : 0; s < c->seq; ++s) std::remove(host_file(c, s, c->rank).c_str());
   } else {
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }

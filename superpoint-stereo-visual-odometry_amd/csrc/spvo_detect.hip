@@ -186,7 +186,7 @@ int spvo_preprocess(spvo_ctx *c, const uint8_t *img, int rows, int cols, size_t 
   if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "detector submissions are in flight: complete them with spvo_detect_wait first");
   if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
   HIP_TRY(c, hipSetDevice(c->cfg.device));
-  const size_t bytes = (size_t)rows * stride;
+  const size_t bytes = (size_t)(rows - 1) * stride + cols;   // what is the caller's of a strided view: not the last row's padding
   if (bytes > c->img_cap) {
     for (int i = 0; i < 2; ++i) { if (c->d_img[i]) (void)hipFree(c->d_img[i]); c->d_img[i] = nullptr; }
     for (int i = 0; i < 2; ++i) { int rc = dev_alloc(c, &c->d_img[i], bytes, false); if (rc) return rc; }
@@ -370,7 +370,7 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   const int ring = (int)(c->submit_count++ % RING);
   for (auto &mc : c->mcache[ring]) mc.valid = false;
   if (host_l) {   // pageable -> pinned (host copy), pinned -> device (DMA on the network stream): the caller's buffers are free on return
-    const size_t bytes = (size_t)rows * stride;
+    const size_t bytes = (size_t)(rows - 1) * stride + cols;   // what is the caller's of a strided view: not the last row's padding
     std::memcpy(c->h_img_r[ring], host_l, bytes);
     std::memcpy(c->h_img_r[ring] + c->img_cap_r, host_r, bytes);
     HIP_TRY(c, hipMemcpyAsync(c->d_img_r[ring], c->h_img_r[ring], bytes, hipMemcpyHostToDevice, c->stream));
@@ -561,13 +561,13 @@ static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_feature
 // buffers of the host-image submissions: allocated on first use, grown when a larger image arrives (never while submissions are in flight)
 static int ensure_host_sets(spvo_ctx *c, size_t image_bytes) {
   const size_t hw2 = (size_t)2 * c->H * c->W, desc = (size_t)2 * c->cfg.max_keypoints * 256;
-  if (!c->d_resized_r[0]) {
+  if (!c->host_sets_ready) {   // (a flag of its own: a failure half-way must not look like "allocated" to the next call)
     for (int r = 0; r < RING; ++r) {
-      int rc = dev_alloc(c, &c->d_resized_r[r], hw2, false);
-      if (rc) return rc;
-      HIP_TRY(c, hipHostMalloc((void **)&c->h_resized_r[r], hw2));
-      HIP_TRY(c, hipHostMalloc((void **)&c->h_desc_r[r], desc * sizeof(float)));
+      if (!c->d_resized_r[r]) { int rc = dev_alloc(c, &c->d_resized_r[r], hw2, false); if (rc) return rc; }
+      if (!c->h_resized_r[r]) HIP_TRY(c, hipHostMalloc((void **)&c->h_resized_r[r], hw2));
+      if (!c->h_desc_r[r]) HIP_TRY(c, hipHostMalloc((void **)&c->h_desc_r[r], desc * sizeof(float)));
     }
+    c->host_sets_ready = true;
   }
   if (image_bytes > c->img_cap_r) {
     if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "the image size grew while submissions are in flight");
@@ -601,7 +601,7 @@ int spvo_detect(spvo_ctx *c, const uint8_t *img_l, const uint8_t *img_r, int row
   if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "detector submissions are in flight: complete them with spvo_detect_wait first");
   if (!c->weights) return fail(c, SPVO_ERR_STATE, "no weights loaded");
   HIP_TRY(c, hipSetDevice(c->cfg.device));
-  const size_t bytes = (size_t)rows * stride;
+  const size_t bytes = (size_t)(rows - 1) * stride + cols;   // what is the caller's of a strided view: not the last row's padding
   if (bytes > c->img_cap) {
     for (int i = 0; i < 2; ++i) { if (c->d_img[i]) (void)hipFree(c->d_img[i]); c->d_img[i] = nullptr; }
     for (int i = 0; i < 2; ++i) { int rc = dev_alloc(c, &c->d_img[i], bytes, false); if (rc) return rc; }
@@ -712,24 +712,33 @@ int spvo_orb_detect(spvo_ctx *c, const uint8_t *img, int rows, int cols, size_t 
       off[l + 1] = off[l] + (((size_t)ph[l] * pw[l] + 255) & ~(size_t)255);
     }
   }
-  const size_t px0 = (size_t)rows * cols;
   const int surv_cap = (rows / 2 + 1) * (cols / 2 + 1);   // 3x3 suppression: at most one survivor per 2x2 block
   const int kp_cap = nfeatures;
-  if (px0 > o.px_cap || kp_cap > o.kp_cap) {
+  // what THIS image needs: the pyramid (all levels side by side), one key / rank entry per possible survivor of every level, the
+  // resize tables of levels 1..7.  All three depend on rows and cols separately (a 100 x 1500 image needs longer tables than a
+  // 400 x 400 one although it has fewer pixels), so each is compared with what is allocated.
+  size_t need_keys = 0, need_tab = 0;
+  for (int l = 0; l < ORB_LEVELS; ++l) {
+    need_keys += (size_t)std::min(surv_cap, (ph[l] / 2 + 1) * (pw[l] / 2 + 1));
+    if (l > 0) need_tab += (size_t)3 * (pw[l] + ph[l]);
+  }
+  const size_t need_pyr = off[ORB_LEVELS] + 256;
+  if (need_pyr > o.pyr_cap || need_keys > o.key_cap || need_tab > o.tab_cap || kp_cap > o.kp_cap) {
     HIP_TRY(c, hipStreamSynchronize(st));
     for (void *p : {(void *)o.im, (void *)o.score, (void *)o.blur, (void *)o.tmp, (void *)o.keys, (void *)o.rank, (void *)o.out_xy, (void *)o.counters, (void *)o.tab,
                     (void *)o.kps, (void *)o.desc}) if (p) (void)hipFree(p);
     o.im = o.score = o.blur = nullptr; o.tmp = nullptr; o.keys = nullptr; o.rank = o.out_xy = o.counters = o.tab = nullptr; o.kps = nullptr; o.desc = nullptr;
-    o.px_cap = 0; o.kp_cap = 0;
+    const size_t pyr = std::max(need_pyr, o.pyr_cap), kall = std::max(need_keys, o.key_cap), tabn = std::max(need_tab, o.tab_cap);
+    const int kpn = std::max(kp_cap, o.kp_cap);
+    o.pyr_cap = o.key_cap = o.tab_cap = 0; o.kp_cap = 0;   // a failed allocation below leaves a context that spvo_destroy and a later call can still handle
     int rc;
-    const size_t pyr = off[ORB_LEVELS] + 256, kall = (size_t)5 * surv_cap;   // all levels side by side (sum of 1 / 1.44^l < 3.3)
     if ((rc = dev_alloc(c, &o.im, pyr)) || (rc = dev_alloc(c, &o.score, pyr)) || (rc = dev_alloc(c, &o.blur, pyr)) || (rc = dev_alloc(c, &o.tmp, pyr)) ||
         (rc = dev_alloc(c, &o.keys, kall)) || (rc = dev_alloc(c, &o.rank, kall)) || (rc = dev_alloc(c, &o.out_xy, 2 * kall)) ||
-        (rc = dev_alloc(c, &o.counters, (size_t)ORB_LEVELS * NMS_COUNTER_INTS)) || (rc = dev_alloc(c, &o.tab, (size_t)16 * (rows + cols))) || (rc = dev_alloc(c, &o.kps, kp_cap)) ||
-        (rc = dev_alloc(c, &o.desc, (size_t)kp_cap * 32)))
+        (rc = dev_alloc(c, &o.counters, (size_t)ORB_LEVELS * NMS_COUNTER_INTS)) || (rc = dev_alloc(c, &o.tab, tabn)) || (rc = dev_alloc(c, &o.kps, kpn)) ||
+        (rc = dev_alloc(c, &o.desc, (size_t)kpn * 32)))
       return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // (dev_alloc clears on the network stream)
-    o.px_cap = px0; o.kp_cap = kp_cap;
+    o.pyr_cap = pyr; o.key_cap = kall; o.tab_cap = tabn; o.kp_cap = kpn;
     o.tab_rows = o.tab_cols = 0;
   }
   // resize tables of all levels, one upload per image size
@@ -761,15 +770,18 @@ int spvo_orb_detect(spvo_ctx *c, const uint8_t *img, int rows, int cols, size_t 
     HIP_TRY(c, hipMemcpy(o.taps, taps, 7 * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(o.disc, disc.data(), disc.size(), hipMemcpyHostToDevice));
   }
-  if ((size_t)rows * stride > o.src_cap) {
+  // of a strided view (a cv::Mat ROI) only (rows - 1) * stride + cols bytes are the caller's: the last row's padding may lie
+  // beyond the end of the parent allocation
+  const size_t src_bytes = (size_t)(rows - 1) * stride + cols;
+  if (src_bytes > o.src_cap) {
     HIP_TRY(c, hipStreamSynchronize(st));
     if (o.src) (void)hipFree(o.src);
     o.src = nullptr; o.src_cap = 0;
-    int rc = dev_alloc(c, &o.src, (size_t)rows * stride, false);
+    int rc = dev_alloc(c, &o.src, src_bytes, false);
     if (rc) return rc;
-    o.src_cap = (size_t)rows * stride;
+    o.src_cap = src_bytes;
   }
-  HIP_TRY(c, hipMemcpyAsync(o.src, img, (size_t)rows * stride, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(o.src, img, src_bytes, hipMemcpyHostToDevice, st));
   HIP_TRY(c, hipMemcpy2DAsync(o.im, cols, o.src, stride, cols, rows, hipMemcpyDeviceToDevice, st));   // level 0: the image, rows packed
   // the whole image is enqueued without a host round trip: the pyramid level by level, then every stage once for all levels;
   // one counter block per level, a level's keypoints land behind those of the levels below (orb_describe_kernel sums their counts)

@@ -191,6 +191,7 @@ struct spvo_ctx {
   size_t img_cap_r = 0;          // bytes per image in those buffers
   uint8_t *d_resized_r[RING] = {nullptr, nullptr, nullptr, nullptr}, *h_resized_r[RING] = {nullptr, nullptr, nullptr, nullptr};
   float *h_desc_r[RING] = {nullptr, nullptr, nullptr, nullptr};   // [2][cap][256]
+  bool host_sets_ready = false;  // d_resized_r / h_resized_r / h_desc_r of EVERY set are allocated
   hipEvent_t ev_net[RING] = {nullptr, nullptr, nullptr, nullptr}, ev_tail[RING] = {nullptr, nullptr, nullptr, nullptr};
   bool match_fp8 = false;        // fp8 shortlist GEMM (approximate; spvo_set_match_fp8)
   bool prematch = false;
@@ -206,7 +207,9 @@ struct spvo_ctx {
   RefineOut *d_refine = nullptr;
   // ORB detector / extractor of the classic front end (orb.hip.h): buffers grow on demand
   struct OrbBufs {
-    size_t px_cap = 0;        // pixels of level 0 the image buffers are sized for
+    size_t pyr_cap = 0;       // bytes per pyramid buffer (all levels side by side), key / rank entries, resize-table ints the buffers hold:
+    size_t key_cap = 0;       // each is compared with what an image NEEDS (they depend on rows and cols separately, not on rows x cols)
+    size_t tab_cap = 0;
     int kp_cap = 0;
     uint8_t *im = nullptr, *score = nullptr, *blur = nullptr, *src = nullptr;   // im: all pyramid levels back to back
     float *tmp = nullptr, *pattern = nullptr, *taps = nullptr;

@@ -48,13 +48,15 @@ class PoseGather:
         self.transport = "local" if self.local_only else transport
         self.transport_note = ""
         if self.transport in ("auto", "c"):
-            try:
-                self.comm = self._make_comm()
+            # Every rank takes the same decision: _make_comm agrees on it collectively (all ranks reach every broadcast /
+            # all-reduce whatever happened locally), so no rank is left waiting in a collective its peers have abandoned.
+            self.comm, why = self._make_comm()
+            if self.comm is not None:
                 self.transport = "c:rccl" if self.device.type == "cuda" else "c:host"
-            except Exception as exc:               # noqa: BLE001 -- any failure selects the other transport
-                if transport == "c":
-                    raise
-                self.transport, self.transport_note = "torch", f"C-ABI communicator unavailable ({exc}); torch.distributed used"
+            elif transport == "c":
+                raise RuntimeError("C-ABI communicator unavailable: " + why)
+            else:
+                self.transport, self.transport_note = "torch", f"C-ABI communicator unavailable ({why}); torch.distributed used"
         self.buf = torch.zeros(7, dtype=torch.float64, device=self.device)
         self.out: List[torch.Tensor] = [torch.zeros(7, dtype=torch.float64, device=self.device) for _ in range(self.world)]
         self._pending: list = []
@@ -63,32 +65,58 @@ class PoseGather:
         self._stage = self._send = self._ready = None
         self._side = None
 
+    def _all_ok(self, ok: bool) -> bool:
+        """True iff `ok` on EVERY rank (one MIN all-reduce; every rank calls it the same number of times)."""
+        if self.world == 1 or not dist.is_initialized():
+            return ok
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
     def _make_comm(self):
+        """(communicator, "") on every rank, or (None, reason) on every rank.  Protocol: (1) each rank checks locally that it can
+        take part (GPU ranks: librccl loads and hands out an id -- rank 0's is the one that is used; host ranks: nothing to check)
+        and the ranks agree on that; (2) rank 0 broadcasts its id / directory -- always, None included; (3) each rank creates its
+        communicator and the ranks agree on the outcome, closing what was created when a peer failed."""
         from . import capi
-        box = [None]
-        if self.device.type == "cuda":
-            if self.rank == 0:
-                box[0] = capi.comm_unique_id()
-            if self.world > 1:
-                dist.broadcast_object_list(box, src=0)
-            return capi.Comm.rccl(self.device.index or 0, self.rank, self.world, box[0])
-        if self.rank == 0:
-            box[0] = tempfile.mkdtemp(prefix="spvo_comm_")
+        box, err = [None], ""
+        cuda = self.device.type == "cuda"
+        try:
+            if cuda:
+                uid = capi.comm_unique_id()          # proves on THIS rank that RCCL can be opened, before any rank enters ncclCommInitRank
+                if self.rank == 0:
+                    box[0] = uid
+            elif self.rank == 0:
+                box[0] = tempfile.mkdtemp(prefix="spvo_comm_")
+        except Exception as exc:               # noqa: BLE001
+            err = repr(exc)
+        if not self._all_ok(not err):
+            return None, err or "a peer rank cannot open the communicator library"
         if self.world > 1:
             dist.broadcast_object_list(box, src=0)
-        self._host_dir = box[0]
-        return capi.Comm.host(box[0], self.rank, self.world)
+        comm = None
+        try:
+            if cuda:
+                comm = capi.Comm.rccl(self.device.index or 0, self.rank, self.world, box[0])
+            else:
+                self._host_dir = box[0]
+                comm = capi.Comm.host(box[0], self.rank, self.world)
+        except Exception as exc:               # noqa: BLE001
+            err = repr(exc)
+        if not self._all_ok(comm is not None):
+            if comm is not None:
+                comm.close()
+            return None, err or "a peer rank failed to create its communicator"
+        return comm, ""
 
     def close(self):
         if self.comm is not None:
             self.comm.close()
             self.comm = None
             d = getattr(self, "_host_dir", None)
-            if d and self.rank == 0 and os.path.isdir(d):
-                try:
-                    os.rmdir(d)
-                except OSError:
-                    pass
+            if d and self.rank == 0 and os.path.isdir(d):   # every peer has closed (spvo_comm_destroy waits for their done_<rank> markers)
+                import shutil
+                shutil.rmtree(d, ignore_errors=True)
 
     def gather(self, q_xyzw, t) -> np.ndarray:
         """Returns [world, 7]; a rank with no pose yet (first frame) contributes the identity."""

@@ -31,3 +31,19 @@ def test_two_ranks_share_one_gpu():
     assert abs(out["value"] - 2 * 40 / (out["ms_per_step"] * 40 / 1e3)) < 0.02 * out["value"]   # whole-job rate = all ranks' frames / max time
     assert "file transport" in out["config"]["pose_gather"]
     assert out["config"]["streams"] == 2
+
+
+def test_gpus_flag_spawns_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: bench.py starts the two ranks itself (fresh child
+    interpreters, started before anything touches the GPU) and rank 0 prints the one JSON line with n_gpus = 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SPVO_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--repeats", "3", "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["repeats"] == 3 and out["value"] > 0
+    assert out["ms_per_step_min"] <= out["ms_per_step"] <= out["ms_per_step_max"]
+    assert out["config"]["streams"] == 2

@@ -57,3 +57,17 @@ def test_orb_keypoints_and_descriptors_are_bit_exact(cpu, sample_images, case):
     assert np.array_equal(g["desc"], r["desc"])
     d = np.abs(g["angle"] - r["angle"])
     assert np.minimum(d, 2 * np.pi - d).max() <= 1e-5
+
+
+def test_orb_buffers_follow_the_image_shape(cpu):
+    """One context, images of different aspect ratios one after the other: a later image with FEWER pixels but longer rows needs
+    longer resize tables and other pyramid offsets than the first one (the buffers are sized by what each image needs, not by
+    rows x cols).  Every image still equals the CPU restatement bit for bit."""
+    rng = np.random.RandomState(7)
+    ctx = make_ctx()
+    for shape in ((400, 400), (100, 1500), (700, 120), (400, 400)):
+        img = rng.randint(0, 256, shape).astype(np.uint8)
+        g, r = ctx.orb(img), cpu.orb(img)
+        assert len(g["xy"]) == len(r["xy"]) and len(g["xy"]) > 100, shape
+        assert np.array_equal(g["xy"], r["xy"]) and np.array_equal(g["octave"], r["octave"]) and np.array_equal(g["desc"], r["desc"]), shape
+    ctx.close()
