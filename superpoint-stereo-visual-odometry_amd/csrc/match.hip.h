@@ -4,9 +4,13 @@
 // (reference: src/odml_visual_odometry/src/feature_detection_base.cpp:27-28,
 // 462-491).  Structure:
 //   K12a  S = A * B^T on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), one 64 x 128 tile per
-//         workgroup; the approximate squared distance dt = |a|^2 + |b|^2 - 2 S of EVERY pair goes
-//         to HBM (4 MB for 1000 x 1000)
-//   K12b  exact re-rank, one wave per query row.  |dt - d2| <= E = 2^-14 (|a|^2 + |b|^2) is a
+//         workgroup, approximate squared distances dt = |a|^2 + |b|^2 - 2 S.  FUSED form (the default): the tile never
+//         leaves the CU -- its epilogue reduces, per query row and in LDS, the tile's two smallest upper bounds dt + E and
+//         keeps the few columns whose lower bound dt - E does not exceed the second of them ("per-row arg-min in LDS");
+//         what goes to HBM is a handful of {column, lower bound} entries per (row, tile).  K12m then merges a row's <= 8
+//         tile lists under the row-wide threshold and re-scores what is left canonically.  The unfused form (dt of EVERY
+//         pair to HBM, 4 MB for 1000 x 1000, read back by K12b) serves the fp8 shortlist mode.
+//   K12b / K12m  exact re-rank, one wave per query row.  |dt - d2| <= E = 2^-14 (|a|^2 + |b|^2) is a
 //         rigorous bound on the distance between dt and the canonical fp32 distance d2 =
 //         sum_k (a_k - b_k)^2 (sequential k, separately rounded multiply and add: bit-identical
 //         to the oracle), derivation at MATCH_ERR_REL.  With U2 = the second smallest dt + E of
@@ -27,6 +31,8 @@ namespace spvo {
 constexpr int MATCH_D = 256;
 constexpr int MATCH_QT = 64;     // query rows per workgroup (2 waves x 32)
 constexpr int MATCH_TT = 128;    // train rows per workgroup (2 waves x 2 x 32)
+constexpr int MATCH_C = 8;       // fused form: entries a (query row, column tile) may keep; a tile with more survivors (a cluster of
+                                 // near-duplicates) is flagged by its count and re-scored column by column in the merge
 
 // Error bound between the GEMM's dt and the canonical fp32 distance d2 (u = 2^-24, n = 256, N = |a|^2 + |b|^2, d^2 <= 2N):
 //   canonical sum: |d2 - d^2| <= gamma(n + 2) d^2 <= 2 * 258 u N                                   = 516 u N
@@ -43,13 +49,17 @@ constexpr float MATCH_ERR_REL_FP8 = 2e-2f;
 __device__ __forceinline__ int dev_count(int n_host, const int *n_ptr) { return n_ptr ? *n_ptr : n_host; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct MatchBest { float d0, d1; int i0, i1; };   // the two nearest so far under (distance, index) order
+struct MatchTwo { float u1, u2; };                // two smallest values
 
 struct MatchJob {
   const float *A, *B;             // [na][256], [nb][256]
   int na, nb;                     // host counts (upper bounds when the *_ptr are set)
   const int *na_ptr, *nb_ptr;     // device counts or NULL
   const float *nA, *nB;           // squared row norms
-  float *dt;                      // [na][ldt] approximate squared distances (K12a -> K12b)
+  float *dt;                      // [na][ldt] approximate squared distances (K12a -> K12b; unfused form only)
+  int2 *cand;                     // [na][nt_stride][MATCH_C] {train row, float bits of dt - E}: a tile's survivors (fused form)
+  int4 *meta;                     // [na][nt_stride] {survivor count (may exceed MATCH_C), float bits of the tile's two smallest dt + E, 0}
   float *best_d2;                 // [na][2]
   int *best_idx;                  // [na][2]
   const unsigned char *A8, *B8;   // fp8 (e4m3) copies [n][256] of A * 16 and B * 16 for the fp8 shortlist GEMM, or NULL
@@ -109,8 +119,8 @@ __host__ __device__ inline int match_ldt(int nb_cap) { return (nb_cap + 31) & ~3
 // memory: a lane's 8 consecutive dimensions of one row are 8 contiguous bytes); dt is then approximate beyond
 // MATCH_ERR_REL -- K12b runs with the statistical window MATCH_ERR_REL_FP8 and still produces exact distances for
 // whatever falls into it -- so this mode is an opt-in (spvo_set_match_fp8).
-template <bool FP8>
-__global__ __launch_bounds__(256) void match_gemm_kernel(MatchJobs jobs, int ldt) {
+template <bool FP8, bool FUSED = false>
+__global__ __launch_bounds__(256) void match_gemm_kernel(MatchJobs jobs, int ldt, float err_rel = 0.f, int nt_stride = 0) {
   const MatchJob jb = jobs.j[blockIdx.z];
   const float *__restrict__ A = jb.A;
   const float *__restrict__ B = jb.B;
@@ -220,6 +230,58 @@ __global__ __launch_bounds__(256) void match_gemm_kernel(MatchJobs jobs, int ldt
       w0[row * LDD + 32] = nav[r] + nbb - 2.f * acc1[r];
     }
   }
+  if constexpr (FUSED) {
+    // ---- per-row reduction of the tile in LDS: the tile's dt never reaches HBM.
+    //   thread (row = tid / 4, part = tid % 4) owns the row's columns 16 i + 4 part .. + 3, i = 0..7 (8 ds_read_b128)
+    //   pass 1: the row's two smallest upper bounds up = dt + E over the tile's columns (4 lanes combined by a butterfly)
+    //   pass 2: columns with lo = dt - E <= (second smallest up) are the tile's survivors: the row's true nearest and second
+    //           nearest are among the survivors of SOME tile whatever the other tiles hold, because the row-wide threshold
+    //           K12m applies (second smallest up of the whole row) is <= this tile's.
+    float *snb = sD + MATCH_QT * LDD;                            // [128] squared norms of the tile's train rows
+    int *scnt = reinterpret_cast<int *>(snb + MATCH_TT);         // [64]  survivors per row
+    int2 *slist = reinterpret_cast<int2 *>(scnt + MATCH_QT);     // [64][MATCH_C]
+    if (tid < MATCH_TT) snb[tid] = jb.nB[min(t0 + tid, nb - 1)];
+    if (tid < MATCH_QT) scnt[tid] = 0;
+    __syncthreads();
+    const int row = tid >> 2, part = tid & 3;
+    const float naq = jb.nA[min(q0 + row, na - 1)];
+    float lo[32];
+    MatchTwo two{__builtin_inff(), __builtin_inff()};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const f32x4 d = *(const f32x4 *)(sD + row * LDD + 16 * i + 4 * part);
+      const f32x4 nv = *(const f32x4 *)(snb + 16 * i + 4 * part);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool in = t0 + 16 * i + 4 * part + e < nb;
+        const float err = err_rel * (naq + nv[e]);
+        const float up = in ? d[e] + err : __builtin_inff();
+        lo[4 * i + e] = in ? d[e] - err : __builtin_inff();
+        if (up < two.u1) { two.u2 = two.u1; two.u1 = up; } else if (up < two.u2) two.u2 = up;
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < 4; o <<= 1) {
+      const float o1 = __shfl_xor(two.u1, o), o2 = __shfl_xor(two.u2, o);
+      const float hi = fmaxf(two.u1, o1);
+      two.u1 = fminf(two.u1, o1);
+      two.u2 = fminf(hi, fminf(two.u2, o2));
+    }
+#pragma unroll
+    for (int k = 0; k < 32; ++k)
+      if (lo[k] <= two.u2) {   // (+inf <= +inf for a tile with a single column: that column survives, as it must)
+        const int pos = atomicAdd(&scnt[row], 1);
+        if (pos < MATCH_C) slist[row * MATCH_C + pos] = make_int2(t0 + 16 * (k >> 2) + 4 * part + (k & 3), __float_as_int(lo[k]));
+      }
+    __syncthreads();
+    if (q0 + row < na) {
+      const size_t slot = (size_t)(q0 + row) * nt_stride + blockIdx.x;
+      const int cnt = scnt[row];
+      if (part == 0) jb.meta[slot] = make_int4(cnt, __float_as_int(two.u1), __float_as_int(two.u2), 0);
+      if (2 * part < min(cnt, MATCH_C)) *reinterpret_cast<int4 *>(jb.cand + slot * MATCH_C + 2 * part) = *reinterpret_cast<const int4 *>(slist + row * MATCH_C + 2 * part);
+    }
+    return;
+  }
   __syncthreads();
   float *__restrict__ D = jb.dt;
   const int c4 = tid & 31, r0 = tid >> 5;
@@ -254,8 +316,6 @@ template <int NCH> struct MatchRerankLds {
 };
 
 // Re-scores queue entries [head, head + n), n <= 64, and merges them into the best two.
-struct MatchBest { float d0, d1; int i0, i1; };   // the two nearest so far under (distance, index) order
-struct MatchTwo { float u1, u2; };                // two smallest values
 
 template <int LIST>
 __device__ __forceinline__ MatchBest match_score_batch(volatile int *list, int head, int n, const float *__restrict__ B,
@@ -469,6 +529,103 @@ __global__ __launch_bounds__(256) void match_rerank_kernel(MatchJobs jobs, int l
       // keeps the nearest of the train rows that chose it, the lowest train row on ties (cv::batchDistance: `d < d0`
       // while the train index runs upwards) = the minimum of {distance bits, train row}
       if (i0 >= 0) atomicMin(&jb.train_best[i0], ((unsigned long long)__float_as_uint(s0) << 32) | (unsigned)q);
+    } else {
+      int out = -1;
+      if (selector == 0) out = i0;
+      else if (i0 >= 0 && i1 >= 0 && s0 < mul_rn(ratio, s1)) out = i0;   // base.cpp:469
+      jb.out[q] = make_int2(out, __float_as_int(s0));
+    }
+  }
+}
+
+// K12m.  The re-rank of the fused form: one wave per query row, fed by the tile lists K12a left behind instead of the row of dt.
+//   threshold  U2 = second smallest of the tiles' {u1, u2} = second smallest dt + E of the whole row
+//   candidates the stored entries with lo <= U2; a tile whose survivor count exceeds MATCH_C kept only some of them, so ALL
+//              its columns are candidates (no dt to prune with: a cluster of near-duplicates pays 128 canonical distances per
+//              such tile, everything else 2-3 per row)
+// then exactly what K12b does: canonical re-score in batches, best two under (distance, index), selector / vote.
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void match_merge_kernel(MatchJobs jobs, int nt_stride, int selector, int cross_check, float ratio) {
+  using L = MatchRerankLds<0>;
+  constexpr int LIST = L::LIST;
+  const MatchJob jb = jobs.j[blockIdx.y];
+  const float *__restrict__ A = jb.A;
+  const float *__restrict__ B = jb.B;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  L &lds = *reinterpret_cast<L *>(smem);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = blockIdx.x * 4 + wave;
+  const int lane = threadIdx.x & 63;
+  const int na = dev_count(jb.na, jb.na_ptr), nb = dev_count(jb.nb, jb.nb_ptr);
+  if (q >= na) return;
+  volatile int *list = lds.list[wave];
+  ((float4 *)lds.a[wave])[lane] = ((const float4 *)(A + (size_t)q * MATCH_D))[lane];
+  const int ntiles = (nb + MATCH_TT - 1) / MATCH_TT;   // <= 64 (the host refuses larger capacities for this form)
+  int cnt = 0;
+  MatchTwo two{__builtin_inff(), __builtin_inff()};
+  if (lane < ntiles) {
+    const int4 m = jb.meta[(size_t)q * nt_stride + lane];
+    cnt = m.x; two.u1 = __int_as_float(m.y); two.u2 = __int_as_float(m.z);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const float4 *a4 = (const float4 *)lds.a[wave];
+  float thr;
+  {
+    float u1 = two.u1, u2 = two.u2;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float o1 = __shfl_xor(u1, o), o2 = __shfl_xor(u2, o);
+      const float hi = fmaxf(u1, o1);
+      u1 = fminf(u1, o1);
+      u2 = fminf(hi, fminf(u2, o2));
+    }
+    thr = u2;   // +inf when the row has fewer than two columns: everything is a candidate
+  }
+  MatchBest best{__builtin_inff(), __builtin_inff(), -1, -1};
+  int head = 0, tail = 0;
+  auto push = [&](bool c, int col) __attribute__((always_inline)) {
+    const unsigned long long mask = __ballot(c);
+    if (c) list[(tail + __popcll(mask & ((1ull << lane) - 1ull))) & (LIST - 1)] = col;
+    tail += __popcll(mask);
+  };
+  auto drain = [&](bool all) __attribute__((always_inline)) {
+    while (tail - head >= 64 || (all && tail > head)) {
+      const int n = min(64, tail - head);
+      best = match_score_batch<LIST>(list, head, n, B, a4, lds.b[wave], lane, best);
+      head += n;
+    }
+  };
+  const int2 *__restrict__ crow = jb.cand + (size_t)q * nt_stride * MATCH_C;
+  for (int base = 0; base < ntiles * MATCH_C; base += 64) {
+    const int s = base + lane, tile = s / MATCH_C, c = s % MATCH_C;
+    const int cnt_t = __shfl(cnt, tile & 63);
+    const bool valid = s < ntiles * MATCH_C && cnt_t <= MATCH_C && c < cnt_t;
+    int2 e = make_int2(0, 0);
+    if (valid) e = crow[s];
+    push(valid && __int_as_float(e.y) <= thr, e.x);
+    drain(false);
+  }
+  unsigned long long over = __ballot(lane < ntiles && cnt > MATCH_C);
+  while (over) {
+    const int t = __builtin_ctzll(over);
+    over &= over - 1;
+#pragma unroll 1
+    for (int h = 0; h < MATCH_TT / 64; ++h) {
+      const int col = t * MATCH_TT + h * 64 + lane;
+      push(col < nb, col);
+      drain(false);
+    }
+  }
+  drain(true);
+
+  const float d0 = best.d0, d1 = best.d1;
+  const int i0 = best.i0, i1 = best.i1;
+  if (lane == 0) {
+    jb.best_d2[2 * q] = d0; jb.best_d2[2 * q + 1] = d1;
+    jb.best_idx[2 * q] = i0; jb.best_idx[2 * q + 1] = i1;
+    const float s0 = sqrtf(d0), s1 = sqrtf(d1);   // BFMatcher L2 returns sqrt(sum of squares)
+    if (selector == 0 && cross_check) {
+      if (i0 >= 0) atomicMin(&jb.train_best[i0], ((unsigned long long)__float_as_uint(s0) << 32) | (unsigned)q);   // see K12b
     } else {
       int out = -1;
       if (selector == 0) out = i0;

@@ -103,7 +103,9 @@ struct MatchCache {
 
 struct MatchScratch {         // one set per concurrently enqueued match
   float *d_na = nullptr, *d_nb = nullptr, *d_best_d2 = nullptr;
-  float *d_dt = nullptr;      // [cap][match_ldt(cap)] approximate squared distances of every pair (K12a -> K12b)
+  float *d_dt = nullptr;      // [cap][match_ldt(cap)] approximate squared distances of every pair (K12a -> K12b; the fp8 shortlist mode)
+  int2 *d_cand = nullptr;     // [cap][nt][MATCH_C] a tile's survivors per query row (fused K12a -> K12m), nt = ceil(cap / 128)
+  int4 *d_meta = nullptr;     // [cap][nt] survivor count and the two smallest upper bounds per (row, tile)
   int *d_best_idx = nullptr;
   unsigned long long *d_train_best = nullptr;
   unsigned char *d_a8 = nullptr, *d_b8 = nullptr;   // fp8 copies of both sides (spvo_set_match_fp8)

@@ -15,7 +15,7 @@ int ensure_match(spvo_ctx *c, int na, int nb) {
   auto drop = [](auto *&p) { if (p) (void)hipFree(p); p = nullptr; };
   drop(c->d_ma); drop(c->d_mb); drop(c->d_match_out);
   for (auto &m : c->ms) {
-    drop(m.d_na); drop(m.d_nb); drop(m.d_best_d2); drop(m.d_dt); drop(m.d_best_idx); drop(m.d_train_best); drop(m.d_a8); drop(m.d_b8);
+    drop(m.d_na); drop(m.d_nb); drop(m.d_best_d2); drop(m.d_dt); drop(m.d_cand); drop(m.d_meta); drop(m.d_best_idx); drop(m.d_train_best); drop(m.d_a8); drop(m.d_b8);
     m.d_out = nullptr;
   }
   for (auto &p : c->h_match_out) { if (p) (void)hipHostFree(p); p = nullptr; }
@@ -32,6 +32,9 @@ int ensure_match(spvo_ctx *c, int na, int nb) {
     if ((rc = dev_alloc(c, &m.d_nb, cap + 4))) return rc;
     if ((rc = dev_alloc(c, &m.d_best_d2, (size_t)cap * 2))) return rc;
     if ((rc = dev_alloc(c, &m.d_dt, (size_t)cap * match_ldt(cap)))) return rc;
+    const size_t nt = (size_t)(cap + MATCH_TT - 1) / MATCH_TT;
+    if ((rc = dev_alloc(c, &m.d_cand, (size_t)cap * nt * MATCH_C))) return rc;
+    if ((rc = dev_alloc(c, &m.d_meta, (size_t)cap * nt))) return rc;
     if ((rc = dev_alloc(c, &m.d_best_idx, (size_t)cap * 2))) return rc;
     if ((rc = dev_alloc(c, &m.d_train_best, cap))) return rc;
     if ((rc = dev_alloc(c, &m.d_a8, (size_t)cap * MATCH_D))) return rc;
@@ -73,7 +76,7 @@ int enqueue_matches(spvo_ctx *c, const MatchReq *req_in, int njobs, int selector
     j.na_ptr = req[k].na_ptr; j.nb_ptr = req[k].nb_ptr;
     j.nA = req[k].sqA ? req[k].sqA : m.d_na;
     j.nB = req[k].sqB ? req[k].sqB : m.d_nb;
-    j.dt = m.d_dt; j.best_d2 = m.d_best_d2; j.best_idx = m.d_best_idx; j.train_best = m.d_train_best; j.out = m.d_out;
+    j.dt = m.d_dt; j.cand = m.d_cand; j.meta = m.d_meta; j.best_d2 = m.d_best_d2; j.best_idx = m.d_best_idx; j.train_best = m.d_train_best; j.out = m.d_out;
     j.A8 = j.B8 = nullptr;
     if (c->match_fp8) {
       hipLaunchKernelGGL(desc_to_fp8_kernel, dim3((req[k].na + 3) / 4), dim3(256), 0, c->post, req[k].dA, req[k].na, req[k].na_ptr, m.d_a8);
@@ -94,13 +97,22 @@ int enqueue_matches(spvo_ctx *c, const MatchReq *req_in, int njobs, int selector
   const size_t lds = MATCH_LDS_BYTES;
   static bool attr[64] = {};
   if (!attr[c->cfg.device & 63]) {
-    HIP_TRY(c, hipFuncSetAttribute((const void *)match_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(c, hipFuncSetAttribute((const void *)match_gemm_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(c, hipFuncSetAttribute((const void *)match_gemm_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr[c->cfg.device & 63] = true;
   }
+  // Default: the fused form -- the distance tile is reduced per query row in LDS (K12a) and a short merge (K12m) finishes the row;
+  // dt never goes to HBM.  The fp8 shortlist mode (and SPVO_MATCH_FUSED=0, for A/B measurements) keeps the two-kernel form that
+  // writes every dt and reads it back.  Column tiles are lanes of the merge: capacities beyond 64 tiles use the unfused form.
+  static const bool fused_on = !(std::getenv("SPVO_MATCH_FUSED") && std::atoi(std::getenv("SPVO_MATCH_FUSED")) == 0);
+  const int nt_stride = (c->match_cap + MATCH_TT - 1) / MATCH_TT;
+  const bool fused = fused_on && !c->match_fp8 && nt_stride <= 64;
+  const dim3 gg(groups, (na_max + MATCH_QT - 1) / MATCH_QT, njobs);
   {
     ScopedStage sg(c, stage_id(c, "match_gemm"), fl, 4.0 * (na_max + nb_max) * MATCH_D * njobs);
-    if (c->match_fp8) hipLaunchKernelGGL(match_gemm_kernel<true>, dim3(groups, (na_max + MATCH_QT - 1) / MATCH_QT, njobs), dim3(256), MATCH_LDS_BYTES_FP8, c->post, jobs, ldt);
-    else hipLaunchKernelGGL(match_gemm_kernel<false>, dim3(groups, (na_max + MATCH_QT - 1) / MATCH_QT, njobs), dim3(256), lds, c->post, jobs, ldt);
+    if (c->match_fp8) hipLaunchKernelGGL((match_gemm_kernel<true, false>), gg, dim3(256), MATCH_LDS_BYTES_FP8, c->post, jobs, ldt, 0.f, 0);
+    else if (fused) hipLaunchKernelGGL((match_gemm_kernel<false, true>), gg, dim3(256), lds, c->post, jobs, ldt, MATCH_ERR_REL, nt_stride);
+    else hipLaunchKernelGGL((match_gemm_kernel<false, false>), gg, dim3(256), lds, c->post, jobs, ldt, 0.f, 0);
   }
   {
     ScopedStage sr(c, stage_id(c, "match_rerank"));
@@ -108,7 +120,8 @@ int enqueue_matches(spvo_ctx *c, const MatchReq *req_in, int njobs, int selector
     const dim3 gr((na_max + 3) / 4, njobs);
     // rows of up to 1024 columns stay in registers between the two passes of the re-rank (8 chunks for 2048 columns
     // measured 2.4x SLOWER than the chunked form: 232 registers, 70 KB of LDS)
-    if (nb_max <= 1024) hipLaunchKernelGGL(match_rerank_kernel<4>, gr, dim3(256), sizeof(MatchRerankLds<4>), c->post, jobs, ldt, err, selector, cross_check, ratio);
+    if (fused) hipLaunchKernelGGL(match_merge_kernel<>, gr, dim3(256), sizeof(MatchRerankLds<0>), c->post, jobs, nt_stride, selector, cross_check, ratio);
+    else if (nb_max <= 1024) hipLaunchKernelGGL(match_rerank_kernel<4>, gr, dim3(256), sizeof(MatchRerankLds<4>), c->post, jobs, ldt, err, selector, cross_check, ratio);
     else hipLaunchKernelGGL(match_rerank_kernel<0>, gr, dim3(256), sizeof(MatchRerankLds<0>), c->post, jobs, ldt, err, selector, cross_check, ratio);
   }
   if (swap) hipLaunchKernelGGL(match_select_cross_kernel, dim3((nb_max + 255) / 256, njobs), dim3(256), 0, c->post, jobs);

@@ -1,6 +1,7 @@
 // Stand-alone timing of the matcher's kernels (csrc/match.hip.h) in the pipeline's configuration: two jobs (stereo and
 // temporal match) per launch.  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/match_bench.hip -o tools/match_bench
-// usage: match_bench [n = 1000] [jobs = 2] [reps = 200]
+// usage: match_bench [n = 1000] [jobs = 2] [reps = 200]   -- times the unfused form (K12a writes dt, K12b reads it back) and the
+// fused form (K12a reduces each tile per row in LDS, K12m merges) and checks that both give the same matches
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -24,7 +25,10 @@ int main(int argc, char **argv) {
   }
   float *d, *sq, *dt, *bd;
   int *bi;
-  int2 *out;
+  int2 *out, *cand;
+  int4 *meta;
+  const int nt = (n + MATCH_TT - 1) / MATCH_TT;
+  CK(hipMalloc(&cand, (size_t)2 * n * nt * MATCH_C * sizeof(int2))); CK(hipMalloc(&meta, (size_t)2 * n * nt * sizeof(int4)));
   CK(hipMalloc(&d, h.size() * 4)); CK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   CK(hipMalloc(&sq, 4 * n * 4 + 64)); CK(hipMalloc(&dt, (size_t)2 * n * ldt * 4)); CK(hipMalloc(&bd, 4 * n * 4)); CK(hipMalloc(&bi, 4 * n * 4));
   CK(hipMalloc(&out, 2 * n * sizeof(int2)));
@@ -34,34 +38,45 @@ int main(int argc, char **argv) {
     MatchJob &j = jobs.j[k];
     j.A = d + (size_t)(2 * k) * n * 256; j.B = d + (size_t)(2 * k + 1) * n * 256; j.na = j.nb = n; j.na_ptr = j.nb_ptr = nullptr;
     j.nA = sq + (2 * k) * n; j.nB = sq + (2 * k + 1) * n; j.dt = dt + (size_t)k * n * ldt; j.best_d2 = bd + 2 * k * n; j.best_idx = bi + 2 * k * n;
+    j.cand = cand + (size_t)k * n * nt * MATCH_C; j.meta = meta + (size_t)k * n * nt;
     j.A8 = j.B8 = nullptr; j.train_best = nullptr; j.out = out + k * n;
   }
-  CK(hipFuncSetAttribute((const void *)match_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH_LDS_BYTES));
+  CK(hipFuncSetAttribute((const void *)match_gemm_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH_LDS_BYTES));
+  CK(hipFuncSetAttribute((const void *)match_gemm_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH_LDS_BYTES));
   const dim3 gg((n + MATCH_TT - 1) / MATCH_TT, (n + MATCH_QT - 1) / MATCH_QT, njobs), gr((n + 3) / 4, njobs);
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float ms;
-  for (int phase = 0; phase < 3; ++phase) {
-    for (int w = 0; w < 2; ++w) {   // w = 0 warms up
-      CK(hipEventRecord(e0));
-      for (int i = 0; i < reps; ++i) {
-        if (phase != 1) hipLaunchKernelGGL(match_gemm_kernel<false>, gg, dim3(256), MATCH_LDS_BYTES, 0, jobs, ldt);
-        if (phase != 0) {
-          if (n <= 1024) hipLaunchKernelGGL(match_rerank_kernel<4>, gr, dim3(256), sizeof(MatchRerankLds<4>), 0, jobs, ldt, MATCH_ERR_REL, 1, 0, 0.8f);
-          else hipLaunchKernelGGL(match_rerank_kernel<0>, gr, dim3(256), sizeof(MatchRerankLds<0>), 0, jobs, ldt, MATCH_ERR_REL, 1, 0, 0.8f);
+  std::vector<int2> ho[2];
+  for (int fused = 0; fused < 2; ++fused) {
+    CK(hipMemset(out, 0xFF, 2 * n * sizeof(int2)));
+    for (int phase = 0; phase < 3; ++phase) {
+      for (int w = 0; w < 2; ++w) {   // w = 0 warms up
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < reps; ++i) {
+          if (phase != 1) {
+            if (fused) hipLaunchKernelGGL((match_gemm_kernel<false, true>), gg, dim3(256), MATCH_LDS_BYTES, 0, jobs, ldt, MATCH_ERR_REL, nt);
+            else hipLaunchKernelGGL((match_gemm_kernel<false, false>), gg, dim3(256), MATCH_LDS_BYTES, 0, jobs, ldt, 0.f, 0);
+          }
+          if (phase != 0) {
+            if (fused) hipLaunchKernelGGL(match_merge_kernel<>, gr, dim3(256), sizeof(MatchRerankLds<0>), 0, jobs, nt, 1, 0, 0.8f);
+            else if (n <= 1024) hipLaunchKernelGGL(match_rerank_kernel<4>, gr, dim3(256), sizeof(MatchRerankLds<4>), 0, jobs, ldt, MATCH_ERR_REL, 1, 0, 0.8f);
+            else hipLaunchKernelGGL(match_rerank_kernel<0>, gr, dim3(256), sizeof(MatchRerankLds<0>), 0, jobs, ldt, MATCH_ERR_REL, 1, 0, 0.8f);
+          }
         }
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
       }
-      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+      const double us = ms * 1e3 / reps, fl = 2.0 * n * n * 256 * njobs;
+      const char *form = fused ? "fused  " : "unfused";
+      if (phase == 0) printf("%s n=%d jobs=%d  gemm   %7.2f us  %6.1f TFLOP/s = %.3f of the fp32 MFMA peak (%d workgroups)\n", form, n, njobs, us, fl / us / 1e6, fl / us / 1e6 / 157.3, gg.x * gg.y * gg.z);
+      if (phase == 1) printf("%s n=%d jobs=%d  %s %7.2f us\n", form, n, njobs, fused ? "merge " : "rerank", us);
+      if (phase == 2) printf("%s n=%d jobs=%d  both   %7.2f us\n", form, n, njobs, us);
     }
-    const double us = ms * 1e3 / reps, fl = 2.0 * n * n * 256 * njobs;
-    if (phase == 0) printf("n=%d jobs=%d  gemm   %7.2f us  %6.1f TFLOP/s = %.3f of the fp32 MFMA peak (%d workgroups)\n", n, njobs, us, fl / us / 1e6, fl / us / 1e6 / 157.3, gg.x * gg.y * gg.z);
-    if (phase == 1) printf("n=%d jobs=%d  rerank %7.2f us\n", n, njobs, us);
-    if (phase == 2) printf("n=%d jobs=%d  both   %7.2f us\n", n, njobs, us);
+    ho[fused].resize(2 * n);
+    CK(hipMemcpy(ho[fused].data(), out, ho[fused].size() * sizeof(int2), hipMemcpyDeviceToHost));
   }
-  std::vector<int2> ho(2 * n);
-  CK(hipMemcpy(ho.data(), out, ho.size() * sizeof(int2), hipMemcpyDeviceToHost));
-  long cs = 0;
-  for (auto &v : ho) cs += v.x;
-  printf("checksum %ld\n", cs);
+  long cs = 0, diff = 0;
+  for (int i = 0; i < njobs * n; ++i) { cs += ho[1][i].x; diff += ho[0][i].x != ho[1][i].x || ho[0][i].y != ho[1][i].y; }
+  printf("checksum %ld, rows on which the two forms differ: %ld\n", cs, diff);
   return 0;
 }
