@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void match_gemm_kernel(MatchJobs jobs, int ldt
         const bool in = t0 + 16 * i + 4 * part + e < nb;
         const float err = err_rel * (naq + nv[e]);
         const float up = in ? d[e] + err : __builtin_inff();
-        lo[4 * i + e] = in ? d[e] - err : __builtin_inff();
+        lo[4 * i + e] = in ? d[e] - err : __builtin_nanf("");   // a column beyond nb never survives: NaN <= x is false, also for x = +inf
         if (up < two.u1) { two.u2 = two.u1; two.u1 = up; } else if (up < two.u2) two.u2 = up;
       }
     }
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void match_gemm_kernel(MatchJobs jobs, int ldt
     }
 #pragma unroll
     for (int k = 0; k < 32; ++k)
-      if (lo[k] <= two.u2) {   // (+inf <= +inf for a tile with a single column: that column survives, as it must)
+      if (lo[k] <= two.u2) {   // (u2 = +inf for a tile with a single column: that column survives, as it must)
         const int pos = atomicAdd(&scnt[row], 1);
         if (pos < MATCH_C) slist[row * MATCH_C + pos] = make_int2(t0 + 16 * (k >> 2) + 4 * part + (k & 3), __float_as_int(lo[k]));
       }
@@ -279,6 +279,15 @@ __global__ __launch_bounds__(256) void match_gemm_kernel(MatchJobs jobs, int ldt
       const int cnt = scnt[row];
       if (part == 0) jb.meta[slot] = make_int4(cnt, __float_as_int(two.u1), __float_as_int(two.u2), 0);
       if (2 * part < min(cnt, MATCH_C)) *reinterpret_cast<int4 *>(jb.cand + slot * MATCH_C + 2 * part) = *reinterpret_cast<const int4 *>(slist + row * MATCH_C + 2 * part);
+      // More survivors than entries (near-duplicate descriptors: every column of the tile inside the window of its own second
+      // smallest): this row's piece of the tile does go to HBM, 512 bytes, and K12m prunes it with the row-wide threshold
+      // exactly as K12b would.  Trained descriptors never take this path (2-3 survivors per row).
+      if (cnt > MATCH_C) {
+        float *__restrict__ drow = jb.dt + (size_t)(q0 + row) * ldt + t0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (t0 + 16 * i + 4 * part < ldt) *(f32x4 *)(drow + 16 * i + 4 * part) = *(const f32x4 *)(sD + row * LDD + 16 * i + 4 * part);
+      }
     }
     return;
   }
@@ -540,12 +549,11 @@ __global__ __launch_bounds__(256) void match_rerank_kernel(MatchJobs jobs, int l
 
 // K12m.  The re-rank of the fused form: one wave per query row, fed by the tile lists K12a left behind instead of the row of dt.
 //   threshold  U2 = second smallest of the tiles' {u1, u2} = second smallest dt + E of the whole row
-//   candidates the stored entries with lo <= U2; a tile whose survivor count exceeds MATCH_C kept only some of them, so ALL
-//              its columns are candidates (no dt to prune with: a cluster of near-duplicates pays 128 canonical distances per
-//              such tile, everything else 2-3 per row)
+//   candidates the stored entries with lo <= U2; a tile whose survivor count exceeds MATCH_C kept only some of them and left the
+//              row's 128 dt values of that tile in HBM instead: they are pruned here with U2, as K12b prunes a whole row
 // then exactly what K12b does: canonical re-score in batches, best two under (distance, index), selector / vote.
 template <int UNUSED = 0>
-__global__ __launch_bounds__(256) void match_merge_kernel(MatchJobs jobs, int nt_stride, int selector, int cross_check, float ratio) {
+__global__ __launch_bounds__(256) void match_merge_kernel(MatchJobs jobs, int nt_stride, int ldt, float err_rel, int selector, int cross_check, float ratio) {
   using L = MatchRerankLds<0>;
   constexpr int LIST = L::LIST;
   const MatchJob jb = jobs.j[blockIdx.y];
@@ -606,14 +614,20 @@ __global__ __launch_bounds__(256) void match_merge_kernel(MatchJobs jobs, int nt
     drain(false);
   }
   unsigned long long over = __ballot(lane < ntiles && cnt > MATCH_C);
-  while (over) {
-    const int t = __builtin_ctzll(over);
-    over &= over - 1;
+  if (over) {
+    const float *__restrict__ drow = jb.dt + (size_t)q * ldt;
+    const float naq = jb.nA[q];
+    while (over) {
+      const int t = __builtin_ctzll(over);
+      over &= over - 1;
 #pragma unroll 1
-    for (int h = 0; h < MATCH_TT / 64; ++h) {
-      const int col = t * MATCH_TT + h * 64 + lane;
-      push(col < nb, col);
-      drain(false);
+      for (int h = 0; h < MATCH_TT / 64; ++h) {
+        const int col = t * MATCH_TT + h * 64 + lane;
+        const bool in = col < nb;
+        const float dv = in ? drow[col] : 0.f, nv = in ? jb.nB[col] : 0.f;
+        push(in && dv - err_rel * (naq + nv) <= thr, col);
+        drain(false);
+      }
     }
   }
   drain(true);

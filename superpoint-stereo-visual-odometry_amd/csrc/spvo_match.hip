@@ -120,7 +120,7 @@ int enqueue_matches(spvo_ctx *c, const MatchReq *req_in, int njobs, int selector
     const dim3 gr((na_max + 3) / 4, njobs);
     // rows of up to 1024 columns stay in registers between the two passes of the re-rank (8 chunks for 2048 columns
     // measured 2.4x SLOWER than the chunked form: 232 registers, 70 KB of LDS)
-    if (fused) hipLaunchKernelGGL(match_merge_kernel<>, gr, dim3(256), sizeof(MatchRerankLds<0>), c->post, jobs, nt_stride, selector, cross_check, ratio);
+    if (fused) hipLaunchKernelGGL(match_merge_kernel<>, gr, dim3(256), sizeof(MatchRerankLds<0>), c->post, jobs, nt_stride, ldt, MATCH_ERR_REL, selector, cross_check, ratio);
     else if (nb_max <= 1024) hipLaunchKernelGGL(match_rerank_kernel<4>, gr, dim3(256), sizeof(MatchRerankLds<4>), c->post, jobs, ldt, err, selector, cross_check, ratio);
     else hipLaunchKernelGGL(match_rerank_kernel<0>, gr, dim3(256), sizeof(MatchRerankLds<0>), c->post, jobs, ldt, err, selector, cross_check, ratio);
   }

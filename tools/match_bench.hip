@@ -1,6 +1,6 @@
 // Stand-alone timing of the matcher's kernels (csrc/match.hip.h) in the pipeline's configuration: two jobs (stereo and
 // temporal match) per launch.  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/match_bench.hip -o tools/match_bench
-// usage: match_bench [n = 1000] [jobs = 2] [reps = 200]   -- times the unfused form (K12a writes dt, K12b reads it back) and the
+// usage: match_bench [n = 1000] [jobs = 2] [reps = 200] [spread = 0]   -- times the unfused form (K12a writes dt, K12b reads it back) and the
 // fused form (K12a reduces each tile per row in LDS, K12m merges) and checks that both give the same matches
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -14,13 +14,14 @@ using namespace spvo;
 
 int main(int argc, char **argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 1000, njobs = argc > 2 ? atoi(argv[2]) : 2, reps = argc > 3 ? atoi(argv[3]) : 200;
+  const float spread = argc > 4 ? (float)atof(argv[4]) : 0.f;   // > 0: every descriptor = one common vector + spread x noise (near-duplicates: many rows inside every window)
   const int ldt = match_ldt(n);
   std::mt19937 rng(1);
   std::normal_distribution<float> nd;
   std::vector<float> h((size_t)4 * n * 256);
   for (int r = 0; r < 4 * n; ++r) {
     double s = 0;
-    for (int k = 0; k < 256; ++k) { float v = nd(rng); h[(size_t)r * 256 + k] = v; s += (double)v * v; }
+    for (int k = 0; k < 256; ++k) { float v = nd(rng); if (spread > 0.f) v = std::sin(0.37f * k) + spread * v; h[(size_t)r * 256 + k] = v; s += (double)v * v; }
     for (int k = 0; k < 256; ++k) h[(size_t)r * 256 + k] /= (float)std::sqrt(s);
   }
   float *d, *sq, *dt, *bd;
@@ -59,7 +60,7 @@ int main(int argc, char **argv) {
             else hipLaunchKernelGGL((match_gemm_kernel<false, false>), gg, dim3(256), MATCH_LDS_BYTES, 0, jobs, ldt, 0.f, 0);
           }
           if (phase != 0) {
-            if (fused) hipLaunchKernelGGL(match_merge_kernel<>, gr, dim3(256), sizeof(MatchRerankLds<0>), 0, jobs, nt, 1, 0, 0.8f);
+            if (fused) hipLaunchKernelGGL(match_merge_kernel<>, gr, dim3(256), sizeof(MatchRerankLds<0>), 0, jobs, nt, ldt, MATCH_ERR_REL, 1, 0, 0.8f);
             else if (n <= 1024) hipLaunchKernelGGL(match_rerank_kernel<4>, gr, dim3(256), sizeof(MatchRerankLds<4>), 0, jobs, ldt, MATCH_ERR_REL, 1, 0, 0.8f);
             else hipLaunchKernelGGL(match_rerank_kernel<0>, gr, dim3(256), sizeof(MatchRerankLds<0>), 0, jobs, ldt, MATCH_ERR_REL, 1, 0, 0.8f);
           }
