@@ -6,6 +6,7 @@
 #include "conv_bf16x3.hip.h"
 #include "conv_wino.hip.h"
 #include "conv_wino2.hip.h"
+#include "conv_wino64.hip.h"
 #include "conv_i8.hip.h"
 
 namespace spvo_int {
@@ -662,6 +663,24 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
         // layer -- one tile's chain of items per workgroup -- becomes a chain of half-size items (SPVO_WINO_NARROW=0: direct kernel)
         const bool narrow_on = !(std::getenv("SPVO_WINO_NARROW") && std::atoi(std::getenv("SPVO_WINO_NARROW")) == 0);
         if (eligible && !op.wino && op.wino2 && narrow_on && (op.cout % 32) == 0 && 2 * wtiles >= min_tiles) op.wino = op.wino_narrow = true;
+      }
+      // 64 input channels (conv1b, conv2a, conv2b, conv3a of the VGG graph): the transformed filters of a 64-channel output tile fit
+      // the registers of one workgroup and stay there (conv_wino64.hip.h) -- no filter staging at all.  Needs even H and W (a
+      // Winograd tile's four outputs are then all inside or all outside the image) and enough 4 x 32 tiles to fill the chip.
+      if (op.wino && !op.wino_narrow && op.wino2 && op.cin == Wino64Tile::CIN && ((ti.H | ti.W) & 1) == 0 &&
+          std::getenv("SPVO_WINO64") && std::atoi(std::getenv("SPVO_WINO64")) != 0) {   // opt-in: measured no faster than the 8-wave form
+        const long t64 = (long)((ti.W + Wino64Tile::TW - 1) / Wino64Tile::TW) * ((ti.H + Wino64Tile::TH - 1) / Wino64Tile::TH) * op.co_tiles * c->cfg.max_batch;
+        if (t64 >= 2 * c->num_cus) {
+          op.wino64 = true;
+          op.ck = Wino64Tile::CK;
+          op.n_chunks = Wino64Tile::NCH;
+          const std::vector<float> pk = pack_conv_weights_wino64(w, b, op.cout, op.cin);
+          int rc = dev_alloc(c, &op.d_w, pk.size(), false);
+          if (rc) return rc;
+          HIP_TRY(c, hipMemcpy(op.d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+          if (!(std::getenv("SPVO_WINO_DYNAMIC") && std::atoi(std::getenv("SPVO_WINO_DYNAMIC")) == 0) && (rc = dev_alloc(c, &op.d_sched, 16))) return rc;
+          continue;
+        }
       }
       if (op.wino) {
         op.ck = WinoTile::CK;

@@ -306,3 +306,24 @@ def test_errors(vgg_weights_path, tmp_path):
         ctx.load_weights(str(bad))
     assert e.value.code == -3
     ctx.close()
+
+
+@pytest.mark.parametrize("H,W,batch", [(360, 1176, 2), (192, 640, 1)])
+def test_register_resident_winograd_form_matches_oracle(vgg_weights_path, vgg_plan, sample_images, H, W, batch, monkeypatch):
+    """SPVO_WINO64=1 (read when an engine is loaded): the layers with 64 input channels run conv_wino64_kernel -- transformed
+    filters resident in registers, cross-wave inverse transform through LDS.  Opt-in (it measured no faster than the default
+    form), held to the same bar: every tensor within 1e-4 of the oracle."""
+    from spvo import capi
+    monkeypatch.setenv("SPVO_WINO64", "1")
+    x = _input(sample_images, H, W, batch)
+    rdet, rdesc, vals = net.forward(vgg_plan, x, return_all=True)
+    ctx = capi.Context(net_height=H, net_width=W)
+    ctx.load_weights(vgg_weights_path)
+    det, desc = ctx.forward(x)
+    for tid, (ch, lvl) in enumerate(vgg_plan.tensors):
+        if tid in (vgg_plan.input_tensor, vgg_plan.desc_tensor):
+            continue
+        got = ctx.debug_tensor(tid, batch, ch, lvl)
+        assert np.abs(got - vals[tid]).max() <= _tol(vals[tid]), f"tensor {tid}"
+    assert np.abs(det - rdet).max() <= _tol(rdet) and np.abs(desc - rdesc.transpose(0, 2, 3, 1)).max() <= 1e-4
+    ctx.close()

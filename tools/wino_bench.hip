@@ -11,7 +11,13 @@
 #include <algorithm>
 #include "../superpoint-stereo-visual-odometry_amd/csrc/conv_wino.hip.h"
 #include "../superpoint-stereo-visual-odometry_amd/csrc/conv_wino2.hip.h"
-#if defined(WINO2) && defined(WINO2_NARROW)   // the 8-wave form with 32 output channels per workgroup
+#include "../superpoint-stereo-visual-odometry_amd/csrc/conv_wino64.hip.h"
+#if defined(WINO64)   // filters resident in registers (cin = 64): -DWINO64
+#define KERNEL(P, R, T, O) conv_wino64_kernel<P, R, T>
+#define PACK pack_conv_weights_wino64
+#define THREADS 256
+#define COT 64
+#elif defined(WINO2) && defined(WINO2_NARROW)   // the 8-wave form with 32 output channels per workgroup
 #define KERNEL(P, R, T, O) conv_wino2_kernel<P, R, T, O, true>
 #define PACK(w, b, co, ci) pack_conv_weights_wino2(w, b, co, ci, 32)
 #define THREADS 512
@@ -28,7 +34,9 @@
 #define COT 64
 #endif
 using namespace spvo;
-#ifdef WINO2
+#if defined(WINO64)
+#define LDSB Wino64Tile::LDS_BYTES
+#elif defined(WINO2)
 #define LDSB WINO2_LDS_BYTES
 #else
 #define LDSB WinoTile::LDS_BYTES
@@ -62,7 +70,12 @@ int main(int argc, char **argv) {
   ConvArgs a{};
   a.in = d_in; a.out = d_out; a.wpack = d_w; a.bias = nullptr; a.H = H; a.W = W;
   a.in_hp = ihp; a.in_wp = iwp; a.in_ctot = cin; a.in_coff = 0; a.out_hp = ohp; a.out_wp = owp; a.out_ctot = cout; a.out_coff = 0;
+#if defined(WINO64)
+  if (cin != 64 || ((H | W) & 1)) { printf("WINO64: cin must be 64, H and W even\n"); return 1; }
+  a.cout = cout; a.n_chunks = Wino64Tile::NCH; a.tiles_x = (W + Wino64Tile::TW - 1) / Wino64Tile::TW; a.tiles_y = (H + Wino64Tile::TH - 1) / Wino64Tile::TH;
+#else
   a.cout = cout; a.n_chunks = cin / WinoTile::CK; a.tiles_x = (W + WinoTile::TW - 1) / WinoTile::TW; a.tiles_y = (H + WinoTile::TH - 1) / WinoTile::TH;
+#endif
   a.co_tiles = (cout + COT - 1) / COT; a.batch = batch;
   const long n_items = (long)a.tiles_x * a.tiles_y * a.co_tiles * batch * a.n_chunks;
   const int grid = argc > 7 ? atoi(argv[7]) : (int)std::min<long>(cus, n_items / a.n_chunks);
