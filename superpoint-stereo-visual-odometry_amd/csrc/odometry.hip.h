@@ -92,11 +92,16 @@ __device__ inline bool solve_linear(double *A, double *b) {
 }
 
 // ------------------------------------------------------------------------- K14
-// One thread per point: 4x4 DLT system, one-sided Jacobi SVD (Hestenes) in f64,
-// right-singular vector of the smallest singular value, stored f32, then x/w in f32.
-// Launched with ONE wave per workgroup (64 points): the chain of f64 square roots and divisions is latency-bound, so 1000
-// points are 16 independent waves on 16 CUs rather than 4 workgroups of 4 waves (the solver runs beside the next pair's
-// convolutions, whose waves own most issue slots of a CU).
+// cv::triangulatePoints + convertPointsFromHomogeneous (base.cpp:211-223): the homogeneous point is the right-singular vector of
+// the smallest singular value of the 4x4 DLT system A (rows x P[2] - P[0], y P[2] - P[1] of both views), then x / w in f32.
+// One thread per point, f64.  That vector is the eigenvector of the smallest eigenvalue of B = A^T A, and it is computed as
+// such: B + mu I = L D L^T (mu = 1e-14 trace(B): the pivots stay positive when the system is exactly rank 3, as noise-free
+// synthetic data make it), then inverse iteration from e_w -- the wanted vector's w component is what a finite point never
+// lacks -- which contracts by (sigma_4 / sigma_3)^2 ~ 1e-4 .. 1e-8 per step; 4 steps.  ~300 f64 instructions, 8 divisions, no
+// square root in the loop.  The one-sided Jacobi SVD this replaces (30 sweeps at most, 3 square roots and 3 divisions per
+// rotation: ~10 k f64 instructions, 58 us inside the pipeline) gave the same vector; both agree with the oracle's SVD to
+// rounding level of the f32 result (tests/test_gpu_odometry.py: <= 2e-6 relative).  A^T A squares the condition number:
+// the direction error is ~ eps (sigma_1 / sigma_3)^2 <= 1e-16 x 1e8, far below the f32 rounding of the stored point.
 __global__ __launch_bounds__(256) void triangulate_kernel(const double *__restrict__ Pl,
                                                           const double *__restrict__ Pr,
                                                           const float *__restrict__ xyl,
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const double *__restri
                                                           float *__restrict__ xyz) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  double A[16], V[16];
+  double A[16];
   {
     const double x0 = xyl[2 * i], y0 = xyl[2 * i + 1], x1 = xyr[2 * i], y1 = xyr[2 * i + 1];
 #pragma unroll
@@ -115,59 +120,41 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const double *__restri
       A[3 * 4 + k] = y1 * Pr[8 + k] - Pr[4 + k];
     }
   }
+  double B[4][4];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) V[k] = ((k >> 2) == (k & 3)) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 30; ++sweep) {
-    bool changed = false;
+  for (int p = 0; p < 4; ++p)
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int q = p; q < 4; ++q) {
+      double sum = 0;
 #pragma unroll
-      for (int q = p + 1; q < 4; ++q) {
-        double a = 0, b = 0, c = 0;
+      for (int r = 0; r < 4; ++r) sum += A[r * 4 + p] * A[r * 4 + q];
+      B[p][q] = sum;
+    }
+  const double mu = 1e-14 * (B[0][0] + B[1][1] + B[2][2] + B[3][3]) + 1e-300;
+  // L D L^T (unit lower triangle l, diagonal d kept as reciprocals)
+  const double d0 = B[0][0] + mu, i0 = 1.0 / d0;
+  const double l10 = B[0][1] * i0, l20 = B[0][2] * i0, l30 = B[0][3] * i0;
+  const double d1 = B[1][1] + mu - l10 * l10 * d0, i1 = 1.0 / d1;
+  const double l21 = (B[1][2] - l20 * l10 * d0) * i1, l31 = (B[1][3] - l30 * l10 * d0) * i1;
+  const double d2 = B[2][2] + mu - l20 * l20 * d0 - l21 * l21 * d1, i2 = 1.0 / d2;
+  const double l32 = (B[2][3] - l30 * l20 * d0 - l31 * l21 * d1) * i2;
+  const double d3 = B[3][3] + mu - l30 * l30 * d0 - l31 * l31 * d1 - l32 * l32 * d2, i3 = 1.0 / d3;
+  double h0 = 0, h1 = 0, h2 = 0, h3 = 1;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          a += A[r * 4 + p] * A[r * 4 + p];
-          b += A[r * 4 + q] * A[r * 4 + q];
-          c += A[r * 4 + p] * A[r * 4 + q];
-        }
-        if (fabs(c) <= 2.220446049250313e-16 * sqrt(a * b)) continue;
-        changed = true;
-        const double zeta = (b - a) / (2.0 * c);
-        const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const double ap = A[r * 4 + p], aq = A[r * 4 + q];
-          A[r * 4 + p] = cs * ap - sn * aq;
-          A[r * 4 + q] = sn * ap + cs * aq;
-          const double vp = V[r * 4 + p], vq = V[r * 4 + q];
-          V[r * 4 + p] = cs * vp - sn * vq;
-          V[r * 4 + q] = sn * vp + cs * vq;
-        }
-      }
-    if (!changed) break;
+  for (int it = 0; it < 4; ++it) {
+    // L y = h
+    const double y0 = h0, y1 = h1 - l10 * y0, y2 = h2 - l20 * y0 - l21 * y1, y3 = h3 - l30 * y0 - l31 * y1 - l32 * y2;
+    // D z = y, L^T x = z
+    const double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3, x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
+    const double m = fmax(fmax(fabs(x0), fabs(x1)), fmax(fabs(x2), fabs(x3)));
+    const double sc = (m > 0 && isfinite(m)) ? 1.0 / m : 1.0;
+    h0 = x0 * sc; h1 = x1 * sc; h2 = x2 * sc; h3 = x3 * sc;
   }
-  int best = 0;
-  double bn = 1e300;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    double s = 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) s += A[r * 4 + c] * A[r * 4 + c];
-    if (s < bn) { bn = s; best = c; }
-  }
-  float h[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    double v = 0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) v = (c == best) ? V[r * 4 + c] : v;
-    h[r] = (float)v;
-  }
-  const float scale = (h[3] != 0.f) ? __fdiv_rn(1.0f, h[3]) : 1.0f;
-  xyz[3 * i + 0] = mul_rn(h[0], scale);
-  xyz[3 * i + 1] = mul_rn(h[1], scale);
-  xyz[3 * i + 2] = mul_rn(h[2], scale);
+  const float f0 = (float)h0, f1 = (float)h1, f2 = (float)h2, f3 = (float)h3;
+  const float scale = (f3 != 0.f) ? __fdiv_rn(1.0f, f3) : 1.0f;
+  xyz[3 * i + 0] = mul_rn(f0, scale);
+  xyz[3 * i + 1] = mul_rn(f1, scale);
+  xyz[3 * i + 2] = mul_rn(f2, scale);
 }
 
 // ------------------------------------------------------------------------- K15
@@ -230,78 +217,132 @@ __device__ __forceinline__ bool reproj_inlier(const double *K, const double *R, 
 
 // (RansacWork: spvo_types.hip.h)
 
-// one wave per hypothesis: lane 0 solves the minimal problem, all lanes score
+// Lane broadcast of a double (two v_readlane_b32; the source lane is wave-uniform).
+__device__ __forceinline__ double lane_bcast(double v, int src_lane) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, src_lane), hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src_lane);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// solve_linear<6> with the six ROWS held by six lanes: lane r < 6 owns row r of A (a[0..5]) and b[r] (rb); every lane of the
+// wave executes the same code (lanes >= 6 carry dead rows).  Gaussian elimination with partial pivoting, the same pivots,
+// multipliers and update order as the serial form -- the rows are not moved, a pivot row is marked used instead -- so the result
+// is the serial one bit for bit; what changes is the latency: the serial form walks a dynamically indexed 6 x 6 array in LDS
+// (~250 dependent LDS accesses per solve: 90 us for a ten-iteration Newton solve in one lane), this one keeps the rows in
+// registers, one row update per lane in parallel and ~45 instructions per column.  x[0..5] is returned in every lane.
+__device__ __forceinline__ bool wave_solve6(double (&a)[6], double rb, int lane, double (&x)[6]) {
+  bool used = lane >= 6;
+  int piv_lane[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    // pivot: the unused row with the largest |a[c]|, the lowest row on ties (rows in their original order)
+    const double mine = used ? -1.0 : fabs(a[c]);
+    double best = -1.0;
+    int bl = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const double v = lane_bcast(mine, r);
+      if (v > best) { best = v; bl = r; }
+    }
+    if (!(best > 1e-300) || !isfinite(best)) return false;
+    piv_lane[c] = bl;
+    double pr[6];
+#pragma unroll
+    for (int k = c; k < 6; ++k) pr[k] = lane_bcast(a[k], bl);
+    const double pb = lane_bcast(rb, bl);
+    const double inv = 1.0 / pr[c];
+    if (lane == bl) used = true;
+    if (!used) {
+      const double f = a[c] * inv;
+      if (f != 0) {
+#pragma unroll
+        for (int k = c; k < 6; ++k) a[k] -= f * pr[k];
+        rb -= f * pb;
+      }
+    }
+  }
+  // back substitution: x[r] from the row that was the pivot of column r
+#pragma unroll
+  for (int r = 5; r >= 0; --r) {
+    double sum = rb;
+#pragma unroll
+    for (int k = r + 1; k < 6; ++k) sum -= a[k] * x[k];
+    x[r] = lane_bcast(sum / a[r], piv_lane[r]);
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+    if (!isfinite(x[k])) return false;
+  return true;
+}
+
+// one wave per hypothesis: the minimal problem is solved by lanes 0..5 together (one residual row each), all lanes score
 __global__ __launch_bounds__(64) void ransac_hypothesis_kernel(const double *__restrict__ Kd,
                                                                const float *__restrict__ xyz,
                                                                const float *__restrict__ xy, int n,
                                                                const double *__restrict__ prior,  // rvec, tvec
                                                                uint32_t seed, double thr2,
                                                                RansacWork w) {
-  __shared__ double sh[16];
-  __shared__ double sJ[36], sf[6], sd[6];   // lane 0's Newton system (LDS: dynamically indexed)
-  __shared__ int sh_ok;
   const int it = blockIdx.x, lane = threadIdx.x;
   double K[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) K[k] = Kd[k];
-  if (lane == 0) {
-    int idx[3];
-    for (int k = 0; k < 3; ++k) {
-      uint32_t attempt = 0;
-      while (true) {
-        const uint32_t r = hash32(seed * 0x9E3779B9u + (uint32_t)it * 0x85EBCA6Bu + (uint32_t)k * 0xC2B2AE35u + attempt * 0x27D4EB2Fu) % (uint32_t)n;
-        bool dup = false;
-        for (int m = 0; m < k; ++m) dup |= (idx[m] == (int)r);
-        if (!dup) { idx[k] = (int)r; break; }
-        ++attempt;
-      }
+  // the sample (every lane computes it: three hashes) and this lane's point: lane l < 6 owns residual row l = (point l >> 1, u or v)
+  int idx[3];
+  for (int k = 0; k < 3; ++k) {
+    uint32_t attempt = 0;
+    while (true) {
+      const uint32_t r = hash32(seed * 0x9E3779B9u + (uint32_t)it * 0x85EBCA6Bu + (uint32_t)k * 0xC2B2AE35u + attempt * 0x27D4EB2Fu) % (uint32_t)n;
+      bool dup = false;
+      for (int m = 0; m < k; ++m) dup |= (idx[m] == (int)r);
+      if (!dup) { idx[k] = (int)r; break; }
+      ++attempt;
     }
-    double q[4], t[3];
-    rvec_to_quat(prior, q);
-    t[0] = prior[3]; t[1] = prior[4]; t[2] = prior[5];
-    double X3[9], uv3[6];
-    for (int k = 0; k < 3; ++k) {
-      for (int c = 0; c < 3; ++c) X3[3 * k + c] = xyz[3 * idx[k] + c];
-      for (int c = 0; c < 2; ++c) uv3[2 * k + c] = xy[2 * idx[k] + c];
-    }
-    bool ok = false, bad = false;
-    for (int iter = 0; iter < 10 && !bad; ++iter) {
-      double R[9];
-      double *f = sf, *J = sJ;
-      quat_to_rot(q, R);
-      for (int k = 0; k < 3; ++k) pnp_residual_jac(K, R, t, X3 + 3 * k, uv3 + 2 * k, f + 2 * k, J + 12 * k);
-      double fm = 0;
-      bool fin = true;
-      for (int k = 0; k < 6; ++k) { fm = fmax(fm, fabs(f[k])); fin &= isfinite(f[k]); }
-      for (int k = 0; k < 36; ++k) fin &= isfinite(J[k]);
-      if (!fin) { bad = true; break; }
-      if (fm < 1e-9) { ok = true; break; }
-      double *d = sd;
-      for (int k = 0; k < 6; ++k) d[k] = -f[k];
-      if (!solve_linear<6>(J, d)) { bad = true; break; }
-      double dm = 0;
-      for (int k = 0; k < 6; ++k) dm = fmax(dm, fabs(d[k]));
-      if (dm > 1e3) { bad = true; break; }
-      apply_delta(q, t, d);
-    }
-    if (!ok && !bad) {
-      double R[9], f[2];
-      quat_to_rot(q, R);
-      double fm = 0;
-      bool fin = true;
-      for (int k = 0; k < 3; ++k) {
-        pnp_residual_jac(K, R, t, X3 + 3 * k, uv3 + 2 * k, f, nullptr);
-        fm = fmax(fm, fmax(fabs(f[0]), fabs(f[1])));
-        fin &= isfinite(f[0]) && isfinite(f[1]);
-      }
-      ok = fin && fm < 1e-6;
-    }
-    sh_ok = (ok && !bad) ? 1 : 0;
-    for (int k = 0; k < 4; ++k) sh[k] = q[k];
-    for (int k = 0; k < 3; ++k) sh[4 + k] = t[k];
   }
-  __syncthreads();
-  if (!sh_ok) {
+  const int my_pt = min(lane >> 1, 2), my_row = lane & 1;
+  const int pi = my_pt == 0 ? idx[0] : my_pt == 1 ? idx[1] : idx[2];
+  const double X3[3] = {xyz[3 * pi], xyz[3 * pi + 1], xyz[3 * pi + 2]};
+  const double uv3[2] = {xy[2 * pi], xy[2 * pi + 1]};
+  double sh[7];   // q (xyzw), t: identical in every lane
+  rvec_to_quat(prior, sh);
+  sh[4] = prior[3]; sh[5] = prior[4]; sh[6] = prior[5];
+  bool ok = false, bad = false;
+  auto wave_max6 = [&](double v) {   // max over lanes 0..5, in every lane
+    double m = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) m = fmax(m, lane_bcast(v, r));
+    return m;
+  };
+  for (int iter = 0; iter < 10 && !bad; ++iter) {
+    double R[9], f2[2], J12[12];
+    quat_to_rot(sh, R);
+    pnp_residual_jac(K, R, sh + 4, X3, uv3, f2, J12);
+    double row[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) row[k] = my_row ? J12[6 + k] : J12[k];
+    const double fr = my_row ? f2[1] : f2[0];
+    bool fin = isfinite(fr);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) fin &= isfinite(row[k]);
+    if (__ballot(!fin && lane < 6)) { bad = true; break; }
+    const double fm = wave_max6(fabs(fr));
+    if (fm < 1e-9) { ok = true; break; }
+    double d[6];
+    if (!wave_solve6(row, -fr, lane, d)) { bad = true; break; }
+    double dm = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dm = fmax(dm, fabs(d[k]));
+    if (dm > 1e3) { bad = true; break; }
+    apply_delta(sh, sh + 4, d);
+  }
+  if (!ok && !bad) {
+    double R[9], f2[2];
+    quat_to_rot(sh, R);
+    pnp_residual_jac(K, R, sh + 4, X3, uv3, f2, nullptr);
+    const double fr = my_row ? f2[1] : f2[0];
+    const bool fin = !__ballot(!isfinite(fr) && lane < 6);
+    ok = fin && wave_max6(fabs(fr)) < 1e-6;
+  }
+  if (!(ok && !bad)) {
     if (lane == 0) w.counts[it] = -1;
     return;
   }
@@ -353,7 +394,6 @@ __global__ __launch_bounds__(256) void ransac_select_kernel(const double *__rest
   __shared__ double s_red[27 * 4];
   __shared__ double s_sum[27];
   __shared__ int s_flag;
-  __shared__ double s_A[36], s_d[6];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double K[9];
 #pragma unroll
@@ -423,22 +463,26 @@ __global__ __launch_bounds__(256) void ransac_select_kernel(const double *__rest
       for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r[0] + J[6 + a] * r[1];
     }
     block_reduce<27, 256>(acc, s_sum, s_red);
-    if (tid == 0) {
-      double *A = s_A, *d = s_d;
-      int o = 0;
-      for (int a = 0; a < 6; ++a)
-        for (int b = a; b < 6; ++b) { A[a * 6 + b] = s_sum[o]; A[b * 6 + a] = s_sum[o]; ++o; }
-      for (int a = 0; a < 6; ++a) d[a] = -s_sum[21 + a];
-      int flag = 0;
-      if (solve_linear<6>(A, d)) {
-        apply_delta(s_pose, s_pose + 4, d);
-        double dm = 0;
-        for (int a = 0; a < 6; ++a) dm = fmax(dm, fabs(d[a]));
-        flag = (dm < 1e-10) ? 1 : 0;
-      } else {
-        flag = 1;
+    if (wave == 0) {   // the 6 x 6 normal equations: one row per lane (wave_solve6), lane 0 applies the step
+      const int ra = min(lane, 5);
+      double row[6];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        const int lo = min(ra, b), hi = max(ra, b);
+        row[b] = s_sum[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
       }
-      s_flag = flag;
+      double d[6];
+      const bool solved = wave_solve6(row, -s_sum[21 + ra], lane, d);
+      if (lane == 0) {
+        int flag = 1;
+        if (solved) {
+          apply_delta(s_pose, s_pose + 4, d);
+          double dm = 0;
+          for (int a = 0; a < 6; ++a) dm = fmax(dm, fabs(d[a]));
+          flag = (dm < 1e-10) ? 1 : 0;
+        }
+        s_flag = flag;
+      }
     }
     __syncthreads();
     if (s_flag) break;
