@@ -228,8 +228,9 @@ int spvo_match_slots(spvo_ctx *ctx, int slot_a, int slot_b, int selector, int cr
 int spvo_set_prematch(spvo_ctx *ctx, int enable, int selector, int cross_check, float ratio);
 
 /* Extension (BASELINE config 5): build the matcher's candidate shortlist with an fp8 (e4m3) distance GEMM instead of
- * the fp32 one.  The exact re-rank still yields exact distances for the candidates it is given, but the shortlist --
- * and therefore a borderline ratio-test decision or a near-tie -- is approximate; off by default. */
+ * the fp32 one.  The GEMM only prunes; the result is EXACT: a first pass re-scores a statistical window canonically, a second
+ * pass every column whose rigorous lower bound (from the per-row norms of the fp8 rounding residuals) does not exceed the
+ * second canonical distance found -- indices and distances are the brute-force ones on every row (csrc/match.hip.h). */
 int spvo_set_match_fp8(spvo_ctx *ctx, int enable);
 
 /* cv::triangulatePoints + convertPointsFromHomogeneous (base.cpp:211-223):

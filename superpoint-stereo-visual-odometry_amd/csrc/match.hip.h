@@ -40,9 +40,16 @@ constexpr int MATCH_C = 8;       // fused form: entries a (query row, column til
 //   squared norms (any summation order, <= 64 roundings) and the two additions of the epilogue     <=  80 u N
 // together 852 u N < 1024 u N = 2^-14 N.
 constexpr float MATCH_ERR_REL = 6.103515625e-5f;   // 2^-14
-// The same window for the fp8 shortlist GEMM (spvo_set_match_fp8): NOT a bound -- e4m3 operands carry 2^-4 relative
-// rounding errors whose sum over 256 random-sign terms is ~5e-3 N; 2e-2 N covers four standard deviations.
+// The fp8 shortlist GEMM (spvo_set_match_fp8) works in two passes.  Pass 1 uses this STATISTICAL window -- e4m3 operands carry
+// 2^-4 relative rounding errors whose sum over 256 random-sign terms is ~5e-3 N; 2e-2 N covers four standard deviations -- and
+// yields two canonical distances d0 <= d1.  Pass 2 makes the result exact: with a8 = the dequantised fp8 copy of a,
+//   a.b - a8.b8 = (a - a8).b + a8.(b - b8),   |.| <= |a - a8| |b| + |a8| |b - b8|      (Cauchy-Schwarz; the four norms are
+// computed per row when the copies are made), so |dt8 - d2| <= E8 = 2 (1 + 2^-10) (|a - a8| |b| + |a8| |b - b8|) + 2^-13 N
+// RIGOROUSLY (the last term: fp32 accumulation of the exact fp8 products, the norms, the canonical sum itself); every column
+// with dt8 - E8 <= d1 that pass 1 has not scored is scored canonically too.  On trained descriptors (nearest ~0.3, typical
+// pair ~1.9, E8 ~0.15) that is a handful of columns per row; the result is the brute-force one by construction.
 constexpr float MATCH_ERR_REL_FP8 = 2e-2f;
+constexpr float MATCH_ERR_REL_FP8_TAIL = 1.220703125e-4f;   // 2^-13
 
 // Row counts come either from the host (n_host) or, when the call is enqueued before the
 // detector's counts are known on the host, from device memory (n_ptr).
@@ -63,6 +70,7 @@ struct MatchJob {
   float *best_d2;                 // [na][2]
   int *best_idx;                  // [na][2]
   const unsigned char *A8, *B8;   // fp8 (e4m3) copies [n][256] of A * 16 and B * 16 for the fp8 shortlist GEMM, or NULL
+  const float2 *qA8, *qB8;        // per row {|x - x8|, |x8|} of those copies (x8 = dequantised), or NULL: the certificate of K12b's second pass
   unsigned long long *train_best; // [nb] (cross-check only: the sides are swapped, nb = query rows; {distance bits, train row})
   int2 *out;                      // [na] packed {train_idx, float bits of the distance} ([nb] with cross-check)
 };
@@ -86,7 +94,7 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float *__restrict
 // descriptors have entries around 1/16, so the scale puts them in the format's normal range).  One wave per row.
 constexpr float MATCH_FP8_SCALE = 16.f;
 __global__ __launch_bounds__(256) void desc_to_fp8_kernel(const float *__restrict__ x, int n_host, const int *__restrict__ n_ptr,
-                                                          unsigned char *__restrict__ out) {
+                                                          unsigned char *__restrict__ out, float2 *__restrict__ qnorm) {
   const int n = dev_count(n_host, n_ptr);
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -96,6 +104,15 @@ __global__ __launch_bounds__(256) void desc_to_fp8_kernel(const float *__restric
   pk = __builtin_amdgcn_cvt_pk_fp8_f32(v.x * MATCH_FP8_SCALE, v.y * MATCH_FP8_SCALE, pk, false);
   pk = __builtin_amdgcn_cvt_pk_fp8_f32(v.z * MATCH_FP8_SCALE, v.w * MATCH_FP8_SCALE, pk, true);
   reinterpret_cast<int *>(out + (size_t)r * MATCH_D)[lane] = pk;
+  // norms of the copy and of what the rounding took away (the copy read back exactly as the matrix cores will see it)
+  const float inv = 1.f / MATCH_FP8_SCALE;
+  const float c0 = __builtin_amdgcn_cvt_f32_fp8(pk, 0) * inv, c1 = __builtin_amdgcn_cvt_f32_fp8(pk, 1) * inv;
+  const float c2 = __builtin_amdgcn_cvt_f32_fp8(pk, 2) * inv, c3 = __builtin_amdgcn_cvt_f32_fp8(pk, 3) * inv;
+  const float e0 = v.x - c0, e1 = v.y - c1, e2 = v.z - c2, e3 = v.w - c3;
+  float se = e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3, sc = c0 * c0 + c1 * c1 + c2 * c2 + c3 * c3;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { se += __shfl_xor(se, o); sc += __shfl_xor(sc, o); }
+  if (lane == 0) qnorm[r] = make_float2(sqrtf(se), sqrtf(sc));
 }
 
 // K12a. grid = (ceil(nb/128), ceil(na/64), jobs): at 1000 x 1000 two jobs are 256 workgroups, one per CU.
@@ -523,6 +540,39 @@ __global__ __launch_bounds__(256) void match_rerank_kernel(MatchJobs jobs, int l
         best = match_score_batch<LIST>(list, head, n, B, a4, lds.b[wave], lane, best);
         head += n;
         if (best.i1 >= 0) thr = fminf(thr, best.d1);   // no row above the second-best canonical distance can enter any more
+      }
+    }
+  }
+  if (jb.qA8) {
+    // fp8 shortlist, pass 2 (see MATCH_ERR_REL_FP8): every column whose rigorous lower bound dt8 - E8 does not exceed the second
+    // canonical distance found so far.  A column pass 1 scored already may come again (it cannot win twice: it lost to the
+    // current best two or is one of them, and those are skipped).
+    const float2 qa = jb.qA8[q];
+    float thr2 = best.i1 >= 0 ? best.d1 : __builtin_inff();
+    head = tail = 0;
+    for (int c0 = 0; c0 < nb; c0 += 256) {
+      const int t = c0 + lane * 4;
+      f32x4 dv = {0.f, 0.f, 0.f, 0.f}, ev = dv;
+      float2 qb[4] = {};
+      if (t < nb) {
+        dv = *(const f32x4 *)(drow + t); ev = *(const f32x4 *)(nB + t);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qb[e] = jb.qB8[min(t + e, nb - 1)];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int col = t + e;
+        const float e8 = 2.001953125f * (qa.x * sqrtf(ev[e]) + qa.y * qb[e].x) + MATCH_ERR_REL_FP8_TAIL * (naq + ev[e]);
+        const bool cand = col < nb && col != best.i0 && col != best.i1 && dv[e] - e8 <= thr2;
+        const unsigned long long mask = __ballot(cand);
+        if (cand) list[(tail + __popcll(mask & ((1ull << lane) - 1ull))) & (LIST - 1)] = col;
+        tail += __popcll(mask);
+      }
+      while (tail - head >= 64 || (c0 + 256 >= nb && tail > head)) {
+        const int n = min(64, tail - head);
+        best = match_score_batch<LIST>(list, head, n, B, a4, lds.b[wave], lane, best);
+        head += n;
+        if (best.i1 >= 0) thr2 = fminf(thr2, best.d1);
       }
     }
   }

@@ -258,8 +258,8 @@ void spvo_destroy(spvo_ctx *c) {
   free_plan(c);
   void *ptrs[] = {c->d_dense_in, c->d_det_dense, c->d_resized, c->d_tab, c->d_img[0], c->d_img[1], c->d_xy_tmp, c->d_desc_tmp,
                   c->d_ma, c->d_mb, c->d_match_out, c->d_counters_all, c->d_xy_stage,
-                  c->ms[0].d_na, c->ms[0].d_nb, c->ms[0].d_best_d2, c->ms[0].d_dt, c->ms[0].d_cand, c->ms[0].d_meta, c->ms[0].d_best_idx, c->ms[0].d_train_best, c->ms[0].d_a8, c->ms[0].d_b8,
-                  c->ms[1].d_na, c->ms[1].d_nb, c->ms[1].d_best_d2, c->ms[1].d_dt, c->ms[1].d_cand, c->ms[1].d_meta, c->ms[1].d_best_idx, c->ms[1].d_train_best, c->ms[1].d_a8, c->ms[1].d_b8,
+                  c->ms[0].d_na, c->ms[0].d_nb, c->ms[0].d_best_d2, c->ms[0].d_dt, c->ms[0].d_cand, c->ms[0].d_meta, c->ms[0].d_best_idx, c->ms[0].d_train_best, c->ms[0].d_a8, c->ms[0].d_b8, c->ms[0].d_qa8, c->ms[0].d_qb8,
+                  c->ms[1].d_na, c->ms[1].d_nb, c->ms[1].d_best_d2, c->ms[1].d_dt, c->ms[1].d_cand, c->ms[1].d_meta, c->ms[1].d_best_idx, c->ms[1].d_train_best, c->ms[1].d_a8, c->ms[1].d_b8, c->ms[1].d_qa8, c->ms[1].d_qb8,
                   c->d_P, c->d_pts_a, c->d_pts_b, c->d_xyz, c->rw.counts, c->rw.poses, c->rw.result, c->rw.inliers, c->d_obs, c->d_refine};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (int r = 0; r < RING; ++r) {

@@ -110,6 +110,7 @@ struct MatchScratch {         // one set per concurrently enqueued match
   int *d_best_idx = nullptr;
   unsigned long long *d_train_best = nullptr;
   unsigned char *d_a8 = nullptr, *d_b8 = nullptr;   // fp8 copies of both sides (spvo_set_match_fp8)
+  float2 *d_qa8 = nullptr, *d_qb8 = nullptr;        // [cap] {|x - x8|, |x8|} per row of those copies: the certificate of the exact second pass
   int2 *d_out = nullptr;      // packed result, points into spvo_ctx::d_match_out
 };
 

@@ -15,7 +15,7 @@ int ensure_match(spvo_ctx *c, int na, int nb) {
   auto drop = [](auto *&p) { if (p) (void)hipFree(p); p = nullptr; };
   drop(c->d_ma); drop(c->d_mb); drop(c->d_match_out);
   for (auto &m : c->ms) {
-    drop(m.d_na); drop(m.d_nb); drop(m.d_best_d2); drop(m.d_dt); drop(m.d_cand); drop(m.d_meta); drop(m.d_best_idx); drop(m.d_train_best); drop(m.d_a8); drop(m.d_b8);
+    drop(m.d_na); drop(m.d_nb); drop(m.d_best_d2); drop(m.d_dt); drop(m.d_cand); drop(m.d_meta); drop(m.d_best_idx); drop(m.d_train_best); drop(m.d_a8); drop(m.d_b8); drop(m.d_qa8); drop(m.d_qb8);
     m.d_out = nullptr;
   }
   for (auto &p : c->h_match_out) { if (p) (void)hipHostFree(p); p = nullptr; }
@@ -39,6 +39,8 @@ int ensure_match(spvo_ctx *c, int na, int nb) {
     if ((rc = dev_alloc(c, &m.d_train_best, cap))) return rc;
     if ((rc = dev_alloc(c, &m.d_a8, (size_t)cap * MATCH_D))) return rc;
     if ((rc = dev_alloc(c, &m.d_b8, (size_t)cap * MATCH_D))) return rc;
+    if ((rc = dev_alloc(c, &m.d_qa8, cap))) return rc;
+    if ((rc = dev_alloc(c, &m.d_qb8, cap))) return rc;
     m.d_out = c->d_match_out + (size_t)k * cap;
   }
   for (int r = 0; r < RING; ++r) HIP_TRY(c, hipHostMalloc((void **)&c->h_match_out[r], (size_t)2 * cap * sizeof(int2)));
@@ -78,10 +80,12 @@ int enqueue_matches(spvo_ctx *c, const MatchReq *req_in, int njobs, int selector
     j.nB = req[k].sqB ? req[k].sqB : m.d_nb;
     j.dt = m.d_dt; j.cand = m.d_cand; j.meta = m.d_meta; j.best_d2 = m.d_best_d2; j.best_idx = m.d_best_idx; j.train_best = m.d_train_best; j.out = m.d_out;
     j.A8 = j.B8 = nullptr;
+    j.qA8 = j.qB8 = nullptr;
     if (c->match_fp8) {
-      hipLaunchKernelGGL(desc_to_fp8_kernel, dim3((req[k].na + 3) / 4), dim3(256), 0, c->post, req[k].dA, req[k].na, req[k].na_ptr, m.d_a8);
-      hipLaunchKernelGGL(desc_to_fp8_kernel, dim3((req[k].nb + 3) / 4), dim3(256), 0, c->post, req[k].dB, req[k].nb, req[k].nb_ptr, m.d_b8);
+      hipLaunchKernelGGL(desc_to_fp8_kernel, dim3((req[k].na + 3) / 4), dim3(256), 0, c->post, req[k].dA, req[k].na, req[k].na_ptr, m.d_a8, m.d_qa8);
+      hipLaunchKernelGGL(desc_to_fp8_kernel, dim3((req[k].nb + 3) / 4), dim3(256), 0, c->post, req[k].dB, req[k].nb, req[k].nb_ptr, m.d_b8, m.d_qb8);
       j.A8 = m.d_a8; j.B8 = m.d_b8;
+      j.qA8 = m.d_qa8; j.qB8 = m.d_qb8;
     }
     na_max = std::max(na_max, req[k].na);
     nb_max = std::max(nb_max, req[k].nb);

@@ -612,7 +612,7 @@ void SuperPointFeatureFrontEnd::loadEngine() {
   logInfo("engine file `" + model_name_full + "` loaded");
   // stereoCallback always asks for CURR_LEFT->CURR_RIGHT and CURR_LEFT->PREV_LEFT right after the
   // detector (node.cpp:196-198): have them enqueued in the detector's own submission
-  if (std::getenv("SPVO_MATCH_FP8")) spvo_set_match_fp8(ctx_, 1);   // fp8 shortlist GEMM (config 5; approximate shortlist, exact re-rank)
+  if (std::getenv("SPVO_MATCH_FP8")) spvo_set_match_fp8(ctx_, 1);   // fp8 shortlist GEMM (config 5; the GEMM only prunes, two-pass exact re-rank)
   if (matcher_ready_ && !std::getenv("SPVO_NO_PREMATCH"))
     spvo_set_prematch(ctx_, 1, selector_type_ == SelectorType::KNN ? SPVO_SELECT_KNN : SPVO_SELECT_NN, matcher_cross_check_ ? 1 : 0, knn_threshold_);
   for (int i = 0; i < 2; ++i) {

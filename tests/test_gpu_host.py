@@ -325,3 +325,59 @@ def test_classic_front_end_on_the_gpu_equals_the_cpu_state_machine(sequence):
         Rt, tt = synth.relative_pose(gt[k - 1], gt[k])
         assert np.abs(np.array(r.t[:]) - tt).max() < 0.1
     c.close()
+
+
+def test_a_node_like_caller_linked_against_the_host_library_runs(tmp_path, squeeze_weights_path, sequence, monkeypatch):
+    """tests/boundary_node_caller.cpp -- construction from launch parameters, stereoCallback, the goal callback's reset, as
+    visual_odometry_node.cpp:150-262, 316, 330-403 write them -- is compiled, LINKED against libspvo_host.so and EXECUTED on
+    the GPU, with both constructors (is_classic false / true).  The poses solveStereoOdometry(tf2::Transform&) hands it equal,
+    bit for bit, those of the same frames through spvo.host (FrontEnd.step / classic_sequence): the caller's path through the
+    class interface and the harness's C wrappers are the same code underneath, and this is the run that proves the first one."""
+    import ctypes as C
+    import subprocess
+    from spvo import capi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.dirname(capi.LIB_PATH)
+    so = str(tmp_path / "libboundary_node_caller.so")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-Wall", "-Werror", "-I" + os.path.join(pkg, "host"),
+                        os.path.join(root, "tests", "boundary_node_caller.cpp"), "-o", so, "-L" + pkg, "-lspvo_host", "-lspvo", "-Wl,-rpath," + pkg],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    models = tmp_path / "models"
+    os.makedirs(models / "laptop")
+    shutil.copyfile(squeeze_weights_path, models / "laptop" / weights.engine_name("superpoint_pretrained", 2, 360, 1176, "FP32"))
+    monkeypatch.setenv("SPVO_MODELS_DIR", str(models))
+    lib = C.CDLL(so)
+    lib.boundary_node_run.restype = C.c_int
+    lib.boundary_node_run.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p]
+    frames, _, P_l, P_r = sequence
+    frames = frames[:3]
+    Ls = np.ascontiguousarray(np.stack([f[0] for f in frames]), np.uint8)
+    Rs = np.ascontiguousarray(np.stack([f[1] for f in frames]), np.uint8)
+    rows, cols = Ls.shape[1:]
+    Pl = np.ascontiguousarray(P_l, np.float64).reshape(12)
+    Pr = np.ascontiguousarray(P_r, np.float64).reshape(12)
+
+    def run(is_classic, min_disparity, h, w):
+        poses = np.zeros((len(frames), 7), np.float64)
+        check = C.c_double(0)
+        n = lib.boundary_node_run(int(is_classic), len(frames), Ls.ctypes.data, Rs.ctypes.data, rows, cols, Pl.ctypes.data, Pr.ctypes.data, min_disparity, h, w,
+                                  poses.ctypes.data, C.byref(check))
+        assert n == len(frames) - 1 and np.isnan(poses[0]).all() and check.value > 0
+        return poses
+
+    # ---- SuperPointFeatureFrontEnd (node.cpp:396-403).  (The harness's constructor call also points the class at this test's
+    # models directory -- SuperPointFeatureFrontEnd::setModelsDir outranks SPVO_MODELS_DIR and earlier tests have set it.)
+    fe = host.FrontEnd(str(models), prefix="superpoint_pretrained", selector="KNN", cross_check=True, min_disparity=0.25)
+    assert fe.engine_loaded, fe.last_error
+    ref = [fe.step(L, R, P_l, P_r) for L, R in frames]
+    fe.close()
+    got = run(False, 0.25, 360, 1176)
+    for k in range(1, len(frames)):
+        assert np.array_equal(got[k, :4], ref[k][0]) and np.array_equal(got[k, 4:], ref[k][1]), k
+        assert np.linalg.norm(ref[k][1]) > 0.3                                   # a real step of the synthetic motion, not the prior
+    # ---- ClassicFeatureFrontEnd (node.cpp:353-360), native resolution
+    got_c = run(True, 2.0, 0, 0)
+    ref_c, stats, _ = host.classic_sequence(frames, P_l, P_r, "KNN", True, 2.0, 4)
+    assert np.array_equal(got_c[1:], ref_c[1:]) and (stats[1:, 3] > 300).all()

@@ -262,28 +262,37 @@ def test_nms_redo_with_two_submissions_in_flight(vgg_plan, tmp_path):
 
 
 def test_fp8_shortlist_matcher(ctx_squeeze, stereo_pair):
-    """BASELINE config 5: the shortlist of the matcher from an fp8 (e4m3) distance GEMM.  The shortlist is approximate,
-    the re-rank exact: every CONFIDENT match (best / second-best distance below 0.7) is found with bit-identical index
-    and distance, and on trained descriptors the borderline rows that may differ are a fraction of a percent."""
+    """BASELINE config 5: the shortlist of the matcher from an fp8 (e4m3) distance GEMM.  The GEMM only prunes: pass 1 re-scores
+    a statistical window canonically, pass 2 every column whose RIGOROUS lower bound (per-row norms of the fp8 rounding residuals,
+    csrc/match.hip.h: MATCH_ERR_REL_FP8) does not exceed the second canonical distance found.  So indices AND distances equal
+    the brute-force oracle's on every row, confident or borderline -- KNN ratio test and plain NN."""
     frames, _, P_l, P_r = stereo_pair
     L, R = frames[0]
     out = ctx_squeeze.detect(L, R, P_l, P_r, 0, 1)
     n = len(out["xy_l"])
     ridx, rd = matching.bf_match(out["desc_l"], out["desc_r"], "KNN", False, 0.8)
-    d2 = np.sort(matching.sq_distances(out["desc_l"], out["desc_r"]), axis=1)
-    confident = np.sqrt(d2[:, 0]) < 0.7 * np.sqrt(d2[:, 1])
+    r_nn, r_nnd = matching.bf_match(out["desc_l"], out["desc_r"], "NN", False, 0.8)
     try:
         ctx_squeeze.set_match_fp8(True)
         idx, d = ctx_squeeze.match_slots(0, 1, n)
         nn_idx, nn_d = ctx_squeeze.match_slots(0, 1, n, "NN", False)
+        # descriptors handed over by the caller (spvo_match) take the same path; a near-duplicate cluster widens every window
+        rng = np.random.RandomState(3)
+        a = rng.randn(700, 256).astype(np.float32)
+        a /= np.linalg.norm(a, axis=1, keepdims=True)
+        b = np.concatenate([a[:300] + 0.02 * rng.randn(300, 256).astype(np.float32), np.repeat(a[300:301], 200, 0) + 1e-3 * rng.randn(200, 256).astype(np.float32),
+                            rng.randn(150, 256).astype(np.float32)])
+        b /= np.linalg.norm(b, axis=1, keepdims=True)
+        b = b.astype(np.float32)
+        sidx, sd = ctx_squeeze.match(a, b)
     finally:
         ctx_squeeze.set_match_fp8(False)
-    assert confident.sum() > 300
-    assert np.array_equal(idx[confident], ridx[confident]) and np.array_equal(d[confident], rd[confident])
-    assert (idx != ridx).mean() < 0.01
-    r_nn, r_nnd = matching.bf_match(out["desc_l"], out["desc_r"], "NN", False, 0.8)
-    assert (nn_idx != r_nn).mean() < 0.01 and np.array_equal(nn_d[nn_idx == r_nn], r_nnd[nn_idx == r_nn])
-    idx2, d2_ = ctx_squeeze.match_slots(0, 1, n)                              # back to the fp32 shortlist: exact again
+    assert (ridx >= 0).sum() > 300
+    assert np.array_equal(idx, ridx) and np.array_equal(d, rd)
+    assert np.array_equal(nn_idx, r_nn) and np.array_equal(nn_d, r_nnd)
+    s_ridx, s_rd = matching.bf_match(a, b, "KNN", False, 0.8)
+    assert np.array_equal(sidx, s_ridx) and np.array_equal(sd, s_rd)
+    idx2, d2_ = ctx_squeeze.match_slots(0, 1, n)                              # back to the fp32 shortlist: the same again
     assert np.array_equal(idx2, ridx) and np.array_equal(d2_, rd)
 
 

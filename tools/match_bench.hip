@@ -40,7 +40,7 @@ int main(int argc, char **argv) {
     j.A = d + (size_t)(2 * k) * n * 256; j.B = d + (size_t)(2 * k + 1) * n * 256; j.na = j.nb = n; j.na_ptr = j.nb_ptr = nullptr;
     j.nA = sq + (2 * k) * n; j.nB = sq + (2 * k + 1) * n; j.dt = dt + (size_t)k * n * ldt; j.best_d2 = bd + 2 * k * n; j.best_idx = bi + 2 * k * n;
     j.cand = cand + (size_t)k * n * nt * MATCH_C; j.meta = meta + (size_t)k * n * nt;
-    j.A8 = j.B8 = nullptr; j.train_best = nullptr; j.out = out + k * n;
+    j.A8 = j.B8 = nullptr; j.qA8 = j.qB8 = nullptr; j.train_best = nullptr; j.out = out + k * n;
   }
   CK(hipFuncSetAttribute((const void *)match_gemm_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH_LDS_BYTES));
   CK(hipFuncSetAttribute((const void *)match_gemm_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH_LDS_BYTES));
