@@ -7,6 +7,7 @@
 #include "conv_wino.hip.h"
 #include "conv_wino2.hip.h"
 #include "conv_wino64.hip.h"
+#include "heads.hip.h"
 #include "conv_i8.hip.h"
 
 namespace spvo_int {
@@ -126,6 +127,8 @@ void free_plan(spvo_ctx *c) {
     if (o.d_qm) (void)hipFree(o.d_qm);
     if (o.d_sched) (void)hipFree(o.d_sched);
   }
+  if (c->d_heads_w) (void)hipFree(c->d_heads_w);
+  c->d_heads_w = nullptr; c->heads_fused = false;
   c->tensors.clear(); c->ops.clear(); c->weights = false; c->fp16 = false; c->int8 = false; c->s3 = false;
 }
 
@@ -714,6 +717,22 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
       if (ti.ch != 256 || to.ch != 256 || ti.level != 3) return fail(c, SPVO_ERR_IO, "op %u: descriptor tail must be 256 channels at 1/8", i);
     } else {
       return fail(c, SPVO_ERR_IO, "op %u: unknown type %d", i, op.type);
+    }
+  }
+  // The tail of the SuperPoint graphs -- convPb 256 -> 65, convDb 256 -> 256 (both 1x1, plain, reading two channel ranges of one
+  // tensor), L2 normalisation -- as ONE launch (heads.hip.h) instead of three: FP32 engines only; SPVO_HEADS_FUSED=0 keeps the plan's ops.
+  if (!c->fp16 && !c->int8 && !c->s3 && c->head_start + 3 == c->ops.size() && !(std::getenv("SPVO_HEADS_FUSED") && std::atoi(std::getenv("SPVO_HEADS_FUSED")) == 0)) {
+    const size_t hs = c->head_start;
+    const Op &pb = c->ops[hs], &db = c->ops[hs + 1], &nm = c->ops[hs + 2];
+    const bool plain = pb.type == OP_CONV && db.type == OP_CONV && nm.type == OP_L2NORM && pb.ks == 1 && db.ks == 1 && pb.flags == 0 && db.flags == 0 &&
+                       pb.cin == HEADS_CIN && db.cin == HEADS_CIN && pb.cout == 65 && db.cout == 256 && pb.in == db.in && pb.out == c->t_det && pb.out_c_off == 0 &&
+                       db.out_c_off == 0 && nm.in == db.out && nm.out == c->t_desc && c->tensors[pb.in].level == 3 && !pb.merged && !db.merged;
+    if (plain) {
+      const std::vector<float> pk = pack_heads_weights(payload + raws[hs].w_off, payload + raws[hs].b_off, pb.cout, payload + raws[hs + 1].w_off, payload + raws[hs + 1].b_off);
+      int rc = dev_alloc(c, &c->d_heads_w, pk.size(), false);
+      if (rc) return rc;
+      HIP_TRY(c, hipMemcpy(c->d_heads_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+      c->heads_fused = true;
     }
   }
   {   // mark the dominant layer

@@ -146,6 +146,9 @@ struct spvo_ctx {
   bool split_req = false;          // spvo_set_fp32_split / SPVO_FP32_SPLIT: FP32 engines loaded from now on run on the bf16x3 kernels
   bool s3 = false;                 // the loaded FP32 engine runs in split mode
   size_t head_start = 0;           // ops [head_start, end) = the 1x1 heads + L2 norm: a submission runs them on the tail stream
+  bool heads_fused = false;        // ... as ONE launch (heads.hip.h): FP32 engines whose tail is convPb (256 -> 65), convDb (256 -> 256), L2 norm
+  bool heads_keep_raw = false;     // the fused launch also stores the un-normalised descriptor planes (spvo_forward / spvo_debug_tensor)
+  float *d_heads_w = nullptr;      // pack_heads_weights()
   bool int8 = false;
   int H = 0, W = 0, Hc = 0, Wc = 0, B = 0;
   int num_cus = 256;

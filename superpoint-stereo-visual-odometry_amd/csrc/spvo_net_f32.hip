@@ -5,6 +5,7 @@
 #include "conv_wino.hip.h"
 #include "conv_wino2.hip.h"
 #include "conv_wino64.hip.h"
+#include "heads.hip.h"
 
 namespace spvo_int {
 
@@ -242,8 +243,38 @@ int launch_op(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream
 // of the tile id).  Per-image streams for the small layers were measured and gave nothing: two persistent
 // kernels do not backfill each other's ragged ends.
 // ops [first, last) on `stream`
+// the fused tail of the graph (heads.hip.h): ops head_start .. head_start + 2 in one launch
+int launch_heads(spvo_ctx *c, int batch, hipStream_t stream) {
+  const Op &pb = c->ops[c->head_start], &db = c->ops[c->head_start + 1];
+  const Tensor &ti = c->tensors[pb.in], &tdet = c->tensors[pb.out], &traw = c->tensors[db.out], &tdesc = c->tensors[c->t_desc];
+  static bool ready[64] = {};
+  const int dev = c->cfg.device & 63;
+  if (!ready[dev]) {
+    HIP_TRY(c, hipFuncSetAttribute((const void *)heads_fused_kernel<>, hipFuncAttributeMaxDynamicSharedMemorySize, HEADS_LDS_BYTES));
+    ready[dev] = true;
+  }
+  HeadsArgs a;
+  a.in = ring_ptr(c, ti); a.in_per_image = ti.per_image; a.in_hp = ti.hp; a.in_wp = ti.wp;
+  a.coff_det = pb.in_c_off; a.coff_desc = db.in_c_off;
+  a.wpack = c->d_heads_w;
+  a.det = ring_ptr(c, tdet); a.det_per_image = tdet.per_image;
+  a.desc_raw = c->heads_keep_raw ? ring_ptr(c, traw) : nullptr; a.raw_per_image = traw.per_image;
+  a.desc = ring_ptr(c, tdesc);
+  a.H = ti.H; a.W = ti.W;
+  ScopedStage st(c, stage_id(c, "heads"), (pb.flops_per_image + db.flops_per_image) * batch, 0, stream);
+  hipLaunchKernelGGL(heads_fused_kernel<>, dim3((ti.W + HEADS_PX - 1) / HEADS_PX, ti.H, batch), dim3(256), HEADS_LDS_BYTES, stream, a);
+  HIP_TRY(c, hipGetLastError());
+  return SPVO_OK;
+}
+
 int run_ops(spvo_ctx *c, int batch, size_t first, size_t last, hipStream_t stream) {
   for (size_t i = first; i < last && i < c->ops.size(); ++i) {
+    if (c->heads_fused && i == c->head_start && last >= c->head_start + 3) {
+      int rc = launch_heads(c, batch, stream);
+      if (rc) return rc;
+      i += 2;
+      continue;
+    }
     int rc = launch_op(c, c->ops[i], 0, batch, stream);
     if (rc) return rc;
   }
@@ -252,7 +283,9 @@ int run_ops(spvo_ctx *c, int batch, size_t first, size_t last, hipStream_t strea
 
 int run_network(spvo_ctx *c, int batch) {
   ScopedStage net(c, stage_id(c, "net"));
+  c->heads_keep_raw = true;    // the synchronous entry points expose every tensor (spvo_debug_tensor)
   int rc = run_ops(c, batch, 0, c->ops.size(), c->stream);
+  c->heads_keep_raw = false;
   if (rc) return rc;
   c->last_batch = batch;
   return SPVO_OK;
