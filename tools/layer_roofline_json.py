@@ -1,0 +1,74 @@
+"""profiles/rNN_layer_roofline.json: every layer of the FP32 VGG engine at the headline size -- kernel, duration (HIP events on the
+context's stream, both images of a stereo pair per launch, layers run back to back alone on the chip), algorithmic GFLOP (direct
+convolution), GFLOP EXECUTED on the matrix pipe (Winograd F(2x2,3x3) layers: 4/9 of the algorithmic count)
+and the fraction of the 157.3 TFLOP/s fp32-MFMA peak the executed flops amount to; HBM-bound layers carry their GB/s instead.
+
+usage: python tools/layer_roofline_json.py out.json [HxW]"""
+import json, os, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "superpoint-stereo-visual-odometry_amd"))
+import numpy as np
+from spvo import capi, weights
+
+out_path = sys.argv[1]
+H, Wd = (int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "360x1176").split("x"))
+plan = weights.vgg_plan()
+p = os.path.join(tempfile.mkdtemp(), "w.spvw"); weights.save(plan, p)
+ctx = capi.Context(net_height=H, net_width=Wd); ctx.load_weights(p)
+x = np.random.RandomState(0).rand(2, 1, H, Wd).astype(np.float32)
+for _ in range(30): ctx.forward(x)
+ctx.profile_enable(True); ctx.profile_reset()
+for _ in range(200): ctx.forward(x)
+prof = ctx.profile()
+PEAK, HBM = 157.3, 8000.0
+names = ["conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "convPa", "convDa", "convPb", "convDb", "l2norm"]
+wino_env = os.environ.get("SPVO_WINOGRAD", "1") != "0"
+rows, tot_us, tot_exec, tot_alg = [], 0.0, 0.0, 0.0
+i = 0
+while i < len(plan.ops):
+    op = plan.ops[i]
+    key = {weights.OP_CONV: "conv", weights.OP_L2NORM: "l2norm"}.get(op.type, "op") + f":{i}"
+    st = prof.get(key)
+    label, ops = names[i], [op]
+    if key == "conv:10" and (not st or not st["calls"]) and prof.get("heads", {}).get("calls"):      # convPb + convDb + l2norm: one launch
+        st, label, ops, step = prof["heads"], "convPb+convDb+l2norm (heads.hip.h)", plan.ops[10:13], 3
+    elif i + 1 < len(plan.ops) and plan.ops[i + 1].type == weights.OP_CONV and op.type == weights.OP_CONV and plan.ops[i + 1].inp == op.inp \
+            and plan.ops[i + 1].out == op.out and not (prof.get(f"conv:{i + 1}") or {}).get("calls"):                # sibling layers in one launch
+        label, ops, step = names[i] + "+" + names[i + 1], plan.ops[i:i + 2], 2
+    else:
+        step = 1
+    if not st or not st["calls"]:
+        i += step
+        continue
+    us = st["total_ms"] / st["calls"] * 1e3
+    alg = byts = 0.0
+    for o in ops:
+        if o.type != weights.OP_CONV:
+            continue
+        lvl_in, lvl_out = plan.tensors[o.inp][1], plan.tensors[o.out][1]
+        px_in, px_out = (H >> lvl_in) * (Wd >> lvl_in), (H >> lvl_out) * (Wd >> lvl_out)
+        alg += 2.0 * 2 * px_in * o.cout * o.cin * o.ksize * o.ksize
+        byts += 2 * 4 * (px_in * o.cin + px_out * o.cout) + o.weight.size * 4
+    o0 = ops[0]
+    wino = wino_env and o0.type == weights.OP_CONV and o0.ksize == 3 and o0.cin > 1
+    executed = alg * (4.0 / 9.0 if wino else 1.0)
+    hbm_bound = o0.type == weights.OP_CONV and o0.cin == 1
+    row = {"layer": label, "shape": f"{o0.cin}->{sum(o.cout for o in ops if o.type == weights.OP_CONV)} k{o0.ksize} @{H >> plan.tensors[o0.inp][1]}x{Wd >> plan.tensors[o0.inp][1]}",
+           "kernel": "conv_first4_kernel (VALU, HBM-write bound)" if hbm_bound else "conv_wino2_kernel (Winograd F(2x2,3x3), fp32 MFMA)" if wino else
+                     "heads_fused_kernel (fp32 MFMA)" if "heads" in label else "conv_mfma_kernel (direct, fp32 MFMA)",
+           "duration_us": round(us, 2), "algorithmic_gflop": round(alg / 1e9, 3), "executed_gflop": round(executed / 1e9, 3),
+           "executed_tflops": round(executed / us / 1e6, 2), "frac_of_fp32_mfma_peak": round(executed / us / 1e6 / PEAK, 4),
+           "algorithmic_MB": round(byts / 1e6, 1), "algorithmic_GBps": round(byts / us / 1e3, 0)}
+    if hbm_bound:
+        row["bound"] = "hbm"; row["frac_of_hbm_peak"] = round(byts / us / 1e3 / HBM, 4)
+    rows.append(row)
+    tot_us += us; tot_exec += executed; tot_alg += alg
+    i += step
+res = {"_how": f"tools/layer_roofline_json.py on one MI355X: VGG SuperPoint fp32, net {H}x{Wd}, both images per launch, 200 forward passes with every layer "
+               "bracketed by HIP events (spvo_profile_*); layers run back to back, nothing else on the chip",
+       "peak_fp32_mfma_tflops": PEAK, "layers": rows,
+       "conv_stack": {"sum_of_layers_us": round(tot_us, 1), "algorithmic_gflop": round(tot_alg / 1e9, 2), "executed_gflop": round(tot_exec / 1e9, 2),
+                      "executed_tflops": round(tot_exec / tot_us / 1e6, 2), "frac_of_fp32_mfma_peak": round(tot_exec / tot_us / 1e6 / PEAK, 4)},
+       "forward_pass_us": round(prof["net"]["total_ms"] / prof["net"]["calls"] * 1e3, 1)}
+json.dump(res, open(out_path, "w"), indent=1)
+print(json.dumps(res, indent=1))

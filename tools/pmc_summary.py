@@ -1,8 +1,8 @@
-"""Turns the counter passes of tools/collect_profiles.sh into one JSON (profiles/r02_pmc.json): per kernel the HBM traffic
+"""Turns the counter passes of tools/collect_profiles_r03.sh into one JSON (profiles/r03_pmc.json): per kernel the HBM traffic
 (FETCH_SIZE x 2 + WRITE_SIZE, with the x 2 validated by the copy kernel of the SAME session), the algorithmic bytes, the
 matrix-pipe busy fraction and the wave-cycle split.
 
-usage: python tools/pmc_summary.py gpurun_out/prof_r02 profiles/r02_pmc.json"""
+usage: python tools/pmc_summary.py gpurun_out/prof_r02 profiles/r03_pmc.json"""
 import collections, csv, glob, json, os, sys
 
 src, out_path = sys.argv[1:3]
@@ -28,7 +28,7 @@ def pick(acc, key):
     return ks[0] if ks else None
 
 
-res = {"_how": "tools/collect_profiles.sh on one MI355X: rocprofv3 --kernel-trace --pmc <group> --output-format csv, one group per pass, stand-alone "
+res = {"_how": "tools/collect_profiles_r03.sh on one MI355X: rocprofv3 --kernel-trace --pmc <group> --output-format csv, one group per pass, stand-alone "
                "binaries tools/wino_bench2 360 1176 64 64 1 (conv1b, both images), tools/match_bench 1000 2 (two 1000 x 1000 jobs), tools/copy_bench 1024",
        "_units": "FETCH_SIZE / WRITE_SIZE in KB; SQ_* wave counters in quad-cycles summed over waves; SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over SIMDs; "
                  "GRBM_GUI_ACTIVE summed over the 8 XCDs"}
@@ -52,11 +52,15 @@ if kd:
     fcorr_dma = 1.0 / ratio
 # ---- kernels
 H, W = 360, 1176
+NT = 8   # column tiles of 128 train rows at 1000 x 1000
 alg = {"conv_wino2_kernel<true, true": 2 * (64 * H * W * 4 + 64 * (H // 2) * (W // 2) * 4) + 16 * 64 * 64 * 4,    # input + pooled output planes + transformed filters
-       "match_gemm_kernel": 2 * (2 * 1000 * 256 * 4 + 1000 * 1000 * 4),                                           # two jobs: both descriptor sets + the distance matrix
-       "match_rerank_kernel": 2 * (1000 * 1000 * 4 + 1000 * 8)}
-flops = {"conv_wino2_kernel<true, true": 2.0 * 2 * H * W * 64 * 64 * 9 * 4 / 9, "match_gemm_kernel": 2 * 2.0 * 1000 * 1000 * 256}
-for prog, keys in (("wino", ["conv_wino2_kernel<true, true"]), ("match", ["match_gemm_kernel", "match_rerank_kernel"])):
+       "match_gemm_kernel<false, false>": 2 * (2 * 1000 * 256 * 4 + 1000 * 1000 * 4),                             # unfused form, two jobs: both descriptor sets + the distance matrix
+       "match_rerank_kernel": 2 * (1000 * 1000 * 4 + 1000 * 8),
+       "match_gemm_kernel<false, true>": 2 * (2 * 1000 * 256 * 4 + 1000 * NT * (16 + 3 * 8)),                     # fused form: descriptor sets + per (row, tile) 16 bytes of bounds and ~3 entries
+       "match_merge_kernel": 2 * (1000 * NT * (16 + 3 * 8) + 1000 * (1 + 3) * 1024 + 1000 * 8)}                   # the lists, the query row + ~3 candidate rows, the result
+flops = {"conv_wino2_kernel<true, true": 2.0 * 2 * H * W * 64 * 64 * 9 * 4 / 9, "match_gemm_kernel<false, false>": 2 * 2.0 * 1000 * 1000 * 256,
+         "match_gemm_kernel<false, true>": 2 * 2.0 * 1000 * 1000 * 256}
+for prog, keys in (("wino", ["conv_wino2_kernel<true, true"]), ("match", ["match_gemm_kernel<false, false>", "match_rerank_kernel", "match_gemm_kernel<false, true>", "match_merge_kernel"])):
     f, _ = counters("pmc_fetch_" + prog); w, _ = counters("pmc_write_" + prog)
     s1, d1 = counters("pmc_sq_" + prog); s2, _ = counters("pmc_sq2_" + prog)
     for key in keys:
@@ -89,6 +93,6 @@ for prog, keys in (("wino", ["conv_wino2_kernel<true, true"]), ("match", ["match
             e["wave_cycle_split"] = {n: round(c[n] / wc, 4) for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if n in c}
             if c.get("SQ_LDS_IDX_ACTIVE"):
                 e["lds_bank_conflict_fraction"] = round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 4)
-        res[key.split("<")[0]] = e
+        res[key.split("<")[0] + ("_fused" if key.endswith("true>") and key.startswith("match_gemm") else "")] = e
 json.dump(res, open(out_path, "w"), indent=1)
 print(json.dumps(res, indent=1)[:6000])
