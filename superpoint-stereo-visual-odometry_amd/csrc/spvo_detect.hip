@@ -454,14 +454,22 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
     rc = launch_nms_rounds(c, 2, np, ring, NMS_FIRST, c->d_counters_all + (size_t)(((ring + 1) % RING) * 2) * NMS_COUNTER_INTS);
   }
   if (!rc) rc = enqueue_sample(c, slots, np, ring);
-  if (!rc && c->prematch) rc = enqueue_prematch(c, slot_l, slot_r, prev_l, ring);
-  if (!rc && (extras & 1))   // resized images (what nn.cpp:154 pushes to images_dq) -> the set's pinned mirror
-    rc = hipMemcpyAsync(c->h_resized_r[ring], c->d_resized_r[ring], (size_t)2 * c->H * c->W, hipMemcpyDeviceToHost, c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipMemcpyAsync failed");
-  if (!rc && (extras & 2)) {   // descriptors of both images: whole slots (the counts are not known on the host yet; rows >= n are stale)
-    const size_t per = (size_t)c->cfg.max_keypoints * 256;
-    for (int i = 0; i < 2 && !rc; ++i)
-      rc = hipMemcpyAsync(c->h_desc_r[ring] + i * per, c->slots[slots[i]].d_desc, per * sizeof(float), hipMemcpyDeviceToHost, c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipMemcpyAsync failed");
+  // Keypoints, counts and descriptors are final here: spvo_detect_wait / _collect waits for THIS point; the matches enqueued behind
+  // it are waited for where they are asked for (spvo_match_slots, ev_tail).  The bulk copies a host-image submission asked for go
+  // out on a stream of their own BESIDE the matches -- 2.8 MB over PCIe are ~110 us the matches need not queue behind.
+  if (!rc) rc = hipEventRecord(c->ev_feat[ring], c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");
+  if (!rc && extras) {
+    rc = hipStreamWaitEvent(c->stream_c, c->ev_feat[ring], 0) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipStreamWaitEvent failed");
+    if (!rc && (extras & 1))   // resized images (what nn.cpp:154 pushes to images_dq) -> the set's pinned mirror
+      rc = hipMemcpyAsync(c->h_resized_r[ring], c->d_resized_r[ring], (size_t)2 * c->H * c->W, hipMemcpyDeviceToHost, c->stream_c) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipMemcpyAsync failed");
+    if (!rc && (extras & 2)) {   // descriptors of both images: whole slots (the counts are not known on the host yet; rows >= n are stale)
+      const size_t per = (size_t)c->cfg.max_keypoints * 256;
+      for (int i = 0; i < 2 && !rc; ++i)
+        rc = hipMemcpyAsync(c->h_desc_r[ring] + i * per, c->slots[slots[i]].d_desc, per * sizeof(float), hipMemcpyDeviceToHost, c->stream_c) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipMemcpyAsync failed");
+    }
+    if (!rc) rc = hipEventRecord(c->ev_copy[ring], c->stream_c) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");
   }
+  if (!rc && c->prematch) rc = enqueue_prematch(c, slot_l, slot_r, prev_l, ring);
   if (!rc && prof_detect) {   // "detect" spans both streams: first kernel on `stream` .. last copy on `stream_t`
     hipEvent_t e1 = get_event(c);
     (void)hipEventRecord(e1, c->stream_t);
@@ -518,7 +526,8 @@ static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_feature
   } else {
     // only this submission's tail: a younger one may be queued behind it on both streams
     const double tw0 = diag_now_us();
-    rc = wait_event(c->ev_tail[pd.ring]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");
+    rc = wait_event(c->ev_feat[pd.ring]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");
+    if (!rc && pd.extras) rc = wait_event(c->ev_copy[pd.ring]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");
     g_diag.max_tail_wait = std::max(g_diag.max_tail_wait, diag_now_us() - tw0);
   }
   bool redone = false;

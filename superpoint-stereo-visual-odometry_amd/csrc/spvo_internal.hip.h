@@ -136,6 +136,7 @@ struct spvo_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // fused solve: overlaps with a detector submission in flight
   hipStream_t stream_t = nullptr;  // detector tail (heat map, NMS, sampling, matching): overlaps with the NEXT submission's network
+  hipStream_t stream_c = nullptr;  // bulk device-to-host copies of a host-image submission (resized images, descriptors): beside its matches
   hipStream_t post = nullptr;      // where post-processing is enqueued right now: `stream`, or `stream_t` for a submission
   std::deque<PendingDetect> pendq;
   int cur_ring = 0;                // set whose network outputs the running forward pass writes
@@ -200,6 +201,10 @@ struct spvo_ctx {
   float *h_desc_r[RING] = {nullptr, nullptr, nullptr, nullptr};   // [2][cap][256]
   bool host_sets_ready = false;  // d_resized_r / h_resized_r / h_desc_r of EVERY set are allocated
   hipEvent_t ev_net[RING] = {nullptr, nullptr, nullptr, nullptr}, ev_tail[RING] = {nullptr, nullptr, nullptr, nullptr};
+  // a submission's tail in two parts: ev_feat = keypoints, counts and descriptors are final (what spvo_detect_wait needs), ev_tail = the
+  // matches enqueued behind them have landed too (what spvo_match_slots needs); ev_copy = the bulk copies on stream_c
+  hipEvent_t ev_feat[RING] = {nullptr, nullptr, nullptr, nullptr}, ev_copy[RING] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_post = nullptr;    // PostScope: orders a synchronous entry point behind what is left on the tail stream
   bool match_fp8 = false;        // fp8 shortlist GEMM (approximate; spvo_set_match_fp8)
   bool prematch = false;
   int pm_selector = SPVO_SELECT_KNN, pm_cross = 0;
@@ -309,7 +314,12 @@ inline float *ring_ptr(spvo_ctx *c, const Tensor &t) { return t.dr[c->cur_ring] 
 // post-processing issued by a synchronous entry point while submissions are queued goes behind them
 struct PostScope {
   spvo_ctx *c;
-  explicit PostScope(spvo_ctx *ctx) : c(ctx) { c->post = c->pendq.empty() ? c->stream : c->stream_t; }
+  explicit PostScope(spvo_ctx *ctx) : c(ctx) {
+    c->post = c->pendq.empty() ? c->stream : c->stream_t;
+    // nothing queued, but the matches of the submission collected last may still run on the tail stream (spvo_detect_wait returns
+    // when the FEATURES are final) and they share the matcher's scratch: the network stream waits for them, asynchronously
+    if (c->pendq.empty() && c->ev_post && hipEventRecord(c->ev_post, c->stream_t) == hipSuccess) (void)hipStreamWaitEvent(c->stream, c->ev_post, 0);
+  }
   ~PostScope() { c->post = c->stream; }
 };
 

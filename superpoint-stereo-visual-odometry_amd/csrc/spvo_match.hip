@@ -238,6 +238,8 @@ int spvo_match_slots(spvo_ctx *c, int slot_a, int slot_b, int selector, int cros
     for (const auto &mc : c->mcache[set])
       if (mc.valid && mc.slot_a == slot_a && mc.slot_b == slot_b && mc.gen_a == a.gen && mc.gen_b == b.gen && mc.selector == selector &&
           mc.cross == (cross_check ? 1 : 0) && mc.ratio == ratio) {
+        // the matches were enqueued behind the submission's features; spvo_detect_wait returned when the features were final
+        HIP_TRY(c, wait_event(c->ev_tail[set]));
         if (a.n > 0) unpack_match(mc.h_out, a.n, train_idx, distance);
         return SPVO_OK;
       }
