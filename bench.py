@@ -451,7 +451,8 @@ def main():
             traffic = None                                                 # HBM bytes per launch from the committed PMC pass
             wino_on = os.environ.get("SPVO_WINOGRAD", "1") != "0"
             wino2_on = wino_on and os.environ.get("SPVO_WINO2", "1") != "0"
-            pmc = os.path.join(ROOT, "profiles", "r02_pmc.json" if wino2_on else "r01j_pmc_conv_traffic.json" if wino_on else "r01_pmc_conv_traffic.json")
+            pmc = os.path.join(ROOT, "profiles", ("r03_pmc.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc.json")) else "r02_pmc.json") if wino2_on
+                               else "r01j_pmc_conv_traffic.json" if wino_on else "r01_pmc_conv_traffic.json")
             if os.path.exists(pmc) and (NET_H, NET_W) == (360, 1176) and args.precision == "FP32" and not args.fp32_split:
                 pj = json.load(open(pmc))
                 traffic = (pj.get("conv_wino2_kernel") or pj).get("traffic_bytes_per_launch")
@@ -583,7 +584,8 @@ def main():
                                                 "keypoints_per_image": int(np.median(stats_c[5:, 0])), "stereo_matches": int(np.median(stats_c[5:, 2])),
                                                 "pnp_inliers": int(np.median(stats_c[5:, 3])),
                                                 "note": "ORB 2000 features / 8 levels / scale 1.2 / FAST 20 (feature_detection_classic.cpp:13-24) + Hamming BF + KNN 0.8 on the GPU, "
-                                                        "synchronous stereoCallback on host images at 376x1241; bit-exact against the CPU restatement (tests/test_gpu_orb.py)"}
+                                                        "synchronous stereoCallback on host images at 376x1241; ORB as restated in oracle/cpu/orb_cpu.inc (bit-exact against THAT, tests/test_gpu_orb.py): "
+                                                        "seeded test pairs and fixed rounding choices, so descriptors are not comparable with OpenCV's cv::ORB"}
             except Exception as exc:   # the headline line must survive a failure of this informational part
                 out["classic_front_end_gpu"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and world == 1 and headline:

@@ -457,19 +457,34 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   // Keypoints, counts and descriptors are final here: spvo_detect_wait / _collect waits for THIS point; the matches enqueued behind
   // it are waited for where they are asked for (spvo_match_slots, ev_tail).  The bulk copies a host-image submission asked for go
   // out on a stream of their own BESIDE the matches -- 2.8 MB over PCIe are ~110 us the matches need not queue behind.
-  if (!rc) rc = hipEventRecord(c->ev_feat[ring], c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");
+  // Submissions WITHOUT bulk copies (device images: the pipelined path) record ev_feat here, in front of the matches.  A host-image
+  // submission (extras != 0) keeps everything on the tail stream behind the matches and one event, as before round 3: its copies on
+  // a stream of their own beside the matches measured SLOWER on one box (synchronous 627-682 against 691 frames/s, look-ahead 923
+  // against 1045; SPVO_TAIL_SPLIT=2 selects that arrangement, = 0 the single event for every submission).
+  static const int split_mode = std::getenv("SPVO_TAIL_SPLIT") ? std::atoi(std::getenv("SPVO_TAIL_SPLIT")) : 1;
+  const bool tail_split = split_mode == 2 || (split_mode == 1 && !extras);
+  hipStream_t cs = tail_split ? c->stream_c : c->stream_t;
+  if (tail_split) {
+    if (!rc) rc = hipEventRecord(c->ev_feat[ring], c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");
+    if (!rc && extras) rc = hipStreamWaitEvent(c->stream_c, c->ev_feat[ring], 0) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipStreamWaitEvent failed");
+  } else if (!rc && c->prematch) {
+    rc = enqueue_prematch(c, slot_l, slot_r, prev_l, ring);
+  }
   if (!rc && extras) {
-    rc = hipStreamWaitEvent(c->stream_c, c->ev_feat[ring], 0) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipStreamWaitEvent failed");
     if (!rc && (extras & 1))   // resized images (what nn.cpp:154 pushes to images_dq) -> the set's pinned mirror
-      rc = hipMemcpyAsync(c->h_resized_r[ring], c->d_resized_r[ring], (size_t)2 * c->H * c->W, hipMemcpyDeviceToHost, c->stream_c) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipMemcpyAsync failed");
+      rc = hipMemcpyAsync(c->h_resized_r[ring], c->d_resized_r[ring], (size_t)2 * c->H * c->W, hipMemcpyDeviceToHost, cs) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipMemcpyAsync failed");
     if (!rc && (extras & 2)) {   // descriptors of both images: whole slots (the counts are not known on the host yet; rows >= n are stale)
       const size_t per = (size_t)c->cfg.max_keypoints * 256;
       for (int i = 0; i < 2 && !rc; ++i)
-        rc = hipMemcpyAsync(c->h_desc_r[ring] + i * per, c->slots[slots[i]].d_desc, per * sizeof(float), hipMemcpyDeviceToHost, c->stream_c) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipMemcpyAsync failed");
+        rc = hipMemcpyAsync(c->h_desc_r[ring] + i * per, c->slots[slots[i]].d_desc, per * sizeof(float), hipMemcpyDeviceToHost, cs) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipMemcpyAsync failed");
     }
-    if (!rc) rc = hipEventRecord(c->ev_copy[ring], c->stream_c) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");
+    if (!rc) rc = hipEventRecord(c->ev_copy[ring], cs) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");
   }
-  if (!rc && c->prematch) rc = enqueue_prematch(c, slot_l, slot_r, prev_l, ring);
+  if (tail_split) {
+    if (!rc && c->prematch) rc = enqueue_prematch(c, slot_l, slot_r, prev_l, ring);
+  } else if (!rc) {
+    rc = hipEventRecord(c->ev_feat[ring], c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");   // = ev_tail: one event, as before round 3
+  }
   if (!rc && prof_detect) {   // "detect" spans both streams: first kernel on `stream` .. last copy on `stream_t`
     hipEvent_t e1 = get_event(c);
     (void)hipEventRecord(e1, c->stream_t);
