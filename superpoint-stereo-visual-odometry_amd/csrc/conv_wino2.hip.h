@@ -13,8 +13,9 @@
 // one's matrix instructions keep the pipe busy.
 //
 // LDS images (the staging loads stay lane-linear 16-byte pieces):
-//   U  [xi 16][cq 4][lane 64][s 2]          lane = 16 (ci & 3) + (co & 15), s = ci >> 2: a lane's two k-steps of one position
-//                                           are one 8-byte piece (ds_read_b64, conflict-free)
+//   U  [xi/2 8][cq 4][lane 64][xi&1][s 2]   lane = 16 (ci & 3) + (co & 15), s = ci >> 2: a lane's two k-steps of TWO positions
+//                                           are one 16-byte piece (ds_read_b128, conflict-free): 8 A reads per item, not 16 --
+//                                           every LDS read next to an fp32 matrix instruction costs ~8 cycles of matrix time
 //   V  [xi 16][tb 2][lane 64][blk 2][s 2]   lane = 16 (ci & 3) + (tile & 15), blk = (tile >> 4) & 1: both 16-tile blocks and
 //                                           both k-steps of one position are one 16-byte piece (ds_read_b128)
 #pragma once
@@ -29,7 +30,7 @@ namespace spvo {
 
 constexpr int WINO2_LDS_BYTES = WinoTile::LDS_BYTES + 16;   // + the slot through which a tile's successor is published (a.sched)
 
-// OIHW weights + bias -> slabs [co_tile][chunk][xi 16][cq][lane 64][s 2] of U = G g G^T (double) + a bias row; cot = output
+// OIHW weights + bias -> slabs [co_tile][chunk][xi/2 8][cq][lane 64][xi&1][s 2] of U = G g G^T (double) + a bias row; cot = output
 // channels per workgroup: 64 (cq 4) or, for the narrow form, 32 (cq 2)
 inline std::vector<float> pack_conv_weights_wino2(const float *w, const float *bias, int cout, int cin, int cot = CO_TILE) {
   constexpr int CK = WinoTile::CK;
@@ -51,7 +52,7 @@ inline std::vector<float> pack_conv_weights_wino2(const float *w, const float *b
           const int lane = 16 * (c & 3) + (o & 15), s = c >> 2, cq = o >> 4;
           for (int a = 0; a < 4; ++a)
             for (int b = 0; b < 4; ++b)
-              slab[((((a * 4 + b) * ncq + cq) * 64 + lane) * 2) + s] = (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
+              slab[((((a * 4 + b) >> 1) * ncq + cq) * 64 + lane) * 4 + 2 * ((a * 4 + b) & 1) + s] = (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
         }
         if (ch == 0) slab[u_floats + o] = bias[co];
       }
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
       v[3 * 512] = tt[r * 4 + 1] - tt[r * 4 + 3];
     }
   };
-  const int a_lane = cq * 64 + lane;   // 8-byte pieces in a filter slab:  + xi * 64 NCQ
+  const int a_lane = cq * 64 + lane;   // 16-byte pieces in a filter slab: + (xi / 2) * 64 NCQ
   const int b_lane = tb * 64 + lane;   // 16-byte (narrow: 8-byte) pieces in a V buffer:  + xi * 128 (256)
 
   // a.sched (dynamic tile assignment, see below): the tiles are cut into 8 contiguous bands, one per group of workgroups that
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
   struct Cursor { TileRef t; int chunk, id; };
   auto advance = [&](Cursor &q) {
     if (++q.chunk == a.n_chunks) {
+      asm volatile("" ::: "memory");   // keeps this a real branch, taken once per tile: the tile decode is three integer divisions on the scalar unit
       q.chunk = 0;
       q.id = a.sched ? nxt_id : q.id + (int)gridDim.x;
       if (q.id < n_tiles) q.t = decode(q.id);
@@ -295,16 +297,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
       float *raw_next2 = smem + T::RAW_OFF + (k & 1) * T::IN_FLOATS;          // raw(k+2) replaces raw(k), transformed during item k-1
       const float *raw_next = smem + T::RAW_OFF + ((k + 1) & 1) * T::IN_FLOATS;
       float *v_next = smem + T::V_OFF + ((k + 1) & 1) * T::V_FLOATS;
-      const f32x2 *ub2 = reinterpret_cast<const f32x2 *>(ub);
       const f32x4v *vb4 = reinterpret_cast<const f32x4v *>(vb);
       {
         // 64 matrix instructions in 4 groups of 4 positions; per position one ds_read_b64 (A: two k-steps) and one ds_read_b128
         // (B: two blocks x two k-steps), read while the previous group multiplies.  Inside a group: k-step outer, position, block
         // inner -- an accumulator is revisited after 7 other instructions.
-        f32x2 av[4];
+        f32x4v avq[2];   // [pair]: positions 4 g + 2 p, 4 g + 2 p + 1, two k-steps each
         f32x4v bv[4];
+        const f32x4v *ub4 = reinterpret_cast<const f32x4v *>(ub);
+        auto lda = [&](int g, int p) { avq[p] = ub4[a_lane + (2 * g + p) * (64 * NCQ)]; };
         auto ld = [&](int g, int x) {
-          av[x] = ub2[a_lane + (4 * g + x) * (64 * NCQ)];
           if constexpr (NARROW) {
             const f32x2 b2 = reinterpret_cast<const f32x2 *>(vb)[b_lane + (4 * g + x) * 256];
             bv[x][0] = b2[0]; bv[x][1] = b2[1];
@@ -312,6 +314,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
             bv[x] = vb4[b_lane + (4 * g + x) * 128];
           }
         };
+        lda(0, 0); lda(0, 1);
 #pragma unroll
         for (int x = 0; x < 4; ++x) ld(0, x);
 #pragma unroll
@@ -320,8 +323,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
 #pragma unroll
           for (int q = 0; q < QN; ++q) {
             const int s = NARROW ? q >> 2 : q >> 3, x = NARROW ? q & 3 : (q >> 1) & 3, blk = NARROW ? 0 : q & 1;
-            if (FIRST && s == 0) acc[4 * g + x][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[x][s], bv[x][2 * blk + s], f32x4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            else acc[4 * g + x][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[x][s], bv[x][2 * blk + s], acc[4 * g + x][blk], 0, 0, 0);
+            const float a_op = avq[x >> 1][2 * (x & 1) + s];
+            if (FIRST && s == 0) acc[4 * g + x][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_op, bv[x][2 * blk + s], f32x4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            else acc[4 * g + x][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_op, bv[x][2 * blk + s], acc[4 * g + x][blk], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #ifndef WINO2_ABL
 #define WINO2_ABL 0   // timing experiments only (results are wrong when != 0): 1 no transform steps, 2 no LDS-DMA, 4 no operand reads in the loop
@@ -339,7 +343,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
                 if (slot == 5 && cr.id < n_tiles) issue_raw(cr.t, cr.chunk, raw_next2);
               }
             }
-            if (!(WINO2_ABL & 4) && g < 3 && q >= QN - 4) ld(g + 1, q - (QN - 4));   // position x's registers were last read by instruction 9 + 2 x (narrow: 4 + x)
+            if (!(WINO2_ABL & 4) && g < 3 && q >= QN - 4) {   // position x's registers were last read by instruction 9 + 2 x (narrow: 4 + x)
+              ld(g + 1, q - (QN - 4));
+              if (q == QN - 4 + (NARROW ? 1 : 0)) lda(g + 1, 0);   // positions 0, 1 are through after instruction 11 (narrow: 5)
+              if (q == QN - 1) lda(g + 1, 1);                      // positions 2, 3 after this one
+            }
             // input transform of item k+1: 20 micro-steps on every other instruction slot (staggering them between the two waves of
             // a SIMD, or packing them densely, measured slower)
             if constexpr (NARROW) {
@@ -398,18 +406,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        // two-wide (v_pk_add_f32): rows of M in pairs for the column pass, (y00, y01) / (y10, y11) for the row pass
-        f32x2 sa[2], sb[2];
+        // column pass per row a of M (positions 4 a + b), then the row pass -- single adds in the association the tests pin
+        // ((m0 + m1) + m2, (m1 - m2) - m3): the two-wide form needed two register moves per packed add to pair its operands,
+        // and every vector instruction here is paid in matrix time
+        float sa[4], sb[4];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const f32x2 m0 = {acc[8 * h + 0][blk][r], acc[8 * h + 4][blk][r]}, m1 = {acc[8 * h + 1][blk][r], acc[8 * h + 5][blk][r]};
-          const f32x2 m2 = {acc[8 * h + 2][blk][r], acc[8 * h + 6][blk][r]}, m3 = {acc[8 * h + 3][blk][r], acc[8 * h + 7][blk][r]};
-          sa[h] = (m0 + m1) + m2;
-          sb[h] = (m1 - m2) - m3;
+        for (int ar = 0; ar < 4; ++ar) {
+          const float m0 = acc[4 * ar + 0][blk][r], m1 = acc[4 * ar + 1][blk][r], m2 = acc[4 * ar + 2][blk][r], m3 = acc[4 * ar + 3][blk][r];
+          sa[ar] = (m0 + m1) + m2;
+          sb[ar] = (m1 - m2) - m3;
         }
-        const f32x2 q0 = {sa[0][0], sb[0][0]}, q1 = {sa[0][1], sb[0][1]}, q2 = {sa[1][0], sb[1][0]}, q3 = {sa[1][1], sb[1][1]};
-        const f32x2 ya = (q0 + q1) + q2, yb = (q1 - q2) - q3;   // ya = (y00, y01), yb = (y10, y11)
-        const float y00 = relu(ya[0]), y01 = relu(ya[1]), y10 = relu(yb[0]), y11 = relu(yb[1]);
+        const float y00 = relu((sa[0] + sa[1]) + sa[2]), y01 = relu((sb[0] + sb[1]) + sb[2]);
+        const float y10 = relu((sa[1] - sa[2]) - sa[3]), y11 = relu((sb[1] - sb[2]) - sb[3]);
         const unsigned vo = r < kmax ? voff : OOB;
         if constexpr (POOL) {
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaxf(fmaxf(y00, y01), fmaxf(y10, y11))), rsrc, vo, r * oplane * 4, 0);
