@@ -137,15 +137,23 @@ __host__ __device__ inline int match_ldt(int nb_cap) { return (nb_cap + 31) & ~3
 // MATCH_ERR_REL -- K12b runs with the statistical window MATCH_ERR_REL_FP8 and still produces exact distances for
 // whatever falls into it -- so this mode is an opt-in (spvo_set_match_fp8).
 template <bool FP8, bool FUSED = false>
-__global__ __launch_bounds__(256) void match_gemm_kernel(MatchJobs jobs, int ldt, float err_rel = 0.f, int nt_stride = 0) {
-  const MatchJob jb = jobs.j[blockIdx.z];
+__global__ __launch_bounds__(256) void match_gemm_kernel(MatchJobs jobs, int ldt, float err_rel, int nt_stride, int gx, int gy, int gz) {
+  // Tile of this workgroup.  The grid is one-dimensional, 8 x chunk workgroups, chunk = ceil(tiles / 8): workgroups with equal
+  // blockIdx.x % 8 share an XCD (MI355X_MICROARCH.md, workgroup dispatch) and take a CONTIGUOUS chunk of the tile order (job,
+  // query tile, train tile): an XCD's L2 then holds a few query tiles and one job's train rows -- 10 MB leave the fabric for the
+  // frame's two jobs instead of 18 (every XCD read every query row of both jobs with the (x, y, z) grid).  For speed only.
+  const int n_tiles_all = gx * gy * gz, chunk = (n_tiles_all + 7) >> 3;
+  const int tile_lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= chunk || tile_lin >= n_tiles_all) return;
+  const int bx = tile_lin % gx, by = (tile_lin / gx) % gy, bz = tile_lin / (gx * gy);
+  const MatchJob jb = jobs.j[bz];
   const float *__restrict__ A = jb.A;
   const float *__restrict__ B = jb.B;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qh = wave >> 1, th = wave & 1;           // the wave's 32 x 64 piece of the 64 x 128 tile
-  const int q0 = blockIdx.y * MATCH_QT, t0 = blockIdx.x * MATCH_TT;
+  const int q0 = by * MATCH_QT, t0 = bx * MATCH_TT;
   const int na = dev_count(jb.na, jb.na_ptr), nb = dev_count(jb.nb, jb.nb_ptr);
   if (q0 >= na || t0 >= nb) return;
 
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(256) void match_gemm_kernel(MatchJobs jobs, int ldt
       }
     __syncthreads();
     if (q0 + row < na) {
-      const size_t slot = (size_t)(q0 + row) * nt_stride + blockIdx.x;
+      const size_t slot = (size_t)(q0 + row) * nt_stride + bx;
       const int cnt = scnt[row];
       if (part == 0) jb.meta[slot] = make_int4(cnt, __float_as_int(two.u1), __float_as_int(two.u2), 0);
       if (2 * part < min(cnt, MATCH_C)) *reinterpret_cast<int4 *>(jb.cand + slot * MATCH_C + 2 * part) = *reinterpret_cast<const int4 *>(slist + row * MATCH_C + 2 * part);

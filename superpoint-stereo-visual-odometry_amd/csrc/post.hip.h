@@ -337,8 +337,11 @@ __device__ __forceinline__ uint8_t nms_decide(const float *__restrict__ hm, uint
 // with 3 independent aligned word loads (27 loads in flight for the 9x9 window);
 // DIST == 0: run-time radius (<= NMS_PAD).
 template <int INNER, int DIST>
+// `collect`: a candidate that is decided KEPT is entered into the survivor list on the spot (decisions are final, so the list is
+// complete when nothing is undecided) and no separate collect launch is needed; the host-driven continuation after an unsettled
+// first batch clears the list and runs nms_collect_kernel over all candidates instead (collect = 0).
 __global__ __launch_bounds__(256) void nms_round_kernel(const float *__restrict__ heat, int H, int W,
-                                                        int dist_rt, NmsPair np, int launch) {
+                                                        int dist_rt, NmsPair np, int launch, int border, int surv_cap, int collect) {
   const NmsBuffers nb = np.b[blockIdx.y];
   if (launch > 0 && nb.counters[8 + launch - 1] == 0) return;  // nothing left undecided
   const float *hm = heat + (size_t)blockIdx.y * H * W;
@@ -356,12 +359,20 @@ __global__ __launch_bounds__(256) void nms_round_kernel(const float *__restrict_
     live0 = ((volatile uint8_t *)state)[sp0] == ST_UNDECIDED;
   }
   const bool extra = gid + stride < n;
+  auto survive = [&](int p, int x, int y) {   // nn.cpp:239-242: a kept candidate inside the border is emitted
+    if (y >= border && y + border < H && x >= border && x + border < W) {
+      const int s = atomicAdd(&nb.counters[1], 1);
+      if (s < surv_cap) nb.surv_key[s] = rank_key(hm[p], x, y, H);
+      else nb.counters[3] = 1;
+    }
+  };
   for (int it = 0; it < INNER; ++it) {
     if (live0) {
       const uint8_t d = nms_decide<DIST>(hm, state, H, W, pitch, dist_rt, p0, x0, y0);
       if (d != ST_UNDECIDED) {
         ((volatile uint8_t *)state)[sp0] = d;
         live0 = false;
+        if (d == ST_KEPT && collect) survive(p0, x0, y0);
       }
     }
     if (extra)
@@ -372,6 +383,7 @@ __global__ __launch_bounds__(256) void nms_round_kernel(const float *__restrict_
         if (((volatile uint8_t *)state)[sp] != ST_UNDECIDED) continue;
         const uint8_t d = nms_decide<DIST>(hm, state, H, W, pitch, dist_rt, p, x, y);
         if (d != ST_UNDECIDED) ((volatile uint8_t *)state)[sp] = d;
+        if (d == ST_KEPT && collect) survive(p, x, y);
       }
     if (!__syncthreads_or(live0 || extra)) break;
   }

@@ -117,16 +117,17 @@ NmsPair nms_pair(spvo_ctx *c, int set) {
 
 // `n_launch` round launches + collect + rank + write for `nimg` images, then the counters travel
 // to the host in one copy.  Launch 0 of a batch never exits early.
-int launch_nms_rounds(spvo_ctx *c, int nimg, const NmsPair &np, int set, int n_launch, int *zero_next) {
+int launch_nms_rounds(spvo_ctx *c, int nimg, const NmsPair &np, int set, int n_launch, int *zero_next, bool redo = false) {
   hipStream_t st = c->post;
   const float *heat = c->d_heat_r[set % RING];
+  const int collect = redo ? 0 : 1;   // first batch: survivors are listed as they are decided; continuation: the list was cleared, re-collect everything
   for (int l = 0; l < n_launch; ++l) {
     if (c->cfg.dist_thresh == 4)
-      hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 4>), dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, 4, np, l);
+      hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 4>), dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, 4, np, l, c->cfg.border_remove, c->surv_cap, collect);
     else
-      hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 0>), dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, c->cfg.dist_thresh, np, l);
+      hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 0>), dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, c->cfg.dist_thresh, np, l, c->cfg.border_remove, c->surv_cap, collect);
   }
-  hipLaunchKernelGGL(nms_collect_kernel, dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, c->cfg.border_remove, c->surv_cap, np);
+  if (redo) hipLaunchKernelGGL(nms_collect_kernel, dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, c->cfg.border_remove, c->surv_cap, np);
   hipLaunchKernelGGL(nms_rank_kernel, dim3(128, nimg), dim3(256), 0, st, c->surv_cap, np);
   hipLaunchKernelGGL(nms_write_kernel, dim3(32, nimg), dim3(256), 0, st, c->H, c->cfg.max_keypoints, c->surv_cap, np, zero_next);
   HIP_TRY(c, hipGetLastError());
@@ -154,7 +155,7 @@ int nms_settle(spvo_ctx *c, int nimg, const NmsPair &np, int set, bool *redone) 
     last = NMS_MAX_LAUNCH;
     for (int i = 0; i < nimg; ++i)   // keep n_cand, clear the rest of the block
       HIP_TRY(c, hipMemsetAsync(np.b[i].counters + 1, 0, (NMS_COUNTER_INTS - 1) * sizeof(int), c->post));
-    int rc = launch_nms_rounds(c, nimg, np, set, last, nullptr);
+    int rc = launch_nms_rounds(c, nimg, np, set, last, nullptr, true);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->post));
   }

@@ -111,12 +111,13 @@ int enqueue_matches(spvo_ctx *c, const MatchReq *req_in, int njobs, int selector
   static const bool fused_on = !(std::getenv("SPVO_MATCH_FUSED") && std::atoi(std::getenv("SPVO_MATCH_FUSED")) == 0);
   const int nt_stride = (c->match_cap + MATCH_TT - 1) / MATCH_TT;
   const bool fused = fused_on && !c->match_fp8 && nt_stride <= 64;
-  const dim3 gg(groups, (na_max + MATCH_QT - 1) / MATCH_QT, njobs);
+  const int gx = groups, gy = (na_max + MATCH_QT - 1) / MATCH_QT;
+  const dim3 gg(8 * ((gx * gy * njobs + 7) / 8));   // one-dimensional: XCD-contiguous chunks of the tile order (see the kernel)
   {
     ScopedStage sg(c, stage_id(c, "match_gemm"), fl, 4.0 * (na_max + nb_max) * MATCH_D * njobs);
-    if (c->match_fp8) hipLaunchKernelGGL((match_gemm_kernel<true, false>), gg, dim3(256), MATCH_LDS_BYTES_FP8, c->post, jobs, ldt, 0.f, 0);
-    else if (fused) hipLaunchKernelGGL((match_gemm_kernel<false, true>), gg, dim3(256), lds, c->post, jobs, ldt, MATCH_ERR_REL, nt_stride);
-    else hipLaunchKernelGGL((match_gemm_kernel<false, false>), gg, dim3(256), lds, c->post, jobs, ldt, 0.f, 0);
+    if (c->match_fp8) hipLaunchKernelGGL((match_gemm_kernel<true, false>), gg, dim3(256), MATCH_LDS_BYTES_FP8, c->post, jobs, ldt, 0.f, 0, gx, gy, njobs);
+    else if (fused) hipLaunchKernelGGL((match_gemm_kernel<false, true>), gg, dim3(256), lds, c->post, jobs, ldt, MATCH_ERR_REL, nt_stride, gx, gy, njobs);
+    else hipLaunchKernelGGL((match_gemm_kernel<false, false>), gg, dim3(256), lds, c->post, jobs, ldt, 0.f, 0, gx, gy, njobs);
   }
   {
     ScopedStage sr(c, stage_id(c, "match_rerank"));

@@ -44,7 +44,8 @@ int main(int argc, char **argv) {
   }
   CK(hipFuncSetAttribute((const void *)match_gemm_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH_LDS_BYTES));
   CK(hipFuncSetAttribute((const void *)match_gemm_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH_LDS_BYTES));
-  const dim3 gg((n + MATCH_TT - 1) / MATCH_TT, (n + MATCH_QT - 1) / MATCH_QT, njobs), gr((n + 3) / 4, njobs);
+  const int gx = (n + MATCH_TT - 1) / MATCH_TT, gy = (n + MATCH_QT - 1) / MATCH_QT;
+  const dim3 gg(8 * ((gx * gy * njobs + 7) / 8)), gr((n + 3) / 4, njobs);
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float ms;
@@ -56,8 +57,8 @@ int main(int argc, char **argv) {
         CK(hipEventRecord(e0));
         for (int i = 0; i < reps; ++i) {
           if (phase != 1) {
-            if (fused) hipLaunchKernelGGL((match_gemm_kernel<false, true>), gg, dim3(256), MATCH_LDS_BYTES, 0, jobs, ldt, MATCH_ERR_REL, nt);
-            else hipLaunchKernelGGL((match_gemm_kernel<false, false>), gg, dim3(256), MATCH_LDS_BYTES, 0, jobs, ldt, 0.f, 0);
+            if (fused) hipLaunchKernelGGL((match_gemm_kernel<false, true>), gg, dim3(256), MATCH_LDS_BYTES, 0, jobs, ldt, MATCH_ERR_REL, nt, gx, gy, njobs);
+            else hipLaunchKernelGGL((match_gemm_kernel<false, false>), gg, dim3(256), MATCH_LDS_BYTES, 0, jobs, ldt, 0.f, 0, gx, gy, njobs);
           }
           if (phase != 0) {
             if (fused) hipLaunchKernelGGL(match_merge_kernel<>, gr, dim3(256), sizeof(MatchRerankLds<0>), 0, jobs, nt, ldt, MATCH_ERR_REL, 1, 0, 0.8f);
@@ -69,7 +70,7 @@ int main(int argc, char **argv) {
       }
       const double us = ms * 1e3 / reps, fl = 2.0 * n * n * 256 * njobs;
       const char *form = fused ? "fused  " : "unfused";
-      if (phase == 0) printf("%s n=%d jobs=%d  gemm   %7.2f us  %6.1f TFLOP/s = %.3f of the fp32 MFMA peak (%d workgroups)\n", form, n, njobs, us, fl / us / 1e6, fl / us / 1e6 / 157.3, gg.x * gg.y * gg.z);
+      if (phase == 0) printf("%s n=%d jobs=%d  gemm   %7.2f us  %6.1f TFLOP/s = %.3f of the fp32 MFMA peak (%d workgroups)\n", form, n, njobs, us, fl / us / 1e6, fl / us / 1e6 / 157.3, gx * gy * njobs);
       if (phase == 1) printf("%s n=%d jobs=%d  %s %7.2f us\n", form, n, njobs, fused ? "merge " : "rerank", us);
       if (phase == 2) printf("%s n=%d jobs=%d  both   %7.2f us\n", form, n, njobs, us);
     }
