@@ -7,6 +7,7 @@
 #include "conv_wino.hip.h"
 #include "conv_wino2.hip.h"
 #include "conv_wino64.hip.h"
+#include "conv_wino4.hip.h"
 #include "heads.hip.h"
 #include "conv_i8.hip.h"
 
@@ -672,6 +673,24 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
         // layer -- one tile's chain of items per workgroup -- becomes a chain of half-size items (SPVO_WINO_NARROW=0: direct kernel)
         const bool narrow_on = !(std::getenv("SPVO_WINO_NARROW") && std::atoi(std::getenv("SPVO_WINO_NARROW")) == 0);
         if (eligible && !op.wino && op.wino2 && narrow_on && (op.cout % 32) == 0 && 2 * wtiles >= min_tiles) op.wino = op.wino_narrow = true;
+      }
+      // F(4x4,3x3) (conv_wino4.hip.h): 36 multiplies per 4x4 outputs instead of F(2x2)'s 64 -- for the Winograd layers with even H
+      // and W (its stores go out in column pairs) and enough 16 x 32 tiles to fill the chip.  SPVO_WINO4=0 keeps F(2x2).
+      if (op.wino && !op.wino_narrow && op.wino2 && (op.cin % Wino4Tile::CK) == 0 && ((ti.H | ti.W) & 1) == 0 &&
+          !(std::getenv("SPVO_WINO4") && std::atoi(std::getenv("SPVO_WINO4")) == 0)) {
+        const long t4 = (long)((ti.W + Wino4Tile::TW - 1) / Wino4Tile::TW) * ((ti.H + Wino4Tile::TH - 1) / Wino4Tile::TH) * op.co_tiles * c->cfg.max_batch;
+        const long min4 = std::getenv("SPVO_WINO4_MIN_TILES") ? std::atol(std::getenv("SPVO_WINO4_MIN_TILES")) : 3 * c->num_cus / 4;
+        if (t4 >= min4) {
+          op.wino4 = true;
+          op.ck = Wino4Tile::CK;
+          op.n_chunks = op.cin / Wino4Tile::CK;
+          const std::vector<float> pk = pack_conv_weights_wino4(w, b, op.cout, op.cin);
+          int rc = dev_alloc(c, &op.d_w, pk.size(), false);
+          if (rc) return rc;
+          HIP_TRY(c, hipMemcpy(op.d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+          if (!(std::getenv("SPVO_WINO_DYNAMIC") && std::atoi(std::getenv("SPVO_WINO_DYNAMIC")) == 0) && (rc = dev_alloc(c, &op.d_sched, 16))) return rc;
+          continue;
+        }
       }
       // 64 input channels (conv1b, conv2a, conv2b, conv3a of the VGG graph): the transformed filters of a 64-channel output tile fit
       // the registers of one workgroup and stay there (conv_wino64.hip.h) -- no filter staging at all.  Needs even H and W (a

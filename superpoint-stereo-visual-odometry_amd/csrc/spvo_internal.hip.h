@@ -59,6 +59,7 @@ struct Op {
   bool wino = false;       // FP32 engines: this 3x3 layer runs the Winograd F(2x2,3x3) kernel (conv_wino.hip.h)
   bool wino_narrow = false;   // ... with 32 instead of 64 output channels per workgroup (layers whose 64-channel tiles would leave CUs idle)
   bool wino64 = false;     // ... the form with the filters resident in registers (conv_wino64.hip.h: layers with 64 input channels; opt-in, SPVO_WINO64=1)
+  bool wino4 = false;      // ... the F(4x4,3x3) form (conv_wino4.hip.h: 9/16 of F(2x2)'s matrix work; layers with even H and W)
   bool wino2 = false;      // ... its 8-wave form (conv_wino2.hip.h: two waves per SIMD; the default, SPVO_WINO2=0 keeps the 4-wave form)
   bool dominant = false;   // the op with the most FLOPs: launched under its own kernel name (TAG = 1)
   float *d_w = nullptr, *d_b = nullptr, *d_bn_scale = nullptr, *d_bn_shift = nullptr;

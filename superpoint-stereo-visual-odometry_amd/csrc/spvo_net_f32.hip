@@ -5,6 +5,7 @@
 #include "conv_wino.hip.h"
 #include "conv_wino2.hip.h"
 #include "conv_wino64.hip.h"
+#include "conv_wino4.hip.h"
 #include "heads.hip.h"
 
 namespace spvo_int {
@@ -104,6 +105,36 @@ int launch_conv_wino_sel(spvo_ctx *c, const ConvArgs &args, bool relu, bool pool
   return relu ? launch_conv_wino_instance<false, true, 0, false, W2>(c, args, stream) : launch_conv_wino_instance<false, false, 0, false, W2>(c, args, stream);
 }
 
+// conv_wino4.hip.h: Winograd F(4x4,3x3), 16 x 32 output tiles, 8 waves, one workgroup per CU
+template <bool POOL, bool RELU, int TAG>
+int launch_conv_wino4_instance(spvo_ctx *c, const ConvArgs &args, hipStream_t stream) {
+  static bool ready[64] = {};
+  const int dev = c->cfg.device & 63;
+  auto k = conv_wino4_kernel<POOL, RELU, TAG>;
+  if (!ready[dev]) {
+    HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, Wino4Tile::LDS_BYTES));
+    ready[dev] = true;
+  }
+  const int n_tiles = args.tiles_x * args.tiles_y * args.co_tiles * args.batch;
+  const int rounds = (n_tiles + c->num_cus - 1) / c->num_cus;
+  const int grid = (n_tiles + rounds - 1) / rounds;   // the smallest grid that keeps the number of rounds (see launch_conv_wino_instance)
+  ConvArgs a2 = args;
+  if (rounds < 2 || args.n_chunks < 4) a2.sched = nullptr;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), Wino4Tile::LDS_BYTES, stream, a2);
+  HIP_TRY(c, hipGetLastError());
+  return SPVO_OK;
+}
+
+int launch_conv_wino4(spvo_ctx *c, const ConvArgs &a, int batch, bool relu, bool pool, bool dominant, hipStream_t stream) {
+  ConvArgs args = a;
+  args.tiles_x = (a.W + Wino4Tile::TW - 1) / Wino4Tile::TW;
+  args.tiles_y = (a.H + Wino4Tile::TH - 1) / Wino4Tile::TH;
+  args.batch = batch;
+  if (dominant && relu) return pool ? launch_conv_wino4_instance<true, true, 1>(c, args, stream) : launch_conv_wino4_instance<false, true, 1>(c, args, stream);
+  if (pool) return relu ? launch_conv_wino4_instance<true, true, 0>(c, args, stream) : launch_conv_wino4_instance<true, false, 0>(c, args, stream);
+  return relu ? launch_conv_wino4_instance<false, true, 0>(c, args, stream) : launch_conv_wino4_instance<false, false, 0>(c, args, stream);
+}
+
 // conv_wino64.hip.h: filters resident in registers (64 input channels), 4 x 32 output tiles, one workgroup per CU
 template <bool POOL, bool RELU, int TAG>
 int launch_conv_wino64_instance(spvo_ctx *c, const ConvArgs &args, hipStream_t stream) {
@@ -183,6 +214,7 @@ int launch_conv(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stre
   a.tiles_x = a.tiles_y = 0;
   a.batch = batch;
   a.sched = op.d_sched;
+  if (op.wino4) return launch_conv_wino4(c, a, batch, relu, pool, op.dominant, stream);
   if (op.wino64) return launch_conv_wino64(c, a, batch, relu, pool, op.dominant, stream);
   if (op.wino) return launch_conv_wino(c, a, batch, relu, pool, op.dominant, op.wino2, op.wino_narrow, stream);
   const int key = op.ks * 10000 + op.ck * 100 + op.wr * 20 + op.wc * 2 + (pool ? 1 : 0);   // ks, ck, wr, wc, pool

@@ -12,7 +12,13 @@
 #include "../superpoint-stereo-visual-odometry_amd/csrc/conv_wino.hip.h"
 #include "../superpoint-stereo-visual-odometry_amd/csrc/conv_wino2.hip.h"
 #include "../superpoint-stereo-visual-odometry_amd/csrc/conv_wino64.hip.h"
-#if defined(WINO64)   // filters resident in registers (cin = 64): -DWINO64
+#include "../superpoint-stereo-visual-odometry_amd/csrc/conv_wino4.hip.h"
+#if defined(WINO4)   // F(4x4, 3x3): -DWINO4
+#define KERNEL(P, R, T, O) conv_wino4_kernel<P, R, T>
+#define PACK pack_conv_weights_wino4
+#define THREADS 512
+#define COT 64
+#elif defined(WINO64)   // filters resident in registers (cin = 64): -DWINO64
 #define KERNEL(P, R, T, O) conv_wino64_kernel<P, R, T>
 #define PACK pack_conv_weights_wino64
 #define THREADS 256
@@ -34,7 +40,9 @@
 #define COT 64
 #endif
 using namespace spvo;
-#if defined(WINO64)
+#if defined(WINO4)
+#define LDSB Wino4Tile::LDS_BYTES
+#elif defined(WINO64)
 #define LDSB Wino64Tile::LDS_BYTES
 #elif defined(WINO2)
 #define LDSB WINO2_LDS_BYTES
@@ -70,7 +78,10 @@ int main(int argc, char **argv) {
   ConvArgs a{};
   a.in = d_in; a.out = d_out; a.wpack = d_w; a.bias = nullptr; a.H = H; a.W = W;
   a.in_hp = ihp; a.in_wp = iwp; a.in_ctot = cin; a.in_coff = 0; a.out_hp = ohp; a.out_wp = owp; a.out_ctot = cout; a.out_coff = 0;
-#if defined(WINO64)
+#if defined(WINO4)
+  if ((cin & 3) || ((H | W) & 1)) { printf("WINO4: cin must be a multiple of 4, H and W even\n"); return 1; }
+  a.cout = cout; a.n_chunks = cin / Wino4Tile::CK; a.tiles_x = (W + Wino4Tile::TW - 1) / Wino4Tile::TW; a.tiles_y = (H + Wino4Tile::TH - 1) / Wino4Tile::TH;
+#elif defined(WINO64)
   if (cin != 64 || ((H | W) & 1)) { printf("WINO64: cin must be 64, H and W even\n"); return 1; }
   a.cout = cout; a.n_chunks = Wino64Tile::NCH; a.tiles_x = (W + Wino64Tile::TW - 1) / Wino64Tile::TW; a.tiles_y = (H + Wino64Tile::TH - 1) / Wino64Tile::TH;
 #else
