@@ -449,31 +449,34 @@ def main():
             avg_ms = dom["total_ms"] / dom["calls"]
             achieved = dom["flops"] / (avg_ms * 1e-3) / 1e12
             traffic = None                                                 # HBM bytes per launch from the committed PMC pass
-            wino_on = os.environ.get("SPVO_WINOGRAD", "1") != "0"
-            wino2_on = wino_on and os.environ.get("SPVO_WINO2", "1") != "0"
-            pmc = os.path.join(ROOT, "profiles", ("r03_pmc.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc.json")) else "r02_pmc.json") if wino2_on
-                               else "r01j_pmc_conv_traffic.json" if wino_on else "r01_pmc_conv_traffic.json")
-            if os.path.exists(pmc) and (NET_H, NET_W) == (360, 1176) and args.precision == "FP32" and not args.fp32_split:
+            # The kernel family the engine runs conv1b on, and the multiply-adds its matrix instructions execute per multiply-add
+            # of the direct convolution, come from the library (spvo_profile_stage_kernel): Winograd F(4x4,3x3) executes 36
+            # multiplies per 4x4 outputs and channel pair instead of the direct method's 144 (1/4), F(2x2,3x3) 16 instead of 36
+            # (4/9), the split mode six bf16 partial products per fp32 product (x6).  `achieved` / `frac` count what the matrix
+            # pipe EXECUTES per launch; the layer's ALGORITHMIC rate (direct 3x3 convolution) is reported
+            # beside it under its own name and never enters `frac` (it exceeds the peak: that is the point of Winograd).
+            kfam, kfactor = ctx.stage_kernel("conv:1")
+            pmc_file = {"conv_wino4_kernel": "r03_pmc.json", "conv_wino2_kernel": "r03_pmc.json", "conv_wino_kernel": "r01j_pmc_conv_traffic.json", "conv_mfma_kernel": "r01_pmc_conv_traffic.json"}.get(kfam)
+            pmc = os.path.join(ROOT, "profiles", pmc_file) if pmc_file else None
+            if pmc and os.path.exists(pmc) and (NET_H, NET_W) == (360, 1176):
                 pj = json.load(open(pmc))
-                traffic = (pj.get("conv_wino2_kernel") or pj).get("traffic_bytes_per_launch")
+                traffic = (pj.get(kfam) or ({} if kfam in ("conv_wino4_kernel", "conv_wino2_kernel") else pj)).get("traffic_bytes_per_launch")
             peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "FP32" and not args.fp32_split else F16_MFMA_PEAK_TFLOPS
-            wino = args.precision == "FP32" and not args.fp32_split and os.environ.get("SPVO_WINOGRAD", "1") != "0"
-            kname = ("conv_s3_kernel<KS=3,...,POOL,RELU>" if args.fp32_split else ("conv_wino2_kernel" if wino2_on else "conv_wino_kernel") + "<POOL,RELU,TAG=1> (Winograd F(2x2,3x3), fp32)" if wino
-                     else "conv_mfma_kernel<KS=3,...,POOL,RELU>" if args.precision == "FP32" else "conv_f16_kernel<KS=3,...,POOL,RELU>")
-            # `achieved` / `frac` count the flops the matrix pipe EXECUTES per launch: the Winograd F(2x2,3x3) kernel runs 16
-            # multiplies per 2x2 outputs and channel pair instead of the direct method's 36 (4/9), the split mode six bf16
-            # partial products per fp32 product (x6).  The layer's ALGORITHMIC rate (direct 3x3 convolution, SURVEY.md
-            # section 8d) is reported beside it under its own name and never enters `frac`.
+            kdesc = {"conv_wino4_kernel": "<POOL,RELU,TAG=1> (Winograd F(4x4,3x3), fp32)", "conv_wino2_kernel": "<POOL,RELU,TAG=1> (Winograd F(2x2,3x3), fp32)",
+                     "conv_wino_kernel": "<POOL,RELU,TAG=1> (Winograd F(2x2,3x3), fp32)", "conv_wino64_kernel": "<POOL,RELU,TAG=1> (Winograd F(2x2,3x3), filters in registers, fp32)"}.get(kfam, "<KS=3,...,POOL,RELU>")
+            counted = {0.25: " (Winograd F(4x4,3x3): 1/4 of the direct convolution's)", 4.0 / 9.0: " (Winograd F(2x2,3x3): 4/9 of the direct convolution's)",
+                       6.0: " (split mode: six bf16 partial products per fp32 product)"}.get(kfactor, "")
             algorithmic = achieved
-            executed_per_launch = dom["flops"] * (6.0 if args.fp32_split else 4.0 / 9.0 if wino else 1.0)
+            executed_per_launch = dom["flops"] * kfactor
             achieved = executed_per_launch / (avg_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": kname + " instance of op 1 = conv1b 64->64 @" + f"{NET_H}x{NET_W}, 2 images",
+            out["roofline"] = {"bound": "mfma", "kernel": kfam + kdesc + " instance of op 1 = conv1b 64->64 @" + f"{NET_H}x{NET_W}, 2 images",
                                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(achieved / peak, 4), "traffic": traffic,
-                               "traffic_source": "profiles/" + os.path.basename(pmc) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x 2, validated by a known-size copy kernel in the same session)",
+                               "traffic_source": ("profiles/" + os.path.basename(pmc) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x 2, validated by a known-size copy kernel in the same session)") if traffic else None,
                                "avg_kernel_ms": round(avg_ms, 5), "flops_per_launch": executed_per_launch,
-                               "flops_counted": "executed on the matrix pipe" + (" (Winograd F(2x2,3x3): 4/9 of the direct convolution's)" if wino else ""),
-                               "algorithmic_flops_per_launch": dom["flops"], "algorithmic_tflops": round(algorithmic, 2)}
+                               "flops_counted": "executed on the matrix pipe" + counted,
+                               "algorithmic_flops_per_launch": dom["flops"], "algorithmic_tflops": round(algorithmic, 2),
+                               "algorithmic_frac_of_peak": round(algorithmic / peak, 4)}
         any_stage = next((v for k, v in prof_all.items() if k.startswith("conv:") and v["calls"]), None)
         if any_stage:   # stage breakdown: the separate pass with every stage timed (it runs ~7 % slower than the timed region)
             calls = any_stage["calls"]

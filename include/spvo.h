@@ -365,6 +365,10 @@ int spvo_profile_only(spvo_ctx *ctx, const char *stage);
 int spvo_profile_count(spvo_ctx *ctx);
 int spvo_profile_get(spvo_ctx *ctx, int i, char *name, size_t name_cap, double *total_ms,
                      long long *calls, double *flops_per_call, double *bytes_per_call);
+/* Which kernel family the loaded engine runs a "conv:<op index>" stage on ("conv_wino4_kernel", "conv_wino2_kernel",
+ * "conv_mfma_kernel", "conv_f16_kernel", ...), and how many multiply-adds the matrix pipe executes per multiply-add of the
+ * direct convolution (Winograd F(4x4,3x3): 0.25, F(2x2,3x3): 4/9, split bf16x3 mode: 6, otherwise 1). */
+int spvo_profile_stage_kernel(spvo_ctx *ctx, const char *stage, char *name, size_t name_cap, double *executed_per_algorithmic);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,10 @@
 #include <vector>
 #include "conv_mfma.hip.h"
 
+#ifndef WINO4_ABL
+#define WINO4_ABL 0   // measurement builds only (tools/wino_bench.hip): 1 no input transform, 2 no filter staging, 4 no raw staging, 8 operands read once, 16 no stores
+#endif
+
 namespace spvo {
 
 struct Wino4Tile {
@@ -297,7 +301,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
       constexpr int LEAD = 6;
       f32x4v av[9], bv[12];
 #pragma unroll
-      for (int p = 0; p < LEAD; ++p) {
+      for (int p = 0; p < ((WINO4_ABL & 8) ? 36 : LEAD); ++p) {
+        if ((WINO4_ABL & 8) && k > 0) break;
         if ((p & 3) == 0) av[p >> 2] = ub4[(p >> 2) * 256];
         if (p % 3 == 0) bv[p / 3] = vb4[(p / 3) * 128];
       }
@@ -308,14 +313,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
         if (FIRST) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_op, b_op, f32x4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         else acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_op, b_op, acc[p], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (p == 1 && cu.id < n_tiles) issue_u(cu.t, cu.chunk, u_next);
-        if (p == 4 && cr.id < n_tiles) issue_raw(cr.t, cr.chunk, raw_next2);
+        if (!(WINO4_ABL & 2) && p == 1 && cu.id < n_tiles) issue_u(cu.t, cu.chunk, u_next);
+        if (!(WINO4_ABL & 4) && p == 4 && cr.id < n_tiles) issue_raw(cr.t, cr.chunk, raw_next2);
         const int q = p + LEAD;
-        if (q < 36) {
+        if (!(WINO4_ABL & 8) && q < 36) {
           if ((q & 3) == 0) av[q >> 2] = ub4[(q >> 2) * 256];
           if (q % 3 == 0) bv[q / 3] = vb4[(q / 3) * 128];
         }
-        if (XF && p >= 8 && p < 28 && !(p & 1)) xf_step(raw_next, v_next, (p - 8) >> 1);   // ten steps on every other slot
+        if (!(WINO4_ABL & 1) && XF && p >= 8 && p < 28 && !(p & 1)) xf_step(raw_next, v_next, (p - 8) >> 1);   // ten steps on every other slot
         __builtin_amdgcn_sched_barrier(0);
       }
       advance(cu);
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
             const float v = fmaxf(fmaxf(y[2 * pi][2 * pj], y[2 * pi][2 * pj + 1]), fmaxf(y[2 * pi + 1][2 * pj], y[2 * pi + 1][2 * pj + 1]));
             const int py = (oy >> 1) + pi, px = (ox >> 1) + pj;
             const unsigned vo = (ch_ok && py < (a.H >> 1) && px < (a.W >> 1)) ? 4u * (unsigned)(4 * g4 * oplane + (py + PADY) * a.out_wp + (px + PADX)) : OOB;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, vo, r * oplane * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, (WINO4_ABL & 16) ? OOB : vo, r * oplane * 4, 0);
           }
       } else {
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -372,7 +377,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
             const int yy = oy + i, xx = ox + 2 * hj;
             const unsigned vo = (ch_ok && yy < a.H && xx < a.W) ? 4u * (unsigned)(4 * g4 * oplane + (yy + PADY) * a.out_wp + (xx + PADX)) : OOB;
             const u32x2 v = {__float_as_uint(y[i][2 * hj]), __float_as_uint(y[i][2 * hj + 1])};
-            __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, vo, r * oplane * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, (WINO4_ABL & 16) ? OOB : vo, r * oplane * 4, 0);
           }
       }
       __builtin_amdgcn_sched_barrier(0);

@@ -835,4 +835,27 @@ int spvo_profile_get(spvo_ctx *c, int i, char *name, size_t name_cap, double *to
   return SPVO_OK;
 }
 
+int spvo_profile_stage_kernel(spvo_ctx *c, const char *stage, char *name, size_t name_cap, double *executed_per_algorithmic) {
+  if (!c || !stage) return fail(c, SPVO_ERR_INVALID, "null argument");
+  for (size_t i = 0; i < c->ops.size(); ++i) {
+    const Op &op = c->ops[i];
+    if (op.stage < 0 || op.stage >= (int)c->stages.size() || c->stages[op.stage].name != stage) continue;
+    const char *k = "other";
+    double f = 1.0;
+    if (op.type == OP_CONV) {
+      if (c->int8) k = "conv_i8_kernel";
+      else if (c->fp16) k = "conv_f16_kernel";
+      else if (c->s3) { k = "conv_s3_kernel"; f = 6.0; }
+      else if (op.wino4) { k = "conv_wino4_kernel"; f = 0.25; }
+      else if (op.wino64) { k = "conv_wino64_kernel"; f = 4.0 / 9.0; }
+      else if (op.wino) { k = op.wino2 ? "conv_wino2_kernel" : "conv_wino_kernel"; f = 4.0 / 9.0; }
+      else k = "conv_mfma_kernel";
+    }
+    if (name && name_cap) { std::strncpy(name, k, name_cap - 1); name[name_cap - 1] = 0; }
+    if (executed_per_algorithmic) *executed_per_algorithmic = f;
+    return SPVO_OK;
+  }
+  return fail(c, SPVO_ERR_INVALID, "no layer of the loaded engine is timed under that stage name");
+}
+
 }  // extern "C"

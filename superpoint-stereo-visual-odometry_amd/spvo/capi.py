@@ -60,7 +60,7 @@ SYMBOLS = [
     "spvo_preprocess", "spvo_forward", "spvo_debug_tensor", "spvo_heatmap", "spvo_nms",
     "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_detect_dev_submit", "spvo_detect_wait", "spvo_detect_submit", "spvo_detect_collect", "spvo_match", "spvo_match_slots", "spvo_set_prematch", "spvo_set_match_fp8",
     "spvo_match_hamming", "spvo_orb_detect", "spvo_orb_tables", "spvo_triangulate", "spvo_pnp_ransac", "spvo_pnp_refine", "spvo_solve_stereo_odometry", "spvo_solve_submit", "spvo_solve_wait", "spvo_stream", "spvo_synchronize",
-    "spvo_profile_enable", "spvo_profile_reset", "spvo_profile_only", "spvo_profile_count", "spvo_profile_get",
+    "spvo_profile_enable", "spvo_profile_reset", "spvo_profile_only", "spvo_profile_count", "spvo_profile_get", "spvo_profile_stage_kernel",
     "spvo_comm_unique_id", "spvo_comm_create", "spvo_comm_create_host", "spvo_comm_rank", "spvo_comm_world", "spvo_comm_destroy",
     "spvo_pose_allgather", "spvo_pose_allgather_n",
 ]
@@ -120,6 +120,7 @@ def load() -> C.CDLL:
     lib.spvo_profile_only.argtypes = [vp, C.c_char_p]
     lib.spvo_profile_count.argtypes = [vp]
     lib.spvo_profile_get.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t, dp, C.POINTER(C.c_longlong), dp, dp]
+    lib.spvo_profile_stage_kernel.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_size_t, dp]
     lib.spvo_comm_unique_id.argtypes = [vp]
     lib.spvo_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]
     lib.spvo_comm_create_host.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
@@ -462,6 +463,13 @@ class Context:
             self._check(self.lib.spvo_profile_get(self.h, i, name, 64, C.byref(ms), C.byref(calls), C.byref(fl), C.byref(by)))
             out[name.value.decode()] = dict(total_ms=ms.value, calls=calls.value, flops=fl.value, bytes=by.value)
         return out
+
+    def stage_kernel(self, stage):
+        """(kernel family, executed / algorithmic multiply-adds) of a "conv:<op index>" stage of the loaded engine."""
+        name = C.create_string_buffer(64)
+        f = C.c_double()
+        self._check(self.lib.spvo_profile_stage_kernel(self.h, stage.encode(), name, 64, C.byref(f)))
+        return name.value.decode(), f.value
 
 
 COMM_ID_BYTES = 128

@@ -50,14 +50,16 @@ while i < len(plan.ops):
         alg += 2.0 * 2 * px_in * o.cout * o.cin * o.ksize * o.ksize
         byts += 2 * 4 * (px_in * o.cin + px_out * o.cout) + o.weight.size * 4
     o0 = ops[0]
-    wino = wino_env and o0.type == weights.OP_CONV and o0.ksize == 3 and o0.cin > 1
-    executed = alg * (4.0 / 9.0 if wino else 1.0)
+    kfam, kfactor = ctx.stage_kernel(key) if o0.type == weights.OP_CONV and "heads" not in label else ("", 1.0)   # what the library runs the layer on
+    wino = kfam.startswith("conv_wino")
+    executed = alg * kfactor
     hbm_bound = o0.type == weights.OP_CONV and o0.cin == 1
     row = {"layer": label, "shape": f"{o0.cin}->{sum(o.cout for o in ops if o.type == weights.OP_CONV)} k{o0.ksize} @{H >> plan.tensors[o0.inp][1]}x{Wd >> plan.tensors[o0.inp][1]}",
-           "kernel": "conv_first4_kernel (VALU, HBM-write bound)" if hbm_bound else "conv_wino2_kernel (Winograd F(2x2,3x3), fp32 MFMA)" if wino else
+           "kernel": "conv_first4_kernel (VALU, HBM-write bound)" if hbm_bound else (kfam + (" (Winograd F(4x4,3x3), fp32 MFMA: executes 1/4 of the direct method's multiplies)" if kfactor == 0.25 else " (Winograd F(2x2,3x3), fp32 MFMA: executes 4/9)")) if wino else
                      "heads_fused_kernel (fp32 MFMA)" if "heads" in label else "conv_mfma_kernel (direct, fp32 MFMA)",
            "duration_us": round(us, 2), "algorithmic_gflop": round(alg / 1e9, 3), "executed_gflop": round(executed / 1e9, 3),
            "executed_tflops": round(executed / us / 1e6, 2), "frac_of_fp32_mfma_peak": round(executed / us / 1e6 / PEAK, 4),
+           "algorithmic_tflops": round(alg / us / 1e6, 2), "algorithmic_frac_of_fp32_mfma_peak": round(alg / us / 1e6 / PEAK, 4),
            "algorithmic_MB": round(byts / 1e6, 1), "algorithmic_GBps": round(byts / us / 1e3, 0)}
     if hbm_bound:
         row["bound"] = "hbm"; row["frac_of_hbm_peak"] = round(byts / us / 1e3 / HBM, 4)
@@ -68,7 +70,8 @@ res = {"_how": f"tools/layer_roofline_json.py on one MI355X: VGG SuperPoint fp32
                "bracketed by HIP events (spvo_profile_*); layers run back to back, nothing else on the chip",
        "peak_fp32_mfma_tflops": PEAK, "layers": rows,
        "conv_stack": {"sum_of_layers_us": round(tot_us, 1), "algorithmic_gflop": round(tot_alg / 1e9, 2), "executed_gflop": round(tot_exec / 1e9, 2),
-                      "executed_tflops": round(tot_exec / tot_us / 1e6, 2), "frac_of_fp32_mfma_peak": round(tot_exec / tot_us / 1e6 / PEAK, 4)},
+                      "executed_tflops": round(tot_exec / tot_us / 1e6, 2), "frac_of_fp32_mfma_peak": round(tot_exec / tot_us / 1e6 / PEAK, 4),
+                      "algorithmic_tflops": round(tot_alg / tot_us / 1e6, 2), "algorithmic_frac_of_fp32_mfma_peak": round(tot_alg / tot_us / 1e6 / PEAK, 4)},
        "forward_pass_us": round(prof["net"]["total_ms"] / prof["net"]["calls"] * 1e3, 1)}
 json.dump(res, open(out_path, "w"), indent=1)
 print(json.dumps(res, indent=1))

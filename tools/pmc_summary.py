@@ -29,7 +29,7 @@ def pick(acc, key):
 
 
 res = {"_how": "tools/collect_profiles_r03.sh on one MI355X: rocprofv3 --kernel-trace --pmc <group> --output-format csv, one group per pass, stand-alone "
-               "binaries tools/wino_bench2 360 1176 64 64 1 (conv1b, both images), tools/match_bench 1000 2 (two 1000 x 1000 jobs), tools/copy_bench 1024",
+               "binaries tools/wino_bench4 360 1176 64 64 1 (conv1b, both images, Winograd F(4x4,3x3)), tools/match_bench 1000 2 (two 1000 x 1000 jobs), tools/copy_bench 1024",
        "_units": "FETCH_SIZE / WRITE_SIZE in KB; SQ_* wave counters in quad-cycles summed over waves; SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over SIMDs; "
                  "GRBM_GUI_ACTIVE summed over the 8 XCDs"}
 # ---- calibration: known-traffic copy kernel in the same session
@@ -53,14 +53,15 @@ if kd:
 # ---- kernels
 H, W = 360, 1176
 NT = 8   # column tiles of 128 train rows at 1000 x 1000
-alg = {"conv_wino2_kernel<true, true": 2 * (64 * H * W * 4 + 64 * (H // 2) * (W // 2) * 4) + 16 * 64 * 64 * 4,    # input + pooled output planes + transformed filters
+alg = {"conv_wino4_kernel<true, true": 2 * (64 * H * W * 4 + 64 * (H // 2) * (W // 2) * 4) + 36 * 64 * 64 * 4,    # input + pooled output planes + transformed filters
        "match_gemm_kernel<false, false>": 2 * (2 * 1000 * 256 * 4 + 1000 * 1000 * 4),                             # unfused form, two jobs: both descriptor sets + the distance matrix
        "match_rerank_kernel": 2 * (1000 * 1000 * 4 + 1000 * 8),
        "match_gemm_kernel<false, true>": 2 * (2 * 1000 * 256 * 4 + 1000 * NT * (16 + 3 * 8)),                     # fused form: descriptor sets + per (row, tile) 16 bytes of bounds and ~3 entries
        "match_merge_kernel": 2 * (1000 * NT * (16 + 3 * 8) + 1000 * (1 + 3) * 1024 + 1000 * 8)}                   # the lists, the query row + ~3 candidate rows, the result
-flops = {"conv_wino2_kernel<true, true": 2.0 * 2 * H * W * 64 * 64 * 9 * 4 / 9, "match_gemm_kernel<false, false>": 2 * 2.0 * 1000 * 1000 * 256,
+flops = {"conv_wino4_kernel<true, true": 2.0 * 2 * H * W * 64 * 64 * 9 / 4,   # executed on the matrix pipe: 1/4 of the direct convolution's
+         "match_gemm_kernel<false, false>": 2 * 2.0 * 1000 * 1000 * 256,
          "match_gemm_kernel<false, true>": 2 * 2.0 * 1000 * 1000 * 256}
-for prog, keys in (("wino", ["conv_wino2_kernel<true, true"]), ("match", ["match_gemm_kernel<false, false>", "match_rerank_kernel", "match_gemm_kernel<false, true>", "match_merge_kernel"])):
+for prog, keys in (("wino", ["conv_wino4_kernel<true, true"]), ("match", ["match_gemm_kernel<false, false>", "match_rerank_kernel", "match_gemm_kernel<false, true>", "match_merge_kernel"])):
     f, _ = counters("pmc_fetch_" + prog); w, _ = counters("pmc_write_" + prog)
     s1, d1 = counters("pmc_sq_" + prog); s2, _ = counters("pmc_sq2_" + prog)
     for key in keys:
@@ -70,7 +71,7 @@ for prog, keys in (("wino", ["conv_wino2_kernel<true, true"]), ("match", ["match
         e = {"kernel": k[:120]}
         fk, wk = mean(f[k]["FETCH_SIZE"]), mean(w[pick(w, key)]["WRITE_SIZE"])
         e["FETCH_SIZE_KB"], e["WRITE_SIZE_KB"] = round(fk, 1), round(wk, 1)
-        fc = fcorr_dma if key.startswith("conv_wino2") else fcorr
+        fc = fcorr_dma if key.startswith("conv_wino") else fcorr
         e["fetch_correction"] = round(fc, 3)
         e["traffic_bytes_per_launch"] = int((fc * fk + wk) * 1024)
         e["algorithmic_bytes_per_launch"] = alg[key]
