@@ -20,7 +20,9 @@
 //   * workgroup tile = 64 output channels x 32 Winograd tiles (4 x 8 tiles = 16 rows x 32 columns of output); wave (cq, tb) owns
 //     16 channels x 16 tiles x all 36 positions on v_mfma_f32_16x16x4_f32: 144 accumulator registers;
 //   * item = (tile, chunk of FOUR input channels): one matrix instruction per position and item; filters U [pos/4 9][cq 4]
-//     [lane 64][4] and transformed input V [(i, j/3) 12][tb 2][lane 64][4 (j % 3, one pad)] in LDS, both read by ds_read_b128;
+//     [lane 64][4] and transformed input V [h 2][q/4 5][tb 2][lane 64][4] in LDS, both read by ds_read_b128 (nine + ten reads per item).
+//     The matrix instructions run in the order p' = 18 h + 3 i + c of the positions (i, j = 3 h + c): the half h of the columns
+//     that one transforming thread produces is contiguous, so its eighteen stores carry compile-time offsets;
 //   * the input transform of an item is 128 patches of 6 x 6: TWO threads per patch, rows {0,1,2} / {3,4,5} for the row pass,
 //     nine v_permlane32_swap exchanges, columns {0,1,2} / {3,4,5} for the column pass (the partner sits 32 lanes away, so the
 //     swap leaves "rows 0-2" and "rows 3-5" in the same registers of both halves: no selects); the four waves 0-3 do it in even
@@ -43,13 +45,14 @@ struct Wino4Tile {
   static constexpr int CK = 4, TH = 16, TW = 32, LW = TW + 8, LH = TH + 2, NT = 32;
   static constexpr int IN_FLOATS = CK * LH * LW;        // 2880: raw halo tile of one chunk, row = x0-4 .. x0+35
   static constexpr int U_FLOATS = 36 * CK * CO_TILE;    // 9216: one filter slab
-  static constexpr int V_FLOATS = 12 * 2 * 64 * 4;      // 6144: transformed input of one chunk, (i, j / 3) pieces of 3 + 1 pad
+  static constexpr int V_FLOATS = 10 * 2 * 64 * 4;      // 5120: transformed input of one chunk, per column half 18 positions in 5 pieces of four
   static constexpr int RAW_OFF = 0, U_OFF = 2 * IN_FLOATS, V_OFF = U_OFF + 2 * U_FLOATS;
-  static constexpr int LDS_BYTES = (V_OFF + 2 * V_FLOATS) * 4 + 16;   // 145 936 (+ the slot through which a tile's successor is published)
+  static constexpr int LDS_BYTES = (V_OFF + 2 * V_FLOATS) * 4 + 16;   // 137 744 (+ the slot through which a tile's successor is published)
 };
 
-// OIHW weights + bias -> slabs [co_tile][chunk][pos/4 9][cq 4][lane 64][4] of U = G g G^T (double), then [co_tiles * 64] biases.
-// pos = 6 i + j; lane = 16 (ci & 3) + (co & 15): the A operand of v_mfma_f32_16x16x4_f32 (row co & 15, k = ci).
+// OIHW weights + bias -> slabs [co_tile][chunk][p'/4 9][cq 4][lane 64][4] of U = G g G^T (double), then [co_tiles * 64] biases.
+// p' = 18 (j / 3) + 3 i + j % 3 (the kernel's instruction order); lane = 16 (ci & 3) + (co & 15): the A operand of
+// v_mfma_f32_16x16x4_f32 (row co & 15, k = ci).
 inline std::vector<float> pack_conv_weights_wino4(const float *w, const float *bias, int cout, int cin) {
   constexpr int CK = Wino4Tile::CK;
   const int co_tiles = (cout + CO_TILE - 1) / CO_TILE, nch = cin / CK;
@@ -70,7 +73,7 @@ inline std::vector<float> pack_conv_weights_wino4(const float *w, const float *b
         const int lane = 16 * (ci % CK) + (o & 15), cq = o >> 4;
         for (int a = 0; a < 6; ++a)
           for (int b = 0; b < 6; ++b) {
-            const int pos = 6 * a + b;
+            const int pos = 18 * (b / 3) + 3 * a + b % 3;
             slab[(((pos >> 2) * 4 + cq) * 64 + lane) * 4 + (pos & 3)] = (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
           }
       }
@@ -163,23 +166,22 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
   const int x_ci = wave & 3, x_tile = lane & 31, x_h = lane >> 5;
   const int x_trow = x_tile >> 3, x_tcol = x_tile & 7;
   const int raw_off = x_ci * (LH * LW) + (4 * x_trow + 3 * x_h) * LW + 4 * x_tcol + 3;   // LDS row 0 = output row y0 - 1, LDS column 4 = output column x0
-  // V[(i, jh)][tb][lane = 16 ci + (tile & 15)][jj]: this thread writes (i = 0..5, jh = h, jj = 0..2)
-  const int v_off = (x_h * 2 + (x_tile >> 4)) * 256 + (16 * x_ci + (x_tile & 15)) * 4;   // + i * 1024 floats
-  // Steps of one patch half: 0..2 read row r (b32, b64, b64, b32 = columns 3 .. 8 of the halo row), 3..5 row pass of row r,
+  // V[h][q / 4][tb][lane = 16 ci + (tile & 15)][q & 3], q = 3 i + c: this thread writes (h, i = 0..5, c = 0..2)
+  const int v_off = x_h * 2560 + (x_tile >> 4) * 256 + (16 * x_ci + (x_tile & 15)) * 4;   // + (q >> 2) * 512 + (q & 3) floats
+  // Steps of one patch half: 0..2 read row r (b32, b128, b32 = columns 3, 4 .. 7, 8 of the halo row), 3..5 row pass of row r,
   // 6 the exchange, 7..9 column pass of column c + stores
   float xr[3][6];        // rows after the row pass; xr[r][0..2] stay, xr[r][3..5] are swapped with the partner's
-  f32x2 xa[3][2];
+  f32x4v xa[3];
   float xs0[3], xs1[3];
   auto xf_step = [&](const float *raw, float *vb, int st) {
     if (st < 3) {
       const float *d = raw + raw_off + st * LW;
       xs0[st] = d[0];
-      xa[st][0] = *reinterpret_cast<const f32x2 *>(d + 1);
-      xa[st][1] = *reinterpret_cast<const f32x2 *>(d + 3);
+      xa[st] = *reinterpret_cast<const f32x4v *>(d + 1);
       xs1[st] = d[5];
     } else if (st < 6) {
       const int r = st - 3;
-      wino4_in6(xs0[r], xa[r][0][0], xa[r][0][1], xa[r][1][0], xa[r][1][1], xs1[r], xr[r]);
+      wino4_in6(xs0[r], xa[r][0], xa[r][1], xa[r][2], xa[r][3], xs1[r], xr[r]);
     } else if (st == 6) {
       // h = 0 keeps columns 0-2 and needs the partner's rows 3-5 of them; h = 1 keeps columns 3-5 and needs rows 0-2.  One swap per
       // value: v0 = the value in column c, v1 = the value in column c + 3; lanes 32-63 of v0 <-> lanes 0-31 of v1.  Afterwards, in
@@ -198,12 +200,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
       float o[6];
       wino4_in6(xr[0][c], xr[1][c], xr[2][c], xr[0][c + 3], xr[1][c + 3], xr[2][c + 3], o);
 #pragma unroll
-      for (int i = 0; i < 6; ++i) vb[v_off + i * 1024 + c] = o[i];
+      for (int i = 0; i < 6; ++i) vb[v_off + ((3 * i + c) >> 2) * 512 + ((3 * i + c) & 3)] = o[i];
     }
   };
 
   const int a_lane = cq * 64 + lane;   // 16-byte pieces in a filter slab: + (pos / 4) * 256
-  const int b_lane = tb * 64 + lane;   // 16-byte pieces in a V buffer:     + (2 i + j / 3) * 128
+  const int b_lane = tb * 64 + lane;   // 16-byte pieces in a V buffer:     + (5 h + q / 4) * 128
 
   // ---- tile assignment: conv_wino2.hip.h's XCD-banded counters (a.sched), or blockIdx.x + k gridDim.x
   const int band = blockIdx.x & 7;
@@ -296,29 +298,30 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
       float *v_next = smem + T::V_OFF + ((k + 1) & 1) * T::V_FLOATS;
       const f32x4v *ub4 = reinterpret_cast<const f32x4v *>(ub) + a_lane;
       const f32x4v *vb4 = reinterpret_cast<const f32x4v *>(vb) + b_lane;
-      // 36 matrix instructions, one per position; operands: A piece pos / 4 (9 reads), B piece 2 i + j / 3 (12 reads), each read
-      // LEAD instructions before its first use
+      // 36 matrix instructions in the order p' = 18 h + q (q = 3 i + c; position 6 i + 3 h + c); operands: A piece p' / 4 (9 reads),
+      // B piece 5 h + q / 4 (10 reads), each read LEAD instructions before its first use
       constexpr int LEAD = 6;
-      f32x4v av[9], bv[12];
+      f32x4v av[9], bv[10];
+      auto b_piece = [](int p) { return 5 * (p / 18) + ((p % 18) >> 2); };
 #pragma unroll
       for (int p = 0; p < ((WINO4_ABL & 8) ? 36 : LEAD); ++p) {
         if ((WINO4_ABL & 8) && k > 0) break;
         if ((p & 3) == 0) av[p >> 2] = ub4[(p >> 2) * 256];
-        if (p % 3 == 0) bv[p / 3] = vb4[(p / 3) * 128];
+        if (p == 0 || b_piece(p) != b_piece(p - 1)) bv[b_piece(p)] = vb4[b_piece(p) * 128];
       }
 #pragma unroll
       for (int p = 0; p < 36; ++p) {
-        const int i = p / 6, j = p % 6;
-        const float a_op = av[p >> 2][p & 3], b_op = bv[2 * i + j / 3][j % 3];
-        if (FIRST) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_op, b_op, f32x4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        else acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_op, b_op, acc[p], 0, 0, 0);
+        const int ph = p / 18, pq = p % 18, pos = 6 * (pq / 3) + 3 * ph + pq % 3;
+        const float a_op = av[p >> 2][p & 3], b_op = bv[b_piece(p)][pq & 3];
+        if (FIRST) acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_op, b_op, f32x4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        else acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_op, b_op, acc[pos], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (!(WINO4_ABL & 2) && p == 1 && cu.id < n_tiles) issue_u(cu.t, cu.chunk, u_next);
         if (!(WINO4_ABL & 4) && p == 4 && cr.id < n_tiles) issue_raw(cr.t, cr.chunk, raw_next2);
         const int q = p + LEAD;
         if (!(WINO4_ABL & 8) && q < 36) {
           if ((q & 3) == 0) av[q >> 2] = ub4[(q >> 2) * 256];
-          if (q % 3 == 0) bv[q / 3] = vb4[(q / 3) * 128];
+          if (b_piece(q) != b_piece(q - 1)) bv[b_piece(q)] = vb4[b_piece(q) * 128];
         }
         if (!(WINO4_ABL & 1) && XF && p >= 8 && p < 28 && !(p & 1)) xf_step(raw_next, v_next, (p - 8) >> 1);   // ten steps on every other slot
         __builtin_amdgcn_sched_barrier(0);
