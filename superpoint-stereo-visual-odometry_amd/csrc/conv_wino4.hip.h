@@ -99,8 +99,9 @@ __device__ __forceinline__ void wino4_out4(const float m0, const float m1, const
   y[3] = fmaf(8.f, d, b) + m5;
 }
 
-template <bool POOL, bool RELU, int TAG = 0>
+template <bool POOL, bool RELU, int TAG = 0, bool ODD = false>   // ODD: H or W odd (no pooling then): outputs leave one by one
 __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
+  static_assert(!(POOL && ODD), "2x2 pooling needs even H and W");
   using T = Wino4Tile;
   constexpr int CK = T::CK, LW = T::LW, LH = T::LH, LW4 = LW / 4;
   constexpr int IN_V4 = T::IN_FLOATS / 4;        // 720 16-byte pieces per raw tile
@@ -370,6 +371,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
             const int py = (oy >> 1) + pi, px = (ox >> 1) + pj;
             const unsigned vo = (ch_ok && py < (a.H >> 1) && px < (a.W >> 1)) ? 4u * (unsigned)(4 * g4 * oplane + (py + PADY) * a.out_wp + (px + PADX)) : OOB;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, (WINO4_ABL & 16) ? OOB : vo, r * oplane * 4, 0);
+          }
+      } else if constexpr (ODD) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int yy = oy + i, xx = ox + jj;
+            const unsigned vo = (ch_ok && yy < a.H && xx < a.W) ? 4u * (unsigned)(4 * g4 * oplane + (yy + PADY) * a.out_wp + (xx + PADX)) : OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[i][jj]), rsrc, (WINO4_ABL & 16) ? OOB : vo, r * oplane * 4, 0);
           }
       } else {
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));

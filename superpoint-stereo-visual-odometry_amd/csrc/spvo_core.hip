@@ -674,9 +674,11 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
         const bool narrow_on = !(std::getenv("SPVO_WINO_NARROW") && std::atoi(std::getenv("SPVO_WINO_NARROW")) == 0);
         if (eligible && !op.wino && op.wino2 && narrow_on && (op.cout % 32) == 0 && 2 * wtiles >= min_tiles) op.wino = op.wino_narrow = true;
       }
-      // F(4x4,3x3) (conv_wino4.hip.h): 36 multiplies per 4x4 outputs instead of F(2x2)'s 64 -- for the Winograd layers with even H
-      // and W (its stores go out in column pairs) and enough 16 x 32 tiles to fill the chip.  SPVO_WINO4=0 keeps F(2x2).
-      if (op.wino && !op.wino_narrow && op.wino2 && (op.cin % Wino4Tile::CK) == 0 && ((ti.H | ti.W) & 1) == 0 &&
+      // F(4x4,3x3) (conv_wino4.hip.h): 36 multiplies per 4x4 outputs instead of F(2x2)'s 64 -- for the Winograd layers with enough
+      // 16 x 32 tiles to fill the chip (odd H or W: its stores go out one by one instead of in column pairs; SPVO_WINO4_ODD=0 keeps
+      // those layers on F(2x2)).  SPVO_WINO4=0 keeps F(2x2) everywhere.
+      if (op.wino && !op.wino_narrow && op.wino2 && (op.cin % Wino4Tile::CK) == 0 &&
+          (((ti.H | ti.W) & 1) == 0 || (!pool && !(std::getenv("SPVO_WINO4_ODD") && std::atoi(std::getenv("SPVO_WINO4_ODD")) == 0))) &&
           !(std::getenv("SPVO_WINO4") && std::atoi(std::getenv("SPVO_WINO4")) == 0)) {
         const long t4 = (long)((ti.W + Wino4Tile::TW - 1) / Wino4Tile::TW) * ((ti.H + Wino4Tile::TH - 1) / Wino4Tile::TH) * op.co_tiles * c->cfg.max_batch;
         const long min4 = std::getenv("SPVO_WINO4_MIN_TILES") ? std::atol(std::getenv("SPVO_WINO4_MIN_TILES")) : 3 * c->num_cus / 4;
