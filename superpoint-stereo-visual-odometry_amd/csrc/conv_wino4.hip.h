@@ -348,6 +348,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
     const int trow = 2 * tb + (c16 >> 3), tcol = c16 & 7;
     auto relu = [](float v) { return RELU ? __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()) : v; };
     const int oy = cur.y0 + 4 * trow, ox = cur.x0 + 4 * tcol;                  // first output pixel of this lane's tile
+    const bool w4 = (a.W & 3) == 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float bias_v = bias_p[r < kmax ? r : 0];
@@ -363,15 +364,31 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
       }
       const bool ch_ok = r < kmax;
       if constexpr (POOL) {
+        float pv[2][2];
 #pragma unroll
         for (int pi = 0; pi < 2; ++pi)
 #pragma unroll
-          for (int pj = 0; pj < 2; ++pj) {
-            const float v = fmaxf(fmaxf(y[2 * pi][2 * pj], y[2 * pi][2 * pj + 1]), fmaxf(y[2 * pi + 1][2 * pj], y[2 * pi + 1][2 * pj + 1]));
-            const int py = (oy >> 1) + pi, px = (ox >> 1) + pj;
+          for (int pj = 0; pj < 2; ++pj)
+            pv[pi][pj] = fmaxf(fmaxf(y[2 * pi][2 * pj], y[2 * pi][2 * pj + 1]), fmaxf(y[2 * pi + 1][2 * pj], y[2 * pi + 1][2 * pj + 1]));
+        if (w4) {   // W a multiple of 4: a tile's two pooled columns are inside or outside together -- one 8-byte store per pooled row
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+          for (int pi = 0; pi < 2; ++pi) {
+            const int py = (oy >> 1) + pi, px = ox >> 1;
             const unsigned vo = (ch_ok && py < (a.H >> 1) && px < (a.W >> 1)) ? 4u * (unsigned)(4 * g4 * oplane + (py + PADY) * a.out_wp + (px + PADX)) : OOB;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, (WINO4_ABL & 16) ? OOB : vo, r * oplane * 4, 0);
+            const u32x2 v = {__float_as_uint(pv[pi][0]), __float_as_uint(pv[pi][1])};
+            __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, (WINO4_ABL & 16) ? OOB : vo, r * oplane * 4, 0);
           }
+        } else {
+#pragma unroll
+          for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+            for (int pj = 0; pj < 2; ++pj) {
+              const int py = (oy >> 1) + pi, px = (ox >> 1) + pj;
+              const unsigned vo = (ch_ok && py < (a.H >> 1) && px < (a.W >> 1)) ? 4u * (unsigned)(4 * g4 * oplane + (py + PADY) * a.out_wp + (px + PADX)) : OOB;
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pv[pi][pj]), rsrc, (WINO4_ABL & 16) ? OOB : vo, r * oplane * 4, 0);
+            }
+        }
       } else if constexpr (ODD) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -381,6 +398,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
             const unsigned vo = (ch_ok && yy < a.H && xx < a.W) ? 4u * (unsigned)(4 * g4 * oplane + (yy + PADY) * a.out_wp + (xx + PADX)) : OOB;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[i][jj]), rsrc, (WINO4_ABL & 16) ? OOB : vo, r * oplane * 4, 0);
           }
+      } else if (w4) {   // W a multiple of 4: a tile's four columns are inside or outside together -- one 16-byte store per row
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int yy = oy + i;
+          const unsigned vo = (ch_ok && yy < a.H && ox < a.W) ? 4u * (unsigned)(4 * g4 * oplane + (yy + PADY) * a.out_wp + (ox + PADX)) : OOB;
+          const u32x4 v = {__float_as_uint(y[i][0]), __float_as_uint(y[i][1]), __float_as_uint(y[i][2]), __float_as_uint(y[i][3])};
+          __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (WINO4_ABL & 16) ? OOB : vo, r * oplane * 4, 0);
+        }
       } else {
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
