@@ -18,6 +18,10 @@
 #include <vector>
 #include "conv_mfma.hip.h"
 
+#ifndef HEADS_ABL
+#define HEADS_ABL 0   // measurement builds only (tools/heads_bench.hip): 1 no epilogue, 2 weights read once, 4 no activation staging, 8 no B-operand reads
+#endif
+
 namespace spvo {
 
 struct HeadsArgs {
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void heads_fused_kernel(const HeadsArgs a) 
   for (int b = 0; b < 3; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-  f32x4v a_cur[3], a_nxt[3];
+  f32x4v a_cur[3], a_nxt[3];   // (two groups in flight instead of one: measured, no change)
 #pragma unroll
   for (int b = 0; b < 3; ++b) a_cur[b] = wp4[((b < nb ? b : 0) * 32 + 0) * 64];
   load_chunk(0);
@@ -102,18 +106,18 @@ __global__ __launch_bounds__(256, 2) void heads_fused_kernel(const HeadsArgs a) 
   __syncthreads();
 #pragma unroll 1
   for (int c = 0; c < HEADS_CIN / HEADS_CK; ++c) {
-    if (c + 1 < HEADS_CIN / HEADS_CK) load_chunk(c + 1);
+    if (!(HEADS_ABL & 4) && c + 1 < HEADS_CIN / HEADS_CK) load_chunk(c + 1);
     const float *xb = sx + (c & 1) * (2 * HEADS_CK * HEADS_PX) + head * (HEADS_CK * HEADS_PX) + half * HEADS_PX + j;   // k-step s: + 2 s * 32
 #pragma unroll
     for (int s4 = 0; s4 < 8; ++s4) {
       const int g = 8 * c + s4 + 1;                            // next group of four k-steps
-      if (g < 32) {
+      if (!(HEADS_ABL & 2) && g < 32) {
 #pragma unroll
         for (int b = 0; b < 3; ++b) a_nxt[b] = wp4[((b < nb ? b : 0) * 32 + g) * 64];
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float bv = xb[(2 * (4 * s4 + e)) * HEADS_PX];
+        const float bv = (HEADS_ABL & 8) ? xb[0] : xb[(2 * (4 * s4 + e)) * HEADS_PX];
 #pragma unroll
         for (int b = 0; b < 3; ++b)
           if (b < nb) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[b][e], bv, acc[b], 0, 0, 0);
@@ -121,12 +125,21 @@ __global__ __launch_bounds__(256, 2) void heads_fused_kernel(const HeadsArgs a) 
 #pragma unroll
       for (int b = 0; b < 3; ++b) a_cur[b] = a_nxt[b];
     }
-    if (c + 1 < HEADS_CIN / HEADS_CK) {
+    if (!(HEADS_ABL & 4) && c + 1 < HEADS_CIN / HEADS_CK) {
       store_chunk((c + 1) & 1);   // (the other buffer: its readers passed the barrier at the end of chunk c - 1)
       __syncthreads();
     }
   }
 
+  if (HEADS_ABL & 1) {
+    float t = 0.f;
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += acc[b][r];
+    if (t == 12345.f) a.desc[0] = t;
+    return;
+  }
   // ---- epilogue.  Register r of a block: output channel (r & 3) + 8 (r >> 2) + 4 half, lane j: pixel x0 + j
   const float *bias = a.wpack + (size_t)HEADS_BLOCKS * 32 * 64 * 4 + 32 * b0;
   const bool px_ok = x0 + j < a.W;
