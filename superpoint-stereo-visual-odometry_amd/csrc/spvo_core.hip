@@ -189,7 +189,8 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
   if (const char *e = std::getenv("SPVO_FP32_SPLIT")) c->split_req = std::atoi(e) != 0;
   for (int r = 0; r < RING; ++r)
     if (hipEventCreateWithFlags(&c->ev_net[r], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_tail[r], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_feat[r], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_copy[r], hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_feat[r], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_copy[r], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_pre[r], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_res[r], hipEventDisableTiming) != hipSuccess) {
       spvo_destroy(c);
       return fail(nullptr, SPVO_ERR_DEVICE, "cannot create events on device %d", cfg->device);
     }
@@ -285,7 +286,7 @@ void spvo_destroy(spvo_ctx *c) {
     if (c->d_resized_r[r]) (void)hipFree(c->d_resized_r[r]);
     if (c->h_resized_r[r]) (void)hipHostFree(c->h_resized_r[r]);
     if (c->h_desc_r[r]) (void)hipHostFree(c->h_desc_r[r]);
-    for (hipEvent_t e : {c->ev_net[r], c->ev_tail[r], c->ev_feat[r], c->ev_copy[r]}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {c->ev_net[r], c->ev_tail[r], c->ev_feat[r], c->ev_copy[r], c->ev_pre[r], c->ev_res[r]}) if (e) (void)hipEventDestroy(e);
   }
   for (int i = 0; i < N_SLOTS; ++i) {
     void *q[] = {c->slots[i].d_xy, c->slots[i].d_xyf, c->slots[i].d_desc, c->slots[i].d_n, c->slots[i].d_sqn};

@@ -372,9 +372,9 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   for (auto &mc : c->mcache[ring]) mc.valid = false;
   if (host_l) {   // pageable -> pinned (host copy), pinned -> device (DMA on the network stream): the caller's buffers are free on return
     const size_t bytes = (size_t)(rows - 1) * stride + cols;   // what is the caller's of a strided view: not the last row's padding
-    std::memcpy(c->h_img_r[ring], host_l, bytes);
-    std::memcpy(c->h_img_r[ring] + c->img_cap_r, host_r, bytes);
+    std::memcpy(c->h_img_r[ring], host_l, bytes);   // (the left image is on its way while the right one is staged)
     HIP_TRY(c, hipMemcpyAsync(c->d_img_r[ring], c->h_img_r[ring], bytes, hipMemcpyHostToDevice, c->stream));
+    std::memcpy(c->h_img_r[ring] + c->img_cap_r, host_r, bytes);
     HIP_TRY(c, hipMemcpyAsync(c->d_img_r[ring] + c->img_cap_r, c->h_img_r[ring] + c->img_cap_r, bytes, hipMemcpyHostToDevice, c->stream));
     srcs[0] = c->d_img_r[ring];
     srcs[1] = c->d_img_r[ring] + c->img_cap_r;
@@ -427,6 +427,16 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
     int rc = launch_preprocess(c, srcs[0], srcs[1], 2, rows, cols, stride, g, 0, (extras & 1) ? c->d_resized_r[ring] : nullptr);
     if (rc) return rc;
   }
+  // The resized images (what nn.cpp:154 pushes to images_dq) are final here: they leave on stream_c now, under the network,
+  // instead of behind the matches at the end of the tail (0.85 MB = ~30 us of a synchronous frame).  SPVO_EARLY_RESIZED=0: as before.
+  static const bool early_res_on = !(std::getenv("SPVO_EARLY_RESIZED") && std::atoi(std::getenv("SPVO_EARLY_RESIZED")) == 0);
+  const bool early_res = (extras & 1) && early_res_on;
+  if (early_res) {
+    HIP_TRY(c, hipEventRecord(c->ev_pre[ring], c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream_c, c->ev_pre[ring], 0));
+    HIP_TRY(c, hipMemcpyAsync(c->h_resized_r[ring], c->d_resized_r[ring], (size_t)2 * c->H * c->W, hipMemcpyDeviceToHost, c->stream_c));
+    HIP_TRY(c, hipEventRecord(c->ev_res[ring], c->stream_c));
+  }
   int rc;
   {
     ScopedStage net(c, stage_id(c, "net"));
@@ -455,14 +465,14 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
     rc = launch_nms_rounds(c, 2, np, ring, NMS_FIRST, c->d_counters_all + (size_t)(((ring + 1) % RING) * 2) * NMS_COUNTER_INTS);
   }
   if (!rc) rc = enqueue_sample(c, slots, np, ring);
-  // Keypoints, counts and descriptors are final here: spvo_detect_wait / _collect waits for THIS point; the matches enqueued behind
-  // it are waited for where they are asked for (spvo_match_slots, ev_tail).  The bulk copies a host-image submission asked for go
-  // out on a stream of their own BESIDE the matches -- 2.8 MB over PCIe are ~110 us the matches need not queue behind.
-  // Submissions WITHOUT bulk copies (device images: the pipelined path) record ev_feat here, in front of the matches.  A host-image
-  // submission (extras != 0) keeps everything on the tail stream behind the matches and one event, as before round 3: its copies on
-  // a stream of their own beside the matches measured SLOWER on one box (synchronous 627-682 against 691 frames/s, look-ahead 923
-  // against 1045; SPVO_TAIL_SPLIT=2 selects that arrangement, = 0 the single event for every submission).
-  static const int split_mode = std::getenv("SPVO_TAIL_SPLIT") ? std::atoi(std::getenv("SPVO_TAIL_SPLIT")) : 1;
+  // Keypoints, counts and descriptors are final here: spvo_detect_wait / _collect waits for THIS point (ev_feat); the matches enqueued
+  // behind it are waited for where they are asked for (spvo_match_slots, ev_tail).  The descriptors a host-image submission
+  // (extras != 0) takes back go out on a stream of their own BESIDE the matches -- 2 MB over PCIe are ~60 us the matches need not
+  // queue behind (synchronous host path 777 -> 787 frames/s, look-ahead 1183 -> 1206-1240 on one box; the same arrangement had
+  // measured slower while the resized images still travelled with them).  SPVO_TAIL_SPLIT=1: only device-image submissions
+  // record ev_feat in front of the matches, host-image submissions keep copies and matches on the tail stream; = 0: one event
+  // behind everything for every submission.
+  static const int split_mode = std::getenv("SPVO_TAIL_SPLIT") ? std::atoi(std::getenv("SPVO_TAIL_SPLIT")) : 2;
   const bool tail_split = split_mode == 2 || (split_mode == 1 && !extras);
   hipStream_t cs = tail_split ? c->stream_c : c->stream_t;
   if (tail_split) {
@@ -472,7 +482,7 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
     rc = enqueue_prematch(c, slot_l, slot_r, prev_l, ring);
   }
   if (!rc && extras) {
-    if (!rc && (extras & 1))   // resized images (what nn.cpp:154 pushes to images_dq) -> the set's pinned mirror
+    if (!rc && (extras & 1) && !early_res)   // resized images -> the set's pinned mirror (unless they left behind the preprocess kernel)
       rc = hipMemcpyAsync(c->h_resized_r[ring], c->d_resized_r[ring], (size_t)2 * c->H * c->W, hipMemcpyDeviceToHost, cs) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipMemcpyAsync failed");
     if (!rc && (extras & 2)) {   // descriptors of both images: whole slots (the counts are not known on the host yet; rows >= n are stale)
       const size_t per = (size_t)c->cfg.max_keypoints * 256;
@@ -499,7 +509,7 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   PendingDetect pd;
   pd.g = CropGeomS{g.row_off, g.col_off, g.crop_rows, g.crop_cols, g.scale};
   pd.rows = rows; pd.cols = cols;
-  pd.slot_l = slot_l; pd.slot_r = slot_r; pd.prev_l = prev_l; pd.ring = ring; pd.extras = extras;
+  pd.slot_l = slot_l; pd.slot_r = slot_r; pd.prev_l = prev_l; pd.ring = ring; pd.extras = extras; pd.early_res = early_res;
   c->pendq.push_back(pd);
   return SPVO_OK;
 }
@@ -546,6 +556,7 @@ static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_feature
     if (!rc && pd.extras) rc = wait_event(c->ev_copy[pd.ring]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");
     g_diag.max_tail_wait = std::max(g_diag.max_tail_wait, diag_now_us() - tw0);
   }
+  if (!rc && pd.early_res) rc = wait_event(c->ev_res[pd.ring]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");   // long done: it left under the network
   bool redone = false;
   const NmsPair np = nms_pair(c, pd.ring);
   if (!rc) rc = nms_settle(c, 2, np, pd.ring, &redone);

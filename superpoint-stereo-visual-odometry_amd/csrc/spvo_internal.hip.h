@@ -129,6 +129,7 @@ struct PendingDetect {           // one spvo_detect*_submit in flight
   int rows = 0, cols = 0, slot_l = 0, slot_r = 0, prev_l = -1, ring = 0;
   bool rematch = false;          // the temporal partner's keypoints were redone after this submission matched against them
   int extras = 0;                // spvo_detect_submit: bit 0 resized images, bit 1 descriptors travel to the set's pinned mirrors
+  bool early_res = false;        // the resized images left on stream_c right behind the preprocess kernel (ev_res), under the network
 };
 
 
@@ -205,6 +206,7 @@ struct spvo_ctx {
   // a submission's tail in two parts: ev_feat = keypoints, counts and descriptors are final (what spvo_detect_wait needs), ev_tail = the
   // matches enqueued behind them have landed too (what spvo_match_slots needs); ev_copy = the bulk copies on stream_c
   hipEvent_t ev_feat[RING] = {nullptr, nullptr, nullptr, nullptr}, ev_copy[RING] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_pre[RING] = {nullptr, nullptr, nullptr, nullptr}, ev_res[RING] = {nullptr, nullptr, nullptr, nullptr};   // preprocess done (network stream) / resized images on the host (stream_c)
   hipEvent_t ev_post = nullptr;    // PostScope: orders a synchronous entry point behind what is left on the tail stream
   bool match_fp8 = false;        // fp8 shortlist GEMM (approximate; spvo_set_match_fp8)
   bool prematch = false;
