@@ -35,6 +35,15 @@
 #include <vector>
 #include "conv_mfma.hip.h"
 
+#ifndef WINO4_LEAD      // tuning (tools/wino_bench.hip): operand reads LEAD slots ahead; transform step s in slot XF_START + s * XF_STRIDE
+#define WINO4_LEAD 6
+#endif
+#ifndef WINO4_XF_START
+#define WINO4_XF_START 4   // (start 4, stride 3: 248 us for conv1b against 254-257 for 8 / 2, 8 / 1, 14 / 1, 2 / 3; LEAD 4 .. 10: no difference)
+#endif
+#ifndef WINO4_XF_STRIDE
+#define WINO4_XF_STRIDE 3
+#endif
 #ifndef WINO4_ABL
 #define WINO4_ABL 0   // measurement builds only (tools/wino_bench.hip): 1 no input transform, 2 no filter staging, 4 no raw staging, 8 operands read once, 16 no stores
 #endif
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
       const f32x4v *vb4 = reinterpret_cast<const f32x4v *>(vb) + b_lane;
       // 36 matrix instructions in the order p' = 18 h + q (q = 3 i + c; position 6 i + 3 h + c); operands: A piece p' / 4 (9 reads),
       // B piece 5 h + q / 4 (10 reads), each read LEAD instructions before its first use
-      constexpr int LEAD = 6;
+      constexpr int LEAD = WINO4_LEAD;
       f32x4v av[9], bv[10];
       auto b_piece = [](int p) { return 5 * (p / 18) + ((p % 18) >> 2); };
 #pragma unroll
@@ -324,7 +333,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
           if ((q & 3) == 0) av[q >> 2] = ub4[(q >> 2) * 256];
           if (b_piece(q) != b_piece(q - 1)) bv[b_piece(q)] = vb4[b_piece(q) * 128];
         }
-        if (!(WINO4_ABL & 1) && XF && p >= 8 && p < 28 && !(p & 1)) xf_step(raw_next, v_next, (p - 8) >> 1);   // ten steps on every other slot
+        if (!(WINO4_ABL & 1) && XF && p >= WINO4_XF_START && p < WINO4_XF_START + 10 * WINO4_XF_STRIDE && (p - WINO4_XF_START) % WINO4_XF_STRIDE == 0)
+          xf_step(raw_next, v_next, (p - WINO4_XF_START) / WINO4_XF_STRIDE);   // ten steps, one per XF_STRIDE slots
         __builtin_amdgcn_sched_barrier(0);
       }
       advance(cu);
