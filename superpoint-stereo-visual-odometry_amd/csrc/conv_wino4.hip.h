@@ -11,9 +11,10 @@
 //   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
 // 36 multiplies per 4x4 outputs and channel pair instead of 144: 1/4 of the direct method's matrix work, 9/16 of
 // F(2x2, 3x3)'s (conv_wino2.hip.h).  The price is numerical: the transforms amplify rounding (coefficients up to 8 instead
-// of 1); on this network's tensors the error against a float64 evaluation is 1.3 - 3.6 x the direct kernel's (measured per
-// tensor by tests/test_gpu_network.py::test_winograd_layers_stay_at_fp32_rounding_level, bar 4 x + 2e-7) and 50 x inside
-// the 1e-4 bar against the oracle.
+// of 1); on this network's tensors the error against a float64 evaluation is 0.4 - 2.7 x the direct kernel's (measured per
+// tensor at 360x1176, 376x1240 and 192x640 by tests/test_gpu_network.py::test_winograd_layers_stay_at_fp32_rounding_level, bar
+// 4 x + 2e-7: worst tensor 2.5e-6 of its maximum against 0.9e-6 direct and 0.5e-6 for F(2x2)), 40 x inside the 1e-4 bar
+// against the oracle.
 //
 // Structure = conv_wino2.hip.h's (8 waves, two per SIMD, LDS-DMA staging, input transform of the next item between the matrix
 // instructions of the current one, one barrier per item) with these differences:

@@ -106,22 +106,26 @@ def test_fp32_split_mode_matches_oracle_at_fp32_rounding_level(vgg_weights_path,
         assert errs["split"][k] <= 4 * errs["native"][k] + 2e-7, (k, errs["native"][k], errs["split"][k])
 
 
-@pytest.mark.parametrize("H,W,batch", [(360, 1176, 2), (192, 640, 1)])
+@pytest.mark.parametrize("H,W,batch", [(360, 1176, 2), (376, 1240, 2), (192, 640, 1)])
 def test_winograd_layers_stay_at_fp32_rounding_level(vgg_weights_path, vgg_plan, sample_images, H, W, batch, monkeypatch):
-    """The default FP32 engine runs its 3x3 layers through the Winograd F(2x2,3x3) kernel (csrc/conv_wino.hip.h); with
-    SPVO_WINOGRAD=0 (read when an engine is loaded) they run the direct kernel.  Both meet the 1e-4 bar against the oracle
-    on every tensor, and against a float64 evaluation of the graph the Winograd engine stays within a small factor of the
-    direct one: fp32 throughout, the transforms only use the coefficients 0, +-1 and +-1/2."""
+    """The default FP32 engine runs its 3x3 layers through the Winograd kernels: F(4x4,3x3) (csrc/conv_wino4.hip.h) where the
+    layer has enough 16 x 32 tiles, F(2x2,3x3) (csrc/conv_wino2.hip.h) for the rest; SPVO_WINO4=0 keeps F(2x2) everywhere and
+    SPVO_WINOGRAD=0 the direct kernel (both read when an engine is loaded).  All three meet the 1e-4 bar against the oracle on
+    every tensor, and against a float64 evaluation of the graph both Winograd engines stay within a small factor of the direct
+    one: fp32 throughout; F(2x2)'s transforms only use the coefficients 0, +-1 and +-1/2, F(4x4)'s go up to 8 (points
+    0, +-1, +-2, inf) and cost a factor of ~1-3 on this network's tensors."""
     from spvo import capi
     x = _input(sample_images, H, W, batch)
     rdet, rdesc, vals = net.forward(vgg_plan, x, return_all=True)
     ref64 = _vgg_forward_f64(vgg_plan, x)
-    errs = {}
-    for mode in ("direct", "winograd"):
+    errs, kernels = {}, {}
+    for mode in ("direct", "f2x2", "f4x4"):
         monkeypatch.setenv("SPVO_WINOGRAD", "0" if mode == "direct" else "1")
+        monkeypatch.setenv("SPVO_WINO4", "1" if mode == "f4x4" else "0")
         ctx = capi.Context(net_height=H, net_width=W)
         ctx.load_weights(vgg_weights_path)
         det, desc = ctx.forward(x)
+        kernels[mode] = [ctx.stage_kernel(f"conv:{i}")[0] for i in range(1, 9)]
         e = {}
         for tid, (ch, lvl) in enumerate(vgg_plan.tensors):
             if tid in (vgg_plan.input_tensor, vgg_plan.desc_tensor):
@@ -133,10 +137,14 @@ def test_winograd_layers_stay_at_fp32_rounding_level(vgg_weights_path, vgg_plan,
         assert np.abs(det - rdet).max() <= _tol(rdet) and np.abs(desc - rdesc.transpose(0, 2, 3, 1)).max() <= 1e-4
         errs[mode] = e
         ctx.close()
-    print("max relative error against float64, direct vs Winograd:", {k: (errs["direct"][k], errs["winograd"][k]) for k in errs["direct"]})
-    assert any(errs["direct"][k] != errs["winograd"][k] for k in errs["direct"])      # the switch did switch kernels
+    print("kernels of conv1b .. convPa:", kernels)
+    print("max relative error against float64, direct / F(2x2) / F(4x4):", {k: tuple(float(f"{errs[m][k]:.3g}") for m in errs) for k in errs["direct"]})
+    # the switches did switch kernels
+    assert all(k == "conv_mfma_kernel" for k in kernels["direct"]) and "conv_wino4_kernel" not in kernels["f2x2"]
+    assert kernels["f4x4"][0] == "conv_wino4_kernel" and any(k.startswith("conv_wino") for k in kernels["f2x2"])
     for k in errs["direct"]:
-        assert errs["winograd"][k] <= 4 * errs["direct"][k] + 2e-7, (k, errs["direct"][k], errs["winograd"][k])
+        for mode in ("f2x2", "f4x4"):
+            assert errs[mode][k] <= 4 * errs["direct"][k] + 2e-7, (mode, k, errs["direct"][k], errs[mode][k])
 
 
 def test_fp32_split_mode_rejects_other_graphs(squeeze_weights_path):
