@@ -23,7 +23,10 @@
 //   * item = (tile, chunk of FOUR input channels): one matrix instruction per position and item; filters U [pos/4 9][cq 4]
 //     [lane 64][4] and transformed input V [h 2][q/4 5][tb 2][lane 64][4] in LDS, both read by ds_read_b128 (nine + ten reads per item).
 //     The matrix instructions run in the order p' = 18 h + 3 i + c of the positions (i, j = 3 h + c): the half h of the columns
-//     that one transforming thread produces is contiguous, so its eighteen stores carry compile-time offsets;
+//     that one transforming thread produces is contiguous, so its eighteen stores carry compile-time offsets.  (The 4-byte
+//     stores hit every fourth bank -- SQ_LDS_BANK_CONFLICT: 40 % of the LDS cycles -- but pieces of 3 positions + 1 pad written
+//     by conflict-free 16-byte stores and read by twelve instead of ten instructions measured 1-2 % SLOWER: stores are the one
+//     thing that is nearly free beside an fp32 matrix instruction, reads are not);
 //   * the input transform of an item is 128 patches of 6 x 6: TWO threads per patch, rows {0,1,2} / {3,4,5} for the row pass,
 //     nine v_permlane32_swap exchanges, columns {0,1,2} / {3,4,5} for the column pass (the partner sits 32 lanes away, so the
 //     swap leaves "rows 0-2" and "rows 3-5" in the same registers of both halves: no selects); the four waves 0-3 do it in even
