@@ -211,6 +211,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=0, help="timed blocks of --steps steps (default 0: as many as make about one second, 5..200); the line reports the median block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational second measurement (FP32 engine in split mode)")
+    ap.add_argument("--legs", default="split,host,trained,classic", help="informational legs to run after the headline (comma list of split, host, trained, classic)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--no-pipeline", action="store_true", help="do not hand the next stereo pairs over early")
     ap.add_argument("--sync-solve", action="store_true", help="solve inside the step (solveStereoOdometry in one piece) instead of handing every frame's solve over and "
@@ -406,22 +407,28 @@ def main():
         ctx.profile_enable(False)
 
     def leg(step_fn, finish, start=args.warmup):
-        """an extra leg timed like the headline: blocks of args.steps steps, the median block"""
+        """an extra (informational) leg timed like the headline: barrier-bracketed blocks, the median block.  Its blocks are at least
+        100 steps long whatever --steps says (each block's barriers drain the pipeline: at the driver's 20 steps that costs a
+        look-ahead leg 10 % and says nothing about the path); the leg reports `steps_per_block`.  Returned: the median block's time
+        scaled to args.steps steps (so that args.steps / time is the leg's frame rate) and the spread fields."""
+        n = max(args.steps, 100)
         cur = [start]
 
         def block():
             barrier()
             t1 = time.perf_counter()
-            for i in range(cur[0], cur[0] + args.steps):
+            for i in range(cur[0], cur[0] + n):
                 step_fn(i)
             finish()
             barrier()
-            cur[0] += args.steps
+            cur[0] += n
             return time.perf_counter() - t1
         ts = [block()]
         ts += [block() for _ in range((args.repeats if args.repeats > 0 else repeats_for(ts[0], 0.6)) - 1)]
-        return spread(ts, args.steps)
+        e, sp = spread(ts, n)
+        return e * args.steps / n, {**sp, "steps_per_block": n}
 
+    legs = set(args.legs.split(","))
     if rank == 0:
         total_frames = args.steps * world
         out = {
@@ -490,7 +497,7 @@ def main():
                 out["net_ops_ms"] = {k: round(v["total_ms"] / max(v["calls"], 1), 4) for k, v in prof_all.items()
                                      if k.startswith(("conv:", "pool:", "l2norm:", "dwconv:"))}
             out["conv_stack_tflops"] = round(conv_fl / (conv_ms * 1e-3) / 1e12, 2)
-        if world == 1 and headline and not args.no_extras:
+        if world == 1 and headline and not args.no_extras and "split" in legs:
             try:
                 # Informational, never `value`: the same workload with the FP32 engine in its opt-in split mode (every fp32 operand as
                 # three bf16 pieces, six partial products on the bf16 matrix pipe, fp32 accumulation: results agree with the
@@ -510,7 +517,7 @@ def main():
                                                       "6 partial products per product, fp32 accumulate; fp32-equivalent results"}
             except Exception as exc:   # the headline line must survive a failure of this informational part
                 out["fp32_split_mode"] = {"error": repr(exc)}
-        if world == 1 and headline and not args.no_extras:
+        if world == 1 and headline and not args.no_extras and "host" in legs:
             try:
                 # The reference's own entry point, addStereoImagePair(cv::Mat&, ...) (node.cpp:175): images in HOST memory (as
                 # cv_bridge hands them over), resized images and descriptors copied back into images_dq / descriptors_dq -- PCIe
@@ -538,7 +545,7 @@ def main():
                                                  "descriptors out per pair (PCIe inclusive); the headline `value` has the images resident in HBM"}
             except Exception as exc:   # the headline line must survive a failure of this informational part
                 out["host_interface"] = {"error": repr(exc)}
-        if world == 1 and headline and not args.no_extras:
+        if world == 1 and headline and not args.no_extras and "trained" in legs:
             try:
                 # Second workload, never `value`: the reference's TRAINED sp_squeeze graph (tests/golden/sp_squeeze.spvw = its ONNX file
                 # re-packed), FP32, same stream and size.  With trained weights the geometry is real: the gate accepts, the LM refinement
@@ -574,7 +581,7 @@ def main():
                                                "mean_lm_iterations": round(float(st[:, 2].mean()), 2), "mean_pnp_inliers": round(float(st[:, 3].mean()), 1)}
             except Exception as exc:   # the headline line must survive a failure of this informational part
                 out["trained_workload"] = {"error": repr(exc)}
-        if world == 1 and headline and not args.no_extras:
+        if world == 1 and headline and not args.no_extras and "classic" in legs:
             try:
                 # BASELINE config 1's front end on the GPU, never `value`: ClassicFeatureFrontEnd(ORB, ORB, BF, KNN) as node.cpp:353-360
                 # constructs it -- ORB (spvo_orb_detect) and Hamming matching (spvo_match_hamming) as HIP kernels, the same solver --

@@ -485,6 +485,7 @@ struct SampleJob {
   float *out_xy_f32;        // [n][2] or NULL
   int *out_xy_i32;          // [n][2] or NULL
   int *out_n;               // device copy of n or NULL
+  float *out_host;          // [n][256] second copy of the descriptors, written straight into pinned HOST memory, or NULL
 };
 struct SampleJobs { SampleJob j[2]; };   // blockIdx.y selects the image
 
@@ -538,6 +539,7 @@ __global__ __launch_bounds__(256) void sample_desc_kernel(SampleJobs jobs, int H
   v.z = __fdiv_rn(v.z, nrm);
   v.w = __fdiv_rn(v.w, nrm);
   *(float4 *)(out + (size_t)k * 256 + lane * 4) = v;
+  if (jb.out_host) *(float4 *)(jb.out_host + (size_t)k * 256 + lane * 4) = v;   // 1 KiB per wave, posted writes over PCIe
   if (jb.out_sqn) {
     float s2 = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
 #pragma unroll

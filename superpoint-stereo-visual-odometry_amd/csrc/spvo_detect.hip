@@ -290,7 +290,7 @@ int spvo_sample_descriptors(spvo_ctx *c, const float *desc_nhwc, const int32_t *
   HIP_TRY(c, hipMemcpyAsync(ts.d, desc_nhwc, ts.per_image * sizeof(float), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->d_xy_tmp, xy, (size_t)n * 2 * sizeof(int), hipMemcpyHostToDevice, c->stream));
   SampleJobs sj;
-  sj.j[0] = SampleJob{ts.d, c->d_xy_tmp, nullptr, n, c->d_desc_tmp, nullptr, nullptr, nullptr, nullptr};
+  sj.j[0] = SampleJob{ts.d, c->d_xy_tmp, nullptr, n, c->d_desc_tmp, nullptr, nullptr, nullptr, nullptr, nullptr};
   sj.j[1] = sj.j[0];
   hipLaunchKernelGGL(sample_desc_kernel, dim3((n + 3) / 4, 1), dim3(256), 0, c->stream, sj, c->H, c->W, c->Hc, c->Wc);
   HIP_TRY(c, hipGetLastError());
@@ -299,7 +299,7 @@ int spvo_sample_descriptors(spvo_ctx *c, const float *desc_nhwc, const int32_t *
   return SPVO_OK;
 }
 
-static int enqueue_sample(spvo_ctx *c, const int slots[2], const NmsPair &np, int ring) {
+static int enqueue_sample(spvo_ctx *c, const int slots[2], const NmsPair &np, int ring, float *host_desc = nullptr) {
   const Tensor &ts = c->tensors[c->t_desc];
   const float *desc = ts.dr[ring] ? ts.dr[ring] : ts.d;
   ScopedStage ss(c, stage_id(c, "sample"));
@@ -310,7 +310,7 @@ static int enqueue_sample(spvo_ctx *c, const int slots[2], const NmsPair &np, in
     FeatureSlot &s = c->slots[slots[i]];
     // the keypoint count is read from the NMS counters on the device: no host round trip
     sj.j[i] = SampleJob{desc + (size_t)i * ts.per_image, np.b[i].out_xy, (const int *)(np.b[i].counters + 2), 0, s.d_desc, s.d_sqn,
-                        stage + (size_t)i * cap * 2, s.d_xy, s.d_n};
+                        stage + (size_t)i * cap * 2, s.d_xy, s.d_n, host_desc ? host_desc + (size_t)i * cap * 256 : nullptr};
   }
   hipLaunchKernelGGL(sample_desc_kernel, dim3((cap + 3) / 4, 2), dim3(256), 0, c->post, sj, c->H, c->W, c->Hc, c->Wc);
   HIP_TRY(c, hipGetLastError());
@@ -370,12 +370,25 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   }
   const int ring = (int)(c->submit_count++ % RING);
   for (auto &mc : c->mcache[ring]) mc.valid = false;
+  static const bool direct_on = !(std::getenv("SPVO_DIRECT_HOST_WRITES") && std::atoi(std::getenv("SPVO_DIRECT_HOST_WRITES")) == 0);
+  const bool direct = extras != 0 && direct_on;
   if (host_l) {   // pageable -> pinned (host copy), pinned -> device (DMA on the network stream): the caller's buffers are free on return
     const size_t bytes = (size_t)(rows - 1) * stride + cols;   // what is the caller's of a strided view: not the last row's padding
+    // The two copies go out on the network stream, in front of the preprocess kernel.  SPVO_UPLOAD_STREAM=1 puts them on a stream
+    // of their own (the network stream waits for their event), so that with earlier submissions in flight the images travel
+    // while the previous pair's network runs: measured both ways -- 1168 against 1216 frames/s in tools/sync_leg.py's look-ahead
+    // run, 1144 against 1107 in bench.py's -- and left off.  (The set's buffers are free either way: at most MAX_INFLIGHT < RING
+    // submissions are in flight, so the one that used this set last has been collected.)
+    static const bool up_split = std::getenv("SPVO_UPLOAD_STREAM") && std::atoi(std::getenv("SPVO_UPLOAD_STREAM")) != 0;
+    hipStream_t us = up_split ? c->stream_u : c->stream;
     std::memcpy(c->h_img_r[ring], host_l, bytes);   // (the left image is on its way while the right one is staged)
-    HIP_TRY(c, hipMemcpyAsync(c->d_img_r[ring], c->h_img_r[ring], bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_img_r[ring], c->h_img_r[ring], bytes, hipMemcpyHostToDevice, us));
     std::memcpy(c->h_img_r[ring] + c->img_cap_r, host_r, bytes);
-    HIP_TRY(c, hipMemcpyAsync(c->d_img_r[ring] + c->img_cap_r, c->h_img_r[ring] + c->img_cap_r, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_img_r[ring] + c->img_cap_r, c->h_img_r[ring] + c->img_cap_r, bytes, hipMemcpyHostToDevice, us));
+    if (up_split) {
+      HIP_TRY(c, hipEventRecord(c->ev_up[ring], c->stream_u));
+      HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_up[ring], 0));
+    }
     srcs[0] = c->d_img_r[ring];
     srcs[1] = c->d_img_r[ring] + c->img_cap_r;
   }
@@ -424,13 +437,18 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   if (prof_detect) { det_e0 = get_event(c); (void)hipEventRecord(det_e0, c->stream); }
   {
     ScopedStage sp(c, stage_id(c, "preprocess"));
-    int rc = launch_preprocess(c, srcs[0], srcs[1], 2, rows, cols, stride, g, 0, (extras & 1) ? c->d_resized_r[ring] : nullptr);
+    // The bulk results a host-image submission takes back -- resized images (0.85 MB), descriptors (2 x 1 MB) -- are WRITTEN into
+    // the set's pinned mirrors by the kernels that produce them (posted PCIe writes, 64 B / 1 KiB per wave instruction) instead of
+    // travelling as copies behind events: a device-to-host copy waiting for its event occupies an SDMA queue, and the NEXT pair's
+    // image upload queued on the same engine waits with it -- whether it does depended on the process's copy history (bench.py's
+    // look-ahead leg 0.95 ms per frame, the same calls from tools/sync_leg.py 0.81).  SPVO_DIRECT_HOST_WRITES=0: copies, as before.
+    int rc = launch_preprocess(c, srcs[0], srcs[1], 2, rows, cols, stride, g, 0, (extras & 1) ? (direct ? c->h_resized_r[ring] : c->d_resized_r[ring]) : nullptr);
     if (rc) return rc;
   }
   // The resized images (what nn.cpp:154 pushes to images_dq) are final here: they leave on stream_c now, under the network,
   // instead of behind the matches at the end of the tail (0.85 MB = ~30 us of a synchronous frame).  SPVO_EARLY_RESIZED=0: as before.
   static const bool early_res_on = !(std::getenv("SPVO_EARLY_RESIZED") && std::atoi(std::getenv("SPVO_EARLY_RESIZED")) == 0);
-  const bool early_res = (extras & 1) && early_res_on;
+  const bool early_res = (extras & 1) && early_res_on && !direct;
   if (early_res) {
     HIP_TRY(c, hipEventRecord(c->ev_pre[ring], c->stream));
     HIP_TRY(c, hipStreamWaitEvent(c->stream_c, c->ev_pre[ring], 0));
@@ -464,7 +482,7 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
     ScopedStage sn(c, stage_id(c, "nms"));
     rc = launch_nms_rounds(c, 2, np, ring, NMS_FIRST, c->d_counters_all + (size_t)(((ring + 1) % RING) * 2) * NMS_COUNTER_INTS);
   }
-  if (!rc) rc = enqueue_sample(c, slots, np, ring);
+  if (!rc) rc = enqueue_sample(c, slots, np, ring, (direct && (extras & 2)) ? c->h_desc_r[ring] : nullptr);
   // Keypoints, counts and descriptors are final here: spvo_detect_wait / _collect waits for THIS point (ev_feat); the matches enqueued
   // behind it are waited for where they are asked for (spvo_match_slots, ev_tail).  The descriptors a host-image submission
   // (extras != 0) takes back go out on a stream of their own BESIDE the matches -- 2 MB over PCIe are ~60 us the matches need not
@@ -477,11 +495,11 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   hipStream_t cs = tail_split ? c->stream_c : c->stream_t;
   if (tail_split) {
     if (!rc) rc = hipEventRecord(c->ev_feat[ring], c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");
-    if (!rc && extras) rc = hipStreamWaitEvent(c->stream_c, c->ev_feat[ring], 0) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipStreamWaitEvent failed");
+    if (!rc && extras && !direct) rc = hipStreamWaitEvent(c->stream_c, c->ev_feat[ring], 0) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipStreamWaitEvent failed");
   } else if (!rc && c->prematch) {
     rc = enqueue_prematch(c, slot_l, slot_r, prev_l, ring);
   }
-  if (!rc && extras) {
+  if (!rc && extras && !direct) {
     if (!rc && (extras & 1) && !early_res)   // resized images -> the set's pinned mirror (unless they left behind the preprocess kernel)
       rc = hipMemcpyAsync(c->h_resized_r[ring], c->d_resized_r[ring], (size_t)2 * c->H * c->W, hipMemcpyDeviceToHost, cs) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipMemcpyAsync failed");
     if (!rc && (extras & 2)) {   // descriptors of both images: whole slots (the counts are not known on the host yet; rows >= n are stale)
@@ -509,7 +527,7 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   PendingDetect pd;
   pd.g = CropGeomS{g.row_off, g.col_off, g.crop_rows, g.crop_cols, g.scale};
   pd.rows = rows; pd.cols = cols;
-  pd.slot_l = slot_l; pd.slot_r = slot_r; pd.prev_l = prev_l; pd.ring = ring; pd.extras = extras; pd.early_res = early_res;
+  pd.slot_l = slot_l; pd.slot_r = slot_r; pd.prev_l = prev_l; pd.ring = ring; pd.extras = extras; pd.early_res = early_res; pd.direct = direct;
   c->pendq.push_back(pd);
   return SPVO_OK;
 }
@@ -553,7 +571,7 @@ static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_feature
     // only this submission's tail: a younger one may be queued behind it on both streams
     const double tw0 = diag_now_us();
     rc = wait_event(c->ev_feat[pd.ring]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");
-    if (!rc && pd.extras) rc = wait_event(c->ev_copy[pd.ring]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");
+    if (!rc && pd.extras && !pd.direct) rc = wait_event(c->ev_copy[pd.ring]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");
     g_diag.max_tail_wait = std::max(g_diag.max_tail_wait, diag_now_us() - tw0);
   }
   if (!rc && pd.early_res) rc = wait_event(c->ev_res[pd.ring]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");   // long done: it left under the network
@@ -563,10 +581,10 @@ static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_feature
   if (!rc && (redone || pd.rematch)) {   // rare: keypoints changed after the first batch -> redo what depends on them
     if (redone) c->stages[stage_id(c, "nms_redo")].calls += 1;       // counted even with profiling off (tests, diagnostics)
     if (pd.rematch) c->stages[stage_id(c, "rematch")].calls += 1;
-    if (redone) rc = enqueue_sample(c, slots, np, pd.ring);
+    if (redone) rc = enqueue_sample(c, slots, np, pd.ring, (pd.direct && (pd.extras & 2)) ? c->h_desc_r[pd.ring] : nullptr);
     if (!rc && c->prematch) rc = enqueue_prematch(c, pd.slot_l, pd.slot_r, pd.prev_l, pd.ring);
     if (!rc && extras) rc = copy_extras();
-    if (!rc && redone) rc = restage();
+    if (!rc && redone && !pd.direct) rc = restage();
     if (!rc) rc = hipStreamSynchronize(c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "stream synchronisation failed");
     if (redone)
       for (auto &q : c->pendq)

@@ -1,5 +1,5 @@
 """The bench's `host_interface.synchronous` leg on its own (addStereoImagePair(cv::Mat&, ...) on host images, one pair at a time,
-matchDescriptors x 2, solveStereoOdometry), with the host wall time of each call.  python tools/sync_leg.py [steps = 300] [lookahead depth = 0]"""
+matchDescriptors x 2, solveStereoOdometry), with the host wall time of each call.  python tools/sync_leg.py [steps = 300] [lookahead depth = 0] [depth of a first, untimed leg]"""
 import os
 import sys
 import tempfile
@@ -55,6 +55,12 @@ def step(i, acc=None):
         fe.step_host(m[0], m[1], P_l, P_r, a[0], a[1], deferred_solve=True, next3_pair=a[2])
 
 
+if len(sys.argv) > 3:      # first run the OTHER mode in the same front end, as bench.py's legs follow each other
+    d0, depth = depth, int(sys.argv[3])
+    for i in range(200):
+        step(i)
+    fe.finish_solve()
+    depth = d0
 for i in range(30):
     step(i)
 fe.finish_solve()
