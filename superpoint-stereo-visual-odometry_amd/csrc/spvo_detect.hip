@@ -304,7 +304,10 @@ static int enqueue_sample(spvo_ctx *c, const int slots[2], const NmsPair &np, in
   const float *desc = ts.dr[ring] ? ts.dr[ring] : ts.d;
   ScopedStage ss(c, stage_id(c, "sample"));
   const int cap = c->cfg.max_keypoints;
-  float *stage = c->d_xy_stage + (size_t)ring * 2 * cap * 2;
+  // the keypoints as floats go straight into the set's pinned mirror (8 bytes per keypoint), not through a staging buffer and a copy
+  static const bool direct_xy = !(std::getenv("SPVO_DIRECT_HOST_WRITES") && std::atoi(std::getenv("SPVO_DIRECT_HOST_WRITES")) == 0) &&
+                           !(std::getenv("SPVO_DIRECT_SMALL") && std::atoi(std::getenv("SPVO_DIRECT_SMALL")) == 0);
+  float *stage = direct_xy ? c->h_xy_r[ring] : c->d_xy_stage + (size_t)ring * 2 * cap * 2;
   SampleJobs sj;
   for (int i = 0; i < 2; ++i) {
     FeatureSlot &s = c->slots[slots[i]];
@@ -314,7 +317,7 @@ static int enqueue_sample(spvo_ctx *c, const int slots[2], const NmsPair &np, in
   }
   hipLaunchKernelGGL(sample_desc_kernel, dim3((cap + 3) / 4, 2), dim3(256), 0, c->post, sj, c->H, c->W, c->Hc, c->Wc);
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemcpyAsync(c->h_xy_r[ring], stage, (size_t)2 * cap * 2 * sizeof(float), hipMemcpyDeviceToHost, c->post));
+  if (!direct_xy) HIP_TRY(c, hipMemcpyAsync(c->h_xy_r[ring], stage, (size_t)2 * cap * 2 * sizeof(float), hipMemcpyDeviceToHost, c->post));
   return SPVO_OK;
 }
 
