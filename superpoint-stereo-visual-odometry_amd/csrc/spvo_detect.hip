@@ -465,11 +465,20 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   }
   if (rc) { c->cur_ring = 0; return rc; }
   c->last_batch = 2;
+  // The heads (2.2 GFLOP: the one heavy piece behind the trunk) stay on the network stream, in front of the next pair's trunk.
+  // On the tail stream (SPVO_HEADS_ON_NET=0, the arrangement until the trunk's kernels became persistent one-workgroup-per-CU
+  // launches) they run beside the next pair's conv1b, which leaves them 12 CUs: the tail then finishes late, the host hands the
+  // next pair over late and the network stream idles 50-70 us per pair (1257-1265 against 1308 frames/s on one box).
+  static const bool heads_on_net = !(std::getenv("SPVO_HEADS_ON_NET") && std::atoi(std::getenv("SPVO_HEADS_ON_NET")) == 0);
+  if (heads_on_net) {
+    rc = run_ops(c, 2, c->head_start, c->ops.size(), c->stream);
+    if (rc) { c->cur_ring = 0; return rc; }
+  }
   if (trunk_timing) { (void)hipEventRecord(tt_e[tt_n % 8], c->stream); ++tt_n; }
   HIP_TRY(c, hipEventRecord(c->ev_net[ring], c->stream));
   HIP_TRY(c, hipStreamWaitEvent(c->stream_t, c->ev_net[ring], 0));
   c->post = c->stream_t;
-  rc = run_ops(c, 2, c->head_start, c->ops.size(), c->stream_t);   // heads: on the tail stream, reading this submission's ring buffers
+  if (!heads_on_net) rc = run_ops(c, 2, c->head_start, c->ops.size(), c->stream_t);   // heads: on the tail stream, reading this submission's ring buffers
   c->cur_ring = 0;
   if (rc) { c->post = c->stream; return rc; }
   const NmsPair np = nms_pair(c, ring);
