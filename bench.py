@@ -484,6 +484,8 @@ def main():
                                "flops_counted": "executed on the matrix pipe" + counted,
                                "algorithmic_flops_per_launch": dom["flops"], "algorithmic_tflops": round(algorithmic, 2),
                                "algorithmic_frac_of_peak": round(algorithmic / peak, 4)}
+            if kfactor == 0.25:   # the same launch priced as round 2's kernel was: what fraction of the peak an F(2x2,3x3) kernel would need to be this fast
+                out["roofline"]["frac_if_counted_as_f2x2"] = round(algorithmic * (4.0 / 9.0) / peak, 4)
         any_stage = next((v for k, v in prof_all.items() if k.startswith("conv:") and v["calls"]), None)
         if any_stage:   # stage breakdown: the separate pass with every stage timed (it runs ~7 % slower than the timed region)
             calls = any_stage["calls"]
