@@ -174,6 +174,21 @@ def test_the_reference_entry_point_with_host_images_equals_the_device_entry(mode
             assert np.array_equal(b[6], ofe.preprocess(frames[k][0], P_l, 360, 1176)[0])           # images_dq holds the resized u8 image (nn.cpp:154)
 
 
+@pytest.mark.parametrize("env", [{"SPVO_DIRECT_HOST_WRITES": "0"}, {"SPVO_DIRECT_HOST_WRITES": "0", "SPVO_EARLY_RESIZED": "0", "SPVO_TAIL_SPLIT": "1"},
+                                 {"SPVO_UPLOAD_STREAM": "1"}, {"SPVO_HEADS_ON_NET": "0"}])
+def test_the_other_arrangements_of_a_host_image_submission_give_the_same_results(env):
+    """The library reads its arrangement switches once per process: bulk results as device-to-host copies instead of direct writes
+    into pinned memory (with the resized images under the network / behind the matches), uploads on a stream of their own, heads
+    on the tail stream.  Each arrangement runs the bit-for-bit comparison above in a process of its own."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_host.py"), "-x", "-q", "-k",
+                        "the_reference_entry_point_with_host_images_equals_the_device_entry or prefetch_pipeline_is_transparent"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_fp16_engine_through_the_host_class(tmp_path, squeeze_weights_path, sequence):
     """TensorRtPrecision::FP16 (hpp:124-126): the front end loads `<prefix>_<B>_<H>_<W>_FP16.spvw`, refuses a file
     of the other precision, and tracks the synthetic ego-motion like the FP32 engine (the trained squeeze weights;
