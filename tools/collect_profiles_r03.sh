@@ -26,5 +26,9 @@ done
 $ROOT/tools/mfma_coissue > $OUT/mfma_coissue.log 2>&1
 (for a in 0_f0 3_f0 11_f0; do echo "conv_wino64 ablation $a"; $ROOT/tools/wino_bench64_st$a 360 1176 64 64 1 20 247; done; echo "conv_wino2 (F(2x2) 8-wave form)"; $ROOT/tools/wino_bench2_st 360 1176 64 64 1 20 238) > $OUT/wino_stamps.log 2>&1
 (for a in 0 1 2 4 6 15 31; do echo "conv_wino4 ablation $a (1 no input transform, 2 no filter staging, 4 no raw staging, 8 operands read once, 16 no stores)"; $ROOT/tools/wino_bench4_abl$a 360 1176 64 64 1 20 244; done) > $OUT/wino4_ablation.log 2>&1
-find $OUT -name "*.csv" | head -40
+
+
+$ROOT/tools/mfma_coissue16 > $OUT/mfma_coissue16.log 2>&1
+python3 $ROOT/tools/sync_leg.py 300 0 > $OUT/sync_leg.log 2>&1
+python3 $ROOT/tools/sync_leg.py 300 2 >> $OUT/sync_leg.log 2>&1
 du -sh $OUT
