@@ -112,9 +112,8 @@ __device__ __forceinline__ void wino4_out4(const float m0, const float m1, const
   y[3] = fmaf(8.f, d, b) + m5;
 }
 
-template <bool POOL, bool RELU, int TAG = 0, bool ODD = false>   // ODD: H or W odd (no pooling then): outputs leave one by one
+template <bool POOL, bool RELU, int TAG = 0>
 __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
-  static_assert(!(POOL && ODD), "2x2 pooling needs even H and W");
   using T = Wino4Tile;
   constexpr int CK = T::CK, LW = T::LW, LH = T::LH, LW4 = LW / 4;
   constexpr int IN_V4 = T::IN_FLOATS / 4;        // 720 16-byte pieces per raw tile
@@ -362,7 +361,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
     const int trow = 2 * tb + (c16 >> 3), tcol = c16 & 7;
     auto relu = [](float v) { return RELU ? __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()) : v; };
     const int oy = cur.y0 + 4 * trow, ox = cur.x0 + 4 * tcol;                  // first output pixel of this lane's tile
-    const bool w4 = (a.W & 3) == 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float bias_v = bias_p[r < kmax ? r : 0];
@@ -377,61 +375,33 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
         for (int jj = 0; jj < 4; ++jj) y[i][jj] = relu(y[i][jj] + bias_v);
       }
       const bool ch_ok = r < kmax;
+      // Stores: one 16-byte piece per tile row (8 bytes per pooled row).  A tile that straddles the right edge writes ZEROS into
+      // the plane's right padding (at least PADX = 4 columns, zero by construction and read as such by the next layer's halo),
+      // so that odd widths and widths that are not multiples of 4 take the same wide stores.
       if constexpr (POOL) {
-        float pv[2][2];
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const int ow = a.W >> 1;
 #pragma unroll
-        for (int pi = 0; pi < 2; ++pi)
+        for (int pi = 0; pi < 2; ++pi) {
+          float pv[2];
 #pragma unroll
           for (int pj = 0; pj < 2; ++pj)
-            pv[pi][pj] = fmaxf(fmaxf(y[2 * pi][2 * pj], y[2 * pi][2 * pj + 1]), fmaxf(y[2 * pi + 1][2 * pj], y[2 * pi + 1][2 * pj + 1]));
-        if (w4) {   // W a multiple of 4: a tile's two pooled columns are inside or outside together -- one 8-byte store per pooled row
-          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-          for (int pi = 0; pi < 2; ++pi) {
-            const int py = (oy >> 1) + pi, px = ox >> 1;
-            const unsigned vo = (ch_ok && py < (a.H >> 1) && px < (a.W >> 1)) ? 4u * (unsigned)(4 * g4 * oplane + (py + PADY) * a.out_wp + (px + PADX)) : OOB;
-            const u32x2 v = {__float_as_uint(pv[pi][0]), __float_as_uint(pv[pi][1])};
-            __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, (WINO4_ABL & 16) ? OOB : vo, r * oplane * 4, 0);
-          }
-        } else {
-#pragma unroll
-          for (int pi = 0; pi < 2; ++pi)
-#pragma unroll
-            for (int pj = 0; pj < 2; ++pj) {
-              const int py = (oy >> 1) + pi, px = (ox >> 1) + pj;
-              const unsigned vo = (ch_ok && py < (a.H >> 1) && px < (a.W >> 1)) ? 4u * (unsigned)(4 * g4 * oplane + (py + PADY) * a.out_wp + (px + PADX)) : OOB;
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pv[pi][pj]), rsrc, (WINO4_ABL & 16) ? OOB : vo, r * oplane * 4, 0);
-            }
+            pv[pj] = fmaxf(fmaxf(y[2 * pi][2 * pj], y[2 * pi][2 * pj + 1]), fmaxf(y[2 * pi + 1][2 * pj], y[2 * pi + 1][2 * pj + 1]));
+          const int py = (oy >> 1) + pi, px = ox >> 1;
+          const unsigned vo = (ch_ok && py < (a.H >> 1) && px < ow) ? 4u * (unsigned)(4 * g4 * oplane + (py + PADY) * a.out_wp + (px + PADX)) : OOB;
+          const u32x2 v = {__float_as_uint(pv[0]), __float_as_uint(px + 1 < ow ? pv[1] : 0.f)};
+          __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, (WINO4_ABL & 16) ? OOB : vo, r * oplane * 4, 0);
         }
-      } else if constexpr (ODD) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            const int yy = oy + i, xx = ox + jj;
-            const unsigned vo = (ch_ok && yy < a.H && xx < a.W) ? 4u * (unsigned)(4 * g4 * oplane + (yy + PADY) * a.out_wp + (xx + PADX)) : OOB;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[i][jj]), rsrc, (WINO4_ABL & 16) ? OOB : vo, r * oplane * 4, 0);
-          }
-      } else if (w4) {   // W a multiple of 4: a tile's four columns are inside or outside together -- one 16-byte store per row
+      } else {
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int yy = oy + i;
           const unsigned vo = (ch_ok && yy < a.H && ox < a.W) ? 4u * (unsigned)(4 * g4 * oplane + (yy + PADY) * a.out_wp + (ox + PADX)) : OOB;
-          const u32x4 v = {__float_as_uint(y[i][0]), __float_as_uint(y[i][1]), __float_as_uint(y[i][2]), __float_as_uint(y[i][3])};
+          const u32x4 v = {__float_as_uint(y[i][0]), __float_as_uint(ox + 1 < a.W ? y[i][1] : 0.f), __float_as_uint(ox + 2 < a.W ? y[i][2] : 0.f),
+                           __float_as_uint(ox + 3 < a.W ? y[i][3] : 0.f)};
           __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (WINO4_ABL & 16) ? OOB : vo, r * oplane * 4, 0);
         }
-      } else {
-        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int hj = 0; hj < 2; ++hj) {   // H and W are even (host): a pair of columns is inside or outside together
-            const int yy = oy + i, xx = ox + 2 * hj;
-            const unsigned vo = (ch_ok && yy < a.H && xx < a.W) ? 4u * (unsigned)(4 * g4 * oplane + (yy + PADY) * a.out_wp + (xx + PADX)) : OOB;
-            const u32x2 v = {__float_as_uint(y[i][2 * hj]), __float_as_uint(y[i][2 * hj + 1])};
-            __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, (WINO4_ABL & 16) ? OOB : vo, r * oplane * 4, 0);
-          }
       }
       __builtin_amdgcn_sched_barrier(0);
     }

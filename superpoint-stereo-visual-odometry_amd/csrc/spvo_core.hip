@@ -678,8 +678,8 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
         if (eligible && !op.wino && op.wino2 && narrow_on && (op.cout % 32) == 0 && 2 * wtiles >= min_tiles) op.wino = op.wino_narrow = true;
       }
       // F(4x4,3x3) (conv_wino4.hip.h): 36 multiplies per 4x4 outputs instead of F(2x2)'s 64 -- for the Winograd layers with enough
-      // 16 x 32 tiles to fill the chip (odd H or W: its stores go out one by one instead of in column pairs; SPVO_WINO4_ODD=0 keeps
-      // those layers on F(2x2)).  SPVO_WINO4=0 keeps F(2x2) everywhere.
+      // 16 x 32 tiles to fill the chip (unpooled layers of any size -- SPVO_WINO4_ODD=0 keeps the odd-sized ones on F(2x2) --, pooled
+      // layers with even H and W).  SPVO_WINO4=0 keeps F(2x2) everywhere.
       if (op.wino && !op.wino_narrow && op.wino2 && (op.cin % Wino4Tile::CK) == 0 &&
           (((ti.H | ti.W) & 1) == 0 || (!pool && !(std::getenv("SPVO_WINO4_ODD") && std::atoi(std::getenv("SPVO_WINO4_ODD")) == 0))) &&
           !(std::getenv("SPVO_WINO4") && std::atoi(std::getenv("SPVO_WINO4")) == 0)) {

@@ -106,11 +106,11 @@ int launch_conv_wino_sel(spvo_ctx *c, const ConvArgs &args, bool relu, bool pool
 }
 
 // conv_wino4.hip.h: Winograd F(4x4,3x3), 16 x 32 output tiles, 8 waves, one workgroup per CU
-template <bool POOL, bool RELU, int TAG, bool ODD = false>
+template <bool POOL, bool RELU, int TAG>
 int launch_conv_wino4_instance(spvo_ctx *c, const ConvArgs &args, hipStream_t stream) {
   static bool ready[64] = {};
   const int dev = c->cfg.device & 63;
-  auto k = conv_wino4_kernel<POOL, RELU, TAG, ODD>;
+  auto k = conv_wino4_kernel<POOL, RELU, TAG>;
   if (!ready[dev]) {
     HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, Wino4Tile::LDS_BYTES));
     ready[dev] = true;
@@ -130,10 +130,7 @@ int launch_conv_wino4(spvo_ctx *c, const ConvArgs &a, int batch, bool relu, bool
   args.tiles_x = (a.W + Wino4Tile::TW - 1) / Wino4Tile::TW;
   args.tiles_y = (a.H + Wino4Tile::TH - 1) / Wino4Tile::TH;
   args.batch = batch;
-  if ((a.H | a.W) & 1) {   // odd sizes: never pooled (the plan loader keeps pooled layers with odd sizes on the other kernels)
-    if (pool) return fail(c, SPVO_ERR_INVALID, "F(4x4) kernel: pooled layer with odd size");
-    return relu ? launch_conv_wino4_instance<false, true, 0, true>(c, args, stream) : launch_conv_wino4_instance<false, false, 0, true>(c, args, stream);
-  }
+  if (pool && ((a.H | a.W) & 1)) return fail(c, SPVO_ERR_INVALID, "F(4x4) kernel: pooled layer with odd size");   // (the plan loader keeps those on the other kernels)
   if (dominant && relu) return pool ? launch_conv_wino4_instance<true, true, 1>(c, args, stream) : launch_conv_wino4_instance<false, true, 1>(c, args, stream);
   if (pool) return relu ? launch_conv_wino4_instance<true, true, 0>(c, args, stream) : launch_conv_wino4_instance<true, false, 0>(c, args, stream);
   return relu ? launch_conv_wino4_instance<false, true, 0>(c, args, stream) : launch_conv_wino4_instance<false, false, 0>(c, args, stream);
