@@ -391,7 +391,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
 #pragma unroll
     for (int blk = 0; blk < NBLK; ++blk) {
       const int trow = NARROW ? tb : 2 * tb + blk, tcol = c16;
-      unsigned voff, voff01 = OOB, voff10 = OOB, voff11 = OOB;
+      unsigned voff, voff10 = OOB;
+      bool col1 = true;   // ODD: the tile's second column is inside the image
       if constexpr (POOL) {
         const int y = (cur.y0 >> 1) + trow, x = (cur.x0 >> 1) + tcol;
         voff = (y < (a.H >> 1) && x < (a.W >> 1)) ? 4u * (unsigned)(4 * g4 * oplane + (y + PADY) * a.out_wp + (x + PADX)) : OOB;
@@ -399,9 +400,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
         const int y = cur.y0 + 2 * trow, x = cur.x0 + 2 * tcol;
         voff = (y < a.H && x < a.W) ? 4u * (unsigned)(4 * g4 * oplane + (y + PADY) * a.out_wp + (x + PADX)) : OOB;
         if constexpr (ODD) {
-          voff01 = (voff != OOB && x + 1 < a.W) ? voff + 4u : OOB;
+          col1 = x + 1 < a.W;
           voff10 = (voff != OOB && y + 1 < a.H) ? voff + 4u * (unsigned)a.out_wp : OOB;
-          voff11 = (voff01 != OOB && voff10 != OOB) ? voff10 + 4u : OOB;
         }
       }
 #pragma unroll
@@ -427,12 +427,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
           __builtin_amdgcn_raw_buffer_store_b64(r0, rsrc, vo, r * oplane * 4, 0);
           __builtin_amdgcn_raw_buffer_store_b64(r1, rsrc, vo == OOB ? OOB : vo + 4u * (unsigned)a.out_wp, r * oplane * 4, 0);
         } else {
-          // odd H or W: the second row / column of the last tiles is outside the image and must stay zero (the next layer's halo)
-          const unsigned v00 = r < kmax ? voff : OOB, v01 = r < kmax ? voff01 : OOB, v10 = r < kmax ? voff10 : OOB, v11 = r < kmax ? voff11 : OOB;
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y00), rsrc, v00, r * oplane * 4, 0);
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y01), rsrc, v01, r * oplane * 4, 0);
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y10), rsrc, v10, r * oplane * 4, 0);
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y11), rsrc, v11, r * oplane * 4, 0);
+          // odd H or W: a second row outside the image is not stored; a second column outside the image is stored as ZERO -- it is
+          // the first column of the plane's zero padding (the next layer's halo), so the row still leaves as one 8-byte piece
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          const u32x2 r0 = {__float_as_uint(y00), __float_as_uint(col1 ? y01 : 0.f)}, r1 = {__float_as_uint(y10), __float_as_uint(col1 ? y11 : 0.f)};
+          __builtin_amdgcn_raw_buffer_store_b64(r0, rsrc, r < kmax ? voff : OOB, r * oplane * 4, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(r1, rsrc, r < kmax ? voff10 : OOB, r * oplane * 4, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
