@@ -429,14 +429,18 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
   for (size_t ti = 0; ti < c->tensors.size(); ++ti) {
     Tensor &t = c->tensors[ti];
     t.per_image = t.nhwc ? (size_t)t.H * t.W * t.ch : t.s3 ? (size_t)t.ch * t.hp * t.wp * 3 / 2 : (size_t)t.ch * t.hp * t.wp / (t.f16 ? 2 : t.i8 ? 4 : 1);
-    int rc = dev_alloc(c, &t.d, t.per_image * c->B);
+    // + 24 rows of slack behind the last plane: a 16-row Winograd tile (conv_wino4.hip.h) stages 18 halo rows from its first row
+    // on, up to 8 more than a plane padded to a multiple of 8 (+ 2) holds -- rows that only feed outputs below the image, which
+    // are never stored, but the last plane's would lie behind the allocation
+    const size_t slack = t.nhwc ? 0 : (size_t)24 * t.wp;
+    int rc = dev_alloc(c, &t.d, t.per_image * c->B + slack);
     if (rc) return rc;
     bool head_input = false;   // read by the head ops, which a submission runs on its tail stream while the next trunk already runs
     for (size_t q = c->head_start; q < c->ops.size(); ++q) head_input |= c->ops[q].in == (int)ti || ((c->ops[q].flags & FLAG_ADD) && c->ops[q].residual == (int)ti);
     if ((int)ti == c->t_det || (int)ti == c->t_desc || head_input) {   // what a submission's tail reads while the next network pass already runs
       t.dr[0] = t.d;
       for (int r = 1; r < RING; ++r)
-        if ((rc = dev_alloc(c, &t.dr[r], t.per_image * c->B))) return rc;
+        if ((rc = dev_alloc(c, &t.dr[r], t.per_image * c->B + slack))) return rc;
     }
   }
   for (uint32_t i = 0; i < no; ++i) {

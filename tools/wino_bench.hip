@@ -77,7 +77,8 @@ int main(int argc, char **argv) {
   const std::vector<float> pk = PACK(w.data(), b.data(), cout, cin);
   float *d_in, *d_out, *d_w;
   const size_t out_n = (size_t)batch * cout * ohp * owp;
-  CK(hipMalloc(&d_in, in.size() * 4)); CK(hipMalloc(&d_out, out_n * 4)); CK(hipMalloc(&d_w, pk.size() * 4));
+  CK(hipMalloc(&d_in, (in.size() + (size_t)24 * iwp) * 4)); CK(hipMalloc(&d_out, out_n * 4));   // + slack rows: a 16-row tile stages halo rows below the last plane's padding
+  CK(hipMemset(d_in, 0, (in.size() + (size_t)24 * iwp) * 4)); CK(hipMalloc(&d_w, pk.size() * 4));
   CK(hipMemcpy(d_in, in.data(), in.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemset(d_out, 0, out_n * 4));
   ConvArgs a{};
