@@ -147,6 +147,63 @@ def test_winograd_layers_stay_at_fp32_rounding_level(vgg_weights_path, vgg_plan,
             assert errs[mode][k] <= 4 * errs["direct"][k] + 2e-7, (mode, k, errs["direct"][k], errs[mode][k])
 
 
+def _awkward_plan(seed):
+    """A small graph whose 3x3 layers have the shapes VGG does not: channel counts that are not multiples of 64 (partial output
+    tiles), 16 .. 72 input channels (4 .. 18 items per tile; the loader wants multiples of 8), a linear layer, pooled and unpooled
+    layers at every level."""
+    from spvo import weights as Wm
+    rng = np.random.RandomState(seed)
+    p = Wm.Plan()
+    cur = p.add_tensor(1, 0)
+    p.input_tensor = cur
+    layers = [(1, 16, True, False), (16, 72, True, True), (72, 24, False, False), (24, 40, True, True), (40, 48, True, False), (48, 16, True, True), (16, 32, True, False)]
+    level = 0
+    for ci, co, relu, pool in layers:
+        if pool:
+            level += 1
+        nxt = p.add_tensor(co, level)
+        w = (rng.randn(co, ci, 3, 3) * np.sqrt(2.0 / (ci * 9))).astype(np.float32)
+        b = (rng.randn(co) * 0.05).astype(np.float32)
+        p.ops.append(Wm.Op(Wm.OP_CONV, cur, nxt, 0, ci, co, 3, (Wm.FLAG_RELU if relu else 0) | (Wm.FLAG_POOL if pool else 0), w, b))
+        cur = nxt
+    det, draw, desc = p.add_tensor(Wm.DET_CHANNELS, 3), p.add_tensor(Wm.DESC_CHANNELS, 3), p.add_tensor(Wm.DESC_CHANNELS, 3)
+    for out, co in ((det, Wm.DET_CHANNELS), (draw, Wm.DESC_CHANNELS)):
+        w = (rng.randn(co, 32, 1, 1) * np.sqrt(1.0 / 32)).astype(np.float32)
+        p.ops.append(Wm.Op(Wm.OP_CONV, cur, out, 0, 32, co, 1, 0, w, (rng.randn(co) * 0.05).astype(np.float32)))
+    p.ops.append(Wm.Op(Wm.OP_L2NORM, draw, desc, 0, Wm.DESC_CHANNELS, Wm.DESC_CHANNELS))
+    p.det_tensor, p.desc_tensor = det, desc
+    return p
+
+
+@pytest.mark.parametrize("H,W", [(96, 168), (104, 200), (120, 392)])
+@pytest.mark.parametrize("mode", ["f4x4", "f2x2"])
+def test_winograd_kernels_on_awkward_layer_shapes(H, W, mode, sample_images, monkeypatch, tmp_path):
+    """Both Winograd kernels, forced onto every 3x3 layer of a graph with partial output tiles, short item chains and odd-sized
+    maps (104 x 200 -> 52 x 100 -> 26 x 50 -> 13 x 25), against the oracle on every tensor."""
+    from spvo import capi, weights as Wm
+    plan = _awkward_plan(3)
+    path = str(tmp_path / "awkward.spvw")
+    Wm.save(plan, path)
+    monkeypatch.setenv("SPVO_WINOGRAD_MIN_TILES", "1")
+    monkeypatch.setenv("SPVO_WINO4_MIN_TILES", "1")
+    monkeypatch.setenv("SPVO_WINO4", "1" if mode == "f4x4" else "0")
+    x = _input(sample_images, H, W, 2)
+    rdet, rdesc, vals = net.forward(plan, x, return_all=True)
+    ctx = capi.Context(net_height=H, net_width=W)
+    ctx.load_weights(path)
+    fams = [ctx.stage_kernel(f"conv:{i}")[0] for i in range(1, 7)]
+    assert all(f.startswith("conv_wino") for f in fams), fams
+    assert ("conv_wino4_kernel" in fams) == (mode == "f4x4"), fams
+    det, desc = ctx.forward(x)
+    for tid, (ch, lvl) in enumerate(plan.tensors):
+        if tid in (plan.input_tensor, plan.desc_tensor):
+            continue
+        got = ctx.debug_tensor(tid, 2, ch, lvl)
+        assert np.abs(got - vals[tid]).max() <= _tol(vals[tid]), (f"tensor {tid}", fams)
+    assert np.abs(det - rdet).max() <= _tol(rdet) and np.abs(desc - rdesc.transpose(0, 2, 3, 1)).max() <= 1e-4
+    ctx.close()
+
+
 def test_fp32_split_mode_rejects_other_graphs(squeeze_weights_path):
     from spvo import capi
     ctx = capi.Context()
