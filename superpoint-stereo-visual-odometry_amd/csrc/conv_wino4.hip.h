@@ -112,6 +112,17 @@ __device__ __forceinline__ void wino4_out4(const float m0, const float m1, const
   y[3] = fmaf(8.f, d, b) + m5;
 }
 
+// the same on two output channels at once (v_pk_add_f32 / v_pk_fma_f32: the epilogue has no matrix instructions to hide behind)
+typedef float wino4_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void wino4_out4(const wino4_f32x2 m0, const wino4_f32x2 m1, const wino4_f32x2 m2, const wino4_f32x2 m3, const wino4_f32x2 m4,
+                                           const wino4_f32x2 m5, wino4_f32x2 (&y)[4]) {
+  const wino4_f32x2 a = m1 + m2, b = m1 - m2, c = m3 + m4, d = m3 - m4;
+  y[0] = (m0 + a) + c;
+  y[1] = __builtin_elementwise_fma(wino4_f32x2{2.f, 2.f}, d, b);
+  y[2] = __builtin_elementwise_fma(wino4_f32x2{4.f, 4.f}, c, a);
+  y[3] = __builtin_elementwise_fma(wino4_f32x2{8.f, 8.f}, d, b) + m5;
+}
+
 template <bool POOL, bool RELU, int TAG = 0>
 __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
   using T = Wino4Tile;
@@ -362,18 +373,28 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
     auto relu = [](float v) { return RELU ? __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()) : v; };
     const int oy = cur.y0 + 4 * trow, ox = cur.x0 + 4 * tcol;                  // first output pixel of this lane's tile
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float bias_v = bias_p[r < kmax ? r : 0];
-      float z[6][4];   // column pass: z[j][.] = A^T M[., j]
+    for (int rp = 0; rp < 2; ++rp) {   // channels 2 rp, 2 rp + 1 of this lane's four: two per vector instruction
+      typedef wino4_f32x2 f32x2;
+      const f32x2 bias_v = {bias_p[2 * rp < kmax ? 2 * rp : 0], bias_p[2 * rp + 1 < kmax ? 2 * rp + 1 : 0]};
+      auto pr = [&](int p) { return f32x2{acc[p][2 * rp], acc[p][2 * rp + 1]}; };
+      f32x2 z[6][4];   // column pass: z[j][.] = A^T M[., j]
 #pragma unroll
-      for (int j = 0; j < 6; ++j) wino4_out4(acc[0 + j][r], acc[6 + j][r], acc[12 + j][r], acc[18 + j][r], acc[24 + j][r], acc[30 + j][r], z[j]);
-      float y[4][4];   // row pass: y[i][.] = A^T z[., i]
+      for (int j = 0; j < 6; ++j) wino4_out4(pr(0 + j), pr(6 + j), pr(12 + j), pr(18 + j), pr(24 + j), pr(30 + j), z[j]);
+      f32x2 y2[4][4];   // row pass: y[i][.] = A^T z[., i]
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        wino4_out4(z[0][i], z[1][i], z[2][i], z[3][i], z[4][i], z[5][i], y[i]);
+        wino4_out4(z[0][i], z[1][i], z[2][i], z[3][i], z[4][i], z[5][i], y2[i]);
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) y[i][jj] = relu(y[i][jj] + bias_v);
+        for (int jj = 0; jj < 4; ++jj) y2[i][jj] += bias_v;
       }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+      const int r = 2 * rp + e;
+      float y[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) y[i][jj] = relu(y2[i][jj][e]);
       const bool ch_ok = r < kmax;
       // Stores: one 16-byte piece per tile row (8 bytes per pooled row).  A tile that straddles the right edge writes ZEROS into
       // the plane's right padding (at least PADX = 4 columns, zero by construction and read as such by the next layer's halo),
@@ -402,6 +423,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
                            __float_as_uint(ox + 3 < a.W ? y[i][3] : 0.f)};
           __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (WINO4_ABL & 16) ? OOB : vo, r * oplane * 4, 0);
         }
+      }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
