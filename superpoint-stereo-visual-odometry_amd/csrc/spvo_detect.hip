@@ -469,7 +469,9 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   // On the tail stream (SPVO_HEADS_ON_NET=0, the arrangement until the trunk's kernels became persistent one-workgroup-per-CU
   // launches) they run beside the next pair's conv1b, which leaves them 12 CUs: the tail then finishes late, the host hands the
   // next pair over late and the network stream idles 50-70 us per pair (1257-1265 against 1308 frames/s on one box).
-  static const bool heads_on_net = !(std::getenv("SPVO_HEADS_ON_NET") && std::atoi(std::getenv("SPVO_HEADS_ON_NET")) == 0);
+  // INT8 engines keep them on the tail stream: their trunk has no such launches and the overlap pays (2360 against 2237 frames/s
+  // on config 5; FP16 engines: 3108 against 3084 either way).  SPVO_HEADS_ON_NET=0 / 1 overrides.
+  const bool heads_on_net = std::getenv("SPVO_HEADS_ON_NET") ? std::atoi(std::getenv("SPVO_HEADS_ON_NET")) != 0 : !c->int8;
   if (heads_on_net) {
     rc = run_ops(c, 2, c->head_start, c->ops.size(), c->stream);
     if (rc) { c->cur_ring = 0; return rc; }
