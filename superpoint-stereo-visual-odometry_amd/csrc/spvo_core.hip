@@ -774,6 +774,12 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
     for (auto &o : c->ops) if (o.type == OP_CONV && (!best || o.flops_per_image > best->flops_per_image)) best = &o;
     if (best) best->dominant = true;
   }
+  {   // where a submission's heads run (spvo_detect.hip): behind the trunk on the network stream when most of the trunk's work is in
+      // launches of one 512-thread workgroup per CU (conv_wino4.hip.h), beside which they would starve; on the tail stream otherwise
+    double all = 0, big = 0;
+    for (const auto &o : c->ops) if (o.type == OP_CONV) { all += o.flops_per_image; if (o.wino4) big += o.flops_per_image; }
+    c->heads_on_net = big > 0.8 * all;   // VGG fp32 at 360x1176: 0.95 (on the network stream: 1308 against 1260 frames/s); sp_squeeze: 0.66 (tail stream: 1286 against 1248)
+  }
   const Tensor &td = c->tensors[c->t_det];
   const Tensor &ts = c->tensors[c->t_desc];
   if (td.ch != 65 || td.level != 3 || td.nhwc || !ts.nhwc || c->tensors[c->t_input].ch != 1 || c->tensors[c->t_input].level != 0)

@@ -469,9 +469,10 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   // On the tail stream (SPVO_HEADS_ON_NET=0, the arrangement until the trunk's kernels became persistent one-workgroup-per-CU
   // launches) they run beside the next pair's conv1b, which leaves them 12 CUs: the tail then finishes late, the host hands the
   // next pair over late and the network stream idles 50-70 us per pair (1257-1265 against 1308 frames/s on one box).
-  // INT8 engines keep them on the tail stream: their trunk has no such launches and the overlap pays (2360 against 2237 frames/s
-  // on config 5; FP16 engines: 3108 against 3084 either way).  SPVO_HEADS_ON_NET=0 / 1 overrides.
-  const bool heads_on_net = std::getenv("SPVO_HEADS_ON_NET") ? std::atoi(std::getenv("SPVO_HEADS_ON_NET")) != 0 : !c->int8;
+  // Engines whose trunk is not made of such launches keep them on the tail stream, where the overlap pays (sp_squeeze fp32 1286
+  // against 1248 frames/s, INT8 sp_mbv1 2360 against 2237, FP16 VGG at 192x640 3084 against 3108: either way): the plan loader
+  // decides (spvo_ctx::heads_on_net).  SPVO_HEADS_ON_NET=0 / 1 overrides.
+  const bool heads_on_net = std::getenv("SPVO_HEADS_ON_NET") ? std::atoi(std::getenv("SPVO_HEADS_ON_NET")) != 0 : c->heads_on_net;
   if (heads_on_net) {
     rc = run_ops(c, 2, c->head_start, c->ops.size(), c->stream);
     if (rc) { c->cur_ring = 0; return rc; }

@@ -259,6 +259,7 @@ struct spvo_ctx {
   int prof_only = -1;            // >= 0: only this stage is timed (spvo_profile_only)
   std::vector<Stage> stages;
   std::vector<Pending> pending;
+  bool heads_on_net = false;       // set by the plan loader: the heads of a submission stay on the network stream (VGG fp32) or go to the tail stream
   std::vector<hipEvent_t> free_events;
 };
 
