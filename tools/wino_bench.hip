@@ -62,7 +62,7 @@ int main(int argc, char **argv) {
   const int reps = argc > 6 ? atoi(argv[6]) : 50;
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
-  const int cus = prop.multiProcessorCount, batch = 2;
+  const int cus = prop.multiProcessorCount, batch = getenv("WINO_BATCH") ? atoi(getenv("WINO_BATCH")) : 2;
   const int ihp = padded_h(H), iwp = padded_w(W), OH = pool ? H / 2 : H, OW = pool ? W / 2 : W, ohp = padded_h(OH), owp = padded_w(OW);
   std::mt19937 rng(1);
   std::uniform_real_distribution<float> ud(-1.f, 1.f);
@@ -77,12 +77,12 @@ int main(int argc, char **argv) {
   const std::vector<float> pk = PACK(w.data(), b.data(), cout, cin);
   float *d_in, *d_out, *d_w;
   const size_t out_n = (size_t)batch * cout * ohp * owp;
-  CK(hipMalloc(&d_in, (in.size() + (size_t)24 * iwp) * 4)); CK(hipMalloc(&d_out, out_n * 4));   // + slack rows: a 16-row tile stages halo rows below the last plane's padding
+  CK(hipMalloc(&d_in, (in.size() + (size_t)24 * iwp) * 4)); CK(hipMalloc(&d_out, (out_n + 1024) * 4));   // + slack rows: a 16-row tile stages halo rows below the last plane's padding
   CK(hipMemset(d_in, 0, (in.size() + (size_t)24 * iwp) * 4)); CK(hipMalloc(&d_w, pk.size() * 4));
   CK(hipMemcpy(d_in, in.data(), in.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemset(d_out, 0, out_n * 4));
   ConvArgs a{};
-  a.in = d_in; a.out = d_out; a.wpack = d_w; a.bias = nullptr; a.H = H; a.W = W;
+  a.in = d_in; a.out = d_out + (getenv("WINO_OUT_SHIFT") ? atoi(getenv("WINO_OUT_SHIFT")) : 0); a.wpack = d_w; a.bias = nullptr; a.H = H; a.W = W;
   a.in_hp = ihp; a.in_wp = iwp; a.in_ctot = cin; a.in_coff = 0; a.out_hp = ohp; a.out_wp = owp; a.out_ctot = cout; a.out_coff = 0;
 #if defined(WINO4)
   if ((cin & 3) || (pool && ((H | W) & 1))) { printf("WINO4: cin must be a multiple of 4, H and W even when pooling\n"); return 1; }
