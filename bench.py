@@ -165,11 +165,17 @@ def pin_to_gpu_numa_node(torch, local_rank):
         return None
 
 
-def spawn_ranks(n):
-    """`python bench.py --gpus N` without a launcher: start N ranks of this script, one per GPU, exactly as
-    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` would (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
-    environment).  The children are fresh interpreters started BEFORE this process has touched the GPU or imported torch (never
-    re-exec a process that has initialised HIP); rank 0 inherits stdout and prints the one JSON line."""
+def spawn_ranks(n, cmd=None, deadline_s=None, grace_s=5.0, poll_s=0.1):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (or of `cmd`, a test hook), one per GPU,
+    exactly as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` would (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+    in the environment).  The children are fresh interpreters started BEFORE this process has touched the GPU or imported
+    torch (never re-exec a process that has initialised HIP); rank 0 inherits stdout and prints the one JSON line.
+
+    The children are POLLED: the first rank that exits non-zero (out of memory, RCCL initialisation, a crash) has its siblings
+    terminated -- SIGTERM, then SIGKILL after `grace_s` -- instead of leaving them in `dist.barrier()` / `ncclAllGather` until
+    somebody's timeout; the launcher then returns that rank's exit code with the tail of its stderr on ours.  `deadline_s`
+    (default: SPVO_BENCH_RANK_DEADLINE or 1500 s) bounds the whole job the same way."""
+    import signal
     import socket
     import subprocess
     port = os.environ.get("MASTER_PORT")
@@ -177,15 +183,74 @@ def spawn_ranks(n):
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = str(sk.getsockname()[1])
-    procs = []
+    if deadline_s is None:
+        deadline_s = float(os.environ.get("SPVO_BENCH_RANK_DEADLINE", "1500"))
+    cmd = list(cmd) if cmd else [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    logdir = tempfile.mkdtemp(prefix="spvo_ranks_")
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for pr in procs:
-        rc = max(rc, abs(pr.wait()))
+        logs.append(open(os.path.join(logdir, f"rank{r}.stderr"), "w+b"))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else subprocess.DEVNULL, stderr=logs[-1]))
+
+    def tail(r, nbytes=3000):
+        logs[r].flush()
+        logs[r].seek(0, os.SEEK_END)
+        size = logs[r].tell()
+        logs[r].seek(max(0, size - nbytes))
+        return logs[r].read().decode("utf-8", "replace")
+
+    def stop_all():   # our own children only, by their exact pids (they stay in this process group: whoever kills the group gets them too)
+        alive = [pr for pr in procs if pr.poll() is None]
+        for pr in alive:
+            pr.terminate()
+        t_end = time.time() + grace_s
+        while time.time() < t_end and any(pr.poll() is None for pr in alive):
+            time.sleep(poll_s)
+        for pr in alive:
+            if pr.poll() is None:
+                pr.kill()
+                pr.wait()
+
+    class Stopped(Exception):
+        pass
+
+    def on_signal(signum, _frame):   # the launcher itself is being stopped: take the ranks along
+        raise Stopped(signum)
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
+
+    t0 = time.time()
+    rc, failed = 0, None
+    try:
+        while True:
+            codes = [pr.poll() for pr in procs]
+            bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed, rc = bad[0], abs(codes[bad[0]]) or 1
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() - t0 > deadline_s:
+                failed, rc = -1, 124
+                break
+            time.sleep(poll_s)
+    except Stopped as st:
+        stop_all()
+        return 128 + int(st.args[0])
+    finally:
+        for sg, h in old.items():
+            signal.signal(sg, h)
+    if failed is not None:
+        stop_all()
+        if failed >= 0:
+            sys.stderr.write(f"bench.py: rank {failed} of {n} exited with code {rc}; the other ranks were terminated.  Its stderr ends:\n{tail(failed)}\n")
+        else:
+            sys.stderr.write(f"bench.py: the {n} ranks did not finish within {deadline_s:.0f} s and were terminated.  Rank 0's stderr ends:\n{tail(0)}\n")
+    else:
+        sys.stderr.write(tail(0, 1 << 20))   # rank 0's diagnostics, as if it had written them itself
+    for f in logs:
+        f.close()
     return rc
 
 
@@ -278,13 +343,17 @@ def main():
     if dist_on and "RANK" not in os.environ:
         os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": os.environ.get("MASTER_PORT", "29533")})
     if dist_on:
+        import datetime
+        # a peer that died leaves a collective waiting: bound that wait (the launcher -- spawn_ranks or torch.distributed.run -- stops the
+        # job as soon as it sees the dead rank; this is the backstop)
+        dist_timeout = datetime.timedelta(seconds=int(os.environ.get("SPVO_BENCH_DIST_TIMEOUT", "300")))
         if shared:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=dist_timeout)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=dist_timeout)
 
-    if world > 1:   # several ranks share the host: do not let each of them spin up one CPU thread per core
-        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
+    if world > 1:   # several ranks share the host: an equal share of the CPUs this job may really use (cgroup quota, not the host's core count)
+        torch.set_num_threads(max(1, usable_cpus() // world))
     from spvo import host, posegather, synth, weights
 
     plan = weights.vgg_plan(seed=0) if args.graph == "vgg" else weights.load(os.path.join(ROOT, "tests", "golden", args.graph + ".spvw"))

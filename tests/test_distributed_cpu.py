@@ -107,3 +107,81 @@ def test_c_abi_comm_rejects_bad_arguments_and_needs_a_gpu_for_rccl(tmp_path):
     assert np.array_equal(c.allgather(poses[0]), poses[None, :1])
     c.close()
     assert not any(f.startswith("pose_") for f in os.listdir(tmp_path))                        # files cleaned up
+
+
+# ---- bench.py's own launcher (`python bench.py --gpus N` without torch.distributed.run): a rank that dies must not leave its
+# ---- siblings waiting in a collective until somebody's timeout (BASELINE config 4: one try on the 8-GPU node)
+_RANK_SCRIPT = '''
+import os, sys, time
+import torch.distributed as dist
+rank = int(os.environ["RANK"])
+open(os.path.join(sys.argv[1], f"pid{rank}"), "w").write(str(os.getpid()))
+dist.init_process_group("gloo")
+dist.barrier()
+sys.stderr.write(f"rank {rank}: past the first barrier\\n")
+sys.stderr.flush()
+if sys.argv[2] == "die" and rank == 1:
+    sys.stderr.write("rank 1: simulated failure (out of memory)\\n")
+    sys.stderr.flush()
+    os._exit(3)
+if sys.argv[2] == "die":
+    time.sleep(600)          # rank 0: stuck, as in a collective whose peer is gone
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _pid_alive(pid):
+    try:
+        os.kill(pid, 0)
+    except OSError:
+        return False
+    try:   # a zombie of ours would still answer: it must have been reaped
+        return open(f"/proc/{pid}/stat").read().split()[2] != "Z"
+    except OSError:
+        return False
+
+
+def test_launcher_stops_the_job_when_a_rank_dies(tmp_path, capfd):
+    import sys
+    import time
+    import bench
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    env_keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
+    saved = {k: os.environ.pop(k) for k in env_keys if k in os.environ}
+    try:
+        t0 = time.time()
+        rc = bench.spawn_ranks(2, cmd=[sys.executable, str(script), str(tmp_path), "die"], grace_s=2.0)
+        took = time.time() - t0
+    finally:
+        os.environ.update(saved)
+    err = capfd.readouterr().err
+    assert rc == 3 and took < 30.0, (rc, took, err)
+    assert "rank 1 of 2 exited with code 3" in err and "simulated failure" in err
+    for r in (0, 1):   # nobody is left behind
+        assert not _pid_alive(int((tmp_path / f"pid{r}").read_text()))
+
+
+def test_launcher_returns_zero_and_forwards_rank0_diagnostics(tmp_path, capfd):
+    import sys
+    import bench
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    rc = bench.spawn_ranks(2, cmd=[sys.executable, str(script), str(tmp_path), "ok"])
+    err = capfd.readouterr().err
+    assert rc == 0 and "rank 0: past the first barrier" in err and "rank 1" not in err
+
+
+def test_launcher_deadline_terminates_a_hung_job(tmp_path, capfd):
+    import sys
+    import time
+    import bench
+    script = tmp_path / "hang.py"
+    script.write_text("import os, sys, time\nopen(os.path.join(sys.argv[1], 'pid' + os.environ['RANK']), 'w').write(str(os.getpid()))\ntime.sleep(600)\n")
+    t0 = time.time()
+    rc = bench.spawn_ranks(2, cmd=[sys.executable, str(script), str(tmp_path)], deadline_s=3.0, grace_s=2.0)
+    assert rc == 124 and time.time() - t0 < 20.0
+    assert "did not finish within 3 s" in capfd.readouterr().err
+    for r in (0, 1):
+        assert not _pid_alive(int((tmp_path / f"pid{r}").read_text()))
