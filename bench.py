@@ -34,6 +34,8 @@ NET_H, NET_W = 360, 1176
 SEQ_LEN = 8
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 F16_MFMA_PEAK_TFLOPS = 2500.0   # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense" (the FP16 engines of config 3)
+HBM_PEAK_GBPS = 8000.0           # same guide, "HBM3E ~8 TB/s"
+I8_MFMA_PEAK_TOPS = 5000.0      # same guide, MFMA table: I8 32x32x32 = the cycles of the BF16 form at 2x the K (the INT8 engines of config 5)
 
 
 def cpu_model():
@@ -276,7 +278,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=0, help="timed blocks of --steps steps (default 0: as many as make about one second, 5..200); the line reports the median block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational second measurement (FP32 engine in split mode)")
-    ap.add_argument("--legs", default="split,host,trained,classic", help="informational legs to run after the headline (comma list of split, host, trained, classic)")
+    ap.add_argument("--legs", default="split,host,trained,classic,configs", help="informational legs to run after the headline (comma list of split, host, trained, classic, configs)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--no-pipeline", action="store_true", help="do not hand the next stereo pairs over early")
     ap.add_argument("--sync-solve", action="store_true", help="solve inside the step (solveStereoOdometry in one piece) instead of handing every frame's solve over and "
@@ -506,7 +508,7 @@ def main():
             **headline_spread, "timing": "median of `repeats` timed blocks of `steps` steps each (barrier + synchronize on both sides, max over ranks per block)",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 as 3 x bf16 (split operands, fp32 accumulate)" if args.fp32_split else {"FP32": "f32", "FP16": "f16", "INT8": "i8"}[args.precision], "data": "synthetic",
             "config": {"workload": (f"SuperPoint VGG {args.precision.lower()} (seeded synthetic weights, {n_params} params)" if args.graph == "vgg" else
-                                    f"SuperPoint {args.graph} {args.precision.lower()} (the reference's ONNX graph, seeded weights, {n_params} params)")
+                                    f"SuperPoint {args.graph} {args.precision.lower()} (the reference's TRAINED ONNX graph, re-packed as tests/golden/{args.graph}.spvw, {n_params} params)")
                                    + f", 1241x376 stereo pairs, net {NET_H}x{NET_W}, {args.max_keypoints} kp cap, "
                                    + ("fp8 shortlist + exact re-rank, " if args.match_fp8 else "")
                                    + "BF+KNN 0.8, P3P-style RANSAC 500 it, LM refinement degree 4; one stereo stream per GPU, RCCL all-gather of poses",
@@ -669,6 +671,87 @@ def main():
                                                         "seeded test pairs and fixed rounding choices, so descriptors are not comparable with OpenCV's cv::ORB"}
             except Exception as exc:   # the headline line must survive a failure of this informational part
                 out["classic_front_end_gpu"] = {"error": repr(exc)}
+        if world == 1 and headline and not args.no_extras and "configs" in legs:
+            # The other GPU configurations of BASELINE.json and the second network size of SURVEY.md section 8d, never `value`: each is
+            # the SAME loop (two pairs handed over ahead, deferred solve) on an engine of its own, timed like the other legs (blocks of
+            # >= 100 steps, the median block), followed by a short pass with every stage bracketed by events that names the dominant
+            # convolution launch and the fraction of its roofline it reaches.
+            from spvo import quant
+            other_specs = [
+                ("native_376x1240", "vgg", "FP32", (376, 1240), 1000, False,
+                 "BASELINE configs[1] at the native network size (SURVEY.md section 8d: report both sizes)"),
+                ("config3_fp16_192x640", "vgg", "FP16", (192, 640), 1000, False,
+                 "BASELINE configs[2]: SuperPoint fp16, 640x192 downscaled input (engine_generation.py:20-24 FP16 engines)"),
+                ("config5_int8_mbv1_2048kp_fp8", "sp_mbv1", "INT8", (360, 1176), 2048, True,
+                 "BASELINE configs[4]: MobileNet-backbone SuperPoint int8 + 2048-keypoint cap, fp8 shortlist GEMM + exact fp32 re-rank"),
+            ]
+            out["other_configs"] = {}
+            for oname, ograph, oprec, (oh, ow), okp, ofp8, owhat in other_specs:
+                try:
+                    fe.close()
+                    oplan = weights.vgg_plan(seed=0) if ograph == "vgg" else weights.load(os.path.join(ROOT, "tests", "golden", ograph + ".spvw"))
+                    o_params = int(sum(op.weight.size + op.bias.size for op in oplan.ops if op.weight is not None))
+                    if oprec == "INT8":
+                        ocal = [quant.calibration_inputs(oplan, frames[k], oh, ow) for k in (0, SEQ_LEN // 2, SEQ_LEN - 1)]
+                        oplan.act_scales = quant.calibrate(oplan, ocal, oh, ow)
+                    oplan.precision = oprec
+                    oprefix = "superpoint_pretrained" if ograph == "vgg" else ograph
+                    odir = os.path.join(tmp, oname)
+                    os.makedirs(os.path.join(odir, "laptop"), exist_ok=True)
+                    weights.save(oplan, os.path.join(odir, "laptop", weights.engine_name(oprefix, 2, oh, ow, oprec)))
+                    oenv = {"SPVO_MAX_KEYPOINTS": str(okp) if okp != 1000 else None, "SPVO_MATCH_FP8": "1" if ofp8 else None}
+                    for k, v in oenv.items():
+                        if v is not None:
+                            os.environ[k] = v
+                    try:
+                        fe = host.FrontEnd(odir, prefix=oprefix, selector="KNN", cross_check=True, batch=2, height=oh, width=ow, conf_thresh=0.015,
+                                           dist_thresh=4, border_remove=4, stereo_threshold=2.0, min_disparity=0.25, refinement_degree=4, precision=oprec)
+                    finally:
+                        for k, v in oenv.items():
+                            if v is not None:
+                                del os.environ[k]
+                    if not fe.engine_loaded:
+                        raise RuntimeError("engine load failed: " + fe.last_error)
+                    for i in range(args.warmup):
+                        step(i)
+                    fe.finish_solve()
+                    eo, spo = leg(lambda i: step(i), lambda: fe.finish_solve())
+                    rec = {"what": owhat, "value": round(args.steps / eo, 2), "unit": "stereo frames/s", "ms_per_step": round(1e3 * eo / args.steps, 4), **spo,
+                           "dtype": {"FP32": "f32", "FP16": "f16", "INT8": "i8"}[oprec],
+                           "workload": (f"SuperPoint VGG {oprec.lower()} (seeded synthetic weights, {o_params} params)" if ograph == "vgg" else
+                                        f"SuperPoint {ograph} {oprec.lower()} (the reference's TRAINED ONNX graph, {o_params} params; activation scales calibrated on this stream)")
+                                       + f", 1241x376 stereo pairs, net {oh}x{ow}, {okp} kp cap" + (", fp8 shortlist + exact re-rank" if ofp8 else "")}
+                    octx = fe.context()
+                    octx.profile_only(None)
+                    octx.profile_enable(True)
+                    octx.profile_reset()
+                    for i in range(50):
+                        step(i)
+                    fe.finish_solve()
+                    barrier()
+                    oprof = octx.profile()
+                    octx.profile_enable(False)
+                    convs = {k: v for k, v in oprof.items() if k.startswith("conv:") and v["calls"] and v["flops"] > 0}
+                    if convs:
+                        dk = max(convs, key=lambda k: convs[k]["total_ms"])
+                        dms = convs[dk]["total_ms"] / convs[dk]["calls"]
+                        kfam, kfac = octx.stage_kernel(dk)
+                        opeak, ounit = {"FP32": (FP32_MFMA_PEAK_TFLOPS, "TFLOP/s"), "FP16": (F16_MFMA_PEAK_TFLOPS, "TFLOP/s"), "INT8": (I8_MFMA_PEAK_TOPS, "TOP/s")}[oprec]
+                        oexec = convs[dk]["flops"] * kfac / (dms * 1e-3) / 1e12            # `flops` = algorithmic operations of ONE launch
+                        stack_ms = sum(v["total_ms"] / v["calls"] for v in convs.values())
+                        obytes = convs[dk].get("bytes", 0.0)                                  # algorithmic HBM bytes of one launch, where the library states them
+                        ogbps = obytes / (dms * 1e-3) / 1e9 if obytes else None
+                        # the roofline that bounds the launch: the larger of (executed operations / matrix peak) and (algorithmic bytes / 8 TB/s)
+                        hbm_bound = bool(obytes) and obytes / (HBM_PEAK_GBPS * 1e9) > convs[dk]["flops"] * kfac / (opeak * 1e12)
+                        rec["dominant_kernel"] = {"stage": dk, "kernel": kfam, "avg_kernel_ms": round(dms, 5), "executed_per_algorithmic": round(kfac, 4),
+                                                  "bound": "hbm" if hbm_bound else "mfma",
+                                                  "achieved": round(oexec, 2), "peak": opeak, "unit": ounit, "frac": round(oexec / opeak, 4),
+                                                  "algorithmic_GBps": round(ogbps, 1) if ogbps else None, "frac_of_hbm_peak": round(ogbps / HBM_PEAK_GBPS, 4) if ogbps else None,
+                                                  "conv_stack_sum_ms": round(stack_ms, 4),
+                                                  "_source": "separate pass of 50 steps with every stage bracketed by HIP events (runs ~7 % slower than the timed blocks)"}
+                    out["other_configs"][oname] = rec
+                except Exception as exc:   # the headline line must survive a failure of this informational part
+                    out["other_configs"][oname] = {"error": repr(exc)}
         if not args.no_cpu_baseline and world == 1 and headline:
             try:
                 out["cpu_baseline"] = cpu_baseline(frames, P_l, P_r, engine_path, order)

@@ -22,8 +22,10 @@ def _h(t: torch.Tensor) -> torch.Tensor:
     return t.half().float()
 
 
-def forward(plan: W.Plan, x: np.ndarray, return_all: bool = False):
-    """x: float32 [B,1,H,W].  Returns (det, desc) as float32 numpy NCHW.
+def forward(plan: W.Plan, x: np.ndarray, return_all: bool = False, f64: bool = False):
+    """x: float32 [B,1,H,W].  Returns (det, desc) as float32 numpy NCHW (float64 with `f64`: the same graph evaluated in
+    double precision from the same fp32 weights and input -- the yardstick the tests use for "fp32 rounding level",
+    FP32 plans only).
 
     plan.precision == "FP16" restates an engine built by engine_generation.py:13-56 with --fp16: the bindings stay
     fp32 (nn.cpp:117) and everything between them is half precision.  TensorRT's internal choices (which layers it
@@ -37,14 +39,17 @@ def forward(plan: W.Plan, x: np.ndarray, return_all: bool = False):
     vals = {}
     vals[plan.input_tensor] = torch.from_numpy(x)
     fp16 = plan.precision == "FP16"
+    assert not (fp16 and f64)
+    dt = torch.float64 if f64 else torch.float32
+    vals[plan.input_tensor] = vals[plan.input_tensor].to(dt)
     keep_f32 = {plan.input_tensor, plan.det_tensor, plan.desc_tensor} | {op.inp for op in plan.ops if op.type == W.OP_L2NORM}
     for op in plan.ops:
         src = vals[op.inp]
         in_off = getattr(op, "in_c_off", 0)
         if op.type in (W.OP_CONV, W.OP_DWCONV):
             xin = src[:, in_off:in_off + op.cin]
-            wt = torch.from_numpy(op.weight)
-            y = F.conv2d(xin, _h(wt) if fp16 else wt, torch.from_numpy(op.bias),
+            wt = torch.from_numpy(op.weight).to(dt)
+            y = F.conv2d(xin, _h(wt) if fp16 else wt, torch.from_numpy(op.bias).to(dt),
                          stride=1, padding=op.ksize // 2,
                          groups=op.cin if op.type == W.OP_DWCONV else 1)
             if op.flags & W.FLAG_RELU:
@@ -52,7 +57,7 @@ def forward(plan: W.Plan, x: np.ndarray, return_all: bool = False):
             if op.flags & W.FLAG_BN:
                 # ONNX BatchNormalization (inference): (x - mean) / sqrt(var + eps) * gamma + beta
                 c = op.cout
-                gam, bet, mean, var = (torch.from_numpy(op.bn[i * c:(i + 1) * c].copy()) for i in range(4))
+                gam, bet, mean, var = (torch.from_numpy(op.bn[i * c:(i + 1) * c].copy()).to(dt) for i in range(4))
                 y = F.relu(F.batch_norm(y, mean, var, gam, bet, training=False, eps=float(op.bn[4 * c])))
             if op.flags & W.FLAG_ADD:
                 y = F.relu(y + vals[op.residual])
@@ -60,7 +65,7 @@ def forward(plan: W.Plan, x: np.ndarray, return_all: bool = False):
                 y = F.max_pool2d(y, 2, 2)
             ch, lvl = plan.tensors[op.out]
             if op.out not in vals:
-                vals[op.out] = torch.zeros((B, ch, H >> lvl, Wd >> lvl), dtype=torch.float32)
+                vals[op.out] = torch.zeros((B, ch, H >> lvl, Wd >> lvl), dtype=dt)
             vals[op.out][:, op.out_c_off:op.out_c_off + op.cout] = _h(y) if fp16 and op.out not in keep_f32 else y
         elif op.type == W.OP_MAXPOOL:
             vals[op.out] = F.max_pool2d(src, 2, 2)

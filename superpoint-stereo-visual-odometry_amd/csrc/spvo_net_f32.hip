@@ -252,7 +252,13 @@ int launch_op(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream
   const Tensor &ti = c->tensors[op.in];
   const Tensor &to = c->tensors[op.out];
   if (op.type == OP_CONV || op.type == OP_DWCONV) {
-    ScopedStage st(c, op.stage, op.flops_per_image * batch, 0, stream);
+    // algorithmic HBM bytes of the launch: the input channels it reads, the output channels it writes (after the
+    // fused pooling), its weights once -- interiors only, in the element size of the engine's tensors
+    auto esz = [](const Tensor &t) { return t.i8 ? 1.0 : (t.f16 || t.s3) ? (t.s3 ? 6.0 : 2.0) : 4.0; };
+    const double wsz = c->int8 ? 1.0 : (c->fp16 ? 2.0 : (c->s3 ? 6.0 : 4.0));
+    const double bytes = batch * ((double)op.cin * ti.H * ti.W * esz(ti) + (double)op.cout * to.H * to.W * esz(to)) +
+                         (double)op.cout * (op.type == OP_DWCONV ? 1 : op.cin) * op.ks * op.ks * wsz;
+    ScopedStage st(c, op.stage, op.flops_per_image * batch, bytes, stream);
     return c->int8 ? launch_conv8(c, op, img0, batch, stream) : c->fp16 ? launch_conv16(c, op, img0, batch, stream)
            : c->s3 ? launch_conv_s3(c, op, img0, batch, stream) : launch_conv(c, op, img0, batch, stream);
   }
@@ -294,7 +300,8 @@ int launch_heads(spvo_ctx *c, int batch, hipStream_t stream) {
   a.desc_raw = c->heads_keep_raw ? ring_ptr(c, traw) : nullptr; a.raw_per_image = traw.per_image;
   a.desc = ring_ptr(c, tdesc);
   a.H = ti.H; a.W = ti.W;
-  ScopedStage st(c, stage_id(c, "heads"), (pb.flops_per_image + db.flops_per_image) * batch, 0, stream);
+  const double hbytes = batch * ((double)(pb.cin + db.cin) * ti.H * ti.W * 4 + (double)(pb.cout + 2 * db.cout) * ti.H * ti.W * 4) + (double)(pb.cout * pb.cin + db.cout * db.cin) * 4;
+  ScopedStage st(c, stage_id(c, "heads"), (pb.flops_per_image + db.flops_per_image) * batch, hbytes, stream);
   hipLaunchKernelGGL(heads_fused_kernel<>, dim3((ti.W + HEADS_PX - 1) / HEADS_PX, ti.H, batch), dim3(256), HEADS_LDS_BYTES, stream, a);
   HIP_TRY(c, hipGetLastError());
   return SPVO_OK;

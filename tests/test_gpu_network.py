@@ -28,7 +28,7 @@ def _input(sample_images, H, W, batch):
     return np.stack(xs)[:, None]
 
 
-@pytest.mark.parametrize("H,W,batch", [(120, 392, 2), (360, 1176, 2), (192, 640, 1), (376, 1240, 2)])
+@pytest.mark.parametrize("H,W,batch", [(120, 392, 2), (360, 1176, 2), (192, 640, 1), (376, 1240, 2), (240, 784, 2)])   # 240x784: the reference's second engine size (engine_generation.py:20)
 def test_vgg_forward_matches_oracle(vgg_weights_path, vgg_plan, sample_images, H, W, batch):
     ctx = make_ctx(vgg_weights_path, net_height=H, net_width=W)
     x = _input(sample_images, H, W, batch)
@@ -106,7 +106,19 @@ def test_fp32_split_mode_matches_oracle_at_fp32_rounding_level(vgg_weights_path,
         assert errs["split"][k] <= 4 * errs["native"][k] + 2e-7, (k, errs["native"][k], errs["split"][k])
 
 
-@pytest.mark.parametrize("H,W,batch", [(360, 1176, 2), (376, 1240, 2), (192, 640, 1)])
+# kernel family of conv1b, conv2a, conv2b, conv3a, conv3b, conv4a, conv4b, convPa(+Da) in the default engine, per network size: the plan
+# loader's tile-count thresholds (csrc/spvo_core.hip, "Winograd F(2x2,3x3) for ..." / "F(4x4,3x3) ...") are pinned here, so that a change of
+# the selection at a size shows up as a test failure, not as a silent change of arithmetic
+_W4, _W2, _DIR = "conv_wino4_kernel", "conv_wino2_kernel", "conv_mfma_kernel"
+DEFAULT_KERNELS = {
+    (360, 1176, 2): [_W4, _W4, _W4, _W4, _W4, _W2, _W2, _W4],
+    (376, 1240, 2): [_W4, _W4, _W4, _W4, _W4, _W2, _W2, _W4],
+    (240, 784, 2): [_W4, _W4, _W4, _W2, _W2, _DIR, _DIR, _W2],      # 30 x 98 cells: conv4a / conv4b have 64 F(2x2) tiles for 256 CUs and stay direct
+    (192, 640, 1): None,
+}
+
+
+@pytest.mark.parametrize("H,W,batch", [(360, 1176, 2), (376, 1240, 2), (192, 640, 1), (240, 784, 2)])
 def test_winograd_layers_stay_at_fp32_rounding_level(vgg_weights_path, vgg_plan, sample_images, H, W, batch, monkeypatch):
     """The default FP32 engine runs its 3x3 layers through the Winograd kernels: F(4x4,3x3) (csrc/conv_wino4.hip.h) where the
     layer has enough 16 x 32 tiles, F(2x2,3x3) (csrc/conv_wino2.hip.h) for the rest; SPVO_WINO4=0 keeps F(2x2) everywhere and
@@ -138,6 +150,8 @@ def test_winograd_layers_stay_at_fp32_rounding_level(vgg_weights_path, vgg_plan,
         errs[mode] = e
         ctx.close()
     print("kernels of conv1b .. convPa:", kernels)
+    if DEFAULT_KERNELS[(H, W, batch)] is not None:
+        assert kernels["f4x4"] == DEFAULT_KERNELS[(H, W, batch)], kernels["f4x4"]
     print("max relative error against float64, direct / F(2x2) / F(4x4):", {k: tuple(float(f"{errs[m][k]:.3g}") for m in errs) for k in errs["direct"]})
     # the switches did switch kernels
     assert all(k == "conv_mfma_kernel" for k in kernels["direct"]) and "conv_wino4_kernel" not in kernels["f2x2"]
@@ -202,6 +216,66 @@ def test_winograd_kernels_on_awkward_layer_shapes(H, W, mode, sample_images, mon
         assert np.abs(got - vals[tid]).max() <= _tol(vals[tid]), (f"tensor {tid}", fams)
     assert np.abs(det - rdet).max() <= _tol(rdet) and np.abs(desc - rdesc.transpose(0, 2, 3, 1)).max() <= 1e-4
     ctx.close()
+
+
+# Distance of an FP32 engine to a float64 evaluation of its graph (oracle/net.py with f64 = True: same fp32 weights and input),
+# per tensor, relative to max(1, max |tensor|).  The yardstick is the fp32 ORACLE's own distance to float64 on the same tensor
+# (torch-CPU fp32: what "an fp32 evaluation in some summation order" costs on this graph -- 1.5e-7 .. 7e-6 depending on the
+# graph: BatchNorm scales of sp_mbv1 amplify it).  Two engines side by side:
+#   * DIRECT kernels only (1x1 / depthwise / BatchNorm / residual layers, every 3x3 layer and the heads with SPVO_WINOGRAD=0 /
+#     SPVO_HEADS_FUSED=0): every tensor within 4 x the oracle's own error + 4e-7;
+#   * the default engine (Winograd 3x3 layers, fused heads): within 4 x the direct engine's error + 2e-7 per tensor, or within
+#     WINOGRAD_F64_LEVEL where the direct kernel happens to be much more accurate than fp32 needs to be.  F(4x4,3x3) on the
+#     TRAINED sp_squeeze weights reaches 6.5e-6 of the tensor maximum (tensor 2 = its conv1b: 6.0e-6 against 4e-7 direct, a ratio
+#     of 14; the seeded VGG weights: 2.5e-6, ratios 0.4 .. 2.7): recorded here, bar 8e-6 = 12 x inside north_star's 1e-4.
+# The 1e-4 bar against the fp32 oracle (above) stays what north_star asks for; this test keeps an accuracy regression from
+# hiding inside it (a kernel 40 x less accurate would still pass 1e-4).
+WINOGRAD_F64_LEVEL = 8e-6
+
+
+@pytest.mark.parametrize("graph,H,W,batch", [("vgg", 360, 1176, 2), ("vgg", 240, 784, 2), ("sp_squeeze", 360, 1176, 2), ("sp_squeeze", 240, 784, 2),
+                                             ("sp_mbv1", 360, 1176, 2), ("sp_mbv2", 360, 1176, 2), ("sp_mbv1", 120, 392, 2), ("sp_mbv2", 120, 392, 2)])
+def test_fp32_engines_stay_at_fp32_rounding_level_against_float64(graph, H, W, batch, vgg_weights_path, vgg_plan, sample_images, monkeypatch):
+    import os
+    from spvo import weights
+    from tests.conftest import GOLDEN
+    path = vgg_weights_path if graph == "vgg" else os.path.join(GOLDEN, graph + ".spvw")
+    plan = vgg_plan if graph == "vgg" else weights.load(path)
+    x = _input(sample_images, H, W, batch)
+    _, _, ref64 = net.forward(plan, x, return_all=True, f64=True)
+    _, _, ref32 = net.forward(plan, x, return_all=True)
+
+    def dist(get):
+        e = {}
+        for tid in range(len(plan.tensors)):
+            if tid in (plan.input_tensor, plan.desc_tensor):
+                continue
+            e[tid] = float(np.abs(get(tid) - ref64[tid]).max() / max(1.0, np.abs(ref64[tid]).max()))
+        return e
+    errs, fams = {"oracle": dist(lambda tid: ref32[tid])}, {}
+    errs["oracle"]["desc"] = float(np.abs(ref32[plan.desc_tensor] - ref64[plan.desc_tensor]).max())
+    for mode in ("direct", "default"):
+        for k in ("SPVO_WINOGRAD", "SPVO_HEADS_FUSED"):
+            if mode == "direct":
+                monkeypatch.setenv(k, "0")
+            else:
+                monkeypatch.delenv(k, raising=False)
+        ctx = make_ctx(path, net_height=H, net_width=W)
+        det, desc = ctx.forward(x)
+        e = dist(lambda tid: ctx.debug_tensor(tid, batch, *plan.tensors[tid]))
+        e["desc"] = float(np.abs(desc - ref64[plan.desc_tensor].transpose(0, 2, 3, 1)).max())
+        fams[mode] = sorted({ctx.stage_kernel(f"conv:{i}")[0] for i, op in enumerate(plan.ops) if op.type == weights.OP_CONV and op.cin > 1})
+        errs[mode] = e
+        ctx.close()
+    worst = {m: max(errs[m], key=errs[m].get) for m in errs}
+    print(f"{graph} {H}x{W}: fp32 oracle worst {errs['oracle'][worst['oracle']]:.3g} (tensor {worst['oracle']}); direct {fams['direct']} worst "
+          f"{errs['direct'][worst['direct']]:.3g} (tensor {worst['direct']}); default {fams['default']} worst {errs['default'][worst['default']]:.3g} (tensor {worst['default']})")
+    assert fams["direct"] == ["conv_mfma_kernel"], fams["direct"]
+    wino = any(f.startswith("conv_wino") for f in fams["default"])
+    for k, v in errs["direct"].items():
+        assert v <= 4 * errs["oracle"][k] + 4e-7, (graph, "direct", k, errs["oracle"][k], v)
+    for k, v in errs["default"].items():
+        assert v <= max(4 * errs["direct"][k] + 2e-7, WINOGRAD_F64_LEVEL if wino else 0.0), (graph, "default", k, errs["direct"][k], v)
 
 
 def test_fp32_split_mode_rejects_other_graphs(squeeze_weights_path):

@@ -43,6 +43,35 @@ def test_detect_matches_oracle_end_to_end(ctx_squeeze, squeeze_plan, stereo_pair
     assert (idx >= 0).sum() > 500
 
 
+@pytest.mark.parametrize("graph", ["vgg", "squeeze"])
+def test_detect_at_the_second_engine_size_matches_oracle(graph, vgg_weights_path, vgg_plan, squeeze_weights_path, squeeze_plan, stereo_pair):
+    """240 x 784 -- the other size engine_generation.py:20 builds engines for (feature_detection.hpp:296 picks the crop / scale by
+    it) -- through the whole GPU path: preprocess (bit-exact image and P), network (another mix of kernels at 30 x 98 cells:
+    tests/test_gpu_network.py pins it), NMS, descriptor sampling, matching."""
+    from spvo import capi
+    frames, _, P_l, P_r = stereo_pair
+    L, R = frames[0]
+    path, plan = (vgg_weights_path, vgg_plan) if graph == "vgg" else (squeeze_weights_path, squeeze_plan)
+    ctx = capi.Context(net_height=240, net_width=784)
+    ctx.load_weights(path)
+    out = ctx.detect(L, R, P_l, P_r, 2, 3, want_resized=True)
+    for side, img, P in (("l", L, P_l), ("r", R, P_r)):
+        ref = fe.detect(plan, img, P, 240, 784)
+        assert np.array_equal(out["resized_" + side], ref["resized"]) and np.array_equal(out["P_" + side], ref["P"])
+        xy = out["xy_" + side].astype(np.int32)
+        a, b = set(map(tuple, xy.tolist())), set(map(tuple, ref["xy"].tolist()))
+        assert len(a & b) / len(a | b) > 0.97, (len(a & b), len(a), len(b))
+        assert len(xy) == len(ref["xy"])
+        pos = {tuple(p): i for i, p in enumerate(ref["xy"].tolist())}
+        common = [(i, pos[tuple(p)]) for i, p in enumerate(xy.tolist()) if tuple(p) in pos]
+        gi, ri = map(np.array, zip(*common))
+        assert np.abs(out["desc_" + side][gi] - ref["descriptors"][ri]).max() <= 1e-4
+    idx, d = ctx.match_slots(2, 3, len(out["xy_l"]))
+    ridx, rd = matching.bf_match(out["desc_l"], out["desc_r"], "KNN", False, 0.8)
+    assert np.array_equal(idx, ridx) and np.array_equal(d, rd)
+    ctx.close()
+
+
 def test_detect_properties_full_size(ctx_vgg, stereo_pair):
     frames, _, P_l, P_r = stereo_pair
     L, R = frames[1]
