@@ -52,6 +52,10 @@
 #define WINO4_ABL 0   // measurement builds only (tools/wino_bench.hip): 1 no input transform, 2 no filter staging, 4 no raw staging, 8 operands read once, 16 no stores
 #endif
 
+#ifndef SPVO_STATIC_BANDS
+#define SPVO_STATIC_BANDS 1   // measurement builds: 0 = tile = blockIdx.x in launches without a.sched
+#endif
+
 namespace spvo {
 
 struct Wino4Tile {
@@ -251,7 +255,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
       for (int k = 0; k < 9; ++k) a.sched[k] = 0;
   };
   int *const sched_slot = reinterpret_cast<int *>(smem + (T::LDS_BYTES - 16) / 4);
-  int tile_id = blockIdx.x;
+  // static assignment (a.sched == nullptr: single-round launches, short K loops): the same XCD bands without the counters -- workgroup
+  // blockIdx.x takes tile (workgroups of lower bands) + (its rank in its band), a permutation of 0 .. gridDim.x - 1, then + k gridDim.x.
+  // With tile = blockIdx.x neighbouring tiles sat on different XCDs and every L2 fetched its own copy of the halos and of the lines
+  // tiles share: conv3a / conv3b / conv4a / conv4b / convPa+Da moved 2.8 - 6 x their algorithmic bytes (profiles/r04_pmc_layers.json)
+  int tile_id = SPVO_STATIC_BANDS ? wgs_before(band) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
   if (a.sched) {
     tile_id = band_lo(band) + (blockIdx.x >> 3);
     if (tile_id >= band_hi(band)) {

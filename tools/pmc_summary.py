@@ -1,4 +1,4 @@
-"""Turns the counter passes of tools/collect_profiles_r03.sh into one JSON (profiles/r03_pmc.json): per kernel the HBM traffic
+"""Turns the counter passes of tools/collect_profiles_r0N.sh into one JSON (profiles/r0N_pmc.json): per kernel the HBM traffic
 (FETCH_SIZE x 2 + WRITE_SIZE, with the x 2 validated by the copy kernel of the SAME session), the algorithmic bytes, the
 matrix-pipe busy fraction and the wave-cycle split.
 
@@ -28,7 +28,7 @@ def pick(acc, key):
     return ks[0] if ks else None
 
 
-res = {"_how": "tools/collect_profiles_r03.sh on one MI355X: rocprofv3 --kernel-trace --pmc <group> --output-format csv, one group per pass, stand-alone "
+res = {"_how": "tools/collect_profiles_r0N.sh on one MI355X: rocprofv3 --kernel-trace --pmc <group> --output-format csv, one group per pass, stand-alone "
                "binaries tools/wino_bench4 360 1176 64 64 1 (conv1b, both images, Winograd F(4x4,3x3)), tools/match_bench 1000 2 (two 1000 x 1000 jobs), tools/copy_bench 1024",
        "_units": "FETCH_SIZE / WRITE_SIZE in KB; SQ_* wave counters in quad-cycles summed over waves; SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over SIMDs; "
                  "GRBM_GUI_ACTIVE summed over the 8 XCDs"}
