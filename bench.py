@@ -323,7 +323,6 @@ def main():
     if args.fp32_split:
         if args.precision != "FP32":
             raise SystemExit("--fp32-split applies to FP32 engines")
-        os.environ["SPVO_FP32_SPLIT"] = "1"
 
     import torch
     import torch.distributed as dist
@@ -356,7 +355,9 @@ def main():
 
     if world > 1:   # several ranks share the host: an equal share of the CPUs this job may really use (cgroup quota, not the host's core count)
         torch.set_num_threads(max(1, usable_cpus() // world))
-    from spvo import host, posegather, synth, weights
+    from spvo import capi, host, posegather, synth, weights
+    if args.fp32_split:
+        capi.set_tuning("fp32_split", 1)   # engines loaded from here on run in split mode (the library reads no environment variable for it)
 
     plan = weights.vgg_plan(seed=0) if args.graph == "vgg" else weights.load(os.path.join(ROOT, "tests", "golden", args.graph + ".spvw"))
     n_params = int(sum(op.weight.size + op.bias.size for op in plan.ops if op.weight is not None))
@@ -576,11 +577,13 @@ def main():
                 # three bf16 pieces, six partial products on the bf16 matrix pipe, fp32 accumulation: results agree with the
                 # native engine to fp32 rounding level, tests/test_gpu_network.py::test_fp32_split_mode_*).
                 fe.close()
-                os.environ["SPVO_FP32_SPLIT"] = "1"
-                fe = host.FrontEnd(tmp, prefix="superpoint_pretrained", selector="KNN", cross_check=True, batch=2,
-                                   height=NET_H, width=NET_W, conf_thresh=0.015, dist_thresh=4, border_remove=4,
-                                   stereo_threshold=2.0, min_disparity=0.25, refinement_degree=4, precision="FP32")
-                del os.environ["SPVO_FP32_SPLIT"]
+                capi.set_tuning("fp32_split", 1)
+                try:
+                    fe = host.FrontEnd(tmp, prefix="superpoint_pretrained", selector="KNN", cross_check=True, batch=2,
+                                       height=NET_H, width=NET_W, conf_thresh=0.015, dist_thresh=4, border_remove=4,
+                                       stereo_threshold=2.0, min_disparity=0.25, refinement_degree=4, precision="FP32")
+                finally:
+                    capi.clear_tuning()
                 if fe.engine_loaded:
                     for i in range(args.warmup):
                         step(i)
@@ -613,6 +616,40 @@ def main():
                     fe.finish_solve()
                     e3, sp3 = leg(hstep, lambda: fe.finish_solve())
                     hi[name] = {"value": round(args.steps / e3, 2), "ms_per_step": round(1e3 * e3 / args.steps, 4), **sp3}
+                    if depth == 0:
+                        # the stage table of THIS leg (the headline's `stages_ms` describes the pipelined loop): host wall time of the node's
+                        # three kinds of calls, then -- a second short pass with every stage bracketed by events -- what the device did in them
+                        import ctypes as C
+                        Plc, Prc = np.ascontiguousarray(P_l, np.float64), np.ascontiguousarray(P_r, np.float64)
+                        hctx = fe.context()
+                        for timed_stages in (False, True):
+                            acc = np.zeros(3)
+                            if timed_stages:
+                                hctx.profile_only(None)
+                                hctx.profile_enable(True)
+                                hctx.profile_reset()
+                            for i in range(100):
+                                m = mats[order[i % len(order)]]
+                                t0 = time.perf_counter()
+                                fe.lib.spvo_host_add_stereo_pair_mat(fe.h, C.c_void_p(m[0]), C.c_void_p(m[1]), host._p(Plc), host._p(Prc))
+                                t1 = time.perf_counter()
+                                fe.match_descriptors(host.CURR_LEFT_CURR_RIGHT)
+                                if fe.dq_size() >= 4:
+                                    fe.match_descriptors(host.CURR_LEFT_PREV_LEFT)
+                                    t2 = time.perf_counter()
+                                    fe.solve_stereo_odometry()
+                                    acc += [t1 - t0, t2 - t1, time.perf_counter() - t2]
+                            if not timed_stages:
+                                hi[name]["host_calls_ms"] = {"addStereoImagePair": round(1e3 * acc[0] / 100, 4), "matchDescriptors_x2": round(1e3 * acc[1] / 100, 4),
+                                                             "solveStereoOdometry": round(1e3 * acc[2] / 100, 4)}
+                            else:
+                                barrier()
+                                hp = hctx.profile()
+                                hctx.profile_enable(False)
+                                hi[name]["device_stages_ms"] = {k: round(v["total_ms"] / max(v["calls"], 1), 4) for k, v in hp.items()
+                                                                if v["calls"] and not k.startswith(("conv:", "pool:", "l2norm:", "dwconv:"))}
+                                hi[name]["device_stages_ms"]["conv_stack_sum"] = round(sum(v["total_ms"] / v["calls"] for k, v in hp.items() if k.startswith("conv:") and v["calls"]), 4)
+                                hi[name]["device_stages_ms"]["_source"] = "second pass of 100 synchronous steps with every stage bracketed by HIP events (slower than the timed blocks)"
                 out["host_interface"] = {"unit": "stereo frames/s", **hi,
                                          "note": "addStereoImagePair(cv::Mat&, ...): 2 x 0.47 MB host images in, 2 x 0.42 MB resized images + 2 x 1 MB "
                                                  "descriptors out per pair (PCIe inclusive); the headline `value` has the images resident in HBM"}

@@ -174,6 +174,25 @@ int spvo_detect_submit(spvo_ctx *ctx, const uint8_t *img_l, const uint8_t *img_r
 int spvo_detect_collect(spvo_ctx *ctx, double P_l[12], double P_r[12], spvo_features *out_l, spvo_features *out_r,
                         uint8_t *resized_l, uint8_t *resized_r);
 
+/* spvo_detect_collect without its host copies: completes the OLDEST submission and hands out POINTERS into the submission's
+ * pinned host mirrors -- n[i] keypoints, xy[i] (n[i] x 2 floats), desc[i] (n[i] x 256 floats; NULL unless `extras` bit 1 was
+ * set at spvo_detect_submit), resized[i] (net_height x net_width u8; NULL unless bit 0 was set), i = 0 left, 1 right.  The
+ * kernels that produce these results write them there; a caller that owns the final containers (descriptors_dq / images_dq,
+ * nn.cpp:154, 494-498) copies each of them ONCE, when it suits it.  The pointers stay valid until three more submissions
+ * have been made on this context (each submission owns one of four sets of mirrors) or the context is destroyed. */
+typedef struct {
+  int n[2];
+  const float *xy[2];
+  const float *desc[2];
+  const uint8_t *resized[2];
+  int token;   /* the submission's set of mirrors (spvo_detect_mirrors_wait) */
+} spvo_detect_mirrors;
+int spvo_detect_collect_mirrors(spvo_ctx *ctx, double P_l[12], double P_r[12], spvo_detect_mirrors *out);
+/* n, xy and resized are complete when spvo_detect_collect_mirrors returns.  The descriptors travel to their mirror BESIDE the
+ * submission's matches (a copy kernel on a stream of its own: the matcher reads the device copy): desc[] may be read once this
+ * call has returned.  A front end that fills descriptors_dq while the solver runs never waits here. */
+int spvo_detect_mirrors_wait(spvo_ctx *ctx, const spvo_detect_mirrors *m);
+
 typedef enum { SPVO_SELECT_NN = 0, SPVO_SELECT_KNN = 1 } spvo_selector;
 
 /* matchDescriptors (base.cpp:434-491) = cv::BFMatcher(NORM_L2) match / knnMatch
@@ -369,6 +388,18 @@ int spvo_profile_get(spvo_ctx *ctx, int i, char *name, size_t name_cap, double *
  * "conv_mfma_kernel", "conv_f16_kernel", ...), and how many multiply-adds the matrix pipe executes per multiply-add of the
  * direct convolution (Winograd F(4x4,3x3): 0.25, F(2x2,3x3): 4/9, split bf16x3 mode: 6, otherwise 1). */
 int spvo_profile_stage_kernel(spvo_ctx *ctx, const char *stage, char *name, size_t name_cap, double *executed_per_algorithmic);
+
+/* ------------------------------------------------------- diagnostic switches (A/B measurements, parity debugging)
+ * Which kernels / streams an engine uses is decided by the library from the plan and the sizes.  The decisions can be overridden
+ * for measurements and tests -- through THIS call only: the library reads no environment variable for them, so the environment
+ * of the process that hosts it (a ROS node) cannot change kernels by accident.  Process-wide; a value takes effect for contexts
+ * created / engines loaded afterwards.  `name` is one of the names INTEGRATION.md lists ("winograd", "wino4", "wino_narrow",
+ * "wino_dynamic", "winograd_min_tiles", "wino4_min_tiles", "merge_siblings", "heads_fused", "heads_on_net", "heads_split",
+ * "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing"); SPVO_ERR_INVALID for any other.
+ * spvo_get_tuning returns the value set, or `dflt`; spvo_clear_tuning forgets every value. */
+int spvo_set_tuning(const char *name, int value);
+int spvo_get_tuning(const char *name, int dflt);
+void spvo_clear_tuning(void);
 
 #ifdef __cplusplus
 }

@@ -1,9 +1,31 @@
-// conv_wino2.hip.h -- K2w, second form: the Winograd F(2x2, 3x3) convolution of conv_wino.hip.h with TWO waves per SIMD.
+// conv_wino2.hip.h -- K2w: 3x3 convolution by the Winograd minimal-filtering algorithm F(2x2, 3x3) on the gfx950 fp32
+// matrix cores, bias + ReLU (+ 2x2 max-pool) fused.  fp32 throughout: operands, products and accumulation.
 //
-// Same algorithm, same tile (64 output channels x 64 Winograd tiles = 8 rows x 32 columns of output per workgroup), same
-// LDS-DMA staging, same interleaved input transform, same in-register epilogue -- see conv_wino.hip.h for all of that and for
-// the reference it replaces (the TensorRT engine enqueued at feature_detection_neural_network.cpp:169).  What changes is who
-// holds the accumulators.  The first form gives each of 4 waves a 32 x 32 block of all 16 transform positions: 256 accumulator
+// Replaces, like conv_mfma.hip.h, the TensorRT engine the reference enqueues at
+// feature_detection_neural_network.cpp:169 for the 3x3 Conv/Relu/MaxPool nodes of the SuperPoint graphs; TensorRT's
+// own fp32 tactics for 3x3 stride-1 layers are Winograd kernels as well.
+//
+// Y(2x2) = A^T [ (G g G^T) .* (B^T d B) ] A  per 4x4 input patch d (patches overlap by 2) and 3x3 filter g, with
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  A^T = [1 1 1 0; 0 1 -1 -1].
+// Summed over input channels the element-wise product is 16 independent GEMMs, one per position xi = (a, b) of the 4x4
+// transform domain:   M[xi][co][tile] = sum_ci U[xi][co][ci] * V[xi][ci][tile]
+// i.e. 16 multiplies per 2x2 outputs and channel pair instead of 36: 4/9 of the direct method's matrix work.
+//
+// Form: EIGHT waves, two per SIMD (round 2; the round-1 form -- 4 waves, each a 32 x 32 block of all 16 positions = 256 accumulator
+// registers, one wave per SIMD -- is gone: every instruction of that one wave which was not a matrix instruction stopped the SIMD's
+// matrix pipe, ~6000 cycles per item for 4096 of matrix work).  Workgroup = 64 output channels x 64 Winograd tiles (8 rows x 32
+// columns of output); its work is a linear sequence of items k = (tile, chunk of 8 input channels), software-pipelined three deep:
+// LDS-DMA (global_load_lds) of the host-transformed filters of item k+1 and of the raw halo tile (8 x 10 x 40 floats) of item k+2
+// from inside the matrix stream of item k, the input transform of item k+1 in micro-steps between the matrix instructions, one
+// barrier per item.  The kernel must not spill: a scratch reload's s_waitcnt vmcnt(0) also waits for the LDS-DMA in flight.
+// Epilogue in registers: inverse transform, bias through position (1,1) (inverse-transform weight +1 for all four outputs), 2x2
+// max-pool = the maximum of the tile's own four outputs.
+//
+// Numerics: the transforms use coefficients 0, +-1, +-1/2 only; against a float64 evaluation the layer's error is of the
+// same order as the direct kernel's accumulated rounding, in fact smaller (tests/test_gpu_network.py: 1e-4 bar on every tensor
+// against the oracle, and test_winograd_layers_stay_at_fp32_rounding_level against float64).
+//
+// Who holds the accumulators.  The round-1 form gave each of 4 waves a 32 x 32 block of all 16 transform positions: 256 accumulator
 // registers, so ONE wave per SIMD, and every instruction that wave issues which is not a matrix instruction -- 13 LDS-DMA
 // pieces, 40 transform micro-steps, 32 operand reads, the barrier -- is time the matrix pipe of that SIMD may stand still
 // (measured: ~6000 cycles per item for 4096 cycles of matrix work).  Here the workgroup has 8 waves; wave (cq, tb) owns 16
@@ -24,13 +46,27 @@
 #include <type_traits>
 #include <vector>
 #include "conv_mfma.hip.h"
-#include "conv_wino.hip.h"
 
 #ifndef SPVO_STATIC_BANDS
 #define SPVO_STATIC_BANDS 1   // measurement builds: 0 = tile = blockIdx.x in launches without a.sched
 #endif
 
 namespace spvo {
+
+#ifndef WINO_STORE_AUX
+#define WINO_STORE_AUX 0   // cache policy of the output stores (experiments: 16 = sc1, write-through)
+#endif
+
+struct WinoTile {
+  static constexpr int CK = 8, TH = 8, TW = 32, LW = TW + 8, LH = TH + 2;
+  static constexpr int IN_FLOATS = CK * LH * LW;            // 3200: raw halo tile, row = x0-4 .. x0+35
+  static constexpr int U_FLOATS = 16 * CK * CO_TILE;        // 8192
+  static constexpr int W_FLOATS = U_FLOATS + CO_TILE;       // + the bias row (chunk 0's slab)
+  static constexpr int V_FLOATS = 16 * CK * 64;             // transformed input
+  // LDS: two raw tiles, two filter slabs, two transformed tiles (everything double-buffered)
+  static constexpr int RAW_OFF = 0, U_OFF = 2 * IN_FLOATS, V_OFF = U_OFF + 2 * W_FLOATS;
+  static constexpr int LDS_BYTES = (V_OFF + 2 * V_FLOATS) * 4;   // 157 184
+};
 
 constexpr int WINO2_LDS_BYTES = WinoTile::LDS_BYTES + 16;   // + the slot through which a tile's successor is published (a.sched)
 

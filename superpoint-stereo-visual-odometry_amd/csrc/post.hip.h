@@ -60,6 +60,22 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t *__restri
   out_plane[(size_t)(y + PADY) * wp + (x + PADX)] = mul_rn((float)v, 1.0f / 255.0f);
 }
 
+// device buffer -> pinned host mirror, 16 bytes per lane (posted PCIe writes; no SDMA engine: see spvo_detect.hip)
+__global__ __launch_bounds__(256) void mirror_copy_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+// the descriptors of both images of a pair, device slots -> pinned host mirrors: one wave per 1 KiB row, only the rows that exist
+// (the counts are read on the device)
+struct MirrorDescJob { const float *src[2]; const int *n[2]; float *dst[2]; };
+__global__ __launch_bounds__(256) void mirror_desc_kernel(MirrorDescJob job) {
+  const int img = blockIdx.y, lane = threadIdx.x & 63;
+  const int n = *job.n[img];
+  const uint4 *s = reinterpret_cast<const uint4 *>(job.src[img]);
+  uint4 *d = reinterpret_cast<uint4 *>(job.dst[img]);
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += gridDim.x * 4) d[(size_t)row * 64 + lane] = s[(size_t)row * 64 + lane];
+}
+
 // Dense f32 [B,1,H,W] -> padded input planes (spvo_forward's host-input path).
 __global__ __launch_bounds__(256) void pad_input_kernel(const float *__restrict__ in,
                                                         float *__restrict__ out, int H, int W,

@@ -1,12 +1,11 @@
 // spvo_core.hip -- context life cycle, engine files (the plan loader: SPVW0003 -> tensors, ops, repacked weights), profiling.
 // Part of the extern "C" shim declared in include/spvo.h; the kernels live in the headers next to this file.
 #include "spvo_internal.hip.h"
+#include <mutex>
 #include "conv_mfma.hip.h"
 #include "conv_f16.hip.h"
 #include "conv_bf16x3.hip.h"
-#include "conv_wino.hip.h"
 #include "conv_wino2.hip.h"
-#include "conv_wino64.hip.h"
 #include "conv_wino4.hip.h"
 #include "heads.hip.h"
 #include "conv_i8.hip.h"
@@ -36,13 +35,31 @@ int stage_id(spvo_ctx *c, const std::string &name) {
   return (int)c->stages.size() - 1;
 }
 
-// SPVO_SPIN_WAIT=1: the waits of the per-frame path poll their event instead of sleeping in the driver (a sleeping host thread
+// ---- diagnostic switches (include/spvo.h: spvo_set_tuning).  One process-wide table, filled by explicit calls only.
+namespace {
+const char *const kTuningNames[] = {"winograd", "wino4", "wino_narrow", "wino_dynamic", "winograd_min_tiles", "wino4_min_tiles", "merge_siblings", "heads_fused",
+                                    "heads_on_net", "heads_split", "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing"};
+constexpr int kTuningCount = sizeof kTuningNames / sizeof kTuningNames[0];
+std::mutex g_tuning_mutex;
+bool g_tuning_set[kTuningCount] = {};
+int g_tuning_value[kTuningCount] = {};
+int tuning_index(const char *name) {
+  for (int i = 0; name && i < kTuningCount; ++i)
+    if (std::strcmp(name, kTuningNames[i]) == 0) return i;
+  return -1;
+}
+}  // namespace
+int tuning(const char *name, int dflt) {
+  const int i = tuning_index(name);
+  if (i < 0) return dflt;
+  std::lock_guard<std::mutex> lock(g_tuning_mutex);
+  return g_tuning_set[i] ? g_tuning_value[i] : dflt;
+}
+
+// tuning "spin_wait" = 1: the waits of the per-frame path poll their event instead of sleeping in the driver (a sleeping host thread
 // pays the wake-up latency of its core at every wait).  Off by default: on the bench box it changed nothing (the waits are
 // dominated by GPU time), and a ROS node should not burn a core while it waits.
-bool spin_wait_enabled() {
-  static const bool on = std::getenv("SPVO_SPIN_WAIT") && std::atoi(std::getenv("SPVO_SPIN_WAIT")) != 0;
-  return on;
-}
+bool spin_wait_enabled() { return tuning("spin_wait", 0) != 0; }
 hipError_t wait_event(hipEvent_t ev) {
   if (spin_wait_enabled()) {
     for (long spins = 0; spins < 20000000; ++spins) {   // far longer than any wait of this library; then fall back to the blocking form
@@ -186,7 +203,7 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
   }
   c->post = c->stream;
   (void)hipEventCreateWithFlags(&c->ev_post, hipEventDisableTiming);
-  if (const char *e = std::getenv("SPVO_FP32_SPLIT")) c->split_req = std::atoi(e) != 0;
+  c->split_req = tuning("fp32_split", 0) != 0;
   for (int r = 0; r < RING; ++r)
     if (hipEventCreateWithFlags(&c->ev_net[r], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_tail[r], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_feat[r], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_copy[r], hipEventDisableTiming) != hipSuccess ||
@@ -418,7 +435,7 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
   // is tiny and launch-bound (64 us for 2.2 GFLOP); a submission runs it on the tail stream, where it fills the CUs the next
   // pair's trunk leaves idle, instead of on the network stream, which is the one that limits the frame rate.
   c->head_start = c->ops.size();
-  if (!(std::getenv("SPVO_HEADS_ON_TAIL") && std::atoi(std::getenv("SPVO_HEADS_ON_TAIL")) == 0))
+  if (tuning("heads_split", 1))   // 0: the heads are ordinary layers of the trunk (no separate placement)
     while (c->head_start > 0) {
       const Op &o = c->ops[c->head_start - 1];
       const bool head = o.type == OP_L2NORM || (o.type == OP_CONV && o.ks == 1 && !(o.flags & FLAG_POOL) && o.cin > 1);
@@ -528,7 +545,7 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
       // channels concatenated: one launch instead of two, and 480 workgroups on 256 CUs instead of twice 240.
       std::vector<float> wcat, bcat;
       if (!c->int8 && !c->fp16 && !c->s3 && op.ks == 3 && op.cin > 1 && !bn && !add && !pool && (op.cout % CO_TILE) == 0 && i + 1 < no &&
-          !(std::getenv("SPVO_MERGE_SIBLINGS") && std::atoi(std::getenv("SPVO_MERGE_SIBLINGS")) == 0)) {
+          tuning("merge_siblings", 1)) {
         Op &nx = c->ops[i + 1];
         const Raw &rn = raws[i + 1];
         if (nx.type == OP_CONV && nx.in == op.in && nx.in_c_off == op.in_c_off && nx.cin == op.cin && nx.ks == op.ks && nx.flags == op.flags &&
@@ -637,12 +654,6 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
         op.co_tiles = (op.cout + CO_TILE - 1) / CO_TILE;
         int ck_unused;
         choose_variant(op.ks, ti.H, ti.W, op.co_tiles, c->cfg.max_batch, pool, c->num_cus, &op.wr, &op.wc, &ck_unused, true);
-        if (const char *force = std::getenv("SPVO_CONV_FORCE")) {   // tuning aid: "op:wr,wc,ck;op:wr,wc,ck" (ck ignored here)
-          for (const char *q = force; q && *q; q = std::strchr(q, ';') ? std::strchr(q, ';') + 1 : nullptr) {
-            int oi, wr, wc, ck;
-            if (std::sscanf(q, "%d:%d,%d,%d", &oi, &wr, &wc, &ck) == 4 && oi == (int)i) { op.wr = wr; op.wc = wc; }
-          }
-        }
         const std::vector<unsigned short> pk = pack_conv_weights_s3(w, b, op.cout, op.cin, op.ks, ckg);
         int rc = dev_alloc(c, &op.d_ws3, pk.size(), false);
         if (rc) return rc;
@@ -660,36 +671,25 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
       }
       op.co_tiles = (op.cout + CO_TILE - 1) / CO_TILE;
       choose_variant(op.ks, ti.H, ti.W, op.co_tiles, c->cfg.max_batch, pool, c->num_cus, &op.wr, &op.wc, &op.ck);
-      if (const char *force = std::getenv("SPVO_CONV_FORCE")) {   // tuning aid: "op:wr,wc,ck;op:wr,wc,ck"
-        for (const char *q = force; q && *q; q = std::strchr(q, ';') ? std::strchr(q, ';') + 1 : nullptr) {
-          int oi, wr, wc, ck;
-          if (std::sscanf(q, "%d:%d,%d,%d", &oi, &wr, &wc, &ck) == 4 && oi == (int)i) { op.wr = wr; op.wc = wc; op.ck = ck; }
-        }
-      }
-      // Winograd F(2x2,3x3) for the plain 3x3 layers (no BatchNorm / residual epilogue) whose 8x32 tiles give at least
-      // SPVO_WINOGRAD_MIN_TILES workgroups (default: 3/4 of the CUs; below that -- conv4a/4b at 45x147: 120 -- the direct kernel's 4x32 tiles fill the chip better: 47 vs 52 us); a pooled layer needs even sizes (the pooling window is
-      // the Winograd tile).  SPVO_WINOGRAD=0 switches it off (A/B measurements, parity debugging).
+      // Winograd for the plain 3x3 layers (no BatchNorm / residual epilogue; a pooled layer needs even sizes: the pooling window lies
+      // inside a Winograd tile).  Which form, by the number of workgroups the layer gives on this chip (`min_tiles`, default 3/4 of the
+      // CUs): F(4x4,3x3) (conv_wino4.hip.h: 36 multiplies per 4x4 outputs instead of F(2x2)'s 64) where the layer has that many
+      // 16 x 32 tiles; else F(2x2,3x3) (conv_wino2.hip.h) on 8 x 32 tiles of 64 output channels; else its narrow form (32 output
+      // channels per workgroup: conv4a / conv4b at 45x147 are 120 wide tiles on 256 CUs); else the direct kernel.
+      // Diagnostic switches (spvo_set_tuning): "winograd" = 0 direct kernels only, "wino4" = 0 F(2x2) only, "wino_narrow" = 0,
+      // "winograd_min_tiles" / "wino4_min_tiles" the thresholds, "wino_dynamic" = 0 static tile assignment.
       {
-        const bool wino_on = !(std::getenv("SPVO_WINOGRAD") && std::atoi(std::getenv("SPVO_WINOGRAD")) == 0);
+        const bool wino_on = tuning("winograd", 1) != 0;
         const long wtiles = (long)((ti.W + WinoTile::TW - 1) / WinoTile::TW) * ((ti.H + WinoTile::TH - 1) / WinoTile::TH) * op.co_tiles * c->cfg.max_batch;
-        const long min_tiles = std::getenv("SPVO_WINOGRAD_MIN_TILES") ? std::atol(std::getenv("SPVO_WINOGRAD_MIN_TILES")) : 3 * c->num_cus / 4;
+        const long min_tiles = tuning("winograd_min_tiles", 3 * c->num_cus / 4);
         const bool eligible = wino_on && op.ks == 3 && !bn && !add && (op.cin % WinoTile::CK) == 0 && (!pool || ((ti.H % 2) == 0 && (ti.W % 2) == 0));
-        op.wino2 = !(std::getenv("SPVO_WINO2") && std::atoi(std::getenv("SPVO_WINO2")) == 0);
         op.wino = eligible && wtiles >= min_tiles;
-        // too few 64-channel tiles (conv4a / conv4b at 45x147: 120 on 256 CUs): 32 channels per workgroup fill the chip, and the
-        // layer -- one tile's chain of items per workgroup -- becomes a chain of half-size items (SPVO_WINO_NARROW=0: direct kernel)
-        const bool narrow_on = !(std::getenv("SPVO_WINO_NARROW") && std::atoi(std::getenv("SPVO_WINO_NARROW")) == 0);
-        if (eligible && !op.wino && op.wino2 && narrow_on && (op.cout % 32) == 0 && 2 * wtiles >= min_tiles) op.wino = op.wino_narrow = true;
+        if (eligible && !op.wino && tuning("wino_narrow", 1) && (op.cout % 32) == 0 && 2 * wtiles >= min_tiles) op.wino = op.wino_narrow = true;
       }
-      // F(4x4,3x3) (conv_wino4.hip.h): 36 multiplies per 4x4 outputs instead of F(2x2)'s 64 -- for the Winograd layers with enough
-      // 16 x 32 tiles to fill the chip (unpooled layers of any size -- SPVO_WINO4_ODD=0 keeps the odd-sized ones on F(2x2) --, pooled
-      // layers with even H and W).  SPVO_WINO4=0 keeps F(2x2) everywhere.
-      if (op.wino && !op.wino_narrow && op.wino2 && (op.cin % Wino4Tile::CK) == 0 &&
-          (((ti.H | ti.W) & 1) == 0 || (!pool && !(std::getenv("SPVO_WINO4_ODD") && std::atoi(std::getenv("SPVO_WINO4_ODD")) == 0))) &&
-          !(std::getenv("SPVO_WINO4") && std::atoi(std::getenv("SPVO_WINO4")) == 0)) {
+      const bool dynamic_tiles = tuning("wino_dynamic", 1) != 0;
+      if (op.wino && !op.wino_narrow && (op.cin % Wino4Tile::CK) == 0 && (((ti.H | ti.W) & 1) == 0 || !pool) && tuning("wino4", 1)) {
         const long t4 = (long)((ti.W + Wino4Tile::TW - 1) / Wino4Tile::TW) * ((ti.H + Wino4Tile::TH - 1) / Wino4Tile::TH) * op.co_tiles * c->cfg.max_batch;
-        const long min4 = std::getenv("SPVO_WINO4_MIN_TILES") ? std::atol(std::getenv("SPVO_WINO4_MIN_TILES")) : 3 * c->num_cus / 4;
-        if (t4 >= min4) {
+        if (t4 >= tuning("wino4_min_tiles", 3 * c->num_cus / 4)) {
           op.wino4 = true;
           op.ck = Wino4Tile::CK;
           op.n_chunks = op.cin / Wino4Tile::CK;
@@ -697,25 +697,7 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
           int rc = dev_alloc(c, &op.d_w, pk.size(), false);
           if (rc) return rc;
           HIP_TRY(c, hipMemcpy(op.d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
-          if (!(std::getenv("SPVO_WINO_DYNAMIC") && std::atoi(std::getenv("SPVO_WINO_DYNAMIC")) == 0) && (rc = dev_alloc(c, &op.d_sched, 16))) return rc;
-          continue;
-        }
-      }
-      // 64 input channels (conv1b, conv2a, conv2b, conv3a of the VGG graph): the transformed filters of a 64-channel output tile fit
-      // the registers of one workgroup and stay there (conv_wino64.hip.h) -- no filter staging at all.  Needs even H and W (a
-      // Winograd tile's four outputs are then all inside or all outside the image) and enough 4 x 32 tiles to fill the chip.
-      if (op.wino && !op.wino_narrow && op.wino2 && op.cin == Wino64Tile::CIN && ((ti.H | ti.W) & 1) == 0 &&
-          std::getenv("SPVO_WINO64") && std::atoi(std::getenv("SPVO_WINO64")) != 0) {   // opt-in: measured no faster than the 8-wave form
-        const long t64 = (long)((ti.W + Wino64Tile::TW - 1) / Wino64Tile::TW) * ((ti.H + Wino64Tile::TH - 1) / Wino64Tile::TH) * op.co_tiles * c->cfg.max_batch;
-        if (t64 >= 2 * c->num_cus) {
-          op.wino64 = true;
-          op.ck = Wino64Tile::CK;
-          op.n_chunks = Wino64Tile::NCH;
-          const std::vector<float> pk = pack_conv_weights_wino64(w, b, op.cout, op.cin);
-          int rc = dev_alloc(c, &op.d_w, pk.size(), false);
-          if (rc) return rc;
-          HIP_TRY(c, hipMemcpy(op.d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
-          if (!(std::getenv("SPVO_WINO_DYNAMIC") && std::atoi(std::getenv("SPVO_WINO_DYNAMIC")) == 0) && (rc = dev_alloc(c, &op.d_sched, 16))) return rc;
+          if (dynamic_tiles && (rc = dev_alloc(c, &op.d_sched, 16))) return rc;
           continue;
         }
       }
@@ -723,11 +705,11 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
         op.ck = WinoTile::CK;
         op.n_chunks = op.cin / op.ck;
         if (op.wino_narrow) op.co_tiles = op.cout / 32;
-        const std::vector<float> pk = op.wino2 ? pack_conv_weights_wino2(w, b, op.cout, op.cin, op.wino_narrow ? 32 : CO_TILE) : pack_conv_weights_wino(w, b, op.cout, op.cin);
+        const std::vector<float> pk = pack_conv_weights_wino2(w, b, op.cout, op.cin, op.wino_narrow ? 32 : CO_TILE);
         int rc = dev_alloc(c, &op.d_w, pk.size(), false);
         if (rc) return rc;
         HIP_TRY(c, hipMemcpy(op.d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
-        if (op.wino2 && !(std::getenv("SPVO_WINO_DYNAMIC") && std::atoi(std::getenv("SPVO_WINO_DYNAMIC")) == 0) && (rc = dev_alloc(c, &op.d_sched, 16))) return rc;
+        if (dynamic_tiles && (rc = dev_alloc(c, &op.d_sched, 16))) return rc;
         continue;
       }
       if (op.cin % op.ck) return fail(c, SPVO_ERR_IO, "op %u: cin %d is not a multiple of %d", i, op.cin, op.ck);
@@ -754,8 +736,8 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
     }
   }
   // The tail of the SuperPoint graphs -- convPb 256 -> 65, convDb 256 -> 256 (both 1x1, plain, reading two channel ranges of one
-  // tensor), L2 normalisation -- as ONE launch (heads.hip.h) instead of three: FP32 engines only; SPVO_HEADS_FUSED=0 keeps the plan's ops.
-  if (!c->fp16 && !c->int8 && !c->s3 && c->head_start + 3 == c->ops.size() && !(std::getenv("SPVO_HEADS_FUSED") && std::atoi(std::getenv("SPVO_HEADS_FUSED")) == 0)) {
+  // tensor), L2 normalisation -- as ONE launch (heads.hip.h) instead of three: FP32 engines only; tuning "heads_fused" = 0 keeps the plan's ops.
+  if (!c->fp16 && !c->int8 && !c->s3 && c->head_start + 3 == c->ops.size() && tuning("heads_fused", 1)) {
     const size_t hs = c->head_start;
     const Op &pb = c->ops[hs], &db = c->ops[hs + 1], &nm = c->ops[hs + 2];
     const bool plain = pb.type == OP_CONV && db.type == OP_CONV && nm.type == OP_L2NORM && pb.ks == 1 && db.ks == 1 && pb.flags == 0 && db.flags == 0 &&
@@ -850,6 +832,22 @@ int spvo_profile_get(spvo_ctx *c, int i, char *name, size_t name_cap, double *to
   return SPVO_OK;
 }
 
+int spvo_set_tuning(const char *name, int value) {
+  const int i = tuning_index(name);
+  if (i < 0) return SPVO_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(g_tuning_mutex);
+  g_tuning_set[i] = true;
+  g_tuning_value[i] = value;
+  return SPVO_OK;
+}
+
+int spvo_get_tuning(const char *name, int dflt) { return tuning(name, dflt); }
+
+void spvo_clear_tuning(void) {
+  std::lock_guard<std::mutex> lock(g_tuning_mutex);
+  for (int i = 0; i < kTuningCount; ++i) g_tuning_set[i] = false;
+}
+
 int spvo_profile_stage_kernel(spvo_ctx *c, const char *stage, char *name, size_t name_cap, double *executed_per_algorithmic) {
   if (!c || !stage) return fail(c, SPVO_ERR_INVALID, "null argument");
   for (size_t i = 0; i < c->ops.size(); ++i) {
@@ -862,8 +860,7 @@ int spvo_profile_stage_kernel(spvo_ctx *c, const char *stage, char *name, size_t
       else if (c->fp16) k = "conv_f16_kernel";
       else if (c->s3) { k = "conv_s3_kernel"; f = 6.0; }
       else if (op.wino4) { k = "conv_wino4_kernel"; f = 0.25; }
-      else if (op.wino64) { k = "conv_wino64_kernel"; f = 4.0 / 9.0; }
-      else if (op.wino) { k = op.wino2 ? "conv_wino2_kernel" : "conv_wino_kernel"; f = 4.0 / 9.0; }
+      else if (op.wino) { k = "conv_wino2_kernel"; f = 4.0 / 9.0; }
       else k = "conv_mfma_kernel";
     }
     if (name && name_cap) { std::strncpy(name, k, name_cap - 1); name[name_cap - 1] = 0; }

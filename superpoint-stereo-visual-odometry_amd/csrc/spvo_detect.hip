@@ -305,9 +305,7 @@ static int enqueue_sample(spvo_ctx *c, const int slots[2], const NmsPair &np, in
   ScopedStage ss(c, stage_id(c, "sample"));
   const int cap = c->cfg.max_keypoints;
   // the keypoints as floats go straight into the set's pinned mirror (8 bytes per keypoint), not through a staging buffer and a copy
-  static const bool direct_xy = !(std::getenv("SPVO_DIRECT_HOST_WRITES") && std::atoi(std::getenv("SPVO_DIRECT_HOST_WRITES")) == 0) &&
-                           !(std::getenv("SPVO_DIRECT_SMALL") && std::atoi(std::getenv("SPVO_DIRECT_SMALL")) == 0);
-  float *stage = direct_xy ? c->h_xy_r[ring] : c->d_xy_stage + (size_t)ring * 2 * cap * 2;
+  float *stage = c->h_xy_r[ring];
   SampleJobs sj;
   for (int i = 0; i < 2; ++i) {
     FeatureSlot &s = c->slots[slots[i]];
@@ -317,7 +315,19 @@ static int enqueue_sample(spvo_ctx *c, const int slots[2], const NmsPair &np, in
   }
   hipLaunchKernelGGL(sample_desc_kernel, dim3((cap + 3) / 4, 2), dim3(256), 0, c->post, sj, c->H, c->W, c->Hc, c->Wc);
   HIP_TRY(c, hipGetLastError());
-  if (!direct_xy) HIP_TRY(c, hipMemcpyAsync(c->h_xy_r[ring], stage, (size_t)2 * cap * 2 * sizeof(float), hipMemcpyDeviceToHost, c->post));
+  return SPVO_OK;
+}
+
+// descriptors of a host-image submission -> the set's pinned mirror, on `st` (a copy kernel: posted PCIe writes, no SDMA engine)
+static int enqueue_desc_mirror(spvo_ctx *c, const int slots[2], int ring, hipStream_t st) {
+  const int cap = c->cfg.max_keypoints;
+  MirrorDescJob mj;
+  for (int i = 0; i < 2; ++i) {
+    const FeatureSlot &s = c->slots[slots[i]];
+    mj.src[i] = s.d_desc; mj.n[i] = s.d_n; mj.dst[i] = c->h_desc_r[ring] + (size_t)i * cap * 256;
+  }
+  hipLaunchKernelGGL(mirror_desc_kernel, dim3(32, 2), dim3(256), 0, st, mj);
+  HIP_TRY(c, hipGetLastError());
   return SPVO_OK;
 }
 
@@ -373,34 +383,26 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   }
   const int ring = (int)(c->submit_count++ % RING);
   for (auto &mc : c->mcache[ring]) mc.valid = false;
-  static const bool direct_on = !(std::getenv("SPVO_DIRECT_HOST_WRITES") && std::atoi(std::getenv("SPVO_DIRECT_HOST_WRITES")) == 0);
-  const bool direct = extras != 0 && direct_on;
-  if (host_l) {   // pageable -> pinned (host copy), pinned -> device (DMA on the network stream): the caller's buffers are free on return
+  // The bulk results a host-image submission takes back (`extras`) are WRITTEN into the set's pinned mirrors by kernels (posted PCIe
+  // writes), never copied behind events: a device-to-host copy waiting for its event occupies an SDMA queue, and the NEXT pair's image
+  // upload queued on the same engine waits with it (round 3: bench.py's look-ahead leg 0.95 ms per frame, the same calls from
+  // tools/sync_leg.py 0.81, depending on the process's copy history).
+  if (host_l) {   // pageable -> pinned (host copy), pinned -> device (ONE DMA on the network stream): the caller's buffers are free on return
     const size_t bytes = (size_t)(rows - 1) * stride + cols;   // what is the caller's of a strided view: not the last row's padding
-    // The two copies go out on the network stream, in front of the preprocess kernel.  SPVO_UPLOAD_STREAM=1 puts them on a stream
-    // of their own (the network stream waits for their event), so that with earlier submissions in flight the images travel
-    // while the previous pair's network runs: measured both ways -- 1168 against 1216 frames/s in tools/sync_leg.py's look-ahead
-    // run, 1144 against 1107 in bench.py's -- and left off.  (The set's buffers are free either way: at most MAX_INFLIGHT < RING
-    // submissions are in flight, so the one that used this set last has been collected.)
-    static const bool up_split = std::getenv("SPVO_UPLOAD_STREAM") && std::atoi(std::getenv("SPVO_UPLOAD_STREAM")) != 0;
-    hipStream_t us = up_split ? c->stream_u : c->stream;
-    std::memcpy(c->h_img_r[ring], host_l, bytes);   // (the left image is on its way while the right one is staged)
-    HIP_TRY(c, hipMemcpyAsync(c->d_img_r[ring], c->h_img_r[ring], bytes, hipMemcpyHostToDevice, us));
+    std::memcpy(c->h_img_r[ring], host_l, bytes);
     std::memcpy(c->h_img_r[ring] + c->img_cap_r, host_r, bytes);
-    HIP_TRY(c, hipMemcpyAsync(c->d_img_r[ring] + c->img_cap_r, c->h_img_r[ring] + c->img_cap_r, bytes, hipMemcpyHostToDevice, us));
-    if (up_split) {
-      HIP_TRY(c, hipEventRecord(c->ev_up[ring], c->stream_u));
-      HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_up[ring], 0));
-    }
+    // both images in one copy (the staging buffers of a set are contiguous, left then right): two copies were 17 + 16 us with 9 us
+    // between them on the synchronous path's critical path (profiles/r04_sync_timeline.log)
+    HIP_TRY(c, hipMemcpyAsync(c->d_img_r[ring], c->h_img_r[ring], c->img_cap_r + bytes, hipMemcpyHostToDevice, c->stream));
     srcs[0] = c->d_img_r[ring];
     srcs[1] = c->d_img_r[ring] + c->img_cap_r;
   }
   // ---- everything below is enqueued without a host round trip
   c->cur_ring = ring;
   c->post = c->stream;
-  // SPVO_TRUNK_TIMING=1 (diagnostic): how long the network stream works per submission and how long it stands idle between two
+  // tuning "trunk_timing" = 1 (diagnostic): how long the network stream works per submission and how long it stands idle between two
   // submissions, from timing events at both ends of the trunk (printed every 200 submissions)
-  static const bool trunk_timing = std::getenv("SPVO_TRUNK_TIMING") != nullptr;
+  static const bool trunk_timing = tuning("trunk_timing", 0) != 0;
   constexpr int TT = 8;   // ring of timing events: deeper than the submissions that can be in flight
   static hipEvent_t tt_b[TT], tt_e[TT];
   static long tt_n = 0;
@@ -440,39 +442,39 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   if (prof_detect) { det_e0 = get_event(c); (void)hipEventRecord(det_e0, c->stream); }
   {
     ScopedStage sp(c, stage_id(c, "preprocess"));
-    // The bulk results a host-image submission takes back -- resized images (0.85 MB), descriptors (2 x 1 MB) -- are WRITTEN into
-    // the set's pinned mirrors by the kernels that produce them (posted PCIe writes, 64 B / 1 KiB per wave instruction) instead of
-    // travelling as copies behind events: a device-to-host copy waiting for its event occupies an SDMA queue, and the NEXT pair's
-    // image upload queued on the same engine waits with it -- whether it does depended on the process's copy history (bench.py's
-    // look-ahead leg 0.95 ms per frame, the same calls from tools/sync_leg.py 0.81).  SPVO_DIRECT_HOST_WRITES=0: copies, as before.
-    int rc = launch_preprocess(c, srcs[0], srcs[1], 2, rows, cols, stride, g, 0, (extras & 1) ? (direct ? c->h_resized_r[ring] : c->d_resized_r[ring]) : nullptr);
+    // the resized u8 images (what nn.cpp:154 pushes to images_dq) stay in device memory here: one byte per thread into pinned host
+    // memory made this kernel 31 us instead of 8, in front of the whole network
+    int rc = launch_preprocess(c, srcs[0], srcs[1], 2, rows, cols, stride, g, 0, (extras & 1) ? c->d_resized_r[ring] : nullptr);
     if (rc) return rc;
   }
-  // The resized images (what nn.cpp:154 pushes to images_dq) are final here: they leave on stream_c now, under the network,
-  // instead of behind the matches at the end of the tail (0.85 MB = ~30 us of a synchronous frame).  SPVO_EARLY_RESIZED=0: as before.
-  static const bool early_res_on = !(std::getenv("SPVO_EARLY_RESIZED") && std::atoi(std::getenv("SPVO_EARLY_RESIZED")) == 0);
-  const bool early_res = (extras & 1) && early_res_on && !direct;
-  if (early_res) {
-    HIP_TRY(c, hipEventRecord(c->ev_pre[ring], c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(c->stream_c, c->ev_pre[ring], 0));
-    HIP_TRY(c, hipMemcpyAsync(c->h_resized_r[ring], c->d_resized_r[ring], (size_t)2 * c->H * c->W, hipMemcpyDeviceToHost, c->stream_c));
-    HIP_TRY(c, hipEventRecord(c->ev_res[ring], c->stream_c));
-  }
+  // ... and leave for the set's pinned mirror UNDER the network: a copy kernel (16 bytes per lane, no SDMA engine involved) on stream_c,
+  // behind the FIRST layer -- beside it (conv1a is bound by its 217 MB of stores) the copy made that layer 54 us instead of 37 --
+  // i.e. beside conv1b, which leaves 12 CUs free and does not notice
+  const bool early_res = (extras & 1) != 0;
   int rc;
   {
     ScopedStage net(c, stage_id(c, "net"));
-    rc = run_ops(c, 2, 0, c->head_start, c->stream);
+    rc = run_ops(c, 2, 0, std::min<size_t>(1, c->head_start), c->stream);
+    if (!rc && early_res) {
+      HIP_TRY(c, hipEventRecord(c->ev_pre[ring], c->stream));
+      HIP_TRY(c, hipStreamWaitEvent(c->stream_c, c->ev_pre[ring], 0));
+      const size_t n16 = ((size_t)2 * c->H * c->W + 15) / 16;   // (the buffers are allocated in multiples of 256 bytes)
+      hipLaunchKernelGGL(mirror_copy_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 64)), dim3(256), 0, c->stream_c,
+                         reinterpret_cast<const uint4 *>(c->d_resized_r[ring]), reinterpret_cast<uint4 *>(c->h_resized_r[ring]), n16);
+      HIP_TRY(c, hipGetLastError());
+      HIP_TRY(c, hipEventRecord(c->ev_res[ring], c->stream_c));
+    }
+    if (!rc) rc = run_ops(c, 2, std::min<size_t>(1, c->head_start), c->head_start, c->stream);
   }
   if (rc) { c->cur_ring = 0; return rc; }
   c->last_batch = 2;
-  // The heads (2.2 GFLOP: the one heavy piece behind the trunk) stay on the network stream, in front of the next pair's trunk.
-  // On the tail stream (SPVO_HEADS_ON_NET=0, the arrangement until the trunk's kernels became persistent one-workgroup-per-CU
-  // launches) they run beside the next pair's conv1b, which leaves them 12 CUs: the tail then finishes late, the host hands the
-  // next pair over late and the network stream idles 50-70 us per pair (1257-1265 against 1308 frames/s on one box).
-  // Engines whose trunk is not made of such launches keep them on the tail stream, where the overlap pays (sp_squeeze fp32 1286
-  // against 1248 frames/s, INT8 sp_mbv1 2360 against 2237, FP16 VGG at 192x640 3084 against 3108: either way): the plan loader
-  // decides (spvo_ctx::heads_on_net).  SPVO_HEADS_ON_NET=0 / 1 overrides.
-  const bool heads_on_net = std::getenv("SPVO_HEADS_ON_NET") ? std::atoi(std::getenv("SPVO_HEADS_ON_NET")) != 0 : c->heads_on_net;
+  // The heads (2.2 GFLOP: the one heavy piece behind the trunk): on the network stream, in front of the next pair's trunk, when the
+  // trunk is made of persistent one-workgroup-per-CU launches (VGG fp32: beside the next pair's conv1b they would have 12 CUs, the
+  // tail would finish late and the network stream idle 50-70 us per pair: 1257-1265 against 1308 frames/s); on the tail stream
+  // otherwise, where the overlap pays (sp_squeeze fp32 1286 against 1248 frames/s, INT8 sp_mbv1 2360 against 2237).  The plan
+  // loader decides (spvo_ctx::heads_on_net); tuning "heads_on_net" = 0 / 1 overrides (measurements).
+  const int hon = tuning("heads_on_net", -1);
+  const bool heads_on_net = hon < 0 ? c->heads_on_net : hon != 0;
   if (heads_on_net) {
     rc = run_ops(c, 2, c->head_start, c->ops.size(), c->stream);
     if (rc) { c->cur_ring = 0; return rc; }
@@ -497,44 +499,26 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
     ScopedStage sn(c, stage_id(c, "nms"));
     rc = launch_nms_rounds(c, 2, np, ring, NMS_FIRST, c->d_counters_all + (size_t)(((ring + 1) % RING) * 2) * NMS_COUNTER_INTS);
   }
-  if (!rc) rc = enqueue_sample(c, slots, np, ring, (direct && (extras & 2)) ? c->h_desc_r[ring] : nullptr);
+  if (!rc) rc = enqueue_sample(c, slots, np, ring);
   // Keypoints, counts and descriptors are final here: spvo_detect_wait / _collect waits for THIS point (ev_feat); the matches enqueued
-  // behind it are waited for where they are asked for (spvo_match_slots, ev_tail).  The descriptors a host-image submission
-  // (extras != 0) takes back go out on a stream of their own BESIDE the matches -- 2 MB over PCIe are ~60 us the matches need not
-  // queue behind (synchronous host path 777 -> 787 frames/s, look-ahead 1183 -> 1206-1240 on one box; the same arrangement had
-  // measured slower while the resized images still travelled with them).  SPVO_TAIL_SPLIT=1: only device-image submissions
-  // record ev_feat in front of the matches, host-image submissions keep copies and matches on the tail stream; = 0: one event
-  // behind everything for every submission.
-  static const int split_mode = std::getenv("SPVO_TAIL_SPLIT") ? std::atoi(std::getenv("SPVO_TAIL_SPLIT")) : 2;
-  const bool tail_split = split_mode == 2 || (split_mode == 1 && !extras);
-  hipStream_t cs = tail_split ? c->stream_c : c->stream_t;
-  if (tail_split) {
-    if (!rc) rc = hipEventRecord(c->ev_feat[ring], c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");
-    if (!rc && extras && !direct) rc = hipStreamWaitEvent(c->stream_c, c->ev_feat[ring], 0) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipStreamWaitEvent failed");
-  } else if (!rc && c->prematch) {
-    rc = enqueue_prematch(c, slot_l, slot_r, prev_l, ring);
-  }
-  if (!rc && extras && !direct) {
-    if (!rc && (extras & 1) && !early_res)   // resized images -> the set's pinned mirror (unless they left behind the preprocess kernel)
-      rc = hipMemcpyAsync(c->h_resized_r[ring], c->d_resized_r[ring], (size_t)2 * c->H * c->W, hipMemcpyDeviceToHost, cs) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipMemcpyAsync failed");
-    if (!rc && (extras & 2)) {   // descriptors of both images: whole slots (the counts are not known on the host yet; rows >= n are stale)
-      const size_t per = (size_t)c->cfg.max_keypoints * 256;
-      for (int i = 0; i < 2 && !rc; ++i)
-        rc = hipMemcpyAsync(c->h_desc_r[ring] + i * per, c->slots[slots[i]].d_desc, per * sizeof(float), hipMemcpyDeviceToHost, cs) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipMemcpyAsync failed");
-    }
-    if (!rc) rc = hipEventRecord(c->ev_copy[ring], cs) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");
-  }
-  if (tail_split) {
-    if (!rc && c->prematch) rc = enqueue_prematch(c, slot_l, slot_r, prev_l, ring);
-  } else if (!rc) {
-    rc = hipEventRecord(c->ev_feat[ring], c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");   // = ev_tail: one event, as before round 3
-  }
+  // behind it are waited for where they are asked for (spvo_match_slots, ev_tail).
+  if (!rc) rc = hipEventRecord(c->ev_feat[ring], c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");
+  if (!rc && c->prematch) rc = enqueue_prematch(c, slot_l, slot_r, prev_l, ring);
   if (!rc && prof_detect) {   // "detect" spans both streams: first kernel on `stream` .. last copy on `stream_t`
     hipEvent_t e1 = get_event(c);
     (void)hipEventRecord(e1, c->stream_t);
     c->pending.push_back({stage_id(c, "detect"), det_e0, e1});
   }
   if (!rc) rc = (hipEventRecord(c->ev_tail[ring], c->stream_t) == hipSuccess) ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");
+  // The descriptors a host-image submission takes back (extras bit 1: 2 x 1 MB) leave for the set's pinned mirror on stream_c, BEHIND the
+  // matches: written by the sampling kernel itself they made it 40 us instead of 4 in front of ev_feat; beside the matches the copy
+  // kernel (44 us of PCIe writes) made the distance GEMM 55 us instead of 20.  ev_copy = they have arrived
+  // (spvo_detect_mirrors_wait; spvo_detect_collect waits for it itself).
+  if (!rc && (extras & 2)) {
+    HIP_TRY(c, hipStreamWaitEvent(c->stream_c, c->ev_tail[ring], 0));
+    rc = enqueue_desc_mirror(c, slots, ring, c->stream_c);
+    if (!rc) HIP_TRY(c, hipEventRecord(c->ev_copy[ring], c->stream_c));
+  }
   c->post = c->stream;
   if (rc) return rc;
   for (int i = 0; i < 2; ++i) c->slots[slots[i]].filled = true;
@@ -542,13 +526,14 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   PendingDetect pd;
   pd.g = CropGeomS{g.row_off, g.col_off, g.crop_rows, g.crop_cols, g.scale};
   pd.rows = rows; pd.cols = cols;
-  pd.slot_l = slot_l; pd.slot_r = slot_r; pd.prev_l = prev_l; pd.ring = ring; pd.extras = extras; pd.early_res = early_res; pd.direct = direct;
+  pd.slot_l = slot_l; pd.slot_r = slot_r; pd.prev_l = prev_l; pd.ring = ring; pd.extras = extras; pd.early_res = early_res;
   c->pendq.push_back(pd);
   return SPVO_OK;
 }
 
 // completes the OLDEST submission
-static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_features *out_l, spvo_features *out_r, uint8_t *resized_l, uint8_t *resized_r) {
+static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_features *out_l, spvo_features *out_r, uint8_t *resized_l, uint8_t *resized_r,
+                       spvo_detect_mirrors *mirrors = nullptr) {
   if (c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "no detector submission in flight");
   const PendingDetect pd = c->pendq.front();
   const int slots[2] = {pd.slot_l, pd.slot_r};
@@ -572,12 +557,6 @@ static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_feature
         if (outs[i] && outs[i]->desc) HIP_TRY(c, hipMemcpyAsync(outs[i]->desc, c->slots[slots[i]].d_desc, (size_t)cap * 256 * sizeof(float), hipMemcpyDeviceToHost, c->post));
     return SPVO_OK;
   };
-  auto restage = [&]() -> int {   // after an NMS redo the set's mirrors are refreshed too
-    if (pd.extras & 2)
-      for (int i = 0; i < 2; ++i)
-        HIP_TRY(c, hipMemcpyAsync(c->h_desc_r[pd.ring] + (size_t)i * cap * 256, c->slots[slots[i]].d_desc, (size_t)cap * 256 * sizeof(float), hipMemcpyDeviceToHost, c->post));
-    return SPVO_OK;
-  };
   int rc = SPVO_OK;
   if (extras) {
     if ((rc = copy_extras())) { c->post = c->stream; return rc; }
@@ -586,20 +565,20 @@ static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_feature
     // only this submission's tail: a younger one may be queued behind it on both streams
     const double tw0 = diag_now_us();
     rc = wait_event(c->ev_feat[pd.ring]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");
-    if (!rc && pd.extras && !pd.direct) rc = wait_event(c->ev_copy[pd.ring]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");
     g_diag.max_tail_wait = std::max(g_diag.max_tail_wait, diag_now_us() - tw0);
   }
-  if (!rc && pd.early_res) rc = wait_event(c->ev_res[pd.ring]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");   // long done: it left under the network
+  if (!rc && pd.early_res) rc = wait_event(c->ev_res[pd.ring]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");   // the resized images: they left under the network (copy kernel on stream_c)
   bool redone = false;
   const NmsPair np = nms_pair(c, pd.ring);
   if (!rc) rc = nms_settle(c, 2, np, pd.ring, &redone);
   if (!rc && (redone || pd.rematch)) {   // rare: keypoints changed after the first batch -> redo what depends on them
     if (redone) c->stages[stage_id(c, "nms_redo")].calls += 1;       // counted even with profiling off (tests, diagnostics)
     if (pd.rematch) c->stages[stage_id(c, "rematch")].calls += 1;
-    if (redone) rc = enqueue_sample(c, slots, np, pd.ring, (pd.direct && (pd.extras & 2)) ? c->h_desc_r[pd.ring] : nullptr);
+    if (redone && (pd.extras & 2)) (void)wait_event(c->ev_copy[pd.ring]);   // the mirror of the superseded descriptors has landed: the new one goes on top
+    if (redone) rc = enqueue_sample(c, slots, np, pd.ring);
+    if (!rc && redone && (pd.extras & 2)) rc = enqueue_desc_mirror(c, slots, pd.ring, c->post);
     if (!rc && c->prematch) rc = enqueue_prematch(c, pd.slot_l, pd.slot_r, pd.prev_l, pd.ring);
     if (!rc && extras) rc = copy_extras();
-    if (!rc && redone && !pd.direct) rc = restage();
     if (!rc) rc = hipStreamSynchronize(c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "stream synchronisation failed");
     if (redone)
       for (auto &q : c->pendq)
@@ -615,12 +594,23 @@ static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_feature
     if (outs[i]) {
       outs[i]->n = s.n;
       if (outs[i]->xy && s.n > 0) std::memcpy(outs[i]->xy, c->h_xy_r[pd.ring] + (size_t)i * cap * 2, (size_t)s.n * 2 * sizeof(float));
-      if (outs[i]->desc && (pd.extras & 2) && s.n > 0) std::memcpy(outs[i]->desc, c->h_desc_r[pd.ring] + (size_t)i * cap * 256, (size_t)s.n * 256 * sizeof(float));
+      if (outs[i]->desc && (pd.extras & 2) && s.n > 0) {
+        (void)wait_event(c->ev_copy[pd.ring]);   // the descriptors' mirror (beside the matches on stream_c)
+        std::memcpy(outs[i]->desc, c->h_desc_r[pd.ring] + (size_t)i * cap * 256, (size_t)s.n * 256 * sizeof(float));
+      }
     }
     if (res[i] && (pd.extras & 1)) std::memcpy(res[i], c->h_resized_r[pd.ring] + (size_t)i * c->H * c->W, (size_t)c->H * c->W);
   }
   for (auto &mc : c->mcache[pd.ring])
     if (mc.valid) { mc.gen_a = c->slots[mc.slot_a].gen; mc.gen_b = c->slots[mc.slot_b].gen; }
+  if (mirrors)
+    for (int i = 0; i < 2; ++i) {
+      mirrors->n[i] = c->slots[slots[i]].n;
+      mirrors->xy[i] = c->h_xy_r[pd.ring] + (size_t)i * cap * 2;
+      mirrors->desc[i] = (pd.extras & 2) ? c->h_desc_r[pd.ring] + (size_t)i * cap * 256 : nullptr;
+      mirrors->resized[i] = (pd.extras & 1) ? c->h_resized_r[pd.ring] + (size_t)i * c->H * c->W : nullptr;
+      mirrors->token = pd.ring;
+    }
   const CropGeom g{pd.g.row_off, pd.g.col_off, pd.g.crop_rows, pd.g.crop_cols, pd.g.scale};
   if (P_l) fix_projection(P_l, g, pd.rows, pd.cols, c->cfg.bug_compat_p);
   if (P_r) fix_projection(P_r, g, pd.rows, pd.cols, c->cfg.bug_compat_p);
@@ -714,6 +704,20 @@ int spvo_detect_collect(spvo_ctx *c, double P_l[12], double P_r[12], spvo_featur
   if (!c) return fail(c, SPVO_ERR_INVALID, "null context");
   HIP_TRY(c, hipSetDevice(c->cfg.device));
   return detect_wait(c, P_l, P_r, out_l, out_r, resized_l, resized_r);
+}
+
+int spvo_detect_mirrors_wait(spvo_ctx *c, const spvo_detect_mirrors *m) {
+  if (!c || !m || m->token < 0 || m->token >= RING) return fail(c, SPVO_ERR_INVALID, "bad argument");
+  if (!m->desc[0] && !m->desc[1]) return SPVO_OK;
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  return wait_event(c->ev_copy[m->token]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");
+}
+
+int spvo_detect_collect_mirrors(spvo_ctx *c, double P_l[12], double P_r[12], spvo_detect_mirrors *out) {
+  if (!c || !out) return fail(c, SPVO_ERR_INVALID, "null argument");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  std::memset(out, 0, sizeof *out);
+  return detect_wait(c, P_l, P_r, nullptr, nullptr, nullptr, nullptr, out);
 }
 
 // ---------------------------------------------------------------- ORB (classic front end, orb.hip.h)

@@ -56,11 +56,9 @@ struct Op {
   int residual = 0;  // tensor added before the last ReLU (FLAG_ADD)
   bool merged = false;     // FP32 engines: this op's output channels are computed by the previous op's launch (sibling layers
                            // that read the same tensor and write adjacent channel ranges of one tensor: convPa + convDa)
-  bool wino = false;       // FP32 engines: this 3x3 layer runs the Winograd F(2x2,3x3) kernel (conv_wino.hip.h)
+  bool wino = false;       // FP32 engines: this 3x3 layer runs a Winograd kernel: F(2x2,3x3) (conv_wino2.hip.h) unless wino4 is set
   bool wino_narrow = false;   // ... with 32 instead of 64 output channels per workgroup (layers whose 64-channel tiles would leave CUs idle)
-  bool wino64 = false;     // ... the form with the filters resident in registers (conv_wino64.hip.h: layers with 64 input channels; opt-in, SPVO_WINO64=1)
-  bool wino4 = false;      // ... the F(4x4,3x3) form (conv_wino4.hip.h: 9/16 of F(2x2)'s matrix work; layers with even H and W)
-  bool wino2 = false;      // ... its 8-wave form (conv_wino2.hip.h: two waves per SIMD; the default, SPVO_WINO2=0 keeps the 4-wave form)
+  bool wino4 = false;      // ... the F(4x4,3x3) form (conv_wino4.hip.h: 9/16 of F(2x2)'s matrix work; pooled layers with even H and W, unpooled layers of any size)
   bool dominant = false;   // the op with the most FLOPs: launched under its own kernel name (TAG = 1)
   float *d_w = nullptr, *d_b = nullptr, *d_bn_scale = nullptr, *d_bn_shift = nullptr;
   int *d_sched = nullptr;      // Winograd layers (8-wave form): {8 band counters, workgroups done}, zero between launches (SPVO_WINO_DYNAMIC=0: none)
@@ -289,6 +287,8 @@ int dev_alloc(spvo_ctx *c, T **p, size_t count, bool zero = true) {
 
 int stage_id(spvo_ctx *c, const std::string &name);
 hipError_t wait_event(hipEvent_t ev);
+// a diagnostic switch (spvo_set_tuning, include/spvo.h): the value set for `name`, or `dflt`.  Never the environment.
+int tuning(const char *name, int dflt);
 hipEvent_t get_event(spvo_ctx *c);
 void resolve_pending(spvo_ctx *c);
 

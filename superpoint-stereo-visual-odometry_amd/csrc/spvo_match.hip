@@ -66,9 +66,7 @@ int enqueue_matches(spvo_ctx *c, const MatchReq *req_in, int njobs, int selector
   const bool swap = selector == SPVO_SELECT_NN && cross_check;
   // host_out is pinned memory of the context (h_match_out / h_match_tmp): the kernels that decide a row write its entry there
   // themselves -- 8 bytes per row over PCIe -- instead of a 16 KB copy behind them (a 19 us blit launch between the merge and the
-  // event the host waits for).  SPVO_DIRECT_HOST_WRITES=0: device buffer + copy, as before.
-  static const bool direct = !(std::getenv("SPVO_DIRECT_HOST_WRITES") && std::atoi(std::getenv("SPVO_DIRECT_HOST_WRITES")) == 0) &&
-                           !(std::getenv("SPVO_DIRECT_SMALL") && std::atoi(std::getenv("SPVO_DIRECT_SMALL")) == 0);
+  // event the host waits for).
   MatchReq req[2];
   for (int k = 0; k < njobs; ++k) {
     req[k] = req_in[k];
@@ -83,7 +81,7 @@ int enqueue_matches(spvo_ctx *c, const MatchReq *req_in, int njobs, int selector
     j.na_ptr = req[k].na_ptr; j.nb_ptr = req[k].nb_ptr;
     j.nA = req[k].sqA ? req[k].sqA : m.d_na;
     j.nB = req[k].sqB ? req[k].sqB : m.d_nb;
-    j.dt = m.d_dt; j.cand = m.d_cand; j.meta = m.d_meta; j.best_d2 = m.d_best_d2; j.best_idx = m.d_best_idx; j.train_best = m.d_train_best; j.out = direct ? host_out + (size_t)k * c->match_cap : m.d_out;
+    j.dt = m.d_dt; j.cand = m.d_cand; j.meta = m.d_meta; j.best_d2 = m.d_best_d2; j.best_idx = m.d_best_idx; j.train_best = m.d_train_best; j.out = host_out + (size_t)k * c->match_cap;
     j.A8 = j.B8 = nullptr;
     j.qA8 = j.qB8 = nullptr;
     if (c->match_fp8) {
@@ -111,9 +109,9 @@ int enqueue_matches(spvo_ctx *c, const MatchReq *req_in, int njobs, int selector
     attr[c->cfg.device & 63] = true;
   }
   // Default: the fused form -- the distance tile is reduced per query row in LDS (K12a) and a short merge (K12m) finishes the row;
-  // dt never goes to HBM.  The fp8 shortlist mode (and SPVO_MATCH_FUSED=0, for A/B measurements) keeps the two-kernel form that
+  // dt never goes to HBM.  The fp8 shortlist mode (and tuning "match_fused" = 0, for A/B measurements) keeps the two-kernel form that
   // writes every dt and reads it back.  Column tiles are lanes of the merge: capacities beyond 64 tiles use the unfused form.
-  static const bool fused_on = !(std::getenv("SPVO_MATCH_FUSED") && std::atoi(std::getenv("SPVO_MATCH_FUSED")) == 0);
+  const bool fused_on = tuning("match_fused", 1) != 0;
   const int nt_stride = (c->match_cap + MATCH_TT - 1) / MATCH_TT;
   const bool fused = fused_on && !c->match_fp8 && nt_stride <= 64;
   const int gx = groups, gy = (na_max + MATCH_QT - 1) / MATCH_QT;
@@ -136,9 +134,6 @@ int enqueue_matches(spvo_ctx *c, const MatchReq *req_in, int njobs, int selector
   }
   if (swap) hipLaunchKernelGGL(match_select_cross_kernel, dim3((nb_max + 255) / 256, njobs), dim3(256), 0, c->post, jobs);
   HIP_TRY(c, hipGetLastError());
-  // jobs' outputs are adjacent in d_match_out (stride match_cap): one copy
-  const size_t count = (njobs == 2) ? (size_t)c->match_cap + req_in[1].na : (size_t)req_in[0].na;
-  if (!direct) HIP_TRY(c, hipMemcpyAsync(host_out, c->d_match_out, count * sizeof(int2), hipMemcpyDeviceToHost, c->post));
   return SPVO_OK;
 }
 

@@ -1,10 +1,8 @@
-// spvo_net_f32.hip -- FP32 engines: launchers of the direct (conv_mfma.hip.h) and Winograd (conv_wino*.hip.h) convolution kernels and the
+// spvo_net_f32.hip -- FP32 engines: launchers of the direct (conv_mfma.hip.h) and Winograd (conv_wino2 / conv_wino4.hip.h) convolution kernels and the
 // layer executor that walks a plan (replaces the TensorRT enqueue at feature_detection_neural_network.cpp:169).
 #include "spvo_internal.hip.h"
 #include "conv_mfma.hip.h"
-#include "conv_wino.hip.h"
 #include "conv_wino2.hip.h"
-#include "conv_wino64.hip.h"
 #include "conv_wino4.hip.h"
 #include "heads.hip.h"
 
@@ -56,53 +54,41 @@ int launch_conv_epi(spvo_ctx *c, const ConvArgs &a, int batch, int epi, hipStrea
                   : launch_conv_instance<1, 16, WR, WC, POOL, false, 2>(c, args, stream);
 }
 
-// Winograd F(2x2, 3x3) instance of a 3x3 layer (conv_wino.hip.h / conv_wino2.hip.h): one tile shape, one workgroup per CU (157 KB of
-// LDS); W2 selects the 8-wave form (two waves per SIMD, 512 threads)
-template <bool POOL, bool RELU, int TAG, bool ODD = false, bool W2 = false, bool NARROW = false>
+// Winograd F(2x2, 3x3) instance of a 3x3 layer (conv_wino2.hip.h): one tile shape, one workgroup of 512 threads per CU (157 KB of LDS)
+template <bool POOL, bool RELU, int TAG, bool ODD = false, bool NARROW = false>
 int launch_conv_wino_instance(spvo_ctx *c, const ConvArgs &args, hipStream_t stream) {
   static bool ready[64] = {};
   const int dev = c->cfg.device & 63;
   const int n_tiles = args.tiles_x * args.tiles_y * args.co_tiles * args.batch;
-  // One workgroup per CU (157 KB of LDS), each walking ceil(n_tiles / grid) tiles.  The grid is the SMALLEST one that keeps that
+  // One workgroup per CU, each walking ceil(n_tiles / grid) tiles.  The grid is the SMALLEST one that keeps that
   // number of rounds: 3330 tiles are 14 rounds on 256 CUs and still 14 rounds on 238, and the 18 CUs left over take the
   // small kernels of the other streams (tail of the previous pair, solver): with all 256 CUs claimed, any of those
   // kernels sitting on a CU when a layer starts keeps that layer's last workgroup waiting for a CU.
   const int rounds = (n_tiles + c->num_cus - 1) / c->num_cus;
   const int grid = (n_tiles + rounds - 1) / rounds;
-  if constexpr (W2) {
-    auto k = conv_wino2_kernel<POOL, RELU, TAG, ODD, NARROW>;
-    if (!ready[dev]) {
-      HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, WINO2_LDS_BYTES));
-      ready[dev] = true;
-    }
-    ConvArgs a2 = args;
-    if (rounds < 2 || args.n_chunks < 4) a2.sched = nullptr;   // one tile per workgroup: nothing to hand out; short K loops: see the kernel
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), WINO2_LDS_BYTES, stream, a2);
-  } else {
-    auto k = conv_wino_kernel<POOL, RELU, TAG, ODD>;
-    if (!ready[dev]) {
-      HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, WinoTile::LDS_BYTES));
-      ready[dev] = true;
-    }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), WinoTile::LDS_BYTES, stream, args);
+  auto k = conv_wino2_kernel<POOL, RELU, TAG, ODD, NARROW>;
+  if (!ready[dev]) {
+    HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, WINO2_LDS_BYTES));
+    ready[dev] = true;
   }
+  ConvArgs a2 = args;
+  if (rounds < 2 || args.n_chunks < 4) a2.sched = nullptr;   // one tile per workgroup: nothing to hand out; short K loops: see the kernel
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), WINO2_LDS_BYTES, stream, a2);
   HIP_TRY(c, hipGetLastError());
   return SPVO_OK;
 }
 
-template <bool W2>
 int launch_conv_wino_sel(spvo_ctx *c, const ConvArgs &args, bool relu, bool pool, bool dominant, bool narrow, hipStream_t stream) {
   const ConvArgs &a = args;
-  if constexpr (W2)
-    if (narrow) {   // 32 output channels per workgroup (layers that would leave CUs idle with 64)
-      if (!pool && ((a.H | a.W) & 1)) return relu ? launch_conv_wino_instance<false, true, 0, true, true, true>(c, args, stream) : launch_conv_wino_instance<false, false, 0, true, true, true>(c, args, stream);
-      if (pool) return relu ? launch_conv_wino_instance<true, true, 0, false, true, true>(c, args, stream) : launch_conv_wino_instance<true, false, 0, false, true, true>(c, args, stream);
-      return relu ? launch_conv_wino_instance<false, true, 0, false, true, true>(c, args, stream) : launch_conv_wino_instance<false, false, 0, false, true, true>(c, args, stream);
-    }
-  if (!pool && ((a.H | a.W) & 1)) return relu ? launch_conv_wino_instance<false, true, 0, true, W2>(c, args, stream) : launch_conv_wino_instance<false, false, 0, true, W2>(c, args, stream);
-  if (dominant && relu) return pool ? launch_conv_wino_instance<true, true, 1, false, W2>(c, args, stream) : launch_conv_wino_instance<false, true, 1, false, W2>(c, args, stream);
-  if (pool) return relu ? launch_conv_wino_instance<true, true, 0, false, W2>(c, args, stream) : launch_conv_wino_instance<true, false, 0, false, W2>(c, args, stream);
-  return relu ? launch_conv_wino_instance<false, true, 0, false, W2>(c, args, stream) : launch_conv_wino_instance<false, false, 0, false, W2>(c, args, stream);
+  if (narrow) {   // 32 output channels per workgroup (layers that would leave CUs idle with 64)
+    if (!pool && ((a.H | a.W) & 1)) return relu ? launch_conv_wino_instance<false, true, 0, true, true>(c, args, stream) : launch_conv_wino_instance<false, false, 0, true, true>(c, args, stream);
+    if (pool) return relu ? launch_conv_wino_instance<true, true, 0, false, true>(c, args, stream) : launch_conv_wino_instance<true, false, 0, false, true>(c, args, stream);
+    return relu ? launch_conv_wino_instance<false, true, 0, false, true>(c, args, stream) : launch_conv_wino_instance<false, false, 0, false, true>(c, args, stream);
+  }
+  if (!pool && ((a.H | a.W) & 1)) return relu ? launch_conv_wino_instance<false, true, 0, true>(c, args, stream) : launch_conv_wino_instance<false, false, 0, true>(c, args, stream);
+  if (dominant && relu) return pool ? launch_conv_wino_instance<true, true, 1, false>(c, args, stream) : launch_conv_wino_instance<false, true, 1, false>(c, args, stream);
+  if (pool) return relu ? launch_conv_wino_instance<true, true, 0, false>(c, args, stream) : launch_conv_wino_instance<true, false, 0, false>(c, args, stream);
+  return relu ? launch_conv_wino_instance<false, true, 0, false>(c, args, stream) : launch_conv_wino_instance<false, false, 0, false>(c, args, stream);
 }
 
 // conv_wino4.hip.h: Winograd F(4x4,3x3), 16 x 32 output tiles, 8 waves, one workgroup per CU
@@ -136,43 +122,12 @@ int launch_conv_wino4(spvo_ctx *c, const ConvArgs &a, int batch, bool relu, bool
   return relu ? launch_conv_wino4_instance<false, true, 0>(c, args, stream) : launch_conv_wino4_instance<false, false, 0>(c, args, stream);
 }
 
-// conv_wino64.hip.h: filters resident in registers (64 input channels), 4 x 32 output tiles, one workgroup per CU
-template <bool POOL, bool RELU, int TAG>
-int launch_conv_wino64_instance(spvo_ctx *c, const ConvArgs &args, hipStream_t stream) {
-  static bool ready[64] = {};
-  const int dev = c->cfg.device & 63;
-  auto k = conv_wino64_kernel<POOL, RELU, TAG>;
-  if (!ready[dev]) {
-    HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, Wino64Tile::LDS_BYTES));
-    ready[dev] = true;
-  }
-  // the smallest grid that keeps the number of rounds (see launch_conv_wino_instance): CUs left over serve the other streams
-  const int n_tiles = args.tiles_x * args.tiles_y * args.co_tiles * args.batch;
-  const int rounds = (n_tiles + c->num_cus - 1) / c->num_cus;
-  const int grid = (n_tiles + rounds - 1) / rounds;
-  ConvArgs a2 = args;
-  if (rounds < 2) a2.sched = nullptr;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(256), Wino64Tile::LDS_BYTES, stream, a2);
-  HIP_TRY(c, hipGetLastError());
-  return SPVO_OK;
-}
-
-int launch_conv_wino64(spvo_ctx *c, const ConvArgs &a, int batch, bool relu, bool pool, bool dominant, hipStream_t stream) {
-  ConvArgs args = a;
-  args.tiles_x = (a.W + Wino64Tile::TW - 1) / Wino64Tile::TW;
-  args.tiles_y = (a.H + Wino64Tile::TH - 1) / Wino64Tile::TH;
-  args.batch = batch;
-  if (dominant && relu) return pool ? launch_conv_wino64_instance<true, true, 1>(c, args, stream) : launch_conv_wino64_instance<false, true, 1>(c, args, stream);
-  if (pool) return relu ? launch_conv_wino64_instance<true, true, 0>(c, args, stream) : launch_conv_wino64_instance<true, false, 0>(c, args, stream);
-  return relu ? launch_conv_wino64_instance<false, true, 0>(c, args, stream) : launch_conv_wino64_instance<false, false, 0>(c, args, stream);
-}
-
-int launch_conv_wino(spvo_ctx *c, const ConvArgs &a, int batch, bool relu, bool pool, bool dominant, bool w2, bool narrow, hipStream_t stream) {
+int launch_conv_wino(spvo_ctx *c, const ConvArgs &a, int batch, bool relu, bool pool, bool dominant, bool narrow, hipStream_t stream) {
   ConvArgs args = a;
   args.tiles_x = (a.W + WinoTile::TW - 1) / WinoTile::TW;
   args.tiles_y = (a.H + WinoTile::TH - 1) / WinoTile::TH;
   args.batch = batch;
-  return w2 ? launch_conv_wino_sel<true>(c, args, relu, pool, dominant, narrow, stream) : launch_conv_wino_sel<false>(c, args, relu, pool, dominant, false, stream);
+  return launch_conv_wino_sel(c, args, relu, pool, dominant, narrow, stream);
 }
 
 // images [img0, img0 + batch) of the tensors, on `stream`
@@ -216,8 +171,7 @@ int launch_conv(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stre
   a.batch = batch;
   a.sched = op.d_sched;
   if (op.wino4) return launch_conv_wino4(c, a, batch, relu, pool, op.dominant, stream);
-  if (op.wino64) return launch_conv_wino64(c, a, batch, relu, pool, op.dominant, stream);
-  if (op.wino) return launch_conv_wino(c, a, batch, relu, pool, op.dominant, op.wino2, op.wino_narrow, stream);
+  if (op.wino) return launch_conv_wino(c, a, batch, relu, pool, op.dominant, op.wino_narrow, stream);
   const int key = op.ks * 10000 + op.ck * 100 + op.wr * 20 + op.wc * 2 + (pool ? 1 : 0);   // ks, ck, wr, wc, pool
   if (epi) {
     a.bn_scale = op.d_bn_scale; a.bn_shift = op.d_bn_shift;

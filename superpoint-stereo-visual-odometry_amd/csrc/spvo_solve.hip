@@ -177,7 +177,7 @@ int spvo_solve_submit(spvo_ctx *c, const spvo_solve_input *in) {
     c->solve_cap = cap;
   }
   if (grow) HIP_TRY(c, hipDeviceSynchronize());
-  static const bool solve_timing = std::getenv("SPVO_SOLVE_TIMING") != nullptr;   // diagnostic: host time per phase of this call
+  static const bool solve_timing = tuning("solve_timing", 0) != 0;   // diagnostic: host time per phase of this call
   static double tacc[4] = {0, 0, 0, 0};
   static long tcalls = 0;
   auto now_us = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };

@@ -4,6 +4,7 @@
 // with every numeric step forwarded to the C ABI (include/spvo.h).  Error convention as in
 // the reference: log and return, never throw (nn.cpp:53-55, 96-100, 490-491).
 #include "feature_detection.hpp"
+#include <mutex>
 
 #include <algorithm>
 #include <cmath>
@@ -124,6 +125,7 @@ void FeatureFrontEnd::clearLagecyData() {
     (void)spvo_solve_wait(ctx_, &so, xyz.data(), inl.data());
   }
   solve_pending_ = false;
+  completeHostCopies();
   images_dq.clear();
   keypoints_dq.clear();
   descriptors_dq.clear();
@@ -184,6 +186,7 @@ void FeatureFrontEnd::matchDescriptors(const MatchType match_type) {
     }
     rc = spvo_match_hamming(ctx_, rows_of(d0, b0), d0.rows, rows_of(d1, b1), d1.rows, nbytes, sel, matcher_cross_check_ ? 1 : 0, knn_threshold_, train.data(), dist.data());
   } else {
+    completeImageCopies();   // the GPU is still matching (spvo_match_slots waits for it): images_dq's share of the deferred copies fits here
     rc = spvo_match_slots(ctx_, slots_dq_.end()[p0], slots_dq_.end()[p1], sel, matcher_cross_check_ ? 1 : 0, knn_threshold_, train.data(), dist.data());
   }
   if (rc != SPVO_OK) {
@@ -213,14 +216,15 @@ void FeatureFrontEnd::matchDescriptors(const MatchType match_type) {
 static double host_now_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
 
 void FeatureFrontEnd::solveStereoOdometry(tf2::Transform &cam0_curr_T_cam0_prev) {
-  if (solveStereoOdometrySubmit()) solveStereoOdometryCollect(cam0_curr_T_cam0_prev);
+  if (solveStereoOdometrySubmit()) solveStereoOdometryCollect(cam0_curr_T_cam0_prev);   // (Collect fills the deques while the kernels run)
+  else completeHostCopies();
 }
 
 // First half (extension): the correspondence join (base.cpp:127-207) and the hand-over of the numeric part to spvo_solve_submit.
 // Nothing of the front end's state changes here except the per-frame maps of the join; the result is taken by
 // solveStereoOdometryCollect, which has to run before the next frame's join (that one needs this frame's points and prior).
 bool FeatureFrontEnd::solveStereoOdometrySubmit() {
-  static const bool timing = std::getenv("SPVO_SOLVE_TIMING") != nullptr;   // diagnostic
+  static const bool timing = spvo_get_tuning("solve_timing", 0) != 0;   // diagnostic (spvo_set_tuning)
   static double acc[3] = {0, 0, 0};
   static long calls = 0;
   const double th0 = timing ? host_now_us() : 0;
@@ -334,6 +338,7 @@ bool FeatureFrontEnd::solveStereoOdometryCollect(tf2::Transform &cam0_curr_T_cam
   const int n = solve_n_;
   std::vector<float> &pts3d = solve_pts3d_;
   spvo_solve_output so;
+  completeHostCopies();   // the solver's kernels are running: the bulk copies into images_dq / descriptors_dq cost nothing here
   const int solve_rc = spvo_solve_wait(ctx_, &so, pts3d.data(), inliers_pnp.data());
   if (solve_rc != SPVO_OK) {
     logError(std::string("spvo_solve_wait: ") + spvo_last_error(ctx_));
@@ -363,12 +368,14 @@ bool FeatureFrontEnd::solveStereoOdometryCollect(tf2::Transform &cam0_curr_T_cam
 }
 
 cv::Mat FeatureFrontEnd::visualizeMatches(const MatchType match_type) {
+  completeHostCopies();
   if (images_dq.size() < 4) return cv::Mat();
   return images_dq.end()[match_type_to_positions[match_type].second].clone();
 }
 
 cv::Mat FeatureFrontEnd::visualizeInliers(const ImagePosition image_position) {
   if (image_position != CURR_LEFT) logError("inlier visualization for " + ImagePosition_str.at(image_position) + " is not implemented yet");
+  completeHostCopies();
   if (images_dq.empty()) return cv::Mat();
   return images_dq.end()[image_position].clone();
 }
@@ -566,6 +573,7 @@ SuperPointFeatureFrontEnd::SuperPointFeatureFrontEnd(const MatcherType matcher_t
 }
 
 SuperPointFeatureFrontEnd::~SuperPointFeatureFrontEnd() {
+  completeHostCopies();   // (their sources are mirrors the context owns)
   drainPrefetch();
   if (ctx_) spvo_destroy(ctx_);
   ctx_ = nullptr;
@@ -613,7 +621,7 @@ void SuperPointFeatureFrontEnd::loadEngine() {
   // stereoCallback always asks for CURR_LEFT->CURR_RIGHT and CURR_LEFT->PREV_LEFT right after the
   // detector (node.cpp:196-198): have them enqueued in the detector's own submission
   if (std::getenv("SPVO_MATCH_FP8")) spvo_set_match_fp8(ctx_, 1);   // fp8 shortlist GEMM (config 5; the GEMM only prunes, two-pass exact re-rank)
-  if (matcher_ready_ && !std::getenv("SPVO_NO_PREMATCH"))
+  if (matcher_ready_ && spvo_get_tuning("prematch", 1))
     spvo_set_prematch(ctx_, 1, selector_type_ == SelectorType::KNN ? SPVO_SELECT_KNN : SPVO_SELECT_NN, matcher_cross_check_ ? 1 : 0, knn_threshold_);
   for (int i = 0; i < 2; ++i) {
     xy_buf_[i].assign((size_t)max_keypoints_ * 2, 0.f);
@@ -624,6 +632,7 @@ void SuperPointFeatureFrontEnd::loadEngine() {
 
 void SuperPointFeatureFrontEnd::addStereoImagePair(cv::Mat &img_l, cv::Mat &img_r, const cv::Mat &projection_matrix_l,
                                                    const cv::Mat &projection_matrix_r) {
+  completeHostCopies();   // a pair whose bulk copies are still owed (no solve followed it): before its mirrors can be reused
   if (!engine_loaded_) {
     logError("addStereoImagePair: no engine loaded");
     return;
@@ -659,24 +668,66 @@ void SuperPointFeatureFrontEnd::addStereoImagePair(cv::Mat &img_l, cv::Mat &img_
       return;
     }
   }
-  spvo_features fl{0, xy_buf_[0].data(), desc_buf_[0].data()}, fr{0, xy_buf_[1].data(), desc_buf_[1].data()};
-  cv::Mat res_l(input_height_, input_width_, CV_8UC1), res_r(input_height_, input_width_, CV_8UC1);
-  const int rc = spvo_detect_collect(ctx_, projection_matrix_l_.ptr<double>(0), projection_matrix_r_.ptr<double>(0), &fl, &fr, res_l.data, res_r.data);
+  // The results sit in the submission's pinned mirrors (the kernels wrote them there): keypoints and the image handed back to the
+  // caller are copied now; the matrices of images_dq / descriptors_dq get their final size now and their contents once --
+  // at once, or (setDeferredHostCopies, the default) while the solver's kernels run.
+  spvo_detect_mirrors mr;
+  const int rc = spvo_detect_collect_mirrors(ctx_, projection_matrix_l_.ptr<double>(0), projection_matrix_r_.ptr<double>(0), &mr);
   if (rc != SPVO_OK) {
-    logError(std::string("spvo_detect_collect: ") + spvo_last_error(ctx_));
+    logError(std::string("spvo_detect_collect_mirrors: ") + spvo_last_error(ctx_));
     return;
   }
+  pending_mirrors_ = mr;
+  const size_t img_bytes = (size_t)input_height_ * input_width_;
+  cv::Mat res[2] = {cv::Mat(input_height_, input_width_, CV_8UC1), cv::Mat(input_height_, input_width_, CV_8UC1)};
+  for (int i = 0; i < 2; ++i) std::memcpy(res[i].data, mr.resized[i], img_bytes);
   // the reference mutates the caller's images in place (crop + resize + convertTo float,
   // base.cpp:89,105,115; nn.cpp:159); hand back the resized image, keep u8
-  img_l = res_l;
-  img_r = res_r;
-  const spvo_features *f[2] = {&fl, &fr};
-  const cv::Mat *res[2] = {&res_l, &res_r};
+  img_l = res[0];
+  img_r = res[1];
   const int slots[2] = {slot_l, slot_r};
-  pushFeatures(f, res, slots, true);
+  for (int i = 0; i < 2; ++i) {
+    cv::Mat im(input_height_, input_width_, CV_8UC1);                       // nn.cpp:154: images_dq holds its own copy
+    cv::Mat d(mr.n[i], output_desc_channel_, CV_32FC1);
+    pending_copies_.push_back(PendingCopy{mr.resized[i], im, img_bytes, false});
+    pending_copies_.push_back(PendingCopy{mr.desc[i], d, (size_t)mr.n[i] * output_desc_channel_ * sizeof(float), true});
+    images_dq.push_back(im);
+    std::vector<cv::KeyPoint> kps;
+    kps.reserve(mr.n[i]);
+    for (int k = 0; k < mr.n[i]; ++k) kps.emplace_back(cv::Point2f(mr.xy[i][2 * k], mr.xy[i][2 * k + 1]), 1.f);  // nn.cpp:243
+    keypoints_dq.push_back(std::move(kps));
+    descriptors_dq.push_back(d);
+    slots_dq_.push_back(slots[i]);
+  }
+  if (!defer_host_copies_) {
+    completeHostCopies();
+  }
+  if (verbose_) logInfo(std::to_string(keypoints_dq.end()[-2].size()) + ", " + std::to_string(keypoints_dq.end()[-1].size()) + " keypoints for img_l and img_r");
+  while (images_dq.size() > 4) {  // nn.cpp:494-498
+    images_dq.pop_front();
+    keypoints_dq.pop_front();
+    descriptors_dq.pop_front();
+    slots_dq_.pop_front();
+  }
+}
+
+void SuperPointFeatureFrontEnd::completeImageCopies() {
+  for (PendingCopy &pc : pending_copies_)
+    if (!pc.descriptors && pc.bytes && pc.src && pc.dst.data) { std::memcpy(pc.dst.data, pc.src, pc.bytes); pc.bytes = 0; }
+}
+
+void SuperPointFeatureFrontEnd::completeHostCopies() {
+  if (pending_copies_.empty()) return;
+  completeImageCopies();
+  if (ctx_ && spvo_detect_mirrors_wait(ctx_, &pending_mirrors_) != SPVO_OK)   // the descriptors travel behind the matches: long there by now
+    logError(std::string("spvo_detect_mirrors_wait: ") + spvo_last_error(ctx_));
+  for (PendingCopy &pc : pending_copies_)
+    if (pc.bytes && pc.src && pc.dst.data) std::memcpy(pc.dst.data, pc.src, pc.bytes);
+  pending_copies_.clear();
 }
 
 void SuperPointFeatureFrontEnd::prefetchStereoImagePair(const cv::Mat &img_l, const cv::Mat &img_r) {
+  completeHostCopies();   // a pair whose bulk copies are still owed (no solve followed it): before its mirrors can be reused
   if (!engine_loaded_ || prefetch_q_.size() >= 3) return;
   if (img_l.type() != CV_8UC1 || img_r.type() != CV_8UC1 || img_l.rows != img_r.rows || img_l.cols != img_r.cols || (size_t)img_l.step != (size_t)img_r.step) return;
   for (const auto &q : prefetch_q_)   // already announced
@@ -695,6 +746,7 @@ void SuperPointFeatureFrontEnd::prefetchStereoImagePair(const cv::Mat &img_l, co
 void SuperPointFeatureFrontEnd::addStereoImagePairDevice(const void *d_img_l, const void *d_img_r, int rows, int cols, size_t stride,
                                                          const cv::Mat &projection_matrix_l, const cv::Mat &projection_matrix_r,
                                                          bool host_descriptors) {
+  completeHostCopies();   // a pair whose bulk copies are still owed (no solve followed it): before its mirrors can be reused
   if (!engine_loaded_) {
     logError("addStereoImagePairDevice: no engine loaded");
     return;
@@ -738,6 +790,7 @@ void SuperPointFeatureFrontEnd::addStereoImagePairDevice(const void *d_img_l, co
 }
 
 void SuperPointFeatureFrontEnd::prefetchStereoImagePairDevice(const void *d_img_l, const void *d_img_r, int rows, int cols, size_t stride) {
+  completeHostCopies();   // a pair whose bulk copies are still owed (no solve followed it): before its mirrors can be reused
   if (!engine_loaded_ || prefetch_q_.size() >= 3) return;
   for (const auto &q : prefetch_q_)   // already announced
     if (!q.host && q.l == d_img_l && q.r == d_img_r && q.rows == rows && q.cols == cols && q.stride == stride) return;

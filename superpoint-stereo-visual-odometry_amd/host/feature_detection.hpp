@@ -57,8 +57,12 @@ public:
   Mat(int r, int c, int type) { create(r, c, type); }
   void create(int r, int c, int type) {
     rows = r; cols = c; type_ = type; step.p = (size_t)c * elemSize();
-    buf_ = std::make_shared<std::vector<uint8_t>>((size_t)r * step.p, 0);
-    data = buf_->empty() ? nullptr : buf_->data();
+    const size_t bytes = (size_t)r * step.p;
+    // cv::Mat::create leaves the buffer uninitialised; this stand-in zero-fills SMALL matrices (pose / projection matrices a test may
+    // build element by element) and leaves image- and descriptor-sized ones alone (1 MB of memset is 30 us of a 1.1 ms frame)
+    buf_ = bytes > 65536 ? std::shared_ptr<uint8_t>(new uint8_t[bytes], std::default_delete<uint8_t[]>())
+                         : std::shared_ptr<uint8_t>(new uint8_t[bytes ? bytes : 1](), std::default_delete<uint8_t[]>());
+    data = bytes ? buf_.get() : nullptr;
   }
   int type() const { return type_; }
   int depth() const { return type_; }   // one channel: type == depth
@@ -78,7 +82,7 @@ public:
 
 private:
   int type_ = CV_8U;
-  std::shared_ptr<std::vector<uint8_t>> buf_;
+  std::shared_ptr<uint8_t> buf_;
 };
 
 struct Point2f {
@@ -210,6 +214,11 @@ public:
   bool solveStereoOdometrySubmit();
   bool solveStereoOdometryCollect(tf2::Transform &cam0_curr_T_cam0_prev);
   bool solvePending() const { return solve_pending_; }
+  // Extension: finish whatever a front end still has to copy into images_dq / descriptors_dq (SuperPointFeatureFrontEnd defers the
+  // bulk copies of a host-image pair until the solver's kernels are running: see there).  Every entry point of this class calls it
+  // where it matters; code that reads the deques DIRECTLY between addStereoImagePair and solveStereoOdometry calls it first.
+  virtual void completeHostCopies() {}
+  virtual void completeImageCopies() {}   // the part of it that does not have to wait for the descriptors' mirror (matchDescriptors runs it while the GPU matches)
   // Drawing only (base.cpp:401-432, 502-553): out of the hot-path scope; they return the
   // stored image untouched so that the node's publish calls keep working.
   cv::Mat visualizeMatches(const MatchType match_type);
@@ -368,6 +377,18 @@ public:
   // reuse them; the following addStereoImagePair with the same images (same data pointers and size) only collects.
   void prefetchStereoImagePair(const cv::Mat &img_l, const cv::Mat &img_r);
   spvo_ctx *context() const { return ctx_; }
+  // The resized images and the descriptors of a HOST-image pair are written by the GPU into pinned mirrors of the submission
+  // (spvo_detect_collect_mirrors) and copied ONCE into the matrices of images_dq / descriptors_dq.  By default those two copies
+  // (2 x 0.42 MB + 2 x 1 MB: ~0.1 ms of host time) are deferred: addStereoImagePair pushes matrices of the final size and returns;
+  // they are filled while the solver's kernels run (solveStereoOdometry, between its submit and its wait: 864 -> 929 frames/s on
+  // the synchronous call sequence; a helper thread for the copies measured the same, 931, and was not kept), or at the next call
+  // that takes a pair, draws, clears or destroys -- always before the mirrors are reused and before anything this class hands
+  // out.  What the unchanged node can observe (visual_odometry_node.cpp:175-218 calls methods only) is unchanged; code that reads
+  // images_dq / descriptors_dq directly between addStereoImagePair and solveStereoOdometry calls completeHostCopies() first, or
+  // switches the deferral off here.  Keypoints, the image handed back to the caller and every index map are never deferred.
+  void setDeferredHostCopies(bool on) { if (!on) completeHostCopies(); defer_host_copies_ = on; }
+  void completeHostCopies() override;
+  void completeImageCopies() override;
 
   inline int getInputHeight() const { return input_height_; }
   inline int getInputWidth() const { return input_width_; }
@@ -398,4 +419,8 @@ private:
   void drainPrefetch();
   void pickSlots(int *slot_l, int *slot_r);
   void pushFeatures(const spvo_features *f[2], const cv::Mat *images[2], const int slots[2], bool host_descriptors);
+  struct PendingCopy { const void *src = nullptr; cv::Mat dst; size_t bytes = 0; bool descriptors = false; };
+  std::vector<PendingCopy> pending_copies_;   // mirror -> matrix copies not made yet (at most one pair's)
+  spvo_detect_mirrors pending_mirrors_;       // ... and where they come from (spvo_detect_mirrors_wait before the descriptors are read)
+  bool defer_host_copies_ = true;
 };

@@ -95,6 +95,9 @@ int spvo_host_solve_pending(void *h) { return static_cast<SuperPointFeatureFront
 
 void spvo_host_clear(void *h) { static_cast<SuperPointFeatureFrontEnd *>(h)->clearLagecyData(); }
 
+// setDeferredHostCopies (feature_detection.hpp): 0 = images_dq / descriptors_dq are filled inside addStereoImagePair
+void spvo_host_set_deferred_copies(void *h, int on) { static_cast<SuperPointFeatureFrontEnd *>(h)->setDeferredHostCopies(on != 0); }
+
 int spvo_host_dq_size(void *h) { return (int)static_cast<SuperPointFeatureFrontEnd *>(h)->keypoints_dq.size(); }
 
 // position: -4..-1 (ImagePosition)
@@ -108,6 +111,7 @@ int spvo_host_keypoints(void *h, int position, float *xy, int cap) {
 
 int spvo_host_descriptors(void *h, int position, float *desc, int cap) {
   auto *fe = static_cast<SuperPointFeatureFrontEnd *>(h);
+  fe->completeHostCopies();   // the harness reads the deque itself (feature_detection.hpp: setDeferredHostCopies)
   if ((int)fe->descriptors_dq.size() + position < 0) return -1;
   const auto &d = fe->descriptors_dq.end()[position];
   const int n = d.rows < cap ? d.rows : cap;
@@ -117,6 +121,7 @@ int spvo_host_descriptors(void *h, int position, float *desc, int cap) {
 
 int spvo_host_image(void *h, int position, uint8_t *out, int cap) {
   auto *fe = static_cast<SuperPointFeatureFrontEnd *>(h);
+  fe->completeHostCopies();   // the harness reads the deque itself (feature_detection.hpp: setDeferredHostCopies)
   if ((int)fe->images_dq.size() + position < 0) return -1;
   const auto &m = fe->images_dq.end()[position];
   if (m.rows * m.cols <= cap) std::memcpy(out, m.data, (size_t)m.rows * m.cols);

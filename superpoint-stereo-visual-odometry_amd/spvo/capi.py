@@ -25,6 +25,10 @@ class Features(C.Structure):
     _fields_ = [("n", C.c_int), ("xy", C.POINTER(C.c_float)), ("desc", C.POINTER(C.c_float))]
 
 
+class DetectMirrors(C.Structure):
+    _fields_ = [("n", C.c_int * 2), ("xy", C.POINTER(C.c_float) * 2), ("desc", C.POINTER(C.c_float) * 2), ("resized", C.POINTER(C.c_uint8) * 2), ("token", C.c_int)]
+
+
 class RansacOpts(C.Structure):
     _fields_ = [("iterations", C.c_int), ("reproj_error", C.c_double), ("confidence", C.c_double),
                 ("seed", C.c_uint32)]
@@ -58,9 +62,10 @@ OBS_DTYPE = np.dtype([("X", np.float32, 3), ("uv", np.float32, 2), ("cam", np.in
 SYMBOLS = [
     "spvo_default_config", "spvo_create", "spvo_destroy", "spvo_last_error", "spvo_load_weights", "spvo_engine_precision", "spvo_set_fp32_split",
     "spvo_preprocess", "spvo_forward", "spvo_debug_tensor", "spvo_heatmap", "spvo_nms",
-    "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_detect_dev_submit", "spvo_detect_wait", "spvo_detect_submit", "spvo_detect_collect", "spvo_match", "spvo_match_slots", "spvo_set_prematch", "spvo_set_match_fp8",
+    "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_detect_dev_submit", "spvo_detect_wait", "spvo_detect_submit", "spvo_detect_collect", "spvo_detect_collect_mirrors", "spvo_detect_mirrors_wait", "spvo_match", "spvo_match_slots", "spvo_set_prematch", "spvo_set_match_fp8",
     "spvo_match_hamming", "spvo_orb_detect", "spvo_orb_tables", "spvo_triangulate", "spvo_pnp_ransac", "spvo_pnp_refine", "spvo_solve_stereo_odometry", "spvo_solve_submit", "spvo_solve_wait", "spvo_stream", "spvo_synchronize",
     "spvo_profile_enable", "spvo_profile_reset", "spvo_profile_only", "spvo_profile_count", "spvo_profile_get", "spvo_profile_stage_kernel",
+    "spvo_set_tuning", "spvo_get_tuning", "spvo_clear_tuning",
     "spvo_comm_unique_id", "spvo_comm_create", "spvo_comm_create_host", "spvo_comm_rank", "spvo_comm_world", "spvo_comm_destroy",
     "spvo_pose_allgather", "spvo_pose_allgather_n",
 ]
@@ -99,6 +104,13 @@ def load() -> C.CDLL:
     lib.spvo_detect_wait.argtypes = [vp, dp, dp, C.POINTER(Features), C.POINTER(Features)]
     lib.spvo_detect_submit.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int]
     lib.spvo_detect_collect.argtypes = [vp, dp, dp, C.POINTER(Features), C.POINTER(Features), vp, vp]
+    lib.spvo_detect_collect_mirrors.argtypes = [vp, dp, dp, C.POINTER(DetectMirrors)]
+    lib.spvo_detect_mirrors_wait.argtypes = [vp, C.POINTER(DetectMirrors)]
+    lib.spvo_set_tuning.argtypes = [C.c_char_p, C.c_int]
+    lib.spvo_get_tuning.argtypes = [C.c_char_p, C.c_int]
+    lib.spvo_get_tuning.restype = C.c_int
+    lib.spvo_clear_tuning.argtypes = []
+    lib.spvo_clear_tuning.restype = None
     lib.spvo_match.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
     lib.spvo_match_slots.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
     lib.spvo_match_hamming.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
@@ -305,6 +317,21 @@ class Context:
             out["resized_l"], out["resized_r"] = rl, rr
         return out
 
+    def detect_collect_mirrors(self, P_l, P_r):
+        """spvo_detect_collect_mirrors: numpy VIEWS of the submission's pinned mirrors (valid until three more submissions)"""
+        Pl = np.ascontiguousarray(P_l, np.float64).reshape(12).copy()
+        Pr = np.ascontiguousarray(P_r, np.float64).reshape(12).copy()
+        m = DetectMirrors()
+        self._check(self.lib.spvo_detect_collect_mirrors(self.h, _dptr(Pl), _dptr(Pr), C.byref(m)))
+        self._check(self.lib.spvo_detect_mirrors_wait(self.h, C.byref(m)))      # the descriptors arrive beside the matches
+        out = dict(P_l=Pl.reshape(3, 4), P_r=Pr.reshape(3, 4))
+        for i, side in enumerate("lr"):
+            n = m.n[i]
+            out["xy_" + side] = np.ctypeslib.as_array(m.xy[i], (max(n, 1), 2))[:n]
+            out["desc_" + side] = np.ctypeslib.as_array(m.desc[i], (max(n, 1), 256))[:n] if m.desc[i] else None
+            out["resized_" + side] = np.ctypeslib.as_array(m.resized[i], (self.H, self.W)) if m.resized[i] else None
+        return out
+
     def detect_wait(self, P_l, P_r):
         Pl = np.ascontiguousarray(P_l, np.float64).reshape(12).copy()
         Pr = np.ascontiguousarray(P_r, np.float64).reshape(12).copy()
@@ -470,6 +497,30 @@ class Context:
         f = C.c_double()
         self._check(self.lib.spvo_profile_stage_kernel(self.h, stage.encode(), name, 64, C.byref(f)))
         return name.value.decode(), f.value
+
+
+def set_tuning(name: str, value: int):
+    """spvo_set_tuning: a diagnostic switch of the library (process-wide; contexts created / engines loaded afterwards).  The library
+    reads no environment variable for these: tests and tools set them through this call."""
+    rc = load().spvo_set_tuning(name.encode(), int(value))
+    if rc:
+        raise SpvoError(rc, f"unknown tuning name {name!r}")
+
+
+def get_tuning(name: str, default: int) -> int:
+    return load().spvo_get_tuning(name.encode(), int(default))
+
+
+def clear_tuning():
+    load().spvo_clear_tuning()
+
+
+def tuning_from_env(prefix: str = "SPVO_TUNE_"):
+    """tools/ only: SPVO_TUNE_<NAME>=<int> in the environment of a measurement script -> set_tuning (the script opts in by calling
+    this; the library itself never looks)."""
+    for k, v in os.environ.items():
+        if k.startswith(prefix):
+            set_tuning(k[len(prefix):].lower(), int(v))
 
 
 COMM_ID_BYTES = 128

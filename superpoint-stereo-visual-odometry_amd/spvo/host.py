@@ -26,6 +26,8 @@ def load():
         lib.spvo_host_create.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]
         lib.spvo_host_destroy.argtypes = [vp]
+        lib.spvo_host_set_deferred_copies.argtypes = [vp, C.c_int]
+        lib.spvo_host_set_deferred_copies.restype = None
         lib.spvo_host_destroy.restype = None
         lib.spvo_host_last_error.argtypes = [vp]
         lib.spvo_host_last_error.restype = C.c_char_p
@@ -146,6 +148,10 @@ class FrontEnd:
         Pr = np.ascontiguousarray(P_r, np.float64)
         self.lib.spvo_host_add_stereo_pair_dev(self.h, C.c_void_p(d_l), C.c_void_p(d_r), rows, cols, stride, _p(Pl), _p(Pr),
                                                int(host_descriptors))
+
+    def set_deferred_copies(self, on):
+        """SuperPointFeatureFrontEnd::setDeferredHostCopies: False = images_dq / descriptors_dq are filled inside addStereoImagePair"""
+        self.lib.spvo_host_set_deferred_copies(self.h, int(on))
 
     def context(self):
         """The spvo_ctx of this front end wrapped for the profiling calls of spvo.capi."""

@@ -42,6 +42,20 @@ def pytest_sessionstart(session):
             subprocess.run(["make", "-C", pkg, "all"], check=False)
 
 
+@pytest.fixture
+def tuning():
+    """Diagnostic switches of the library for one test: tuning(name=value, ...) sets them (spvo_set_tuning), everything is forgotten
+    again when the test ends.  The library reads no environment variable for these."""
+    from spvo import capi
+
+    def set_(**kw):
+        capi.clear_tuning()
+        for k, v in kw.items():
+            capi.set_tuning(k, v)
+    yield set_
+    capi.clear_tuning()
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -128,17 +128,23 @@ def test_prefetch_pipeline_is_transparent(models_dir, sequence):
                 assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1])      # poses: bit-identical
 
 
-def test_the_reference_entry_point_with_host_images_equals_the_device_entry(models_dir, sequence):
+@pytest.mark.parametrize("arrangement", ["default", "eager_copies", "heads_on_tail", "heads_on_net"])
+def test_the_reference_entry_point_with_host_images_equals_the_device_entry(models_dir, sequence, arrangement, tuning):
     """addStereoImagePair(cv::Mat&, ...) -- the reference's own interface (node.cpp:175): host images in, resized images and
     descriptors back in images_dq / descriptors_dq -- without look-ahead, with one and with two pairs announced through
     prefetchStereoImagePair, and the device-resident entry: the same keypoints, descriptors, index maps, inliers and poses,
-    bit for bit."""
+    bit for bit.  Arrangements: the bulk copies into the deques deferred behind the solve (default) or made inside
+    addStereoImagePair (setDeferredHostCopies(false)); the heads on the tail / on the network stream (diagnostic switch)."""
     import torch
     frames, poses, P_l, P_r = sequence
     rows, cols = frames[0][0].shape
     out = {}
+    if arrangement.startswith("heads_on"):
+        tuning(heads_on_net=1 if arrangement == "heads_on_net" else 0)
     for mode in ("device", 0, 1, 2):
         fe = host.FrontEnd(models_dir, prefix="sp_squeeze")
+        if arrangement == "eager_copies":
+            fe.set_deferred_copies(False)
         res = []
         if mode == "device":
             dev = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
@@ -172,21 +178,6 @@ def test_the_reference_entry_point_with_host_images_equals_the_device_entry(mode
             if a[0] is not None:
                 assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1])      # poses: bit-identical
             assert np.array_equal(b[6], ofe.preprocess(frames[k][0], P_l, 360, 1176)[0])           # images_dq holds the resized u8 image (nn.cpp:154)
-
-
-@pytest.mark.parametrize("env", [{"SPVO_DIRECT_HOST_WRITES": "0"}, {"SPVO_DIRECT_HOST_WRITES": "0", "SPVO_EARLY_RESIZED": "0", "SPVO_TAIL_SPLIT": "1"},
-                                 {"SPVO_UPLOAD_STREAM": "1"}, {"SPVO_HEADS_ON_NET": "0"}])
-def test_the_other_arrangements_of_a_host_image_submission_give_the_same_results(env):
-    """The library reads its arrangement switches once per process: bulk results as device-to-host copies instead of direct writes
-    into pinned memory (with the resized images under the network / behind the matches), uploads on a stream of their own, heads
-    on the tail stream.  Each arrangement runs the bit-for-bit comparison above in a process of its own."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_host.py"), "-x", "-q", "-k",
-                        "the_reference_entry_point_with_host_images_equals_the_device_entry or prefetch_pipeline_is_transparent"],
-                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=900, cwd=root)
-    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_fp16_engine_through_the_host_class(tmp_path, squeeze_weights_path, sequence):

@@ -119,10 +119,10 @@ DEFAULT_KERNELS = {
 
 
 @pytest.mark.parametrize("H,W,batch", [(360, 1176, 2), (376, 1240, 2), (192, 640, 1), (240, 784, 2)])
-def test_winograd_layers_stay_at_fp32_rounding_level(vgg_weights_path, vgg_plan, sample_images, H, W, batch, monkeypatch):
+def test_winograd_layers_stay_at_fp32_rounding_level(vgg_weights_path, vgg_plan, sample_images, H, W, batch, tuning):
     """The default FP32 engine runs its 3x3 layers through the Winograd kernels: F(4x4,3x3) (csrc/conv_wino4.hip.h) where the
-    layer has enough 16 x 32 tiles, F(2x2,3x3) (csrc/conv_wino2.hip.h) for the rest; SPVO_WINO4=0 keeps F(2x2) everywhere and
-    SPVO_WINOGRAD=0 the direct kernel (both read when an engine is loaded).  All three meet the 1e-4 bar against the oracle on
+    layer has enough 16 x 32 tiles, F(2x2,3x3) (csrc/conv_wino2.hip.h) for the rest; the diagnostic switch "wino4" = 0 keeps F(2x2)
+    everywhere and "winograd" = 0 the direct kernel (spvo_set_tuning; read when an engine is loaded).  All three meet the 1e-4 bar against the oracle on
     every tensor, and against a float64 evaluation of the graph both Winograd engines stay within a small factor of the direct
     one: fp32 throughout; F(2x2)'s transforms only use the coefficients 0, +-1 and +-1/2, F(4x4)'s go up to 8 (points
     0, +-1, +-2, inf) and cost a factor of ~1-3 on this network's tensors."""
@@ -132,8 +132,7 @@ def test_winograd_layers_stay_at_fp32_rounding_level(vgg_weights_path, vgg_plan,
     ref64 = _vgg_forward_f64(vgg_plan, x)
     errs, kernels = {}, {}
     for mode in ("direct", "f2x2", "f4x4"):
-        monkeypatch.setenv("SPVO_WINOGRAD", "0" if mode == "direct" else "1")
-        monkeypatch.setenv("SPVO_WINO4", "1" if mode == "f4x4" else "0")
+        tuning(winograd=0 if mode == "direct" else 1, wino4=1 if mode == "f4x4" else 0)
         ctx = capi.Context(net_height=H, net_width=W)
         ctx.load_weights(vgg_weights_path)
         det, desc = ctx.forward(x)
@@ -191,16 +190,14 @@ def _awkward_plan(seed):
 
 @pytest.mark.parametrize("H,W", [(96, 168), (104, 200), (120, 392)])
 @pytest.mark.parametrize("mode", ["f4x4", "f2x2"])
-def test_winograd_kernels_on_awkward_layer_shapes(H, W, mode, sample_images, monkeypatch, tmp_path):
+def test_winograd_kernels_on_awkward_layer_shapes(H, W, mode, sample_images, tuning, tmp_path):
     """Both Winograd kernels, forced onto every 3x3 layer of a graph with partial output tiles, short item chains and odd-sized
     maps (104 x 200 -> 52 x 100 -> 26 x 50 -> 13 x 25), against the oracle on every tensor."""
     from spvo import capi, weights as Wm
     plan = _awkward_plan(3)
     path = str(tmp_path / "awkward.spvw")
     Wm.save(plan, path)
-    monkeypatch.setenv("SPVO_WINOGRAD_MIN_TILES", "1")
-    monkeypatch.setenv("SPVO_WINO4_MIN_TILES", "1")
-    monkeypatch.setenv("SPVO_WINO4", "1" if mode == "f4x4" else "0")
+    tuning(winograd_min_tiles=1, wino4_min_tiles=1, wino4=1 if mode == "f4x4" else 0)
     x = _input(sample_images, H, W, 2)
     rdet, rdesc, vals = net.forward(plan, x, return_all=True)
     ctx = capi.Context(net_height=H, net_width=W)
@@ -222,8 +219,8 @@ def test_winograd_kernels_on_awkward_layer_shapes(H, W, mode, sample_images, mon
 # per tensor, relative to max(1, max |tensor|).  The yardstick is the fp32 ORACLE's own distance to float64 on the same tensor
 # (torch-CPU fp32: what "an fp32 evaluation in some summation order" costs on this graph -- 1.5e-7 .. 7e-6 depending on the
 # graph: BatchNorm scales of sp_mbv1 amplify it).  Two engines side by side:
-#   * DIRECT kernels only (1x1 / depthwise / BatchNorm / residual layers, every 3x3 layer and the heads with SPVO_WINOGRAD=0 /
-#     SPVO_HEADS_FUSED=0): every tensor within 4 x the oracle's own error + 4e-7;
+#   * DIRECT kernels only (1x1 / depthwise / BatchNorm / residual layers, every 3x3 layer and the heads with the diagnostic
+#     switches "winograd" = 0, "heads_fused" = 0): every tensor within 4 x the oracle's own error + 4e-7;
 #   * the default engine (Winograd 3x3 layers, fused heads): within 4 x the direct engine's error + 2e-7 per tensor, or within
 #     WINOGRAD_F64_LEVEL where the direct kernel happens to be much more accurate than fp32 needs to be.  F(4x4,3x3) on the
 #     TRAINED sp_squeeze weights reaches 6.5e-6 of the tensor maximum (tensor 2 = its conv1b: 6.0e-6 against 4e-7 direct, a ratio
@@ -235,7 +232,7 @@ WINOGRAD_F64_LEVEL = 8e-6
 
 @pytest.mark.parametrize("graph,H,W,batch", [("vgg", 360, 1176, 2), ("vgg", 240, 784, 2), ("sp_squeeze", 360, 1176, 2), ("sp_squeeze", 240, 784, 2),
                                              ("sp_mbv1", 360, 1176, 2), ("sp_mbv2", 360, 1176, 2), ("sp_mbv1", 120, 392, 2), ("sp_mbv2", 120, 392, 2)])
-def test_fp32_engines_stay_at_fp32_rounding_level_against_float64(graph, H, W, batch, vgg_weights_path, vgg_plan, sample_images, monkeypatch):
+def test_fp32_engines_stay_at_fp32_rounding_level_against_float64(graph, H, W, batch, vgg_weights_path, vgg_plan, sample_images, tuning):
     import os
     from spvo import weights
     from tests.conftest import GOLDEN
@@ -255,11 +252,10 @@ def test_fp32_engines_stay_at_fp32_rounding_level_against_float64(graph, H, W, b
     errs, fams = {"oracle": dist(lambda tid: ref32[tid])}, {}
     errs["oracle"]["desc"] = float(np.abs(ref32[plan.desc_tensor] - ref64[plan.desc_tensor]).max())
     for mode in ("direct", "default"):
-        for k in ("SPVO_WINOGRAD", "SPVO_HEADS_FUSED"):
-            if mode == "direct":
-                monkeypatch.setenv(k, "0")
-            else:
-                monkeypatch.delenv(k, raising=False)
+        if mode == "direct":
+            tuning(winograd=0, heads_fused=0)
+        else:
+            tuning()
         ctx = make_ctx(path, net_height=H, net_width=W)
         det, desc = ctx.forward(x)
         e = dist(lambda tid: ctx.debug_tensor(tid, batch, *plan.tensors[tid]))
@@ -444,25 +440,4 @@ def test_errors(vgg_weights_path, tmp_path):
     with pytest.raises(capi.SpvoError) as e:
         ctx.load_weights(str(bad))
     assert e.value.code == -3
-    ctx.close()
-
-
-@pytest.mark.parametrize("H,W,batch", [(360, 1176, 2), (192, 640, 1)])
-def test_register_resident_winograd_form_matches_oracle(vgg_weights_path, vgg_plan, sample_images, H, W, batch, monkeypatch):
-    """SPVO_WINO64=1 (read when an engine is loaded): the layers with 64 input channels run conv_wino64_kernel -- transformed
-    filters resident in registers, cross-wave inverse transform through LDS.  Opt-in (it measured no faster than the default
-    form), held to the same bar: every tensor within 1e-4 of the oracle."""
-    from spvo import capi
-    monkeypatch.setenv("SPVO_WINO64", "1")
-    x = _input(sample_images, H, W, batch)
-    rdet, rdesc, vals = net.forward(vgg_plan, x, return_all=True)
-    ctx = capi.Context(net_height=H, net_width=W)
-    ctx.load_weights(vgg_weights_path)
-    det, desc = ctx.forward(x)
-    for tid, (ch, lvl) in enumerate(vgg_plan.tensors):
-        if tid in (vgg_plan.input_tensor, vgg_plan.desc_tensor):
-            continue
-        got = ctx.debug_tensor(tid, batch, ch, lvl)
-        assert np.abs(got - vals[tid]).max() <= _tol(vals[tid]), f"tensor {tid}"
-    assert np.abs(det - rdet).max() <= _tol(rdet) and np.abs(desc - rdesc.transpose(0, 2, 3, 1)).max() <= 1e-4
     ctx.close()

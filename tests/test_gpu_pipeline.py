@@ -125,26 +125,24 @@ def test_detect_in_fp32_split_mode_matches_oracle(vgg_weights_path, vgg_plan, st
     ctx.close()
 
 
-@pytest.mark.parametrize("env", [{"SPVO_WINOGRAD": "0"}, {"SPVO_WINO2": "0"}, {"SPVO_HEADS_ON_TAIL": "0"}, {"SPVO_MERGE_SIBLINGS": "0"},
-                                 {"SPVO_WINO_NARROW": "0"}, {"SPVO_WINO_DYNAMIC": "0"},
-                                 {"SPVO_WINOGRAD": "0", "SPVO_HEADS_ON_TAIL": "0", "SPVO_MERGE_SIBLINGS": "0"}])
-def test_kernel_selection_switches_do_not_change_the_detector(vgg_weights_path, stereo_pair, env, monkeypatch):
-    """The engine-load switches (direct instead of Winograd 3x3 kernels, heads on the network stream, head
-    siblings launched separately) select other kernels / streams for the same arithmetic: keypoints are identical up to
-    threshold outcomes of heat-map values that differ in the last bits, descriptors agree to 1e-5."""
+@pytest.mark.parametrize("switches", [{"winograd": 0}, {"wino4": 0}, {"heads_split": 0}, {"heads_fused": 0}, {"merge_siblings": 0}, {"wino_narrow": 0}, {"wino_dynamic": 0},
+                                      {"winograd": 0, "heads_split": 0, "merge_siblings": 0}])
+def test_kernel_selection_switches_do_not_change_the_detector(vgg_weights_path, stereo_pair, switches, tuning):
+    """The diagnostic switches (spvo_set_tuning, INTEGRATION.md: direct instead of Winograd 3x3 kernels, F(2x2) only, heads as ordinary
+    trunk layers / unfused, head siblings launched separately, static tile assignment) select other kernels / streams for the same
+    arithmetic: keypoints are identical up to threshold outcomes of heat-map values that differ in the last bits, descriptors agree
+    to 1e-5.  The library reads NO environment variable for any of this: an unknown name is refused."""
     from spvo import capi
+    with pytest.raises(capi.SpvoError):
+        capi.set_tuning("no_such_switch", 1)
     frames, _, P_l, P_r = stereo_pair
     L, R = frames[1]
     outs = []
-    for e in ({}, env):
-        for k in ("SPVO_WINOGRAD", "SPVO_WINO2", "SPVO_HEADS_ON_TAIL", "SPVO_MERGE_SIBLINGS", "SPVO_WINO_NARROW", "SPVO_WINO_DYNAMIC"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in e.items():
-            monkeypatch.setenv(k, v)
+    for e in ({}, switches):
+        tuning(**e)
         ctx = capi.Context()
         ctx.load_weights(vgg_weights_path)
         outs.append(ctx.detect(L, R, P_l, P_r, 2, 3))
-        # two submissions in flight exercise the ring buffers of the head inputs
         ctx.close()
     a, b = outs
     for side in ("l", "r"):
@@ -345,6 +343,17 @@ def test_host_image_submissions_are_bit_identical_to_the_synchronous_entry(ctx_s
     for (gi, gd), (ri, rd) in zip(got_m, ref_m):
         assert np.array_equal(gi, ri) and np.array_equal(gd, rd)
     ctx_squeeze.set_prematch(False, "KNN", False, 0.8)
+    # the same results as VIEWS of the submissions' pinned mirrors (spvo_detect_collect_mirrors: what the host class copies once into
+    # images_dq / descriptors_dq); the first pair's views stay intact while the second pair is collected
+    ctx_squeeze.detect_submit(frames[0][0].copy(), frames[0][1].copy(), 4, 5)       # (slot 6 is this submission's temporal partner: not reusable yet)
+    ctx_squeeze.detect_submit(frames[1][0].copy(), frames[1][1].copy(), 8, 9)
+    views = [ctx_squeeze.detect_collect_mirrors(P_l, P_r), ctx_squeeze.detect_collect_mirrors(P_l, P_r)]
+    for g, r in zip(views, ref):
+        for k in ("xy_l", "xy_r", "desc_l", "desc_r", "resized_l", "resized_r", "P_l", "P_r"):
+            assert np.array_equal(g[k], r[k]), k
+    ctx_squeeze.detect_submit(frames[0][0], frames[0][1], 0, 1, extras=1)          # descriptors not requested: no view of them
+    v = ctx_squeeze.detect_collect_mirrors(P_l, P_r)
+    assert v["desc_l"] is None and np.array_equal(v["resized_r"], ref[0]["resized_r"]) and np.array_equal(v["xy_l"], ref[0]["xy_l"])
     # extras not requested at submit time cannot be fetched while a younger submission is in flight -- and the refusal
     # leaves the queue intact (the oldest submission is still collectable)
     from spvo import capi

@@ -1,4 +1,5 @@
 // conv_wino64.hip.h -- K2u: the Winograd F(2x2, 3x3) convolution of conv_wino.hip.h for layers with 64 INPUT channels per
+// (round 4: moved out of the library into tools/ -- measured no faster than the 8-wave form; kept for tools/wino_bench.hip -DWINO64)
 // output-channel tile (VGG SuperPoint: conv1b, conv2a, conv2b 64 -> 64, conv3a 64 -> 128 = 540 of the 880 us of the conv
 // stack), with the transformed filters RESIDENT IN REGISTERS.
 //
@@ -28,7 +29,8 @@
 #include <stdint.h>
 #include <type_traits>
 #include <vector>
-#include "conv_mfma.hip.h"
+#include "../superpoint-stereo-visual-odometry_amd/csrc/conv_mfma.hip.h"
+#include "../superpoint-stereo-visual-odometry_amd/csrc/conv_wino2.hip.h"   // WinoTile
 
 namespace spvo {
 

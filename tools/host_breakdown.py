@@ -13,8 +13,7 @@ import torch  # noqa: E402
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "FP32"
 H, W = (int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "360x1176").split("x"))
-if len(sys.argv) > 3 and sys.argv[3] == "split":
-    os.environ["SPVO_FP32_SPLIT"] = "1"
+split = len(sys.argv) > 3 and sys.argv[3] == "split"
 os.environ.setdefault("SPVO_QUIET", "1")
 torch.cuda.init()
 from spvo import host, synth, weights  # noqa: E402
@@ -62,6 +61,6 @@ for i in range(N + 20):
     t4 = time.perf_counter()
     if i >= 20:
         acc += [t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0]
-print(f"{prec} {H}x{W} {'split' if os.environ.get('SPVO_FP32_SPLIT') else ''}: per step [ms] add/wait {acc[0]/N*1e3:.3f}  hand-over {acc[1]/N*1e3:.3f}  "
+print(f"{prec} {H}x{W} {'split' if split else ''}: per step [ms] add/wait {acc[0]/N*1e3:.3f}  hand-over {acc[1]/N*1e3:.3f}  "
       f"matches {acc[2]/N*1e3:.3f}  solve {acc[3]/N*1e3:.3f}  total {acc[4]/N*1e3:.3f}")
 fe.close()

@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "superpoint-stereo-visual-odometry_amd"))
 import numpy as np
 from spvo import capi, weights
+capi.tuning_from_env()   # SPVO_TUNE_WINOGRAD=0 etc.: this measurement script opts in (the library itself reads no environment variable)
 
 out_path = sys.argv[1]
 H, Wd = (int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "360x1176").split("x"))
@@ -27,7 +28,6 @@ for _ in range(200): ctx.forward(x)
 prof = ctx.profile()
 PEAK, HBM = (157.3 if prec == "FP32" else 2500.0), 8000.0
 names = ["conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "convPa", "convDa", "convPb", "convDb", "l2norm"]
-wino_env = os.environ.get("SPVO_WINOGRAD", "1") != "0"
 rows, tot_us, tot_exec, tot_alg = [], 0.0, 0.0, 0.0
 i = 0
 while i < len(plan.ops):

@@ -29,7 +29,7 @@ for k in sorted(set(fetch) | set(write)):
     per[k] = {"dispatches": len(fetch.get(k, write.get(k))),
               "FETCH_SIZE_KB_mean": round(sum(fetch[k]) / len(fetch[k]), 1) if k in fetch else None,
               "WRITE_SIZE_KB_mean": round(sum(write[k]) / len(write[k]), 1) if k in write else None}
-# conv1b = the pooled 3x3 kernel instance (Winograd by default, the direct MFMA kernel with SPVO_WINOGRAD=0) with the
+# conv1b = the pooled 3x3 kernel instance (Winograd by default, the direct MFMA kernel with the diagnostic switch "winograd" = 0) with the
 # largest fetch volume
 cands = [k for k in per if ("conv_wino_kernel<true, true" in k or ("conv_mfma_kernel<3" in k and "true, true" in k)) and per[k]["FETCH_SIZE_KB_mean"]]
 dom = max(cands, key=lambda k: per[k]["FETCH_SIZE_KB_mean"])

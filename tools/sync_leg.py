@@ -27,6 +27,8 @@ order = list(range(8)) + list(range(6, 0, -1))
 fe = host.FrontEnd(tmp, prefix="superpoint_pretrained", selector="KNN", cross_check=True, batch=2, height=H, width=W, conf_thresh=0.015, dist_thresh=4,
                    border_remove=4, stereo_threshold=2.0, min_disparity=0.25, refinement_degree=4, precision="FP32")
 assert fe.engine_loaded, fe.last_error
+if len(sys.argv) > 4:   # 0 = copies inside addStereoImagePair, 1 = deferred behind the solve (default)
+    fe.set_deferred_copies(int(sys.argv[4]))
 mats = [(fe.make_image(L), fe.make_image(R)) for L, R in frames]
 Pl, Pr = np.ascontiguousarray(P_l, np.float64), np.ascontiguousarray(P_r, np.float64)
 import ctypes as C  # noqa: E402

@@ -9,9 +9,8 @@
 #include <random>
 #include <vector>
 #include <algorithm>
-#include "../superpoint-stereo-visual-odometry_amd/csrc/conv_wino.hip.h"
 #include "../superpoint-stereo-visual-odometry_amd/csrc/conv_wino2.hip.h"
-#include "../superpoint-stereo-visual-odometry_amd/csrc/conv_wino64.hip.h"
+#include "conv_wino64.hip.h"
 #include "../superpoint-stereo-visual-odometry_amd/csrc/conv_wino4.hip.h"
 #if defined(WINO4)   // F(4x4, 3x3): -DWINO4
 #define KERNEL(P, R, T, O) conv_wino4_kernel<P, R, T>
@@ -33,11 +32,12 @@
 #define PACK pack_conv_weights_wino2
 #define THREADS 512
 #define COT 64
-#else
-#define KERNEL(P, R, T, O) conv_wino_kernel<P, R, T, O>
-#define PACK pack_conv_weights_wino
-#define THREADS 256
+#else   // (the round-1 four-wave form is gone: the default is the 8-wave F(2x2) kernel)
+#define KERNEL(P, R, T, O) conv_wino2_kernel<P, R, T, O>
+#define PACK pack_conv_weights_wino2
+#define THREADS 512
 #define COT 64
+#define WINO2 1
 #endif
 using namespace spvo;
 #if defined(WINO4)   // multiplies the matrix pipe executes per multiply of the direct convolution
