@@ -535,8 +535,10 @@ def main():
             # pipe EXECUTES per launch; the layer's ALGORITHMIC rate (direct 3x3 convolution) is reported
             # beside it under its own name and never enters `frac` (it exceeds the peak: that is the point of Winograd).
             kfam, kfactor = ctx.stage_kernel("conv:1")
-            pmc_file = {"conv_wino4_kernel": "r03_pmc.json", "conv_wino2_kernel": "r03_pmc.json", "conv_wino_kernel": "r01j_pmc_conv_traffic.json", "conv_mfma_kernel": "r01_pmc_conv_traffic.json"}.get(kfam)
+            pmc_file = {"conv_wino4_kernel": "r04_pmc.json", "conv_wino2_kernel": "r03_pmc.json", "conv_mfma_kernel": "r01_pmc_conv_traffic.json"}.get(kfam)
             pmc = os.path.join(ROOT, "profiles", pmc_file) if pmc_file else None
+            if pmc and not os.path.exists(pmc) and pmc_file == "r04_pmc.json":
+                pmc = os.path.join(ROOT, "profiles", "r03_pmc.json")
             if pmc and os.path.exists(pmc) and (NET_H, NET_W) == (360, 1176):
                 pj = json.load(open(pmc))
                 traffic = (pj.get(kfam) or ({} if kfam in ("conv_wino4_kernel", "conv_wino2_kernel") else pj)).get("traffic_bytes_per_launch")
@@ -571,6 +573,18 @@ def main():
                 out["net_ops_ms"] = {k: round(v["total_ms"] / max(v["calls"], 1), 4) for k, v in prof_all.items()
                                      if k.startswith(("conv:", "pool:", "l2norm:", "dwconv:"))}
             out["conv_stack_tflops"] = round(conv_fl / (conv_ms * 1e-3) / 1e12, 2)
+            # north_star: "rocprof reports achieved HBM GB/s on the conv stack".  Bytes per forward pass from the committed counter passes
+            # (FETCH_SIZE x 2 + WRITE_SIZE per layer, tools/pmc_layers.py) over the stack's time measured HERE (sum of the layers' HIP-event
+            # times in the pass above); the algorithmic bytes beside it.
+            pl_path = os.path.join(ROOT, "profiles", "r04_pmc_layers.json")
+            if "roofline" in out and headline and (NET_H, NET_W) == (360, 1176) and os.path.exists(pl_path):
+                cs = json.load(open(pl_path)).get("conv_stack", {})
+                if cs.get("traffic_MB"):
+                    out["roofline"]["conv_stack_traffic"] = int(cs["traffic_MB"] * 1e6)
+                    out["roofline"]["conv_stack_algorithmic_bytes"] = int(cs["algorithmic_MB"] * 1e6)
+                    out["roofline"]["conv_stack_hbm_gbps"] = round(cs["traffic_MB"] * 1e6 / (conv_ms * 1e-3) / 1e9, 1)
+                    out["roofline"]["conv_stack_frac_of_hbm_peak"] = round(cs["traffic_MB"] * 1e6 / (conv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+                    out["roofline"]["conv_stack_traffic_source"] = "profiles/r04_pmc_layers.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over a forward-only loop, per layer; counters include Infinity-Cache hits) / conv_stack_sum of this run"
         if world == 1 and headline and not args.no_extras and "split" in legs:
             try:
                 # Informational, never `value`: the same workload with the FP32 engine in its opt-in split mode (every fp32 operand as

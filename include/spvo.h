@@ -357,6 +357,11 @@ typedef struct spvo_comm spvo_comm;
 /* Rank 0 creates the id (ncclGetUniqueId) and hands it to the other ranks out of band (ROS parameter server, a file,
  * MPI, torchrun's store); every rank then calls spvo_comm_create -- collectively, like ncclCommInitRank. */
 int spvo_comm_unique_id(unsigned char id[SPVO_COMM_ID_BYTES]);
+/* SPVO_OK when librccl can be opened and has the entry points this library uses (dlopen + dlsym: no bootstrap state is created,
+ * unlike spvo_comm_unique_id): what every rank checks BEFORE the ranks enter spvo_comm_create together.  A failure INSIDE
+ * ncclCommInitRank (a peer that died after this check) is not recoverable collectively: the launcher's job (bench.py: spawn_ranks /
+ * torch.distributed.run stop the job when a rank dies). */
+int spvo_comm_available(void);
 int spvo_comm_create(int device, int rank, int world, const unsigned char id[SPVO_COMM_ID_BYTES], spvo_comm **out);
 /* TEST transport, no GPU: ranks exchange through files in `dir` (world-size-2 CPU tests of the N > 1 code path). */
 int spvo_comm_create_host(const char *dir, int rank, int world, spvo_comm **out);

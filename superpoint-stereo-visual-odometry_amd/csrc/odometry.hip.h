@@ -139,17 +139,26 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const double *__restri
   const double d2 = B[2][2] + mu - l20 * l20 * d0 - l21 * l21 * d1, i2 = 1.0 / d2;
   const double l32 = (B[2][3] - l30 * l20 * d0 - l31 * l21 * d1) * i2;
   const double d3 = B[3][3] + mu - l30 * l30 * d0 - l31 * l31 * d1 - l32 * l32 * d2, i3 = 1.0 / d3;
-  double h0 = 0, h1 = 0, h2 = 0, h3 = 1;
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
+  double h0 = 0, h1 = 0, h2 = 0, h3 = 1, delta = 0;
+  auto inverse_step = [&]() {
     // L y = h
     const double y0 = h0, y1 = h1 - l10 * y0, y2 = h2 - l20 * y0 - l21 * y1, y3 = h3 - l30 * y0 - l31 * y1 - l32 * y2;
     // D z = y, L^T x = z
     const double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3, x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
     const double m = fmax(fmax(fabs(x0), fabs(x1)), fmax(fabs(x2), fabs(x3)));
     const double sc = (m > 0 && isfinite(m)) ? 1.0 / m : 1.0;
-    h0 = x0 * sc; h1 = x1 * sc; h2 = x2 * sc; h3 = x3 * sc;
-  }
+    const double n0 = x0 * sc, n1 = x1 * sc, n2 = x2 * sc, n3 = x3 * sc;
+    // change of the direction (the iterates are scaled to maximum norm 1; B^-1 is positive definite, so they do not change sign)
+    delta = fmax(fmax(fabs(n0 - h0), fabs(n1 - h1)), fmax(fabs(n2 - h2), fabs(n3 - h3)));
+    h0 = n0; h1 = n1; h2 = n2; h3 = n3;
+  };
+#pragma unroll
+  for (int it = 0; it < 4; ++it) inverse_step();
+  // Four steps settle every correspondence the pipeline lets through (y threshold, minimum disparity: base.cpp:127-207).  A caller of
+  // spvo_triangulate with unfiltered matches can hand in a point at (almost) infinity -- its null vector has w ~ 0, nearly orthogonal
+  // to the start vector -- or a pair with a large vertical offset (sigma_4 / sigma_3 not small): keep iterating until the direction
+  // stands still (the serial Jacobi SVD this replaced needed no such care; the result is the same vector)
+  for (int it = 4; it < 200 && delta > 1e-13; ++it) inverse_step();
   const float f0 = (float)h0, f1 = (float)h1, f2 = (float)h2, f3 = (float)h3;
   const float scale = (f3 != 0.f) ? __fdiv_rn(1.0f, f3) : 1.0f;
   xyz[3 * i + 0] = mul_rn(f0, scale);

@@ -163,12 +163,22 @@ int spvo_comm_create(int device, int rank, int world, const unsigned char id[SPV
   return SPVO_OK;
 }
 
+static std::string host_file(const spvo_comm *c, long seq, int rank);
+
+int spvo_comm_available(void) {
+  return rccl() ? SPVO_OK : comm_fail(SPVO_ERR_DEVICE, "librccl.so.1 cannot be opened (SPVO_RCCL_LIB, $ROCM_PATH/lib, /opt/rocm/lib, the loader path)");
+}
+
 int spvo_comm_create_host(const char *dir, int rank, int world, spvo_comm **out) {
   if (!out || !dir || !*dir || world < 1 || rank < 0 || rank >= world) return comm_fail(SPVO_ERR_INVALID, "bad rank / world / directory");
   struct stat st;
   if (stat(dir, &st) != 0 || !S_ISDIR(st.st_mode)) return comm_fail(SPVO_ERR_IO, "no such directory: %s", dir);
   spvo_comm *c = new spvo_comm;
   c->rank = rank; c->world = world; c->host = true; c->dir = dir;
+  // a directory that served an earlier communicator: this rank's done_ marker and pose files of that one must not be taken for this
+  // one's (the destroy handshake would skip its wait and a peer could read a stale gather)
+  std::remove((c->dir + "/done_" + std::to_string(rank)).c_str());
+  for (long s = 0; s < 4; ++s) std::remove(host_file(c, s, rank).c_str());
   *out = c;
   return SPVO_OK;
 }

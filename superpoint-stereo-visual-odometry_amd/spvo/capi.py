@@ -66,7 +66,7 @@ SYMBOLS = [
     "spvo_match_hamming", "spvo_orb_detect", "spvo_orb_tables", "spvo_triangulate", "spvo_pnp_ransac", "spvo_pnp_refine", "spvo_solve_stereo_odometry", "spvo_solve_submit", "spvo_solve_wait", "spvo_stream", "spvo_synchronize",
     "spvo_profile_enable", "spvo_profile_reset", "spvo_profile_only", "spvo_profile_count", "spvo_profile_get", "spvo_profile_stage_kernel",
     "spvo_set_tuning", "spvo_get_tuning", "spvo_clear_tuning",
-    "spvo_comm_unique_id", "spvo_comm_create", "spvo_comm_create_host", "spvo_comm_rank", "spvo_comm_world", "spvo_comm_destroy",
+    "spvo_comm_unique_id", "spvo_comm_available", "spvo_comm_create", "spvo_comm_create_host", "spvo_comm_rank", "spvo_comm_world", "spvo_comm_destroy",
     "spvo_pose_allgather", "spvo_pose_allgather_n",
 ]
 
@@ -524,6 +524,11 @@ def tuning_from_env(prefix: str = "SPVO_TUNE_"):
 
 
 COMM_ID_BYTES = 128
+
+
+def comm_available() -> bool:
+    """spvo_comm_available: librccl opens and has the entry points the library uses (no bootstrap state is created)"""
+    return load().spvo_comm_available() == 0
 
 
 def comm_unique_id() -> bytes:

@@ -77,15 +77,17 @@ class PoseGather:
         """(communicator, "") on every rank, or (None, reason) on every rank.  Protocol: (1) each rank checks locally that it can
         take part (GPU ranks: librccl loads and hands out an id -- rank 0's is the one that is used; host ranks: nothing to check)
         and the ranks agree on that; (2) rank 0 broadcasts its id / directory -- always, None included; (3) each rank creates its
-        communicator and the ranks agree on the outcome, closing what was created when a peer failed."""
+        communicator and the ranks agree on the outcome, closing what was created when a peer failed.  (A rank that fails INSIDE
+        ncclCommInitRank leaves its peers in that call: not recoverable from here -- the launcher stops the job when a rank dies.)"""
         from . import capi
         box, err = [None], ""
         cuda = self.device.type == "cuda"
         try:
             if cuda:
-                uid = capi.comm_unique_id()          # proves on THIS rank that RCCL can be opened, before any rank enters ncclCommInitRank
+                if not capi.comm_available():        # dlopen + dlsym on THIS rank, before any rank enters ncclCommInitRank (no bootstrap state)
+                    raise RuntimeError(capi.load().spvo_last_error(None).decode())
                 if self.rank == 0:
-                    box[0] = uid
+                    box[0] = capi.comm_unique_id()   # only the rank whose id is used asks RCCL for one
             elif self.rank == 0:
                 box[0] = tempfile.mkdtemp(prefix="spvo_comm_")
         except Exception as exc:               # noqa: BLE001

@@ -185,3 +185,34 @@ def test_launcher_deadline_terminates_a_hung_job(tmp_path, capfd):
     assert "did not finish within 3 s" in capfd.readouterr().err
     for r in (0, 1):
         assert not _pid_alive(int((tmp_path / f"pid{r}").read_text()))
+
+
+def test_host_transport_directory_can_serve_a_second_communicator(tmp_path):
+    """spvo_comm_create_host in a directory an earlier communicator has used: the done_<rank> markers of the first one must not
+    satisfy the destroy handshake of the second (a rank would remove files a peer is still reading).  Two ranks as threads
+    (ctypes releases the GIL), two communicators one after the other in the same directory, three gathers each."""
+    import threading
+    from spvo import capi
+    assert isinstance(capi.comm_available(), bool)          # dlopen probe: no GPU and no bootstrap state needed
+    errors = []
+
+    def rank_main(rank, generation):
+        try:
+            comm = capi.Comm.host(str(tmp_path), rank, 2)
+            for k in range(3):
+                mine = np.array([[0.0, 0.0, 0.0, 1.0, generation, rank, k]])
+                got = comm.allgather(mine)
+                assert got.shape == (2, 1, 7) or got.shape == (2, 7), got.shape
+                got = got.reshape(2, 7)
+                assert np.array_equal(got[:, 4], [generation, generation]) and np.array_equal(got[:, 5], [0, 1]) and np.array_equal(got[:, 6], [k, k])
+            comm.close()
+        except Exception as exc:      # noqa: BLE001
+            errors.append((rank, generation, repr(exc)))
+
+    for generation in (1, 2):
+        ts = [threading.Thread(target=rank_main, args=(r, generation)) for r in (0, 1)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=60)
+        assert not errors and not any(t.is_alive() for t in ts), errors

@@ -25,6 +25,29 @@ def test_triangulate(ctx_vgg, golden_dir):
     assert np.allclose(ctx_vgg.triangulate(P_l, P_r, o["cl"], o["cr"]), ref, rtol=1e-5)
 
 
+def test_triangulate_unfiltered_correspondences(ctx_vgg, golden_dir):
+    """spvo_triangulate on what the pipeline's own filters (y threshold, minimum disparity: base.cpp:127-207) would have dropped:
+    almost-zero disparity (the null vector's w is ~0, nearly orthogonal to the inverse iteration's start vector) and large vertical
+    offsets (sigma_4 / sigma_3 not small).  The kernel iterates until the direction stands still; the result is the SVD's null
+    vector (oracle: numpy.linalg.svd), compared as a direction -- the dehomogenised point of such a pair is ill-conditioned itself."""
+    o = np.load(os.path.join(golden_dir, "oracle_odometry.npz"))
+    P_l, P_r = o["P_l"], o["P_r"]
+    rng = np.random.RandomState(3)
+    n = 400
+    cl = np.stack([rng.uniform(50, 1100, n), rng.uniform(20, 340, n)], 1).astype(np.float32)
+    disp = np.concatenate([np.full(100, 1e-3), np.full(100, 0.02), rng.uniform(0.25, 60, 200)]).astype(np.float32)
+    dy = np.concatenate([np.zeros(200), rng.uniform(-40, 40, 200)]).astype(np.float32)
+    cr = np.stack([cl[:, 0] - disp, cl[:, 1] + dy], 1).astype(np.float32)
+    got = ctx_vgg.triangulate(P_l, P_r, cl, cr).astype(np.float64)
+    assert np.isfinite(got).all()
+    for i in range(n):
+        A = np.stack([cl[i, 0] * P_l[2] - P_l[0], cl[i, 1] * P_l[2] - P_l[1], cr[i, 0] * P_r[2] - P_r[0], cr[i, 1] * P_r[2] - P_r[1]]).astype(np.float64)
+        v = np.linalg.svd(A)[2][-1]
+        g = np.append(got[i], 1.0)
+        cosang = abs(g @ v) / (np.linalg.norm(g) * np.linalg.norm(v))
+        assert 1.0 - cosang <= 1e-9, (i, disp[i], dy[i], 1.0 - cosang)     # the same direction (f32 rounding of the stored point)
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_ransac_matches_oracle(ctx_vgg, seed):
     P_l, P_r, Xc, cl, cr, pl, pr, rv, tv, bad = _scene(seed=seed, n=400, noise=0.3, outliers=0.3)
