@@ -196,8 +196,7 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
   // serialise the three streams of the pipeline against each other.  Device pointers handed to the *_dev entry points
   // have to be complete when the call is made (include/spvo.h).
   if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->stream_t, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->stream_u, hipStreamNonBlocking) != hipSuccess) {
+      hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->stream_t, hipStreamNonBlocking) != hipSuccess) {
     delete c;
     return fail(nullptr, SPVO_ERR_DEVICE, "cannot create a stream on device %d", cfg->device);
   }
@@ -207,7 +206,7 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
   for (int r = 0; r < RING; ++r)
     if (hipEventCreateWithFlags(&c->ev_net[r], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_tail[r], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_feat[r], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_copy[r], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_pre[r], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_up[r], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_res[r], hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_pre[r], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_res[r], hipEventDisableTiming) != hipSuccess) {
       spvo_destroy(c);
       return fail(nullptr, SPVO_ERR_DEVICE, "cannot create events on device %d", cfg->device);
     }
@@ -277,8 +276,6 @@ void spvo_destroy(spvo_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   if (c->stream_t) (void)hipStreamSynchronize(c->stream_t);
-  if (c->stream_c) (void)hipStreamSynchronize(c->stream_c);
-  if (c->stream_u) (void)hipStreamSynchronize(c->stream_u);
   if (c->ev_solve) (void)hipEventDestroy(c->ev_solve);
   if (c->ev_post) (void)hipEventDestroy(c->ev_post);
   resolve_pending(c);
@@ -304,7 +301,7 @@ void spvo_destroy(spvo_ctx *c) {
     if (c->d_resized_r[r]) (void)hipFree(c->d_resized_r[r]);
     if (c->h_resized_r[r]) (void)hipHostFree(c->h_resized_r[r]);
     if (c->h_desc_r[r]) (void)hipHostFree(c->h_desc_r[r]);
-    for (hipEvent_t e : {c->ev_net[r], c->ev_tail[r], c->ev_feat[r], c->ev_copy[r], c->ev_pre[r], c->ev_res[r], c->ev_up[r]}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {c->ev_net[r], c->ev_tail[r], c->ev_feat[r], c->ev_copy[r], c->ev_pre[r], c->ev_res[r]}) if (e) (void)hipEventDestroy(e);
   }
   for (int i = 0; i < N_SLOTS; ++i) {
     void *q[] = {c->slots[i].d_xy, c->slots[i].d_xyf, c->slots[i].d_desc, c->slots[i].d_n, c->slots[i].d_sqn};
@@ -319,8 +316,6 @@ void spvo_destroy(spvo_ctx *c) {
   for (auto hp : c->h_match_out) if (hp) (void)hipHostFree(hp);
   if (c->h_match_tmp) (void)hipHostFree(c->h_match_tmp);
   if (c->stream_t) (void)hipStreamDestroy(c->stream_t);
-  if (c->stream_c) (void)hipStreamDestroy(c->stream_c);
-  if (c->stream_u) (void)hipStreamDestroy(c->stream_u);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   delete c;
@@ -788,7 +783,6 @@ int spvo_synchronize(spvo_ctx *c) {
   if (!c) return fail(c, SPVO_ERR_INVALID, "null context");
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream_t));
-  HIP_TRY(c, hipStreamSynchronize(c->stream_c));
   HIP_TRY(c, hipStreamSynchronize(c->stream2));
   return SPVO_OK;
 }

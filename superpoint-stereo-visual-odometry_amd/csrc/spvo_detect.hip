@@ -447,7 +447,7 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
     int rc = launch_preprocess(c, srcs[0], srcs[1], 2, rows, cols, stride, g, 0, (extras & 1) ? c->d_resized_r[ring] : nullptr);
     if (rc) return rc;
   }
-  // ... and leave for the set's pinned mirror UNDER the network: a copy kernel (16 bytes per lane, no SDMA engine involved) on stream_c,
+  // ... and leave for the set's pinned mirror UNDER the network: a copy kernel (16 bytes per lane, no SDMA engine involved) on the TAIL stream
   // behind the FIRST layer -- beside it (conv1a is bound by its 217 MB of stores) the copy made that layer 54 us instead of 37 --
   // i.e. beside conv1b, which leaves 12 CUs free and does not notice
   const bool early_res = (extras & 1) != 0;
@@ -457,12 +457,12 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
     rc = run_ops(c, 2, 0, std::min<size_t>(1, c->head_start), c->stream);
     if (!rc && early_res) {
       HIP_TRY(c, hipEventRecord(c->ev_pre[ring], c->stream));
-      HIP_TRY(c, hipStreamWaitEvent(c->stream_c, c->ev_pre[ring], 0));
+      HIP_TRY(c, hipStreamWaitEvent(c->stream_t, c->ev_pre[ring], 0));
       const size_t n16 = ((size_t)2 * c->H * c->W + 15) / 16;   // (the buffers are allocated in multiples of 256 bytes)
-      hipLaunchKernelGGL(mirror_copy_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 64)), dim3(256), 0, c->stream_c,
+      hipLaunchKernelGGL(mirror_copy_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 64)), dim3(256), 0, c->stream_t,
                          reinterpret_cast<const uint4 *>(c->d_resized_r[ring]), reinterpret_cast<uint4 *>(c->h_resized_r[ring]), n16);
       HIP_TRY(c, hipGetLastError());
-      HIP_TRY(c, hipEventRecord(c->ev_res[ring], c->stream_c));
+      HIP_TRY(c, hipEventRecord(c->ev_res[ring], c->stream_t));
     }
     if (!rc) rc = run_ops(c, 2, std::min<size_t>(1, c->head_start), c->head_start, c->stream);
   }
@@ -510,14 +510,15 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
     c->pending.push_back({stage_id(c, "detect"), det_e0, e1});
   }
   if (!rc) rc = (hipEventRecord(c->ev_tail[ring], c->stream_t) == hipSuccess) ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");
-  // The descriptors a host-image submission takes back (extras bit 1: 2 x 1 MB) leave for the set's pinned mirror on stream_c, BEHIND the
-  // matches: written by the sampling kernel itself they made it 40 us instead of 4 in front of ev_feat; beside the matches the copy
+  // The descriptors a host-image submission takes back (extras bit 1: 2 x 1 MB) leave for the set's pinned mirror BEHIND the
+  // matches, on the tail stream (a stream of their own had them share a hardware queue with the network stream in processes that had
+  // created and destroyed contexts before -- the runtime deals streams onto four queues -- and bench.py's look-ahead leg fell from 1230
+  // to 1070 frames/s while the same calls from tools/sync_leg.py ran at 1260): written by the sampling kernel itself they made it 40 us instead of 4 in front of ev_feat; beside the matches the copy
   // kernel (44 us of PCIe writes) made the distance GEMM 55 us instead of 20.  ev_copy = they have arrived
   // (spvo_detect_mirrors_wait; spvo_detect_collect waits for it itself).
   if (!rc && (extras & 2)) {
-    HIP_TRY(c, hipStreamWaitEvent(c->stream_c, c->ev_tail[ring], 0));
-    rc = enqueue_desc_mirror(c, slots, ring, c->stream_c);
-    if (!rc) HIP_TRY(c, hipEventRecord(c->ev_copy[ring], c->stream_c));
+    rc = enqueue_desc_mirror(c, slots, ring, c->stream_t);
+    if (!rc) HIP_TRY(c, hipEventRecord(c->ev_copy[ring], c->stream_t));
   }
   c->post = c->stream;
   if (rc) return rc;
@@ -567,7 +568,7 @@ static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_feature
     rc = wait_event(c->ev_feat[pd.ring]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");
     g_diag.max_tail_wait = std::max(g_diag.max_tail_wait, diag_now_us() - tw0);
   }
-  if (!rc && pd.early_res) rc = wait_event(c->ev_res[pd.ring]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");   // the resized images: they left under the network (copy kernel on stream_c)
+  if (!rc && pd.early_res) rc = wait_event(c->ev_res[pd.ring]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");   // the resized images: they left under the network (copy kernel on the tail stream)
   bool redone = false;
   const NmsPair np = nms_pair(c, pd.ring);
   if (!rc) rc = nms_settle(c, 2, np, pd.ring, &redone);
@@ -595,7 +596,7 @@ static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_feature
       outs[i]->n = s.n;
       if (outs[i]->xy && s.n > 0) std::memcpy(outs[i]->xy, c->h_xy_r[pd.ring] + (size_t)i * cap * 2, (size_t)s.n * 2 * sizeof(float));
       if (outs[i]->desc && (pd.extras & 2) && s.n > 0) {
-        (void)wait_event(c->ev_copy[pd.ring]);   // the descriptors' mirror (beside the matches on stream_c)
+        (void)wait_event(c->ev_copy[pd.ring]);   // the descriptors' mirror (copy kernel behind the matches)
         std::memcpy(outs[i]->desc, c->h_desc_r[pd.ring] + (size_t)i * cap * 256, (size_t)s.n * 256 * sizeof(float));
       }
     }

@@ -127,8 +127,7 @@ struct PendingDetect {           // one spvo_detect*_submit in flight
   int rows = 0, cols = 0, slot_l = 0, slot_r = 0, prev_l = -1, ring = 0;
   bool rematch = false;          // the temporal partner's keypoints were redone after this submission matched against them
   int extras = 0;                // spvo_detect_submit: bit 0 resized images, bit 1 descriptors travel to the set's pinned mirrors
-  bool early_res = false;        // the resized images left on stream_c right behind the preprocess kernel (ev_res), under the network
-  bool direct = false;           // resized images and descriptors were WRITTEN into the pinned mirrors by the kernels that produce them: no bulk copies
+  bool early_res = false;        // the resized images leave for their pinned mirror behind the first layer (copy kernel on the tail stream, ev_res), under the network
 };
 
 
@@ -137,8 +136,6 @@ struct spvo_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // fused solve: overlaps with a detector submission in flight
   hipStream_t stream_t = nullptr;  // detector tail (heat map, NMS, sampling, matching): overlaps with the NEXT submission's network
-  hipStream_t stream_c = nullptr;  // bulk device-to-host copies of a host-image submission (resized images, descriptors): beside its matches
-  hipStream_t stream_u = nullptr;  // host-to-device copies of a host-image submission: the images of pair k+2 travel while pair k+1's network runs
   hipStream_t post = nullptr;      // where post-processing is enqueued right now: `stream`, or `stream_t` for a submission
   std::deque<PendingDetect> pendq;
   int cur_ring = 0;                // set whose network outputs the running forward pass writes
@@ -204,10 +201,9 @@ struct spvo_ctx {
   bool host_sets_ready = false;  // d_resized_r / h_resized_r / h_desc_r of EVERY set are allocated
   hipEvent_t ev_net[RING] = {nullptr, nullptr, nullptr, nullptr}, ev_tail[RING] = {nullptr, nullptr, nullptr, nullptr};
   // a submission's tail in two parts: ev_feat = keypoints, counts and descriptors are final (what spvo_detect_wait needs), ev_tail = the
-  // matches enqueued behind them have landed too (what spvo_match_slots needs); ev_copy = the bulk copies on stream_c
+  // matches enqueued behind them have landed too (what spvo_match_slots needs); ev_copy = the descriptors of a host-image submission have reached their pinned mirror (copy kernel behind the matches)
   hipEvent_t ev_feat[RING] = {nullptr, nullptr, nullptr, nullptr}, ev_copy[RING] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_up[RING] = {nullptr, nullptr, nullptr, nullptr};   // the set's images are on the device (stream_u)
-  hipEvent_t ev_pre[RING] = {nullptr, nullptr, nullptr, nullptr}, ev_res[RING] = {nullptr, nullptr, nullptr, nullptr};   // preprocess done (network stream) / resized images on the host (stream_c)
+  hipEvent_t ev_pre[RING] = {nullptr, nullptr, nullptr, nullptr}, ev_res[RING] = {nullptr, nullptr, nullptr, nullptr};   // first layer done (network stream) / resized images on the host (tail stream)
   hipEvent_t ev_post = nullptr;    // PostScope: orders a synchronous entry point behind what is left on the tail stream
   bool match_fp8 = false;        // fp8 shortlist GEMM (approximate; spvo_set_match_fp8)
   bool prematch = false;

@@ -218,7 +218,9 @@ int launch_op(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream
   }
   const float *tin = (ti.dr[c->cur_ring] ? ti.dr[c->cur_ring] : ti.d) + (size_t)img0 * ti.per_image;
   float *tout = (to.dr[c->cur_ring] ? to.dr[c->cur_ring] : to.d) + (size_t)img0 * to.per_image;
-  ScopedStage st(c, op.stage, 0, 0, stream);
+  // (max-pool / L2 normalisation: read one tensor, write one -- in the element sizes of the engine's tensors)
+  auto tsz = [](const Tensor &t) { return t.i8 ? 1.0 : t.f16 ? 2.0 : t.s3 ? 6.0 : 4.0; };
+  ScopedStage st(c, op.stage, 0, batch * ((double)ti.ch * ti.H * ti.W * tsz(ti) + (double)to.ch * to.H * to.W * tsz(to)), stream);
   if (op.type == OP_MAXPOOL && ti.f16) {
     return launch_maxpool_f16(c, ti, to, tin, tout, batch, stream);
   } else if (op.type == OP_MAXPOOL) {

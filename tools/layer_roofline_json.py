@@ -63,7 +63,7 @@ while i < len(plan.ops):
     hbm_bound = o0.type == weights.OP_CONV and o0.cin == 1
     row = {"layer": label, "shape": f"{o0.cin}->{sum(o.cout for o in ops if o.type == weights.OP_CONV)} k{o0.ksize} @{H >> plan.tensors[o0.inp][1]}x{Wd >> plan.tensors[o0.inp][1]}",
            "kernel": "conv_first4_kernel (VALU, HBM-write bound)" if hbm_bound else (kfam + (" (Winograd F(4x4,3x3), fp32 MFMA: executes 1/4 of the direct method's multiplies)" if kfactor == 0.25 else " (Winograd F(2x2,3x3), fp32 MFMA: executes 4/9)")) if wino else
-                     "heads_fused_kernel (fp32 MFMA)" if "heads" in label else (kfam + " (direct, fp16 MFMA, fp32 accumulate)" if prec == "FP16" else "conv_mfma_kernel (direct, fp32 MFMA)"),
+                     "heads_fused_kernel (fp32 MFMA)" if "heads" in label else "l2norm_nhwc_kernel (VALU, HBM)" if o0.type == weights.OP_L2NORM else (kfam + " (direct, fp16 MFMA, fp32 accumulate)" if prec == "FP16" else "conv_mfma_kernel (direct, fp32 MFMA)"),
            "duration_us": round(us, 2), "algorithmic_gflop": round(alg / 1e9, 3), "executed_gflop": round(executed / 1e9, 3),
            "executed_tflops": round(executed / us / 1e6, 2), "frac_of_mfma_peak": round(executed / us / 1e6 / PEAK, 4),
            "algorithmic_tflops": round(alg / us / 1e6, 2), "algorithmic_frac_of_mfma_peak": round(alg / us / 1e6 / PEAK, 4),

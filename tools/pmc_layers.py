@@ -50,7 +50,7 @@ for k, l in enumerate(out_layers):
     f_kb, w_kb = per_counter["FETCH_SIZE"][k], per_counter["WRITE_SIZE"][k]
     traffic = (2 * f_kb + w_kb) * 1024
     l.update(FETCH_SIZE_KB=round(f_kb, 1), WRITE_SIZE_KB=round(w_kb, 1), traffic_MB=round(traffic / 1e6, 1),
-             traffic_over_algorithmic=round(traffic / 1e6 / l["algorithmic_MB"], 3),
+             traffic_over_algorithmic=round(traffic / 1e6 / l["algorithmic_MB"], 3) if l["algorithmic_MB"] else None,
              hbm_GBps=round(traffic / l["duration_us"] / 1e3, 0), frac_of_hbm_peak=round(traffic / l["duration_us"] / 1e3 / 8000.0, 4))
     tot_t += traffic; tot_a += l["algorithmic_MB"] * 1e6; tot_us += l["duration_us"]
 res = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/forward_loop.py; dispatches matched to layers by "
@@ -62,4 +62,4 @@ res = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (se
 json.dump(res, open(out_path, "w"), indent=1)
 print(json.dumps(res["conv_stack"]))
 for l in out_layers:
-    print(f'{l["layer"][:28]:30s} {l["duration_us"]:7.1f} us  traffic {l["traffic_MB"]:7.1f} MB = {l["traffic_over_algorithmic"]:5.2f} x algorithmic  {l["hbm_GBps"]:6.0f} GB/s')
+    print(f'{l["layer"][:28]:30s} {l["duration_us"]:7.1f} us  traffic {l["traffic_MB"]:7.1f} MB = {(l["traffic_over_algorithmic"] or 0):5.2f} x algorithmic  {l["hbm_GBps"]:6.0f} GB/s')
