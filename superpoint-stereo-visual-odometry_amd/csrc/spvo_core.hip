@@ -38,7 +38,7 @@ int stage_id(spvo_ctx *c, const std::string &name) {
 // ---- diagnostic switches (include/spvo.h: spvo_set_tuning).  One process-wide table, filled by explicit calls only.
 namespace {
 const char *const kTuningNames[] = {"winograd", "wino4", "wino_narrow", "wino_dynamic", "winograd_min_tiles", "wino4_min_tiles", "merge_siblings", "heads_fused",
-                                    "heads_on_net", "heads_split", "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing"};
+                                    "heads_on_net", "heads_split", "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing", "buffer_images", "pair_trunks"};
 constexpr int kTuningCount = sizeof kTuningNames / sizeof kTuningNames[0];
 std::mutex g_tuning_mutex;
 bool g_tuning_set[kTuningCount] = {};
@@ -191,7 +191,8 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
   spvo_ctx *c = new spvo_ctx();
   c->cfg = *cfg;
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  c->H = cfg->net_height; c->W = cfg->net_width; c->Hc = c->H / 8; c->Wc = c->W / 8; c->B = 2;
+  c->H = cfg->net_height; c->W = cfg->net_width; c->Hc = c->H / 8; c->Wc = c->W / 8;
+  c->B = std::max(2, std::min(4, tuning("buffer_images", 2)));   // images the activation buffers hold (4: two pairs per trunk launch)
   // Non-blocking streams: work the caller puts on the NULL stream (a framework's default stream, a blocking hipMemcpy) must not
   // serialise the three streams of the pipeline against each other.  Device pointers handed to the *_dev entry points
   // have to be complete when the call is made (include/spvo.h).
@@ -217,8 +218,8 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
   const int cell = cfg->dist_thresh + 1;
   c->surv_cap = ((c->H + cell - 1) / cell) * ((c->W + cell - 1) / cell) + 64;
   do {
-    if ((rc = dev_alloc(c, &c->d_dense_in, 2 * hw))) break;
-    if ((rc = dev_alloc(c, &c->d_det_dense, (size_t)2 * 65 * c->Hc * c->Wc))) break;
+    if ((rc = dev_alloc(c, &c->d_dense_in, c->B * hw))) break;
+    if ((rc = dev_alloc(c, &c->d_det_dense, (size_t)c->B * 65 * c->Hc * c->Wc))) break;
     if ((rc = dev_alloc(c, &c->d_counters_all, (size_t)(RING + 1) * 2 * NMS_COUNTER_INTS))) break;   // RING submission sets, stand-alone
     if ((rc = dev_alloc(c, &c->d_xy_stage, (size_t)RING * 2 * cfg->max_keypoints * 2))) break;
     for (int r = 0; r < RING && !rc; ++r) {
