@@ -298,7 +298,7 @@ def main():
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 5],
                     help="BASELINE.json config shortcut: 2 = default; 3 = FP16 192x640; 5 = sp_mbv1 INT8, 2048 keypoints, fp8 shortlist")
     ap.add_argument("--dump-ops", action="store_true", help="add per-layer network times to the JSON line")
-    ap.add_argument("--depth", type=int, default=2, choices=[1, 2, 3], help="stereo pairs handed over ahead of the one being solved (3 measured no faster than 2)")
+    ap.add_argument("--depth", type=int, default=4, choices=[1, 2, 3, 4], help="stereo pairs handed over ahead of the one being solved; at 4 the front end pairs trunks (two stereo pairs per set of network launches: spvo_set_trunk_pairing)")
     args = ap.parse_args()
     if args.config == 3:
         args.precision, args.net_size = "FP16", "192x640"
@@ -356,6 +356,7 @@ def main():
     if world > 1:   # several ranks share the host: an equal share of the CPUs this job may really use (cgroup quota, not the host's core count)
         torch.set_num_threads(max(1, usable_cpus() // world))
     from spvo import capi, host, posegather, synth, weights
+    capi.tuning_from_env()   # SPVO_TUNE_<NAME>=<int>: diagnostic switches for A/B runs of this script (the library itself never reads the environment)
     if args.fp32_split:
         capi.set_tuning("fp32_split", 1)   # engines loaded from here on run in split mode (the library reads no environment variable for it)
 
@@ -383,6 +384,16 @@ def main():
     d_frames = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
     rows, cols = frames[0][0].shape
     order = list(range(SEQ_LEN)) + list(range(SEQ_LEN - 2, 0, -1))       # ping-pong: every step is a real motion
+    # one device buffer per POSITION of the cycle: the front end recognises an announced pair by its pointers, and with more than two pairs
+    # handed over ahead the ping-pong order shows the same frame twice inside the window (6, 7, 6)
+    cycles = {}
+
+    def cycle_buffers(seq):
+        key = tuple(seq)
+        if key not in cycles:
+            distinct = len(set(seq)) == len(seq)
+            cycles[key] = [d_frames[f] if distinct else tuple(t.clone() for t in d_frames[f]) for f in seq]
+        return cycles[key]
 
     fe = host.FrontEnd(tmp, prefix="superpoint_pretrained", selector="KNN", cross_check=True, batch=2,
                        height=NET_H, width=NET_W, conf_thresh=0.015, dist_thresh=4, border_remove=4,
@@ -396,14 +407,15 @@ def main():
     deferred = not (args.no_pipeline or args.sync_solve)
 
     def step(i, order=order):
-        dl, dr = d_frames[order[i % len(order)]]
-        ahead = [None, None, None]                                          # the next pairs are already in HBM
+        cyc = cycle_buffers(order)
+        dl, dr = cyc[i % len(cyc)]
+        ahead = [None] * 4                                                  # the next pairs are already in HBM
         for d in range(0 if args.no_pipeline else args.depth):
-            nl, nr = d_frames[order[(i + 1 + d) % len(order)]]
+            nl, nr = cyc[(i + 1 + d) % len(cyc)]
             ahead[d] = (nl.data_ptr(), nr.data_ptr())
         # with pairs handed over ahead the solve is handed over too: the pose of frame i is collected in step i + 1 (or by
         # fe.finish_solve() after the last step), so the solver's latency is never between two hand-overs of images
-        res = fe.step_device(dl.data_ptr(), dr.data_ptr(), rows, cols, dl.stride(0), P_l, P_r, ahead[0], ahead[1], deferred_solve=deferred, next3_pair=ahead[2])
+        res = fe.step_device(dl.data_ptr(), dr.data_ptr(), rows, cols, dl.stride(0), P_l, P_r, ahead[0], ahead[1], deferred_solve=deferred, next3_pair=ahead[2], next4_pair=ahead[3])
         if dist_on:                                                       # pose staged; RCCL all-gather per 64 frames on a side stream
             pg.gather_async(*(res if res is not None else (None, None)))
             if (i + 1) % 1024 == 0:
@@ -514,7 +526,7 @@ def main():
                                    + ("fp8 shortlist + exact re-rank, " if args.match_fp8 else "")
                                    + "BF+KNN 0.8, P3P-style RANSAC 500 it, LM refinement degree 4; one stereo stream per GPU, RCCL all-gather of poses",
                        "net_size": [NET_H, NET_W], "input_size": [rows, cols], "streams": world,
-                       "hand_over": ("images of the next %d pairs handed over ahead (prefetchStereoImagePairDevice)" % args.depth if not args.no_pipeline else "one pair at a time")
+                       "hand_over": ("images of the next %d pairs handed over ahead (prefetchStereoImagePairDevice)" % args.depth + ("; with four ahead the front end pairs trunks: a pair whose network would only queue waits for its successor and the two run through every layer in one launch (spvo_set_trunk_pairing)" if args.depth >= 4 else "") if not args.no_pipeline else "one pair at a time")
                                     + ("; each frame's solve handed over too, its pose collected during the next step (solveStereoOdometrySubmit / Collect), the last one before the closing barrier" if deferred else ""),
                        "pose_gather": {"local": "single stream, no collective", "c:rccl": "spvo_pose_allgather_n (C ABI, RCCL), one collective per 64 frames",
                                        "c:host": "spvo_pose_allgather_n (C ABI, file transport: test hook)",
@@ -550,7 +562,7 @@ def main():
             algorithmic = achieved
             executed_per_launch = dom["flops"] * kfactor
             achieved = executed_per_launch / (avg_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": kfam + kdesc + " instance of op 1 = conv1b 64->64 @" + f"{NET_H}x{NET_W}, 2 images",
+            out["roofline"] = {"bound": "mfma", "kernel": kfam + kdesc + " instance of op 1 = conv1b 64->64 @" + f"{NET_H}x{NET_W}, " + ("2 or 4 images per launch (trunk pairing: flops and time are the means over the timed launches)" if args.depth >= 4 and not args.no_pipeline else "2 images"),
                                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(achieved / peak, 4), "traffic": traffic,
                                "traffic_source": ("profiles/" + os.path.basename(pmc) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x 2, validated by a known-size copy kernel in the same session)") if traffic else None,
@@ -612,19 +624,20 @@ def main():
                 # The reference's own entry point, addStereoImagePair(cv::Mat&, ...) (node.cpp:175): images in HOST memory (as
                 # cv_bridge hands them over), resized images and descriptors copied back into images_dq / descriptors_dq -- PCIe
                 # both ways inside the timed region.  Never `value`.  "synchronous" = the unchanged node's call sequence, one pair at
-                # a time (nothing can overlap across frames: the per-frame latency); "lookahead" = the next two pairs announced
+                # a time (nothing can overlap across frames: the per-frame latency); "lookahead" = the next --depth pairs announced
                 # through prefetchStereoImagePair as a node can do from its message queue (node.cpp:307-313: queue of 20).
                 fe.close()
                 fe = host.FrontEnd(tmp, prefix="superpoint_pretrained", selector="KNN", cross_check=True, batch=2,
                                    height=NET_H, width=NET_W, conf_thresh=0.015, dist_thresh=4, border_remove=4,
                                    stereo_threshold=2.0, min_disparity=0.25, refinement_degree=4, precision="FP32")
-                mats = [(fe.make_image(L), fe.make_image(R)) for L, R in frames]
+                # one cv::Mat pair per POSITION of the cycle (the front end recognises an announced pair by its data pointers: see cycle_buffers)
+                mats = [(fe.make_image(frames[f][0]), fe.make_image(frames[f][1])) for f in order]
                 hi = {}
-                for name, depth in (("synchronous", 0), ("lookahead", 2)):
+                for name, depth in (("synchronous", 0), ("lookahead", args.depth)):
                     def hstep(i, depth=depth):
-                        a = [mats[order[(i + 1 + d) % len(order)]] if d < depth else None for d in range(3)]
-                        m = mats[order[i % len(order)]]
-                        return fe.step_host(m[0], m[1], P_l, P_r, a[0], a[1], deferred_solve=depth > 0 and deferred, next3_pair=a[2])
+                        a = [mats[(i + 1 + d) % len(mats)] if d < depth else None for d in range(4)]
+                        m = mats[i % len(mats)]
+                        return fe.step_host(m[0], m[1], P_l, P_r, a[0], a[1], deferred_solve=depth > 0 and deferred, next3_pair=a[2], next4_pair=a[3])
                     for i in range(args.warmup):
                         hstep(i)
                     fe.finish_solve()
@@ -643,7 +656,7 @@ def main():
                                 hctx.profile_enable(True)
                                 hctx.profile_reset()
                             for i in range(100):
-                                m = mats[order[i % len(order)]]
+                                m = mats[i % len(mats)]
                                 t0 = time.perf_counter()
                                 fe.lib.spvo_host_add_stereo_pair_mat(fe.h, C.c_void_p(m[0]), C.c_void_p(m[1]), host._p(Plc), host._p(Prc))
                                 t1 = time.perf_counter()

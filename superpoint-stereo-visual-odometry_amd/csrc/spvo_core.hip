@@ -38,7 +38,7 @@ int stage_id(spvo_ctx *c, const std::string &name) {
 // ---- diagnostic switches (include/spvo.h: spvo_set_tuning).  One process-wide table, filled by explicit calls only.
 namespace {
 const char *const kTuningNames[] = {"winograd", "wino4", "wino_narrow", "wino_dynamic", "winograd_min_tiles", "wino4_min_tiles", "merge_siblings", "heads_fused",
-                                    "heads_on_net", "heads_split", "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing", "buffer_images", "pair_trunks"};
+                                    "heads_on_net", "heads_split", "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing"};
 constexpr int kTuningCount = sizeof kTuningNames / sizeof kTuningNames[0];
 std::mutex g_tuning_mutex;
 bool g_tuning_set[kTuningCount] = {};
@@ -90,6 +90,8 @@ void resolve_pending(spvo_ctx *c) {
     if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
       c->stages[p.stage].total_ms += ms;
       c->stages[p.stage].calls += 1;
+      c->stages[p.stage].flops_sum += p.flops;
+      c->stages[p.stage].bytes_sum += p.bytes;
     }
     c->free_events.push_back(p.e0);
     c->free_events.push_back(p.e1);
@@ -192,7 +194,7 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
   c->cfg = *cfg;
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c->H = cfg->net_height; c->W = cfg->net_width; c->Hc = c->H / 8; c->Wc = c->W / 8;
-  c->B = std::max(2, std::min(4, tuning("buffer_images", 2)));   // images the activation buffers hold (4: two pairs per trunk launch)
+  c->B = 4;   // images the activation buffers hold: two stereo pairs per trunk launch (spvo_set_trunk_pairing)
   // Non-blocking streams: work the caller puts on the NULL stream (a framework's default stream, a blocking hipMemcpy) must not
   // serialise the three streams of the pipeline against each other.  Device pointers handed to the *_dev entry points
   // have to be complete when the call is made (include/spvo.h).
@@ -805,7 +807,7 @@ int spvo_profile_only(spvo_ctx *c, const char *stage) {
 int spvo_profile_reset(spvo_ctx *c) {
   if (!c) return fail(c, SPVO_ERR_INVALID, "null context");
   resolve_pending(c);
-  for (auto &s : c->stages) { s.total_ms = 0; s.calls = 0; }
+  for (auto &s : c->stages) { s.total_ms = 0; s.calls = 0; s.flops_sum = 0; s.bytes_sum = 0; }
   return SPVO_OK;
 }
 
@@ -822,8 +824,9 @@ int spvo_profile_get(spvo_ctx *c, int i, char *name, size_t name_cap, double *to
   if (name && name_cap) { std::strncpy(name, s.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
   if (total_ms) *total_ms = s.total_ms;
   if (calls) *calls = s.calls;
-  if (flops_per_call) *flops_per_call = s.flops;
-  if (bytes_per_call) *bytes_per_call = s.bytes;
+  // per call = the MEAN over the timed calls (so that flops / (total_ms / calls) is the rate also when launches of different batch mix)
+  if (flops_per_call) *flops_per_call = s.calls ? s.flops_sum / s.calls : s.flops;
+  if (bytes_per_call) *bytes_per_call = s.calls ? s.bytes_sum / s.calls : s.bytes;
   return SPVO_OK;
 }
 

@@ -82,6 +82,8 @@ int ensure_tables(spvo_ctx *c, const CropGeom &g) {
 }
 
 // one launch for `count` images (d_src0, d_src1) into slots slot0, slot0 + 1 of the resized-image buffer and the input tensor
+// slot0: the first image of the network's input planes the pair goes to (and of c->d_resized, the stand-alone entries' resized images);
+// resized_dst: a submission's own buffer for its two resized images instead (never offset)
 int launch_preprocess(spvo_ctx *c, const uint8_t *d_src0, const uint8_t *d_src1, int count, int rows, int cols, size_t stride, const CropGeom &g, int slot0,
                       uint8_t *resized_dst = nullptr) {
   int rc = ensure_tables(c, g);
@@ -93,7 +95,7 @@ int launch_preprocess(spvo_ctx *c, const uint8_t *d_src0, const uint8_t *d_src1,
   const int identity = (g.crop_rows == c->H && g.crop_cols == c->W) ? 1 : 0;
   dim3 grid((c->W + 63) / 64, (c->H + 3) / 4, count);
   hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, c->stream, d_src0, d_src1, stride, rows, cols, g.row_off, g.col_off, g.crop_rows, g.crop_cols, tab, c->H, c->W,
-                     (resized_dst ? resized_dst : c->d_resized) + (size_t)slot0 * c->H * c->W, tin.d + (size_t)slot0 * tin.per_image, tin.per_image, tin.hp, tin.wp, identity);
+                     resized_dst ? resized_dst : c->d_resized + (size_t)(slot0 & 1) * c->H * c->W, tin.d + (size_t)slot0 * tin.per_image, tin.per_image, tin.hp, tin.wp, identity);
   HIP_TRY(c, hipGetLastError());
   return SPVO_OK;
 }
@@ -299,9 +301,10 @@ int spvo_sample_descriptors(spvo_ctx *c, const float *desc_nhwc, const int32_t *
   return SPVO_OK;
 }
 
-static int enqueue_sample(spvo_ctx *c, const int slots[2], const NmsPair &np, int ring, float *host_desc = nullptr) {
+// ring: the submission's own set (keypoint mirror); tring / img0: whose network outputs hold this pair's descriptor maps, and where
+static int enqueue_sample(spvo_ctx *c, const int slots[2], const NmsPair &np, int ring, int tring, int img0) {
   const Tensor &ts = c->tensors[c->t_desc];
-  const float *desc = ts.dr[ring] ? ts.dr[ring] : ts.d;
+  const float *desc = (ts.dr[tring] ? ts.dr[tring] : ts.d) + (size_t)img0 * ts.per_image;
   ScopedStage ss(c, stage_id(c, "sample"));
   const int cap = c->cfg.max_keypoints;
   // the keypoints as floats go straight into the set's pinned mirror (8 bytes per keypoint), not through a staging buffer and a copy
@@ -311,7 +314,7 @@ static int enqueue_sample(spvo_ctx *c, const int slots[2], const NmsPair &np, in
     FeatureSlot &s = c->slots[slots[i]];
     // the keypoint count is read from the NMS counters on the device: no host round trip
     sj.j[i] = SampleJob{desc + (size_t)i * ts.per_image, np.b[i].out_xy, (const int *)(np.b[i].counters + 2), 0, s.d_desc, s.d_sqn,
-                        stage + (size_t)i * cap * 2, s.d_xy, s.d_n, host_desc ? host_desc + (size_t)i * cap * 256 : nullptr};
+                        stage + (size_t)i * cap * 2, s.d_xy, s.d_n, nullptr};
   }
   hipLaunchKernelGGL(sample_desc_kernel, dim3((cap + 3) / 4, 2), dim3(256), 0, c->post, sj, c->H, c->W, c->Hc, c->Wc);
   HIP_TRY(c, hipGetLastError());
@@ -353,11 +356,20 @@ static int enqueue_prematch(spvo_ctx *c, int slot_l, int slot_r, int prev_l, int
 }
 
 // Submission = network on `stream`, then the tail (heat map + NMS, sampling, the two matches and
-// their copies to pinned memory) on `stream_t` behind an event.  Up to MAX_INFLIGHT submissions may
+// their writes to pinned memory) on `stream_t` behind an event.  Up to MAX_INFLIGHT submissions may
 // be queued: the tail of one overlaps with the network of the next, whose kernels leave CUs idle at
 // their ragged ends.  Every buffer a tail touches belongs to the submission's set (RING of them), so
 // a later submission -- or the rare host-driven NMS redo of an earlier one -- never meets it.
+//
+// Trunk pairing (spvo_set_trunk_pairing, round 4): a submission's images are preprocessed at once, but its network may be HELD
+// until the next submission arrives and then run for both pairs in ONE set of launches (four images per layer): every layer pays
+// its launch, its first loads and its last stores once per two pairs, and 912 tiles spread better over 256 CUs than twice 456 --
+// 678 instead of 738 us per pair for the forward pass (tools/fwd_batch.py).  A pair is only held while an earlier trunk is still
+// queued or running (holding costs nothing then); spvo_detect_wait on a held pair launches it alone.  Results are independent of
+// the grouping: the kernels were selected for two images at engine load and every tile is computed the same way wherever it runs
+// (tests/test_gpu_host.py::test_prefetch_pipeline_is_transparent, depths 3 and 4).
 static int ensure_host_sets(spvo_ctx *c, size_t image_bytes);
+static int launch_group(spvo_ctx *c);
 
 // host_l / host_r != NULL: the images are in HOST memory -- they are staged through the set's pinned buffers and copied to the
 // device on the network stream (d_l, d_r are then ignored); extras: see PendingDetect
@@ -370,7 +382,6 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
       return fail(c, SPVO_ERR_STATE, "feature slots %d, %d are used by a submission in flight", slot_l, slot_r);
   if (c->cfg.max_batch != 2) return fail(c, SPVO_ERR_INVALID, "max_batch == 1 detect path is not built yet; use max_batch = 2");
   const CropGeom g = crop_geometry(rows, cols, c->H, c->W);
-  const Tensor &td = c->tensors[c->t_det];
   const uint8_t *srcs[2] = {d_l, d_r};
   const int slots[2] = {slot_l, slot_r};
   if (!host_l && (!d_l || !d_r)) return fail(c, SPVO_ERR_INVALID, "null image");
@@ -397,26 +408,72 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
     srcs[0] = c->d_img_r[ring];
     srcs[1] = c->d_img_r[ring] + c->img_cap_r;
   }
-  // ---- everything below is enqueued without a host round trip
-  c->cur_ring = ring;
+  // ---- phase A, at once: the pair's images into the network's input planes (images 2 * position in the group, + 1).  Same stream as
+  // the trunks: it runs behind the trunk that is using the input planes now.
+  const int pos = c->held;      // 0, or 1 when a held submission is waiting for a partner
   c->post = c->stream;
-  // tuning "trunk_timing" = 1 (diagnostic): how long the network stream works per submission and how long it stands idle between two
-  // submissions, from timing events at both ends of the trunk (printed every 200 submissions)
+  {
+    ScopedStage sp(c, stage_id(c, "preprocess"));
+    // the resized u8 images (what nn.cpp:154 pushes to images_dq) stay in device memory here: one byte per thread into pinned host
+    // memory made this kernel 31 us instead of 8, in front of the whole network
+    int rc = launch_preprocess(c, srcs[0], srcs[1], 2, rows, cols, stride, g, 2 * pos, (extras & 1) ? c->d_resized_r[ring] : nullptr);
+    if (rc) return rc;
+  }
+  for (int i = 0; i < 2; ++i) c->slots[slots[i]].filled = true;
+  c->last_slot_l = slot_l;
+  PendingDetect pd;
+  pd.g = CropGeomS{g.row_off, g.col_off, g.crop_rows, g.crop_cols, g.scale};
+  pd.rows = rows; pd.cols = cols;
+  pd.slot_l = slot_l; pd.slot_r = slot_r; pd.prev_l = prev_l; pd.ring = ring; pd.extras = extras; pd.early_res = (extras & 1) != 0;
+  pd.launched = false; pd.img0 = 2 * pos; pd.tring = ring;
+  c->pendq.push_back(pd);
+  c->held += 1;
+  // ---- phases B and C now, unless the pair may wait for a partner: pairing is on, it is the first of its group, and an earlier
+  // trunk is still queued or running (so nothing idles while it waits)
+  const bool earlier_trunk_pending = c->last_launch_ring >= 0 && hipEventQuery(c->ev_net[c->last_launch_ring]) == hipErrorNotReady;
+  if (c->pair_trunks && c->held == 1 && earlier_trunk_pending) return SPVO_OK;
+  return launch_group(c);
+}
+
+extern "C++" {
+namespace spvo_int {
+int release_held_if_idle(spvo_ctx *c) {
+  if (c->held != 1 || (c->last_launch_ring >= 0 && hipEventQuery(c->ev_net[c->last_launch_ring]) == hipErrorNotReady)) return SPVO_OK;
+  return launch_group(c);
+}
+}  // namespace spvo_int
+}
+
+// phases B (the trunk of the held pairs: one or two, 2 or 4 images per launch) and C (each pair's tail)
+static int launch_group(spvo_ctx *c) {
+  const int n = c->held;
+  if (n <= 0) return SPVO_OK;
+  if (n > 2 || (int)c->pendq.size() < n) return fail(c, SPVO_ERR_STATE, "internal: %d held submissions, %zu in flight", n, c->pendq.size());
+  c->held = 0;
+  PendingDetect *mem[2] = {&c->pendq[c->pendq.size() - n], n == 2 ? &c->pendq[c->pendq.size() - 1] : nullptr};
+  const int tring = mem[0]->ring;      // the set whose network outputs (det, desc, head inputs) hold all images of the group
+  const int batch = 2 * n;
+  const Tensor &td = c->tensors[c->t_det];
+  // ---- everything below is enqueued without a host round trip
+  c->cur_ring = tring;
+  c->post = c->stream;
+  // tuning "trunk_timing" = 1 (diagnostic): how long the network stream works per trunk launch and how long it stands idle between two,
+  // from timing events at both ends of the trunk (printed every 200 launches)
   static const bool trunk_timing = tuning("trunk_timing", 0) != 0;
-  constexpr int TT = 8;   // ring of timing events: deeper than the submissions that can be in flight
+  constexpr int TT = 16;   // ring of timing events: deeper than the launches that can be in flight
   static hipEvent_t tt_b[TT], tt_e[TT];
   static long tt_n = 0;
-  static double tt_busy = 0, tt_idle = 0;
+  static double tt_busy = 0, tt_idle = 0, tt_pairs = 0;
   if (trunk_timing) {
     const double tnow = diag_now_us();
-    if (c->submit_count > 1 && hipEventQuery(c->ev_net[(c->submit_count - 2) % RING]) == hipSuccess) ++g_diag.late;   // the trunk before this one is done already: the stream is idle
+    if (c->last_launch_ring >= 0 && hipEventQuery(c->ev_net[c->last_launch_ring]) == hipSuccess) ++g_diag.late;   // the trunk before this one is done already: the stream is idle
     g_diag.depth_sum += (int)c->pendq.size();
     if (g_diag.t_last_submit > 0) g_diag.max_interval = std::max(g_diag.max_interval, tnow - g_diag.t_last_submit);
     g_diag.t_last_submit = tnow;
     if (tt_n == 0)
       for (int r = 0; r < TT; ++r) { (void)hipEventCreate(&tt_b[r]); (void)hipEventCreate(&tt_e[r]); }
-    if (tt_n >= TT) {   // the submissions before those that may be in flight are complete: ring slots (n-4) and (n-5)
-      const int r2 = (int)((tt_n - 4) % TT), r3 = (int)((tt_n - 5) % TT);
+    if (tt_n >= TT) {   // the launches before those that may be in flight are complete: ring slots (n-8) and (n-9)
+      const int r2 = (int)((tt_n - 8) % TT), r3 = (int)((tt_n - 9) % TT);
       float busy = 0, idle = 0;
       static int tt_late = 0;
       static float tt_max = 0;
@@ -426,48 +483,46 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
         tt_max = std::max(tt_max, idle);
       }
       if (tt_n % 200 == 0) {
-        std::fprintf(stderr, "[spvo] trunk timing over 200 submissions: network stream busy %.1f us, idle %.1f us per submission (%d gaps above 50 us, longest %.0f us)\n",
-                     tt_busy * 1e3 / 200, tt_idle * 1e3 / 200, tt_late, tt_max * 1e3);
-        std::fprintf(stderr, "[spvo]   host: longest interval between submissions %.0f us, longest wait for a tail %.0f us, for a solve %.0f us, matches not served from the cache %d; "
-                             "submissions that found the network stream idle %d, mean submissions in flight at submit %.2f\n",
+        std::fprintf(stderr, "[spvo] trunk timing over 200 launches (%.0f pairs): network stream busy %.1f us, idle %.1f us per launch (%d gaps above 50 us, longest %.0f us)\n",
+                     tt_pairs, tt_busy * 1e3 / 200, tt_idle * 1e3 / 200, tt_late, tt_max * 1e3);
+        std::fprintf(stderr, "[spvo]   host: longest interval between launches %.0f us, longest wait for a tail %.0f us, for a solve %.0f us, matches not served from the cache %d; "
+                             "launches that found the network stream idle %d, mean submissions in flight at launch %.2f\n",
                      g_diag.max_interval, g_diag.max_tail_wait, g_diag.max_solve_wait, g_diag.match_miss, g_diag.late, g_diag.depth_sum / 200.0);
         g_diag.max_interval = g_diag.max_tail_wait = g_diag.max_solve_wait = 0; g_diag.match_miss = 0; g_diag.late = 0; g_diag.depth_sum = 0;
-        tt_busy = tt_idle = 0; tt_late = 0; tt_max = 0;
+        tt_busy = tt_idle = tt_pairs = 0; tt_late = 0; tt_max = 0;
       }
     }
+    tt_pairs += n;
     (void)hipEventRecord(tt_b[tt_n % TT], c->stream);
   }
   hipEvent_t det_e0 = nullptr;
   const bool prof_detect = c->prof && (c->prof_only < 0 || c->prof_only == stage_id(c, "detect"));
   if (prof_detect) { det_e0 = get_event(c); (void)hipEventRecord(det_e0, c->stream); }
-  {
-    ScopedStage sp(c, stage_id(c, "preprocess"));
-    // the resized u8 images (what nn.cpp:154 pushes to images_dq) stay in device memory here: one byte per thread into pinned host
-    // memory made this kernel 31 us instead of 8, in front of the whole network
-    int rc = launch_preprocess(c, srcs[0], srcs[1], 2, rows, cols, stride, g, 0, (extras & 1) ? c->d_resized_r[ring] : nullptr);
-    if (rc) return rc;
-  }
-  // ... and leave for the set's pinned mirror UNDER the network: a copy kernel (16 bytes per lane, no SDMA engine involved) on the TAIL stream
-  // behind the FIRST layer -- beside it (conv1a is bound by its 217 MB of stores) the copy made that layer 54 us instead of 37 --
-  // i.e. beside conv1b, which leaves 12 CUs free and does not notice
-  const bool early_res = (extras & 1) != 0;
   int rc;
   {
     ScopedStage net(c, stage_id(c, "net"));
-    rc = run_ops(c, 2, 0, std::min<size_t>(1, c->head_start), c->stream);
-    if (!rc && early_res) {
-      HIP_TRY(c, hipEventRecord(c->ev_pre[ring], c->stream));
-      HIP_TRY(c, hipStreamWaitEvent(c->stream_t, c->ev_pre[ring], 0));
+    rc = run_ops(c, batch, 0, std::min<size_t>(1, c->head_start), c->stream);
+    // The resized images leave for their sets' pinned mirrors UNDER the network: a copy kernel (16 bytes per lane, no SDMA engine involved)
+    // on the TAIL stream behind the FIRST layer -- beside it (conv1a is bound by its 217 MB of stores) the copy made that layer 54 us
+    // instead of 37 -- i.e. beside conv1b, which leaves 12 CUs free and does not notice
+    bool any_res = false;
+    for (int m = 0; m < n; ++m) any_res = any_res || mem[m]->early_res;
+    if (!rc && any_res) {
+      HIP_TRY(c, hipEventRecord(c->ev_pre[tring], c->stream));
+      HIP_TRY(c, hipStreamWaitEvent(c->stream_t, c->ev_pre[tring], 0));
       const size_t n16 = ((size_t)2 * c->H * c->W + 15) / 16;   // (the buffers are allocated in multiples of 256 bytes)
-      hipLaunchKernelGGL(mirror_copy_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 64)), dim3(256), 0, c->stream_t,
-                         reinterpret_cast<const uint4 *>(c->d_resized_r[ring]), reinterpret_cast<uint4 *>(c->h_resized_r[ring]), n16);
-      HIP_TRY(c, hipGetLastError());
-      HIP_TRY(c, hipEventRecord(c->ev_res[ring], c->stream_t));
+      for (int m = 0; m < n; ++m) {
+        if (!mem[m]->early_res) continue;
+        hipLaunchKernelGGL(mirror_copy_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 64)), dim3(256), 0, c->stream_t,
+                           reinterpret_cast<const uint4 *>(c->d_resized_r[mem[m]->ring]), reinterpret_cast<uint4 *>(c->h_resized_r[mem[m]->ring]), n16);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(c->ev_res[mem[m]->ring], c->stream_t));
+      }
     }
-    if (!rc) rc = run_ops(c, 2, std::min<size_t>(1, c->head_start), c->head_start, c->stream);
+    if (!rc) rc = run_ops(c, batch, std::min<size_t>(1, c->head_start), c->head_start, c->stream);
   }
   if (rc) { c->cur_ring = 0; return rc; }
-  c->last_batch = 2;
+  c->last_batch = batch;
   // The heads (2.2 GFLOP: the one heavy piece behind the trunk): on the network stream, in front of the next pair's trunk, when the
   // trunk is made of persistent one-workgroup-per-CU launches (VGG fp32: beside the next pair's conv1b they would have 12 CUs, the
   // tail would finish late and the network stream idle 50-70 us per pair: 1257-1265 against 1308 frames/s); on the tail stream
@@ -476,66 +531,71 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   const int hon = tuning("heads_on_net", -1);
   const bool heads_on_net = hon < 0 ? c->heads_on_net : hon != 0;
   if (heads_on_net) {
-    rc = run_ops(c, 2, c->head_start, c->ops.size(), c->stream);
+    rc = run_ops(c, batch, c->head_start, c->ops.size(), c->stream);
     if (rc) { c->cur_ring = 0; return rc; }
   }
-  if (trunk_timing) { (void)hipEventRecord(tt_e[tt_n % 8], c->stream); ++tt_n; }
-  HIP_TRY(c, hipEventRecord(c->ev_net[ring], c->stream));
-  HIP_TRY(c, hipStreamWaitEvent(c->stream_t, c->ev_net[ring], 0));
+  if (trunk_timing) { (void)hipEventRecord(tt_e[tt_n % TT], c->stream); ++tt_n; }
+  for (int m = 0; m < n; ++m) HIP_TRY(c, hipEventRecord(c->ev_net[mem[m]->ring], c->stream));
+  c->last_launch_ring = mem[n - 1]->ring;
+  HIP_TRY(c, hipStreamWaitEvent(c->stream_t, c->ev_net[tring], 0));
   c->post = c->stream_t;
-  if (!heads_on_net) rc = run_ops(c, 2, c->head_start, c->ops.size(), c->stream_t);   // heads: on the tail stream, reading this submission's ring buffers
+  if (!heads_on_net) rc = run_ops(c, batch, c->head_start, c->ops.size(), c->stream_t);   // heads: on the tail stream, reading this group's ring buffers
   c->cur_ring = 0;
   if (rc) { c->post = c->stream; return rc; }
-  const NmsPair np = nms_pair(c, ring);
-  {
-    // heat map + threshold + candidate list in one kernel; the counter block of this set was
-    // zeroed by the previous submission's last NMS kernel (or at allocation)
-    ScopedStage sh(c, stage_id(c, "heatmap"));
-    hipLaunchKernelGGL(heatmap_nms_kernel, dim3((c->Wc + 63) / 64, (c->Hc + 3) / 4, 2), dim3(256), 0, c->post, td.dr[ring], c->d_heat_r[ring], c->Hc, c->Wc, td.hp, td.wp,
-                       c->cfg.conf_thresh, np);
-    HIP_TRY(c, hipGetLastError());
-  }
-  {
-    ScopedStage sn(c, stage_id(c, "nms"));
-    rc = launch_nms_rounds(c, 2, np, ring, NMS_FIRST, c->d_counters_all + (size_t)(((ring + 1) % RING) * 2) * NMS_COUNTER_INTS);
-  }
-  if (!rc) rc = enqueue_sample(c, slots, np, ring);
-  // Keypoints, counts and descriptors are final here: spvo_detect_wait / _collect waits for THIS point (ev_feat); the matches enqueued
-  // behind it are waited for where they are asked for (spvo_match_slots, ev_tail).
-  if (!rc) rc = hipEventRecord(c->ev_feat[ring], c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");
-  if (!rc && c->prematch) rc = enqueue_prematch(c, slot_l, slot_r, prev_l, ring);
-  if (!rc && prof_detect) {   // "detect" spans both streams: first kernel on `stream` .. last copy on `stream_t`
-    hipEvent_t e1 = get_event(c);
-    (void)hipEventRecord(e1, c->stream_t);
-    c->pending.push_back({stage_id(c, "detect"), det_e0, e1});
-  }
-  if (!rc) rc = (hipEventRecord(c->ev_tail[ring], c->stream_t) == hipSuccess) ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");
-  // The descriptors a host-image submission takes back (extras bit 1: 2 x 1 MB) leave for the set's pinned mirror BEHIND the
-  // matches, on the tail stream (a stream of their own had them share a hardware queue with the network stream in processes that had
-  // created and destroyed contexts before -- the runtime deals streams onto four queues -- and bench.py's look-ahead leg fell from 1230
-  // to 1070 frames/s while the same calls from tools/sync_leg.py ran at 1260): written by the sampling kernel itself they made it 40 us instead of 4 in front of ev_feat; beside the matches the copy
-  // kernel (44 us of PCIe writes) made the distance GEMM 55 us instead of 20.  ev_copy = they have arrived
-  // (spvo_detect_mirrors_wait; spvo_detect_collect waits for it itself).
-  if (!rc && (extras & 2)) {
-    rc = enqueue_desc_mirror(c, slots, ring, c->stream_t);
-    if (!rc) HIP_TRY(c, hipEventRecord(c->ev_copy[ring], c->stream_t));
+  // ---- phase C: each pair's tail, in submission order (the second pair's temporal match reads the first pair's features)
+  for (int m = 0; m < n && !rc; ++m) {
+    PendingDetect &pd = *mem[m];
+    const int ring = pd.ring, slots[2] = {pd.slot_l, pd.slot_r};
+    pd.tring = tring;
+    const NmsPair np = nms_pair(c, ring);
+    {
+      // heat map + threshold + candidate list in one kernel; the counter block of this set was
+      // zeroed by the previous submission's last NMS kernel (or at allocation)
+      ScopedStage sh(c, stage_id(c, "heatmap"));
+      hipLaunchKernelGGL(heatmap_nms_kernel, dim3((c->Wc + 63) / 64, (c->Hc + 3) / 4, 2), dim3(256), 0, c->post, td.dr[tring] + (size_t)pd.img0 * td.per_image, c->d_heat_r[ring],
+                         c->Hc, c->Wc, td.hp, td.wp, c->cfg.conf_thresh, np);
+      HIP_TRY(c, hipGetLastError());
+    }
+    {
+      ScopedStage sn(c, stage_id(c, "nms"));
+      rc = launch_nms_rounds(c, 2, np, ring, NMS_FIRST, c->d_counters_all + (size_t)(((ring + 1) % RING) * 2) * NMS_COUNTER_INTS);
+    }
+    if (!rc) rc = enqueue_sample(c, slots, np, ring, tring, pd.img0);
+    // Keypoints, counts and descriptors are final here: spvo_detect_wait / _collect waits for THIS point (ev_feat); the matches enqueued
+    // behind it are waited for where they are asked for (spvo_match_slots, ev_tail).
+    if (!rc) rc = hipEventRecord(c->ev_feat[ring], c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");
+    if (!rc && c->prematch) rc = enqueue_prematch(c, pd.slot_l, pd.slot_r, pd.prev_l, ring);
+    if (!rc && prof_detect) {   // "detect" spans both streams: first kernel on `stream` .. last kernel on `stream_t`
+      hipEvent_t e1 = get_event(c);
+      (void)hipEventRecord(e1, c->stream_t);
+      c->pending.push_back({stage_id(c, "detect"), det_e0, e1});
+      if (m + 1 < n) { det_e0 = get_event(c); (void)hipEventRecord(det_e0, c->stream_t); }   // (an event is timed once)
+    }
+    if (!rc) rc = (hipEventRecord(c->ev_tail[ring], c->stream_t) == hipSuccess) ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");
+    // The descriptors a host-image submission takes back (extras bit 1: 2 x 1 MB) leave for the set's pinned mirror BEHIND the
+    // matches, on the tail stream (a stream of their own had them share a hardware queue with the network stream in processes that had
+    // created and destroyed contexts before -- the runtime deals streams onto four queues -- and bench.py's look-ahead leg fell from
+    // 1230 to 1070 frames/s while the same calls from tools/sync_leg.py ran at 1260): written by the sampling kernel itself they
+    // made it 40 us instead of 4 in front of ev_feat; beside the matches the copy kernel (44 us of PCIe writes) made the distance GEMM
+    // 55 us instead of 20.  ev_copy = they have arrived (spvo_detect_mirrors_wait; spvo_detect_collect waits for it itself).
+    if (!rc && (pd.extras & 2)) {
+      rc = enqueue_desc_mirror(c, slots, ring, c->stream_t);
+      if (!rc) HIP_TRY(c, hipEventRecord(c->ev_copy[ring], c->stream_t));
+    }
+    pd.launched = true;
   }
   c->post = c->stream;
-  if (rc) return rc;
-  for (int i = 0; i < 2; ++i) c->slots[slots[i]].filled = true;
-  c->last_slot_l = slot_l;
-  PendingDetect pd;
-  pd.g = CropGeomS{g.row_off, g.col_off, g.crop_rows, g.crop_cols, g.scale};
-  pd.rows = rows; pd.cols = cols;
-  pd.slot_l = slot_l; pd.slot_r = slot_r; pd.prev_l = prev_l; pd.ring = ring; pd.extras = extras; pd.early_res = early_res;
-  c->pendq.push_back(pd);
-  return SPVO_OK;
+  return rc;
 }
 
 // completes the OLDEST submission
 static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_features *out_l, spvo_features *out_r, uint8_t *resized_l, uint8_t *resized_r,
                        spvo_detect_mirrors *mirrors = nullptr) {
   if (c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "no detector submission in flight");
+  if (!c->pendq.front().launched) {   // a pair that was held for a partner (trunk pairing) and is asked for first: it runs alone
+    const int rcl = launch_group(c);
+    if (rcl) return rcl;
+  }
   const PendingDetect pd = c->pendq.front();
   const int slots[2] = {pd.slot_l, pd.slot_r};
   const int cap = c->cfg.max_keypoints;
@@ -576,7 +636,7 @@ static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_feature
     if (redone) c->stages[stage_id(c, "nms_redo")].calls += 1;       // counted even with profiling off (tests, diagnostics)
     if (pd.rematch) c->stages[stage_id(c, "rematch")].calls += 1;
     if (redone && (pd.extras & 2)) (void)wait_event(c->ev_copy[pd.ring]);   // the mirror of the superseded descriptors has landed: the new one goes on top
-    if (redone) rc = enqueue_sample(c, slots, np, pd.ring);
+    if (redone) rc = enqueue_sample(c, slots, np, pd.ring, pd.tring, pd.img0);
     if (!rc && redone && (pd.extras & 2)) rc = enqueue_desc_mirror(c, slots, pd.ring, c->post);
     if (!rc && c->prematch) rc = enqueue_prematch(c, pd.slot_l, pd.slot_r, pd.prev_l, pd.ring);
     if (!rc && extras) rc = copy_extras();
@@ -705,6 +765,13 @@ int spvo_detect_collect(spvo_ctx *c, double P_l[12], double P_r[12], spvo_featur
   if (!c) return fail(c, SPVO_ERR_INVALID, "null context");
   HIP_TRY(c, hipSetDevice(c->cfg.device));
   return detect_wait(c, P_l, P_r, out_l, out_r, resized_l, resized_r);
+}
+
+int spvo_set_trunk_pairing(spvo_ctx *c, int on) {
+  if (!c) return fail(c, SPVO_ERR_INVALID, "null context");
+  c->pair_trunks = on != 0;
+  if (!c->pair_trunks && c->held) return launch_group(c);   // nobody is left waiting for a partner that will not be paired
+  return SPVO_OK;
 }
 
 int spvo_detect_mirrors_wait(spvo_ctx *c, const spvo_detect_mirrors *m) {

@@ -31,9 +31,9 @@ using namespace spvo;
 
 namespace spvo_int {
 
-constexpr int RING = 4;          // buffer sets a detector submission owns (network outputs, heat map, NMS state, counters, host mirrors)
-constexpr int MAX_INFLIGHT = 3;  // detector submissions that may be queued at once (RING - 1: the set of the pair just completed still serves its matches)
-constexpr int N_SLOTS = 10;      // feature slots: 5 stereo pairs (previous, current and three in flight)
+constexpr int RING = 8;          // buffer sets a detector submission owns (network outputs, heat map, NMS state, counters, host mirrors)
+constexpr int MAX_INFLIGHT = 6;  // detector submissions that may be queued at once (< RING - 1: the sets of the pairs just completed still serve their matches and mirrors)
+constexpr int N_SLOTS = 16;      // feature slots: 8 stereo pairs (previous, current and up to six in flight)
 
 struct Tensor {
   int ch = 0, level = 0, H = 0, W = 0, hp = 0, wp = 0;
@@ -77,9 +77,10 @@ struct Stage {
   double total_ms = 0;
   long long calls = 0;
   double flops = 0, bytes = 0;  // algorithmic, per call (last call's value)
+  double flops_sum = 0, bytes_sum = 0;   // ... summed over the timed calls (launches of two and of four images mix under trunk pairing)
 };
 
-struct Pending { int stage; hipEvent_t e0, e1; };
+struct Pending { int stage; hipEvent_t e0, e1; double flops = 0, bytes = 0; };
 
 struct FeatureSlot {
   int n = 0;
@@ -128,6 +129,9 @@ struct PendingDetect {           // one spvo_detect*_submit in flight
   bool rematch = false;          // the temporal partner's keypoints were redone after this submission matched against them
   int extras = 0;                // spvo_detect_submit: bit 0 resized images, bit 1 descriptors travel to the set's pinned mirrors
   bool early_res = false;        // the resized images leave for their pinned mirror behind the first layer (copy kernel on the tail stream, ev_res), under the network
+  bool launched = false;         // its trunk and tail are enqueued (false: held for a partner, spvo_set_trunk_pairing)
+  int img0 = 0;                  // its first image in the network's planes (0, or 2 as the second pair of a group)
+  int tring = 0;                 // the set whose network outputs hold its detector / descriptor maps (its own, or its group's first)
 };
 
 
@@ -138,6 +142,9 @@ struct spvo_ctx {
   hipStream_t stream_t = nullptr;  // detector tail (heat map, NMS, sampling, matching): overlaps with the NEXT submission's network
   hipStream_t post = nullptr;      // where post-processing is enqueued right now: `stream`, or `stream_t` for a submission
   std::deque<PendingDetect> pendq;
+  int held = 0;                  // submissions at the back of pendq whose trunk has not been launched yet (0 .. 2: trunk pairing)
+  bool pair_trunks = false;      // spvo_set_trunk_pairing
+  int last_launch_ring = -1;     // ev_net[...] of the newest trunk launched
   int cur_ring = 0;                // set whose network outputs the running forward pass writes
   unsigned submit_count = 0;
   std::string error;
@@ -285,6 +292,9 @@ int stage_id(spvo_ctx *c, const std::string &name);
 hipError_t wait_event(hipEvent_t ev);
 // a diagnostic switch (spvo_set_tuning, include/spvo.h): the value set for `name`, or `dflt`.  Never the environment.
 int tuning(const char *name, int dflt);
+// trunk pairing: a pair held for a partner whose predecessor's trunk has meanwhile finished is launched alone (called from the entry
+// points a host passes through while it waits: the network stream must not idle because the partner is late)
+int release_held_if_idle(spvo_ctx *c);
 hipEvent_t get_event(spvo_ctx *c);
 void resolve_pending(spvo_ctx *c);
 
@@ -306,7 +316,7 @@ struct ScopedStage {
     if (id < 0) return;
     hipEvent_t e1 = get_event(c);
     (void)hipEventRecord(e1, st);
-    c->pending.push_back({id, e0, e1});
+    c->pending.push_back({id, e0, e1, c->stages[id].flops, c->stages[id].bytes});
     if (c->pending.size() > 8192) resolve_pending(c);
   }
 };

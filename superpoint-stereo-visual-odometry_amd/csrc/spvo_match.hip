@@ -230,6 +230,7 @@ int spvo_match_hamming(spvo_ctx *c, const uint8_t *desc_a, int na, const uint8_t
 int spvo_match_slots(spvo_ctx *c, int slot_a, int slot_b, int selector, int cross_check, float ratio, int32_t *train_idx, float *distance) {
   if (!c || slot_a < 0 || slot_a >= N_SLOTS || slot_b < 0 || slot_b >= N_SLOTS) return fail(c, SPVO_ERR_INVALID, "bad slot");
   if (selector != SPVO_SELECT_NN && selector != SPVO_SELECT_KNN) return fail(c, SPVO_ERR_INVALID, "bad selector");
+  (void)release_held_if_idle(c);
   const FeatureSlot &a = c->slots[slot_a], &b = c->slots[slot_b];
   if (a.n > 0 && (!train_idx || !distance)) return fail(c, SPVO_ERR_INVALID, "null output");
   for (int set = 0; set < RING; ++set) {   // already computed alongside the detector (spvo_set_prematch)?

@@ -143,6 +143,7 @@ int spvo_pnp_refine(spvo_ctx *c, const double P_l[12], const double P_r[12], con
 int spvo_solve_submit(spvo_ctx *c, const spvo_solve_input *in) {
   if (!c || !in) return fail(c, SPVO_ERR_INVALID, "null argument");
   if (c->solve_pending.active) return fail(c, SPVO_ERR_STATE, "a solve is pending: complete it with spvo_solve_wait first");
+  (void)release_held_if_idle(c);
   const int n = in->n;
   if (n < 0 || (n > 0 && (!in->xy_cl || !in->xy_cr || !in->xy_pl || !in->xy_pr))) return fail(c, SPVO_ERR_INVALID, "bad argument");
   if (in->ransac.iterations <= 0 || in->ransac.iterations > 65536 || !(in->ransac.reproj_error > 0) || in->refine.max_iterations < 0 ||
@@ -246,6 +247,7 @@ int spvo_solve_submit(spvo_ctx *c, const spvo_solve_input *in) {
 int spvo_solve_wait(spvo_ctx *c, spvo_solve_output *out, float *xyz, int32_t *inliers) {
   if (!c || !out) return fail(c, SPVO_ERR_INVALID, "null argument");
   if (!c->solve_pending.active) return fail(c, SPVO_ERR_STATE, "no solve pending");
+  (void)release_held_if_idle(c);
   const spvo_ctx::SolvePending pend = c->solve_pending;
   const int n = pend.n;
   if (n > 0 && (!xyz || !inliers)) return fail(c, SPVO_ERR_INVALID, "bad argument");   // (the solve stays pending)

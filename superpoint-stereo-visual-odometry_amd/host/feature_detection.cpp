@@ -728,7 +728,7 @@ void SuperPointFeatureFrontEnd::completeHostCopies() {
 
 void SuperPointFeatureFrontEnd::prefetchStereoImagePair(const cv::Mat &img_l, const cv::Mat &img_r) {
   completeHostCopies();   // a pair whose bulk copies are still owed (no solve followed it): before its mirrors can be reused
-  if (!engine_loaded_ || prefetch_q_.size() >= 3) return;
+  if (!engine_loaded_ || prefetch_q_.size() >= 4) return;
   if (img_l.type() != CV_8UC1 || img_r.type() != CV_8UC1 || img_l.rows != img_r.rows || img_l.cols != img_r.cols || (size_t)img_l.step != (size_t)img_r.step) return;
   for (const auto &q : prefetch_q_)   // already announced
     if (q.host && q.l == img_l.data && q.r == img_r.data && q.rows == img_l.rows && q.cols == img_l.cols) return;
@@ -741,6 +741,7 @@ void SuperPointFeatureFrontEnd::prefetchStereoImagePair(const cv::Mat &img_l, co
   pf.l = img_l.data; pf.r = img_r.data;
   pf.rows = img_l.rows; pf.cols = img_l.cols; pf.stride = (size_t)img_l.step; pf.host = true;
   prefetch_q_.push_back(pf);
+  notePrefetchDepth();
 }
 
 void SuperPointFeatureFrontEnd::addStereoImagePairDevice(const void *d_img_l, const void *d_img_r, int rows, int cols, size_t stride,
@@ -791,7 +792,7 @@ void SuperPointFeatureFrontEnd::addStereoImagePairDevice(const void *d_img_l, co
 
 void SuperPointFeatureFrontEnd::prefetchStereoImagePairDevice(const void *d_img_l, const void *d_img_r, int rows, int cols, size_t stride) {
   completeHostCopies();   // a pair whose bulk copies are still owed (no solve followed it): before its mirrors can be reused
-  if (!engine_loaded_ || prefetch_q_.size() >= 3) return;
+  if (!engine_loaded_ || prefetch_q_.size() >= 4) return;
   for (const auto &q : prefetch_q_)   // already announced
     if (!q.host && q.l == d_img_l && q.r == d_img_r && q.rows == rows && q.cols == cols && q.stride == stride) return;
   Prefetch pf;
@@ -803,6 +804,14 @@ void SuperPointFeatureFrontEnd::prefetchStereoImagePairDevice(const void *d_img_
   pf.l = d_img_l; pf.r = d_img_r;
   pf.rows = rows; pf.cols = cols; pf.stride = stride;
   prefetch_q_.push_back(pf);
+  notePrefetchDepth();
+}
+
+// A caller that announces pairs FOUR ahead gets trunk pairing (spvo_set_trunk_pairing: two pairs per set of network launches).  From
+// then on the library holds a pair whose network would only queue, until its successor arrives; with fewer pairs ahead each held
+// pair would leave the network stream idle, so shallower look-ahead never switches it on.
+void SuperPointFeatureFrontEnd::notePrefetchDepth() {
+  if (!trunk_pairing_ && prefetch_q_.size() >= 4 && ctx_ && spvo_set_trunk_pairing(ctx_, 1) == SPVO_OK) trunk_pairing_ = true;
 }
 
 void SuperPointFeatureFrontEnd::drainPrefetch() {
@@ -814,10 +823,10 @@ void SuperPointFeatureFrontEnd::drainPrefetch() {
 }
 
 void SuperPointFeatureFrontEnd::pickSlots(int *slot_l, int *slot_r) {
-  // device slots: a ring of 5 pairs -- the previous and the current pair plus up to three pairs in flight
+  // device slots: a ring of 8 pairs -- the previous and the current pair plus up to four pairs announced ahead (and margin)
   *slot_l = 2 * next_pair_;
   *slot_r = *slot_l + 1;
-  next_pair_ = (next_pair_ + 1) % 5;
+  next_pair_ = (next_pair_ + 1) % 8;
 }
 
 void SuperPointFeatureFrontEnd::pushFeatures(const spvo_features *f[2], const cv::Mat *images[2], const int slots[2], bool host_descriptors) {

@@ -414,8 +414,10 @@ private:
     size_t stride = 0;
     bool host = false;
   };
-  std::deque<Prefetch> prefetch_q_;   // pairs announced ahead (at most 2), oldest first
-  int next_pair_ = 0;                 // ring of 5 slot pairs: previous, current and three in flight
+  std::deque<Prefetch> prefetch_q_;   // pairs announced ahead (at most 4), oldest first
+  int next_pair_ = 0;                 // ring of 8 slot pairs: previous, current, up to four announced ahead
+  bool trunk_pairing_ = false;        // four pairs ahead have been seen: spvo_set_trunk_pairing is on
+  void notePrefetchDepth();
   void drainPrefetch();
   void pickSlots(int *slot_l, int *slot_r);
   void pushFeatures(const spvo_features *f[2], const cv::Mat *images[2], const int slots[2], bool host_descriptors);

@@ -62,7 +62,7 @@ OBS_DTYPE = np.dtype([("X", np.float32, 3), ("uv", np.float32, 2), ("cam", np.in
 SYMBOLS = [
     "spvo_default_config", "spvo_create", "spvo_destroy", "spvo_last_error", "spvo_load_weights", "spvo_engine_precision", "spvo_set_fp32_split",
     "spvo_preprocess", "spvo_forward", "spvo_debug_tensor", "spvo_heatmap", "spvo_nms",
-    "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_detect_dev_submit", "spvo_detect_wait", "spvo_detect_submit", "spvo_detect_collect", "spvo_detect_collect_mirrors", "spvo_detect_mirrors_wait", "spvo_match", "spvo_match_slots", "spvo_set_prematch", "spvo_set_match_fp8",
+    "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_detect_dev_submit", "spvo_detect_wait", "spvo_set_trunk_pairing", "spvo_detect_submit", "spvo_detect_collect", "spvo_detect_collect_mirrors", "spvo_detect_mirrors_wait", "spvo_match", "spvo_match_slots", "spvo_set_prematch", "spvo_set_match_fp8",
     "spvo_match_hamming", "spvo_orb_detect", "spvo_orb_tables", "spvo_triangulate", "spvo_pnp_ransac", "spvo_pnp_refine", "spvo_solve_stereo_odometry", "spvo_solve_submit", "spvo_solve_wait", "spvo_stream", "spvo_synchronize",
     "spvo_profile_enable", "spvo_profile_reset", "spvo_profile_only", "spvo_profile_count", "spvo_profile_get", "spvo_profile_stage_kernel",
     "spvo_set_tuning", "spvo_get_tuning", "spvo_clear_tuning",
@@ -295,6 +295,9 @@ class Context:
     def detect_dev_submit(self, d_img_l: int, d_img_r: int, rows: int, cols: int, stride: int, slot_l: int, slot_r: int):
         """Enqueue a detector pass (at most two may be in flight); complete them oldest-first with detect_wait."""
         self._check(self.lib.spvo_detect_dev_submit(self.h, C.c_void_p(d_img_l), C.c_void_p(d_img_r), rows, cols, stride, slot_l, slot_r))
+
+    def set_trunk_pairing(self, on: bool):
+        self._check(self.lib.spvo_set_trunk_pairing(self.h, int(on)))
 
     def detect_submit(self, img_l: np.ndarray, img_r: np.ndarray, slot_l: int, slot_r: int, extras: int = 3):
         """Asynchronous detector pass on HOST images (spvo_detect_submit); complete with detect_collect."""

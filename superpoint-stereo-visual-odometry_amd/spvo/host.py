@@ -165,14 +165,14 @@ class FrontEnd:
     def prefetch_device(self, d_l: int, d_r: int, rows: int, cols: int, stride: int):
         self.lib.spvo_host_prefetch_dev(self.h, C.c_void_p(d_l), C.c_void_p(d_r), rows, cols, stride)
 
-    def step_device(self, d_l, d_r, rows, cols, stride, P_l, P_r, next_pair=None, next2_pair=None, deferred_solve=False, next3_pair=None):
+    def step_device(self, d_l, d_r, rows, cols, stride, P_l, P_r, next_pair=None, next2_pair=None, deferred_solve=False, next3_pair=None, next4_pair=None):
         """One stereoCallback on a device-resident pair; `next_pair` / `next2_pair` = (d_l, d_r) of the
         following two frames, handed over early: their detector runs while this frame is matched and
         solved, and the post-processing of one overlaps with the network of the other.
         deferred_solve: this frame's solve is only handed over (solveStereoOdometrySubmit); its pose is what the NEXT call -- or
         finish_solve() -- returns, so the solver never keeps the host from handing the next images over."""
         self.add_stereo_image_pair_device(d_l, d_r, rows, cols, stride, P_l, P_r)
-        for nxt in (next_pair, next2_pair, next3_pair):
+        for nxt in (next_pair, next2_pair, next3_pair, next4_pair):
             if nxt is not None:
                 self.prefetch_device(nxt[0], nxt[1], rows, cols, stride)   # no-op if already announced
         return self._match_and_solve(deferred_solve)
@@ -205,13 +205,13 @@ class FrontEnd:
     def free_image(self, handle: int):
         self.lib.spvo_host_free_image(C.c_void_p(handle))
 
-    def step_host(self, mat_l: int, mat_r: int, P_l, P_r, next_pair=None, next2_pair=None, deferred_solve=False, next3_pair=None):
+    def step_host(self, mat_l: int, mat_r: int, P_l, P_r, next_pair=None, next2_pair=None, deferred_solve=False, next3_pair=None, next4_pair=None):
         """One stereoCallback through addStereoImagePair(cv::Mat&, ...) (node.cpp:175) on HOST images; `next_pair` /
         `next2_pair` = (mat_l, mat_r) handles of the following frames, announced with prefetchStereoImagePair."""
         Pl = np.ascontiguousarray(P_l, np.float64)
         Pr = np.ascontiguousarray(P_r, np.float64)
         self.lib.spvo_host_add_stereo_pair_mat(self.h, C.c_void_p(mat_l), C.c_void_p(mat_r), _p(Pl), _p(Pr))
-        for nxt in (next_pair, next2_pair, next3_pair):
+        for nxt in (next_pair, next2_pair, next3_pair, next4_pair):
             if nxt is not None:
                 self.lib.spvo_host_prefetch_mat(self.h, C.c_void_p(nxt[0]), C.c_void_p(nxt[1]))
         return self._match_and_solve(deferred_solve)

@@ -110,16 +110,16 @@ def test_prefetch_pipeline_is_transparent(models_dir, sequence):
     dev = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
     rows, cols = frames[0][0].shape
     out = {}
-    for depth in (0, 1, 2):
+    for depth in (0, 1, 2, 3, 4):     # 4: the front end switches trunk pairing on (two pairs per set of network launches)
         fe = host.FrontEnd(models_dir, prefix="sp_squeeze")
         res = []
         for k, (dl, dr) in enumerate(dev):
-            ahead = [(dev[k + d][0].data_ptr(), dev[k + d][1].data_ptr()) if d <= depth and k + d < len(dev) else None for d in (1, 2)]
-            r = fe.step_device(dl.data_ptr(), dr.data_ptr(), rows, cols, dl.stride(0), P_l, P_r, ahead[0], ahead[1])
+            ahead = [(dev[k + d][0].data_ptr(), dev[k + d][1].data_ptr()) if d <= depth and k + d < len(dev) else None for d in (1, 2, 3, 4)]
+            r = fe.step_device(dl.data_ptr(), dr.data_ptr(), rows, cols, dl.stride(0), P_l, P_r, ahead[0], ahead[1], next3_pair=ahead[2], next4_pair=ahead[3])
             res.append((r, fe.keypoints(host.CURR_LEFT), fe.map_of_indices(0), fe.map_of_indices(1) if k else None, fe.inliers("pnp")))
         out[depth] = res
         fe.close()
-    for depth in (1, 2):
+    for depth in (1, 2, 3, 4):
         for a, b in zip(out[0], out[depth]):
             assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4])
             if a[3] is not None:
@@ -141,7 +141,7 @@ def test_the_reference_entry_point_with_host_images_equals_the_device_entry(mode
     out = {}
     if arrangement.startswith("heads_on"):
         tuning(heads_on_net=1 if arrangement == "heads_on_net" else 0)
-    for mode in ("device", 0, 1, 2):
+    for mode in ("device", 0, 1, 2, 4):
         fe = host.FrontEnd(models_dir, prefix="sp_squeeze")
         if arrangement == "eager_copies":
             fe.set_deferred_copies(False)
@@ -160,8 +160,8 @@ def test_the_reference_entry_point_with_host_images_equals_the_device_entry(mode
         else:
             mats = [(fe.make_image(L), fe.make_image(R)) for L, R in frames]
             for k in range(len(frames)):
-                ahead = [mats[k + d] if d <= mode and k + d < len(mats) else None for d in (1, 2)]
-                r = fe.step_host(mats[k][0], mats[k][1], P_l, P_r, ahead[0], ahead[1])
+                ahead = [mats[k + d] if d <= mode and k + d < len(mats) else None for d in (1, 2, 3, 4)]
+                r = fe.step_host(mats[k][0], mats[k][1], P_l, P_r, ahead[0], ahead[1], next3_pair=ahead[2], next4_pair=ahead[3])
                 res.append((r, fe.keypoints(host.CURR_LEFT), fe.descriptors(host.CURR_RIGHT), fe.map_of_indices(0), fe.map_of_indices(1) if k else None,
                             fe.inliers("pnp"), fe.image(host.CURR_LEFT)))
             for m in mats:
@@ -169,7 +169,7 @@ def test_the_reference_entry_point_with_host_images_equals_the_device_entry(mode
         out[mode] = res
         fe.close()
     from oracle import frontend as ofe
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 4):
         for k, (a, b) in enumerate(zip(out["device"], out[mode])):
             for i in (1, 2, 3, 5):
                 assert np.array_equal(a[i], b[i]), (mode, k, i)

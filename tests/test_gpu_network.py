@@ -416,6 +416,11 @@ def test_forward_is_deterministic_and_batch_independent(ctx_vgg, sample_images):
     assert np.array_equal(d1, d2) and np.array_equal(s1, s2)          # bit-identical reruns
     d3, s3 = ctx_vgg.forward(x[1:2])
     assert np.array_equal(d3[0], d1[1]) and np.array_equal(s3[0], s1[1])  # image 1 alone == image 1 in the pair
+    # four images per launch (two stereo pairs: spvo_set_trunk_pairing) -- each image as it comes out of a two-image pass
+    x4 = np.concatenate([x, _input(sample_images, 360, 1176, 3)[1:3]])
+    d4, s4 = ctx_vgg.forward(x4)
+    d5, s5 = ctx_vgg.forward(x4[2:4])
+    assert np.array_equal(d4[:2], d1) and np.array_equal(s4[:2], s1) and np.array_equal(d4[2:], d5) and np.array_equal(s4[2:], s5)
 
 
 def test_forward_linearity_of_first_layers(ctx_vgg, vgg_plan):

@@ -172,7 +172,7 @@ def test_prematch_is_transparent(ctx_squeeze, stereo_pair):
 
 
 def test_submissions_in_flight(ctx_squeeze, stereo_pair):
-    """spvo_detect_dev_submit x3 / spvo_detect_wait x3 through the C ABI: same keypoints and matches as the
+    """spvo_detect_dev_submit x6 / spvo_detect_wait x6 through the C ABI: same keypoints and matches as the
     synchronous calls, oldest-first completion, and the documented SPVO_ERR_STATE refusals."""
     import torch
     from spvo import capi
@@ -189,9 +189,10 @@ def test_submissions_in_flight(ctx_squeeze, stereo_pair):
     assert e.value.code == -4
     ctx_squeeze.detect_dev_submit(*args(0), 4, 5)
     ctx_squeeze.detect_dev_submit(*args(1), 6, 7)
-    ctx_squeeze.detect_dev_submit(*args(0), 8, 9)                             # a third one: the limit
+    for k, sl in enumerate(((8, 9), (10, 11), (12, 13), (14, 15))):          # ... up to six: the limit
+        ctx_squeeze.detect_dev_submit(*args(k & 1), *sl)
     with pytest.raises(capi.SpvoError) as e:
-        ctx_squeeze.detect_dev_submit(*args(1), 0, 1)                         # a fourth one
+        ctx_squeeze.detect_dev_submit(*args(1), 0, 1)                         # a seventh one
     assert e.value.code == -4
     with pytest.raises(capi.SpvoError) as e:
         ctx_squeeze.forward(np.zeros((1, 1, 360, 1176), np.float32))          # would overwrite the activations
@@ -202,6 +203,9 @@ def test_submissions_in_flight(ctx_squeeze, stereo_pair):
     assert e.value.code == -4
     b = ctx_squeeze.detect_wait(P_l, P_r)
     c3 = ctx_squeeze.detect_wait(P_l, P_r)
+    rest = [ctx_squeeze.detect_wait(P_l, P_r) for _ in range(3)]
+    for k, r in enumerate(rest):
+        assert np.array_equal(r["xy_l"], ref[(k + 1) & 1]["xy_l"]) and np.array_equal(r["xy_r"], ref[(k + 1) & 1]["xy_r"])
     assert np.array_equal(c3["xy_l"], ref[0]["xy_l"]) and np.array_equal(c3["xy_r"], ref[0]["xy_r"])
     for got, want in ((a, ref[0]), (b, ref[1])):
         assert np.array_equal(got["xy_l"], want["xy_l"]) and np.array_equal(got["xy_r"], want["xy_r"])
@@ -211,6 +215,49 @@ def test_submissions_in_flight(ctx_squeeze, stereo_pair):
     for (gi, gd), (ri, rd) in zip(got_m, ref_m):
         assert np.array_equal(gi, ri) and np.array_equal(gd, rd)
     ctx_squeeze.set_prematch(False, "KNN", False, 0.8)
+
+
+@pytest.mark.parametrize("graph", ["vgg", "squeeze"])
+def test_trunk_pairing_does_not_change_results(graph, vgg_weights_path, squeeze_weights_path, stereo_pair):
+    """spvo_set_trunk_pairing: a submission whose network would only queue is held until the next one arrives and the two pairs
+    run through every layer in ONE launch (four images).  Keypoints, descriptors (through the pinned mirrors) and both matches of
+    every pair are bit-identical to the unpaired run -- the kernels are the ones selected for two images and every tile is
+    computed the same way wherever it runs -- whether a pair ends up grouped (2 + 2), alone because nothing was queued, or alone
+    because it was waited for while held."""
+    from spvo import capi
+    frames, _, P_l, P_r = stereo_pair
+    seq = [frames[k & 1] for k in range(7)]
+    path = vgg_weights_path if graph == "vgg" else squeeze_weights_path
+    out = {}
+    for pairing in (False, True):
+        ctx = capi.Context()
+        ctx.load_weights(path)
+        ctx.set_prematch(True, "KNN", False, 0.8)
+        ctx.set_trunk_pairing(pairing)
+        res = []
+
+        def collect(slot_l):
+            v = ctx.detect_collect_mirrors(P_l, P_r)
+            n = len(v["xy_l"])
+            m = [ctx.match_slots(slot_l, slot_l + 1, n)] + ([ctx.match_slots(slot_l, (slot_l - 2) % 16, n)] if res else [])
+            res.append(({k: np.array(v[k]) for k in ("xy_l", "xy_r", "desc_l", "desc_r", "resized_l")}, [(i.copy(), d.copy()) for i, d in m]))
+        # pairs 0..3 handed over in one go (pair 0 runs alone, 1 is held, 2 joins it, 3 is held and launched by its own wait), then one
+        # at a time behind a collect (each finds its predecessor's trunk queued or done), then a last one
+        for k in range(4):
+            ctx.detect_submit(seq[k][0], seq[k][1], 2 * k, 2 * k + 1)
+        collect(0); collect(2)
+        ctx.detect_submit(seq[4][0], seq[4][1], 8, 9)
+        collect(4)
+        ctx.detect_submit(seq[5][0], seq[5][1], 10, 11)
+        ctx.detect_submit(seq[6][0], seq[6][1], 12, 13)
+        collect(6); collect(8); collect(10); collect(12)
+        out[pairing] = res
+        ctx.close()
+    for k, ((fa, ma), (fb, mb)) in enumerate(zip(out[False], out[True])):
+        for key in fa:
+            assert np.array_equal(fa[key], fb[key]), (k, key)
+        for (ia, da), (ib, db) in zip(ma, mb):
+            assert np.array_equal(ia, ib) and np.array_equal(da, db), k
 
 
 def test_keypoint_cap_2048(vgg_weights_path, vgg_plan, stereo_pair):
