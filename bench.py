@@ -554,6 +554,8 @@ def main():
             if pmc and os.path.exists(pmc) and (NET_H, NET_W) == (360, 1176):
                 pj = json.load(open(pmc))
                 traffic = (pj.get(kfam) or ({} if kfam in ("conv_wino4_kernel", "conv_wino2_kernel") else pj)).get("traffic_bytes_per_launch")
+                if traffic:   # the counter pass ran launches of TWO images; with trunk pairing the timed launches average more (per image the same)
+                    traffic = int(traffic * dom["flops"] / (2.0 * 2 * NET_H * NET_W * 64 * 64 * 9))
             peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "FP32" and not args.fp32_split else F16_MFMA_PEAK_TFLOPS
             kdesc = {"conv_wino4_kernel": "<POOL,RELU,TAG=1> (Winograd F(4x4,3x3), fp32)", "conv_wino2_kernel": "<POOL,RELU,TAG=1> (Winograd F(2x2,3x3), fp32)",
                      "conv_wino_kernel": "<POOL,RELU,TAG=1> (Winograd F(2x2,3x3), fp32)", "conv_wino64_kernel": "<POOL,RELU,TAG=1> (Winograd F(2x2,3x3), filters in registers, fp32)"}.get(kfam, "<KS=3,...,POOL,RELU>")

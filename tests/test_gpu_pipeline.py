@@ -217,8 +217,8 @@ def test_submissions_in_flight(ctx_squeeze, stereo_pair):
     ctx_squeeze.set_prematch(False, "KNN", False, 0.8)
 
 
-@pytest.mark.parametrize("graph", ["vgg", "squeeze"])
-def test_trunk_pairing_does_not_change_results(graph, vgg_weights_path, squeeze_weights_path, stereo_pair):
+@pytest.mark.parametrize("graph", ["vgg", "squeeze", "vgg_fp16"])
+def test_trunk_pairing_does_not_change_results(graph, vgg_weights_path, squeeze_weights_path, stereo_pair, vgg_plan, tmp_path):
     """spvo_set_trunk_pairing: a submission whose network would only queue is held until the next one arrives and the two pairs
     run through every layer in ONE launch (four images).  Keypoints, descriptors (through the pinned mirrors) and both matches of
     every pair are bit-identical to the unpaired run -- the kernels are the ones selected for two images and every tile is
@@ -228,6 +228,13 @@ def test_trunk_pairing_does_not_change_results(graph, vgg_weights_path, squeeze_
     frames, _, P_l, P_r = stereo_pair
     seq = [frames[k & 1] for k in range(7)]
     path = vgg_weights_path if graph == "vgg" else squeeze_weights_path
+    if graph == "vgg_fp16":          # the FP16 engine's kernels take the batch from the launch as well
+        import copy
+        from spvo import weights
+        p16 = copy.copy(vgg_plan)
+        p16.precision = "FP16"
+        path = str(tmp_path / weights.engine_name("superpoint_pretrained", 2, 360, 1176, "FP16"))
+        weights.save(p16, path)
     out = {}
     for pairing in (False, True):
         ctx = capi.Context()
