@@ -682,7 +682,9 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
         const long min_tiles = tuning("winograd_min_tiles", 3 * c->num_cus / 4);
         const bool eligible = wino_on && op.ks == 3 && !bn && !add && (op.cin % WinoTile::CK) == 0 && (!pool || ((ti.H % 2) == 0 && (ti.W % 2) == 0));
         op.wino = eligible && wtiles >= min_tiles;
-        if (eligible && !op.wino && tuning("wino_narrow", 1) && (op.cout % 32) == 0 && 2 * wtiles >= min_tiles) op.wino = op.wino_narrow = true;
+        // (narrow form: a workgroup's chain of items is as long as the layer's K whatever the number of workgroups, so half a chip of them
+        // still beats the direct kernel -- conv4a / conv4b at 30 x 98 cells, the reference's 240 x 784 engines: 128 workgroups, 45 -> 30 us)
+        if (eligible && !op.wino && tuning("wino_narrow", 1) && (op.cout % 32) == 0 && 3 * wtiles >= min_tiles) op.wino = op.wino_narrow = true;
       }
       const bool dynamic_tiles = tuning("wino_dynamic", 1) != 0;
       if (op.wino && !op.wino_narrow && (op.cin % Wino4Tile::CK) == 0 && (((ti.H | ti.W) & 1) == 0 || !pool) && tuning("wino4", 1)) {

@@ -113,7 +113,7 @@ _W4, _W2, _DIR = "conv_wino4_kernel", "conv_wino2_kernel", "conv_mfma_kernel"
 DEFAULT_KERNELS = {
     (360, 1176, 2): [_W4, _W4, _W4, _W4, _W4, _W2, _W2, _W4],
     (376, 1240, 2): [_W4, _W4, _W4, _W4, _W4, _W2, _W2, _W4],
-    (240, 784, 2): [_W4, _W4, _W4, _W2, _W2, _DIR, _DIR, _W2],      # 30 x 98 cells: conv4a / conv4b have 64 F(2x2) tiles for 256 CUs and stay direct
+    (240, 784, 2): [_W4, _W4, _W4, _W2, _W2, _W2, _W2, _W2],        # 30 x 98 cells: conv4a / conv4b run the narrow F(2x2) form on 128 workgroups
     (192, 640, 1): None,
 }
 

@@ -1,3 +1,5 @@
+"""Forward pass of the FP32 VGG engine on two and on four images per launch (spvo_set_trunk_pairing runs two stereo pairs through every
+layer in one launch): per-layer HIP-event times.  python tools/fwd_batch.py"""
 import os, sys, tempfile
 ROOT = "/root/repo"
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "superpoint-stereo-visual-odometry_amd"))
@@ -7,8 +9,7 @@ plan = weights.vgg_plan()
 p = os.path.join(tempfile.mkdtemp(), "w.spvw"); weights.save(plan, p)
 for B in (2, 4):
     capi.clear_tuning()
-    capi.set_tuning("buffer_images", B)
-    # keep the kernel selection of the 2-image engine: thresholds scale with the batch
+    # the same engine (kernels selected for two images at load) run on two and on four images per launch: what trunk pairing saves
     ctx = capi.Context(net_height=360, net_width=1176, max_batch=2); ctx.load_weights(p)
     fams = [ctx.stage_kernel(f"conv:{i}")[0] for i in range(1, 9)]
     x = np.random.RandomState(0).rand(B, 1, 360, 1176).astype(np.float32)
