@@ -300,6 +300,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
     for (int st = 0; st < 10; ++st) xf_step(smem + T::RAW_OFF, smem + T::V_OFF, st);
   }
 
+#ifdef WINO_STAMPS   // diagnostic build (tools/wino_bench.hip): shader-clock cycles per wave waiting for LDS-DMA / stores at an item's start (o[7]: of
+                     // which in a tile's SECOND item, the first wait behind an epilogue's stores), at the barrier, in the matrix stream, in epilogues
+  unsigned long long st_dma = 0, st_bar = 0, st_mfma = 0, st_epi = 0, st_items = 0, st_post = 0;
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+  int st_c = 0;
+#endif
   int k = 0;                    // items done: selects the buffers and the transforming half
   bool drained = true;          // the LDS-DMA this item needs has been waited for already
   constexpr unsigned OOB = 0xFFFFFFFFu;
@@ -317,11 +323,22 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
       constexpr bool FIRST = decltype(first_tag)::value;   // the tile's first chunk: C = 0 in every accumulator's (only) instruction
       // waves 0-3 transform the next item's input in even items, waves 4-7 in odd ones (wave-uniform: a scalar branch per step)
       const bool XF = __builtin_amdgcn_readfirstlane((wave >> 2) == (k & 1) ? 1 : 0) != 0;
+#ifdef WINO_STAMPS
+      const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
       if (!drained) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       drained = false;
+#ifdef WINO_STAMPS
+      const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
       if (publish && tid == 0) *sched_slot = dyn_fetch < band_hi(band) ? dyn_fetch : n_tiles;
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (publish) nxt_id = __builtin_amdgcn_readfirstlane(*sched_slot);
+#ifdef WINO_STAMPS
+      const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+      st_dma += ts1 - ts0; st_bar += ts2 - ts1;
+      if (st_c == 1) st_post += ts1 - ts0;
+#endif
       const float *ub = smem + T::U_OFF + (k & 1) * T::U_FLOATS;
       const float *vb = smem + T::V_OFF + (k & 1) * T::V_FLOATS;
       float *u_next = smem + T::U_OFF + ((k + 1) & 1) * T::U_FLOATS;
@@ -362,11 +379,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
       advance(cu);
       advance(cr);
       ++k;
+#ifdef WINO_STAMPS
+      st_mfma += __builtin_amdgcn_s_memtime() - ts2;
+      ++st_items; ++st_c;
+#endif
     };
+#ifdef WINO_STAMPS
+    st_c = 0;
+#endif
     item(std::true_type{}, false);
     for (int c = 1; c < a.n_chunks; ++c) item(std::false_type{}, a.sched != nullptr && c == 1);
 
     // everything in flight for the next item has landed before this tile's stores queue up behind it
+#ifdef WINO_STAMPS
+    const unsigned long long te0 = __builtin_amdgcn_s_memtime();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     drained = true;
 
@@ -435,10 +462,20 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef WINO_STAMPS
+    st_epi += __builtin_amdgcn_s_memtime() - te0;
+#endif
     tile_id = nxt_id;
     if (tile_id < n_tiles) cur = decode(tile_id);
   }
   all_done();   // the last workgroup out resets the counters for the next launch
+#ifdef WINO_STAMPS
+  if (lane == 0 && a.stamps) {
+    unsigned long long *o = a.stamps + 8 * (blockIdx.x * 8 + wave);
+    o[0] = st_dma; o[1] = st_bar; o[2] = st_mfma; o[3] = st_epi; o[4] = st_items;
+    o[5] = __builtin_amdgcn_s_memtime() - st_t0; o[6] = __builtin_amdgcn_s_memrealtime() - st_r0; o[7] = st_post;
+  }
+#endif
 }
 
 }  // namespace spvo

@@ -135,6 +135,12 @@ int main(int argc, char **argv) {
     int n = 0;
     for (int i = 0; i < nw; ++i) { if (!st[8 * i + 4]) continue; ++n; for (int k = 0; k < 7; ++k) sum[k] += (double)st[8 * i + k]; }
     const double items = sum[4] / n, clk = sum[5] / sum[6] * 100e6;
+    {
+      double post = 0;
+      for (int i = 0; i < nw; ++i) if (st[8 * i + 4]) post += (double)st[8 * i + 7];
+      printf("  of the waits at an item's start, in a tile's second item (behind the epilogue's stores): %.0f cycles per wave = %.0f per tile (%.1f tiles per wave)\n",
+             post / n, post / n / std::max(1.0, sum[4] / n / a.n_chunks), sum[4] / n / a.n_chunks);
+    }
     printf("  per wave: %.1f items, %.0f cycles total at %.2f GHz (100 MHz reference); per item: LDS-DMA wait %.0f, barrier %.0f, matrix stream %.0f, epilogue %.0f (per item share), other %.0f cycles\n",
            items, sum[5] / n, clk / 1e9, sum[0] / n / items, sum[1] / n / items, sum[2] / n / items, sum[3] / n / items,
            (sum[5] - sum[0] - sum[1] - sum[2] - sum[3]) / n / items);
