@@ -728,7 +728,7 @@ void SuperPointFeatureFrontEnd::completeHostCopies() {
 
 void SuperPointFeatureFrontEnd::prefetchStereoImagePair(const cv::Mat &img_l, const cv::Mat &img_r) {
   completeHostCopies();   // a pair whose bulk copies are still owed (no solve followed it): before its mirrors can be reused
-  if (!engine_loaded_ || prefetch_q_.size() >= 4) return;
+  if (!engine_loaded_ || prefetch_q_.size() >= 5) return;
   if (img_l.type() != CV_8UC1 || img_r.type() != CV_8UC1 || img_l.rows != img_r.rows || img_l.cols != img_r.cols || (size_t)img_l.step != (size_t)img_r.step) return;
   for (const auto &q : prefetch_q_)   // already announced
     if (q.host && q.l == img_l.data && q.r == img_r.data && q.rows == img_l.rows && q.cols == img_l.cols) return;
@@ -792,7 +792,7 @@ void SuperPointFeatureFrontEnd::addStereoImagePairDevice(const void *d_img_l, co
 
 void SuperPointFeatureFrontEnd::prefetchStereoImagePairDevice(const void *d_img_l, const void *d_img_r, int rows, int cols, size_t stride) {
   completeHostCopies();   // a pair whose bulk copies are still owed (no solve followed it): before its mirrors can be reused
-  if (!engine_loaded_ || prefetch_q_.size() >= 4) return;
+  if (!engine_loaded_ || prefetch_q_.size() >= 5) return;
   for (const auto &q : prefetch_q_)   // already announced
     if (!q.host && q.l == d_img_l && q.r == d_img_r && q.rows == rows && q.cols == cols && q.stride == stride) return;
   Prefetch pf;

@@ -414,7 +414,7 @@ private:
     size_t stride = 0;
     bool host = false;
   };
-  std::deque<Prefetch> prefetch_q_;   // pairs announced ahead (at most 4), oldest first
+  std::deque<Prefetch> prefetch_q_;   // pairs announced and not collected yet (at most 5: the one about to be collected + four ahead), oldest first
   int next_pair_ = 0;                 // ring of 8 slot pairs: previous, current, up to four announced ahead
   bool trunk_pairing_ = false;        // four pairs ahead have been seen: spvo_set_trunk_pairing is on
   void notePrefetchDepth();

@@ -171,10 +171,14 @@ class FrontEnd:
         solved, and the post-processing of one overlaps with the network of the other.
         deferred_solve: this frame's solve is only handed over (solveStereoOdometrySubmit); its pose is what the NEXT call -- or
         finish_solve() -- returns, so the solver never keeps the host from handing the next images over."""
-        self.add_stereo_image_pair_device(d_l, d_r, rows, cols, stride, P_l, P_r)
+        # the pairs ahead are announced BEFORE this pair is collected (a node learns of them when they arrive, not when it has time):
+        # their submissions -- and, with trunk pairing, the launch of a completed group -- do not wait for this pair's tail
+        if next_pair is not None:
+            self.prefetch_device(d_l, d_r, rows, cols, stride)            # (this pair first, if it has not been announced: the queue is in call order)
         for nxt in (next_pair, next2_pair, next3_pair, next4_pair):
             if nxt is not None:
                 self.prefetch_device(nxt[0], nxt[1], rows, cols, stride)   # no-op if already announced
+        self.add_stereo_image_pair_device(d_l, d_r, rows, cols, stride, P_l, P_r)
         return self._match_and_solve(deferred_solve)
 
     def _match_and_solve(self, deferred_solve):
@@ -210,10 +214,12 @@ class FrontEnd:
         `next2_pair` = (mat_l, mat_r) handles of the following frames, announced with prefetchStereoImagePair."""
         Pl = np.ascontiguousarray(P_l, np.float64)
         Pr = np.ascontiguousarray(P_r, np.float64)
-        self.lib.spvo_host_add_stereo_pair_mat(self.h, C.c_void_p(mat_l), C.c_void_p(mat_r), _p(Pl), _p(Pr))
-        for nxt in (next_pair, next2_pair, next3_pair, next4_pair):
+        if next_pair is not None:
+            self.lib.spvo_host_prefetch_mat(self.h, C.c_void_p(mat_l), C.c_void_p(mat_r))
+        for nxt in (next_pair, next2_pair, next3_pair, next4_pair):     # (announced before this pair is collected: see step_device)
             if nxt is not None:
                 self.lib.spvo_host_prefetch_mat(self.h, C.c_void_p(nxt[0]), C.c_void_p(nxt[1]))
+        self.lib.spvo_host_add_stereo_pair_mat(self.h, C.c_void_p(mat_l), C.c_void_p(mat_r), _p(Pl), _p(Pr))
         return self._match_and_solve(deferred_solve)
 
     def match_descriptors(self, match_type):
