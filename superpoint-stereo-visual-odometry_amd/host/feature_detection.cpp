@@ -807,11 +807,12 @@ void SuperPointFeatureFrontEnd::prefetchStereoImagePairDevice(const void *d_img_
   notePrefetchDepth();
 }
 
-// A caller that announces pairs FOUR ahead gets trunk pairing (spvo_set_trunk_pairing: two pairs per set of network launches).  From
-// then on the library holds a pair whose network would only queue, until its successor arrives; with fewer pairs ahead each held
-// pair would leave the network stream idle, so shallower look-ahead never switches it on.
+// A caller that keeps FIVE pairs announced -- the one it is about to collect and four ahead of it, each announced when it arrives --
+// gets trunk pairing (spvo_set_trunk_pairing: two pairs per set of network launches).  From then on the library holds a pair whose
+// network would only queue, until its successor arrives; with fewer pairs ahead each held pair would leave the network stream idle,
+// so shallower look-ahead never switches it on.
 void SuperPointFeatureFrontEnd::notePrefetchDepth() {
-  if (!trunk_pairing_ && prefetch_q_.size() >= 4 && ctx_ && spvo_set_trunk_pairing(ctx_, 1) == SPVO_OK) trunk_pairing_ = true;
+  if (!trunk_pairing_ && prefetch_q_.size() >= 5 && ctx_ && spvo_set_trunk_pairing(ctx_, 1) == SPVO_OK) trunk_pairing_ = true;
 }
 
 void SuperPointFeatureFrontEnd::drainPrefetch() {

@@ -416,7 +416,7 @@ private:
   };
   std::deque<Prefetch> prefetch_q_;   // pairs announced and not collected yet (at most 5: the one about to be collected + four ahead), oldest first
   int next_pair_ = 0;                 // ring of 8 slot pairs: previous, current, up to four announced ahead
-  bool trunk_pairing_ = false;        // four pairs ahead have been seen: spvo_set_trunk_pairing is on
+  bool trunk_pairing_ = false;        // five announced pairs (the current one + four ahead) have been seen: spvo_set_trunk_pairing is on
   void notePrefetchDepth();
   void drainPrefetch();
   void pickSlots(int *slot_l, int *slot_r);
