@@ -594,10 +594,14 @@ def main():
             if "roofline" in out and headline and (NET_H, NET_W) == (360, 1176) and os.path.exists(pl_path):
                 cs = json.load(open(pl_path)).get("conv_stack", {})
                 if cs.get("traffic_MB"):
-                    out["roofline"]["conv_stack_traffic"] = int(cs["traffic_MB"] * 1e6)
-                    out["roofline"]["conv_stack_algorithmic_bytes"] = int(cs["algorithmic_MB"] * 1e6)
-                    out["roofline"]["conv_stack_hbm_gbps"] = round(cs["traffic_MB"] * 1e6 / (conv_ms * 1e-3) / 1e9, 1)
-                    out["roofline"]["conv_stack_frac_of_hbm_peak"] = round(cs["traffic_MB"] * 1e6 / (conv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+                    # the counter pass ran two images per launch; the stage pass above averages launches of two and of four (trunk pairing):
+                    # bytes per launch scale with the images, i.e. with the mean algorithmic flops per launch (143.61 GFLOP at two images)
+                    pairs_per_launch = conv_fl / 143.61e9
+                    out["roofline"]["conv_stack_traffic"] = int(cs["traffic_MB"] * 1e6 * pairs_per_launch)
+                    out["roofline"]["conv_stack_algorithmic_bytes"] = int(cs["algorithmic_MB"] * 1e6 * pairs_per_launch)
+                    out["roofline"]["conv_stack_pairs_per_launch"] = round(pairs_per_launch, 3)
+                    out["roofline"]["conv_stack_hbm_gbps"] = round(cs["traffic_MB"] * 1e6 * pairs_per_launch / (conv_ms * 1e-3) / 1e9, 1)
+                    out["roofline"]["conv_stack_frac_of_hbm_peak"] = round(cs["traffic_MB"] * 1e6 * pairs_per_launch / (conv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
                     out["roofline"]["conv_stack_traffic_source"] = "profiles/r04_pmc_layers.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over a forward-only loop, per layer; counters include Infinity-Cache hits) / conv_stack_sum of this run"
         if world == 1 and headline and not args.no_extras and "split" in legs:
             try:
