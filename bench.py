@@ -595,8 +595,8 @@ def main():
                 cs = json.load(open(pl_path)).get("conv_stack", {})
                 if cs.get("traffic_MB"):
                     # the counter pass ran two images per launch; the stage pass above averages launches of two and of four (trunk pairing):
-                    # bytes per launch scale with the images, i.e. with the mean algorithmic flops per launch (143.61 GFLOP at two images)
-                    pairs_per_launch = conv_fl / 143.61e9
+                    # bytes per launch scale with the images, i.e. with the mean algorithmic flops per launch (141.44 GFLOP at two images without the heads)
+                    pairs_per_launch = conv_fl / 141.44e9   # (the stages named conv:<i>: the fused heads launch is a stage of its own)
                     out["roofline"]["conv_stack_traffic"] = int(cs["traffic_MB"] * 1e6 * pairs_per_launch)
                     out["roofline"]["conv_stack_algorithmic_bytes"] = int(cs["algorithmic_MB"] * 1e6 * pairs_per_launch)
                     out["roofline"]["conv_stack_pairs_per_launch"] = round(pairs_per_launch, 3)
