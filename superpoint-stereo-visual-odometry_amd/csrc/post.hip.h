@@ -467,12 +467,16 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(int surv_cap, NmsPair np)
   }
 }
 
-__global__ __launch_bounds__(256) void nms_write_kernel(int H, int max_kp, int surv_cap, NmsPair np, int *zero_next) {
+// host_counters: the set's pinned mirror of the counter blocks ([image][NMS_COUNTER_INTS]); this kernel is the last one that changes a
+// block (entry 2, the keypoint count), so its first workgroup writes the mirror itself: no 48-byte copy behind the chain
+__global__ __launch_bounds__(256) void nms_write_kernel(int H, int max_kp, int surv_cap, NmsPair np, int *zero_next, int *host_counters) {
   const NmsBuffers nb = np.b[blockIdx.y];
   // hand the next submission a clean counter block (it belongs to the other parity)
   if (zero_next && blockIdx.x == 0 && threadIdx.x < NMS_COUNTER_INTS) zero_next[blockIdx.y * NMS_COUNTER_INTS + threadIdx.x] = 0;
   const int n = min(nb.counters[1], surv_cap);
   if (blockIdx.x == 0 && threadIdx.x == 0) nb.counters[2] = min(n, max_kp);
+  if (host_counters && blockIdx.x == 0 && threadIdx.x < NMS_COUNTER_INTS)
+    host_counters[blockIdx.y * NMS_COUNTER_INTS + threadIdx.x] = threadIdx.x == 2 ? min(n, max_kp) : nb.counters[threadIdx.x];
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const int rank = nb.rank[i];
     nb.rank[i] = 0;

@@ -117,8 +117,8 @@ NmsPair nms_pair(spvo_ctx *c, int set) {
   return p;
 }
 
-// `n_launch` round launches + collect + rank + write for `nimg` images, then the counters travel
-// to the host in one copy.  Launch 0 of a batch never exits early.
+// `n_launch` round launches + collect + rank + write for `nimg` images; the last kernel writes the counters
+// into the set's pinned mirror.  Launch 0 of a batch never exits early.
 int launch_nms_rounds(spvo_ctx *c, int nimg, const NmsPair &np, int set, int n_launch, int *zero_next, bool redo = false) {
   hipStream_t st = c->post;
   const float *heat = c->d_heat_r[set % RING];
@@ -131,9 +131,8 @@ int launch_nms_rounds(spvo_ctx *c, int nimg, const NmsPair &np, int set, int n_l
   }
   if (redo) hipLaunchKernelGGL(nms_collect_kernel, dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, c->cfg.border_remove, c->surv_cap, np);
   hipLaunchKernelGGL(nms_rank_kernel, dim3(128, nimg), dim3(256), 0, st, c->surv_cap, np);
-  hipLaunchKernelGGL(nms_write_kernel, dim3(32, nimg), dim3(256), 0, st, c->H, c->cfg.max_keypoints, c->surv_cap, np, zero_next);
+  hipLaunchKernelGGL(nms_write_kernel, dim3(32, nimg), dim3(256), 0, st, c->H, c->cfg.max_keypoints, c->surv_cap, np, zero_next, c->h_counters_r[set % RING]);
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemcpyAsync(c->h_counters_r[set % RING], np.b[0].counters, (size_t)nimg * NMS_COUNTER_INTS * sizeof(int), hipMemcpyDeviceToHost, st));
   return SPVO_OK;
 }
 
