@@ -574,6 +574,10 @@ def main():
                                "algorithmic_frac_of_peak": round(algorithmic / peak, 4)}
             if kfactor == 0.25:   # the same launch priced as round 2's kernel was: what fraction of the peak an F(2x2,3x3) kernel would need to be this fast
                 out["roofline"]["frac_if_counted_as_f2x2"] = round(algorithmic * (4.0 / 9.0) / peak, 4)
+        # NMS: round launches are enqueued with the submission; a heat map whose decisions are still open after them is continued by
+        # the HOST (spvo_detect_wait), synchronously behind everything queued on the tail stream -- in the pipelined loop that is a
+        # stall of more than a trunk.  Counted over the timed blocks: 0 is what the default of four launches is chosen for.
+        out["nms_host_continuations"] = {"timed_region": int(prof.get("nms_redo", {}).get("calls", 0)), "timed_steps": args.steps * len(block_times)}
         any_stage = next((v for k, v in prof_all.items() if k.startswith("conv:") and v["calls"]), None)
         if any_stage:   # stage breakdown: the separate pass with every stage timed (it runs ~7 % slower than the timed region)
             calls = any_stage["calls"]

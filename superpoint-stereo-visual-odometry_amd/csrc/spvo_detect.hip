@@ -102,6 +102,7 @@ int launch_preprocess(spvo_ctx *c, const uint8_t *d_src0, const uint8_t *d_src1,
 
 // ---------------------------------------------------------------- NMS pipeline
 constexpr int NMS_INNER = 4;
+constexpr int NMS_INNER_LAST = 16;
 constexpr int NMS_GRID = 128;
 
 // NMS counter blocks rotate through RING sets with the submissions: the last NMS kernel of one
@@ -124,10 +125,17 @@ int launch_nms_rounds(spvo_ctx *c, int nimg, const NmsPair &np, int set, int n_l
   const float *heat = c->d_heat_r[set % RING];
   const int collect = redo ? 0 : 1;   // first batch: survivors are listed as they are decided; continuation: the list was cleared, re-collect everything
   for (int l = 0; l < n_launch; ++l) {
-    if (c->cfg.dist_thresh == 4)
-      hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 4>), dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, 4, np, l, c->cfg.border_remove, c->surv_cap, collect);
-    else
-      hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 0>), dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, c->cfg.dist_thresh, np, l, c->cfg.border_remove, c->surv_cap, collect);
+    // the LAST launch of a submission's first batch iterates longer in the kernel (decided threads cost nothing, a workgroup without
+    // undecided candidates leaves at once): whatever chain of decisions is still open gets NMS_INNER_LAST more rounds before the
+    // host would have to continue (nms_settle)
+    const bool longer = !redo && l == n_launch - 1 && n_launch > 1;
+    if (c->cfg.dist_thresh == 4) {
+      if (longer) hipLaunchKernelGGL((nms_round_kernel<NMS_INNER_LAST, 4>), dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, 4, np, l, c->cfg.border_remove, c->surv_cap, collect);
+      else hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 4>), dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, 4, np, l, c->cfg.border_remove, c->surv_cap, collect);
+    } else {
+      if (longer) hipLaunchKernelGGL((nms_round_kernel<NMS_INNER_LAST, 0>), dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, c->cfg.dist_thresh, np, l, c->cfg.border_remove, c->surv_cap, collect);
+      else hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 0>), dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, c->cfg.dist_thresh, np, l, c->cfg.border_remove, c->surv_cap, collect);
+    }
   }
   if (redo) hipLaunchKernelGGL(nms_collect_kernel, dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, c->cfg.border_remove, c->surv_cap, np);
   hipLaunchKernelGGL(nms_rank_kernel, dim3(128, nimg), dim3(256), 0, st, c->surv_cap, np);
@@ -141,11 +149,10 @@ int launch_nms_rounds(spvo_ctx *c, int nimg, const NmsPair &np, int set, int n_l
 // simply take more batches -- every launch decides at least the best undecided candidate, so the
 // loop terminates.  nms_enqueue only submits; nms_settle runs after the caller's sync and returns
 // 1 if it had to redo work (the caller then re-runs what depends on the keypoints).
-constexpr int NMS_FIRST = 3;
 
 // more rounds for the (rare) submissions whose first batch left candidates undecided
 int nms_settle(spvo_ctx *c, int nimg, const NmsPair &np, int set, bool *redone) {
-  int last = NMS_FIRST;
+  int last = c->nms_first;
   *redone = false;
   const int *hc = c->h_counters_r[set % RING];
   for (;;) {
@@ -171,7 +178,7 @@ int run_nms(spvo_ctx *c, int nimg) {
   for (int i = 0; i < nimg; ++i) HIP_TRY(c, hipMemsetAsync(np.b[i].counters, 0, NMS_COUNTER_INTS * sizeof(int), c->stream));
   dim3 grid((c->W + 63) / 64, (c->H + 3) / 4, nimg);
   hipLaunchKernelGGL(nms_threshold_kernel, grid, dim3(256), 0, c->stream, c->d_heat, c->H, c->W, c->cfg.conf_thresh, np);
-  int rc = launch_nms_rounds(c, nimg, np, RING, NMS_FIRST, nullptr);
+  int rc = launch_nms_rounds(c, nimg, np, RING, c->nms_first, nullptr);
   if (rc) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   bool redone;
@@ -460,17 +467,29 @@ static int launch_group(spvo_ctx *c) {
   // from timing events at both ends of the trunk (printed every 200 launches)
   static const bool trunk_timing = tuning("trunk_timing", 0) != 0;
   constexpr int TT = 16;   // ring of timing events: deeper than the launches that can be in flight
-  static hipEvent_t tt_b[TT], tt_e[TT];
+  static hipEvent_t tt_b[TT], tt_e[TT], tt_tb[TT], tt_te[TT];   // trunk begin / end (network stream), tail begin / end (tail stream)
+  static double tt_tail = 0, tt_lag = 0;
+  static int tt_np[TT];
   static long tt_n = 0;
   static double tt_busy = 0, tt_idle = 0, tt_pairs = 0;
+  static const int trace_lo = tuning("trunk_timing", 0);   // > 1: one line per launch from that launch on (80 of them), with the host clock
   if (trunk_timing) {
     const double tnow = diag_now_us();
-    if (c->last_launch_ring >= 0 && hipEventQuery(c->ev_net[c->last_launch_ring]) == hipSuccess) ++g_diag.late;   // the trunk before this one is done already: the stream is idle
+    const bool found_idle = c->last_launch_ring >= 0 && hipEventQuery(c->ev_net[c->last_launch_ring]) == hipSuccess;
+    if (found_idle) ++g_diag.late;   // the trunk before this one is done already: the stream is idle
+    if (trace_lo > 1 && g_diag.launches + 1 >= trace_lo && g_diag.launches + 1 < trace_lo + 80)
+      std::fprintf(stderr, "T %.0f launch %ld: %d pairs, stream %s, submissions so far %u, in flight %zu\n", tnow, g_diag.launches + 1, n, found_idle ? "IDLE" : "busy", c->submit_count, c->pendq.size());
+    if (++g_diag.launches > 100 && g_diag.iv_printed < 16 && (found_idle || g_diag.iv_printed % 4 != 0)) {   // an idle launch and the three behind it
+      std::fprintf(stderr, "[spvo]   launch %ld (%d pairs, stream %s): %.0f us since the previous launch, of which the host waited %.0f us for features, %.0f us for matches, %.0f us for the solver; %zu submissions in flight\n",
+                   g_diag.launches, n, found_idle ? "IDLE" : "busy", tnow - g_diag.t_last_submit, g_diag.iv_tail, g_diag.iv_match, g_diag.iv_solve, c->pendq.size());
+      ++g_diag.iv_printed;
+    }
+    g_diag.iv_tail = g_diag.iv_match = g_diag.iv_solve = 0;
     g_diag.depth_sum += (int)c->pendq.size();
     if (g_diag.t_last_submit > 0) g_diag.max_interval = std::max(g_diag.max_interval, tnow - g_diag.t_last_submit);
     g_diag.t_last_submit = tnow;
     if (tt_n == 0)
-      for (int r = 0; r < TT; ++r) { (void)hipEventCreate(&tt_b[r]); (void)hipEventCreate(&tt_e[r]); }
+      for (int r = 0; r < TT; ++r) { (void)hipEventCreate(&tt_b[r]); (void)hipEventCreate(&tt_e[r]); (void)hipEventCreate(&tt_tb[r]); (void)hipEventCreate(&tt_te[r]); }
     if (tt_n >= TT) {   // the launches before those that may be in flight are complete: ring slots (n-8) and (n-9)
       const int r2 = (int)((tt_n - 8) % TT), r3 = (int)((tt_n - 9) % TT);
       float busy = 0, idle = 0;
@@ -481,9 +500,28 @@ static int launch_group(spvo_ctx *c) {
         tt_late += idle > 0.05f ? 1 : 0;
         tt_max = std::max(tt_max, idle);
       }
+      static std::string tt_pat;
+      tt_pat += (char)('0' + tt_np[r2]);
+      if (idle > 0.05f) tt_pat += idle > 0.3f ? 'I' : 'i';
+      if (tt_n % 200 == 0) { std::fprintf(stderr, "[spvo]   pairs per launch (i / I: the stream stood idle > 50 / > 300 us in front of it): %s\n", tt_pat.c_str()); tt_pat.clear(); }
+      if (trace_lo > 1) {   // device-side times of launch (tt_n - 8), relative to the first trace line's moment
+        static hipEvent_t base = nullptr;
+        static double base_host = 0;
+        if (!base && g_diag.launches >= trace_lo - 8) { (void)hipEventCreate(&base); (void)hipEventRecord(base, c->stream_t); (void)hipEventSynchronize(base); base_host = diag_now_us(); }
+        float b0 = 0, e0 = 0, tb0 = 0, te0 = 0;
+        if (base && g_diag.launches - 8 >= trace_lo && g_diag.launches - 8 < trace_lo + 80 && hipEventElapsedTime(&b0, base, tt_b[r2]) == hipSuccess &&
+            hipEventElapsedTime(&e0, base, tt_e[r2]) == hipSuccess && hipEventElapsedTime(&tb0, base, tt_tb[r2]) == hipSuccess && hipEventElapsedTime(&te0, base, tt_te[r2]) == hipSuccess)
+          std::fprintf(stderr, "G launch %ld (%d pairs): trunk %.0f .. %.0f, tail %.0f .. %.0f (host clock)\n", g_diag.launches - 8, tt_np[r2], base_host + b0 * 1e3, base_host + e0 * 1e3,
+                       base_host + tb0 * 1e3, base_host + te0 * 1e3);
+      }
+      float tail = 0, lag = 0;
+      if (hipEventElapsedTime(&tail, tt_tb[r2], tt_te[r2]) == hipSuccess && hipEventElapsedTime(&lag, tt_e[r2], tt_te[r2]) == hipSuccess) { tt_tail += tail; tt_lag += lag; }
       if (tt_n % 200 == 0) {
         std::fprintf(stderr, "[spvo] trunk timing over 200 launches (%.0f pairs): network stream busy %.1f us, idle %.1f us per launch (%d gaps above 50 us, longest %.0f us)\n",
                      tt_pairs, tt_busy * 1e3 / 200, tt_idle * 1e3 / 200, tt_late, tt_max * 1e3);
+        std::fprintf(stderr, "[spvo]   NMS continuations driven by the host so far: %lld\n", c->stages[stage_id(c, "nms_redo")].calls);
+        std::fprintf(stderr, "[spvo]   tail stream: %.1f us per launch from its first kernel to its last, which ends %.1f us behind the trunk\n", tt_tail * 1e3 / 200, tt_lag * 1e3 / 200);
+        tt_tail = tt_lag = 0;
         std::fprintf(stderr, "[spvo]   host: longest interval between launches %.0f us, longest wait for a tail %.0f us, for a solve %.0f us, matches not served from the cache %d; "
                              "launches that found the network stream idle %d, mean submissions in flight at launch %.2f\n",
                      g_diag.max_interval, g_diag.max_tail_wait, g_diag.max_solve_wait, g_diag.match_miss, g_diag.late, g_diag.depth_sum / 200.0);
@@ -492,6 +530,7 @@ static int launch_group(spvo_ctx *c) {
       }
     }
     tt_pairs += n;
+    tt_np[tt_n % TT] = n;
     (void)hipEventRecord(tt_b[tt_n % TT], c->stream);
   }
   hipEvent_t det_e0 = nullptr;
@@ -533,10 +572,11 @@ static int launch_group(spvo_ctx *c) {
     rc = run_ops(c, batch, c->head_start, c->ops.size(), c->stream);
     if (rc) { c->cur_ring = 0; return rc; }
   }
-  if (trunk_timing) { (void)hipEventRecord(tt_e[tt_n % TT], c->stream); ++tt_n; }
+  if (trunk_timing) (void)hipEventRecord(tt_e[tt_n % TT], c->stream);
   for (int m = 0; m < n; ++m) HIP_TRY(c, hipEventRecord(c->ev_net[mem[m]->ring], c->stream));
   c->last_launch_ring = mem[n - 1]->ring;
   HIP_TRY(c, hipStreamWaitEvent(c->stream_t, c->ev_net[tring], 0));
+  if (trunk_timing) (void)hipEventRecord(tt_tb[tt_n % TT], c->stream_t);
   c->post = c->stream_t;
   if (!heads_on_net) rc = run_ops(c, batch, c->head_start, c->ops.size(), c->stream_t);   // heads: on the tail stream, reading this group's ring buffers
   c->cur_ring = 0;
@@ -557,7 +597,7 @@ static int launch_group(spvo_ctx *c) {
     }
     {
       ScopedStage sn(c, stage_id(c, "nms"));
-      rc = launch_nms_rounds(c, 2, np, ring, NMS_FIRST, c->d_counters_all + (size_t)(((ring + 1) % RING) * 2) * NMS_COUNTER_INTS);
+      rc = launch_nms_rounds(c, 2, np, ring, c->nms_first, c->d_counters_all + (size_t)(((ring + 1) % RING) * 2) * NMS_COUNTER_INTS);
     }
     if (!rc) rc = enqueue_sample(c, slots, np, ring, tring, pd.img0);
     // Keypoints, counts and descriptors are final here: spvo_detect_wait / _collect waits for THIS point (ev_feat); the matches enqueued
@@ -583,6 +623,7 @@ static int launch_group(spvo_ctx *c) {
     }
     pd.launched = true;
   }
+  if (trunk_timing) { (void)hipEventRecord(tt_te[tt_n % TT], c->stream_t); ++tt_n; }
   c->post = c->stream;
   return rc;
 }
@@ -626,6 +667,7 @@ static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_feature
     const double tw0 = diag_now_us();
     rc = wait_event(c->ev_feat[pd.ring]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");
     g_diag.max_tail_wait = std::max(g_diag.max_tail_wait, diag_now_us() - tw0);
+    g_diag.iv_tail += diag_now_us() - tw0;
   }
   if (!rc && pd.early_res) rc = wait_event(c->ev_res[pd.ring]) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "event synchronisation failed");   // the resized images: they left under the network (copy kernel on the tail stream)
   bool redone = false;

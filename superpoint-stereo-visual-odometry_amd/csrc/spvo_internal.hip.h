@@ -172,6 +172,7 @@ struct spvo_ctx {
   float *d_heat_base = nullptr;
   NmsImage nms[2];
   int surv_cap = 0;
+  int nms_first = 4;             // round launches enqueued with a submission (4 in-kernel rounds each, 16 in the last); a heat map that needs more is continued by the host (nms_settle)
   int *h_counters = nullptr;     // pinned [2][NMS_COUNTER_INTS]
   uint8_t *d_img[2] = {nullptr, nullptr};
   size_t img_cap = 0;
@@ -267,7 +268,8 @@ struct spvo_ctx {
 namespace spvo_int {
 
 // SPVO_TRUNK_TIMING diagnostics: where the host spends its time between two submissions (maxima over the 200 submissions of a report)
-struct HostDiag { double t_last_submit = 0, max_interval = 0, max_tail_wait = 0, max_solve_wait = 0; int match_miss = 0, late = 0, depth_sum = 0; };
+struct HostDiag { double t_last_submit = 0, max_interval = 0, max_tail_wait = 0, max_solve_wait = 0; int match_miss = 0, late = 0, depth_sum = 0;
+                  double iv_tail = 0, iv_match = 0, iv_solve = 0; int iv_printed = 0; long launches = 0; };   // iv_*: host time inside the three waits since the previous launch
 extern HostDiag g_diag;
 inline double diag_now_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
 

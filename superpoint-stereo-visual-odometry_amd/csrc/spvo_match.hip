@@ -241,7 +241,9 @@ int spvo_match_slots(spvo_ctx *c, int slot_a, int slot_b, int selector, int cros
       if (mc.valid && mc.slot_a == slot_a && mc.slot_b == slot_b && mc.gen_a == a.gen && mc.gen_b == b.gen && mc.selector == selector &&
           mc.cross == (cross_check ? 1 : 0) && mc.ratio == ratio) {
         // the matches were enqueued behind the submission's features; spvo_detect_wait returned when the features were final
+        const double tw0 = diag_now_us();
         HIP_TRY(c, wait_event(c->ev_tail[set]));
+        g_diag.iv_match += diag_now_us() - tw0;
         if (a.n > 0) unpack_match(mc.h_out, a.n, train_idx, distance);
         return SPVO_OK;
       }

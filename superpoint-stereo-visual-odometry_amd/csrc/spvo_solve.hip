@@ -269,6 +269,7 @@ int spvo_solve_wait(spvo_ctx *c, spvo_solve_output *out, float *xyz, int32_t *in
     const double tw0 = diag_now_us();
     HIP_TRY(c, wait_event(c->ev_solve));
     g_diag.max_solve_wait = std::max(g_diag.max_solve_wait, diag_now_us() - tw0);
+    g_diag.iv_solve += diag_now_us() - tw0;
   }
   std::memcpy(xyz, c->h_solve_o, (size_t)3 * n * 4);
   if (n < 4) { prior_pose(); return SPVO_OK; }                                      // no model possible: prior is kept

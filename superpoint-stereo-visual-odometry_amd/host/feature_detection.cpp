@@ -58,7 +58,7 @@ Transform Transform::operator*(const Transform &o) const {
 // ------------------------------------------------------------------------- logging
 void FeatureFrontEnd::logError(const std::string &msg) {
   last_error_ = msg;
-  static const bool quiet = std::getenv("SPVO_QUIET") != nullptr;   // benchmarks with untrained weights trip the gating message every frame
+  static const bool quiet = std::getenv("SPVO_QUIET") != nullptr && std::strcmp(std::getenv("SPVO_QUIET"), "0") != 0;   // benchmarks with untrained weights trip the gating message every frame
   if (!quiet) std::fprintf(stderr, "[ERROR] %s\n", msg.c_str());  // ROS_ERROR stand-in
 }
 void FeatureFrontEnd::logInfo(const std::string &msg) const {
