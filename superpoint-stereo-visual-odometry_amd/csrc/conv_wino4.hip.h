@@ -58,14 +58,19 @@
 
 namespace spvo {
 
-struct Wino4Tile {
-  static constexpr int CK = 4, TH = 16, TW = 32, LW = TW + 8, LH = TH + 2, NT = 32;
-  static constexpr int IN_FLOATS = CK * LH * LW;        // 2880: raw halo tile of one chunk, row = x0-4 .. x0+35
+// TB = tile blocks of 16 Winograd tiles (2 x 8 tiles = 8 rows x 32 columns of output) a workgroup covers: 2 = the 8-wave form (16 x 32
+// outputs), 1 = the 4-wave form (8 x 32 outputs, one wave per SIMD) for layers whose 16 x 32 tiles would leave half the CUs without a
+// workgroup (conv4a / conv4b: 45 x 147 = 15 tiles per image and 64 output channels).  Same filter slabs, same per-wave work.
+template <int TB>
+struct Wino4TileT {
+  static constexpr int CK = 4, TH = 8 * TB, TW = 32, LW = TW + 8, LH = TH + 2, NT = 16 * TB, NTH = 256 * TB;
+  static constexpr int IN_FLOATS = CK * LH * LW;        // 2880 (1600): raw halo tile of one chunk, row = x0-4 .. x0+35
   static constexpr int U_FLOATS = 36 * CK * CO_TILE;    // 9216: one filter slab
-  static constexpr int V_FLOATS = 10 * 2 * 64 * 4;      // 5120: transformed input of one chunk, per column half 18 positions in 5 pieces of four
+  static constexpr int V_FLOATS = 10 * TB * 64 * 4;     // 5120 (2560): transformed input of one chunk, per column half 18 positions in 5 pieces of four
   static constexpr int RAW_OFF = 0, U_OFF = 2 * IN_FLOATS, V_OFF = U_OFF + 2 * U_FLOATS;
-  static constexpr int LDS_BYTES = (V_OFF + 2 * V_FLOATS) * 4 + 16;   // 137 744 (+ the slot through which a tile's successor is published)
+  static constexpr int LDS_BYTES = (V_OFF + 2 * V_FLOATS) * 4 + 16;   // 137 744 (107 024) (+ the slot through which a tile's successor is published)
 };
+using Wino4Tile = Wino4TileT<2>;
 
 // OIHW weights + bias -> slabs [co_tile][chunk][p'/4 9][cq 4][lane 64][4] of U = G g G^T (double), then [co_tiles * 64] biases.
 // p' = 18 (j / 3) + 3 i + j % 3 (the kernel's instruction order); lane = 16 (ci & 3) + (co & 15): the A operand of
@@ -127,13 +132,13 @@ __device__ __forceinline__ void wino4_out4(const wino4_f32x2 m0, const wino4_f32
   y[3] = __builtin_elementwise_fma(wino4_f32x2{8.f, 8.f}, d, b) + m5;
 }
 
-template <bool POOL, bool RELU, int TAG = 0>
-__global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
-  using T = Wino4Tile;
-  constexpr int CK = T::CK, LW = T::LW, LH = T::LH, LW4 = LW / 4;
-  constexpr int IN_V4 = T::IN_FLOATS / 4;        // 720 16-byte pieces per raw tile
+template <bool POOL, bool RELU, int TAG = 0, int TB = 2>
+__global__ __launch_bounds__(256 * TB, TB) void conv_wino4_kernel(const ConvArgs a) {
+  using T = Wino4TileT<TB>;
+  constexpr int CK = T::CK, LW = T::LW, LH = T::LH, LW4 = LW / 4, NTH = T::NTH;
+  constexpr int IN_V4 = T::IN_FLOATS / 4;        // 720 (400) 16-byte pieces per raw tile
   constexpr int U_V4 = T::U_FLOATS / 4;          // 2304 per filter slab
-  constexpr int NIT_U = (U_V4 + 511) / 512;      // 5 (the last one: threads 0..255)
+  constexpr int NIT_U = (U_V4 + NTH - 1) / NTH;  // 5, the last one by threads 0..255 (9, all full)
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef float f32x4v __attribute__((ext_vector_type(4)));
 
@@ -165,7 +170,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
   };
 
   // ---- staging plans (wave-uniform 64-bit base + 32-bit lane offset).  Raw tile: pieces 0..511 by every thread, pieces
-  // 512..719 by threads 256.. (waves 4-7, which carry one filter piece less: six LDS-DMA instructions per wave and item everywhere)
+  // 512..719 by threads 256.. (waves 4-7, which carry one filter piece less: six LDS-DMA instructions per wave and item everywhere);
+  // 4-wave form: pieces 0..255 by every thread, 256..399 by threads 0..143
   auto raw_piece_off = [&](int idx) {
     idx = min(idx, IN_V4 - 1);
     const int ci = idx / (LH * LW4);
@@ -174,28 +180,30 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
     const int q = rem - r * LW4;
     return 4u * (unsigned)(ci * (int)in_plane + r * a.in_wp + q * 4);
   };
-  const unsigned roff0 = raw_piece_off(tid), roff1 = raw_piece_off(512 + (tid - 256));
-  const bool raw2 = tid >= 256 && 512 + (tid - 256) < IN_V4;
+  constexpr int R0 = NTH - 256;   // first thread that carries a second raw piece
+  const unsigned roff0 = raw_piece_off(tid), roff1 = raw_piece_off(NTH + (tid - R0));
+  const bool raw2 = tid >= R0 && NTH + (tid - R0) < IN_V4;
   auto issue_raw = [&](const TileRef &t, int chunk, float *buf) {
     const char *inb = reinterpret_cast<const char *>(t.in_base + (size_t)chunk * CK * in_plane);
     glds16(reinterpret_cast<const float *>(inb + roff0), buf + (wave * 64) * 4);
-    if (raw2) glds16(reinterpret_cast<const float *>(inb + roff1), buf + (512 + (wave - 4) * 64) * 4);
+    if (raw2) glds16(reinterpret_cast<const float *>(inb + roff1), buf + (NTH + (wave - R0 / 64) * 64) * 4);
   };
   const unsigned uoff = 16u * (unsigned)tid;
   auto issue_u = [&](const TileRef &t, int chunk, float *buf) {
     const char *wb = reinterpret_cast<const char *>(t.w_base + (size_t)chunk * T::U_FLOATS);
 #pragma unroll
     for (int it = 0; it < NIT_U; ++it)
-      if (it < NIT_U - 1 || tid < U_V4 - (NIT_U - 1) * 512) glds16(reinterpret_cast<const float *>(wb + (uoff + 8192u * it)), buf + (it * 512 + wave * 64) * 4);
+      if (it < NIT_U - 1 || tid < U_V4 - (NIT_U - 1) * NTH) glds16(reinterpret_cast<const float *>(wb + (uoff + 16u * NTH * it)), buf + (it * NTH + wave * 64) * 4);
   };
 
   // ---- input transform: two threads per patch.  u = tid & 255: input channel = u >> 6 (= wave & 3), tile = lane & 31 (tile row
   // tile >> 3, tile column tile & 7), half h = lane >> 5 (patch rows 3 h .. 3 h + 2 in the row pass, columns 3 h .. in the column pass)
-  const int x_ci = wave & 3, x_tile = lane & 31, x_h = lane >> 5;
+  // (4-wave form: 64 patches = two waves; input channel = 2 (wave & 1) + bit 4 of the lane, tile = lane & 15)
+  const int x_ci = TB == 2 ? (wave & 3) : 2 * (wave & 1) + ((lane >> 4) & 1), x_tile = TB == 2 ? (lane & 31) : (lane & 15), x_h = lane >> 5;
   const int x_trow = x_tile >> 3, x_tcol = x_tile & 7;
   const int raw_off = x_ci * (LH * LW) + (4 * x_trow + 3 * x_h) * LW + 4 * x_tcol + 3;   // LDS row 0 = output row y0 - 1, LDS column 4 = output column x0
   // V[h][q / 4][tb][lane = 16 ci + (tile & 15)][q & 3], q = 3 i + c: this thread writes (h, i = 0..5, c = 0..2)
-  const int v_off = x_h * 2560 + (x_tile >> 4) * 256 + (16 * x_ci + (x_tile & 15)) * 4;   // + (q >> 2) * 512 + (q & 3) floats
+  const int v_off = x_h * (1280 * TB) + (x_tile >> 4) * 256 + (16 * x_ci + (x_tile & 15)) * 4;   // + (q >> 2) * 256 TB + (q & 3) floats
   // Steps of one patch half: 0..2 read row r (b32, b128, b32 = columns 3, 4 .. 7, 8 of the halo row), 3..5 row pass of row r,
   // 6 the exchange, 7..9 column pass of column c + stores
   float xr[3][6];        // rows after the row pass; xr[r][0..2] stay, xr[r][3..5] are swapped with the partner's
@@ -228,12 +236,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
       float o[6];
       wino4_in6(xr[0][c], xr[1][c], xr[2][c], xr[0][c + 3], xr[1][c + 3], xr[2][c + 3], o);
 #pragma unroll
-      for (int i = 0; i < 6; ++i) vb[v_off + ((3 * i + c) >> 2) * 512 + ((3 * i + c) & 3)] = o[i];
+      for (int i = 0; i < 6; ++i) vb[v_off + ((3 * i + c) >> 2) * (256 * TB) + ((3 * i + c) & 3)] = o[i];
     }
   };
 
   const int a_lane = cq * 64 + lane;   // 16-byte pieces in a filter slab: + (pos / 4) * 256
-  const int b_lane = tb * 64 + lane;   // 16-byte pieces in a V buffer:     + (5 h + q / 4) * 128
+  const int b_lane = tb * 64 + lane;   // 16-byte pieces in a V buffer:     + (5 h + q / 4) * 64 TB
 
   // ---- tile assignment: conv_wino2.hip.h's XCD-banded counters (a.sched), or blockIdx.x + k gridDim.x
   const int band = blockIdx.x & 7;
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
   Cursor cr = cu;
   advance(cr);                                   // item 2
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  if (wave < 4) {                                // item 0's transform has nothing to hide behind
+  if (wave < 2 * TB) {                           // item 0's transform has nothing to hide behind
 #pragma unroll
     for (int st = 0; st < 10; ++st) xf_step(smem + T::RAW_OFF, smem + T::V_OFF, st);
   }
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
     auto item = [&](auto first_tag, bool publish) {
       constexpr bool FIRST = decltype(first_tag)::value;   // the tile's first chunk: C = 0 in every accumulator's (only) instruction
       // waves 0-3 transform the next item's input in even items, waves 4-7 in odd ones (wave-uniform: a scalar branch per step)
-      const bool XF = __builtin_amdgcn_readfirstlane((wave >> 2) == (k & 1) ? 1 : 0) != 0;
+      const bool XF = __builtin_amdgcn_readfirstlane((wave >> TB) == (k & 1) ? 1 : 0) != 0;
 #ifdef WINO_STAMPS
       const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
       for (int p = 0; p < ((WINO4_ABL & 8) ? 36 : LEAD); ++p) {
         if ((WINO4_ABL & 8) && k > 0) break;
         if ((p & 3) == 0) av[p >> 2] = ub4[(p >> 2) * 256];
-        if (p == 0 || b_piece(p) != b_piece(p - 1)) bv[b_piece(p)] = vb4[b_piece(p) * 128];
+        if (p == 0 || b_piece(p) != b_piece(p - 1)) bv[b_piece(p)] = vb4[b_piece(p) * (64 * TB)];
       }
 #pragma unroll
       for (int p = 0; p < 36; ++p) {
@@ -370,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
         const int q = p + LEAD;
         if (!(WINO4_ABL & 8) && q < 36) {
           if ((q & 3) == 0) av[q >> 2] = ub4[(q >> 2) * 256];
-          if (b_piece(q) != b_piece(q - 1)) bv[b_piece(q)] = vb4[b_piece(q) * 128];
+          if (b_piece(q) != b_piece(q - 1)) bv[b_piece(q)] = vb4[b_piece(q) * (64 * TB)];
         }
         if (!(WINO4_ABL & 1) && XF && p >= WINO4_XF_START && p < WINO4_XF_START + 10 * WINO4_XF_STRIDE && (p - WINO4_XF_START) % WINO4_XF_STRIDE == 0)
           xf_step(raw_next, v_next, (p - WINO4_XF_START) / WINO4_XF_STRIDE);   // ten steps, one per XF_STRIDE slots
@@ -471,7 +479,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
   all_done();   // the last workgroup out resets the counters for the next launch
 #ifdef WINO_STAMPS
   if (lane == 0 && a.stamps) {
-    unsigned long long *o = a.stamps + 8 * (blockIdx.x * 8 + wave);
+    unsigned long long *o = a.stamps + 8 * (blockIdx.x * (4 * TB) + wave);
     o[0] = st_dma; o[1] = st_bar; o[2] = st_mfma; o[3] = st_epi; o[4] = st_items;
     o[5] = __builtin_amdgcn_s_memtime() - st_t0; o[6] = __builtin_amdgcn_s_memrealtime() - st_r0; o[7] = st_post;
   }

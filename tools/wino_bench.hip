@@ -13,9 +13,12 @@
 #include "conv_wino64.hip.h"
 #include "../superpoint-stereo-visual-odometry_amd/csrc/conv_wino4.hip.h"
 #if defined(WINO4)   // F(4x4, 3x3): -DWINO4
-#define KERNEL(P, R, T, O) conv_wino4_kernel<P, R, T>
+#ifndef WINO4_TB
+#define WINO4_TB 2   // -DWINO4_TB=1: the 4-wave form (8 x 32 outputs per workgroup)
+#endif
+#define KERNEL(P, R, T, O) conv_wino4_kernel<P, R, T, WINO4_TB>
 #define PACK pack_conv_weights_wino4
-#define THREADS 512
+#define THREADS (256 * WINO4_TB)
 #define COT 64
 #elif defined(WINO64)   // filters resident in registers (cin = 64): -DWINO64
 #define KERNEL(P, R, T, O) conv_wino64_kernel<P, R, T>
@@ -46,7 +49,7 @@ using namespace spvo;
 #define EXEC (4.0 / 9.0)
 #endif
 #if defined(WINO4)
-#define LDSB Wino4Tile::LDS_BYTES
+#define LDSB Wino4TileT<WINO4_TB>::LDS_BYTES
 #elif defined(WINO64)
 #define LDSB Wino64Tile::LDS_BYTES
 #elif defined(WINO2)
@@ -86,7 +89,7 @@ int main(int argc, char **argv) {
   a.in_hp = ihp; a.in_wp = iwp; a.in_ctot = cin; a.in_coff = 0; a.out_hp = ohp; a.out_wp = owp; a.out_ctot = cout; a.out_coff = 0;
 #if defined(WINO4)
   if ((cin & 3) || (pool && ((H | W) & 1))) { printf("WINO4: cin must be a multiple of 4, H and W even when pooling\n"); return 1; }
-  a.cout = cout; a.n_chunks = cin / Wino4Tile::CK; a.tiles_x = (W + Wino4Tile::TW - 1) / Wino4Tile::TW; a.tiles_y = (H + Wino4Tile::TH - 1) / Wino4Tile::TH;
+  a.cout = cout; a.n_chunks = cin / Wino4Tile::CK; a.tiles_x = (W + Wino4Tile::TW - 1) / Wino4Tile::TW; a.tiles_y = (H + Wino4TileT<WINO4_TB>::TH - 1) / Wino4TileT<WINO4_TB>::TH;
 #elif defined(WINO64)
   if (cin != 64 || ((H | W) & 1)) { printf("WINO64: cin must be 64, H and W even\n"); return 1; }
   a.cout = cout; a.n_chunks = Wino64Tile::NCH; a.tiles_x = (W + Wino64Tile::TW - 1) / Wino64Tile::TW; a.tiles_y = (H + Wino64Tile::TH - 1) / Wino64Tile::TH;
