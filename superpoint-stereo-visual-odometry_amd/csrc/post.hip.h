@@ -418,6 +418,71 @@ __global__ __launch_bounds__(256) void nms_round_kernel(const float *__restrict_
   }
 }
 
+// K10f: the stragglers.  After the first round launches a real heat map has a few hundred candidates left whose decision hangs on a
+// chain of better neighbours; every further round launch decides one more link per chain (a workgroup sees what the others wrote at
+// the next kernel boundary at the latest).  ONE workgroup per image takes them all: it lists the undecided candidates in LDS and
+// iterates rounds over that list with workgroup barriers between them -- all writers and readers of the state bytes sit on one CU,
+// so every round sees the round before it -- until nothing is undecided.  Decisions are final and unique whatever the order they
+// are taken in (nms_decide), so the keypoints are the ones the round launches alone would give.  More undecided candidates than the
+// list holds, or chains longer than the round budget (adversarial heat maps), are left to the host's continuation (the count of what
+// is left goes into the launch's slot of the counter block, as after a round launch).
+constexpr int NMS_FIN_THREADS = 512, NMS_FIN_CAP = 8192;
+template <int DIST>
+__global__ __launch_bounds__(NMS_FIN_THREADS) void nms_finish_kernel(const float *__restrict__ heat, int H, int W, int dist_rt, NmsPair np, int launch, int border,
+                                                                     int surv_cap) {
+  __shared__ int s_list[NMS_FIN_CAP];
+  __shared__ int s_n, s_rem;
+  const NmsBuffers nb = np.b[blockIdx.x];
+  if (nb.counters[8 + launch - 1] == 0) return;   // nothing left undecided
+  const float *hm = heat + (size_t)blockIdx.x * H * W;
+  const int n = nb.counters[0];
+  const int pitch = nms_state_pitch(W);
+  uint8_t *state = nb.state;
+  if (threadIdx.x == 0) { s_n = 0; s_rem = 0; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += NMS_FIN_THREADS) {
+    const int p = nb.cand[i];
+    const int y = p / W, x = p - y * W;
+    if (((volatile uint8_t *)state)[(y + NMS_PAD) * pitch + x + NMS_PAD] == ST_UNDECIDED) {
+      const int k = atomicAdd(&s_n, 1);
+      if (k < NMS_FIN_CAP) s_list[k] = p;
+    }
+  }
+  __syncthreads();
+  const int total = s_n;
+  if (total > NMS_FIN_CAP) {   // not a job for one workgroup
+    if (threadIdx.x == 0) atomicAdd(&nb.counters[8 + launch], total);
+    return;
+  }
+  const int max_rounds = total > 2048 ? 32 : 256;
+  bool any = total > 0;
+  for (int round = 0; round < max_rounds && any; ++round) {
+    bool live = false;
+    for (int k = threadIdx.x; k < total; k += NMS_FIN_THREADS) {
+      const int p = s_list[k];
+      if (p < 0) continue;
+      const int y = p / W, x = p - y * W;
+      const uint8_t d = nms_decide<DIST>(hm, state, H, W, pitch, dist_rt, p, x, y);
+      if (d == ST_UNDECIDED) { live = true; continue; }
+      ((volatile uint8_t *)state)[(y + NMS_PAD) * pitch + x + NMS_PAD] = d;
+      s_list[k] = -1;
+      if (d == ST_KEPT && y >= border && y + border < H && x >= border && x + border < W) {   // nn.cpp:239-242, as in nms_round_kernel
+        const int s = atomicAdd(&nb.counters[1], 1);
+        if (s < surv_cap) nb.surv_key[s] = rank_key(hm[p], x, y, H);
+        else nb.counters[3] = 1;
+      }
+    }
+    any = __syncthreads_or(live) != 0;
+  }
+  if (any) {
+    int rem = 0;
+    for (int k = threadIdx.x; k < total; k += NMS_FIN_THREADS) rem += s_list[k] >= 0 ? 1 : 0;
+    if (rem) atomicAdd(&s_rem, rem);
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&nb.counters[8 + launch], s_rem);
+  }
+}
+
 __global__ __launch_bounds__(256) void nms_collect_kernel(const float *__restrict__ heat, int H,
                                                           int W, int border, int surv_cap,
                                                           NmsPair np) {

@@ -102,7 +102,6 @@ int launch_preprocess(spvo_ctx *c, const uint8_t *d_src0, const uint8_t *d_src1,
 
 // ---------------------------------------------------------------- NMS pipeline
 constexpr int NMS_INNER = 4;
-constexpr int NMS_INNER_LAST = 16;
 constexpr int NMS_GRID = 128;
 
 // NMS counter blocks rotate through RING sets with the submissions: the last NMS kernel of one
@@ -124,18 +123,20 @@ int launch_nms_rounds(spvo_ctx *c, int nimg, const NmsPair &np, int set, int n_l
   hipStream_t st = c->post;
   const float *heat = c->d_heat_r[set % RING];
   const int collect = redo ? 0 : 1;   // first batch: survivors are listed as they are decided; continuation: the list was cleared, re-collect everything
-  for (int l = 0; l < n_launch; ++l) {
-    // the LAST launch of a submission's first batch iterates longer in the kernel (decided threads cost nothing, a workgroup without
-    // undecided candidates leaves at once): whatever chain of decisions is still open gets NMS_INNER_LAST more rounds before the
-    // host would have to continue (nms_settle)
-    const bool longer = !redo && l == n_launch - 1 && n_launch > 1;
-    if (c->cfg.dist_thresh == 4) {
-      if (longer) hipLaunchKernelGGL((nms_round_kernel<NMS_INNER_LAST, 4>), dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, 4, np, l, c->cfg.border_remove, c->surv_cap, collect);
-      else hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 4>), dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, 4, np, l, c->cfg.border_remove, c->surv_cap, collect);
-    } else {
-      if (longer) hipLaunchKernelGGL((nms_round_kernel<NMS_INNER_LAST, 0>), dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, c->cfg.dist_thresh, np, l, c->cfg.border_remove, c->surv_cap, collect);
-      else hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 0>), dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, c->cfg.dist_thresh, np, l, c->cfg.border_remove, c->surv_cap, collect);
-    }
+  // a submission's first batch: n_launch - 1 round launches, then the one-workgroup-per-image kernel that finishes the stragglers
+  // (nms_finish_kernel); the host's continuation (redo): round launches only
+  const int n_round = (!redo && n_launch > 1) ? n_launch - 1 : n_launch;
+  for (int l = 0; l < n_round; ++l) {
+    if (c->cfg.dist_thresh == 4)
+      hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 4>), dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, 4, np, l, c->cfg.border_remove, c->surv_cap, collect);
+    else
+      hipLaunchKernelGGL((nms_round_kernel<NMS_INNER, 0>), dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, c->cfg.dist_thresh, np, l, c->cfg.border_remove, c->surv_cap, collect);
+  }
+  if (n_round < n_launch) {
+    if (c->cfg.dist_thresh == 4)
+      hipLaunchKernelGGL((nms_finish_kernel<4>), dim3(nimg), dim3(NMS_FIN_THREADS), 0, st, heat, c->H, c->W, 4, np, n_round, c->cfg.border_remove, c->surv_cap);
+    else
+      hipLaunchKernelGGL((nms_finish_kernel<0>), dim3(nimg), dim3(NMS_FIN_THREADS), 0, st, heat, c->H, c->W, c->cfg.dist_thresh, np, n_round, c->cfg.border_remove, c->surv_cap);
   }
   if (redo) hipLaunchKernelGGL(nms_collect_kernel, dim3(NMS_GRID, nimg), dim3(256), 0, st, heat, c->H, c->W, c->cfg.border_remove, c->surv_cap, np);
   hipLaunchKernelGGL(nms_rank_kernel, dim3(128, nimg), dim3(256), 0, st, c->surv_cap, np);
@@ -144,11 +145,13 @@ int launch_nms_rounds(spvo_ctx *c, int nimg, const NmsPair &np, int set, int n_l
   return SPVO_OK;
 }
 
-// processOneHeatmap for images [0, nimg).  Real heat maps settle in 2-3 launches of 4 in-kernel
-// rounds; adversarial ones (e.g. a constant image: one decision chain across the whole picture)
-// simply take more batches -- every launch decides at least the best undecided candidate, so the
-// loop terminates.  nms_enqueue only submits; nms_settle runs after the caller's sync and returns
-// 1 if it had to redo work (the caller then re-runs what depends on the keypoints).
+// processOneHeatmap for images [0, nimg).  With a submission go three round launches of 4 in-kernel rounds (trained weights' heat
+// maps settle in 2-3; a launch whose predecessor left nothing undecided exits at once) and the finishing kernel, one workgroup per
+// image that iterates over whatever is still undecided until nothing is (post.hip.h).  Adversarial maps (e.g. a constant image: one
+// decision chain across the whole picture) are continued by the host in batches of round launches -- every launch decides at least
+// the best undecided candidate, so the loop terminates -- but that continuation queues behind everything on the tail stream and
+// synchronises: in a pipelined loop it costs more than a trunk, which is what the finishing kernel is for.
+// nms_settle runs after the caller's wait and reports whether it had to redo work (the caller then re-runs what depends on the keypoints).
 
 // more rounds for the (rare) submissions whose first batch left candidates undecided
 int nms_settle(spvo_ctx *c, int nimg, const NmsPair &np, int set, bool *redone) {

@@ -172,7 +172,7 @@ struct spvo_ctx {
   float *d_heat_base = nullptr;
   NmsImage nms[2];
   int surv_cap = 0;
-  int nms_first = 4;             // round launches enqueued with a submission (4 in-kernel rounds each, 16 in the last); a heat map that needs more is continued by the host (nms_settle)
+  int nms_first = 4;             // NMS launches enqueued with a submission: nms_first - 1 round launches (4 in-kernel rounds each) + the finishing kernel; what that leaves undecided is continued by the host (nms_settle)
   int *h_counters = nullptr;     // pinned [2][NMS_COUNTER_INTS]
   uint8_t *d_img[2] = {nullptr, nullptr};
   size_t img_cap = 0;

@@ -51,9 +51,9 @@ def test_gpus_flag_spawns_the_ranks_itself():
 
 def test_headline_workload_needs_no_host_driven_nms_continuation():
     """bench.py's headline workload (seeded VGG weights at 360x1176: denser heat maps than the trained graphs') through the pipelined
-    loop: every heat map's suppression settles inside the round launches enqueued with the submission.  A continuation by the host
-    (spvo_detect_wait -> nms_settle) waits behind everything queued on the tail stream; with three launches of four rounds it ran on
-    7 % of the frames and cost the headline 6 %."""
+    loop: every heat map's suppression settles inside the launches enqueued with the submission (three round launches + the
+    finishing kernel).  A continuation by the host (spvo_detect_wait -> nms_settle) waits behind everything queued on the tail
+    stream; with three round launches alone it ran on 7 % of the frames and cost the headline 6 %."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "10", "--repeats", "2", "--no-cpu-baseline", "--no-extras"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)

@@ -7,7 +7,8 @@ for p in (ROOT, os.path.join(ROOT, "superpoint-stereo-visual-odometry_amd")):
     sys.path.insert(0, p)
 import numpy as np
 os.environ.setdefault("SPVO_QUIET", "1")
-from spvo import host, synth, weights
+from spvo import host, synth, weights, capi
+capi.tuning_from_env()   # SPVO_TUNE_<NAME>=<int>: diagnostic switches for A/B runs
 
 trained = len(sys.argv) > 1 and sys.argv[1] == "sp_squeeze"
 tmp = tempfile.mkdtemp(); os.makedirs(os.path.join(tmp, "laptop"))
