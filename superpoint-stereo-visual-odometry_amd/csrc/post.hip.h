@@ -422,11 +422,11 @@ __global__ __launch_bounds__(256) void nms_round_kernel(const float *__restrict_
 // chain of better neighbours; every further round launch decides one more link per chain (a workgroup sees what the others wrote at
 // the next kernel boundary at the latest).  ONE workgroup per image takes them all: it lists the undecided candidates in LDS and
 // iterates rounds over that list with workgroup barriers between them -- all writers and readers of the state bytes sit on one CU,
-// so every round sees the round before it -- until nothing is undecided.  Decisions are final and unique whatever the order they
+// so every round sees the round before it -- until nothing is undecided (or its budget of rounds / window evaluations is spent).  Decisions are final and unique whatever the order they
 // are taken in (nms_decide), so the keypoints are the ones the round launches alone would give.  More undecided candidates than the
 // list holds, or chains longer than the round budget (adversarial heat maps), are left to the host's continuation (the count of what
 // is left goes into the launch's slot of the counter block, as after a round launch).
-constexpr int NMS_FIN_THREADS = 512, NMS_FIN_CAP = 8192;
+constexpr int NMS_FIN_THREADS = 512, NMS_FIN_CAP = 8192, NMS_FIN_ROUNDS = 1024, NMS_FIN_EVALS = 768;
 template <int DIST>
 __global__ __launch_bounds__(NMS_FIN_THREADS) void nms_finish_kernel(const float *__restrict__ heat, int H, int W, int dist_rt, NmsPair np, int launch, int border,
                                                                      int surv_cap) {
@@ -454,14 +454,16 @@ __global__ __launch_bounds__(NMS_FIN_THREADS) void nms_finish_kernel(const float
     if (threadIdx.x == 0) atomicAdd(&nb.counters[8 + launch], total);
     return;
   }
-  const int max_rounds = total > 2048 ? 32 : 256;
+  // budget: NMS_FIN_ROUNDS rounds, NMS_FIN_EVALS window evaluations per thread (~2 us each: about a millisecond in the worst case)
   bool any = total > 0;
-  for (int round = 0; round < max_rounds && any; ++round) {
+  int evals = 0;
+  for (int round = 0; round < NMS_FIN_ROUNDS && any; ++round) {
     bool live = false;
     for (int k = threadIdx.x; k < total; k += NMS_FIN_THREADS) {
       const int p = s_list[k];
       if (p < 0) continue;
       const int y = p / W, x = p - y * W;
+      ++evals;
       const uint8_t d = nms_decide<DIST>(hm, state, H, W, pitch, dist_rt, p, x, y);
       if (d == ST_UNDECIDED) { live = true; continue; }
       ((volatile uint8_t *)state)[(y + NMS_PAD) * pitch + x + NMS_PAD] = d;
@@ -473,6 +475,7 @@ __global__ __launch_bounds__(NMS_FIN_THREADS) void nms_finish_kernel(const float
       }
     }
     any = __syncthreads_or(live) != 0;
+    if (__syncthreads_or(evals >= NMS_FIN_EVALS)) break;
   }
   if (any) {
     int rem = 0;

@@ -162,6 +162,7 @@ int nms_settle(spvo_ctx *c, int nimg, const NmsPair &np, int set, bool *redone) 
     bool pending = false;
     for (int i = 0; i < nimg; ++i) pending |= hc[i * NMS_COUNTER_INTS + 8 + last - 1] != 0;
     if (!pending) break;
+    if (!*redone) c->stages[stage_id(c, "nms_redo")].calls += 1;   // host-driven continuations: counted even with profiling off (tests, diagnostics, bench.py)
     *redone = true;
     last = NMS_MAX_LAUNCH;
     for (int i = 0; i < nimg; ++i)   // keep n_cand, clear the rest of the block
@@ -677,7 +678,6 @@ static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_feature
   const NmsPair np = nms_pair(c, pd.ring);
   if (!rc) rc = nms_settle(c, 2, np, pd.ring, &redone);
   if (!rc && (redone || pd.rematch)) {   // rare: keypoints changed after the first batch -> redo what depends on them
-    if (redone) c->stages[stage_id(c, "nms_redo")].calls += 1;       // counted even with profiling off (tests, diagnostics)
     if (pd.rematch) c->stages[stage_id(c, "rematch")].calls += 1;
     if (redone && (pd.extras & 2)) (void)wait_event(c->ev_copy[pd.ring]);   // the mirror of the superseded descriptors has landed: the new one goes on top
     if (redone) rc = enqueue_sample(c, slots, np, pd.ring, pd.tring, pd.img0);

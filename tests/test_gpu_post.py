@@ -87,6 +87,26 @@ def test_nms_edge_cases(vgg_weights_path):
     ctx.close()
 
 
+def test_nms_long_chains_are_finished_on_the_device(vgg_weights_path):
+    """Decision chains far longer than the three round launches' twelve rounds -- rows of candidates with confidences falling along
+    the row: every fifth one is kept, and each decision waits for the one before it -- are settled by nms_finish_kernel (one workgroup
+    per image, rounds separated by workgroup barriers) without the host's continuation; a map whose stragglers do not fit that
+    kernel's list (every pixel a link of one chain) still takes the host path.  Both bit-exact against the sequential oracle."""
+    H, W = 120, 392
+    ctx = make_ctx(vgg_weights_path, net_height=H, net_width=W, max_keypoints=1000)
+    heat = np.full((H, W), 0.001, np.float32)
+    for r, y in enumerate(range(8, H - 8, 12)):                      # nine rows, far enough apart not to interact
+        heat[y, :] = (0.9 - 0.002 * np.arange(W) - 0.0001 * r).astype(np.float32)   # ~78 links per chain
+    got, ref = _nms_both(ctx, heat)
+    assert np.array_equal(got, ref) and len(ref) > 500
+    assert ctx.profile().get("nms_redo", {"calls": 0})["calls"] == 0                   # no host continuation: the finishing kernel settled it
+    ramp = (np.arange(H * W, dtype=np.float32).reshape(H, W) + 1) / (H * W)
+    got, ref = _nms_both(ctx, ramp)
+    assert np.array_equal(got, ref)
+    assert ctx.profile()["nms_redo"]["calls"] >= 1                   # 47 k undecided candidates: the host's continuation
+    ctx.close()
+
+
 @pytest.mark.parametrize("H,W,dist,border", [(360, 1176, 4, 4), (120, 392, 4, 4), (120, 392, 2, 0), (120, 392, 8, 3), (192, 640, 3, 4)])
 def test_nms_on_sparse_tied_clustered_and_dense_heat_maps(vgg_weights_path, H, W, dist, border):
     """processOneHeatmap on synthetic heat maps of four kinds -- sparse with distinct confidences, many exact ties and near-ties,
