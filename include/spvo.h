@@ -408,7 +408,7 @@ int spvo_profile_stage_kernel(spvo_ctx *ctx, const char *stage, char *name, size
  * of the process that hosts it (a ROS node) cannot change kernels by accident.  Process-wide; a value takes effect for contexts
  * created / engines loaded afterwards.  `name` is one of the names INTEGRATION.md lists ("winograd", "wino4", "wino_narrow",
  * "wino_dynamic", "winograd_min_tiles", "wino4_min_tiles", "merge_siblings", "heads_fused", "heads_on_net", "heads_split",
- * "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing", "nms_first"); SPVO_ERR_INVALID for any other.
+ * "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing", "nms_first", "upload_side"); SPVO_ERR_INVALID for any other.
  * spvo_get_tuning returns the value set, or `dflt`; spvo_clear_tuning forgets every value. */
 int spvo_set_tuning(const char *name, int value);
 int spvo_get_tuning(const char *name, int dflt);

@@ -38,7 +38,7 @@ int stage_id(spvo_ctx *c, const std::string &name) {
 // ---- diagnostic switches (include/spvo.h: spvo_set_tuning).  One process-wide table, filled by explicit calls only.
 namespace {
 const char *const kTuningNames[] = {"winograd", "wino4", "wino_narrow", "wino_dynamic", "winograd_min_tiles", "wino4_min_tiles", "merge_siblings", "heads_fused",
-                                    "heads_on_net", "heads_split", "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing", "nms_first"};
+                                    "heads_on_net", "heads_split", "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing", "nms_first", "upload_side"};
 constexpr int kTuningCount = sizeof kTuningNames / sizeof kTuningNames[0];
 std::mutex g_tuning_mutex;
 bool g_tuning_set[kTuningCount] = {};
@@ -210,7 +210,8 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
   for (int r = 0; r < RING; ++r)
     if (hipEventCreateWithFlags(&c->ev_net[r], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_tail[r], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_feat[r], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_copy[r], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_pre[r], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_res[r], hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_pre[r], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_res[r], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_up[r], hipEventDisableTiming) != hipSuccess) {
       spvo_destroy(c);
       return fail(nullptr, SPVO_ERR_DEVICE, "cannot create events on device %d", cfg->device);
     }
@@ -305,7 +306,7 @@ void spvo_destroy(spvo_ctx *c) {
     if (c->d_resized_r[r]) (void)hipFree(c->d_resized_r[r]);
     if (c->h_resized_r[r]) (void)hipHostFree(c->h_resized_r[r]);
     if (c->h_desc_r[r]) (void)hipHostFree(c->h_desc_r[r]);
-    for (hipEvent_t e : {c->ev_net[r], c->ev_tail[r], c->ev_feat[r], c->ev_copy[r], c->ev_pre[r], c->ev_res[r]}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {c->ev_net[r], c->ev_tail[r], c->ev_feat[r], c->ev_copy[r], c->ev_pre[r], c->ev_res[r], c->ev_up[r]}) if (e) (void)hipEventDestroy(e);
   }
   for (int i = 0; i < N_SLOTS; ++i) {
     void *q[] = {c->slots[i].d_xy, c->slots[i].d_xyf, c->slots[i].d_desc, c->slots[i].d_n, c->slots[i].d_sqn};

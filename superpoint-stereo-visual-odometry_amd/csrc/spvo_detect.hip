@@ -414,7 +414,16 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
     std::memcpy(c->h_img_r[ring] + c->img_cap_r, host_r, bytes);
     // both images in one copy (the staging buffers of a set are contiguous, left then right): two copies were 17 + 16 us with 9 us
     // between them on the synchronous path's critical path (profiles/r04_sync_timeline.log)
-    HIP_TRY(c, hipMemcpyAsync(c->d_img_r[ring], c->h_img_r[ring], c->img_cap_r + bytes, hipMemcpyHostToDevice, c->stream));
+    // ... on the SOLVER's stream when the pair's trunk will only queue behind another one: the copy then runs at once, beside the
+    // running trunk, instead of between two trunks on the network stream, which only waits for its event (look-ahead leg 1313 ->
+    // 1332-1343 frames/s; no device-to-host copy shares that engine any more: the bulk results leave through copy kernels).
+    // Tuning "upload_side" = 0: always on the network stream.
+    const bool up_side = tuning("upload_side", 1) != 0 && c->last_launch_ring >= 0 && hipEventQuery(c->ev_net[c->last_launch_ring]) == hipErrorNotReady;
+    HIP_TRY(c, hipMemcpyAsync(c->d_img_r[ring], c->h_img_r[ring], c->img_cap_r + bytes, hipMemcpyHostToDevice, up_side ? c->stream2 : c->stream));
+    if (up_side) {
+      HIP_TRY(c, hipEventRecord(c->ev_up[ring], c->stream2));
+      HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_up[ring], 0));
+    }
     srcs[0] = c->d_img_r[ring];
     srcs[1] = c->d_img_r[ring] + c->img_cap_r;
   }

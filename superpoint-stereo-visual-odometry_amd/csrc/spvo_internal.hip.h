@@ -212,6 +212,7 @@ struct spvo_ctx {
   // matches enqueued behind them have landed too (what spvo_match_slots needs); ev_copy = the descriptors of a host-image submission have reached their pinned mirror (copy kernel behind the matches)
   hipEvent_t ev_feat[RING] = {nullptr, nullptr, nullptr, nullptr}, ev_copy[RING] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_pre[RING] = {nullptr, nullptr, nullptr, nullptr}, ev_res[RING] = {nullptr, nullptr, nullptr, nullptr};   // first layer done (network stream) / resized images on the host (tail stream)
+  hipEvent_t ev_up[RING] = {nullptr, nullptr, nullptr, nullptr};   // a queued host-image submission's upload, on the solver's stream, has landed (its preprocess kernel waits for it)
   hipEvent_t ev_post = nullptr;    // PostScope: orders a synchronous entry point behind what is left on the tail stream
   bool match_fp8 = false;        // fp8 shortlist GEMM (approximate; spvo_set_match_fp8)
   bool prematch = false;
