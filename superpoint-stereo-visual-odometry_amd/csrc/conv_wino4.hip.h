@@ -29,8 +29,10 @@
 //     thing that is nearly free beside an fp32 matrix instruction, reads are not);
 //   * the input transform of an item is 128 patches of 6 x 6: TWO threads per patch, rows {0,1,2} / {3,4,5} for the row pass,
 //     nine v_permlane32_swap exchanges, columns {0,1,2} / {3,4,5} for the column pass (the partner sits 32 lanes away, so the
-//     swap leaves "rows 0-2" and "rows 3-5" in the same registers of both halves: no selects); the four waves 0-3 do it in even
-//     items, waves 4-7 in odd ones -- one transforming wave per SIMD in every item;
+//     swap leaves "rows 0-2" and "rows 3-5" in the same registers of both halves: no selects); waves 0-3 transform the even
+//     items, waves 4-7 the odd ones, each transform in two halves in two consecutive items (rows + row pass two items ahead,
+//     exchange + column pass + stores one item ahead; 18 registers carry it across the barrier), so that in every item BOTH
+//     waves of a SIMD do half a transform;
 //   * the inverse transform (36 -> 16 per output channel and tile) runs in registers, as before.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -42,11 +44,25 @@
 #ifndef WINO4_LEAD      // tuning (tools/wino_bench.hip): operand reads LEAD slots ahead; transform step s in slot XF_START + s * XF_STRIDE
 #define WINO4_LEAD 6
 #endif
-#ifndef WINO4_XF_START
-#define WINO4_XF_START 4   // (start 4, stride 3: 248 us for conv1b against 254-257 for 8 / 2, 8 / 1, 14 / 1, 2 / 3; LEAD 4 .. 10: no difference)
+// The input transform of an item is done in two halves, in two consecutive items, by the same waves: H1 (steps 0..5: the patch rows
+// from the raw tile, row pass) two items ahead, H2 (steps 6..9: exchange, column pass, stores into V) one item ahead.  In every item one
+// group of waves does H1 of item k + 2 and the other H2 of item k + 1: the same extra work for both waves of a SIMD.  (With a whole
+// transform per item by alternating groups, the transforming wave's matrix stream took 3900 cycles and the other's 2630, which then
+// waited 1300 cycles at the barrier while the transforming wave ran alone: tools/wino_bench -DWINO_STAMPS -DWINO_STAMPS_ROLES.)
+#ifndef WINO4_H1_STEPS
+#define WINO4_H1_STEPS 6   // steps of the first half (6: up to the row pass; 7: + the exchange -- no better)
 #endif
-#ifndef WINO4_XF_STRIDE
-#define WINO4_XF_STRIDE 3
+#ifndef WINO4_H1_START
+#define WINO4_H1_START 3
+#endif
+#ifndef WINO4_H1_STRIDE
+#define WINO4_H1_STRIDE 5
+#endif
+#ifndef WINO4_H2_START
+#define WINO4_H2_START 4
+#endif
+#ifndef WINO4_H2_STRIDE
+#define WINO4_H2_STRIDE 8
 #endif
 #ifndef WINO4_ABL
 #define WINO4_ABL 0   // measurement builds only (tools/wino_bench.hip): 1 no input transform, 2 no filter staging, 4 no raw staging, 8 operands read once, 16 no stores
@@ -303,19 +319,25 @@ __global__ __launch_bounds__(256 * TB, TB) void conv_wino4_kernel(const ConvArgs
   Cursor cr = cu;
   advance(cr);                                   // item 2
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  if (wave < 2 * TB) {                           // item 0's transform has nothing to hide behind
+  if (wave < 2 * TB) {                           // item 0's transform has nothing to hide behind ...
 #pragma unroll
     for (int st = 0; st < 10; ++st) xf_step(smem + T::RAW_OFF, smem + T::V_OFF, st);
+  } else {                                       // ... nor has the first half of item 1's (the other group: its second half follows in item 0)
+#pragma unroll
+    for (int st = 0; st < WINO4_H1_STEPS; ++st) xf_step(smem + T::RAW_OFF + T::IN_FLOATS, smem + T::V_OFF + T::V_FLOATS, st);
   }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // raw tile 0 is read: item 2's goes there (first half of its transform: in item 0)
+  if (cr.id < n_tiles) issue_raw(cr.t, cr.chunk, smem + T::RAW_OFF);
+  advance(cr);                                   // item 3
 
 #ifdef WINO_STAMPS   // diagnostic build (tools/wino_bench.hip): shader-clock cycles per wave waiting for LDS-DMA / stores at an item's start (o[7]: of
                      // which in a tile's SECOND item, the first wait behind an epilogue's stores), at the barrier, in the matrix stream, in epilogues
-  unsigned long long st_dma = 0, st_bar = 0, st_mfma = 0, st_epi = 0, st_items = 0, st_post = 0;
+  unsigned long long st_dma = 0, st_bar = 0, st_mfma = 0, st_epi = 0, st_items = 0, st_post = 0, st_bar_xf = 0, st_mfma_xf = 0;   // _xf: in the items in which this wave does the transform's first half
   const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
   int st_c = 0;
 #endif
   int k = 0;                    // items done: selects the buffers and the transforming half
-  bool drained = true;          // the LDS-DMA this item needs has been waited for already
+  bool drained = false;         // the LDS-DMA this item needs has been waited for already
   constexpr unsigned OOB = 0xFFFFFFFFu;
 
   while (tile_id < n_tiles) {
@@ -329,7 +351,8 @@ __global__ __launch_bounds__(256 * TB, TB) void conv_wino4_kernel(const ConvArgs
     f32x4v acc[36];
     auto item = [&](auto first_tag, bool publish) {
       constexpr bool FIRST = decltype(first_tag)::value;   // the tile's first chunk: C = 0 in every accumulator's (only) instruction
-      // waves 0-3 transform the next item's input in even items, waves 4-7 in odd ones (wave-uniform: a scalar branch per step)
+      // group k & 1 (waves 0-3 / 4-7) does the first half of item k + 2's transform, the other group the second half of item k + 1's
+      // (wave-uniform: a scalar branch per step)
       const bool XF = __builtin_amdgcn_readfirstlane((wave >> TB) == (k & 1) ? 1 : 0) != 0;
 #ifdef WINO_STAMPS
       const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
@@ -346,12 +369,13 @@ __global__ __launch_bounds__(256 * TB, TB) void conv_wino4_kernel(const ConvArgs
       const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
       st_dma += ts1 - ts0; st_bar += ts2 - ts1;
       if (st_c == 1) st_post += ts1 - ts0;
+      if (XF) st_bar_xf += ts2 - ts1;
 #endif
       const float *ub = smem + T::U_OFF + (k & 1) * T::U_FLOATS;
       const float *vb = smem + T::V_OFF + (k & 1) * T::V_FLOATS;
       float *u_next = smem + T::U_OFF + ((k + 1) & 1) * T::U_FLOATS;
-      float *raw_next2 = smem + T::RAW_OFF + (k & 1) * T::IN_FLOATS;          // raw(k+2) replaces raw(k), transformed during item k-1
-      const float *raw_next = smem + T::RAW_OFF + ((k + 1) & 1) * T::IN_FLOATS;
+      const float *raw_next2 = smem + T::RAW_OFF + (k & 1) * T::IN_FLOATS;    // raw(k+2): landed before this item, read by H1 now
+      float *raw_next3 = smem + T::RAW_OFF + ((k + 1) & 1) * T::IN_FLOATS;    // raw(k+3) replaces raw(k+1), whose H1 ran during item k-1
       float *v_next = smem + T::V_OFF + ((k + 1) & 1) * T::V_FLOATS;
       const f32x4v *ub4 = reinterpret_cast<const f32x4v *>(ub) + a_lane;
       const f32x4v *vb4 = reinterpret_cast<const f32x4v *>(vb) + b_lane;
@@ -374,21 +398,23 @@ __global__ __launch_bounds__(256 * TB, TB) void conv_wino4_kernel(const ConvArgs
         else acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_op, b_op, acc[pos], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (!(WINO4_ABL & 2) && p == 1 && cu.id < n_tiles) issue_u(cu.t, cu.chunk, u_next);
-        if (!(WINO4_ABL & 4) && p == 4 && cr.id < n_tiles) issue_raw(cr.t, cr.chunk, raw_next2);
+        if (!(WINO4_ABL & 4) && p == 4 && cr.id < n_tiles) issue_raw(cr.t, cr.chunk, raw_next3);
         const int q = p + LEAD;
         if (!(WINO4_ABL & 8) && q < 36) {
           if ((q & 3) == 0) av[q >> 2] = ub4[(q >> 2) * 256];
           if (b_piece(q) != b_piece(q - 1)) bv[b_piece(q)] = vb4[b_piece(q) * (64 * TB)];
         }
-        if (!(WINO4_ABL & 1) && XF && p >= WINO4_XF_START && p < WINO4_XF_START + 10 * WINO4_XF_STRIDE && (p - WINO4_XF_START) % WINO4_XF_STRIDE == 0)
-          xf_step(raw_next, v_next, (p - WINO4_XF_START) / WINO4_XF_STRIDE);   // ten steps, one per XF_STRIDE slots
+        if (!(WINO4_ABL & 1) && XF && p >= WINO4_H1_START && p < WINO4_H1_START + WINO4_H1_STEPS * WINO4_H1_STRIDE && (p - WINO4_H1_START) % WINO4_H1_STRIDE == 0)
+          xf_step(raw_next2, v_next, (p - WINO4_H1_START) / WINO4_H1_STRIDE);                          // H1 of item k + 2
+        if (!(WINO4_ABL & 1) && !XF && p >= WINO4_H2_START && p < WINO4_H2_START + (10 - WINO4_H1_STEPS) * WINO4_H2_STRIDE && (p - WINO4_H2_START) % WINO4_H2_STRIDE == 0)
+          xf_step(raw_next2, v_next, WINO4_H1_STEPS + (p - WINO4_H2_START) / WINO4_H2_STRIDE);        // H2 of item k + 1 (registers of this wave's H1 in the item before)
         __builtin_amdgcn_sched_barrier(0);
       }
       advance(cu);
       advance(cr);
       ++k;
 #ifdef WINO_STAMPS
-      st_mfma += __builtin_amdgcn_s_memtime() - ts2;
+      { const unsigned long long dt = __builtin_amdgcn_s_memtime() - ts2; st_mfma += dt; if (XF) st_mfma_xf += dt; }
       ++st_items; ++st_c;
 #endif
     };
@@ -482,6 +508,9 @@ __global__ __launch_bounds__(256 * TB, TB) void conv_wino4_kernel(const ConvArgs
     unsigned long long *o = a.stamps + 8 * (blockIdx.x * (4 * TB) + wave);
     o[0] = st_dma; o[1] = st_bar; o[2] = st_mfma; o[3] = st_epi; o[4] = st_items;
     o[5] = __builtin_amdgcn_s_memtime() - st_t0; o[6] = __builtin_amdgcn_s_memrealtime() - st_r0; o[7] = st_post;
+#ifdef WINO_STAMPS_ROLES   // o[0], o[7]: matrix stream and barrier wait (in front) of the items in which this wave did the transform's FIRST half: half of its items
+    o[0] = st_mfma_xf; o[7] = st_bar_xf;
+#endif
   }
 #endif
 }

@@ -105,7 +105,7 @@ int launch_conv_wino4_instance(spvo_ctx *c, const ConvArgs &args, hipStream_t st
   const int rounds = (n_tiles + c->num_cus - 1) / c->num_cus;
   const int grid = (n_tiles + rounds - 1) / rounds;   // the smallest grid that keeps the number of rounds (see launch_conv_wino_instance)
   ConvArgs a2 = args;
-  if (rounds < 2 || args.n_chunks < 4) a2.sched = nullptr;
+  if (rounds < 2 || args.n_chunks < 5) a2.sched = nullptr;   // (the raw-tile cursor runs three items ahead: a tile's successor must be known by the end of its second item)
   hipLaunchKernelGGL(k, dim3(grid), dim3(512), Wino4Tile::LDS_BYTES, stream, a2);
   HIP_TRY(c, hipGetLastError());
   return SPVO_OK;

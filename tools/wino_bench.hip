@@ -144,6 +144,16 @@ int main(int argc, char **argv) {
       printf("  of the waits at an item's start, in a tile's second item (behind the epilogue's stores): %.0f cycles per wave = %.0f per tile (%.1f tiles per wave)\n",
              post / n, post / n / std::max(1.0, sum[4] / n / a.n_chunks), sum[4] / n / a.n_chunks);
     }
+#ifdef WINO_STAMPS_ROLES
+    {
+      double bx = 0, mx = 0;
+      for (int i = 0; i < nw; ++i) if (st[8 * i + 4]) { mx += (double)st[8 * i + 0]; bx += (double)st[8 * i + 7]; }
+      const double it = sum[4], ix = it / 2, bn = sum[1] - bx, mn = sum[2] - mx, in = it - ix;
+      printf("  by role, cycles per item: items in which the wave does the transform's first half: matrix stream %.0f, barrier wait in front %.0f; its other items (second half): matrix stream %.0f, barrier wait in front %.0f\n",
+             mx / ix, bx / ix, mn / in, bn / in);
+      sum[0] = 0;
+    }
+#endif
     printf("  per wave: %.1f items, %.0f cycles total at %.2f GHz (100 MHz reference); per item: LDS-DMA wait %.0f, barrier %.0f, matrix stream %.0f, epilogue %.0f (per item share), other %.0f cycles\n",
            items, sum[5] / n, clk / 1e9, sum[0] / n / items, sum[1] / n / items, sum[2] / n / items, sum[3] / n / items,
            (sum[5] - sum[0] - sum[1] - sum[2] - sum[3]) / n / items);
