@@ -49,6 +49,14 @@
 // group of waves does H1 of item k + 2 and the other H2 of item k + 1: the same extra work for both waves of a SIMD.  (With a whole
 // transform per item by alternating groups, the transforming wave's matrix stream took 3900 cycles and the other's 2630, which then
 // waited 1300 cycles at the barrier while the transforming wave ran alone: tools/wino_bench -DWINO_STAMPS -DWINO_STAMPS_ROLES.)
+// A wave's issue priority falls as it advances through an item (s_setprio 3, 2, 1, 0 at slots 0, 9, 18, 27): of the two waves of a SIMD
+// the one that is BEHIND wins the matrix pipe.  Without it the older wave of each SIMD (waves 0-3) wins every arbitration, finishes
+// its item ~1000 cycles ahead and stands at the barrier while the younger one runs on alone with every stall of its own exposed
+// (stamps by wave, tools/wino_bench -DWINO_STAMPS: barrier wait 1180 / 180 cycles per item -> 560 / 200).  0: off; 2..4: other
+// schedules that measured no better.
+#ifndef WINO4_PRIO
+#define WINO4_PRIO 1
+#endif
 #ifndef WINO4_H1_STEPS
 #define WINO4_H1_STEPS 6   // steps of the first half (6: up to the row pass; 7: + the exchange -- no better)
 #endif
@@ -394,6 +402,24 @@ __global__ __launch_bounds__(256 * TB, TB) void conv_wino4_kernel(const ConvArgs
       for (int p = 0; p < 36; ++p) {
         const int ph = p / 18, pq = p % 18, pos = 6 * (pq / 3) + 3 * ph + pq % 3;
         const float a_op = av[p >> 2][p & 3], b_op = bv[b_piece(p)][pq & 3];
+#if WINO4_PRIO
+#if WINO4_PRIO == 1
+        if (p == 0) asm volatile("s_setprio 3");
+        if (p == 9) asm volatile("s_setprio 2");
+        if (p == 18) asm volatile("s_setprio 1");
+        if (p == 27) asm volatile("s_setprio 0");
+#elif WINO4_PRIO == 2   // the younger wave of a SIMD (tb = 1) keeps each level longer
+        if (p == 0) asm volatile("s_setprio 3");
+        if (tb == 0) { if (p == 6) asm volatile("s_setprio 2"); if (p == 15) asm volatile("s_setprio 1"); if (p == 24) asm volatile("s_setprio 0"); }
+        else { if (p == 12) asm volatile("s_setprio 2"); if (p == 24) asm volatile("s_setprio 1"); }
+#elif WINO4_PRIO == 3   // two levels only: high in the first half of the item
+        if (p == 0) asm volatile("s_setprio 1");
+        if (p == 18) asm volatile("s_setprio 0");
+#elif WINO4_PRIO == 4   // older wave one level below the younger one throughout, both falling
+        if (tb == 0) { if (p == 0) asm volatile("s_setprio 2"); if (p == 12) asm volatile("s_setprio 1"); if (p == 24) asm volatile("s_setprio 0"); }
+        else { if (p == 0) asm volatile("s_setprio 3"); if (p == 12) asm volatile("s_setprio 2"); if (p == 24) asm volatile("s_setprio 1"); }
+#endif
+#endif
         if (FIRST) acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_op, b_op, f32x4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         else acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_op, b_op, acc[pos], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);

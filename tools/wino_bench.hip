@@ -144,6 +144,16 @@ int main(int argc, char **argv) {
       printf("  of the waits at an item's start, in a tile's second item (behind the epilogue's stores): %.0f cycles per wave = %.0f per tile (%.1f tiles per wave)\n",
              post / n, post / n / std::max(1.0, sum[4] / n / a.n_chunks), sum[4] / n / a.n_chunks);
     }
+    {   // by wave of the workgroup (waves w and w + 4 share a SIMD; w is the older one)
+      const int wpw = THREADS / 64;
+      printf("  by wave, cycles per item (barrier wait | matrix stream):");
+      for (int w = 0; w < wpw; ++w) {
+        double b = 0, m = 0, it2 = 0;
+        for (int i = w; i < nw; i += wpw) if (st[8 * i + 4]) { b += (double)st[8 * i + 1]; m += (double)st[8 * i + 2]; it2 += (double)st[8 * i + 4]; }
+        printf("  w%d %.0f | %.0f", w, b / it2, m / it2);
+      }
+      printf("\n");
+    }
 #ifdef WINO_STAMPS_ROLES
     {
       double bx = 0, mx = 0;
