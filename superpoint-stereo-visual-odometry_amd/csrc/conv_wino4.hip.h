@@ -33,6 +33,8 @@
 //     items, waves 4-7 the odd ones, each transform in two halves in two consecutive items (rows + row pass two items ahead,
 //     exchange + column pass + stores one item ahead; 18 registers carry it across the barrier), so that in every item BOTH
 //     waves of a SIMD do half a transform;
+//   * a wave's issue priority falls as it advances through an item (WINO4_PRIO below), so that the two waves of a SIMD reach the
+//     item's barrier together;
 //   * the inverse transform (36 -> 16 per output channel and tile) runs in registers, as before.
 #pragma once
 #include <hip/hip_runtime.h>
