@@ -87,6 +87,27 @@ def test_nms_edge_cases(vgg_weights_path):
     ctx.close()
 
 
+@pytest.mark.parametrize("nms_first", [1, 2, 3, 6])
+def test_nms_result_does_not_depend_on_the_launches_enqueued_with_a_submission(vgg_weights_path, tuning, nms_first):
+    """`nms_first` (diagnostic switch; default 4 = three round launches + the finishing kernel): a single round launch, one round
+    launch + the finishing kernel, two + it, five + it -- what the first batch leaves undecided is continued by the host, and the
+    keypoints are the oracle's in every case (dense map: every pixel a candidate; clustered map: blobs that need several rounds)."""
+    tuning(nms_first=nms_first)
+    H, W = 120, 392
+    ctx = make_ctx(vgg_weights_path, net_height=H, net_width=W, max_keypoints=1000)
+    rng = np.random.RandomState(nms_first)
+    dense = (0.02 + 0.9 * rng.rand(H, W)).astype(np.float32)
+    clustered = np.full((H, W), 0.001, np.float32)
+    for _ in range(100):
+        cy, cx = rng.randint(0, H), rng.randint(0, W)
+        y0, y1, x0, x1 = max(cy - 6, 0), min(cy + 7, H), max(cx - 6, 0), min(cx + 7, W)
+        clustered[y0:y1, x0:x1] = 0.1 + 0.8 * rng.rand(y1 - y0, x1 - x0).astype(np.float32)
+    for heat in (dense, clustered):
+        got, ref = _nms_both(ctx, heat)
+        assert np.array_equal(got, ref)
+    ctx.close()
+
+
 def test_nms_long_chains_are_finished_on_the_device(vgg_weights_path):
     """Decision chains far longer than the three round launches' twelve rounds -- rows of candidates with confidences falling along
     the row: every fifth one is kept, and each decision waits for the one before it -- are settled by nms_finish_kernel (one workgroup
