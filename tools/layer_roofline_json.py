@@ -3,7 +3,7 @@ context's stream, both images of a stereo pair per launch, layers run back to ba
 convolution), GFLOP EXECUTED on the matrix pipe (Winograd F(2x2,3x3) layers: 4/9 of the algorithmic count)
 and the fraction of the 157.3 TFLOP/s fp32-MFMA peak the executed flops amount to; HBM-bound layers carry their GB/s instead.
 
-usage: python tools/layer_roofline_json.py out.json [HxW] [FP32|FP16]
+usage: python tools/layer_roofline_json.py out.json [HxW] [FP32|FP16] [images per launch = 2; 4: two stereo pairs per launch, as under trunk pairing]
 
 FP16 (BASELINE config 3): the same table for the FP16 engine against the 2.5 PFLOP/s dense fp16 peak; every row also carries the roofline that
 bounds it (`bound`: the larger of executed flops / matrix peak and algorithmic bytes / 8 TB/s) -- the HBM <-> MFMA crossover per layer."""
@@ -17,11 +17,12 @@ capi.tuning_from_env()   # SPVO_TUNE_WINOGRAD=0 etc.: this measurement script op
 out_path = sys.argv[1]
 H, Wd = (int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "360x1176").split("x"))
 prec = sys.argv[3] if len(sys.argv) > 3 else "FP32"
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 plan = weights.vgg_plan()
 plan.precision = prec
 p = os.path.join(tempfile.mkdtemp(), "w.spvw"); weights.save(plan, p)
 ctx = capi.Context(net_height=H, net_width=Wd); ctx.load_weights(p)
-x = np.random.RandomState(0).rand(2, 1, H, Wd).astype(np.float32)
+x = np.random.RandomState(0).rand(B, 1, H, Wd).astype(np.float32)
 for _ in range(30): ctx.forward(x)
 ctx.profile_enable(True); ctx.profile_reset()
 for _ in range(200): ctx.forward(x)
@@ -52,8 +53,8 @@ while i < len(plan.ops):
             continue
         lvl_in, lvl_out = plan.tensors[o.inp][1], plan.tensors[o.out][1]
         px_in, px_out = (H >> lvl_in) * (Wd >> lvl_in), (H >> lvl_out) * (Wd >> lvl_out)
-        alg += 2.0 * 2 * px_in * o.cout * o.cin * o.ksize * o.ksize
-        byts += 2 * 4 * (px_in * o.cin + px_out * o.cout) + o.weight.size * 4
+        alg += 2.0 * B * px_in * o.cout * o.cin * o.ksize * o.ksize
+        byts += B * 4 * (px_in * o.cin + px_out * o.cout) + o.weight.size * 4
     if st.get("bytes", 0) > 0:      # the library's own statement of the launch's algorithmic bytes (element sizes of the engine's tensors)
         byts = st["bytes"]
     o0 = ops[0]
@@ -76,7 +77,7 @@ while i < len(plan.ops):
     rows.append(row)
     tot_us += us; tot_exec += executed; tot_alg += alg
     i += step
-res = {"_how": f"tools/layer_roofline_json.py on one MI355X: VGG SuperPoint {prec.lower()}, net {H}x{Wd}, both images per launch, 200 forward passes with every layer "
+res = {"_how": f"tools/layer_roofline_json.py on one MI355X: VGG SuperPoint {prec.lower()}, net {H}x{Wd}, {B} images per launch, 200 forward passes with every layer "
                "bracketed by HIP events (spvo_profile_*); layers run back to back, nothing else on the chip",
        "precision": prec, "peak_mfma_tflops": PEAK, "ridge_flop_per_byte": round(PEAK * 1e12 / (HBM * 1e9), 1), "layers": rows,
        "conv_stack": {"sum_of_layers_us": round(tot_us, 1), "algorithmic_gflop": round(tot_alg / 1e9, 2), "executed_gflop": round(tot_exec / 1e9, 2),
