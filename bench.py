@@ -28,6 +28,18 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+
+def _early_cpu_limit(argv):
+    """`--cpus N`: restrict the process to N CPUs before numpy / torch / HIP create their helper threads (they inherit the mask)."""
+    for k, a in enumerate(argv):
+        n = a.split("=", 1)[1] if a.startswith("--cpus=") else (argv[k + 1] if a == "--cpus" and k + 1 < len(argv) else None)
+        if n and int(n) > 0 and hasattr(os, "sched_setaffinity"):
+            os.sched_setaffinity(0, set(sorted(os.sched_getaffinity(0))[:int(n)]))
+
+
+if __name__ == "__main__":
+    _early_cpu_limit(sys.argv[1:])
+
 import numpy as np  # noqa: E402
 
 NET_H, NET_W = 360, 1176
@@ -193,10 +205,14 @@ def spawn_ranks(n, cmd=None, deadline_s=None, grace_s=5.0, poll_s=0.1):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        logs.append(open(os.path.join(logdir, f"rank{r}.stderr"), "w+b"))
+        # rank 0 writes to OUR stdout and stderr as it goes (the JSON line, progress and [spvo] diagnostics of a long job are visible live);
+        # the other ranks' stderr is captured and shown only if one of them fails
+        logs.append(None if r == 0 else open(os.path.join(logdir, f"rank{r}.stderr"), "w+b"))
         procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else subprocess.DEVNULL, stderr=logs[-1]))
 
     def tail(r, nbytes=3000):
+        if logs[r] is None:
+            return "(rank 0 wrote to this process's stderr: see above)"
         logs[r].flush()
         logs[r].seek(0, os.SEEK_END)
         size = logs[r].tell()
@@ -237,23 +253,24 @@ def spawn_ranks(n, cmd=None, deadline_s=None, grace_s=5.0, poll_s=0.1):
                 failed, rc = -1, 124
                 break
             time.sleep(poll_s)
+        if failed is not None:
+            stop_all()
+            if failed >= 0:
+                sys.stderr.write(f"bench.py: rank {failed} of {n} exited with code {rc}; the other ranks were terminated.  Its stderr ends:\n{tail(failed)}\n")
+            else:
+                sys.stderr.write(f"bench.py: the {n} ranks did not finish within {deadline_s:.0f} s and were terminated.\n")
+        return rc
     except Stopped as st:
         stop_all()
         return 128 + int(st.args[0])
-    finally:
+    finally:   # every path, the stopped one included: handlers back, log files closed, the temporary directory gone
         for sg, h in old.items():
             signal.signal(sg, h)
-    if failed is not None:
-        stop_all()
-        if failed >= 0:
-            sys.stderr.write(f"bench.py: rank {failed} of {n} exited with code {rc}; the other ranks were terminated.  Its stderr ends:\n{tail(failed)}\n")
-        else:
-            sys.stderr.write(f"bench.py: the {n} ranks did not finish within {deadline_s:.0f} s and were terminated.  Rank 0's stderr ends:\n{tail(0)}\n")
-    else:
-        sys.stderr.write(tail(0, 1 << 20))   # rank 0's diagnostics, as if it had written them itself
-    for f in logs:
-        f.close()
-    return rc
+        for f in logs:
+            if f is not None:
+                f.close()
+        import shutil
+        shutil.rmtree(logdir, ignore_errors=True)
 
 
 def repeats_for(first_elapsed, target_s=1.0):
@@ -298,6 +315,8 @@ def main():
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 5],
                     help="BASELINE.json config shortcut: 2 = default; 3 = FP16 192x640; 5 = sp_mbv1 INT8, 2048 keypoints, fp8 shortlist")
     ap.add_argument("--dump-ops", action="store_true", help="add per-layer network times to the JSON line")
+    ap.add_argument("--cpus", type=int, default=0, help="restrict this process to that many CPUs (os.sched_setaffinity, BEFORE anything touches the GPU): what one rank of an "
+                                                          "8-rank job gets of the GPU box's 16-CPU quota is 2 -- the host-budget check of DESIGN.md section 6")
     ap.add_argument("--depth", type=int, default=4, choices=[1, 2, 3, 4], help="stereo pairs handed over ahead of the one being solved; at 4 the front end pairs trunks (two stereo pairs per set of network launches: spvo_set_trunk_pairing)")
     args = ap.parse_args()
     if args.config == 3:
@@ -314,12 +333,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    os.environ["SPVO_DEVICE"] = str(local_rank)
     os.environ.setdefault("SPVO_QUIET", "1")    # the seeded (untrained) weights make the reference's gating message fire on every frame
-    if args.max_keypoints != 1000:
-        os.environ["SPVO_MAX_KEYPOINTS"] = str(args.max_keypoints)
-    if args.match_fp8:
-        os.environ["SPVO_MATCH_FP8"] = "1"
     if args.fp32_split:
         if args.precision != "FP32":
             raise SystemExit("--fp32-split applies to FP32 engines")
@@ -334,7 +348,6 @@ def main():
     shared = os.environ.get("SPVO_BENCH_SHARED_GPU") == "1"
     if shared:
         local_rank = local_rank % torch.cuda.device_count()
-        os.environ["SPVO_DEVICE"] = str(local_rank)
     elif local_rank >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, {torch.cuda.device_count()} visible (one rank per GPU; --gpus {args.gpus})")
     torch.cuda.set_device(local_rank)
@@ -356,6 +369,9 @@ def main():
     if world > 1:   # several ranks share the host: an equal share of the CPUs this job may really use (cgroup quota, not the host's core count)
         torch.set_num_threads(max(1, usable_cpus() // world))
     from spvo import capi, host, posegather, synth, weights
+    # device, keypoint cap and fp8 shortlist of the front ends created below: the host class's setters (setDevice, setMaxKeypoints,
+    # setMatchFp8), not environment variables
+    host.set_options(device=local_rank, max_keypoints=args.max_keypoints, match_fp8=1 if args.match_fp8 else 0)
     capi.tuning_from_env()   # SPVO_TUNE_<NAME>=<int>: diagnostic switches for A/B runs of this script (the library itself never reads the environment)
     if args.fp32_split:
         capi.set_tuning("fp32_split", 1)   # engines loaded from here on run in split mode (the library reads no environment variable for it)
@@ -526,6 +542,7 @@ def main():
                                    + ("fp8 shortlist + exact re-rank, " if args.match_fp8 else "")
                                    + "BF+KNN 0.8, P3P-style RANSAC 500 it, LM refinement degree 4; one stereo stream per GPU, RCCL all-gather of poses",
                        "net_size": [NET_H, NET_W], "input_size": [rows, cols], "streams": world,
+                       "host_cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
                        "hand_over": ("images of the next %d pairs handed over ahead (prefetchStereoImagePairDevice)" % args.depth + ("; with four ahead the front end pairs trunks: a pair whose network would only queue waits for its successor and the two run through every layer in one launch (spvo_set_trunk_pairing)" if args.depth >= 4 else "") if not args.no_pipeline else "one pair at a time")
                                     + ("; each frame's solve handed over too, its pose collected during the next step (solveStereoOdometrySubmit / Collect), the last one before the closing barrier" if deferred else ""),
                        "pose_gather": {"local": "single stream, no collective", "c:rccl": "spvo_pose_allgather_n (C ABI, RCCL), one collective per 64 frames",
@@ -773,17 +790,12 @@ def main():
                     odir = os.path.join(tmp, oname)
                     os.makedirs(os.path.join(odir, "laptop"), exist_ok=True)
                     weights.save(oplan, os.path.join(odir, "laptop", weights.engine_name(oprefix, 2, oh, ow, oprec)))
-                    oenv = {"SPVO_MAX_KEYPOINTS": str(okp) if okp != 1000 else None, "SPVO_MATCH_FP8": "1" if ofp8 else None}
-                    for k, v in oenv.items():
-                        if v is not None:
-                            os.environ[k] = v
+                    host.set_options(device=local_rank, max_keypoints=okp, match_fp8=1 if ofp8 else 0)
                     try:
                         fe = host.FrontEnd(odir, prefix=oprefix, selector="KNN", cross_check=True, batch=2, height=oh, width=ow, conf_thresh=0.015,
                                            dist_thresh=4, border_remove=4, stereo_threshold=2.0, min_disparity=0.25, refinement_degree=4, precision=oprec)
                     finally:
-                        for k, v in oenv.items():
-                            if v is not None:
-                                del os.environ[k]
+                        host.set_options(device=local_rank, max_keypoints=args.max_keypoints, match_fp8=1 if args.match_fp8 else 0)
                     if not fe.engine_loaded:
                         raise RuntimeError("engine load failed: " + fe.last_error)
                     for i in range(args.warmup):

@@ -172,7 +172,7 @@ int spvo_set_trunk_pairing(spvo_ctx *ctx, int on);
 
 /* The asynchronous form for images in HOST memory -- what a ROS node holds (cv_bridge::toCvCopy, node.cpp:163-168).
  * _submit copies the two images into pinned staging buffers of the submission (the caller's buffers are free when it
- * returns), queues the host-to-device copies and the whole detector chain behind them and returns; up to three
+ * returns), queues the host-to-device copies and the whole detector chain behind them and returns; up to six
  * submissions may be in flight, exactly as with spvo_detect_dev_submit (same slot rules).  `extras`: bit 0 = the resized
  * u8 images (nn.cpp:154, images_dq), bit 1 = the descriptors (descriptors_dq) also travel back, into pinned mirrors of
  * the submission.  _collect completes the OLDEST submission (of either kind) like spvo_detect_wait and hands out what was
@@ -186,8 +186,8 @@ int spvo_detect_collect(spvo_ctx *ctx, double P_l[12], double P_r[12], spvo_feat
  * pinned host mirrors -- n[i] keypoints, xy[i] (n[i] x 2 floats), desc[i] (n[i] x 256 floats; NULL unless `extras` bit 1 was
  * set at spvo_detect_submit), resized[i] (net_height x net_width u8; NULL unless bit 0 was set), i = 0 left, 1 right.  The
  * kernels that produce these results write them there; a caller that owns the final containers (descriptors_dq / images_dq,
- * nn.cpp:154, 494-498) copies each of them ONCE, when it suits it.  The pointers stay valid until three more submissions
- * have been made on this context (each submission owns one of four sets of mirrors) or the context is destroyed. */
+ * nn.cpp:154, 494-498) copies each of them ONCE, when it suits it.  The pointers stay valid until seven more submissions
+ * have been made on this context (each submission owns one of eight sets of mirrors) or the context is destroyed. */
 typedef struct {
   int n[2];
   const float *xy[2];
@@ -259,6 +259,8 @@ int spvo_set_prematch(spvo_ctx *ctx, int enable, int selector, int cross_check, 
  * pass every column whose rigorous lower bound (from the per-row norms of the fp8 rounding residuals) does not exceed the
  * second canonical distance found -- indices and distances are the brute-force ones on every row (csrc/match.hip.h). */
 int spvo_set_match_fp8(spvo_ctx *ctx, int enable);
+/* 1 / 0: the fp8 shortlist is on / off in this context (what the host class's setMatchFp8 asked for); negative: error. */
+int spvo_get_match_fp8(const spvo_ctx *ctx);
 
 /* cv::triangulatePoints + convertPointsFromHomogeneous (base.cpp:211-223):
  * DLT null vector of the 4x4 system in f64, stored f32, then x/w.

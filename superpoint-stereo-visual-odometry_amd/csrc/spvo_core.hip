@@ -38,7 +38,7 @@ int stage_id(spvo_ctx *c, const std::string &name) {
 // ---- diagnostic switches (include/spvo.h: spvo_set_tuning).  One process-wide table, filled by explicit calls only.
 namespace {
 const char *const kTuningNames[] = {"winograd", "wino4", "wino_narrow", "wino_dynamic", "winograd_min_tiles", "wino4_min_tiles", "merge_siblings", "heads_fused",
-                                    "heads_on_net", "heads_split", "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing", "nms_first", "upload_side"};
+                                    "heads_on_net", "heads_split", "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing", "nms_first", "upload_side", "inject_launch_failure"};
 constexpr int kTuningCount = sizeof kTuningNames / sizeof kTuningNames[0];
 std::mutex g_tuning_mutex;
 bool g_tuning_set[kTuningCount] = {};
@@ -195,6 +195,9 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c->H = cfg->net_height; c->W = cfg->net_width; c->Hc = c->H / 8; c->Wc = c->W / 8;
   c->nms_first = std::min(std::max(tuning("nms_first", 4), 1), NMS_MAX_LAUNCH);   // (diagnostic override)
+  c->trunk_timing = tuning("trunk_timing", 0);
+  c->solve_timing = tuning("solve_timing", 0);
+  c->inject_launch_failure = tuning("inject_launch_failure", 0);
   c->B = 4;   // images the activation buffers hold: two stereo pairs per trunk launch (spvo_set_trunk_pairing)
   // Non-blocking streams: work the caller puts on the NULL stream (a framework's default stream, a blocking hipMemcpy) must not
   // serialise the three streams of the pipeline against each other.  Device pointers handed to the *_dev entry points
@@ -284,6 +287,9 @@ void spvo_destroy(spvo_ctx *c) {
   if (c->ev_solve) (void)hipEventDestroy(c->ev_solve);
   if (c->ev_post) (void)hipEventDestroy(c->ev_post);
   resolve_pending(c);
+  for (int r = 0; r < TrunkDiag::TT; ++r)
+    for (hipEvent_t e : {c->tdiag.b[r], c->tdiag.e[r], c->tdiag.tb[r], c->tdiag.te[r]}) if (e) (void)hipEventDestroy(e);
+  if (c->tdiag.base) (void)hipEventDestroy(c->tdiag.base);
   for (auto e : c->free_events) (void)hipEventDestroy(e);
   free_plan(c);
   void *ptrs[] = {c->d_dense_in, c->d_det_dense, c->d_resized, c->d_tab, c->d_img[0], c->d_img[1], c->d_xy_tmp, c->d_desc_tmp,

@@ -379,7 +379,8 @@ static int enqueue_prematch(spvo_ctx *c, int slot_l, int slot_r, int prev_l, int
 // the grouping: the kernels were selected for two images at engine load and every tile is computed the same way wherever it runs
 // (tests/test_gpu_host.py::test_prefetch_pipeline_is_transparent, depths 3 and 4).
 static int ensure_host_sets(spvo_ctx *c, size_t image_bytes);
-static int launch_group(spvo_ctx *c);
+static int launch_group(spvo_ctx *c, bool from_submit = false);
+static int launch_group_body(spvo_ctx *c);
 
 // host_l / host_r != NULL: the images are in HOST memory -- they are staged through the set's pinned buffers and copied to the
 // device on the network stream (d_l, d_r are then ignored); extras: see PendingDetect
@@ -451,7 +452,7 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   // trunk is still queued or running (so nothing idles while it waits)
   const bool earlier_trunk_pending = c->last_launch_ring >= 0 && hipEventQuery(c->ev_net[c->last_launch_ring]) == hipErrorNotReady;
   if (c->pair_trunks && c->held == 1 && earlier_trunk_pending) return SPVO_OK;
-  return launch_group(c);
+  return launch_group(c, true);
 }
 
 extern "C++" {
@@ -463,8 +464,34 @@ int release_held_if_idle(spvo_ctx *c) {
 }  // namespace spvo_int
 }
 
+// Launches the held pairs and keeps the queue consistent when that fails (a HIP error in a layer launch, the NMS rounds, an event
+// record): the members' events were never recorded, so nothing may wait for them.  A member the caller has been told about (its submit
+// returned SPVO_OK earlier) stays queued, marked `failed`: spvo_detect_wait / _collect takes it off the queue and returns the error, so the
+// host's queue of accepted pairs and this one stay in step.  The member whose submit call is failing right now (`from_submit`) leaves
+// the queue: that caller never counted it.
+static int launch_group(spvo_ctx *c, bool from_submit) {
+  const int n = c->held;
+  if (n <= 0) return SPVO_OK;
+  const int rc = launch_group_body(c);
+  if (rc == SPVO_OK) return rc;
+  const std::string why = c->error;
+  c->held = 0;
+  c->post = c->stream;
+  c->cur_ring = 0;
+  for (int m = 0; m < n && m < (int)c->pendq.size(); ++m) {
+    PendingDetect &pd = c->pendq[c->pendq.size() - 1 - m];
+    pd.failed = true;
+    pd.launched = false;
+    c->slots[pd.slot_l].filled = c->slots[pd.slot_r].filled = false;
+    if (c->last_slot_l == pd.slot_l) c->last_slot_l = -1;
+  }
+  if (from_submit && !c->pendq.empty()) c->pendq.pop_back();
+  c->error = why;
+  return rc;
+}
+
 // phases B (the trunk of the held pairs: one or two, 2 or 4 images per launch) and C (each pair's tail)
-static int launch_group(spvo_ctx *c) {
+static int launch_group_body(spvo_ctx *c) {
   const int n = c->held;
   if (n <= 0) return SPVO_OK;
   if (n > 2 || (int)c->pendq.size() < n) return fail(c, SPVO_ERR_STATE, "internal: %d held submissions, %zu in flight", n, c->pendq.size());
@@ -478,14 +505,18 @@ static int launch_group(spvo_ctx *c) {
   c->post = c->stream;
   // tuning "trunk_timing" = 1 (diagnostic): how long the network stream works per trunk launch and how long it stands idle between two,
   // from timing events at both ends of the trunk (printed every 200 launches)
-  static const bool trunk_timing = tuning("trunk_timing", 0) != 0;
-  constexpr int TT = 16;   // ring of timing events: deeper than the launches that can be in flight
-  static hipEvent_t tt_b[TT], tt_e[TT], tt_tb[TT], tt_te[TT];   // trunk begin / end (network stream), tail begin / end (tail stream)
-  static double tt_tail = 0, tt_lag = 0;
-  static int tt_np[TT];
-  static long tt_n = 0;
-  static double tt_busy = 0, tt_idle = 0, tt_pairs = 0;
-  static const int trace_lo = tuning("trunk_timing", 0);   // > 1: one line per launch from that launch on (80 of them), with the host clock
+  // -- the switch is read when the context is created (spvo_create), its timing events and sums belong to the context
+  TrunkDiag &td_ = c->tdiag;
+  const bool trunk_timing = c->trunk_timing != 0;
+  constexpr int TT = TrunkDiag::TT;   // ring of timing events: deeper than the launches that can be in flight
+  hipEvent_t *tt_b = td_.b, *tt_e = td_.e, *tt_tb = td_.tb, *tt_te = td_.te;   // trunk begin / end (network stream), tail begin / end (tail stream)
+  double &tt_tail = td_.tail, &tt_lag = td_.lag;
+  int *tt_np = td_.np;
+  long &tt_n = td_.n;
+  double &tt_busy = td_.busy, &tt_idle = td_.idle, &tt_pairs = td_.pairs;
+  const int trace_lo = c->trunk_timing;   // > 1: one line per launch from that launch on (80 of them), with the host clock
+  if (c->inject_launch_failure > 0 && ++c->launch_count == c->inject_launch_failure)   // tests of the error path (tuning "inject_launch_failure")
+    return fail(c, SPVO_ERR_DEVICE, "injected launch failure (diagnostic switch)");
   if (trunk_timing) {
     const double tnow = diag_now_us();
     const bool found_idle = c->last_launch_ring >= 0 && hipEventQuery(c->ev_net[c->last_launch_ring]) == hipSuccess;
@@ -506,20 +537,20 @@ static int launch_group(spvo_ctx *c) {
     if (tt_n >= TT) {   // the launches before those that may be in flight are complete: ring slots (n-8) and (n-9)
       const int r2 = (int)((tt_n - 8) % TT), r3 = (int)((tt_n - 9) % TT);
       float busy = 0, idle = 0;
-      static int tt_late = 0;
-      static float tt_max = 0;
+      int &tt_late = td_.late;
+      float &tt_max = td_.max_idle;
       if (hipEventElapsedTime(&busy, tt_b[r2], tt_e[r2]) == hipSuccess && hipEventElapsedTime(&idle, tt_e[r3], tt_b[r2]) == hipSuccess) {
         tt_busy += busy; tt_idle += idle;
         tt_late += idle > 0.05f ? 1 : 0;
         tt_max = std::max(tt_max, idle);
       }
-      static std::string tt_pat;
+      std::string &tt_pat = td_.pat;
       tt_pat += (char)('0' + tt_np[r2]);
       if (idle > 0.05f) tt_pat += idle > 0.3f ? 'I' : 'i';
       if (tt_n % 200 == 0) { std::fprintf(stderr, "[spvo]   pairs per launch (i / I: the stream stood idle > 50 / > 300 us in front of it): %s\n", tt_pat.c_str()); tt_pat.clear(); }
       if (trace_lo > 1) {   // device-side times of launch (tt_n - 8), relative to the first trace line's moment
-        static hipEvent_t base = nullptr;
-        static double base_host = 0;
+        hipEvent_t &base = td_.base;
+        double &base_host = td_.base_host;
         if (!base && g_diag.launches >= trace_lo - 8) { (void)hipEventCreate(&base); (void)hipEventRecord(base, c->stream_t); (void)hipEventSynchronize(base); base_host = diag_now_us(); }
         float b0 = 0, e0 = 0, tb0 = 0, te0 = 0;
         if (base && g_diag.launches - 8 >= trace_lo && g_diag.launches - 8 < trace_lo + 80 && hipEventElapsedTime(&b0, base, tt_b[r2]) == hipSuccess &&
@@ -645,9 +676,21 @@ static int launch_group(spvo_ctx *c) {
 static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_features *out_l, spvo_features *out_r, uint8_t *resized_l, uint8_t *resized_r,
                        spvo_detect_mirrors *mirrors = nullptr) {
   if (c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "no detector submission in flight");
+  if (c->pendq.front().failed) {   // its group's launch failed after the submission had been accepted (launch_group): nothing of it is in flight
+    c->pendq.pop_front();
+    const std::string why = c->error;
+    return fail(c, SPVO_ERR_STATE, "the submission's network launch had failed: %s", why.c_str());
+  }
   if (!c->pendq.front().launched) {   // a pair that was held for a partner (trunk pairing) and is asked for first: it runs alone
+    if (c->held == 0) {   // unlaunched with nothing held: no event of it was ever recorded -- never wait for one
+      c->pendq.pop_front();
+      return fail(c, SPVO_ERR_STATE, "internal: an unlaunched submission with no group held");
+    }
     const int rcl = launch_group(c);
-    if (rcl) return rcl;
+    if (rcl) {            // (launch_group marked it failed; it is the front of the queue)
+      if (!c->pendq.empty() && c->pendq.front().failed) c->pendq.pop_front();
+      return rcl;
+    }
   }
   const PendingDetect pd = c->pendq.front();
   const int slots[2] = {pd.slot_l, pd.slot_r};

@@ -130,13 +130,32 @@ struct PendingDetect {           // one spvo_detect*_submit in flight
   int extras = 0;                // spvo_detect_submit: bit 0 resized images, bit 1 descriptors travel to the set's pinned mirrors
   bool early_res = false;        // the resized images leave for their pinned mirror behind the first layer (copy kernel on the tail stream, ev_res), under the network
   bool launched = false;         // its trunk and tail are enqueued (false: held for a partner, spvo_set_trunk_pairing)
+  bool failed = false;           // its group's launch failed after the submission had been accepted: spvo_detect_wait / _collect takes it off the queue and reports that
   int img0 = 0;                  // its first image in the network's planes (0, or 2 as the second pair of a group)
   int tring = 0;                 // the set whose network outputs hold its detector / descriptor maps (its own, or its group's first)
 };
 
 
+// tuning "trunk_timing" (diagnostic): timing events at both ends of every trunk and tail, and what is summed from them
+struct TrunkDiag {
+  static constexpr int TT = 16;
+  hipEvent_t b[TT] = {}, e[TT] = {}, tb[TT] = {}, te[TT] = {};
+  hipEvent_t base = nullptr;
+  double base_host = 0, tail = 0, lag = 0, busy = 0, idle = 0, pairs = 0;
+  int np[TT] = {};
+  long n = 0;
+  int late = 0;
+  float max_idle = 0;
+  std::string pat;
+};
+
 struct spvo_ctx {
   spvo_config cfg;
+  int trunk_timing = 0, solve_timing = 0;   // diagnostic switches, read at spvo_create (spvo_set_tuning: "takes effect for contexts created afterwards")
+  int inject_launch_failure = 0, launch_count = 0;   // tests of launch_group's error path: the n-th group launch of this context fails
+  TrunkDiag tdiag;
+  double solve_tacc[4] = {0, 0, 0, 0};
+  long solve_tcalls = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // fused solve: overlaps with a detector submission in flight
   hipStream_t stream_t = nullptr;  // detector tail (heat map, NMS, sampling, matching): overlaps with the NEXT submission's network

@@ -230,7 +230,8 @@ int spvo_match_hamming(spvo_ctx *c, const uint8_t *desc_a, int na, const uint8_t
 int spvo_match_slots(spvo_ctx *c, int slot_a, int slot_b, int selector, int cross_check, float ratio, int32_t *train_idx, float *distance) {
   if (!c || slot_a < 0 || slot_a >= N_SLOTS || slot_b < 0 || slot_b >= N_SLOTS) return fail(c, SPVO_ERR_INVALID, "bad slot");
   if (selector != SPVO_SELECT_NN && selector != SPVO_SELECT_KNN) return fail(c, SPVO_ERR_INVALID, "bad selector");
-  (void)release_held_if_idle(c);
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  (void)release_held_if_idle(c);   // (a failing launch is reported by that pair's spvo_detect_wait: launch_group)
   const FeatureSlot &a = c->slots[slot_a], &b = c->slots[slot_b];
   if (a.n > 0 && (!train_idx || !distance)) return fail(c, SPVO_ERR_INVALID, "null output");
   for (int set = 0; set < RING; ++set) {   // already computed alongside the detector (spvo_set_prematch)?
@@ -278,5 +279,7 @@ int spvo_set_match_fp8(spvo_ctx *c, int enable) {
     for (auto &mc : set) mc.valid = false;
   return SPVO_OK;
 }
+
+int spvo_get_match_fp8(const spvo_ctx *c) { return c ? (c->match_fp8 ? 1 : 0) : SPVO_ERR_INVALID; }
 
 }  // extern "C"

@@ -143,13 +143,15 @@ int spvo_pnp_refine(spvo_ctx *c, const double P_l[12], const double P_r[12], con
 int spvo_solve_submit(spvo_ctx *c, const spvo_solve_input *in) {
   if (!c || !in) return fail(c, SPVO_ERR_INVALID, "null argument");
   if (c->solve_pending.active) return fail(c, SPVO_ERR_STATE, "a solve is pending: complete it with spvo_solve_wait first");
-  (void)release_held_if_idle(c);
   const int n = in->n;
   if (n < 0 || (n > 0 && (!in->xy_cl || !in->xy_cr || !in->xy_pl || !in->xy_pr))) return fail(c, SPVO_ERR_INVALID, "bad argument");
   if (in->ransac.iterations <= 0 || in->ransac.iterations > 65536 || !(in->ransac.reproj_error > 0) || in->refine.max_iterations < 0 ||
       !(in->refine.huber_delta > 0))
     return fail(c, SPVO_ERR_INVALID, "bad solver options");
   HIP_TRY(c, hipSetDevice(c->cfg.device));
+  // (a held pair's launch that fails here is not this call's failure: launch_group marks the submission, and the spvo_detect_wait /
+  // _collect that asks for it reports the error)
+  (void)release_held_if_idle(c);
   spvo_ctx::SolvePending pend;
   pend.n = n; pend.refinement_degree = in->refinement_degree;
   for (int k = 0; k < 3; ++k) { pend.rvec[k] = in->rvec_pred[k]; pend.tvec[k] = in->tvec_pred[k]; }
@@ -178,9 +180,9 @@ int spvo_solve_submit(spvo_ctx *c, const spvo_solve_input *in) {
     c->solve_cap = cap;
   }
   if (grow) HIP_TRY(c, hipDeviceSynchronize());
-  static const bool solve_timing = tuning("solve_timing", 0) != 0;   // diagnostic: host time per phase of this call
-  static double tacc[4] = {0, 0, 0, 0};
-  static long tcalls = 0;
+  const bool solve_timing = c->solve_timing != 0;   // diagnostic (read at spvo_create): host time per phase of this call
+  double *tacc = c->solve_tacc;
+  long &tcalls = c->solve_tcalls;
   auto now_us = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
   const double tm0 = solve_timing ? now_us() : 0;
   // ---- pack: 64 doubles, then cl cr pl pr [2n each], prev_xyz [3n], prev_valid [n]
@@ -247,7 +249,7 @@ int spvo_solve_submit(spvo_ctx *c, const spvo_solve_input *in) {
 int spvo_solve_wait(spvo_ctx *c, spvo_solve_output *out, float *xyz, int32_t *inliers) {
   if (!c || !out) return fail(c, SPVO_ERR_INVALID, "null argument");
   if (!c->solve_pending.active) return fail(c, SPVO_ERR_STATE, "no solve pending");
-  (void)release_held_if_idle(c);
+  if (hipSetDevice(c->cfg.device) == hipSuccess) (void)release_held_if_idle(c);   // (a failing launch is reported by that pair's spvo_detect_wait: launch_group)
   const spvo_ctx::SolvePending pend = c->solve_pending;
   const int n = pend.n;
   if (n > 0 && (!xyz || !inliers)) return fail(c, SPVO_ERR_INVALID, "bad argument");   // (the solve stays pending)

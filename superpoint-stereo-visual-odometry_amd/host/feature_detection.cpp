@@ -79,11 +79,20 @@ void FeatureFrontEnd::initMatcher() {
   }
 }
 
+static int g_device = -1;   // FeatureFrontEnd::setDevice
+void FeatureFrontEnd::setDevice(int device) { g_device = device; }
+static int configured_device() {
+  if (g_device >= 0) return g_device;
+  if (const char *dev = std::getenv("SPVO_DEVICE")) return std::atoi(dev);
+  return 0;
+}
+
 bool FeatureFrontEnd::ensureContext() {
   if (ctx_) return true;
   spvo_config cfg;
   spvo_default_config(&cfg);
-  if (const char *dev = std::getenv("SPVO_DEVICE")) cfg.device = std::atoi(dev);
+  cfg.device = configured_device();
+  solve_timing_ = spvo_get_tuning("solve_timing", 0) != 0;
   if (input_height_ > 0 && input_width_ > 0) {
     cfg.net_height = (input_height_ + 7) / 8 * 8;   // only the pre-processing geometry matters to a context without an engine
     cfg.net_width = (input_width_ + 7) / 8 * 8;
@@ -224,9 +233,9 @@ void FeatureFrontEnd::solveStereoOdometry(tf2::Transform &cam0_curr_T_cam0_prev)
 // Nothing of the front end's state changes here except the per-frame maps of the join; the result is taken by
 // solveStereoOdometryCollect, which has to run before the next frame's join (that one needs this frame's points and prior).
 bool FeatureFrontEnd::solveStereoOdometrySubmit() {
-  static const bool timing = spvo_get_tuning("solve_timing", 0) != 0;   // diagnostic (spvo_set_tuning)
-  static double acc[3] = {0, 0, 0};
-  static long calls = 0;
+  const bool timing = solve_timing_;   // diagnostic (spvo_set_tuning "solve_timing", read when this front end created its context)
+  double *acc = solve_timing_acc_;
+  long &calls = solve_timing_calls_;
   const double th0 = timing ? host_now_us() : 0;
   if (solve_pending_) {
     logError("solveStereoOdometrySubmit: the previous solve has not been collected");
@@ -551,8 +560,11 @@ void ClassicFeatureFrontEnd::addStereoImagePair(cv::Mat &img_l, cv::Mat &img_r, 
 
 // ------------------------------------------------------------------------- SuperPoint front end
 static std::string g_models_dir;
+static int g_max_keypoints = -1, g_match_fp8 = -1;
 
 void SuperPointFeatureFrontEnd::setModelsDir(const std::string &dir) { g_models_dir = dir; }
+void SuperPointFeatureFrontEnd::setMaxKeypoints(int cap) { g_max_keypoints = cap; }
+void SuperPointFeatureFrontEnd::setMatchFp8(int on) { g_match_fp8 = on; }
 
 SuperPointFeatureFrontEnd::SuperPointFeatureFrontEnd()
     : SuperPointFeatureFrontEnd(MatcherType::BF, SelectorType::NN, true, "superpoint_pretrained", 2, "laptop", TRT_FP32, 120, 392,
@@ -582,7 +594,8 @@ SuperPointFeatureFrontEnd::~SuperPointFeatureFrontEnd() {
 void SuperPointFeatureFrontEnd::loadEngine() {
   spvo_config cfg;
   spvo_default_config(&cfg);
-  if (const char *dev = std::getenv("SPVO_DEVICE")) cfg.device = std::atoi(dev);
+  cfg.device = configured_device();
+  solve_timing_ = spvo_get_tuning("solve_timing", 0) != 0;
   cfg.net_height = input_height_;
   cfg.net_width = input_width_;
   // model_batch_size_ only changes how the reference batches its TensorRT calls (hpp:342-344);
@@ -591,7 +604,8 @@ void SuperPointFeatureFrontEnd::loadEngine() {
   cfg.conf_thresh = conf_thresh_;
   cfg.dist_thresh = dist_thresh_;
   cfg.border_remove = border_remove_;
-  if (const char *mk = std::getenv("SPVO_MAX_KEYPOINTS")) max_keypoints_ = std::max(1, std::atoi(mk));
+  if (g_max_keypoints > 0) max_keypoints_ = g_max_keypoints;
+  else if (const char *mk = std::getenv("SPVO_MAX_KEYPOINTS")) max_keypoints_ = std::max(1, std::atoi(mk));
   cfg.max_keypoints = max_keypoints_;
   if (const char *bc = std::getenv("SPVO_BUG_COMPAT_P")) cfg.bug_compat_p = std::atoi(bc);
   if (model_batch_size_ != 1 && model_batch_size_ != 2) {
@@ -620,7 +634,7 @@ void SuperPointFeatureFrontEnd::loadEngine() {
   logInfo("engine file `" + model_name_full + "` loaded");
   // stereoCallback always asks for CURR_LEFT->CURR_RIGHT and CURR_LEFT->PREV_LEFT right after the
   // detector (node.cpp:196-198): have them enqueued in the detector's own submission
-  if (std::getenv("SPVO_MATCH_FP8")) spvo_set_match_fp8(ctx_, 1);   // fp8 shortlist GEMM (config 5; the GEMM only prunes, two-pass exact re-rank)
+  if (g_match_fp8 >= 0 ? g_match_fp8 != 0 : std::getenv("SPVO_MATCH_FP8") != nullptr) spvo_set_match_fp8(ctx_, 1);   // fp8 shortlist GEMM (config 5; the GEMM only prunes, two-pass exact re-rank)
   if (matcher_ready_ && spvo_get_tuning("prematch", 1))
     spvo_set_prematch(ctx_, 1, selector_type_ == SelectorType::KNN ? SPVO_SELECT_KNN : SPVO_SELECT_NN, matcher_cross_check_ ? 1 : 0, knn_threshold_);
   for (int i = 0; i < 2; ++i) {

@@ -214,6 +214,9 @@ public:
   bool solveStereoOdometrySubmit();
   bool solveStereoOdometryCollect(tf2::Transform &cam0_curr_T_cam0_prev);
   bool solvePending() const { return solve_pending_; }
+  // Extension: the HIP device the front ends constructed AFTERWARDS create their context on (one process per GPU sets its local
+  // rank here).  < 0 (default): environment variable SPVO_DEVICE, else device 0.
+  static void setDevice(int device);
   // Extension: finish whatever a front end still has to copy into images_dq / descriptors_dq (SuperPointFeatureFrontEnd defers the
   // bulk copies of a host-image pair until the solver's kernels are running: see there).  Every entry point of this class calls it
   // where it matters; code that reads the deques DIRECTLY between addStereoImagePair and solveStereoOdometry calls it first.
@@ -264,6 +267,9 @@ protected:
   bool matcher_ready_ = false;
   bool matcher_cross_check_ = false;
   bool solve_pending_ = false;     // solveStereoOdometrySubmit .. Collect
+  bool solve_timing_ = false;      // tuning "solve_timing", read when the context is created
+  double solve_timing_acc_[3] = {0, 0, 0};
+  long solve_timing_calls_ = 0;
   int solve_n_ = 0;
   std::vector<float> solve_pts3d_;
   bool matcher_hamming_ = false;   // NORM_HAMMING descriptors of the classic front end (base.cpp:13-28): spvo_match_hamming
@@ -355,6 +361,11 @@ public:
   // environment variable SPVO_MODELS_DIR, or setModelsDir() before construction.
   void loadEngine();
   static void setModelsDir(const std::string &dir);
+  // Build-side options that change RESULTS, set like the models dir: before construction, for the front ends constructed afterwards
+  // (the 17-argument constructor is the reference's and has no room for them).  A value < 0 (the default) leaves the decision to the
+  // environment variable named beside it, which is kept as a fallback for unchanged launch files; 0 / a positive value overrides it.
+  static void setMaxKeypoints(int cap);   // keypoint cap per image (hpp:368: 1000; BASELINE config 5: 2048); env SPVO_MAX_KEYPOINTS
+  static void setMatchFp8(int on);        // fp8 shortlist GEMM in the matcher (exact re-rank behind it, config 5); env SPVO_MATCH_FP8
 
   void addStereoImagePair(cv::Mat &img_l, cv::Mat &img_r, const cv::Mat &projection_matrix_l,
                           const cv::Mat &projection_matrix_r) override;
@@ -393,6 +404,7 @@ public:
   inline int getInputHeight() const { return input_height_; }
   inline int getInputWidth() const { return input_width_; }
   bool engineLoaded() const { return engine_loaded_; }
+  int maxKeypoints() const { return max_keypoints_; }
 
 private:
   const std::string model_name_prefix_;
@@ -404,7 +416,7 @@ private:
   const float conf_thresh_;
   const int dist_thresh_;
   const int border_remove_;
-  int max_keypoints_ = 1000;   // hpp:368 (static constexpr there); env SPVO_MAX_KEYPOINTS raises it (BASELINE config 5: 2048)
+  int max_keypoints_ = 1000;   // hpp:368 (static constexpr there); setMaxKeypoints (or env SPVO_MAX_KEYPOINTS) raises it (BASELINE config 5: 2048)
   const int num_threads_;  // kept for signature parity; the work runs on the GPU
   bool engine_loaded_ = false;
   std::vector<float> xy_buf_[2], desc_buf_[2];

@@ -18,6 +18,15 @@ void *spvo_host_create(const char *models_dir, const char *prefix, const char *m
   return fe;
 }
 
+// the class-level options of the host mirror (feature_detection.hpp: setDevice, setMaxKeypoints, setMatchFp8): for the front ends created
+// afterwards; a negative value hands the decision back to the environment variable
+void spvo_host_set_options(int device, int max_keypoints, int match_fp8) {
+  FeatureFrontEnd::setDevice(device);
+  SuperPointFeatureFrontEnd::setMaxKeypoints(max_keypoints);
+  SuperPointFeatureFrontEnd::setMatchFp8(match_fp8);
+}
+int spvo_host_max_keypoints(void *h) { return static_cast<SuperPointFeatureFrontEnd *>(h)->maxKeypoints(); }
+
 void spvo_host_destroy(void *h) { delete static_cast<SuperPointFeatureFrontEnd *>(h); }
 
 int spvo_host_engine_loaded(void *h) { return static_cast<SuperPointFeatureFrontEnd *>(h)->engineLoaded() ? 1 : 0; }

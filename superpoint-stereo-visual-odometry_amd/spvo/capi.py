@@ -62,7 +62,7 @@ OBS_DTYPE = np.dtype([("X", np.float32, 3), ("uv", np.float32, 2), ("cam", np.in
 SYMBOLS = [
     "spvo_default_config", "spvo_create", "spvo_destroy", "spvo_last_error", "spvo_load_weights", "spvo_engine_precision", "spvo_set_fp32_split",
     "spvo_preprocess", "spvo_forward", "spvo_debug_tensor", "spvo_heatmap", "spvo_nms",
-    "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_detect_dev_submit", "spvo_detect_wait", "spvo_set_trunk_pairing", "spvo_detect_submit", "spvo_detect_collect", "spvo_detect_collect_mirrors", "spvo_detect_mirrors_wait", "spvo_match", "spvo_match_slots", "spvo_set_prematch", "spvo_set_match_fp8",
+    "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_detect_dev_submit", "spvo_detect_wait", "spvo_set_trunk_pairing", "spvo_detect_submit", "spvo_detect_collect", "spvo_detect_collect_mirrors", "spvo_detect_mirrors_wait", "spvo_match", "spvo_match_slots", "spvo_set_prematch", "spvo_set_match_fp8", "spvo_get_match_fp8",
     "spvo_match_hamming", "spvo_orb_detect", "spvo_orb_tables", "spvo_triangulate", "spvo_pnp_ransac", "spvo_pnp_refine", "spvo_solve_stereo_odometry", "spvo_solve_submit", "spvo_solve_wait", "spvo_stream", "spvo_synchronize",
     "spvo_profile_enable", "spvo_profile_reset", "spvo_profile_only", "spvo_profile_count", "spvo_profile_get", "spvo_profile_stage_kernel",
     "spvo_set_tuning", "spvo_get_tuning", "spvo_clear_tuning",
@@ -286,6 +286,11 @@ class Context:
     def set_match_fp8(self, enable: bool):
         self._check(self.lib.spvo_set_match_fp8(self.h, int(enable)))
 
+    def match_fp8(self) -> bool:
+        rc = self.lib.spvo_get_match_fp8(self.h)
+        self._check(min(rc, 0))
+        return rc == 1
+
     def engine_precision(self) -> str:
         rc = self.lib.spvo_engine_precision(self.h)
         if rc < 0:
@@ -293,7 +298,7 @@ class Context:
         return {0: "FP32", 1: "FP16", 2: "INT8"}[rc]
 
     def detect_dev_submit(self, d_img_l: int, d_img_r: int, rows: int, cols: int, stride: int, slot_l: int, slot_r: int):
-        """Enqueue a detector pass (at most two may be in flight); complete them oldest-first with detect_wait."""
+        """Enqueue a detector pass (at most six may be in flight); complete them oldest-first with detect_wait."""
         self._check(self.lib.spvo_detect_dev_submit(self.h, C.c_void_p(d_img_l), C.c_void_p(d_img_r), rows, cols, stride, slot_l, slot_r))
 
     def set_trunk_pairing(self, on: bool):
@@ -321,7 +326,7 @@ class Context:
         return out
 
     def detect_collect_mirrors(self, P_l, P_r):
-        """spvo_detect_collect_mirrors: numpy VIEWS of the submission's pinned mirrors (valid until three more submissions)"""
+        """spvo_detect_collect_mirrors: numpy VIEWS of the submission's pinned mirrors (valid until seven more submissions)"""
         Pl = np.ascontiguousarray(P_l, np.float64).reshape(12).copy()
         Pr = np.ascontiguousarray(P_r, np.float64).reshape(12).copy()
         m = DetectMirrors()

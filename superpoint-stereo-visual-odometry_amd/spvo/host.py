@@ -26,6 +26,9 @@ def load():
         lib.spvo_host_create.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]
         lib.spvo_host_destroy.argtypes = [vp]
+        lib.spvo_host_set_options.argtypes = [C.c_int, C.c_int, C.c_int]
+        lib.spvo_host_set_options.restype = None
+        lib.spvo_host_max_keypoints.argtypes = [vp]
         lib.spvo_host_set_deferred_copies.argtypes = [vp, C.c_int]
         lib.spvo_host_set_deferred_copies.restype = None
         lib.spvo_host_destroy.restype = None
@@ -99,6 +102,13 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def set_options(device=-1, max_keypoints=-1, match_fp8=-1):
+    """FeatureFrontEnd::setDevice / SuperPointFeatureFrontEnd::setMaxKeypoints / ::setMatchFp8 (host/feature_detection.hpp): options of
+    the front ends constructed AFTERWARDS; a negative value hands the decision back to the environment variable (SPVO_DEVICE,
+    SPVO_MAX_KEYPOINTS, SPVO_MATCH_FP8)."""
+    load().spvo_host_set_options(int(device), int(max_keypoints), int(match_fp8))
+
+
 class FrontEnd:
     """SuperPointFeatureFrontEnd with the reference launch-file defaults
     (launch/visual_odometry_superpoint.launch:3-26)."""
@@ -112,7 +122,7 @@ class FrontEnd:
                                            conf_thresh, dist_thresh, border_remove, stereo_threshold, min_disparity,
                                            refinement_degree, int(verbose), {"FP32": 0, "FP16": 1, "INT8": 2}[precision])
         self.H, self.W = height, width
-        self.cap = max(1000, int(os.environ.get("SPVO_MAX_KEYPOINTS", "1000")))
+        self.cap = max(1000, int(self.lib.spvo_host_max_keypoints(self.h)))
 
     def close(self):
         if self.h:

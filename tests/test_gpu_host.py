@@ -251,6 +251,56 @@ def test_int8_engine_through_the_host_class(tmp_path, sequence):
         assert len(a & b) / len(a | b) > 0.4
 
 
+def test_result_changing_options_have_setters(models_dir, sequence, monkeypatch):
+    """SuperPointFeatureFrontEnd::setMaxKeypoints / ::setMatchFp8 and FeatureFrontEnd::setDevice (through harness_capi's
+    spvo_host_set_options): the options of the front ends constructed afterwards.  A setter outranks the environment variable of the same
+    name, a negative value hands the decision back to it."""
+    frames, _, P_l, P_r = sequence
+    L, R = frames[0]
+    try:
+        host.set_options(max_keypoints=300)
+        fe = host.FrontEnd(models_dir, prefix="sp_squeeze")
+        assert fe.engine_loaded, fe.last_error
+        fe.add_stereo_image_pair(L, R, P_l, P_r)
+        assert len(fe.keypoints(host.CURR_LEFT)) == 300 and len(fe.keypoints(host.CURR_RIGHT)) == 300      # the cap bites (the frames give ~1000)
+        fe.close()
+        monkeypatch.setenv("SPVO_MAX_KEYPOINTS", "200")
+        fe = host.FrontEnd(models_dir, prefix="sp_squeeze")
+        fe.add_stereo_image_pair(L, R, P_l, P_r)
+        assert len(fe.keypoints(host.CURR_LEFT)) == 300                      # the setter outranks the environment
+        fe.close()
+        host.set_options(max_keypoints=-1)
+        fe = host.FrontEnd(models_dir, prefix="sp_squeeze")
+        fe.add_stereo_image_pair(L, R, P_l, P_r)
+        assert len(fe.keypoints(host.CURR_LEFT)) == 200                      # ... and hands the decision back to it
+        fe.close()
+        monkeypatch.delenv("SPVO_MAX_KEYPOINTS")
+        # fp8 shortlist: the GEMM only prunes, the re-rank is exact -- the matches are the fp32 matcher's, bit for bit
+        got = {}
+        for fp8 in (0, 1):
+            host.set_options(match_fp8=fp8)
+            fe = host.FrontEnd(models_dir, prefix="sp_squeeze")
+            fe.add_stereo_image_pair(L, R, P_l, P_r)
+            fe.match_descriptors(host.CURR_LEFT_CURR_RIGHT)
+            got[fp8] = fe.matches(host.CURR_LEFT_CURR_RIGHT)
+            assert fe.context().match_fp8() == bool(fp8)
+            fe.close()
+        for x, y in zip(got[0], got[1]):
+            assert np.array_equal(x, y)
+        # device: an index that does not exist is refused when the context is created (no silent fall-back to device 0)
+        host.set_options(device=63)
+        fe = host.FrontEnd(models_dir, prefix="sp_squeeze")
+        assert not fe.engine_loaded and "device 63" in fe.last_error
+        fe.close()
+        monkeypatch.setenv("SPVO_DEVICE", "62")
+        host.set_options(device=0)
+        fe = host.FrontEnd(models_dir, prefix="sp_squeeze")
+        assert fe.engine_loaded, fe.last_error                              # setDevice(0) outranks SPVO_DEVICE=62
+        fe.close()
+    finally:
+        host.set_options()
+
+
 @pytest.mark.parametrize("knn,cross", [(1, 0), (0, 0), (0, 1)])
 def test_classic_front_end_matches_binary_descriptors_on_the_gpu(knn, cross):
     """matchDescriptors of a ClassicFeatureFrontEnd(ORB, ORB, BF, ...) -- base.cpp:434-500 with the NORM_HAMMING matcher of

@@ -267,6 +267,44 @@ def test_trunk_pairing_does_not_change_results(graph, vgg_weights_path, squeeze_
             assert np.array_equal(ia, ib) and np.array_equal(da, db), k
 
 
+def test_a_failed_group_launch_keeps_the_queue_consistent(squeeze_weights_path, stereo_pair, tuning):
+    """Trunk pairing, error path: the launch of a held group fails (injected: the context's third group launch) while one of its two
+    members had already been accepted.  The submit that triggers the launch returns the error and is NOT queued; the member accepted
+    earlier stays queued and its spvo_detect_wait reports SPVO_ERR_STATE instead of waiting for events that were never recorded (and
+    handing out another submission's stale keypoints); nothing is left in flight, and the context keeps working afterwards."""
+    import torch
+    from spvo import capi
+    frames, _, P_l, P_r = stereo_pair
+    dev = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
+    rows, cols = frames[0][0].shape
+    args = lambda k: (dev[k][0].data_ptr(), dev[k][1].data_ptr(), rows, cols, dev[k][0].stride(0))
+    tuning(inject_launch_failure=3)                       # read at spvo_create: launch 1 = the reference pair, 2 = pair A, 3 = the group (B, C)
+    ctx = capi.Context()
+    ctx.load_weights(squeeze_weights_path)
+    ref = ctx.detect_dev(*args(0), P_l, P_r, 0, 1)
+    ref_xy = ref["xy_l"].copy()
+    ctx.set_trunk_pairing(True)
+    ctx.detect_dev_submit(*args(0), 2, 3)                 # A: launched at once (nothing queued in front of it)
+    ctx.detect_dev_submit(*args(1), 4, 5)                 # B: held for a partner while A's trunk runs
+    with pytest.raises(capi.SpvoError) as e:
+        ctx.detect_dev_submit(*args(0), 6, 7)             # C: completes the group, whose launch fails
+    assert "injected" in str(e.value)
+    a = ctx.detect_wait(P_l, P_r)
+    assert np.array_equal(a["xy_l"], ref_xy)              # A is untouched
+    with pytest.raises(capi.SpvoError) as e:
+        ctx.detect_wait(P_l, P_r)                         # B: accepted earlier, never launched
+    assert e.value.code == -4 and "launch had failed" in str(e.value)
+    with pytest.raises(capi.SpvoError) as e:
+        ctx.detect_wait(P_l, P_r)                         # C was never queued
+    assert e.value.code == -4
+    ctx.detect_dev_submit(*args(0), 8, 9)                 # the context keeps working (slots 4..7 are free again)
+    ctx.detect_dev_submit(*args(1), 4, 5)
+    again = ctx.detect_wait(P_l, P_r)
+    assert np.array_equal(again["xy_l"], ref_xy)
+    assert len(ctx.detect_wait(P_l, P_r)["xy_l"]) > 0
+    ctx.close()
+
+
 def test_keypoint_cap_2048(vgg_weights_path, vgg_plan, stereo_pair):
     """BASELINE config 5 raises the reference's static cap of 1000 keypoints (hpp:368) to 2048: the cap is a
     context parameter; NMS (on the same heat map) stays bit-exact against the oracle and the matcher handles 2048 x 2048."""
