@@ -744,13 +744,14 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
     }
   }
   // The tail of the SuperPoint graphs -- convPb 256 -> 65, convDb 256 -> 256 (both 1x1, plain, reading two channel ranges of one
-  // tensor), L2 normalisation -- as ONE launch (heads.hip.h) instead of three: FP32 engines only; tuning "heads_fused" = 0 keeps the plan's ops.
+  // tensor or two tensors), L2 normalisation -- as ONE launch (heads.hip.h) instead of three: FP32 engines only; tuning "heads_fused" = 0 keeps the plan's ops.
   if (!c->fp16 && !c->int8 && !c->s3 && c->head_start + 3 == c->ops.size() && tuning("heads_fused", 1)) {
     const size_t hs = c->head_start;
     const Op &pb = c->ops[hs], &db = c->ops[hs + 1], &nm = c->ops[hs + 2];
     const bool plain = pb.type == OP_CONV && db.type == OP_CONV && nm.type == OP_L2NORM && pb.ks == 1 && db.ks == 1 && pb.flags == 0 && db.flags == 0 &&
-                       pb.cin == HEADS_CIN && db.cin == HEADS_CIN && pb.cout == 65 && db.cout == 256 && pb.in == db.in && pb.out == c->t_det && pb.out_c_off == 0 &&
-                       db.out_c_off == 0 && nm.in == db.out && nm.out == c->t_desc && c->tensors[pb.in].level == 3 && !pb.merged && !db.merged;
+                       pb.cin == HEADS_CIN && db.cin == HEADS_CIN && pb.cout == 65 && db.cout == 256 && pb.out == c->t_det && pb.out_c_off == 0 &&
+                       db.out_c_off == 0 && nm.in == db.out && nm.out == c->t_desc && c->tensors[pb.in].level == 3 && c->tensors[db.in].level == 3 &&
+                       !c->tensors[pb.in].nhwc && !c->tensors[db.in].nhwc && !pb.merged && !db.merged;   // (the two branches may read one tensor -- the VGG plan's merged convPa + convDa output -- or two)
     if (plain) {
       const std::vector<float> pk = pack_heads_weights(payload + raws[hs].w_off, payload + raws[hs].b_off, pb.cout, payload + raws[hs + 1].w_off, payload + raws[hs + 1].b_off);
       int rc = dev_alloc(c, &c->d_heads_w, pk.size(), false);

@@ -241,24 +241,28 @@ int launch_op(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream
 // the fused tail of the graph (heads.hip.h): ops head_start .. head_start + 2 in one launch
 int launch_heads(spvo_ctx *c, int batch, hipStream_t stream) {
   const Op &pb = c->ops[c->head_start], &db = c->ops[c->head_start + 1];
-  const Tensor &ti = c->tensors[pb.in], &tdet = c->tensors[pb.out], &traw = c->tensors[db.out], &tdesc = c->tensors[c->t_desc];
+  const Tensor &ti = c->tensors[pb.in], &te = c->tensors[db.in], &tdet = c->tensors[pb.out], &traw = c->tensors[db.out], &tdesc = c->tensors[c->t_desc];
   static bool ready[64] = {};
   const int dev = c->cfg.device & 63;
   if (!ready[dev]) {
     HIP_TRY(c, hipFuncSetAttribute((const void *)heads_fused_kernel<>, hipFuncAttributeMaxDynamicSharedMemorySize, HEADS_LDS_BYTES));
     ready[dev] = true;
   }
+  const size_t plane = (size_t)ti.hp * ti.wp;
   HeadsArgs a;
-  a.in = ring_ptr(c, ti); a.in_per_image = ti.per_image; a.in_hp = ti.hp; a.in_wp = ti.wp;
-  a.coff_det = pb.in_c_off; a.coff_desc = db.in_c_off;
+  a.in_det = ring_ptr(c, ti) + (size_t)pb.in_c_off * plane; a.det_in_per_image = ti.per_image;
+  a.in_desc = ring_ptr(c, te) + (size_t)db.in_c_off * plane; a.desc_in_per_image = te.per_image;
+  a.in_hp = ti.hp; a.in_wp = ti.wp;
   a.wpack = c->d_heads_w;
   a.det = ring_ptr(c, tdet); a.det_per_image = tdet.per_image;
   a.desc_raw = c->heads_keep_raw ? ring_ptr(c, traw) : nullptr; a.raw_per_image = traw.per_image;
   a.desc = ring_ptr(c, tdesc);
-  a.H = ti.H; a.W = ti.W;
+  a.H = ti.H; a.W = ti.W; a.batch = batch;
   const double hbytes = batch * ((double)(pb.cin + db.cin) * ti.H * ti.W * 4 + (double)(pb.cout + 2 * db.cout) * ti.H * ti.W * 4) + (double)(pb.cout * pb.cin + db.cout * db.cin) * 4;
   ScopedStage st(c, stage_id(c, "heads"), (pb.flops_per_image + db.flops_per_image) * batch, hbytes, stream);
-  hipLaunchKernelGGL(heads_fused_kernel<>, dim3((ti.W + HEADS_PX - 1) / HEADS_PX, ti.H, batch), dim3(256), HEADS_LDS_BYTES, stream, a);
+  // one workgroup per CU: each takes an equal share of the 16-pixel tiles of all images (heads.hip.h)
+  const int ntiles = (batch * ti.H * ti.W + 15) / 16;
+  hipLaunchKernelGGL(heads_fused_kernel<>, dim3(std::min(c->num_cus, (ntiles + 1) / 2)), dim3(HEADS_THREADS), HEADS_LDS_BYTES, stream, a);
   HIP_TRY(c, hipGetLastError());
   return SPVO_OK;
 }
