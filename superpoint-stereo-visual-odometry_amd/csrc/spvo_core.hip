@@ -9,6 +9,7 @@
 #include "conv_wino4.hip.h"
 #include "heads.hip.h"
 #include "conv_i8.hip.h"
+#include "conv_i8_fused.hip.h"
 
 namespace spvo_int {
 
@@ -38,7 +39,7 @@ int stage_id(spvo_ctx *c, const std::string &name) {
 // ---- diagnostic switches (include/spvo.h: spvo_set_tuning).  One process-wide table, filled by explicit calls only.
 namespace {
 const char *const kTuningNames[] = {"winograd", "wino4", "wino_narrow", "wino_dynamic", "winograd_min_tiles", "wino4_min_tiles", "merge_siblings", "heads_fused",
-                                    "heads_on_net", "heads_split", "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing", "nms_first", "upload_side", "inject_launch_failure"};
+                                    "heads_on_net", "heads_split", "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing", "nms_first", "upload_side", "inject_launch_failure", "int8_fused"};
 constexpr int kTuningCount = sizeof kTuningNames / sizeof kTuningNames[0];
 std::mutex g_tuning_mutex;
 bool g_tuning_set[kTuningCount] = {};
@@ -144,6 +145,7 @@ void free_plan(spvo_ctx *c) {
     if (o.d_w8) (void)hipFree(o.d_w8);
     if (o.d_ws3) (void)hipFree(o.d_ws3);
     if (o.d_wq32) (void)hipFree(o.d_wq32);
+    if (o.d_wsel) (void)hipFree(o.d_wsel);
     if (o.d_qm) (void)hipFree(o.d_qm);
     if (o.d_sched) (void)hipFree(o.d_sched);
   }
@@ -495,6 +497,9 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
         if ((rc = dev_alloc(c, &op.d_qm, op.cout, false))) return rc;
         if ((rc = dev_alloc(c, &op.d_b, op.cout, false))) return rc;
         HIP_TRY(c, hipMemcpy(op.d_wq32, wq32.data(), wq32.size() * 4, hipMemcpyHostToDevice));
+        const std::vector<int> wsel = pack_dw_wsel(wq.data(), op.cout);
+        if ((rc = dev_alloc(c, &op.d_wsel, wsel.size(), false))) return rc;
+        HIP_TRY(c, hipMemcpy(op.d_wsel, wsel.data(), wsel.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(op.d_qm, qm.data(), qm.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(op.d_b, payload + r.b_off, (size_t)op.cout * 4, hipMemcpyHostToDevice));
         continue;
@@ -760,6 +765,7 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
       c->heads_fused = true;
     }
   }
+  if (c->int8 && tuning("int8_fused", 1)) plan_int8_fusion(c);
   {   // mark the dominant layer
     Op *best = nullptr;
     for (auto &o : c->ops) if (o.type == OP_CONV && (!best || o.flops_per_image > best->flops_per_image)) best = &o;

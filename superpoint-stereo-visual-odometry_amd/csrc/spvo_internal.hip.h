@@ -66,6 +66,10 @@ struct Op {
   int8_t *d_w8 = nullptr;      // INT8 engines: pack_conv_weights_i8()
   unsigned short *d_ws3 = nullptr;   // FP32 engines in split mode: pack_conv_weights_s3()
   int *d_wq32 = nullptr;       // INT8 engines, depthwise: quantised weights [C][9] as int32
+  int *d_wsel = nullptr;       // INT8 engines, depthwise: the dot4 operands of the fused block kernel (conv_i8_fused.hip.h: pack_dw_wsel)
+  int fused_dw = -1;           // INT8 engines, pointwise 1x1 op: index of the depthwise op in front of it that runs in the SAME launch (dwpw_i8_kernel), or -1
+  bool fused_stem = false;     // ... and ops 0, 1 (the fp32 stem) as well
+  bool fused_away = false;     // INT8 engines: this op's work is done by a later op's launch
   float *d_qm = nullptr;       // INT8 engines: weight scale * input scale per output channel
   float inv_s_out = 0.f, s_res = 0.f;
   double flops_per_image = 0;
@@ -364,6 +368,7 @@ void free_plan(spvo_ctx *c);
 int launch_conv16(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream);
 int launch_conv_s3(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream);
 int launch_conv8(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream);
+void plan_int8_fusion(spvo_ctx *c);   // spvo_net_i8.hip: marks the MobileNet blocks (and the stem) of a loaded INT8 plan that run as one launch
 int launch_maxpool_f16(spvo_ctx *c, const Tensor &ti, const Tensor &to, const float *tin, float *tout, int batch, hipStream_t stream);
 void launch_unpad_c8(const Tensor &t, int batch, float *dst, hipStream_t stream);    // spvo_debug_tensor
 void launch_unpad_s3(const Tensor &t, int batch, float *dst, hipStream_t stream);

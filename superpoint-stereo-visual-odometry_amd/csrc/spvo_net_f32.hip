@@ -202,7 +202,7 @@ int launch_conv(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stre
 }
 
 int launch_op(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream) {
-  if (op.merged) return SPVO_OK;
+  if (op.merged || op.fused_away) return SPVO_OK;
   const Tensor &ti = c->tensors[op.in];
   const Tensor &to = c->tensors[op.out];
   if (op.type == OP_CONV || op.type == OP_DWCONV) {
@@ -212,6 +212,14 @@ int launch_op(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream
     const double wsz = c->int8 ? 1.0 : (c->fp16 ? 2.0 : (c->s3 ? 6.0 : 4.0));
     const double bytes = batch * ((double)op.cin * ti.H * ti.W * esz(ti) + (double)op.cout * to.H * to.W * esz(to)) +
                          (double)op.cout * (op.type == OP_DWCONV ? 1 : op.cin) * op.ks * op.ks * wsz;
+    if (op.fused_dw >= 0) {   // INT8 MobileNet block in one launch (spvo_net_i8.hip): what the depthwise op (and the stem) would have done counts here
+      const Op &dw = c->ops[op.fused_dw];
+      const Tensor &t0 = c->tensors[op.fused_stem ? c->ops[0].in : dw.in];
+      double fl = op.flops_per_image + dw.flops_per_image, by = (double)t0.ch * t0.H * t0.W * esz(t0) + (double)op.cout * to.H * to.W * esz(to);
+      if (op.fused_stem) fl += c->ops[0].flops_per_image + c->ops[1].flops_per_image;
+      ScopedStage st(c, op.stage, fl * batch, batch * by + (double)op.cout * op.cin + 9.0 * dw.cout, stream);
+      return launch_conv8(c, op, img0, batch, stream);
+    }
     ScopedStage st(c, op.stage, op.flops_per_image * batch, bytes, stream);
     return c->int8 ? launch_conv8(c, op, img0, batch, stream) : c->fp16 ? launch_conv16(c, op, img0, batch, stream)
            : c->s3 ? launch_conv_s3(c, op, img0, batch, stream) : launch_conv(c, op, img0, batch, stream);

@@ -1,6 +1,7 @@
 // spvo_net_i8.hip -- INT8 engines (conv_i8.hip.h): kernel launchers.
 #include "spvo_internal.hip.h"
 #include "conv_i8.hip.h"
+#include "conv_i8_fused.hip.h"
 
 namespace spvo_int {
 
@@ -37,7 +38,90 @@ int launch_conv8_variant(spvo_ctx *c, const ConvArgs8 &a, bool relu, bool out_f3
   return relu ? launch_conv8_instance<KS, CKG, WR, WC, POOL, true, false>(c, a, stream) : launch_conv8_instance<KS, CKG, WR, WC, POOL, false, false>(c, a, stream);
 }
 
+// ---------------------------------------------------------------- MobileNet blocks as one launch (conv_i8_fused.hip.h)
+// A depthwise 3x3 (+ ReLU) whose only reader is the pointwise 1x1 (+ ReLU [+ BatchNorm] [+ pool]) behind it, both int8, 64 or 128
+// channels in, 64 or 128 out: the pointwise op's launch does both (`fused_dw`), the depthwise op launches nothing (`fused_away`).
+// If that block is ops 2, 3 of the plan and ops 0, 1 are the sp_mbv1 stem (3x3 1 -> 1 + ReLU on the fp32 input plane, 1x1 1 -> 64 +
+// ReLU + BatchNorm into int8), the same launch computes the stem as well (`fused_stem`).
+void plan_int8_fusion(spvo_ctx *c) {
+  auto readers = [&](int tensor) { int n = 0; for (const auto &o : c->ops) n += (o.in == tensor) + ((o.flags & FLAG_ADD) && o.residual == tensor); return n; };
+  for (size_t i = 0; i + 1 < c->ops.size(); ++i) {
+    Op &dw = c->ops[i], &pw = c->ops[i + 1];
+    if (dw.type != OP_DWCONV || pw.type != OP_CONV || pw.ks != 1 || pw.in != dw.out || pw.in_c_off || pw.out_c_off || pw.cin != dw.cout) continue;
+    if (dw.flags != FLAG_RELU || !(pw.flags & FLAG_RELU) || (pw.flags & FLAG_ADD)) continue;
+    const Tensor &ti = c->tensors[dw.in], &tm = c->tensors[dw.out], &to = c->tensors[pw.out];
+    if (!ti.i8 || !tm.i8 || !to.i8 || (dw.cout != 64 && dw.cout != 128) || (pw.cout != 64 && pw.cout != 128) || to.ch != pw.cout) continue;
+    if (readers(dw.out) != 1 || (int)dw.out == c->t_det || (int)dw.out == c->t_desc || !dw.d_wsel || !pw.d_w8) continue;
+    if ((pw.flags & FLAG_POOL) && ((ti.H | ti.W) & 1)) continue;
+    pw.fused_dw = (int)i;
+    dw.fused_away = true;
+    if (i == 2) {
+      Op &s0 = c->ops[0], &s1 = c->ops[1];
+      const bool stem = s0.type == OP_CONV && s0.cin == 1 && s0.cout == 1 && s0.ks == 3 && s0.flags == FLAG_RELU && s0.in == c->t_input && !c->tensors[s0.out].i8 &&
+                        s1.type == OP_CONV && s1.cin == 1 && s1.cout == 64 && s1.ks == 1 && s1.flags == (FLAG_RELU | FLAG_BN) && s1.in == s0.out && s1.out == dw.in &&
+                        !s1.out_c_off && dw.cout == 64 && readers(s0.out) == 1 && readers(s1.out) == 1 && s1.d_bn_scale;
+      if (stem) { pw.fused_stem = true; s0.fused_away = s1.fused_away = true; }
+    }
+  }
+}
+
+template <int G, bool STEM, bool POOL, int EPI>
+static int launch_dwpw8_instance(spvo_ctx *c, const DwPwArgs8 &a, hipStream_t stream) {
+  using T = DwPwTile<G, STEM>;
+  auto k = dwpw_i8_kernel<G, STEM, POOL, EPI>;
+  static int per_cu[64] = {};
+  const int dev = c->cfg.device & 63;
+  if (!per_cu[dev]) {
+    HIP_TRY(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+    int n = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k, DWPW_THREADS, T::LDS_BYTES));
+    per_cu[dev] = std::max(n, 1);
+  }
+  const int n_tiles = a.tiles_x * a.tiles_y * a.batch;
+  const int force = tuning("int8_fused", 1);   // (measurements: 2, 3, 4 = one, two, three workgroups per CU)
+  const int wg_per_cu = force > 1 ? force - 1 : per_cu[dev];
+  hipLaunchKernelGGL(k, dim3(std::min(n_tiles, c->num_cus * wg_per_cu)), dim3(DWPW_THREADS), T::LDS_BYTES, stream, a);
+  HIP_TRY(c, hipGetLastError());
+  return SPVO_OK;
+}
+
+static int launch_dwpw8(spvo_ctx *c, const Op &pw, int img0, int batch, hipStream_t stream) {
+  const Op &dw = c->ops[pw.fused_dw];
+  const Tensor &ti = c->tensors[dw.in], &tm = c->tensors[dw.out], &to = c->tensors[pw.out];
+  DwPwArgs8 a;
+  a.hp = ti.hp; a.wp = ti.wp; a.H = ti.H; a.W = ti.W;
+  a.in = (const int8_t *)(ring_ptr(c, ti) + (size_t)img0 * ti.per_image);
+  a.in_per_image = ti.per_image * 4;
+  a.dw_wsel = dw.d_wsel; a.dw_qm = dw.d_qm; a.dw_bias = dw.d_b; a.inv_s_dw = dw.inv_s_out;
+  a.pw_w = pw.d_w8; a.pw_qm = pw.d_qm; a.pw_bias = pw.d_b; a.bn_scale = pw.d_bn_scale; a.bn_shift = pw.d_bn_shift; a.inv_s_out = pw.inv_s_out;
+  a.out = (int8_t *)(ring_ptr(c, to) + (size_t)img0 * to.per_image);
+  a.out_per_image = to.per_image * 4;
+  a.out_hp = to.hp; a.out_wp = to.wp; a.cout = pw.cout; a.co_tiles = pw.cout / CO_TILE;
+  a.tiles_x = (ti.W + 31) / 32; a.tiles_y = (ti.H + 7) / 8; a.batch = batch;
+  const bool keep = c->heads_keep_raw;   // the synchronous entry points expose every tensor (spvo_debug_tensor): the skipped ones are stored too
+  if (keep) { a.dbg_dw_out = (int8_t *)(tm.d + (size_t)img0 * tm.per_image); a.dbg_c16_per_image = tm.per_image * 4; }
+  const bool pool = pw.flags & FLAG_POOL, bn = pw.flags & FLAG_BN;
+  if (pw.fused_stem) {
+    const Op &s0 = c->ops[0], &s1 = c->ops[1];
+    const Tensor &t0 = c->tensors[s0.in], &t1 = c->tensors[s0.out];
+    a.in = nullptr;
+    a.in_f32 = ring_ptr(c, t0) + (size_t)img0 * t0.per_image;
+    a.in_per_image = t0.per_image;
+    a.w0 = s0.d_w; a.b0 = s0.d_b; a.w1 = s1.d_w; a.b1 = s1.d_b; a.bn1_scale = s1.d_bn_scale; a.bn1_shift = s1.d_bn_shift; a.inv_s_stem = s1.inv_s_out;
+    if (keep) { a.dbg_stem_plane = t1.d + (size_t)img0 * t1.per_image; a.dbg_stem_plane_per_image = t1.per_image; a.dbg_stem_out = (int8_t *)(ti.d + (size_t)img0 * ti.per_image); }
+    if (pool) return bn ? launch_dwpw8_instance<4, true, true, 1>(c, a, stream) : launch_dwpw8_instance<4, true, true, 0>(c, a, stream);
+    return bn ? launch_dwpw8_instance<4, true, false, 1>(c, a, stream) : launch_dwpw8_instance<4, true, false, 0>(c, a, stream);
+  }
+  if (dw.cout == 64) {
+    if (pool) return bn ? launch_dwpw8_instance<4, false, true, 1>(c, a, stream) : launch_dwpw8_instance<4, false, true, 0>(c, a, stream);
+    return bn ? launch_dwpw8_instance<4, false, false, 1>(c, a, stream) : launch_dwpw8_instance<4, false, false, 0>(c, a, stream);
+  }
+  if (pool) return bn ? launch_dwpw8_instance<8, false, true, 1>(c, a, stream) : launch_dwpw8_instance<8, false, true, 0>(c, a, stream);
+  return bn ? launch_dwpw8_instance<8, false, false, 1>(c, a, stream) : launch_dwpw8_instance<8, false, false, 0>(c, a, stream);
+}
+
 int launch_conv8(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream) {
+  if (op.fused_dw >= 0) return launch_dwpw8(c, op, img0, batch, stream);
   const Tensor &ti = c->tensors[op.in];
   const Tensor &to = c->tensors[op.out];
   const float *tin = (ti.dr[c->cur_ring] ? ti.dr[c->cur_ring] : ti.d) + (size_t)img0 * ti.per_image;

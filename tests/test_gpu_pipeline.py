@@ -1,5 +1,7 @@
 """End-to-end GPU checks: spvo_detect / spvo_match_slots vs the oracle on the same stereo pair,
 and full-size properties that do not depend on the oracle finishing quickly."""
+import os
+
 import numpy as np
 import pytest
 
@@ -217,7 +219,44 @@ def test_submissions_in_flight(ctx_squeeze, stereo_pair):
     ctx_squeeze.set_prematch(False, "KNN", False, 0.8)
 
 
-@pytest.mark.parametrize("graph", ["vgg", "squeeze", "vgg_fp16"])
+def _mbv1_int8_engine(tmp_path, frames):
+    """sp_mbv1 as an INT8 engine at 360x1176, calibrated on the device on the first frame (spvo/quant.py)"""
+    from spvo import quant, weights
+    from tests.conftest import GOLDEN
+    plan = weights.load(os.path.join(GOLDEN, "sp_mbv1.spvw"))
+    plan.act_scales = quant.calibrate(plan, [quant.calibration_inputs(plan, frames[0], 360, 1176)], 360, 1176)
+    path = str(tmp_path / weights.engine_name("sp_mbv1", 2, 360, 1176, "INT8"))
+    weights.save(plan, path, precision="INT8")
+    return path
+
+
+def test_int8_blocks_in_one_launch_equal_the_layerwise_engine(stereo_pair, tmp_path, tuning):
+    """INT8 engines run a MobileNet block (depthwise 3x3 -> pointwise 1x1, the first one with the fp32 stem in front) as ONE launch
+    (csrc/conv_i8_fused.hip.h; tuning "int8_fused" = 0 keeps one launch per layer).  Same arithmetic in the same order: the network
+    outputs, keypoints and descriptors of a detector pass are bit-identical either way -- in the pipelined entry points too, where the
+    fused kernels do not store the tensors they skip (tests/test_gpu_network.py::test_int8_engine_is_bit_exact covers every tensor
+    through the synchronous entry points, where they do)."""
+    from spvo import capi
+    frames, _, P_l, P_r = stereo_pair
+    path = _mbv1_int8_engine(tmp_path, frames)
+    out = {}
+    for fused in (0, 1):
+        tuning(int8_fused=fused)
+        ctx = capi.Context()
+        ctx.load_weights(path)
+        assert ctx.engine_precision() == "INT8"
+        r = ctx.detect(frames[0][0], frames[0][1], P_l, P_r, 0, 1)
+        x = np.stack([fe.to_network_input(fe.preprocess(img, P_l, 360, 1176, True)[0]) for img in frames[1]])[:, None]
+        det, desc = ctx.forward(x)
+        out[fused] = ({k: np.array(r[k]) for k in ("xy_l", "xy_r", "desc_l", "desc_r")}, det.copy(), desc.copy())
+        ctx.close()
+    for key in out[0][0]:
+        assert np.array_equal(out[0][0][key], out[1][0][key]), key
+    assert len(out[1][0]["xy_l"]) > 300
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
+@pytest.mark.parametrize("graph", ["vgg", "squeeze", "vgg_fp16", "mbv1_int8"])
 def test_trunk_pairing_does_not_change_results(graph, vgg_weights_path, squeeze_weights_path, stereo_pair, vgg_plan, tmp_path):
     """spvo_set_trunk_pairing: a submission whose network would only queue is held until the next one arrives and the two pairs
     run through every layer in ONE launch (four images).  Keypoints, descriptors (through the pinned mirrors) and both matches of
@@ -235,6 +274,8 @@ def test_trunk_pairing_does_not_change_results(graph, vgg_weights_path, squeeze_
         p16.precision = "FP16"
         path = str(tmp_path / weights.engine_name("superpoint_pretrained", 2, 360, 1176, "FP16"))
         weights.save(p16, path)
+    if graph == "mbv1_int8":         # ... and so do the INT8 engine's, the fused MobileNet blocks included
+        path = _mbv1_int8_engine(tmp_path, frames)
     out = {}
     for pairing in (False, True):
         ctx = capi.Context()

@@ -4,6 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "superpoint-stereo-visual-odometry_amd"))
 import numpy as np
 from spvo import capi, quant, weights
+capi.tuning_from_env()
+if os.environ.get('PEROP_LIB'): capi.LIB_PATH = os.environ['PEROP_LIB']   # a variant build (make BUILD=... OUT=variants/x EXTRA=-D...)
 graph = sys.argv[1] if len(sys.argv) > 1 else "mbv1"
 H, Wd = (int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "360x1176").split("x"))
 plan = weights.vgg_plan() if graph == "vgg" else weights.load(os.path.join(ROOT, "tests", "golden", f"sp_{graph}.spvw"))
