@@ -315,6 +315,8 @@ def main():
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 5],
                     help="BASELINE.json config shortcut: 2 = default; 3 = FP16 192x640; 5 = sp_mbv1 INT8, 2048 keypoints, fp8 shortlist")
     ap.add_argument("--dump-ops", action="store_true", help="add per-layer network times to the JSON line")
+    ap.add_argument("--py-loop", action="store_true", help="drive the timed steps from Python, one front-end call at a time, instead of handing blocks of stereoCallbacks to the host "
+                                                             "library's C loop (spvo_host_run_device_block): what the interpreter costs per step, for A/B")
     ap.add_argument("--cpus", type=int, default=0, help="restrict this process to that many CPUs (os.sched_setaffinity, BEFORE anything touches the GPU): what one rank of an "
                                                           "8-rank job gets of the GPU box's 16-CPU quota is 2 -- the host-budget check of DESIGN.md section 6")
     ap.add_argument("--depth", type=int, default=4, choices=[1, 2, 3, 4], help="stereo pairs handed over ahead of the one being solved; at 4 the front end pairs trunks (two stereo pairs per set of network launches: spvo_set_trunk_pairing)")
@@ -438,6 +440,33 @@ def main():
                 pg.collect()
         return res
 
+    ptr_cache = {}
+
+    def run_frames(first, n, order=order, depth=None, records=None):
+        """n stereoCallbacks starting at frame index `first`: through the host library's C loop in sub-blocks of at most 64 frames (the
+        poses of a sub-block go to the pose gather as they did per step), or -- with --py-loop -- one Python call per front-end call.
+        Appends the frames' records (pose, first-call -> pose latency, solver outcome) to `records` when given."""
+        depth = (0 if args.no_pipeline else args.depth) if depth is None else depth
+        if args.py_loop:
+            for i in range(first, first + n):
+                step(i, order)
+            return
+        key = tuple(order)
+        if key not in ptr_cache:
+            cyc = cycle_buffers(order)
+            ptr_cache[key] = ([c[0].data_ptr() for c in cyc], [c[1].data_ptr() for c in cyc], cyc[0][0].stride(0))
+        pl, pr, stride = ptr_cache[key]
+        done = 0
+        while done < n:
+            m = min(64, n - done)
+            rec = fe.run_device_block(pl, pr, rows, cols, stride, P_l, P_r, first + done, m, depth, deferred and depth > 0)
+            if dist_on:
+                for r in rec:
+                    pg.gather_async(*((r["q"], r["t"]) if r["has_pose"] else (None, None)))
+            if records is not None:
+                records.append(rec)
+            done += m
+
     def barrier():
         if dist_on:
             dist.barrier()
@@ -452,8 +481,7 @@ def main():
     gc.collect()
     gc.freeze()
     gc.disable()
-    for i in range(args.warmup):
-        step(i)
+    run_frames(0, args.warmup)
     if dist_on:
         pg.collect()
     # Inside the timed region only the dominant kernel (conv1b = stage "conv:1") is bracketed by HIP events on the
@@ -467,13 +495,13 @@ def main():
     # of the driver's 20 steps lasts 18 ms, one such sample is thin -- and `value` is the MEDIAN block (max over ranks per block);
     # the number of repeats follows from the first block's duration and is the same on every rank.
     cursor = [args.warmup]
+    timed_records = []
 
     def timed_block():
         barrier()
         t0 = time.perf_counter()
-        for i in range(cursor[0], cursor[0] + args.steps):
-            step(i)
-        last = fe.finish_solve()                                            # the last step's pose (deferred solve): inside the timed region
+        run_frames(cursor[0], args.steps, records=timed_records)
+        last = fe.finish_solve()                                            # the last step's pose (deferred solve): inside the timed region (the C loop collects it itself)
         if dist_on and last is not None:
             pg.gather_async(*last)
         if dist_on:
@@ -500,11 +528,50 @@ def main():
         ctx.profile_only(None)
         ctx.profile_reset()
         n_extra = min(max(args.steps, 50), 100)
-        for i in range(cursor[0], cursor[0] + n_extra):
-            step(i)
+        run_frames(cursor[0], n_extra)
+        fe.finish_solve()
         barrier()
         prof_all = ctx.profile()
         ctx.profile_enable(False)
+
+    def frame_summary(records):
+        """latency and solver statistics of the frames of the timed blocks (C loop records).  Latency: from the first call that handed a
+        pair over (its announcement, `depth` frames ahead of its turn, or addStereoImagePair itself) to its pose in the caller's hands --
+        the reference's t_total (visual_odometry_node.cpp:246-258) plus what look-ahead and the deferred solve add."""
+        if not records:
+            return {}
+        r = np.concatenate(records)
+        r = r[r["has_pose"] == 1]
+        if r.size == 0:
+            return {}
+        lat = np.sort(r["latency_ms"])
+        return {"latency_ms": {"p50": round(float(lat[lat.size // 2]), 3), "p99": round(float(lat[min(lat.size - 1, int(0.99 * lat.size))]), 3),
+                               "mean": round(float(lat.mean()), 3), "frames": int(lat.size),
+                               "definition": "first call that hands the pair over (announcement or addStereoImagePair) -> its pose returned; the reference's t_total when depth = 0"},
+                "solver_stats": {"pnp_ok_rate": round(float(r["pnp_ok"].mean()), 3), "accepted_rate": round(float(r["accepted"].mean()), 3),
+                                 "refined_rate": round(float(r["refined"].mean()), 3), "mean_lm_iterations": round(float(r["lm_iterations"].mean()), 2),
+                                 "mean_pnp_inliers": round(float(r["pnp_inliers"].mean()), 1), "mean_stereo_matches": round(float(r["stereo_matches"].mean()), 1),
+                                 "mean_keypoints_left": round(float(r["keypoints_left"].mean()), 1)}}
+
+    def leg_frames(order_=order, start=args.warmup, depth=None):
+        """an extra (informational) leg on device images, timed like the headline through the same C loop: barrier-bracketed blocks of at least
+        100 frames (each block's barriers drain the pipeline), the median block; returns (time scaled to args.steps steps, spread fields, frame summary)"""
+        n = max(args.steps, 100)
+        cur = [start]
+        recs = []
+
+        def block():
+            barrier()
+            t1 = time.perf_counter()
+            run_frames(cur[0], n, order_, depth, recs)
+            fe.finish_solve()
+            barrier()
+            cur[0] += n
+            return time.perf_counter() - t1
+        ts = [block()]
+        ts += [block() for _ in range((args.repeats if args.repeats > 0 else repeats_for(ts[0], 0.6)) - 1)]
+        e, sp = spread(ts, n)
+        return e * args.steps / n, {**sp, "steps_per_block": n}, frame_summary(recs)
 
     def leg(step_fn, finish, start=args.warmup):
         """an extra (informational) leg timed like the headline: barrier-bracketed blocks, the median block.  Its blocks are at least
@@ -550,6 +617,9 @@ def main():
                                        "torch": "torch.distributed all_gather (RCCL), one collective per 64 frames"}.get(pg.transport, pg.transport)
                                       + (" -- " + pg.transport_note if pg.transport_note else "")},
         }
+        out.update(frame_summary(timed_records))
+        out["step_loop"] = ("one Python call per front-end call (--py-loop)" if args.py_loop else
+                            "blocks of stereoCallbacks handed to the host library's C loop (host/harness_capi.cpp: spvo_host_run_device_block), as the reference's C++ node runs them")
         dom = prof.get("conv:1") if args.graph == "vgg" and args.precision != "INT8" else None
         if args.fp32_split:
             out["config"]["workload"] = out["config"]["workload"].replace(" fp32 ", " fp32 [split mode: bf16x3 operands, 6 partial products] ")     # conv1b: 43 % of all CNN FLOPs
@@ -638,10 +708,10 @@ def main():
                 finally:
                     capi.clear_tuning()
                 if fe.engine_loaded:
-                    for i in range(args.warmup):
-                        step(i)
-                    e2, sp2 = leg(lambda i: step(i), lambda: fe.finish_solve())
-                    out["fp32_split_mode"] = {"value": round(args.steps / e2, 2), "unit": "stereo frames/s", "ms_per_step": round(1e3 * e2 / args.steps, 4), **sp2,
+                    run_frames(0, args.warmup)
+                    fe.finish_solve()
+                    e2, sp2, fs2 = leg_frames()
+                    out["fp32_split_mode"] = {"value": round(args.steps / e2, 2), "unit": "stereo frames/s", "ms_per_step": round(1e3 * e2 / args.steps, 4), **sp2, **fs2,
                                               "note": "opt-in (spvo_set_fp32_split / bench.py --fp32-split), not the headline: fp32 operands as 3 bf16 pieces, "
                                                       "6 partial products per product, fp32 accumulate; fp32-equivalent results"}
             except Exception as exc:   # the headline line must survive a failure of this informational part
@@ -661,15 +731,29 @@ def main():
                 mats = [(fe.make_image(frames[f][0]), fe.make_image(frames[f][1])) for f in order]
                 hi = {}
                 for name, depth in (("synchronous", 0), ("lookahead", args.depth)):
-                    def hstep(i, depth=depth):
+                    lat, ann = [], {}
+
+                    def hstep(i, depth=depth, lat=lat, ann=ann):
                         a = [mats[(i + 1 + d) % len(mats)] if d < depth else None for d in range(4)]
                         m = mats[i % len(mats)]
-                        return fe.step_host(m[0], m[1], P_l, P_r, a[0], a[1], deferred_solve=depth > 0 and deferred, next3_pair=a[2], next4_pair=a[3])
+                        t_in = time.perf_counter()
+                        for f in range(i, i + depth + 1):
+                            ann.setdefault(f, t_in)                         # the first call that hands frame f over
+                        r = fe.step_host(m[0], m[1], P_l, P_r, a[0], a[1], deferred_solve=depth > 0 and deferred, next3_pair=a[2], next4_pair=a[3])
+                        if r is not None:                                   # the pose of this frame, or -- deferred solve -- of the one before
+                            f = i - 1 if depth > 0 and deferred else i
+                            if f in ann:
+                                lat.append(1e3 * (time.perf_counter() - ann.pop(f)))
+                        return r
                     for i in range(args.warmup):
                         hstep(i)
                     fe.finish_solve()
+                    lat.clear()
                     e3, sp3 = leg(hstep, lambda: fe.finish_solve())
-                    hi[name] = {"value": round(args.steps / e3, 2), "ms_per_step": round(1e3 * e3 / args.steps, 4), **sp3}
+                    ls = np.sort(np.asarray(lat)) if lat else np.zeros(1)
+                    hi[name] = {"value": round(args.steps / e3, 2), "ms_per_step": round(1e3 * e3 / args.steps, 4), **sp3,
+                                "latency_ms": {"p50": round(float(ls[ls.size // 2]), 3), "p99": round(float(ls[min(ls.size - 1, int(0.99 * ls.size))]), 3), "frames": int(ls.size),
+                                               "definition": "first call that hands the pair over -> its pose returned (Python clock around the calls): the reference's t_total for the synchronous sequence"}}
                     if depth == 0:
                         # the stage table of THIS leg (the headline's `stages_ms` describes the pipelined loop): host wall time of the node's
                         # three kinds of calls, then -- a second short pass with every stage bracketed by events -- what the device did in them
@@ -723,26 +807,16 @@ def main():
                                    height=NET_H, width=NET_W, conf_thresh=0.015, dist_thresh=4, border_remove=4,
                                    stereo_threshold=2.0, min_disparity=0.25, refinement_degree=4, precision="FP32")
                 if fe.engine_loaded:
-                    stats = []
                     # frames 0..7 over and over: seven real forward steps and one jump back to the start per cycle.  (The ping-pong
                     # order of the headline reverses the motion twice per cycle; the reference's acceleration gate, base.cpp:251-260,
                     # then rejects the pose and keeps its stale prediction until the motion reverses again: half of all frames.)
                     cyc = list(range(SEQ_LEN))
-                    def tstep(i):
-                        r = step(i, cyc)
-                        if r is not None:
-                            ls = fe.last_solve()
-                            stats.append((ls["accepted"], ls["refined"], ls["lm_iterations"], len(fe.inliers("pnp"))))
-                    for i in range(args.warmup):
-                        tstep(i)
-                    stats.clear()
-                    e4, sp4 = leg(tstep, lambda: fe.finish_solve())
-                    st = np.array(stats, np.float64)
+                    run_frames(0, args.warmup, cyc)
+                    fe.finish_solve()
+                    e4, sp4, fs4 = leg_frames(cyc)
                     out["trained_workload"] = {"graph": "sp_squeeze (the reference's trained ONNX graph, 844353 params), FP32, net %dx%d; frames 0..7 cyclically "
                                                         "(one jump back per cycle, which the gate rejects)" % (NET_H, NET_W),
-                                               "value": round(args.steps / e4, 2), "unit": "stereo frames/s", "ms_per_step": round(1e3 * e4 / args.steps, 4), **sp4,
-                                               "accepted_rate": round(float(st[:, 0].mean()), 3), "refined_rate": round(float(st[:, 1].mean()), 3),
-                                               "mean_lm_iterations": round(float(st[:, 2].mean()), 2), "mean_pnp_inliers": round(float(st[:, 3].mean()), 1)}
+                                               "value": round(args.steps / e4, 2), "unit": "stereo frames/s", "ms_per_step": round(1e3 * e4 / args.steps, 4), **sp4, **fs4}
             except Exception as exc:   # the headline line must survive a failure of this informational part
                 out["trained_workload"] = {"error": repr(exc)}
         if world == 1 and headline and not args.no_extras and "classic" in legs:
@@ -798,11 +872,10 @@ def main():
                         host.set_options(device=local_rank, max_keypoints=args.max_keypoints, match_fp8=1 if args.match_fp8 else 0)
                     if not fe.engine_loaded:
                         raise RuntimeError("engine load failed: " + fe.last_error)
-                    for i in range(args.warmup):
-                        step(i)
+                    run_frames(0, args.warmup)
                     fe.finish_solve()
-                    eo, spo = leg(lambda i: step(i), lambda: fe.finish_solve())
-                    rec = {"what": owhat, "value": round(args.steps / eo, 2), "unit": "stereo frames/s", "ms_per_step": round(1e3 * eo / args.steps, 4), **spo,
+                    eo, spo, fso = leg_frames()
+                    rec = {"what": owhat, "value": round(args.steps / eo, 2), "unit": "stereo frames/s", "ms_per_step": round(1e3 * eo / args.steps, 4), **spo, **fso,
                            "dtype": {"FP32": "f32", "FP16": "f16", "INT8": "i8"}[oprec],
                            "workload": (f"SuperPoint VGG {oprec.lower()} (seeded synthetic weights, {o_params} params)" if ograph == "vgg" else
                                         f"SuperPoint {ograph} {oprec.lower()} (the reference's TRAINED ONNX graph, {o_params} params; activation scales calibrated on this stream)")
@@ -811,8 +884,7 @@ def main():
                     octx.profile_only(None)
                     octx.profile_enable(True)
                     octx.profile_reset()
-                    for i in range(50):
-                        step(i)
+                    run_frames(0, 50)
                     fe.finish_solve()
                     barrier()
                     oprof = octx.profile()

@@ -39,7 +39,7 @@ int stage_id(spvo_ctx *c, const std::string &name) {
 // ---- diagnostic switches (include/spvo.h: spvo_set_tuning).  One process-wide table, filled by explicit calls only.
 namespace {
 const char *const kTuningNames[] = {"winograd", "wino4", "wino_narrow", "wino_dynamic", "winograd_min_tiles", "wino4_min_tiles", "merge_siblings", "heads_fused",
-                                    "heads_on_net", "heads_split", "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing", "nms_first", "upload_side", "inject_launch_failure", "int8_fused"};
+                                    "heads_on_net", "heads_split", "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing", "nms_first", "upload_side", "inject_launch_failure", "int8_fused", "pair_always"};
 constexpr int kTuningCount = sizeof kTuningNames / sizeof kTuningNames[0];
 std::mutex g_tuning_mutex;
 bool g_tuning_set[kTuningCount] = {};
@@ -197,6 +197,7 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c->H = cfg->net_height; c->W = cfg->net_width; c->Hc = c->H / 8; c->Wc = c->W / 8;
   c->nms_first = std::min(std::max(tuning("nms_first", 4), 1), NMS_MAX_LAUNCH);   // (diagnostic override)
+  c->pair_always = tuning("pair_always", 1) != 0;
   c->trunk_timing = tuning("trunk_timing", 0);
   c->solve_timing = tuning("solve_timing", 0);
   c->inject_launch_failure = tuning("inject_launch_failure", 0);

@@ -167,6 +167,7 @@ struct spvo_ctx {
   std::deque<PendingDetect> pendq;
   int held = 0;                  // submissions at the back of pendq whose trunk has not been launched yet (0 .. 2: trunk pairing)
   bool pair_trunks = false;      // spvo_set_trunk_pairing
+  bool pair_always = true;       // ... the first pair of a group waits for its partner also when the network stream is idle (tuning "pair_always", read at spvo_create)
   int last_launch_ring = -1;     // ev_net[...] of the newest trunk launched
   int cur_ring = 0;                // set whose network outputs the running forward pass writes
   unsigned submit_count = 0;

@@ -273,4 +273,93 @@ int spvo_host_last_solve(void *h) {
 
 int spvo_host_frame_count(void *h) { return static_cast<SuperPointFeatureFrontEnd *>(h)->frameCount(); }
 
+// ---- a block of stereoCallbacks in one call (bench.py's timed region: no interpreter between two frames, as in the reference's C++ node)
+// What one frame of a block leaves behind.  latency_ms: from the FIRST call that handed the pair over (its announcement through
+// prefetchStereoImagePairDevice, or addStereoImagePairDevice itself when nothing was announced) to the moment its pose was in
+// the caller's hands -- the reference's t_total (visual_odometry_node.cpp:246-258) when pairs are handed over one at a time, and what
+// look-ahead and a deferred solve cost on top of it when they are not.
+struct SpvoFrameRecord {
+  double q[4], t[3];        // cam0_curr_T_cam0_prev (identity for a frame without a pose: the first of a sequence)
+  double latency_ms;
+  int has_pose, pnp_ok, accepted, refined, lm_iterations, pnp_inliers, stereo_matches, keypoints_left;
+};
+
+static double now_ms() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+// n stereoCallbacks (node.cpp:150-262) on device-resident pairs: frame k of the block is pair (first + k) % cycle of d_l / d_r.  depth > 0:
+// the next `depth` pairs are announced ahead (prefetchStereoImagePairDevice), before the current one is collected; deferred != 0: a frame's
+// solve is handed over (solveStereoOdometrySubmit) and its pose collected while the next frame is processed -- the block's last one before
+// the call returns, so that every frame of the block has its record.  Returns the number of frames processed.
+int spvo_host_run_device_block(void *h, const void *const *d_l, const void *const *d_r, int cycle, int rows, int cols, size_t stride, const double *P_l,
+                               const double *P_r, long first, int n, int depth, int deferred, SpvoFrameRecord *rec) {
+  auto *fe = static_cast<SuperPointFeatureFrontEnd *>(h);
+  if (!fe || !d_l || !d_r || cycle <= 0 || n < 0 || !rec || depth < 0 || depth > 4) return -1;
+  cv::Mat pl(3, 4, CV_64FC1), pr(3, 4, CV_64FC1);
+  std::memcpy(pl.data, P_l, 12 * sizeof(double));
+  std::memcpy(pr.data, P_r, 12 * sizeof(double));
+  constexpr int RINGN = 16;
+  // when frame g was first handed over (ring by g % 16: at most five pairs are ever announced and uncollected), and up to which frame
+  // announcements have been made: kept across calls -- the last `depth` pairs a block announces are collected by the next block
+  static struct { void *h; double t_first[RINGN]; long up_to; } st = {nullptr, {}, -1};
+  if (st.h != h || st.up_to < first - 1 || st.up_to > first + depth) { st.h = h; st.up_to = first - 1; }
+  double *t_first = st.t_first;
+  long &announced_up_to = st.up_to;
+  auto record_pose = [&](int k, const tf2::Transform &T, bool ok) {
+    SpvoFrameRecord &r = rec[k];
+    r.has_pose = ok ? 1 : 0;
+    r.q[0] = T.getRotation().x(); r.q[1] = T.getRotation().y(); r.q[2] = T.getRotation().z(); r.q[3] = T.getRotation().w();
+    r.t[0] = T.getOrigin().x(); r.t[1] = T.getOrigin().y(); r.t[2] = T.getOrigin().z();
+    r.latency_ms = now_ms() - t_first[(first + k) % RINGN];
+    r.pnp_ok = fe->lastPnpOk(); r.accepted = fe->lastAccepted(); r.refined = fe->lastRefined(); r.lm_iterations = fe->lastLmIterations();
+    r.pnp_inliers = (int)fe->inliersPnp().size();
+  };
+  int pending = -1;                   // frame of the block whose deferred solve is in flight
+  for (int k = 0; k < n; ++k) {
+    const long g = first + k;
+    SpvoFrameRecord &r = rec[k];
+    std::memset(&r, 0, sizeof r);
+    r.q[3] = 1;
+    if (depth > 0)
+      for (long a = g; a <= g + depth; ++a) {
+        if (a > announced_up_to) { t_first[a % RINGN] = now_ms(); announced_up_to = a; }
+        fe->prefetchStereoImagePairDevice(d_l[a % cycle], d_r[a % cycle], rows, cols, stride);   // (no-op if already announced)
+      }
+    else
+      t_first[g % RINGN] = now_ms();
+    fe->addStereoImagePairDevice(d_l[g % cycle], d_r[g % cycle], rows, cols, stride, pl, pr, false);
+    fe->matchDescriptors(CURR_LEFT_CURR_RIGHT);
+    r.keypoints_left = fe->keypoints_dq.size() >= 2 ? (int)fe->keypoints_dq.end()[CURR_LEFT].size() : 0;
+    r.stereo_matches = (int)fe->cv_DMatches_list[CURR_LEFT_CURR_RIGHT].size();
+    if (fe->keypoints_dq.size() < 4) {   // node.cpp:188-193: the first pair of a sequence has no pose
+      r.latency_ms = now_ms() - t_first[g % RINGN];
+      continue;
+    }
+    fe->matchDescriptors(CURR_LEFT_PREV_LEFT);
+    tf2::Transform T;
+    T.setIdentity();
+    if (!deferred) {
+      fe->solveStereoOdometry(T);
+      record_pose(k, T, true);
+      continue;
+    }
+    if (fe->solvePending()) {   // the previous frame's pose: its points and prior enter this frame's join
+      const bool ok = fe->solveStereoOdometryCollect(T);
+      if (pending >= 0) record_pose(pending, T, ok);
+      pending = -1;
+    }
+    if (fe->solveStereoOdometrySubmit()) pending = k;
+  }
+  if (fe->solvePending()) {
+    tf2::Transform T;
+    T.setIdentity();
+    const bool ok = fe->solveStereoOdometryCollect(T);
+    if (pending >= 0) record_pose(pending, T, ok);
+  }
+  return n;
+}
+
 }  // extern "C"

@@ -44,6 +44,7 @@ def load():
         lib.spvo_host_add_stereo_pair_dev.restype = None
         lib.spvo_host_prefetch_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t]
         lib.spvo_host_prefetch_dev.restype = None
+        lib.spvo_host_run_device_block.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, C.c_long, C.c_int, C.c_int, C.c_int, vp]
         lib.spvo_host_make_image.argtypes = [vp, C.c_int, C.c_int]
         lib.spvo_host_make_image.restype = vp
         lib.spvo_host_free_image.argtypes = [vp]
@@ -100,6 +101,16 @@ def write_latency_csv(directory, prefix, batch, height, width, precision, kitti_
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+class FrameRecord(C.Structure):
+    """host/harness_capi.cpp: SpvoFrameRecord -- what one frame of spvo_host_run_device_block leaves behind"""
+    _fields_ = [("q", C.c_double * 4), ("t", C.c_double * 3), ("latency_ms", C.c_double), ("has_pose", C.c_int), ("pnp_ok", C.c_int), ("accepted", C.c_int),
+                ("refined", C.c_int), ("lm_iterations", C.c_int), ("pnp_inliers", C.c_int), ("stereo_matches", C.c_int), ("keypoints_left", C.c_int)]
+
+RECORD_DTYPE = np.dtype([("q", np.float64, 4), ("t", np.float64, 3), ("latency_ms", np.float64), ("has_pose", np.int32), ("pnp_ok", np.int32), ("accepted", np.int32),
+                         ("refined", np.int32), ("lm_iterations", np.int32), ("pnp_inliers", np.int32), ("stereo_matches", np.int32), ("keypoints_left", np.int32)])
+assert RECORD_DTYPE.itemsize == C.sizeof(FrameRecord)
 
 
 def set_options(device=-1, max_keypoints=-1, match_fp8=-1):
@@ -171,6 +182,21 @@ class FrontEnd:
         c.h = C.c_void_p(self.lib.spvo_host_ctx(self.h))
         c.close = lambda: None                         # owned by the C++ object
         return c
+
+    def run_device_block(self, d_l, d_r, rows, cols, stride, P_l, P_r, first, n, depth=4, deferred=True):
+        """n stereoCallbacks on device-resident pairs in ONE call (host/harness_capi.cpp: spvo_host_run_device_block): frame k of the block is
+        pair (first + k) % len(d_l); `depth` pairs announced ahead, the solve deferred by a frame (the block's last pose is collected before
+        the call returns).  d_l / d_r: device pointers of the cycle.  Returns a structured array of n records (RECORD_DTYPE): pose,
+        first-call -> pose latency in ms, solver outcome, keypoint and match counts."""
+        cyc = len(d_l)
+        pl = (C.c_void_p * cyc)(*d_l)
+        pr = (C.c_void_p * cyc)(*d_r)
+        rec = np.zeros(n, RECORD_DTYPE)
+        Pl, Pr = np.ascontiguousarray(P_l, np.float64), np.ascontiguousarray(P_r, np.float64)
+        got = self.lib.spvo_host_run_device_block(self.h, pl, pr, cyc, rows, cols, stride, _p(Pl), _p(Pr), first, n, depth, int(deferred), _p(rec))
+        if got != n:
+            raise RuntimeError("spvo_host_run_device_block failed: " + self.last_error)
+        return rec
 
     def prefetch_device(self, d_l: int, d_r: int, rows: int, cols: int, stride: int):
         self.lib.spvo_host_prefetch_dev(self.h, C.c_void_p(d_l), C.c_void_p(d_r), rows, cols, stride)
