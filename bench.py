@@ -96,7 +96,7 @@ def cpu_baseline(frames, P_l, P_r, weights_path, order, budget_s=25.0):
         L, R = frames[order[k % len(order)]]
         r = cpu.frontend_step(L, R, P_l, P_r)
         if k >= warm:
-            rows.append((r.t_detect_ms, r.t_match_ms, r.t_solve_ms, r.t_total_ms, r.n_inliers, r.refined))
+            rows.append((r.t_detect_ms, r.t_match_ms, r.t_solve_ms, r.t_total_ms, r.n_inliers, r.refined, r.accepted, r.pnp_ok, r.lm_iterations, r.n_stereo, r.n_kp_l))
         k += 1
         if len(rows) >= 50 or (len(rows) >= 10 and time.time() - t_start > budget_s):
             break
@@ -131,7 +131,12 @@ def cpu_baseline(frames, P_l, P_r, weights_path, order, budget_s=25.0):
     return {"value": round(1e3 / float(med[3]), 3), "unit": "stereo frames/s", "cores": int(threads), "kind": "port",
             "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "cpu_quota": usable_cpus(),
             "stage_median_ms": {"detect": round(float(med[0]), 2), "match": round(float(med[1]), 2), "solve": round(float(med[2]), 2), "total": round(float(med[3]), 2)},
-            "refined_rate": round(float(a[:, 5].mean()), 3), "mean_inliers": round(float(a[:, 4].mean()), 1),
+            "solver_stats": {"pnp_ok_rate": round(float(a[:, 7].mean()), 3), "accepted_rate": round(float(a[:, 6].mean()), 3), "refined_rate": round(float(a[:, 5].mean()), 3),
+                             "mean_lm_iterations": round(float(a[:, 8].mean()), 2), "mean_pnp_inliers": round(float(a[:, 4].mean()), 1),
+                             "mean_stereo_matches": round(float(a[:, 9].mean()), 1), "mean_keypoints_left": round(float(a[:, 10].mean()), 1),
+                             "note": "the same fields as the headline's solver_stats, on the same frames (the CPU restatement's RANSAC draws the same samples: oracle/cpu)"},
+            "latency_ms": {"p50": round(float(np.median(a[:, 3])), 3), "p99": round(float(np.sort(a[:, 3])[min(len(a) - 1, int(0.99 * len(a)))]), 3),
+                           "definition": "t_total per frame (one pair at a time: the reference's latency column, visual_odometry_node.cpp:246-258)"},
             "config1_orb_front_end": orb,
             "sample": f"{len(rows)} stereo frames after {warm} warm-ups through oracle/cpu (C++17 + OpenMP restatement of the whole step: "
                       f"crop/resize, VGG fp32 direct convolution, softmax/NMS, descriptor sampling, brute-force L2 matching, triangulation, "
@@ -634,15 +639,22 @@ def main():
             # pipe EXECUTES per launch; the layer's ALGORITHMIC rate (direct 3x3 convolution) is reported
             # beside it under its own name and never enters `frac` (it exceeds the peak: that is the point of Winograd).
             kfam, kfactor = ctx.stage_kernel("conv:1")
-            pmc_file = {"conv_wino4_kernel": "r04_pmc.json", "conv_wino2_kernel": "r03_pmc.json", "conv_mfma_kernel": "r01_pmc_conv_traffic.json"}.get(kfam)
+            # ... quoted only when the counter file was collected on THESE kernel sources: tools/collect_profiles_r05.sh stamps every
+            # profiles/r05_*.json with the hash of csrc/ (tools/csrc_hash.py); a stamp that differs from the sources the running library
+            # was built from gives `traffic: null, traffic_stale: true` instead of a number nobody re-measured
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from csrc_hash import csrc_sha16
+            src_tag = csrc_sha16(ROOT)
+            pmc_file = {"conv_wino4_kernel": "r05_pmc.json"}.get(kfam)
             pmc = os.path.join(ROOT, "profiles", pmc_file) if pmc_file else None
-            if pmc and not os.path.exists(pmc) and pmc_file == "r04_pmc.json":
-                pmc = os.path.join(ROOT, "profiles", "r03_pmc.json")
+            traffic_stale = None
             if pmc and os.path.exists(pmc) and (NET_H, NET_W) == (360, 1176):
                 pj = json.load(open(pmc))
-                traffic = (pj.get(kfam) or ({} if kfam in ("conv_wino4_kernel", "conv_wino2_kernel") else pj)).get("traffic_bytes_per_launch")
-                if traffic:   # the counter pass ran launches of TWO images; with trunk pairing the timed launches average more (per image the same)
-                    traffic = int(traffic * dom["flops"] / (2.0 * 2 * NET_H * NET_W * 64 * 64 * 9))
+                traffic_stale = pj.get("csrc_sha16") != src_tag
+                if not traffic_stale:
+                    traffic = (pj.get(kfam) or {}).get("traffic_bytes_per_launch")
+                    if traffic:   # the counter pass ran launches of TWO images; with trunk pairing the timed launches average more (per image the same)
+                        traffic = int(traffic * dom["flops"] / (2.0 * 2 * NET_H * NET_W * 64 * 64 * 9))
             peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "FP32" and not args.fp32_split else F16_MFMA_PEAK_TFLOPS
             kdesc = {"conv_wino4_kernel": "<POOL,RELU,TAG=1> (Winograd F(4x4,3x3), fp32)", "conv_wino2_kernel": "<POOL,RELU,TAG=1> (Winograd F(2x2,3x3), fp32)",
                      "conv_wino_kernel": "<POOL,RELU,TAG=1> (Winograd F(2x2,3x3), fp32)", "conv_wino64_kernel": "<POOL,RELU,TAG=1> (Winograd F(2x2,3x3), filters in registers, fp32)"}.get(kfam, "<KS=3,...,POOL,RELU>")
@@ -653,8 +665,8 @@ def main():
             achieved = executed_per_launch / (avg_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": kfam + kdesc + " instance of op 1 = conv1b 64->64 @" + f"{NET_H}x{NET_W}, " + ("2 or 4 images per launch (trunk pairing: flops and time are the means over the timed launches)" if args.depth >= 4 and not args.no_pipeline else "2 images"),
                                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(achieved / peak, 4), "traffic": traffic,
-                               "traffic_source": ("profiles/" + os.path.basename(pmc) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x 2, validated by a known-size copy kernel in the same session)") if traffic else None,
+                               "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_stale": traffic_stale, "csrc_sha16": src_tag,
+                               "traffic_source": ("profiles/" + os.path.basename(pmc) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x 2 as the guide prescribes for gfx950; same csrc_sha16)") if traffic else None,
                                "avg_kernel_ms": round(avg_ms, 5), "flops_per_launch": executed_per_launch,
                                "flops_counted": "executed on the matrix pipe" + counted,
                                "algorithmic_flops_per_launch": dom["flops"], "algorithmic_tflops": round(algorithmic, 2),
@@ -678,13 +690,25 @@ def main():
                 out["net_ops_ms"] = {k: round(v["total_ms"] / max(v["calls"], 1), 4) for k, v in prof_all.items()
                                      if k.startswith(("conv:", "pool:", "l2norm:", "dwconv:"))}
             out["conv_stack_tflops"] = round(conv_fl / (conv_ms * 1e-3) / 1e12, 2)
+            mg = prof_all.get("match_gemm")
+            if mg and mg["calls"] and mg["flops"] > 0:   # north_star: "MFMA utilisation on the distance GEMM" -- by HIP-event time of the launch, not by a counter quotient
+                mms = mg["total_ms"] / mg["calls"]
+                mtf = mg["flops"] / (mms * 1e-3) / 1e12
+                mpeak = 2 * F16_MFMA_PEAK_TFLOPS if args.match_fp8 else FP32_MFMA_PEAK_TFLOPS
+                out["roofline_matcher"] = {"kernel": "match_gemm_kernel" + ("<fp8 shortlist>" if args.match_fp8 else "<fp32, fused per-row reduction>") + ": the frame's two jobs (stereo, temporal) in one launch",
+                                           "bound": "mfma", "avg_kernel_ms": round(mms, 5), "flops_per_launch": mg["flops"], "achieved": round(mtf, 2), "peak": mpeak, "unit": "TFLOP/s",
+                                           "frac": round(mtf / mpeak, 4),
+                                           "where": "inside the pipelined loop (stage pass: HIP events around the launch on the tail stream, which shares the chip with the next pairs' trunk); "
+                                                    "un-contended: host_interface.synchronous.roofline_matcher"}
             # north_star: "rocprof reports achieved HBM GB/s on the conv stack".  Bytes per forward pass from the committed counter passes
             # (FETCH_SIZE x 2 + WRITE_SIZE per layer, tools/pmc_layers.py) over the stack's time measured HERE (sum of the layers' HIP-event
             # times in the pass above); the algorithmic bytes beside it.
-            pl_path = os.path.join(ROOT, "profiles", "r04_pmc_layers.json")
+            pl_path = os.path.join(ROOT, "profiles", "r05_pmc_layers.json")
             if "roofline" in out and headline and (NET_H, NET_W) == (360, 1176) and os.path.exists(pl_path):
-                cs = json.load(open(pl_path)).get("conv_stack", {})
-                if cs.get("traffic_MB"):
+                plj = json.load(open(pl_path))
+                cs = plj.get("conv_stack", {})
+                out["roofline"]["conv_stack_traffic_stale"] = plj.get("csrc_sha16") != out["roofline"]["csrc_sha16"]
+                if cs.get("traffic_MB") and not out["roofline"]["conv_stack_traffic_stale"]:
                     # the counter pass ran two images per launch; the stage pass above averages launches of two and of four (trunk pairing):
                     # bytes per launch scale with the images, i.e. with the mean algorithmic flops per launch (141.44 GFLOP at two images without the heads)
                     pairs_per_launch = conv_fl / 141.44e9   # (the stages named conv:<i>: the fused heads launch is a stage of its own)
@@ -693,7 +717,7 @@ def main():
                     out["roofline"]["conv_stack_pairs_per_launch"] = round(pairs_per_launch, 3)
                     out["roofline"]["conv_stack_hbm_gbps"] = round(cs["traffic_MB"] * 1e6 * pairs_per_launch / (conv_ms * 1e-3) / 1e9, 1)
                     out["roofline"]["conv_stack_frac_of_hbm_peak"] = round(cs["traffic_MB"] * 1e6 * pairs_per_launch / (conv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
-                    out["roofline"]["conv_stack_traffic_source"] = "profiles/r04_pmc_layers.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over a forward-only loop, per layer; counters include Infinity-Cache hits) / conv_stack_sum of this run"
+                    out["roofline"]["conv_stack_traffic_source"] = "profiles/r05_pmc_layers.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over a forward-only loop, per layer; counters include Infinity-Cache hits; same csrc_sha16) / conv_stack_sum of this run"
         if world == 1 and headline and not args.no_extras and "split" in legs:
             try:
                 # Informational, never `value`: the same workload with the FP32 engine in its opt-in split mode (every fp32 operand as
@@ -788,6 +812,11 @@ def main():
                                                                 if v["calls"] and not k.startswith(("conv:", "pool:", "l2norm:", "dwconv:"))}
                                 hi[name]["device_stages_ms"]["conv_stack_sum"] = round(sum(v["total_ms"] / v["calls"] for k, v in hp.items() if k.startswith("conv:") and v["calls"]), 4)
                                 hi[name]["device_stages_ms"]["_source"] = "second pass of 100 synchronous steps with every stage bracketed by HIP events (slower than the timed blocks)"
+                                mg = hp.get("match_gemm")
+                                if mg and mg["calls"] and mg["flops"] > 0:
+                                    mms = mg["total_ms"] / mg["calls"]
+                                    hi[name]["roofline_matcher"] = {"avg_kernel_ms": round(mms, 5), "achieved": round(mg["flops"] / (mms * 1e-3) / 1e12, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                                    "frac": round(mg["flops"] / (mms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), "where": "alone on the chip (synchronous call sequence), HIP-event time"}
                 out["host_interface"] = {"unit": "stereo frames/s", **hi,
                                          "note": "addStereoImagePair(cv::Mat&, ...): 2 x 0.47 MB host images in, 2 x 0.42 MB resized images + 2 x 1 MB "
                                                  "descriptors out per pair (PCIe inclusive); the headline `value` has the images resident in HBM"}

@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libspvo.so")
+LIB_PATH = os.path.join(os.environ.get("SPVO_LIB_DIR") or os.path.dirname(_HERE), "libspvo.so")   # SPVO_LIB_DIR: a side build (make BUILD=... OUT=variants/x) for A/B measurements
 
 
 class Config(C.Structure):

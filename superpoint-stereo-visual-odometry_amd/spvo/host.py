@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libspvo_host.so")
+LIB_PATH = os.path.join(os.environ.get("SPVO_LIB_DIR") or os.path.dirname(_HERE), "libspvo_host.so")   # SPVO_LIB_DIR: a side build (make BUILD=... OUT=variants/x) for A/B measurements
 _lib = None
 
 CURR_LEFT_CURR_RIGHT, CURR_LEFT_PREV_LEFT, PREV_LEFT_PREV_RIGHT = 0, 1, 2

@@ -309,7 +309,7 @@ def test_trunk_pairing_does_not_change_results(graph, vgg_weights_path, squeeze_
 
 
 def test_a_failed_group_launch_keeps_the_queue_consistent(squeeze_weights_path, stereo_pair, tuning):
-    """Trunk pairing, error path: the launch of a held group fails (injected: the context's third group launch) while one of its two
+    """Trunk pairing, error path: the launch of a held group fails (injected: the context's fourth group launch) while one of its two
     members had already been accepted.  The submit that triggers the launch returns the error and is NOT queued; the member accepted
     earlier stays queued and its spvo_detect_wait reports SPVO_ERR_STATE instead of waiting for events that were never recorded (and
     handing out another submission's stale keypoints); nothing is left in flight, and the context keeps working afterwards."""
@@ -319,30 +319,32 @@ def test_a_failed_group_launch_keeps_the_queue_consistent(squeeze_weights_path, 
     dev = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
     rows, cols = frames[0][0].shape
     args = lambda k: (dev[k][0].data_ptr(), dev[k][1].data_ptr(), rows, cols, dev[k][0].stride(0))
-    tuning(inject_launch_failure=3)                       # read at spvo_create: launch 1 = the reference pair, 2 = pair A, 3 = the group (B, C)
+    tuning(inject_launch_failure=4)                       # read at spvo_create: launches 1, 2 = the reference pairs, 3 = the group (A, B), 4 = the group (C, D)
     ctx = capi.Context()
     ctx.load_weights(squeeze_weights_path)
-    ref = ctx.detect_dev(*args(0), P_l, P_r, 0, 1)
-    ref_xy = ref["xy_l"].copy()
+    ref = [ctx.detect_dev(*args(k), P_l, P_r, 0, 1)["xy_l"].copy() for k in (0, 1)]   # launches 1 and 2
     ctx.set_trunk_pairing(True)
-    ctx.detect_dev_submit(*args(0), 2, 3)                 # A: launched at once (nothing queued in front of it)
-    ctx.detect_dev_submit(*args(1), 4, 5)                 # B: held for a partner while A's trunk runs
+    ctx.detect_dev_submit(*args(0), 2, 3)                 # A: held for a partner
+    ctx.detect_dev_submit(*args(1), 4, 5)                 # B: completes the group, launch 3
+    ctx.detect_dev_submit(*args(0), 6, 7)                 # C: held
     with pytest.raises(capi.SpvoError) as e:
-        ctx.detect_dev_submit(*args(0), 6, 7)             # C: completes the group, whose launch fails
+        ctx.detect_dev_submit(*args(1), 8, 9)             # D: completes the group, whose launch fails
     assert "injected" in str(e.value)
-    a = ctx.detect_wait(P_l, P_r)
-    assert np.array_equal(a["xy_l"], ref_xy)              # A is untouched
+    assert np.array_equal(ctx.detect_wait(P_l, P_r)["xy_l"], ref[0])      # A and B are untouched
+    assert np.array_equal(ctx.detect_wait(P_l, P_r)["xy_l"], ref[1])
     with pytest.raises(capi.SpvoError) as e:
-        ctx.detect_wait(P_l, P_r)                         # B: accepted earlier, never launched
+        ctx.detect_wait(P_l, P_r)                         # C: accepted earlier, never launched
     assert e.value.code == -4 and "launch had failed" in str(e.value)
     with pytest.raises(capi.SpvoError) as e:
-        ctx.detect_wait(P_l, P_r)                         # C was never queued
+        ctx.detect_wait(P_l, P_r)                         # D was never queued
     assert e.value.code == -4
-    ctx.detect_dev_submit(*args(0), 8, 9)                 # the context keeps working (slots 4..7 are free again)
-    ctx.detect_dev_submit(*args(1), 4, 5)
-    again = ctx.detect_wait(P_l, P_r)
-    assert np.array_equal(again["xy_l"], ref_xy)
-    assert len(ctx.detect_wait(P_l, P_r)["xy_l"]) > 0
+    ctx.detect_dev_submit(*args(0), 10, 11)               # the context keeps working (the failed members' slots are free again)
+    ctx.detect_dev_submit(*args(1), 6, 7)
+    assert np.array_equal(ctx.detect_wait(P_l, P_r)["xy_l"], ref[0])
+    assert np.array_equal(ctx.detect_wait(P_l, P_r)["xy_l"], ref[1])
+    # ... and a held pair that is asked for before its partner arrives is launched alone, by the wait
+    ctx.detect_dev_submit(*args(0), 12, 13)
+    assert np.array_equal(ctx.detect_wait(P_l, P_r)["xy_l"], ref[0])
     ctx.close()
 
 
