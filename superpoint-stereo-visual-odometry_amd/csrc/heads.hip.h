@@ -42,8 +42,8 @@
 namespace spvo {
 
 struct HeadsArgs {
-  const float *in_det, *in_desc;        // padded planes: image 0, first of the 256 input channels of each branch
-  size_t det_in_per_image, desc_in_per_image;   // floats
+  const float *in_det, *in_desc;        // padded planes: image 0, first of the 256 input channels of each branch (F16IN: C8 fp16 groups [g][hp][wp][8])
+  size_t det_in_per_image, desc_in_per_image;   // in 4-byte units
   int in_hp, in_wp;
   const float *wpack;                   // pack_heads_weights()
   float *det;                           // [img][65][hp][wp] padded planes (same level: hp, wp as the input)
@@ -62,8 +62,10 @@ constexpr int HEADS_LDS_BYTES = (2 * HEADS_CHUNK_FLOATS + HEADS_SRED_FLOATS) * 4
 
 // OIHW 1x1 weights + biases of both heads -> [unit 21][s4 16][lane 64][e 4] (lane l: output channel 16 u + (l & 15) of the unit's
 // branch, input channel 16 s4 + 4 e + (l >> 4): the A operand of k-step 4 s4 + e) followed by [21 x 16] biases; detector channels
-// beyond `cout_det` are zero.
-inline std::vector<float> pack_heads_weights(const float *w_det, const float *b_det, int cout_det, const float *w_desc, const float *b_desc) {
+// beyond `cout_det` are zero.  `f16` (FP16 engines, whose activations are C8 fp16): the weights rounded to fp16 as conv_f16.hip.h's
+// packer rounds them (biases stay fp32), and the lane's four k-steps are four CONSECUTIVE input channels -- 16 s4 + 4 (l >> 4) + e --
+// so that the loader's lane fetches them as one 8-byte piece of a C8 group.
+inline std::vector<float> pack_heads_weights(const float *w_det, const float *b_det, int cout_det, const float *w_desc, const float *b_desc, bool f16 = false) {
   std::vector<float> out((size_t)HEADS_UNITS * 16 * 64 * 4 + HEADS_UNITS * 16, 0.f);
   float *bias = out.data() + (size_t)HEADS_UNITS * 16 * 64 * 4;
   for (int u = 0; u < HEADS_UNITS; ++u)
@@ -74,8 +76,8 @@ inline std::vector<float> pack_heads_weights(const float *w_det, const float *b_
       const float *w = (det ? w_det : w_desc) + (size_t)co * HEADS_CIN;
       bias[16 * u + o] = det ? b_det[co] : b_desc[co];
       for (int ci = 0; ci < HEADS_CIN; ++ci) {
-        const int s4 = ci >> 4, e = (ci >> 2) & 3, lane = 16 * (ci & 3) + o;
-        out[(((size_t)u * 16 + s4) * 64 + lane) * 4 + e] = w[ci];
+        const int s4 = ci >> 4, e = f16 ? ci & 3 : (ci >> 2) & 3, lane = 16 * (f16 ? (ci >> 2) & 3 : ci & 3) + o;
+        out[(((size_t)u * 16 + s4) * 64 + lane) * 4 + e] = f16 ? (float)(_Float16)w[ci] : w[ci];
       }
     }
   return out;
@@ -314,12 +316,16 @@ constexpr unsigned HEADS_A1 = heads_hm(1, 1, 1, 1, 1, 1), HEADS_B1 = heads_hm(0,
 // wave's loads and stores IN ORDER: with the activation loads in the computing waves (round 5's second form) every weight fetch issued
 // behind them waited for their HBM latency, and the chunked pipeline hid nothing (49 us; with the loader 3x us).  Pass v (0..3) covers the
 // quarter of the chunk the v-th computing wave would have staged: tile v & 1, input channels 16 (2 i + (v >> 1)) + 4 e + (lane >> 4).
+template <bool F16IN>
 struct HeadsLoader {
-  const float *src[2][2];   // [tile][branch]: this lane's pixel, channel lane >> 4
+  typedef unsigned heads_u2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 heads_h4 __attribute__((ext_vector_type(4)));
+  const float *src[2][2];   // [tile][branch]: this lane's pixel, channel lane >> 4 (F16IN: channels 4 (lane >> 4) .. + 3 of the branch's first C8 groups)
   size_t plane;
   int lane, nh;
   bool ok[2];               // the lane's pixel of each tile exists in the images
-  heads_f4 sv[4][4];        // [pass][branch * 2 + i]: the chunk in flight
+  heads_f4 sv[F16IN ? 1 : 4][4];   // [pass][branch * 2 + i]: the chunk in flight
+  heads_u2 hv[F16IN ? 4 : 1][4];   // the same of an FP16 engine: four fp16 values per piece
   __device__ __forceinline__ void pixels(const HeadsArgs &a, int t, int nh_, int npx) {
     const int hw = a.H * a.W;
     nh = nh_;
@@ -329,7 +335,9 @@ struct HeadsLoader {
       ok[h] = h < nh && fpx < npx;
       const int fc = ok[h] ? fpx : 0;
       const int img = fc / hw, rem = fc - img * hw, y = rem / a.W, x = rem - y * a.W;
-      const size_t pix = (size_t)(y + PADY) * a.in_wp + (x + PADX) + (size_t)(lane >> 4) * plane;
+      const size_t at = (size_t)(y + PADY) * a.in_wp + (x + PADX);
+      // F16IN: a pixel of a C8 group is 16 bytes = four 4-byte units; the lane's four channels are its low or high half
+      const size_t pix = F16IN ? ((size_t)(lane >> 5) * plane + at) * 4 + ((lane >> 4) & 1) * 2 : at + (size_t)(lane >> 4) * plane;
       src[h][0] = a.in_det + (size_t)img * a.det_in_per_image + pix;
       src[h][1] = a.in_desc + (size_t)img * a.desc_in_per_image + pix;
     }
@@ -342,9 +350,14 @@ struct HeadsLoader {
 #pragma unroll
       for (int head = 0; head < 2; ++head)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+          if constexpr (F16IN) {   // input channels 64 c + 16 (2 i + (v >> 1)) + 4 (lane >> 4) + e: C8 group 8 c + 2 (2 i + (v >> 1)) + (lane >> 5)
+            hv[v][head * 2 + i] = *reinterpret_cast<const heads_u2 *>(src[v & 1][head] + (size_t)(8 * c + 2 * (2 * i + (v >> 1))) * plane * 4);
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) sv[v][head * 2 + i][e] = src[v & 1][head][(size_t)(64 * c + 16 * (2 * i + (v >> 1)) + 4 * e) * plane];
+            for (int e = 0; e < 4; ++e) sv[v][head * 2 + i][e] = src[v & 1][head][(size_t)(64 * c + 16 * (2 * i + (v >> 1)) + 4 * e) * plane];
+          }
+        }
     }
   }
   __device__ __forceinline__ void store(float *sx) const {
@@ -355,8 +368,16 @@ struct HeadsLoader {
 #pragma unroll
       for (int head = 0; head < 2; ++head)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-          *reinterpret_cast<heads_f4 *>(sx + ((size_t)((head * 4 + 2 * i + (v >> 1)) * 2 + (v & 1)) * 64 + lane) * 4) = ok[v & 1] ? sv[v][head * 2 + i] : heads_f4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 2; ++i) {
+          heads_f4 val;
+          if constexpr (F16IN) {
+            const heads_h4 h4 = __builtin_bit_cast(heads_h4, hv[v][head * 2 + i]);
+            val = heads_f4{(float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]};
+          } else {
+            val = sv[v][head * 2 + i];
+          }
+          *reinterpret_cast<heads_f4 *>(sx + ((size_t)((head * 4 + 2 * i + (v >> 1)) * 2 + (v & 1)) * 64 + lane) * 4) = ok[v & 1] ? val : heads_f4{0.f, 0.f, 0.f, 0.f};
+        }
     }
   }
 };
@@ -397,7 +418,7 @@ __device__ __forceinline__ void heads_wave_step(const HeadsArgs &a, float *smem,
 
 constexpr int HEADS_THREADS = 320;   // four computing waves + the loader
 
-template <int UNUSED = 0>   // (a template so that every translation unit may include this header)
+template <bool F16IN = false>   // F16IN: the activations are C8 fp16 (FP16 engines); everything behind the loader is the same fp32 arithmetic
 __global__ __launch_bounds__(HEADS_THREADS) void heads_fused_kernel(const HeadsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // two chunk buffers, then [wave 4][tile 2][px 16] partial squared norms
   const int tid = threadIdx.x, lane = tid & 63;
@@ -408,7 +429,7 @@ __global__ __launch_bounds__(HEADS_THREADS) void heads_fused_kernel(const HeadsA
   if (tb >= te) return;
   int buf = 0;
   if (w == 4) {   // ---- the loader: chunk k + 1 is fetched and stored while the computing waves multiply chunk k
-    HeadsLoader ld;
+    HeadsLoader<F16IN> ld;
     ld.plane = (size_t)a.in_hp * a.in_wp;
     ld.lane = lane;
     ld.pixels(a, tb, te - tb >= 2 ? 2 : 1, npx);

@@ -556,7 +556,7 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
       // convolutions convPa / convDa write channels 0..255 and 256..511 of one tensor) run as ONE layer with the output
       // channels concatenated: one launch instead of two, and 480 workgroups on 256 CUs instead of twice 240.
       std::vector<float> wcat, bcat;
-      if (!c->int8 && !c->fp16 && !c->s3 && op.ks == 3 && op.cin > 1 && !bn && !add && !pool && (op.cout % CO_TILE) == 0 && i + 1 < no &&
+      if (!c->s3 && op.ks == 3 && op.cin > 1 && !bn && !add && !pool && (op.cout % CO_TILE) == 0 && i + 1 < no &&
           tuning("merge_siblings", 1)) {
         Op &nx = c->ops[i + 1];
         const Raw &rn = raws[i + 1];
@@ -750,16 +750,18 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
     }
   }
   // The tail of the SuperPoint graphs -- convPb 256 -> 65, convDb 256 -> 256 (both 1x1, plain, reading two channel ranges of one
-  // tensor or two tensors), L2 normalisation -- as ONE launch (heads.hip.h) instead of three: FP32 engines only; tuning "heads_fused" = 0 keeps the plan's ops.
-  if (!c->fp16 && !c->int8 && !c->s3 && c->head_start + 3 == c->ops.size() && tuning("heads_fused", 1)) {
+  // tensor or two tensors), L2 normalisation -- as ONE launch (heads.hip.h) instead of three: FP32 and FP16 engines
+  // (the latter: the loader wave converts the C8 fp16 activations, the weights are the fp16-rounded ones); tuning "heads_fused" = 0 keeps the plan's ops.
+  if (!c->int8 && !c->s3 && c->head_start + 3 == c->ops.size() && tuning("heads_fused", 1)) {
     const size_t hs = c->head_start;
     const Op &pb = c->ops[hs], &db = c->ops[hs + 1], &nm = c->ops[hs + 2];
     const bool plain = pb.type == OP_CONV && db.type == OP_CONV && nm.type == OP_L2NORM && pb.ks == 1 && db.ks == 1 && pb.flags == 0 && db.flags == 0 &&
                        pb.cin == HEADS_CIN && db.cin == HEADS_CIN && pb.cout == 65 && db.cout == 256 && pb.out == c->t_det && pb.out_c_off == 0 &&
                        db.out_c_off == 0 && nm.in == db.out && nm.out == c->t_desc && c->tensors[pb.in].level == 3 && c->tensors[db.in].level == 3 &&
-                       !c->tensors[pb.in].nhwc && !c->tensors[db.in].nhwc && !pb.merged && !db.merged;   // (the two branches may read one tensor -- the VGG plan's merged convPa + convDa output -- or two)
+                       !c->tensors[pb.in].nhwc && !c->tensors[db.in].nhwc && !pb.merged && !db.merged &&
+                       c->tensors[pb.in].f16 == c->fp16 && c->tensors[db.in].f16 == c->fp16 && (!c->fp16 || ((pb.in_c_off | db.in_c_off) % 8) == 0);   // (the two branches may read one tensor -- the VGG plan's merged convPa + convDa output -- or two)
     if (plain) {
-      const std::vector<float> pk = pack_heads_weights(payload + raws[hs].w_off, payload + raws[hs].b_off, pb.cout, payload + raws[hs + 1].w_off, payload + raws[hs + 1].b_off);
+      const std::vector<float> pk = pack_heads_weights(payload + raws[hs].w_off, payload + raws[hs].b_off, pb.cout, payload + raws[hs + 1].w_off, payload + raws[hs + 1].b_off, c->fp16);
       int rc = dev_alloc(c, &c->d_heads_w, pk.size(), false);
       if (rc) return rc;
       HIP_TRY(c, hipMemcpy(c->d_heads_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));

@@ -253,24 +253,28 @@ int launch_heads(spvo_ctx *c, int batch, hipStream_t stream) {
   static bool ready[64] = {};
   const int dev = c->cfg.device & 63;
   if (!ready[dev]) {
-    HIP_TRY(c, hipFuncSetAttribute((const void *)heads_fused_kernel<>, hipFuncAttributeMaxDynamicSharedMemorySize, HEADS_LDS_BYTES));
+    HIP_TRY(c, hipFuncSetAttribute((const void *)heads_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, HEADS_LDS_BYTES));
+    HIP_TRY(c, hipFuncSetAttribute((const void *)heads_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, HEADS_LDS_BYTES));
     ready[dev] = true;
   }
+  const bool f16 = ti.f16;   // an FP16 engine: C8 fp16 activations in, the same fp32 arithmetic and fp32 bindings out
   const size_t plane = (size_t)ti.hp * ti.wp;
   HeadsArgs a;
-  a.in_det = ring_ptr(c, ti) + (size_t)pb.in_c_off * plane; a.det_in_per_image = ti.per_image;
-  a.in_desc = ring_ptr(c, te) + (size_t)db.in_c_off * plane; a.desc_in_per_image = te.per_image;
+  a.in_det = ring_ptr(c, ti) + (size_t)pb.in_c_off * plane / (f16 ? 2 : 1); a.det_in_per_image = ti.per_image;
+  a.in_desc = ring_ptr(c, te) + (size_t)db.in_c_off * plane / (f16 ? 2 : 1); a.desc_in_per_image = te.per_image;
   a.in_hp = ti.hp; a.in_wp = ti.wp;
   a.wpack = c->d_heads_w;
   a.det = ring_ptr(c, tdet); a.det_per_image = tdet.per_image;
   a.desc_raw = c->heads_keep_raw ? ring_ptr(c, traw) : nullptr; a.raw_per_image = traw.per_image;
   a.desc = ring_ptr(c, tdesc);
   a.H = ti.H; a.W = ti.W; a.batch = batch;
-  const double hbytes = batch * ((double)(pb.cin + db.cin) * ti.H * ti.W * 4 + (double)(pb.cout + 2 * db.cout) * ti.H * ti.W * 4) + (double)(pb.cout * pb.cin + db.cout * db.cin) * 4;
+  const double hbytes = batch * ((double)(pb.cin + db.cin) * ti.H * ti.W * (f16 ? 2 : 4) + (double)(pb.cout + 2 * db.cout) * ti.H * ti.W * 4) + (double)(pb.cout * pb.cin + db.cout * db.cin) * 4;
   ScopedStage st(c, stage_id(c, "heads"), (pb.flops_per_image + db.flops_per_image) * batch, hbytes, stream);
   // one workgroup per CU: each takes an equal share of the 16-pixel tiles of all images (heads.hip.h)
   const int ntiles = (batch * ti.H * ti.W + 15) / 16;
-  hipLaunchKernelGGL(heads_fused_kernel<>, dim3(std::min(c->num_cus, (ntiles + 1) / 2)), dim3(HEADS_THREADS), HEADS_LDS_BYTES, stream, a);
+  const dim3 grid(std::min(c->num_cus, (ntiles + 1) / 2));
+  if (f16) hipLaunchKernelGGL(heads_fused_kernel<true>, grid, dim3(HEADS_THREADS), HEADS_LDS_BYTES, stream, a);
+  else hipLaunchKernelGGL(heads_fused_kernel<false>, grid, dim3(HEADS_THREADS), HEADS_LDS_BYTES, stream, a);
   HIP_TRY(c, hipGetLastError());
   return SPVO_OK;
 }
