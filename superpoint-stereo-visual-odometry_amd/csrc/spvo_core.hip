@@ -39,7 +39,7 @@ int stage_id(spvo_ctx *c, const std::string &name) {
 // ---- diagnostic switches (include/spvo.h: spvo_set_tuning).  One process-wide table, filled by explicit calls only.
 namespace {
 const char *const kTuningNames[] = {"winograd", "wino4", "wino_narrow", "wino_dynamic", "winograd_min_tiles", "wino4_min_tiles", "merge_siblings", "heads_fused",
-                                    "heads_on_net", "heads_split", "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing", "nms_first", "upload_side", "inject_launch_failure", "int8_fused", "pair_always"};
+                                    "heads_on_net", "heads_split", "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing", "nms_first", "upload_side", "inject_launch_failure", "int8_fused", "pair_always", "preprocess_fused", "heads_keep_raw"};
 constexpr int kTuningCount = sizeof kTuningNames / sizeof kTuningNames[0];
 std::mutex g_tuning_mutex;
 bool g_tuning_set[kTuningCount] = {};
@@ -774,6 +774,11 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
     for (auto &o : c->ops) if (o.type == OP_CONV && (!best || o.flops_per_image > best->flops_per_image)) best = &o;
     if (best) best->dominant = true;
   }
+  {   // a submission's preprocess inside the first layer's launch (conv_first_pre.hip.h): FP32 engines whose first op is the plain 3x3 layer on the input plane
+    const Op &o0 = c->ops[0];
+    c->pre_fused = !c->fp16 && !c->int8 && !c->s3 && c->head_start >= 1 && o0.type == OP_CONV && o0.cin == 1 && o0.ks == 3 && o0.in == c->t_input && !o0.d_bn_scale &&
+                   !(o0.flags & (FLAG_POOL | FLAG_ADD)) && !c->tensors[o0.out].nhwc && (c->W % 8) == 0 && tuning("preprocess_fused", 1) != 0;
+  }
   {   // where a submission's heads run (spvo_detect.hip): behind the trunk on the network stream when most of the trunk's work is in
       // launches of one 512-thread workgroup per CU (conv_wino4.hip.h), beside which they would starve; on the tail stream otherwise
     double all = 0, big = 0;
@@ -874,13 +879,14 @@ int spvo_profile_stage_kernel(spvo_ctx *c, const char *stage, char *name, size_t
     const char *k = "other";
     double f = 1.0;
     if (op.type == OP_CONV) {
-      if (c->int8) k = "conv_i8_kernel";
+      if (c->int8) k = (op.fused_dw >= 0 || op.fused_stem) ? "dwpw_i8_kernel" : "conv_i8_kernel";   // (the fused block: depthwise 3x3 + pointwise 1x1 in one launch)
       else if (c->fp16) k = "conv_f16_kernel";
       else if (c->s3) { k = "conv_s3_kernel"; f = 6.0; }
       else if (op.wino4) { k = "conv_wino4_kernel"; f = 0.25; }
       else if (op.wino) { k = "conv_wino2_kernel"; f = 4.0 / 9.0; }
       else k = "conv_mfma_kernel";
     }
+    if (op.type == OP_DWCONV) k = c->int8 ? "dwconv3x3_i8_kernel" : c->fp16 ? "dwconv3x3_f16_kernel" : "dwconv3x3_kernel";
     if (name && name_cap) { std::strncpy(name, k, name_cap - 1); name[name_cap - 1] = 0; }
     if (executed_per_algorithmic) *executed_per_algorithmic = f;
     return SPVO_OK;

@@ -3,6 +3,7 @@
 #include "spvo_internal.hip.h"
 #include "conv_mfma.hip.h"
 #include "post.hip.h"
+#include "conv_first_pre.hip.h"
 #include "orb.hip.h"
 
 namespace spvo_int {
@@ -96,6 +97,39 @@ int launch_preprocess(spvo_ctx *c, const uint8_t *d_src0, const uint8_t *d_src1,
   dim3 grid((c->W + 63) / 64, (c->H + 3) / 4, count);
   hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, c->stream, d_src0, d_src1, stride, rows, cols, g.row_off, g.col_off, g.crop_rows, g.crop_cols, tab, c->H, c->W,
                      resized_dst ? resized_dst : c->d_resized + (size_t)(slot0 & 1) * c->H * c->W, tin.d + (size_t)slot0 * tin.per_image, tin.per_image, tin.hp, tin.wp, identity);
+  HIP_TRY(c, hipGetLastError());
+  return SPVO_OK;
+}
+
+// the same, inside the first layer's launch (conv_first_pre.hip.h): the images of a group of `n` submissions (two each) -> resized u8 images,
+// fp32 input planes and the first layer's output planes of the group's set.  The tables are the context's (ensure_tables at submission).
+int launch_first_pre(spvo_ctx *c, PendingDetect *const *mem, int n, hipStream_t stream) {
+  const Op &op = c->ops[0];
+  const Tensor &ti = c->tensors[op.in], &to = c->tensors[op.out];
+  const CropGeomS &g = mem[0]->g;
+  FirstPreArgs a;
+  for (int k = 0; k < 4; ++k) { a.src[k] = nullptr; a.out_u8[k] = nullptr; }
+  const size_t hw = (size_t)c->H * c->W;
+  for (int m = 0; m < n; ++m)
+    for (int i = 0; i < 2; ++i) {
+      a.src[2 * m + i] = mem[m]->src[i];
+      // (without a buffer of its own a submission's resized images go where the stand-alone entry points keep theirs: the last submission's stay)
+      a.out_u8[2 * m + i] = mem[m]->res_dst ? mem[m]->res_dst + i * hw : (m == n - 1 ? c->d_resized + i * hw : nullptr);
+    }
+  a.stride = mem[0]->stride;
+  a.row_off = g.row_off; a.col_off = g.col_off; a.crop_rows = g.crop_rows; a.crop_cols = g.crop_cols;
+  a.identity = (g.crop_rows == c->H && g.crop_cols == c->W) ? 1 : 0;
+  a.tab.xi = c->d_tab; a.tab.xa0 = c->d_tab + c->W; a.tab.xa1 = c->d_tab + 2 * c->W;
+  a.tab.yi = c->d_tab + 3 * c->W; a.tab.yb0 = a.tab.yi + c->H; a.tab.yb1 = a.tab.yi + 2 * c->H;
+  a.in_plane = ti.d; a.in_per_image = ti.per_image;
+  a.out = to.dr[c->cur_ring] ? to.dr[c->cur_ring] : to.d;
+  a.w = op.d_w; a.bias = op.d_b;
+  a.H = ti.H; a.W = ti.W; a.hp = ti.hp; a.wp = ti.wp; a.out_ctot = to.ch; a.out_coff = op.out_c_off; a.cout = op.cout;
+  const int batch = 2 * n;
+  ScopedStage st(c, op.stage, op.flops_per_image * batch, 0.0, stream);
+  const dim3 grid((ti.W + 255) / 256, (ti.H + 3) / 4, batch);
+  if (op.flags & FLAG_RELU) hipLaunchKernelGGL(conv_first4_pre_kernel<true>, grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(conv_first4_pre_kernel<false>, grid, dim3(256), 0, stream, a);
   HIP_TRY(c, hipGetLastError());
   return SPVO_OK;
 }
@@ -430,9 +464,21 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   }
   // ---- phase A, at once: the pair's images into the network's input planes (images 2 * position in the group, + 1).  Same stream as
   // the trunks: it runs behind the trunk that is using the input planes now.
+  // (preprocess fused into the first layer, conv_first_pre.hip.h: one launch reads the images of the whole group with ONE crop geometry and the
+  // context's tables -- a held submission of another geometry goes first, alone)
+  if (c->pre_fused && c->held) {
+    const PendingDetect &h = c->pendq.back();
+    if (h.rows != rows || h.cols != cols || h.stride != stride || h.g.crop_rows != g.crop_rows || h.g.crop_cols != g.crop_cols || h.g.row_off != g.row_off || h.g.col_off != g.col_off) {
+      int rc = launch_group(c, false);
+      if (rc) return rc;
+    }
+  }
   const int pos = c->held;      // 0, or 1 when a held submission is waiting for a partner
   c->post = c->stream;
-  {
+  if (c->pre_fused) {
+    int rc = ensure_tables(c, g);
+    if (rc) return rc;
+  } else {
     ScopedStage sp(c, stage_id(c, "preprocess"));
     // the resized u8 images (what nn.cpp:154 pushes to images_dq) stay in device memory here: one byte per thread into pinned host
     // memory made this kernel 31 us instead of 8, in front of the whole network
@@ -446,6 +492,7 @@ static int detect_submit(spvo_ctx *c, const uint8_t *d_l, const uint8_t *d_r, in
   pd.rows = rows; pd.cols = cols;
   pd.slot_l = slot_l; pd.slot_r = slot_r; pd.prev_l = prev_l; pd.ring = ring; pd.extras = extras; pd.early_res = (extras & 1) != 0;
   pd.launched = false; pd.img0 = 2 * pos; pd.tring = ring;
+  if (c->pre_fused) { pd.pre_pending = true; pd.src[0] = srcs[0]; pd.src[1] = srcs[1]; pd.res_dst = (extras & 1) ? c->d_resized_r[ring] : nullptr; pd.stride = stride; }
   c->pendq.push_back(pd);
   c->held += 1;
   // ---- phases B and C now, unless the pair may wait for a partner: pairing is on, it is the first of its group, and an earlier
@@ -587,7 +634,8 @@ static int launch_group_body(spvo_ctx *c) {
   int rc;
   {
     ScopedStage net(c, stage_id(c, "net"));
-    rc = run_ops(c, batch, 0, std::min<size_t>(1, c->head_start), c->stream);
+    rc = mem[0]->pre_pending ? launch_first_pre(c, mem, n, c->stream) : run_ops(c, batch, 0, std::min<size_t>(1, c->head_start), c->stream);
+    for (int m = 0; m < n; ++m) mem[m]->pre_pending = false;
     // The resized images leave for their sets' pinned mirrors UNDER the network: a copy kernel (16 bytes per lane, no SDMA engine involved)
     // on the TAIL stream behind the FIRST layer -- beside it (conv1a is bound by its 217 MB of stores) the copy made that layer 54 us
     // instead of 37 -- i.e. beside conv1b, which leaves 12 CUs free and does not notice

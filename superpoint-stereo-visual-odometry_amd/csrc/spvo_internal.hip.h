@@ -137,6 +137,11 @@ struct PendingDetect {           // one spvo_detect*_submit in flight
   bool failed = false;           // its group's launch failed after the submission had been accepted: spvo_detect_wait / _collect takes it off the queue and reports that
   int img0 = 0;                  // its first image in the network's planes (0, or 2 as the second pair of a group)
   int tring = 0;                 // the set whose network outputs hold its detector / descriptor maps (its own, or its group's first)
+  // preprocess fused into the first layer (conv_first_pre.hip.h): what the launch of its group needs of the submission's images
+  bool pre_pending = false;
+  const uint8_t *src[2] = {nullptr, nullptr};
+  uint8_t *res_dst = nullptr;    // the submission's own buffer for its two resized images, or NULL (the context's)
+  size_t stride = 0;
 };
 
 
@@ -286,6 +291,7 @@ struct spvo_ctx {
   int prof_only = -1;            // >= 0: only this stage is timed (spvo_profile_only)
   std::vector<Stage> stages;
   std::vector<Pending> pending;
+  bool pre_fused = false;          // set by the plan loader: a submission's crop / resize / normalise runs inside its group's first layer (conv_first_pre.hip.h; tuning "preprocess_fused")
   bool heads_on_net = false;       // set by the plan loader: the heads of a submission stay on the network stream (VGG fp32) or go to the tail stream
   std::vector<hipEvent_t> free_events;
 };

@@ -13,6 +13,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "superpoint-ster
 import numpy as np
 from spvo import capi, weights
 capi.tuning_from_env()   # SPVO_TUNE_WINOGRAD=0 etc.: this measurement script opts in (the library itself reads no environment variable)
+capi.set_tuning("heads_keep_raw", 0)   # time the fused heads as a detector submission runs them (spvo_forward would also write the un-normalised planes it exposes)
 
 out_path = sys.argv[1]
 H, Wd = (int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "360x1176").split("x"))

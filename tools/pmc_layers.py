@@ -12,7 +12,7 @@ import collections, csv, glob, json, os, sys
 
 fetch_dir, write_dir, lr_path, out_path = sys.argv[1:5]
 passes = int(sys.argv[5]) if len(sys.argv) > 5 else 30
-LAYER_KERNELS = ("conv_", "heads_fused", "l2norm", "dwconv", "maxpool")
+LAYER_KERNELS = ("conv_", "heads_fused", "l2norm", "dwconv", "dwpw_", "maxpool")
 
 
 def sequence(d, counter):
@@ -32,6 +32,8 @@ per_counter = {}
 for name, d in (("FETCH_SIZE", fetch_dir), ("WRITE_SIZE", write_dir)):
     seq = sequence(d, name)
     L = len(layers)
+    if len(seq) > passes * L:      # dispatches in front of the loop (an INT8 engine's calibration passes run on an fp32 engine first)
+        seq = seq[len(seq) - passes * L:]
     if len(seq) % L or len(seq) // L != passes:
         raise SystemExit(f"{name}: {len(seq)} layer dispatches do not make {passes} passes of {L} layers")
     acc = collections.defaultdict(list)
