@@ -102,16 +102,10 @@ __device__ inline bool solve_linear(double *A, double *b) {
 // rotation: ~10 k f64 instructions, 58 us inside the pipeline) gave the same vector; both agree with the oracle's SVD to
 // rounding level of the f32 result (tests/test_gpu_odometry.py: <= 2e-6 relative).  A^T A squares the condition number:
 // the direction error is ~ eps (sigma_1 / sigma_3)^2 <= 1e-16 x 1e8, far below the f32 rounding of the stored point.
-__global__ __launch_bounds__(256) void triangulate_kernel(const double *__restrict__ Pl,
-                                                          const double *__restrict__ Pr,
-                                                          const float *__restrict__ xyl,
-                                                          const float *__restrict__ xyr, int n,
-                                                          float *__restrict__ xyz) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// one correspondence: (x0, y0) in the left, (x1, y1) in the right image -> out[0..2]
+__device__ __forceinline__ void triangulate_point(const double *Pl, const double *Pr, const double x0, const double y0, const double x1, const double y1, float *out) {
   double A[16];
   {
-    const double x0 = xyl[2 * i], y0 = xyl[2 * i + 1], x1 = xyr[2 * i], y1 = xyr[2 * i + 1];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       A[0 * 4 + k] = x0 * Pl[8 + k] - Pl[0 + k];
@@ -161,9 +155,37 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const double *__restri
   for (int it = 4; it < 200 && delta > 1e-13; ++it) inverse_step();
   const float f0 = (float)h0, f1 = (float)h1, f2 = (float)h2, f3 = (float)h3;
   const float scale = (f3 != 0.f) ? __fdiv_rn(1.0f, f3) : 1.0f;
-  xyz[3 * i + 0] = mul_rn(f0, scale);
-  xyz[3 * i + 1] = mul_rn(f1, scale);
-  xyz[3 * i + 2] = mul_rn(f2, scale);
+  out[0] = mul_rn(f0, scale);
+  out[1] = mul_rn(f1, scale);
+  out[2] = mul_rn(f2, scale);
+}
+
+__global__ __launch_bounds__(256) void triangulate_kernel(const double *__restrict__ Pl,
+                                                          const double *__restrict__ Pr,
+                                                          const float *__restrict__ xyl,
+                                                          const float *__restrict__ xyr, int n,
+                                                          float *__restrict__ xyz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  triangulate_point(Pl, Pr, xyl[2 * i], xyl[2 * i + 1], xyr[2 * i], xyr[2 * i + 1], xyz + 3 * i);
+}
+
+// The fused solve's first kernel (spvo_solve_submit): the same triangulation reading the call's packed inputs STRAIGHT from the pinned host
+// buffer the caller filled (64 doubles of header, then cl cr pl pr [2n floats each], prev_xyz [3n], prev_valid [n]) and leaving the device
+// copy the later kernels read -- a host-to-device copy in front of this kernel was one more dependent operation on the solver's stream, and
+// every operation of that chain costs ~8-10 us whatever it does (the chain's latency bounds the frame loop of the small engines: a frame's
+// solve needs the previous frame's pose as its prior).  Every byte crosses PCIe once: 16-byte pieces spread over the grid, the projection
+// matrices once per workgroup into LDS.
+__global__ __launch_bounds__(256) void solve_in_triangulate_kernel(const uint4 *__restrict__ h_in, uint4 *__restrict__ d_in, int n16, int n, float *__restrict__ xyz) {
+  __shared__ double sP[24];
+  const int tid = threadIdx.x, i = blockIdx.x * 256 + tid;
+  for (int k = i; k < n16; k += gridDim.x * 256) d_in[k] = h_in[k];
+  if (tid < 24) sP[tid] = reinterpret_cast<const double *>(h_in)[tid];
+  __syncthreads();
+  if (i >= n) return;
+  const float2 *fw = reinterpret_cast<const float2 *>(h_in + 32);   // behind the 512-byte header
+  const float2 l = fw[i], r = fw[n + i];
+  triangulate_point(sP, sP + 12, l.x, l.y, r.x, r.y, xyz + 3 * i);
 }
 
 // ------------------------------------------------------------------------- K15
@@ -583,13 +605,13 @@ __device__ __forceinline__ void cost32(const double *P /*3x4*/, const double *q,
 // `ctl` (optional, device): ctl[0] = run flag, ctl[1] = n_obs -- written by solve_gate_build_kernel
 // when the whole of solveStereoOdometry is enqueued without a host round trip.
 template <int NT>
-__global__ __launch_bounds__(NT) void pnp_refine_kernel(const double *__restrict__ Pl,
-                                                        const double *__restrict__ Pr,
-                                                        const ObsDev *__restrict__ obs, int n_obs_host,
-                                                        const int *__restrict__ ctl,
-                                                        const double *__restrict__ start /*q,t*/,
-                                                        int max_iterations, double huber_delta,
-                                                        RefineOut *__restrict__ out) {
+__device__ __forceinline__ void pnp_refine_body(const double *__restrict__ Pl,
+                                                const double *__restrict__ Pr,
+                                                const ObsDev *__restrict__ obs, int n_obs_host,
+                                                const int *__restrict__ ctl,
+                                                const double *__restrict__ start /*q,t*/,
+                                                int max_iterations, double huber_delta,
+                                                RefineOut *__restrict__ out) {
   const int n_obs = ctl ? ctl[1] : n_obs_host;
   if (ctl && ctl[0] == 0) {   // gated out (base.cpp:244-260) or refinement_degree == 0
     if (threadIdx.x == 0) {
@@ -777,6 +799,27 @@ __global__ __launch_bounds__(NT) void pnp_refine_kernel(const double *__restrict
     out->v[7] = it; out->v[8] = converged; out->v[9] = usable;
     out->v[10] = initial_cost; out->v[11] = final_cost;
   }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void pnp_refine_kernel(const double *__restrict__ Pl, const double *__restrict__ Pr, const ObsDev *__restrict__ obs, int n_obs_host,
+                                                        const int *__restrict__ ctl, const double *__restrict__ start /*q,t*/, int max_iterations, double huber_delta,
+                                                        RefineOut *__restrict__ out) {
+  pnp_refine_body<NT>(Pl, Pr, obs, n_obs_host, ctl, start, max_iterations, huber_delta, out);
+}
+
+// The fused solve's last kernel: the refinement, then everything the host collects -- the triangulated points and the inlier list
+// (`o_words` 4-byte words at d_o) and the 40 doubles of results (RANSAC, gate, refinement) -- written into the call's pinned host buffers by
+// this workgroup (posted PCIe writes, complete when the event behind the kernel is): two device-to-host copies fewer in the chain.
+template <int NT>
+__global__ __launch_bounds__(NT) void pnp_refine_out_kernel(const double *__restrict__ Pl, const double *__restrict__ Pr, const ObsDev *__restrict__ obs,
+                                                            const int *__restrict__ ctl, const double *__restrict__ start /*q,t*/, int max_iterations, double huber_delta,
+                                                            RefineOut *__restrict__ out, const unsigned *d_o, unsigned *h_o, int o_words, const double *d_res, double *h_res) {
+  pnp_refine_body<NT>(Pl, Pr, obs, 0, ctl, start, max_iterations, huber_delta, out);
+  __threadfence_block();
+  __syncthreads();   // (every thread comes back from the body: its early exits are workgroup-uniform)
+  for (int k = threadIdx.x; k < o_words; k += NT) h_o[k] = d_o[k];
+  if (threadIdx.x < 40) h_res[threadIdx.x] = reinterpret_cast<const volatile double *>(d_res)[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------- fused solve glue

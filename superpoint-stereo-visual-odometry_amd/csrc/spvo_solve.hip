@@ -206,7 +206,6 @@ int spvo_solve_submit(spvo_ctx *c, const spvo_solve_input *in) {
   }
   const size_t used = 64 * sizeof(double) + (size_t)12 * n * 4;
   const double tm1 = solve_timing ? now_us() : 0;
-  HIP_TRY(c, hipMemcpyAsync(c->d_solve_in, c->h_solve_in, used, hipMemcpyHostToDevice, c->stream2));
   const double *dh = (const double *)c->d_solve_in;
   const float *df = (const float *)(c->d_solve_in + 64 * sizeof(double));
   float *d_xyz = (float *)c->d_solve_o;
@@ -217,20 +216,22 @@ int spvo_solve_submit(spvo_ctx *c, const spvo_solve_input *in) {
   const double thr2 = in->ransac.reproj_error * in->ransac.reproj_error;
   {
     ScopedStage st(c, stage_id(c, "solve"), 0, 0, c->stream2);
-    hipLaunchKernelGGL(triangulate_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream2, dh, dh + 12, df, df + 2 * n, n, d_xyz);
+    // (the inputs travel inside the first kernel, the results inside the last one: see odometry.hip.h)
+    hipLaunchKernelGGL(solve_in_triangulate_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream2, reinterpret_cast<const uint4 *>(c->h_solve_in),
+                       reinterpret_cast<uint4 *>(c->d_solve_in), (int)(used / 16), n, d_xyz);
     if (n >= 4) {
       hipLaunchKernelGGL(ransac_hypothesis_kernel, dim3(in->ransac.iterations), dim3(64), 0, c->stream2, dh + 24, d_xyz, df + 4 * n, n, dh + 33, in->ransac.seed, thr2, rw);
       hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(256), 0, c->stream2, dh + 24, d_xyz, df + 4 * n, n, dh + 33, in->ransac.iterations, thr2, rw);
       hipLaunchKernelGGL(solve_gate_build_kernel, dim3(1), dim3(256), 0, c->stream2, dh, c->d_solve_res, d_inl, d_xyz, df, df + 2 * n, df + 4 * n, df + 6 * n,
                          have_prev ? df + 8 * n : (const float *)nullptr, have_prev ? (const int *)(df + 11 * n) : (const int *)nullptr, c->d_obs, c->d_ctl,
                          c->d_solve_res + 8);
-      hipLaunchKernelGGL(pnp_refine_kernel<512>, dim3(1), dim3(512), 0, c->stream2, dh, dh + 12, c->d_obs, 0, (const int *)c->d_ctl, c->d_solve_res + 8,
-                         in->refine.max_iterations, in->refine.huber_delta, (RefineOut *)(c->d_solve_res + 24));
+      hipLaunchKernelGGL(pnp_refine_out_kernel<512>, dim3(1), dim3(512), 0, c->stream2, dh, dh + 12, c->d_obs, (const int *)c->d_ctl, c->d_solve_res + 8,
+                         in->refine.max_iterations, in->refine.huber_delta, (RefineOut *)(c->d_solve_res + 24), reinterpret_cast<const unsigned *>(c->d_solve_o),
+                         reinterpret_cast<unsigned *>(c->h_solve_o), 4 * n, c->d_solve_res, c->h_solve_res);
     }
     HIP_TRY(c, hipGetLastError());
   }
-  HIP_TRY(c, hipMemcpyAsync(c->h_solve_o, c->d_solve_o, (size_t)4 * n * 4, hipMemcpyDeviceToHost, c->stream2));
-  if (n >= 4) HIP_TRY(c, hipMemcpyAsync(c->h_solve_res, c->d_solve_res, 40 * sizeof(double), hipMemcpyDeviceToHost, c->stream2));
+  if (n < 4) HIP_TRY(c, hipMemcpyAsync(c->h_solve_o, c->d_solve_o, (size_t)4 * n * 4, hipMemcpyDeviceToHost, c->stream2));   // (no model possible: only the points travel)
   if (!c->ev_solve) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_solve, hipEventDisableTiming));
   HIP_TRY(c, hipEventRecord(c->ev_solve, c->stream2));
   if (solve_timing) {
