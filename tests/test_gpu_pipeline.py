@@ -308,6 +308,38 @@ def test_trunk_pairing_does_not_change_results(graph, vgg_weights_path, squeeze_
             assert np.array_equal(ia, ib) and np.array_equal(da, db), k
 
 
+def test_preprocess_inside_the_first_layer_is_bit_identical(vgg_weights_path, stereo_pair, tuning):
+    """Round 5: a submission's crop / resize / normalise runs inside its group's first layer (csrc/conv_first_pre.hip.h) instead of in a
+    launch of its own (tuning "preprocess_fused" = 0).  Same integer arithmetic, same fp32 planes: every output -- resized u8 images,
+    keypoints, descriptors, matches -- is identical bit for bit, for pairs grouped two per launch, for a pair alone, and when a pair of
+    ANOTHER image size arrives while one is held (one launch has one crop geometry: the held pair then goes first, alone)."""
+    from spvo import capi
+    frames, _, P_l, P_r = stereo_pair
+    small = [(np.ascontiguousarray(L[4:-4, 8:-9]), np.ascontiguousarray(R[4:-4, 8:-9])) for L, R in frames]     # another size -> another crop
+    order = [frames[0], frames[1], small[0], frames[0], small[1], small[0]]
+    out = {}
+    for fused in (1, 0):
+        tuning(preprocess_fused=fused)
+        ctx = capi.Context()
+        ctx.load_weights(vgg_weights_path)
+        ctx.set_prematch(True, "KNN", False, 0.8)
+        ctx.set_trunk_pairing(True)
+        res = []
+        for k, (L, R) in enumerate(order):
+            ctx.detect_submit(L, R, 2 * k, 2 * k + 1)
+        for k in range(len(order)):
+            v = ctx.detect_collect_mirrors(P_l, P_r)
+            n = len(v["xy_l"])
+            m = ctx.match_slots(2 * k, 2 * k + 1, n)
+            res.append({**{key: np.array(v[key]) for key in ("xy_l", "xy_r", "desc_l", "desc_r", "resized_l", "resized_r")}, "mi": m[0].copy(), "md": m[1].copy()})
+        out[fused] = res
+        ctx.close()
+    for k, (a, b) in enumerate(zip(out[1], out[0])):
+        for key in a:
+            assert np.array_equal(a[key], b[key]), (k, key)
+    assert len(out[1][2]["xy_l"]) > 100 and len(out[1][0]["xy_l"]) > 100
+
+
 def test_a_failed_group_launch_keeps_the_queue_consistent(squeeze_weights_path, stereo_pair, tuning):
     """Trunk pairing, error path: the launch of a held group fails (injected: the context's fourth group launch) while one of its two
     members had already been accepted.  The submit that triggers the launch returns the error and is NOT queued; the member accepted
