@@ -390,7 +390,7 @@ __global__ __launch_bounds__(64) void ransac_hypothesis_kernel(const double *__r
   }
 }
 
-// deterministic block reduction of NV doubles per thread; result valid in thread 0's `out`
+// deterministic block reduction of NV doubles per thread; result in `out` (LDS), valid for every thread behind the closing barrier
 template <int NV, int NT>
 __device__ inline void block_reduce(const double *v, double *out, double *scratch /*[NV][NT/64]*/) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -402,27 +402,26 @@ __device__ inline void block_reduce(const double *v, double *out, double *scratc
     if (lane == 0) scratch[k * (NT / 64) + wave] = x;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < NV) {   // one value per thread, the waves' partial sums in wave order
+    const int k = threadIdx.x;
+    double s = 0;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      double s = 0;
-      for (int wv = 0; wv < NT / 64; ++wv) s += scratch[k * (NT / 64) + wv];
-      out[k] = s;
-    }
+    for (int wv = 0; wv < NT / 64; ++wv) s += scratch[k * (NT / 64) + wv];
+    out[k] = s;
   }
   __syncthreads();
 }
 
 // pick the best hypothesis, list its inliers in ascending order, Gauss-Newton refit
-__global__ __launch_bounds__(256) void ransac_select_kernel(const double *__restrict__ Kd,
-                                                            const float *__restrict__ xyz,
-                                                            const float *__restrict__ xy, int n,
-                                                            const double *__restrict__ prior,
-                                                            int iterations, double thr2, RansacWork w) {
-  __shared__ int s_cnt[256], s_it[256];
+// (a device function on NT threads: the stand-alone kernel below and the fused solve's tail kernel run the SAME instantiation, so that
+// spvo_pnp_ransac and spvo_solve_* return identical bits)
+template <int NT>
+__device__ __forceinline__ void ransac_select_body(const double *Kd, const float *xyz, const float *xy, int n, const double *prior,
+                                                   int iterations, double thr2, RansacWork w) {
+  __shared__ int s_cnt[NT], s_it[NT];
   __shared__ double s_pose[7];
-  __shared__ int s_base, s_wave_cnt[4];
-  __shared__ double s_red[27 * 4];
+  __shared__ int s_base, s_wave_cnt[NT / 64];
+  __shared__ double s_red[27 * (NT / 64)];
   __shared__ double s_sum[27];
   __shared__ int s_flag;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -430,13 +429,13 @@ __global__ __launch_bounds__(256) void ransac_select_kernel(const double *__rest
 #pragma unroll
   for (int k = 0; k < 9; ++k) K[k] = Kd[k];
   int bc = -1, bi = 0x7FFFFFFF;
-  for (int it = tid; it < iterations; it += 256) {
+  for (int it = tid; it < iterations; it += NT) {
     const int c = w.counts[it];
     if (c > bc) { bc = c; bi = it; }   // ascending it per thread: first max kept
   }
   s_cnt[tid] = bc; s_it[tid] = bi;
   __syncthreads();
-  for (int s = 128; s >= 1; s >>= 1) {
+  for (int s = NT / 2; s >= 1; s >>= 1) {
     if (tid < s) {
       const int oc = s_cnt[tid + s], oi = s_it[tid + s];
       if (oc > s_cnt[tid] || (oc == s_cnt[tid] && oi < s_it[tid])) { s_cnt[tid] = oc; s_it[tid] = oi; }
@@ -458,7 +457,7 @@ __global__ __launch_bounds__(256) void ransac_select_kernel(const double *__rest
   quat_to_rot(s_pose, R);
   t[0] = s_pose[4]; t[1] = s_pose[5]; t[2] = s_pose[6];
   // ordered compaction of the inlier indices
-  for (int base = 0; base < n; base += 256) {
+  for (int base = 0; base < n; base += NT) {
     const int i = base + tid;
     const bool in = (i < n) && reproj_inlier(K, R, t, xyz + 3 * i, xy + 2 * i, thr2);
     const unsigned long long m = __ballot(in);
@@ -468,7 +467,7 @@ __global__ __launch_bounds__(256) void ransac_select_kernel(const double *__rest
     for (int wv = 0; wv < wave; ++wv) off += s_wave_cnt[wv];
     if (in) w.inliers[off + __popcll(m & ((1ull << lane) - 1ull))] = i;
     __syncthreads();
-    if (tid == 0) s_base += s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+    if (tid == 0) for (int wv = 0; wv < NT / 64; ++wv) s_base += s_wave_cnt[wv];
     __syncthreads();
   }
   const int ninl = s_base;
@@ -479,7 +478,7 @@ __global__ __launch_bounds__(256) void ransac_select_kernel(const double *__rest
     double acc[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc[k] = 0;
-    for (int k = tid; k < ninl; k += 256) {
+    for (int k = tid; k < ninl; k += NT) {
       const int i = w.inliers[k];
       const double X[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
       const double uv[2] = {xy[2 * i], xy[2 * i + 1]};
@@ -493,7 +492,7 @@ __global__ __launch_bounds__(256) void ransac_select_kernel(const double *__rest
 #pragma unroll
       for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r[0] + J[6 + a] * r[1];
     }
-    block_reduce<27, 256>(acc, s_sum, s_red);
+    block_reduce<27, NT>(acc, s_sum, s_red);
     if (wave == 0) {   // the 6 x 6 normal equations: one row per lane (wave_solve6), lane 0 applies the step
       const int ra = min(lane, 5);
       double row[6];
@@ -523,6 +522,13 @@ __global__ __launch_bounds__(256) void ransac_select_kernel(const double *__rest
     w.result[3] = s_pose[4]; w.result[4] = s_pose[5]; w.result[5] = s_pose[6];
     w.result[6] = 1; w.result[7] = (double)ninl;
   }
+}
+
+constexpr int SOLVE_TAIL_THREADS = 512;   // the one workgroup behind the hypotheses: selection, gating, refinement
+
+__global__ __launch_bounds__(SOLVE_TAIL_THREADS) void ransac_select_kernel(const double *Kd, const float *xyz, const float *xy, int n, const double *prior,
+                                                                           int iterations, double thr2, RansacWork w) {
+  ransac_select_body<SOLVE_TAIL_THREADS>(Kd, xyz, xy, n, prior, iterations, thr2, w);
 }
 
 // ------------------------------------------------------------------------- K16
@@ -605,13 +611,8 @@ __device__ __forceinline__ void cost32(const double *P /*3x4*/, const double *q,
 // `ctl` (optional, device): ctl[0] = run flag, ctl[1] = n_obs -- written by solve_gate_build_kernel
 // when the whole of solveStereoOdometry is enqueued without a host round trip.
 template <int NT>
-__device__ __forceinline__ void pnp_refine_body(const double *__restrict__ Pl,
-                                                const double *__restrict__ Pr,
-                                                const ObsDev *__restrict__ obs, int n_obs_host,
-                                                const int *__restrict__ ctl,
-                                                const double *__restrict__ start /*q,t*/,
-                                                int max_iterations, double huber_delta,
-                                                RefineOut *__restrict__ out) {
+__device__ __forceinline__ void pnp_refine_body(const double *Pl, const double *Pr, const ObsDev *obs, int n_obs_host, const int *ctl, const double *start /*q,t*/,
+                                                int max_iterations, double huber_delta, RefineOut *out) {
   const int n_obs = ctl ? ctl[1] : n_obs_host;
   if (ctl && ctl[0] == 0) {   // gated out (base.cpp:244-260) or refinement_degree == 0
     if (threadIdx.x == 0) {
@@ -625,7 +626,6 @@ __device__ __forceinline__ void pnp_refine_body(const double *__restrict__ Pl,
   __shared__ double s_red[28 * (NT / 64)];
   __shared__ double s_sum[28];
   __shared__ int s_action;                 // 0 continue with candidate eval, 1 stop
-  __shared__ int s_eval_jac;
   const int tid = threadIdx.x;
   if (tid < 12) { s_P[tid] = Pl[tid]; s_P[12 + tid] = Pr[tid]; }
   if (tid < 7) s_x[tid] = start[tid];
@@ -663,21 +663,28 @@ __device__ __forceinline__ void pnp_refine_body(const double *__restrict__ Pl,
   };
 
   // thread-0 state (arrays in LDS: they are indexed dynamically)
-  __shared__ double A[36], g[6], scale[6], ds[6], s_As[36], s_gs[6], s_M[36], s_rhs[6];
+  __shared__ double A[36], g[6], scale[6];
   double cost = 0, radius = 1e4, decrease = 2.0, x_norm = 0;
   double model_change = 0;
   int invalid = 0, it = 0, converged = 0, usable = 0;
   double initial_cost = 0, final_cost = 0;
 
   evaluate(s_x, true);
-  if (tid == 0) {
-    int o = 0;
-    for (int a = 0; a < 6; ++a)
-      for (int b = a; b < 6; ++b) { A[a * 6 + b] = s_sum[o]; A[b * 6 + a] = s_sum[o]; ++o; }
-    for (int a = 0; a < 6; ++a) g[a] = s_sum[21 + a];
+  // The trust-region logic runs on every lane of wave 0 (its scalars are wave-uniform: the step below needs them in all lanes); lane 0
+  // writes what lives in LDS.  block_reduce's closing barrier makes s_sum visible.
+  auto unpack = [&]() {   // s_sum -> A (symmetric), g
+    if (tid == 0) {
+      int o = 0;
+      for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b) { A[a * 6 + b] = s_sum[o]; A[b * 6 + a] = s_sum[o]; ++o; }
+      for (int a = 0; a < 6; ++a) g[a] = s_sum[21 + a];
+    }
+  };
+  if (tid < 64) {
+    unpack();
     cost = 0.5 * s_sum[27];
     initial_cost = final_cost = cost;
-    for (int a = 0; a < 6; ++a) scale[a] = 1.0 / (1.0 + sqrt(A[a * 6 + a]));
+    if (tid == 0) for (int a = 0; a < 6; ++a) scale[a] = 1.0 / (1.0 + sqrt(s_sum[a * 6 - a * (a - 1) / 2]));   // (the diagonal entry A[a][a])
     x_norm = 0;
     for (int k = 0; k < 7; ++k) x_norm += s_x[k] * s_x[k];
     x_norm = sqrt(x_norm);
@@ -686,41 +693,46 @@ __device__ __forceinline__ void pnp_refine_body(const double *__restrict__ Pl,
     else {
       usable = 1;
       double gm = 0;
-      for (int a = 0; a < 6; ++a) gm = fmax(gm, fabs(g[a]));
+      for (int a = 0; a < 6; ++a) gm = fmax(gm, fabs(s_sum[21 + a]));
       if (gm <= 1e-10) { converged = 1; stop = 1; }
     }
     if (n_obs == 0) { converged = 1; usable = 1; stop = 1; }
-    s_action = stop;
+    if (tid == 0) s_action = stop;
   }
   __syncthreads();
 
   while (!s_action) {
-    // ---- thread 0: compute a trust-region step (possibly several invalid ones)
-    if (tid == 0) {
+    // ---- wave 0: compute a trust-region step (possibly several invalid ones).  The 6 x 6 system is solved across lanes (wave_solve6: lane
+    // r < 6 holds row r in registers; the same pivots, multipliers and update order as the serial solve_linear<6>, which walked a
+    // dynamically indexed array in LDS -- ~9 us per solve, the largest single piece of an iteration and of the whole solver chain, whose
+    // latency is the cycle time of the small engines' frame loop).  Every lane carries the loop's scalars (it, invalid, radius, decrease,
+    // model_change): they are wave-uniform, the other waves get them back through LDS below.
+    if (tid < 64) {
+      const int lane = tid, ra = min(lane, 5);
       int stop = 0, have_step = 0;
       while (!stop && !have_step) {
         if (it >= max_iterations) { stop = 1; break; }
         ++it;
-        double *As = s_As, *gs = s_gs, *M = s_M, *rhs = s_rhs;
-        for (int a = 0; a < 6; ++a) {
-          gs[a] = g[a] * scale[a];
-          for (int b = 0; b < 6; ++b) As[a * 6 + b] = A[a * 6 + b] * scale[a] * scale[b];
-        }
-        for (int k = 0; k < 36; ++k) M[k] = As[k];
-        for (int a = 0; a < 6; ++a) {
-          const double dg = fmin(fmax(As[a * 6 + a], 1e-6), 1e32) / radius;
-          M[a * 6 + a] += dg;
-          rhs[a] = -gs[a];
-        }
-        bool ok = solve_linear<6>(M, rhs);
+        const double sc_r = scale[ra], gs_r = g[ra] * sc_r;
+        double As_r[6], M_r[6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) { As_r[b] = A[ra * 6 + b] * sc_r * scale[b]; M_r[b] = As_r[b]; }
+        double diag = 0;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) diag = (b == ra) ? As_r[b] : diag;
+        const double dg = fmin(fmax(diag, 1e-6), 1e32) / radius;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) M_r[b] += (b == ra) ? dg : 0.0;
+        double x[6];
+        const bool ok = wave_solve6(M_r, -gs_r, lane, x);
         model_change = 0;
         if (ok) {
-          for (int a = 0; a < 6; ++a) {
-            ds[a] = rhs[a];
-            double Ad = 0;
-            for (int b = 0; b < 6; ++b) Ad += As[a * 6 + b] * rhs[b];
-            model_change -= rhs[a] * (gs[a] + 0.5 * Ad);
-          }
+          double Ad = 0;
+#pragma unroll
+          for (int b = 0; b < 6; ++b) Ad += As_r[b] * x[b];
+          const double inner = gs_r + 0.5 * Ad;          // row ra's (gs[a] + 0.5 (As d)[a])
+#pragma unroll
+          for (int a = 0; a < 6; ++a) model_change -= x[a] * lane_bcast(inner, a);   // in the order a = 0 .. 5 of the serial form
         }
         if (!ok || !(model_change > 0)) {
           if (++invalid >= 5) { usable = 0; stop = 1; break; }
@@ -730,7 +742,8 @@ __device__ __forceinline__ void pnp_refine_body(const double *__restrict__ Pl,
         invalid = 0;
         // candidate = Plus(x, ds * scale)
         double d[6];
-        for (int a = 0; a < 6; ++a) d[a] = ds[a] * scale[a];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) d[a] = x[a] * scale[a];
         const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
         double qc[4];
         if (nd > 0) {
@@ -740,16 +753,21 @@ __device__ __forceinline__ void pnp_refine_body(const double *__restrict__ Pl,
         } else {
           for (int k = 0; k < 4; ++k) qc[k] = s_x[k];
         }
-        for (int k = 0; k < 4; ++k) s_c[k] = qc[k];
-        for (int k = 0; k < 3; ++k) s_c[4 + k] = s_x[4 + k] + d[3 + k];
+        if (lane == 0) {
+          for (int k = 0; k < 4; ++k) s_c[k] = qc[k];
+          for (int k = 0; k < 3; ++k) s_c[4 + k] = s_x[4 + k] + d[3 + k];
+        }
         have_step = 1;
       }
-      s_action = stop;
+      if (lane == 0) s_action = stop;
     }
     __syncthreads();
     if (s_action) break;
-    evaluate(s_c, false);
-    if (tid == 0) {
+    // cost AND normal equations at the candidate in ONE pass over the residual blocks: an accepted candidate is the next iterate, and its
+    // Jacobian pass (a second evaluation of the same point, a second reduction, a second pair of barriers) was a third of an iteration;
+    // a rejected candidate (rare) wasted the Jacobian part
+    evaluate(s_c, true);
+    if (tid < 64) {
       const double cand_cost = 0.5 * s_sum[27];
       double sn2 = 0;
       for (int k = 0; k < 7; ++k) sn2 += (s_c[k] - s_x[k]) * (s_c[k] - s_x[k]);
@@ -769,30 +787,21 @@ __device__ __forceinline__ void pnp_refine_body(const double *__restrict__ Pl,
           }
         }
       }
-      if (accept) for (int k = 0; k < 7; ++k) s_x[k] = s_c[k];
-      s_eval_jac = accept;
-      s_action = stop;
-    }
-    __syncthreads();
-    if (s_action) break;
-    if (s_eval_jac) {
-      evaluate(s_x, true);
-      if (tid == 0) {
-        int o = 0;
-        for (int a = 0; a < 6; ++a)
-          for (int b = a; b < 6; ++b) { A[a * 6 + b] = s_sum[o]; A[b * 6 + a] = s_sum[o]; ++o; }
-        for (int a = 0; a < 6; ++a) g[a] = s_sum[21 + a];
-        cost = 0.5 * s_sum[27];
+      if (accept) {   // the candidate becomes the iterate: its sums are the next step's system
+        unpack();
+        cost = cand_cost;
         final_cost = cost;
         x_norm = 0;
-        for (int k = 0; k < 7; ++k) x_norm += s_x[k] * s_x[k];
+        for (int k = 0; k < 7; ++k) x_norm += s_c[k] * s_c[k];
         x_norm = sqrt(x_norm);
         double gm = 0;
-        for (int a = 0; a < 6; ++a) gm = fmax(gm, fabs(g[a]));
-        if (gm <= 1e-10 || radius < 1e-32) { converged = 1; s_action = 1; }
+        for (int a = 0; a < 6; ++a) gm = fmax(gm, fabs(s_sum[21 + a]));
+        if (gm <= 1e-10 || radius < 1e-32) { converged = 1; stop = 1; }
+        if (tid == 0) for (int k = 0; k < 7; ++k) s_x[k] = s_c[k];
       }
-      __syncthreads();
+      if (tid == 0) s_action = stop;
     }
+    __syncthreads();
   }
   if (tid == 0) {
     for (int k = 0; k < 7; ++k) out->v[k] = s_x[k];
@@ -808,20 +817,6 @@ __global__ __launch_bounds__(NT) void pnp_refine_kernel(const double *__restrict
   pnp_refine_body<NT>(Pl, Pr, obs, n_obs_host, ctl, start, max_iterations, huber_delta, out);
 }
 
-// The fused solve's last kernel: the refinement, then everything the host collects -- the triangulated points and the inlier list
-// (`o_words` 4-byte words at d_o) and the 40 doubles of results (RANSAC, gate, refinement) -- written into the call's pinned host buffers by
-// this workgroup (posted PCIe writes, complete when the event behind the kernel is): two device-to-host copies fewer in the chain.
-template <int NT>
-__global__ __launch_bounds__(NT) void pnp_refine_out_kernel(const double *__restrict__ Pl, const double *__restrict__ Pr, const ObsDev *__restrict__ obs,
-                                                            const int *__restrict__ ctl, const double *__restrict__ start /*q,t*/, int max_iterations, double huber_delta,
-                                                            RefineOut *__restrict__ out, const unsigned *d_o, unsigned *h_o, int o_words, const double *d_res, double *h_res) {
-  pnp_refine_body<NT>(Pl, Pr, obs, 0, ctl, start, max_iterations, huber_delta, out);
-  __threadfence_block();
-  __syncthreads();   // (every thread comes back from the body: its early exits are workgroup-uniform)
-  for (int k = threadIdx.x; k < o_words; k += NT) h_o[k] = d_o[k];
-  if (threadIdx.x < 40) h_res[threadIdx.x] = reinterpret_cast<const volatile double *>(d_res)[threadIdx.x];
-}
-
 // ------------------------------------------------------------------------- fused solve glue
 // Gating (base.cpp:241-272), rvec -> quaternion (base.cpp:274-280) and the residual-block list in
 // the order base.cpp:291-356 adds it, all on the device so that triangulation, RANSAC and the
@@ -830,19 +825,11 @@ __global__ __launch_bounds__(NT) void pnp_refine_out_kernel(const double *__rest
 //                  [39] frame_count, [40] refinement_degree, [41] max_acceleration, [42] time_interval,
 //                  [43] ignore_frame_count
 //   gate_out (doubles): [0..6] start q,t   [7] do_optmz   [8] pnp_ok   [9] accepted rvec/tvec follow in [10..15]
-__global__ __launch_bounds__(256) void solve_gate_build_kernel(const double *__restrict__ hdr,
-                                                               const double *__restrict__ ransac_result,
-                                                               const int *__restrict__ inliers,
-                                                               const float *__restrict__ xyz,
-                                                               const float *__restrict__ xy_cl,
-                                                               const float *__restrict__ xy_cr,
-                                                               const float *__restrict__ xy_pl,
-                                                               const float *__restrict__ xy_pr,
-                                                               const float *__restrict__ prev_xyz,
-                                                               const int *__restrict__ prev_valid,
-                                                               ObsDev *__restrict__ obs, int *__restrict__ ctl,
-                                                               double *__restrict__ gate_out) {
-  __shared__ int s_scan[256];
+template <int NT>
+__device__ __forceinline__ void solve_gate_build_body(const double *hdr, const double *ransac_result, const int *inliers, const float *xyz,
+                                                      const float *xy_cl, const float *xy_cr, const float *xy_pl, const float *xy_pr,
+                                                      const float *prev_xyz, const int *prev_valid, ObsDev *obs, int *ctl, double *gate_out) {
+  __shared__ int s_scan[NT];
   __shared__ int s_run, s_base;
   const int tid = threadIdx.x;
   const int degree = (int)hdr[40];
@@ -871,7 +858,7 @@ __global__ __launch_bounds__(256) void solve_gate_build_kernel(const double *__r
   __syncthreads();
   const int run = s_run;
   if (run) {
-    for (int base = 0; base < ninl; base += 256) {
+    for (int base = 0; base < ninl; base += NT) {
       const int k = base + tid;
       int vi = 0, cnt = 0, pv = 0;
       if (k < ninl) {
@@ -881,7 +868,7 @@ __global__ __launch_bounds__(256) void solve_gate_build_kernel(const double *__r
       }
       s_scan[tid] = cnt;
       __syncthreads();
-      for (int o = 1; o < 256; o <<= 1) {
+      for (int o = 1; o < NT; o <<= 1) {
         const int v = (tid >= o) ? s_scan[tid - o] : 0;
         __syncthreads();
         s_scan[tid] += v;
@@ -902,7 +889,7 @@ __global__ __launch_bounds__(256) void solve_gate_build_kernel(const double *__r
         if (pv && degree >= 4) put(prev_xyz + 3 * vi, xy_cr + 2 * vi, 1, 1);
       }
       __syncthreads();
-      if (tid == 255) s_base += s_scan[255];
+      if (tid == NT - 1) s_base += s_scan[NT - 1];
       __syncthreads();
     }
   }
@@ -910,6 +897,50 @@ __global__ __launch_bounds__(256) void solve_gate_build_kernel(const double *__r
     ctl[0] = run;
     ctl[1] = run ? s_base : 0;
   }
+}
+
+__global__ __launch_bounds__(SOLVE_TAIL_THREADS) void solve_gate_build_kernel(const double *hdr, const double *ransac_result, const int *inliers, const float *xyz,
+                                                                              const float *xy_cl, const float *xy_cr, const float *xy_pl, const float *xy_pr,
+                                                                              const float *prev_xyz, const int *prev_valid, ObsDev *obs, int *ctl, double *gate_out) {
+  solve_gate_build_body<SOLVE_TAIL_THREADS>(hdr, ransac_result, inliers, xyz, xy_cl, xy_cr, xy_pl, xy_pr, prev_xyz, prev_valid, obs, ctl, gate_out);
+}
+
+// The fused solve's TAIL: everything behind the hypotheses in ONE launch of one workgroup -- selection + refit (K15), gating and the
+// residual-block list, the Levenberg-Marquardt loop (K16), then the results into the call's pinned host buffers.  Three dependent launches
+// were three times the wait for a CU beside the other streams' kernels (the chain's latency is the cycle time of the small engines' frame
+// loop: a frame's solve needs the previous frame's pose).  The phases hand their results over through global memory exactly as the
+// separate kernels do; __syncthreads() between them orders those writes within the workgroup.
+struct SolveTailArgs {
+  const double *hdr;           // the call's header (device copy): P_l, P_r, K [24..32], prior [33..38], ...
+  const float *xyz, *xy_cl, *xy_cr, *xy_pl, *xy_pr, *prev_xyz;
+  const int *prev_valid;
+  int n, iterations;
+  double thr2;
+  RansacWork w;                // result = the 40-double result block, inliers = behind the points in the output block
+  ObsDev *obs;
+  int *ctl;
+  double *res;                 // [0..7] RANSAC, [8..23] gate, [24..] refinement
+  int max_iterations;
+  double huber_delta;
+  const unsigned *d_o;         // points + inliers (device) -> h_o, `o_words` words
+  unsigned *h_o;
+  int o_words;
+  double *h_res;
+};
+
+__global__ __launch_bounds__(SOLVE_TAIL_THREADS) void solve_tail_kernel(const SolveTailArgs a) {
+  constexpr int NT = SOLVE_TAIL_THREADS;
+  ransac_select_body<NT>(a.hdr + 24, a.xyz, a.xy_pl, a.n, a.hdr + 33, a.iterations, a.thr2, a.w);
+  __threadfence_block();
+  __syncthreads();
+  solve_gate_build_body<NT>(a.hdr, a.res, a.w.inliers, a.xyz, a.xy_cl, a.xy_cr, a.xy_pl, a.xy_pr, a.prev_xyz, a.prev_valid, a.obs, a.ctl, a.res + 8);
+  __threadfence_block();
+  __syncthreads();
+  pnp_refine_body<NT>(a.hdr, a.hdr + 12, a.obs, 0, a.ctl, a.res + 8, a.max_iterations, a.huber_delta, reinterpret_cast<RefineOut *>(a.res + 24));
+  __threadfence_block();
+  __syncthreads();   // (every thread comes back from the bodies: their early exits are workgroup-uniform)
+  for (int k = threadIdx.x; k < a.o_words; k += NT) a.h_o[k] = a.d_o[k];
+  if (threadIdx.x < 40) a.h_res[threadIdx.x] = reinterpret_cast<const volatile double *>(a.res)[threadIdx.x];
 }
 
 }  // namespace spvo

@@ -89,7 +89,7 @@ int spvo_pnp_ransac(spvo_ctx *c, const double K[9], const float *xyz, const floa
   {
     ScopedStage st(c, stage_id(c, "ransac"));
     hipLaunchKernelGGL(ransac_hypothesis_kernel, dim3(o.iterations), dim3(64), 0, c->stream, c->d_P + 24, c->d_pts_a, c->d_pts_b, n, c->d_P + 33, o.seed, o.reproj_error * o.reproj_error, c->rw);
-    hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(256), 0, c->stream, c->d_P + 24, c->d_pts_a, c->d_pts_b, n, c->d_P + 33, o.iterations, o.reproj_error * o.reproj_error, c->rw);
+    hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(SOLVE_TAIL_THREADS), 0, c->stream, c->d_P + 24, c->d_pts_a, c->d_pts_b, n, c->d_P + 33, o.iterations, o.reproj_error * o.reproj_error, c->rw);
   }
   HIP_TRY(c, hipGetLastError());
   double res[8];
@@ -221,13 +221,14 @@ int spvo_solve_submit(spvo_ctx *c, const spvo_solve_input *in) {
                        reinterpret_cast<uint4 *>(c->d_solve_in), (int)(used / 16), n, d_xyz);
     if (n >= 4) {
       hipLaunchKernelGGL(ransac_hypothesis_kernel, dim3(in->ransac.iterations), dim3(64), 0, c->stream2, dh + 24, d_xyz, df + 4 * n, n, dh + 33, in->ransac.seed, thr2, rw);
-      hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(256), 0, c->stream2, dh + 24, d_xyz, df + 4 * n, n, dh + 33, in->ransac.iterations, thr2, rw);
-      hipLaunchKernelGGL(solve_gate_build_kernel, dim3(1), dim3(256), 0, c->stream2, dh, c->d_solve_res, d_inl, d_xyz, df, df + 2 * n, df + 4 * n, df + 6 * n,
-                         have_prev ? df + 8 * n : (const float *)nullptr, have_prev ? (const int *)(df + 11 * n) : (const int *)nullptr, c->d_obs, c->d_ctl,
-                         c->d_solve_res + 8);
-      hipLaunchKernelGGL(pnp_refine_out_kernel<512>, dim3(1), dim3(512), 0, c->stream2, dh, dh + 12, c->d_obs, (const int *)c->d_ctl, c->d_solve_res + 8,
-                         in->refine.max_iterations, in->refine.huber_delta, (RefineOut *)(c->d_solve_res + 24), reinterpret_cast<const unsigned *>(c->d_solve_o),
-                         reinterpret_cast<unsigned *>(c->h_solve_o), 4 * n, c->d_solve_res, c->h_solve_res);
+      SolveTailArgs ta;   // selection + refit, gating + residual blocks, refinement, results to the pinned buffers: one launch (odometry.hip.h)
+      ta.hdr = dh; ta.xyz = d_xyz; ta.xy_cl = df; ta.xy_cr = df + 2 * n; ta.xy_pl = df + 4 * n; ta.xy_pr = df + 6 * n;
+      ta.prev_xyz = have_prev ? df + 8 * n : nullptr; ta.prev_valid = have_prev ? (const int *)(df + 11 * n) : nullptr;
+      ta.n = n; ta.iterations = in->ransac.iterations; ta.thr2 = thr2; ta.w = rw;
+      ta.obs = c->d_obs; ta.ctl = c->d_ctl; ta.res = c->d_solve_res;
+      ta.max_iterations = in->refine.max_iterations; ta.huber_delta = in->refine.huber_delta;
+      ta.d_o = reinterpret_cast<const unsigned *>(c->d_solve_o); ta.h_o = reinterpret_cast<unsigned *>(c->h_solve_o); ta.o_words = 4 * n; ta.h_res = c->h_solve_res;
+      hipLaunchKernelGGL(solve_tail_kernel, dim3(1), dim3(SOLVE_TAIL_THREADS), 0, c->stream2, ta);
     }
     HIP_TRY(c, hipGetLastError());
   }
