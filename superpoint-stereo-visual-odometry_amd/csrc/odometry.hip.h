@@ -390,17 +390,30 @@ __global__ __launch_bounds__(64) void ransac_hypothesis_kernel(const double *__r
   }
 }
 
-// deterministic block reduction of NV doubles per thread; result in `out` (LDS), valid for every thread behind the closing barrier
+// deterministic block reduction of NV <= 32 doubles per thread; result in `out` (LDS), valid for every thread behind the closing barrier.
+// Within a wave the values are reduced TRANSPOSED: at the step over lane bit 5 a lane keeps half of its values and hands the other half to
+// its partner (which keeps that half), and so on down to one value per lane pair -- 16 + 8 + 4 + 2 + 1 + 1 = 32 exchanges for all values
+// instead of 6 per value (168 for the 28 sums of a Levenberg-Marquardt evaluation: ds_bpermute traffic of eight waves through one LDS was a
+// third of an evaluation).  Lane l ends with the wave's sum of value l >> 1; the order of the additions is fixed by the lane numbers.
 template <int NV, int NT>
 __device__ inline void block_reduce(const double *v, double *out, double *scratch /*[NV][NT/64]*/) {
+  static_assert(NV <= 32, "block_reduce: at most 32 values");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double a[32];
 #pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    double x = v[k];
+  for (int k = 0; k < 32; ++k) a[k] = k < NV ? v[k] : 0.0;
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
-    if (lane == 0) scratch[k * (NT / 64) + wave] = x;
+  for (int h = 32, n = 16; h >= 2; h >>= 1, n >>= 1) {
+    const bool up = (lane & h) != 0;
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+      if (k >= NV && k + n >= NV) continue;                 // (both halves are padding)
+      const double send = up ? a[k] : a[k + n], keep = up ? a[k + n] : a[k];
+      a[k] = keep + __shfl_xor(send, h);
+    }
   }
+  a[0] += __shfl_xor(a[0], 1);
+  if (!(lane & 1) && (lane >> 1) < NV) scratch[(lane >> 1) * (NT / 64) + wave] = a[0];
   __syncthreads();
   if (threadIdx.x < NV) {   // one value per thread, the waves' partial sums in wave order
     const int k = threadIdx.x;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # the fused solve's chain shortened: parity tests, then config 3 / 5, the host legs and the headline against the side build variants/base
-O=gpurun_out/r5r; mkdir -p $O
+O=gpurun_out/r5s; mkdir -p $O
 python -m pytest tests/test_gpu_odometry.py tests/test_gpu_host.py tests/test_gpu_pipeline.py -x -q -m gpu > $O/pytest.log 2>&1; tail -3 $O/pytest.log
 V=$PWD/superpoint-stereo-visual-odometry_amd/variants/base
 for rep in 1 2; do
@@ -14,7 +14,7 @@ done
 unset SPVO_LIB_DIR
 python - <<'PY'
 import json, glob
-for f in sorted(glob.glob("gpurun_out/r5r/*.json")):
+for f in sorted(glob.glob("gpurun_out/r5s/*.json")):
     d = json.loads(open(f).read().strip().splitlines()[-1])
     hi = d.get("host_interface") or {}
     print(f, d["value"], d["ms_per_step"], d.get("latency_ms", {}).get("p50"), {k: (v.get("value") if isinstance(v, dict) else v) for k, v in hi.items() if k in ("synchronous", "lookahead")}, d.get("stages_ms", {}).get("solve"))
