@@ -45,6 +45,7 @@ python3 $ROOT/tools/pmc_summary.py $OUT $OUT/pmc.json > $OUT/pmc_summary.log 2>&
 # the heads kernel alone (two / four images), self-checked against a float64 host evaluation
 $ROOT/tools/heads_bench 45 147 2 > $OUT/heads_bench.log 2>&1
 $ROOT/tools/heads_bench 45 147 4 >> $OUT/heads_bench.log 2>&1
+bash $ROOT/tools/r05_cfg3_trace.sh 3 > /dev/null 2>&1; cp $ROOT/gpurun_out/r5p/solve_chain.log $OUT/solve_chain_cfg3.log   # the solver chain inside config 3's loop (kernel trace)
 python3 $ROOT/tools/sync_leg.py 300 0 > $OUT/sync_leg.log 2>&1
 python3 $ROOT/tools/sync_leg.py 300 2 >> $OUT/sync_leg.log 2>&1
 find $OUT -name "*.csv" -size +3M -delete   # raw traces stay on the box; the summaries above are what travels
