@@ -81,10 +81,13 @@ for prog, keys in (("wino", ["conv_wino4_kernel<true, true"]), ("match", ["match
             c = {n: mean(v) for n, v in s1[k1].items()}
             dur_ns = mean(d1[k1])
             e["duration_us_under_pmc"] = round(dur_ns / 1e3, 2)
-            clk_ghz = c["GRBM_GUI_ACTIVE"] / 8 / dur_ns
-            e["clock_GHz_from_GRBM_GUI_ACTIVE"] = round(clk_ghz, 3)
             e["SQ_VALU_MFMA_BUSY_CYCLES"] = c["SQ_VALU_MFMA_BUSY_CYCLES"]
-            e["mfma_busy_fraction_of_wall"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * c["GRBM_GUI_ACTIVE"] / 8), 4)
+            if dur_ns >= 0.2e6:   # the GRBM quotient reads high (3-4 GHz on a 2.4 GHz part) for dispatches of tens of microseconds: clock and busy-of-wall only for the 0.2 ms+ kernel (2.22 GHz: physical)
+                clk_ghz = c["GRBM_GUI_ACTIVE"] / 8 / dur_ns
+                e["clock_GHz_from_GRBM_GUI_ACTIVE"] = round(clk_ghz, 3)
+                e["mfma_busy_fraction_of_wall"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * c["GRBM_GUI_ACTIVE"] / 8), 4)
+            else:   # by time instead: busy cycles per SIMD at the nominal 2.4 GHz against the dispatch's duration
+                e["mfma_busy_fraction_of_duration_at_2.4GHz"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / 2.4 / dur_ns, 4)
             if key in flops:
                 e["executed_tflops_under_pmc"] = round(flops[key] / dur_ns / 1e3, 2)
         k2 = pick(s2, key)
