@@ -621,7 +621,7 @@ __device__ __forceinline__ void cost32(const double *P /*3x4*/, const double *q,
 
 // Whole Levenberg-Marquardt loop in ONE workgroup: no host round trips.
 // All threads evaluate residual blocks; thread 0 runs the trust-region logic.
-// `ctl` (optional, device): ctl[0] = run flag, ctl[1] = n_obs -- written by solve_gate_build_kernel
+// `ctl` (optional, device): ctl[0] = run flag, ctl[1] = n_obs -- written by solve_gate_build_body (solve_tail_kernel)
 // when the whole of solveStereoOdometry is enqueued without a host round trip.
 template <int NT>
 __device__ __forceinline__ void pnp_refine_body(const double *Pl, const double *Pr, const ObsDev *obs, int n_obs_host, const int *ctl, const double *start /*q,t*/,
@@ -910,12 +910,6 @@ __device__ __forceinline__ void solve_gate_build_body(const double *hdr, const d
     ctl[0] = run;
     ctl[1] = run ? s_base : 0;
   }
-}
-
-__global__ __launch_bounds__(SOLVE_TAIL_THREADS) void solve_gate_build_kernel(const double *hdr, const double *ransac_result, const int *inliers, const float *xyz,
-                                                                              const float *xy_cl, const float *xy_cr, const float *xy_pl, const float *xy_pr,
-                                                                              const float *prev_xyz, const int *prev_valid, ObsDev *obs, int *ctl, double *gate_out) {
-  solve_gate_build_body<SOLVE_TAIL_THREADS>(hdr, ransac_result, inliers, xyz, xy_cl, xy_cr, xy_pl, xy_pr, prev_xyz, prev_valid, obs, ctl, gate_out);
 }
 
 // The fused solve's TAIL: everything behind the hypotheses in ONE launch of one workgroup -- selection + refit (K15), gating and the
