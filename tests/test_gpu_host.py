@@ -359,6 +359,42 @@ def test_deferred_solve_gives_the_same_poses_one_step_later(models_dir, sequence
         assert np.array_equal(qa, qb) and np.array_equal(ta, tb)
 
 
+def test_the_block_loop_equals_the_call_sequence(models_dir, sequence):
+    """spvo_host_run_device_block (host/harness_capi.cpp: the C loop bench.py times -- n stereoCallbacks per call, pairs announced `depth`
+    ahead, the solve deferred by a frame) against the plain call sequence of the node on the same frames: every pose identical bit for
+    bit, one record per frame, whatever the depth and however the sequence is cut into blocks (the pairs a block announces last are
+    collected by the next block); the records carry a latency and the solver's outcome."""
+    import torch
+    frames, _, P_l, P_r = sequence
+    dev = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
+    torch.cuda.synchronize()
+    rows, cols = frames[0][0].shape
+    stride = dev[0][0].stride(0)
+    n = len(dev)
+    fe = host.FrontEnd(models_dir, prefix="sp_squeeze")
+    assert fe.engine_loaded, fe.last_error
+    ref = []
+    for k, (L, R) in enumerate(dev):
+        r = fe.step_device(L.data_ptr(), R.data_ptr(), rows, cols, stride, P_l, P_r)
+        ref.append(None if r is None else (r[0].copy(), r[1].copy()))
+    fe.close()
+    dl, dr = [d[0].data_ptr() for d in dev], [d[1].data_ptr() for d in dev]
+    for depth, cuts in ((4, (n,)), (4, (3, n - 3)), (2, (1, 2, n - 3)), (0, (n,))):
+        fe = host.FrontEnd(models_dir, prefix="sp_squeeze")
+        recs, first = [], 0
+        for m in cuts:
+            # (the last block of a run must not announce pairs beyond the sequence: the cycle wraps, as in bench.py, so it simply would)
+            recs.append(fe.run_device_block(dl, dr, rows, cols, stride, P_l, P_r, first, m, depth=depth, deferred=depth > 0))
+            first += m
+        rec = np.concatenate(recs)
+        fe.close()
+        assert len(rec) == n and not rec["has_pose"][0] and rec["has_pose"][1:].all()
+        for k in range(1, n):
+            assert np.array_equal(rec["q"][k], ref[k][0]) and np.array_equal(rec["t"][k], ref[k][1]), (depth, cuts, k)
+        assert (rec["latency_ms"] > 0).all() and (rec["keypoints_left"] > 100).all() and (rec["pnp_inliers"][1:] > 10).all()
+        assert rec["accepted"][1:].mean() > 0.5 and (rec["lm_iterations"][rec["refined"] == 1] > 0).all()
+
+
 def test_classic_front_end_on_the_gpu_equals_the_cpu_state_machine(sequence):
     """ClassicFeatureFrontEnd(ORB, ORB, BF, KNN) -- BASELINE config 1's front end, node.cpp:353-360 -- through the mirror class:
     ORB on the GPU (spvo_orb_detect), Hamming matching on the GPU (spvo_match_hamming), the solver through the C ABI, at the
