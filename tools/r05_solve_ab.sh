@@ -1,4 +1,7 @@
 #!/bin/bash
+# Same-box A/B of the working tree against a SIDE BUILD of another revision.  The side build is made here, before the GPU call:
+#   git stash (or git worktree of the other revision); make -C superpoint-stereo-visual-odometry_amd -j8 BUILD=build_base OUT=variants/base; git stash pop; make -C ... -j8
+# (variants/ is git-ignored and travels with the snapshot; spvo/capi.py and spvo/host.py load from SPVO_LIB_DIR when it is set)
 # the fused solve's chain shortened: parity tests, then config 3 / 5, the host legs and the headline against the side build variants/base
 O=gpurun_out/r5s; mkdir -p $O
 python -m pytest tests/test_gpu_odometry.py tests/test_gpu_host.py tests/test_gpu_pipeline.py -x -q -m gpu > $O/pytest.log 2>&1; tail -3 $O/pytest.log
