@@ -39,6 +39,12 @@ def _early_cpu_limit(argv):
 
 if __name__ == "__main__":
     _early_cpu_limit(sys.argv[1:])
+    # The HIP runtime deals a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A front end has three streams; the
+    # FP16 / INT8 legs (BASELINE configs 3 and 5) run with a second tail stream (spvo_set_tuning "tail_streams" = 2), which only pays with a
+    # queue of its own -- so this process asks for eight, as a deployment of those engines would in its launch file.  The
+    # headline's engine keeps one tail stream; with it the queue count changes nothing measurable.  Read by the
+    # runtime when it initialises: set before torch is imported.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 
@@ -379,6 +385,9 @@ def main():
     # device, keypoint cap and fp8 shortlist of the front ends created below: the host class's setters (setDevice, setMaxKeypoints,
     # setMatchFp8), not environment variables
     host.set_options(device=local_rank, max_keypoints=args.max_keypoints, match_fp8=1 if args.match_fp8 else 0)
+    small_engine = args.precision in ("FP16", "INT8")
+    if small_engine and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 8:
+        capi.set_tuning("tail_streams", 2)   # (BASELINE configs 3 / 5 as this script's own workload: as in the `other_configs` legs below)
     capi.tuning_from_env()   # SPVO_TUNE_<NAME>=<int>: diagnostic switches for A/B runs of this script (the library itself never reads the environment)
     if args.fp32_split:
         capi.set_tuning("fp32_split", 1)   # engines loaded from here on run in split mode (the library reads no environment variable for it)
@@ -894,18 +903,24 @@ def main():
                     os.makedirs(os.path.join(odir, "laptop"), exist_ok=True)
                     weights.save(oplan, os.path.join(odir, "laptop", weights.engine_name(oprefix, 2, oh, ow, oprec)))
                     host.set_options(device=local_rank, max_keypoints=okp, match_fp8=1 if ofp8 else 0)
+                    two_tails = oprec in ("FP16", "INT8") and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 8 and "SPVO_TUNE_TAIL_STREAMS" not in os.environ
+                    if two_tails:
+                        capi.set_tuning("tail_streams", 2)   # read when the engine is loaded; the FP32 legs keep one tail stream
                     try:
                         fe = host.FrontEnd(odir, prefix=oprefix, selector="KNN", cross_check=True, batch=2, height=oh, width=ow, conf_thresh=0.015,
                                            dist_thresh=4, border_remove=4, stereo_threshold=2.0, min_disparity=0.25, refinement_degree=4, precision=oprec)
                     finally:
                         host.set_options(device=local_rank, max_keypoints=args.max_keypoints, match_fp8=1 if args.match_fp8 else 0)
+                        if two_tails:
+                            capi.set_tuning("tail_streams", 1)
                     if not fe.engine_loaded:
                         raise RuntimeError("engine load failed: " + fe.last_error)
                     run_frames(0, args.warmup)
                     fe.finish_solve()
                     eo, spo, fso = leg_frames()
                     rec = {"what": owhat, "value": round(args.steps / eo, 2), "unit": "stereo frames/s", "ms_per_step": round(1e3 * eo / args.steps, 4), **spo, **fso,
-                           "dtype": {"FP32": "f32", "FP16": "f16", "INT8": "i8"}[oprec],
+                           "dtype": {"FP32": "f32", "FP16": "f16", "INT8": "i8"}[oprec], "tail_streams": 2 if two_tails else 1,
+                           "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                            "workload": (f"SuperPoint VGG {oprec.lower()} (seeded synthetic weights, {o_params} params)" if ograph == "vgg" else
                                         f"SuperPoint {ograph} {oprec.lower()} (the reference's TRAINED ONNX graph, {o_params} params; activation scales calibrated on this stream)")
                                        + f", 1241x376 stereo pairs, net {oh}x{ow}, {okp} kp cap" + (", fp8 shortlist + exact re-rank" if ofp8 else "")}

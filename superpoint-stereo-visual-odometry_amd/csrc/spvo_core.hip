@@ -39,7 +39,7 @@ int stage_id(spvo_ctx *c, const std::string &name) {
 // ---- diagnostic switches (include/spvo.h: spvo_set_tuning).  One process-wide table, filled by explicit calls only.
 namespace {
 const char *const kTuningNames[] = {"winograd", "wino4", "wino_narrow", "wino_dynamic", "winograd_min_tiles", "wino4_min_tiles", "merge_siblings", "heads_fused",
-                                    "heads_on_net", "heads_split", "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing", "nms_first", "upload_side", "inject_launch_failure", "int8_fused", "pair_always", "preprocess_fused", "heads_keep_raw"};
+                                    "heads_on_net", "heads_split", "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing", "nms_first", "upload_side", "inject_launch_failure", "int8_fused", "pair_always", "preprocess_fused", "heads_keep_raw", "tail_streams"};
 constexpr int kTuningCount = sizeof kTuningNames / sizeof kTuningNames[0];
 std::mutex g_tuning_mutex;
 bool g_tuning_set[kTuningCount] = {};
@@ -206,12 +206,15 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
   // serialise the three streams of the pipeline against each other.  Device pointers handed to the *_dev entry points
   // have to be complete when the call is made (include/spvo.h).
   if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->stream_t, hipStreamNonBlocking) != hipSuccess) {
+      hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->stream_t, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->stream_tb, hipStreamNonBlocking) != hipSuccess) {
     delete c;
     return fail(nullptr, SPVO_ERR_DEVICE, "cannot create a stream on device %d", cfg->device);
   }
   c->post = c->stream;
   (void)hipEventCreateWithFlags(&c->ev_post, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&c->ev_post_b, hipEventDisableTiming);
+  for (int r = 0; r < RING; ++r) (void)hipEventCreateWithFlags(&c->ev_heads[r], hipEventDisableTiming);
   c->split_req = tuning("fp32_split", 0) != 0;
   for (int r = 0; r < RING; ++r)
     if (hipEventCreateWithFlags(&c->ev_net[r], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_tail[r], hipEventDisableTiming) != hipSuccess ||
@@ -287,8 +290,11 @@ void spvo_destroy(spvo_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   if (c->stream_t) (void)hipStreamSynchronize(c->stream_t);
+  if (c->stream_tb) (void)hipStreamSynchronize(c->stream_tb);
   if (c->ev_solve) (void)hipEventDestroy(c->ev_solve);
   if (c->ev_post) (void)hipEventDestroy(c->ev_post);
+  if (c->ev_post_b) (void)hipEventDestroy(c->ev_post_b);
+  for (int r = 0; r < RING; ++r) if (c->ev_heads[r]) (void)hipEventDestroy(c->ev_heads[r]);
   resolve_pending(c);
   for (int r = 0; r < TrunkDiag::TT; ++r)
     for (hipEvent_t e : {c->tdiag.b[r], c->tdiag.e[r], c->tdiag.tb[r], c->tdiag.te[r]}) if (e) (void)hipEventDestroy(e);
@@ -297,10 +303,13 @@ void spvo_destroy(spvo_ctx *c) {
   free_plan(c);
   void *ptrs[] = {c->d_dense_in, c->d_det_dense, c->d_resized, c->d_tab, c->d_img[0], c->d_img[1], c->d_xy_tmp, c->d_desc_tmp,
                   c->d_ma, c->d_mb, c->d_match_out, c->d_counters_all, c->d_xy_stage,
-                  c->ms[0].d_na, c->ms[0].d_nb, c->ms[0].d_best_d2, c->ms[0].d_dt, c->ms[0].d_cand, c->ms[0].d_meta, c->ms[0].d_best_idx, c->ms[0].d_train_best, c->ms[0].d_a8, c->ms[0].d_b8, c->ms[0].d_qa8, c->ms[0].d_qb8,
-                  c->ms[1].d_na, c->ms[1].d_nb, c->ms[1].d_best_d2, c->ms[1].d_dt, c->ms[1].d_cand, c->ms[1].d_meta, c->ms[1].d_best_idx, c->ms[1].d_train_best, c->ms[1].d_a8, c->ms[1].d_b8, c->ms[1].d_qa8, c->ms[1].d_qb8,
                   c->d_P, c->d_pts_a, c->d_pts_b, c->d_xyz, c->rw.counts, c->rw.poses, c->rw.result, c->rw.inliers, c->d_obs, c->d_refine};
   for (void *p : ptrs) if (p) (void)hipFree(p);
+  for (auto &set : c->ms)
+    for (auto &m : set)
+      for (void *p : {(void *)m.d_na, (void *)m.d_nb, (void *)m.d_best_d2, (void *)m.d_dt, (void *)m.d_cand, (void *)m.d_meta, (void *)m.d_best_idx, (void *)m.d_train_best,
+                      (void *)m.d_a8, (void *)m.d_b8, (void *)m.d_qa8, (void *)m.d_qb8})
+        if (p) (void)hipFree(p);
   for (int r = 0; r < RING; ++r) {
     for (int i = 0; i < 2; ++i) {
       NmsBuffers &b = c->nms_r[r][i].b;
@@ -330,6 +339,7 @@ void spvo_destroy(spvo_ctx *c) {
   for (auto hp : c->h_match_out) if (hp) (void)hipHostFree(hp);
   if (c->h_match_tmp) (void)hipHostFree(c->h_match_tmp);
   if (c->stream_t) (void)hipStreamDestroy(c->stream_t);
+  if (c->stream_tb) (void)hipStreamDestroy(c->stream_tb);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   delete c;
@@ -779,6 +789,11 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
     c->pre_fused = !c->fp16 && !c->int8 && !c->s3 && c->head_start >= 1 && o0.type == OP_CONV && o0.cin == 1 && o0.ks == 3 && o0.in == c->t_input && !o0.d_bn_scale &&
                    !(o0.flags & (FLAG_POOL | FLAG_ADD)) && !c->tensors[o0.out].nhwc && (c->W % 8) == 0 && tuning("preprocess_fused", 1) != 0;
   }
+  {   // one tail stream, or two when the caller says so (tuning "tail_streams" = 2: spvo_detect.hip; only with nothing in flight -- the parity
+      // of a submission's set selects its stream)
+    const int ts = tuning("tail_streams", 0);
+    if (c->pendq.empty()) c->tail_streams = ts == 2 ? 2 : 1;
+  }
   {   // where a submission's heads run (spvo_detect.hip): behind the trunk on the network stream when most of the trunk's work is in
       // launches of one 512-thread workgroup per CU (conv_wino4.hip.h), beside which they would starve; on the tail stream otherwise
     double all = 0, big = 0;
@@ -811,6 +826,7 @@ int spvo_synchronize(spvo_ctx *c) {
   if (!c) return fail(c, SPVO_ERR_INVALID, "null context");
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream_t));
+  HIP_TRY(c, hipStreamSynchronize(c->stream_tb));
   HIP_TRY(c, hipStreamSynchronize(c->stream2));
   return SPVO_OK;
 }

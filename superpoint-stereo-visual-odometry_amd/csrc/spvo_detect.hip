@@ -671,10 +671,28 @@ static int launch_group_body(spvo_ctx *c) {
   if (trunk_timing) (void)hipEventRecord(tt_e[tt_n % TT], c->stream);
   for (int m = 0; m < n; ++m) HIP_TRY(c, hipEventRecord(c->ev_net[mem[m]->ring], c->stream));
   c->last_launch_ring = mem[n - 1]->ring;
-  HIP_TRY(c, hipStreamWaitEvent(c->stream_t, c->ev_net[tring], 0));
-  if (trunk_timing) (void)hipEventRecord(tt_tb[tt_n % TT], c->stream_t);
-  c->post = c->stream_t;
-  if (!heads_on_net) rc = run_ops(c, batch, c->head_start, c->ops.size(), c->stream_t);   // heads: on the tail stream, reading this group's ring buffers
+  // Tail streams: one, or two that consecutive submissions alternate between by the parity of their set (tuning "tail_streams" = 2: for
+  // engines whose network is shorter than a pair's chain of ~10 dependent tail kernels -- FP16 / INT8 -- that chain, one pair after the
+  // other on one stream, is the frame loop's cycle time: config 3 5670 -> 6490 frames/s).  It pays only when the second stream gets a
+  // hardware queue of its own: the runtime deals a process's streams onto GPU_MAX_HW_QUEUES (default 4) queues, and a fifth stream that
+  // shares one with the network or the first tail stream makes things worse (5300).  Opt-in, with GPU_MAX_HW_QUEUES=8 in the process's
+  // environment; FP32 engines lose with it (more small kernels beside the trunk's persistent launches).  What crosses
+  // from one submission's tail to the next one's: the features the temporal match reads (ev_feat of the submission before) and the clean
+  // NMS counter block, which a tail hands to the next submission ON ITS OWN STREAM (two sets ahead with two streams).
+  hipStream_t tstreams[2] = {c->stream_t, c->tail_streams == 2 ? c->stream_tb : c->stream_t};
+  for (int m = 0; m < n; ++m) mem[m]->ts = c->tail_streams == 2 ? (mem[m]->ring & 1) : 0;
+  hipStream_t ts0 = tstreams[mem[0]->ts];
+  HIP_TRY(c, hipStreamWaitEvent(ts0, c->ev_net[tring], 0));
+  if (n == 2 && mem[1]->ts != mem[0]->ts) HIP_TRY(c, hipStreamWaitEvent(tstreams[mem[1]->ts], c->ev_net[tring], 0));
+  if (trunk_timing) (void)hipEventRecord(tt_tb[tt_n % TT], ts0);
+  c->post = ts0;
+  if (!heads_on_net) {
+    rc = run_ops(c, batch, c->head_start, c->ops.size(), ts0);   // heads: on the (first pair's) tail stream, reading this group's ring buffers
+    if (!rc && n == 2 && mem[1]->ts != mem[0]->ts) {
+      HIP_TRY(c, hipEventRecord(c->ev_heads[tring], ts0));
+      HIP_TRY(c, hipStreamWaitEvent(tstreams[mem[1]->ts], c->ev_heads[tring], 0));
+    }
+  }
   c->cur_ring = 0;
   if (rc) { c->post = c->stream; return rc; }
   // ---- phase C: each pair's tail, in submission order (the second pair's temporal match reads the first pair's features)
@@ -683,6 +701,9 @@ static int launch_group_body(spvo_ctx *c) {
     const int ring = pd.ring, slots[2] = {pd.slot_l, pd.slot_r};
     pd.tring = tring;
     const NmsPair np = nms_pair(c, ring);
+    hipStream_t tsm = tstreams[pd.ts];
+    c->post = tsm;
+    c->ms_set = pd.ts;
     {
       // heat map + threshold + candidate list in one kernel; the counter block of this set was
       // zeroed by the previous submission's last NMS kernel (or at allocation)
@@ -693,20 +714,24 @@ static int launch_group_body(spvo_ctx *c) {
     }
     {
       ScopedStage sn(c, stage_id(c, "nms"));
-      rc = launch_nms_rounds(c, 2, np, ring, c->nms_first, c->d_counters_all + (size_t)(((ring + 1) % RING) * 2) * NMS_COUNTER_INTS);
+      rc = launch_nms_rounds(c, 2, np, ring, c->nms_first, c->d_counters_all + (size_t)(((ring + c->tail_streams) % RING) * 2) * NMS_COUNTER_INTS);
     }
     if (!rc) rc = enqueue_sample(c, slots, np, ring, tring, pd.img0);
     // Keypoints, counts and descriptors are final here: spvo_detect_wait / _collect waits for THIS point (ev_feat); the matches enqueued
     // behind it are waited for where they are asked for (spvo_match_slots, ev_tail).
-    if (!rc) rc = hipEventRecord(c->ev_feat[ring], c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");
-    if (!rc && c->prematch) rc = enqueue_prematch(c, pd.slot_l, pd.slot_r, pd.prev_l, ring);
-    if (!rc && prof_detect) {   // "detect" spans both streams: first kernel on `stream` .. last kernel on `stream_t`
-      hipEvent_t e1 = get_event(c);
-      (void)hipEventRecord(e1, c->stream_t);
-      c->pending.push_back({stage_id(c, "detect"), det_e0, e1});
-      if (m + 1 < n) { det_e0 = get_event(c); (void)hipEventRecord(det_e0, c->stream_t); }   // (an event is timed once)
+    if (!rc) rc = hipEventRecord(c->ev_feat[ring], tsm) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");
+    if (!rc && c->prematch) {
+      // (two tail streams: the temporal partner's features come from the submission before, on the other stream)
+      if (c->tail_streams == 2 && pd.prev_l >= 0) HIP_TRY(c, hipStreamWaitEvent(tsm, c->ev_feat[(ring + RING - 1) % RING], 0));
+      rc = enqueue_prematch(c, pd.slot_l, pd.slot_r, pd.prev_l, ring);
     }
-    if (!rc) rc = (hipEventRecord(c->ev_tail[ring], c->stream_t) == hipSuccess) ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");
+    if (!rc && prof_detect) {   // "detect" spans both streams: first kernel on `stream` .. last kernel on the tail stream
+      hipEvent_t e1 = get_event(c);
+      (void)hipEventRecord(e1, tsm);
+      c->pending.push_back({stage_id(c, "detect"), det_e0, e1});
+      if (m + 1 < n) { det_e0 = get_event(c); (void)hipEventRecord(det_e0, tstreams[mem[m + 1]->ts]); }   // (an event is timed once)
+    }
+    if (!rc) rc = (hipEventRecord(c->ev_tail[ring], tsm) == hipSuccess) ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");
     // The descriptors a host-image submission takes back (extras bit 1: 2 x 1 MB) leave for the set's pinned mirror BEHIND the
     // matches, on the tail stream (a stream of their own had them share a hardware queue with the network stream in processes that had
     // created and destroyed contexts before -- the runtime deals streams onto four queues -- and bench.py's look-ahead leg fell from
@@ -714,13 +739,14 @@ static int launch_group_body(spvo_ctx *c) {
     // made it 40 us instead of 4 in front of ev_feat; beside the matches the copy kernel (44 us of PCIe writes) made the distance GEMM
     // 55 us instead of 20.  ev_copy = they have arrived (spvo_detect_mirrors_wait; spvo_detect_collect waits for it itself).
     if (!rc && (pd.extras & 2)) {
-      rc = enqueue_desc_mirror(c, slots, ring, c->stream_t);
-      if (!rc) HIP_TRY(c, hipEventRecord(c->ev_copy[ring], c->stream_t));
+      rc = enqueue_desc_mirror(c, slots, ring, tsm);
+      if (!rc) HIP_TRY(c, hipEventRecord(c->ev_copy[ring], tsm));
     }
     pd.launched = true;
   }
-  if (trunk_timing) { (void)hipEventRecord(tt_te[tt_n % TT], c->stream_t); ++tt_n; }
+  if (trunk_timing) { (void)hipEventRecord(tt_te[tt_n % TT], tstreams[mem[n - 1]->ts]); ++tt_n; }
   c->post = c->stream;
+  c->ms_set = 0;
   return rc;
 }
 
@@ -755,7 +781,9 @@ static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_feature
   const bool extras = (want_res && !(pd.extras & 1)) || (want_desc && !(pd.extras & 2));
   if (extras && c->pendq.size() > 1) return fail(c, SPVO_ERR_STATE, "resized images / host descriptors can only be fetched with one submission in flight (or request them at spvo_detect_submit)");
   c->pendq.pop_front();
-  c->post = c->stream_t;
+  hipStream_t tsw = (pd.ts && c->stream_tb) ? c->stream_tb : c->stream_t;   // the submission's own tail stream
+  c->post = tsw;
+  c->ms_set = pd.ts;
   auto copy_extras = [&]() -> int {
     if (!(pd.extras & 1))
       for (int i = 0; i < 2; ++i)
@@ -768,8 +796,8 @@ static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_feature
   };
   int rc = SPVO_OK;
   if (extras) {
-    if ((rc = copy_extras())) { c->post = c->stream; return rc; }
-    rc = hipStreamSynchronize(c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "stream synchronisation failed");
+    if ((rc = copy_extras())) { c->post = c->stream; c->ms_set = 0; return rc; }
+    rc = hipStreamSynchronize(tsw) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "stream synchronisation failed");
   } else {
     // only this submission's tail: a younger one may be queued behind it on both streams
     const double tw0 = diag_now_us();
@@ -788,12 +816,13 @@ static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_feature
     if (!rc && redone && (pd.extras & 2)) rc = enqueue_desc_mirror(c, slots, pd.ring, c->post);
     if (!rc && c->prematch) rc = enqueue_prematch(c, pd.slot_l, pd.slot_r, pd.prev_l, pd.ring);
     if (!rc && extras) rc = copy_extras();
-    if (!rc) rc = hipStreamSynchronize(c->stream_t) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "stream synchronisation failed");
+    if (!rc) rc = hipStreamSynchronize(tsw) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "stream synchronisation failed");
     if (redone)
       for (auto &q : c->pendq)
         if (q.prev_l == pd.slot_l) q.rematch = true;   // it matched against keypoints that have just been replaced
   }
   c->post = c->stream;
+  c->ms_set = 0;
   if (rc) return rc;
   const int *hc = c->h_counters_r[pd.ring];
   for (int i = 0; i < 2; ++i) {

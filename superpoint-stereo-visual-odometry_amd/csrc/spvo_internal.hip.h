@@ -137,6 +137,7 @@ struct PendingDetect {           // one spvo_detect*_submit in flight
   bool failed = false;           // its group's launch failed after the submission had been accepted: spvo_detect_wait / _collect takes it off the queue and reports that
   int img0 = 0;                  // its first image in the network's planes (0, or 2 as the second pair of a group)
   int tring = 0;                 // the set whose network outputs hold its detector / descriptor maps (its own, or its group's first)
+  int ts = 0;                    // the tail stream its tail runs on (0: stream_t, 1: stream_tb)
   // preprocess fused into the first layer (conv_first_pre.hip.h): what the launch of its group needs of the submission's images
   bool pre_pending = false;
   const uint8_t *src[2] = {nullptr, nullptr};
@@ -168,6 +169,9 @@ struct spvo_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // fused solve: overlaps with a detector submission in flight
   hipStream_t stream_t = nullptr;  // detector tail (heat map, NMS, sampling, matching): overlaps with the NEXT submission's network
+  hipStream_t stream_tb = nullptr; // a second tail stream (tail_streams == 2): submissions alternate between the two by the parity of their set
+  int tail_streams = 1;            // set by the plan loader from tuning "tail_streams" (1, or 2: opt-in for the small engines, needs GPU_MAX_HW_QUEUES >= 8)
+  int ms_set = 0;                  // which set of matcher scratch enqueue_matches uses: the tail stream's index (0 for everything else)
   hipStream_t post = nullptr;      // where post-processing is enqueued right now: `stream`, or `stream_t` for a submission
   std::deque<PendingDetect> pendq;
   int held = 0;                  // submissions at the back of pendq whose trunk has not been launched yet (0 .. 2: trunk pairing)
@@ -217,7 +221,7 @@ struct spvo_ctx {
   // matching scratch
   int match_cap = 0;
   float *d_ma = nullptr, *d_mb = nullptr;
-  MatchScratch ms[2];
+  MatchScratch ms[2][2];         // [tail stream][stereo, temporal]
   int2 *d_match_out = nullptr;   // [2][cap]: both jobs' results leave in one copy
   int2 *h_match_out[RING] = {nullptr, nullptr, nullptr, nullptr};   // pinned [2][cap] per submission set
   int2 *h_match_tmp = nullptr;   // pinned [cap] for the synchronous entry points
@@ -242,7 +246,8 @@ struct spvo_ctx {
   hipEvent_t ev_feat[RING] = {nullptr, nullptr, nullptr, nullptr}, ev_copy[RING] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_pre[RING] = {nullptr, nullptr, nullptr, nullptr}, ev_res[RING] = {nullptr, nullptr, nullptr, nullptr};   // first layer done (network stream) / resized images on the host (tail stream)
   hipEvent_t ev_up[RING] = {nullptr, nullptr, nullptr, nullptr};   // a queued host-image submission's upload, on the solver's stream, has landed (its preprocess kernel waits for it)
-  hipEvent_t ev_post = nullptr;    // PostScope: orders a synchronous entry point behind what is left on the tail stream
+  hipEvent_t ev_post = nullptr, ev_post_b = nullptr;    // PostScope: orders a synchronous entry point behind what is left on the tail stream(s)
+  hipEvent_t ev_heads[RING] = {};  // the group's heads are done (tail_streams == 2, heads on the tail stream: the second pair's stream waits for it)
   bool match_fp8 = false;        // fp8 shortlist GEMM (approximate; spvo_set_match_fp8)
   bool prematch = false;
   int pm_selector = SPVO_SELECT_KNN, pm_cross = 0;
@@ -362,9 +367,11 @@ struct PostScope {
   spvo_ctx *c;
   explicit PostScope(spvo_ctx *ctx) : c(ctx) {
     c->post = c->pendq.empty() ? c->stream : c->stream_t;
+    c->ms_set = 0;
     // nothing queued, but the matches of the submission collected last may still run on the tail stream (spvo_detect_wait returns
     // when the FEATURES are final) and they share the matcher's scratch: the network stream waits for them, asynchronously
     if (c->pendq.empty() && c->ev_post && hipEventRecord(c->ev_post, c->stream_t) == hipSuccess) (void)hipStreamWaitEvent(c->stream, c->ev_post, 0);
+    if (c->stream_tb && c->ev_post_b && hipEventRecord(c->ev_post_b, c->stream_tb) == hipSuccess) (void)hipStreamWaitEvent(c->post, c->ev_post_b, 0);
   }
   ~PostScope() { c->post = c->stream; }
 };

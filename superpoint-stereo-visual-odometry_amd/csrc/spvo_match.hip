@@ -14,10 +14,11 @@ int ensure_match(spvo_ctx *c, int na, int nb) {
   c->match_cap = 0;
   auto drop = [](auto *&p) { if (p) (void)hipFree(p); p = nullptr; };
   drop(c->d_ma); drop(c->d_mb); drop(c->d_match_out);
-  for (auto &m : c->ms) {
-    drop(m.d_na); drop(m.d_nb); drop(m.d_best_d2); drop(m.d_dt); drop(m.d_cand); drop(m.d_meta); drop(m.d_best_idx); drop(m.d_train_best); drop(m.d_a8); drop(m.d_b8); drop(m.d_qa8); drop(m.d_qb8);
-    m.d_out = nullptr;
-  }
+  for (auto &set : c->ms)
+    for (auto &m : set) {
+      drop(m.d_na); drop(m.d_nb); drop(m.d_best_d2); drop(m.d_dt); drop(m.d_cand); drop(m.d_meta); drop(m.d_best_idx); drop(m.d_train_best); drop(m.d_a8); drop(m.d_b8); drop(m.d_qa8); drop(m.d_qb8);
+      m.d_out = nullptr;
+    }
   for (auto &p : c->h_match_out) { if (p) (void)hipHostFree(p); p = nullptr; }
   if (c->h_match_tmp) (void)hipHostFree(c->h_match_tmp);
   c->h_match_tmp = nullptr;
@@ -25,9 +26,10 @@ int ensure_match(spvo_ctx *c, int na, int nb) {
   int rc;
   if ((rc = dev_alloc(c, &c->d_ma, (size_t)cap * MATCH_D))) return rc;
   if ((rc = dev_alloc(c, &c->d_mb, (size_t)cap * MATCH_D))) return rc;
-  if ((rc = dev_alloc(c, &c->d_match_out, (size_t)2 * cap))) return rc;
-  for (int k = 0; k < 2; ++k) {
-    MatchScratch &m = c->ms[k];
+  if ((rc = dev_alloc(c, &c->d_match_out, (size_t)4 * cap))) return rc;
+  for (int k4 = 0; k4 < 4; ++k4) {
+    const int k = k4 & 1;
+    MatchScratch &m = c->ms[k4 >> 1][k];
     if ((rc = dev_alloc(c, &m.d_na, cap + 4))) return rc;   // K12b reads the norms four at a time
     if ((rc = dev_alloc(c, &m.d_nb, cap + 4))) return rc;
     if ((rc = dev_alloc(c, &m.d_best_d2, (size_t)cap * 2))) return rc;
@@ -41,7 +43,7 @@ int ensure_match(spvo_ctx *c, int na, int nb) {
     if ((rc = dev_alloc(c, &m.d_b8, (size_t)cap * MATCH_D))) return rc;
     if ((rc = dev_alloc(c, &m.d_qa8, cap))) return rc;
     if ((rc = dev_alloc(c, &m.d_qb8, cap))) return rc;
-    m.d_out = c->d_match_out + (size_t)k * cap;
+    m.d_out = c->d_match_out + (size_t)k4 * cap;
   }
   for (int r = 0; r < RING; ++r) HIP_TRY(c, hipHostMalloc((void **)&c->h_match_out[r], (size_t)2 * cap * sizeof(int2)));
   HIP_TRY(c, hipHostMalloc((void **)&c->h_match_tmp, (size_t)cap * sizeof(int2)));
@@ -74,7 +76,7 @@ int enqueue_matches(spvo_ctx *c, const MatchReq *req_in, int njobs, int selector
       std::swap(req[k].dA, req[k].dB); std::swap(req[k].na, req[k].nb);
       std::swap(req[k].na_ptr, req[k].nb_ptr); std::swap(req[k].sqA, req[k].sqB);
     }
-    MatchScratch &m = c->ms[k];
+    MatchScratch &m = c->ms[c->ms_set & 1][k];
     MatchJob &j = jobs.j[k];
     j.A = req[k].dA; j.B = req[k].dB;
     j.na = req[k].na; j.nb = req[k].nb;

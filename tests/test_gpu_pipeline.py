@@ -340,6 +340,59 @@ def test_preprocess_inside_the_first_layer_is_bit_identical(vgg_weights_path, st
     assert len(out[1][2]["xy_l"]) > 100 and len(out[1][0]["xy_l"]) > 100
 
 
+@pytest.mark.parametrize("graph", ["squeeze", "vgg_fp16", "mbv1_int8"])
+def test_two_tail_streams_do_not_change_results(graph, squeeze_weights_path, stereo_pair, vgg_plan, tmp_path, tuning):
+    """spvo_set_tuning("tail_streams", 2): consecutive submissions' tails (heat map, NMS, sampling, the two matches) alternate between
+    two streams instead of queueing on one -- what crosses between them is ordered by events (the temporal partner's features, the heads
+    of a paired group) and by hand-over on the own stream (the clean NMS counter block, two sets ahead).  Keypoints, descriptors, resized
+    images and both matches of every pair are bit-identical to the one-stream run, with trunk pairing and without."""
+    from spvo import capi
+    frames, _, P_l, P_r = stereo_pair
+    seq = [frames[k & 1] for k in range(8)]
+    path = squeeze_weights_path
+    if graph == "vgg_fp16":
+        import copy
+        from spvo import weights
+        p16 = copy.copy(vgg_plan)
+        p16.precision = "FP16"
+        path = str(tmp_path / weights.engine_name("superpoint_pretrained", 2, 360, 1176, "FP16"))
+        weights.save(p16, path)
+    if graph == "mbv1_int8":
+        path = _mbv1_int8_engine(tmp_path, frames)
+    out = {}
+    for tails, pairing in ((1, False), (2, False), (2, True)):
+        tuning(tail_streams=tails)
+        ctx = capi.Context()
+        ctx.load_weights(path)
+        ctx.set_prematch(True, "KNN", False, 0.8)
+        ctx.set_trunk_pairing(pairing)
+        res = []
+
+        def collect(slot_l):
+            v = ctx.detect_collect_mirrors(P_l, P_r)
+            n = len(v["xy_l"])
+            m = [ctx.match_slots(slot_l, slot_l + 1, n)] + ([ctx.match_slots(slot_l, (slot_l - 2) % 16, n)] if res else [])
+            res.append(({k: np.array(v[k]) for k in ("xy_l", "xy_r", "desc_l", "desc_r", "resized_l")}, [(i.copy(), d.copy()) for i, d in m]))
+        for k in range(5):
+            ctx.detect_submit(seq[k][0], seq[k][1], 2 * k, 2 * k + 1)
+        collect(0); collect(2)
+        ctx.detect_submit(seq[5][0], seq[5][1], 10, 11)
+        ctx.detect_submit(seq[6][0], seq[6][1], 12, 13)
+        collect(4); collect(6); collect(8)
+        ctx.detect_submit(seq[7][0], seq[7][1], 14, 15)
+        collect(10); collect(12); collect(14)
+        out[(tails, pairing)] = res
+        ctx.close()
+    ref = out[(1, False)]
+    for key in ((2, False), (2, True)):
+        for k, ((fa, ma), (fb, mb)) in enumerate(zip(ref, out[key])):
+            for name in fa:
+                assert np.array_equal(fa[name], fb[name]), (key, k, name)
+            for (ia, da), (ib, db) in zip(ma, mb):
+                assert np.array_equal(ia, ib) and np.array_equal(da, db), (key, k)
+    assert len(ref) == 8 and all(len(f["xy_l"]) > 100 for f, _ in ref)
+
+
 def test_a_failed_group_launch_keeps_the_queue_consistent(squeeze_weights_path, stereo_pair, tuning):
     """Trunk pairing, error path: the launch of a held group fails (injected: the context's fourth group launch) while one of its two
     members had already been accepted.  The submit that triggers the launch returns the error and is NOT queued; the member accepted
