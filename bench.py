@@ -582,7 +582,12 @@ def main():
             barrier()
             cur[0] += n
             return time.perf_counter() - t1
-        ts = [block()]
+        t_probe = block()
+        if t_probe < 0.05:      # short steps (the small engines: 0.15 - 0.27 ms): blocks of at least ~50 ms, so that the fill and drain of the
+            n = min(1000, -(-int(n * 0.05 / t_probe) // 50) * 50)   # four-deep pipeline and the host's jitter stay a small part of a block
+            recs.clear()
+            t_probe = block()
+        ts = [t_probe]
         ts += [block() for _ in range((args.repeats if args.repeats > 0 else repeats_for(ts[0], 0.6)) - 1)]
         e, sp = spread(ts, n)
         return e * args.steps / n, {**sp, "steps_per_block": n}, frame_summary(recs)
