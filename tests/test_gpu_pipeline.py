@@ -470,8 +470,10 @@ def test_matches_on_the_headline_workload_are_exact(ctx_vgg, stereo_pair):
             assert np.array_equal(idx, ridx) and np.array_equal(d, rd), (sa, sb, selector, cross)
 
 
-def test_nms_redo_with_two_submissions_in_flight(vgg_plan, tmp_path):
-    """The rare path of spvo_detect_wait: the first batch of NMS rounds leaves candidates undecided, so the host
+@pytest.mark.parametrize("tails", [1, 2])
+def test_nms_redo_with_two_submissions_in_flight(vgg_plan, tmp_path, tails, tuning):
+    """(with one tail stream and with two: the continuation, the re-sampling and the rematch run on the submission's OWN tail stream)
+    The rare path of spvo_detect_wait: the first batch of NMS rounds leaves candidates undecided, so the host
     enqueues more rounds, re-samples the descriptors and redoes the matches of that submission AND the temporal
     match of the younger submission that had already matched against the replaced keypoints.  Forced here with
     all-zero images and a threshold below the uniform response (every pixel is a candidate and ties with its
@@ -482,6 +484,7 @@ def test_nms_redo_with_two_submissions_in_flight(vgg_plan, tmp_path):
     H, W = 120, 392
     path = str(tmp_path / weights.engine_name("superpoint_pretrained", 2, H, W, "FP32"))
     weights.save(vgg_plan, path)
+    tuning(tail_streams=tails)
     ctx = make_ctx(path, net_height=H, net_width=W, conf_thresh=0.001)
     P_l, P_r = synth.projection_matrices()
     z = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
