@@ -629,6 +629,8 @@ def main():
                                    + "BF+KNN 0.8, P3P-style RANSAC 500 it, LM refinement degree 4; one stereo stream per GPU, RCCL all-gather of poses",
                        "net_size": [NET_H, NET_W], "input_size": [rows, cols], "streams": world,
                        "host_cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+                       "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),   # the HIP runtime's queue count this process asked for (used by the FP16 / INT8 legs' second tail stream)
+                       "tail_streams": capi.get_tuning("tail_streams", 1),
                        "hand_over": ("images of the next %d pairs handed over ahead (prefetchStereoImagePairDevice)" % args.depth + ("; with four ahead the front end pairs trunks: a pair whose network would only queue waits for its successor and the two run through every layer in one launch (spvo_set_trunk_pairing)" if args.depth >= 4 else "") if not args.no_pipeline else "one pair at a time")
                                     + ("; each frame's solve handed over too, its pose collected during the next step (solveStereoOdometrySubmit / Collect), the last one before the closing barrier" if deferred else ""),
                        "pose_gather": {"local": "single stream, no collective", "c:rccl": "spvo_pose_allgather_n (C ABI, RCCL), one collective per 64 frames",
