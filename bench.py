@@ -79,7 +79,7 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(frames, P_l, P_r, weights_path, order, budget_s=25.0):
+def cpu_baseline(frames, P_l, P_r, weights_path, order, budget_s=25.0, ate_frames=None, ate_weights=None):
     """The CPU restatement of the whole stereoCallback (oracle/cpu: plain C++17 + OpenMP, `-O3 -march=native` rebuilt on THIS
     machine) timed on the host cores: a bounded sample of the same workload -- 5 warm-up frames, then up to 50 timed frames
     (fewer when 25 s of CPU time are used up first), medians per stage in the reference's latency-CSV columns
@@ -98,9 +98,11 @@ def cpu_baseline(frames, P_l, P_r, weights_path, order, budget_s=25.0):
     cpu.frontend_reset("KNN", True, 2.0, 0.25, 4)
     rows, t_start, k = [], time.time(), 0
     warm = 5
+    per_frame = []    # EVERY frame from the reset on (warm-ups included): what the GPU pass over the same frame indices is compared with
     while True:
         L, R = frames[order[k % len(order)]]
         r = cpu.frontend_step(L, R, P_l, P_r)
+        per_frame.append((r.pnp_ok, r.accepted, r.refined, r.lm_iterations, r.n_inliers, r.n_stereo, r.n_kp_l, *r.q[:], *r.t[:]))
         if k >= warm:
             rows.append((r.t_detect_ms, r.t_match_ms, r.t_solve_ms, r.t_total_ms, r.n_inliers, r.refined, r.accepted, r.pnp_ok, r.lm_iterations, r.n_stereo, r.n_kp_l))
         k += 1
@@ -134,13 +136,29 @@ def cpu_baseline(frames, P_l, P_r, weights_path, order, budget_s=25.0):
     except Exception as exc:
         orb = {"error": repr(exc)}
     cpu.close()
-    return {"value": round(1e3 / float(med[3]), 3), "unit": "stereo frames/s", "cores": int(threads), "kind": "port",
+    ate_cpu = None
+    if ate_frames is not None and ate_weights:   # the ATE sequence (trained sp_squeeze graph) end to end on the CPU: its own features, matcher, solver
+        try:
+            cpu2 = cpu_backend.CpuBackend(lib, net_height=NET_H, net_width=NET_W, num_threads=usable_cpus())
+            cpu2.load_weights(ate_weights)
+            cpu2.frontend_reset("KNN", True, 2.0, 0.25, 4)
+            ate_cpu = []
+            for L, R in ate_frames:
+                r = cpu2.frontend_step(L, R, P_l, P_r)
+                ate_cpu.append((r.pnp_ok, r.accepted, r.refined, r.lm_iterations, r.n_inliers, r.n_stereo, r.n_kp_l, *r.q[:], *r.t[:]))
+            cpu2.close()
+        except Exception as exc:
+            ate_cpu = repr(exc)
+    return {"_per_frame": np.array(per_frame, np.float64), "_ate_cpu": ate_cpu,
+            "value": round(1e3 / float(med[3]), 3), "unit": "stereo frames/s", "cores": int(threads), "kind": "port",
             "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "cpu_quota": usable_cpus(),
             "stage_median_ms": {"detect": round(float(med[0]), 2), "match": round(float(med[1]), 2), "solve": round(float(med[2]), 2), "total": round(float(med[3]), 2)},
             "solver_stats": {"pnp_ok_rate": round(float(a[:, 7].mean()), 3), "accepted_rate": round(float(a[:, 6].mean()), 3), "refined_rate": round(float(a[:, 5].mean()), 3),
                              "mean_lm_iterations": round(float(a[:, 8].mean()), 2), "mean_pnp_inliers": round(float(a[:, 4].mean()), 1),
                              "mean_stereo_matches": round(float(a[:, 9].mean()), 1), "mean_keypoints_left": round(float(a[:, 10].mean()), 1),
-                             "note": "the same fields as the headline's solver_stats, on the same frames (the CPU restatement's RANSAC draws the same samples: oracle/cpu)"},
+                             "note": "the same fields as the headline's solver_stats, but NOT the same frames: these are the sample's frames 5.. after a reset (frame_count <= 10 "
+                                     "accepts everything, base.cpp:251), the headline's are thousands of frames of the ping-pong cycle with the gate armed; the like-for-like "
+                                     "comparison is `solver_stats_same_frames` below"},
             "latency_ms": {"p50": round(float(np.median(a[:, 3])), 3), "p99": round(float(np.sort(a[:, 3])[min(len(a) - 1, int(0.99 * len(a)))]), 3),
                            "definition": "t_total per frame (one pair at a time: the reference's latency column, visual_odometry_node.cpp:246-258)"},
             "config1_orb_front_end": orb,
@@ -167,6 +185,77 @@ def cached_stream(synth, tex, seed):
         except OSError:
             pass
         return frames, poses, P_l, P_r
+
+
+ATE_FRAMES = 40      # the untimed trajectory pass (`ate` in the JSON line): a monotone synthetic sequence with exact ground truth
+ATE_SEED = 100
+_OUTCOME_COLS = ("pnp_ok", "accepted", "refined", "lm_iterations", "pnp_inliers", "stereo_matches", "keypoints_left")
+
+
+def cached_ate_sequence(synth, tex):
+    """ATE_FRAMES synthetic stereo frames with their ground-truth poses, rendered once per machine (0.2 s per frame)"""
+    path = os.path.join(tempfile.gettempdir(), f"spvo_synth_ate_{ATE_FRAMES}_{ATE_SEED}.npz")
+    try:
+        z = np.load(path)
+        return [(z["L"][k], z["R"][k]) for k in range(ATE_FRAMES)], [(z["Rw"][k], z["tw"][k]) for k in range(ATE_FRAMES)]
+    except Exception:
+        frames, poses, _, _ = synth.stereo_sequence(ATE_FRAMES, tex, seed=ATE_SEED)
+        tmp = f"{path}.{os.getpid()}.tmp.npz"
+        try:
+            np.savez(tmp, L=np.stack([f[0] for f in frames]), R=np.stack([f[1] for f in frames]), Rw=np.stack([p[0] for p in poses]), tw=np.stack([p[1] for p in poses]))
+            os.replace(tmp, path)
+        except OSError:
+            pass
+        return frames, poses
+
+
+def _quat_to_rot(q):
+    x, y, z, w = np.asarray(q, np.float64) / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def integrate_steps(steps):
+    """camera centres in the first camera's frame from cam0_curr_T_cam0_prev steps (R or q, t), as visual_odometry_node.cpp:118-127 chains them"""
+    T = np.eye(4)
+    out = [np.zeros(3)]
+    for r, t in steps:
+        S = np.eye(4)
+        S[:3, :3] = r if np.ndim(r) == 2 else _quat_to_rot(r)
+        S[:3, 3] = t
+        T = T @ np.linalg.inv(S)
+        out.append(T[:3, 3].copy())
+    return np.array(out)
+
+
+def ate_rmse(a, b):
+    e = np.linalg.norm(a - b, axis=1)
+    return float(np.sqrt(np.mean(e ** 2))), float(e.max())
+
+
+def gpu_sequence(host, models_dir, prefix, seq, P_l, P_r):
+    """the unchanged node's call sequence (addStereoImagePair on host images, matchDescriptors x 2, solveStereoOdometry) over `seq` on a fresh front
+    end of the FP32 engine `prefix`: one row per frame = _OUTCOME_COLS + q (xyzw) + t of cam0_curr_T_cam0_prev (identity on the first frame)"""
+    fe = host.FrontEnd(models_dir, prefix=prefix, selector="KNN", cross_check=True, batch=2, height=NET_H, width=NET_W, conf_thresh=0.015, dist_thresh=4,
+                       border_remove=4, stereo_threshold=2.0, min_disparity=0.25, refinement_degree=4, precision="FP32")
+    if not fe.engine_loaded:
+        raise RuntimeError("engine load failed: " + fe.last_error)
+    rows = []
+    for L, R in seq:
+        res = fe.step(L, R, P_l, P_r)
+        f = fe.last_solve() if res is not None else dict(pnp_ok=0, accepted=0, refined=0, lm_iterations=0)
+        q, t = res if res is not None else ((0, 0, 0, 1), (0, 0, 0))
+        rows.append((f["pnp_ok"], f["accepted"], f["refined"], f["lm_iterations"], len(fe.inliers("pnp")) if res is not None else 0,
+                     len(fe.matches(host.CURR_LEFT_CURR_RIGHT)[0]), len(fe.keypoints(host.CURR_LEFT)), *q, *t))
+    fe.close()
+    return np.array(rows, np.float64)
+
+
+def outcome_stats(a):
+    return {"pnp_ok_rate": round(float(a[:, 0].mean()), 3), "accepted_rate": round(float(a[:, 1].mean()), 3), "refined_rate": round(float(a[:, 2].mean()), 3),
+            "mean_lm_iterations": round(float(a[:, 3].mean()), 2), "mean_pnp_inliers": round(float(a[:, 4].mean()), 1),
+            "mean_stereo_matches": round(float(a[:, 5].mean()), 1), "mean_keypoints_left": round(float(a[:, 6].mean()), 1)}
 
 
 def pin_to_gpu_numa_node(torch, local_rank):
@@ -510,6 +599,8 @@ def main():
     # the number of repeats follows from the first block's duration and is the same on every rank.
     cursor = [args.warmup]
     timed_records = []
+    local_times = []        # THIS rank's block times (the line's `value` uses the max over ranks per block; `per_rank_fps` shows the ranks apart)
+    pg.reset_timing()
 
     def timed_block():
         barrier()
@@ -521,8 +612,10 @@ def main():
         if dist_on:
             gathered = pg.collect()                                         # every pose of every rank has arrived: inside the timed region
             assert gathered.shape[1:] == (world, 7)
+        t_own = time.perf_counter() - t0                                    # this rank's frames and its share of the collectives, before it waits for the slowest rank
         barrier()
         cursor[0] += args.steps
+        local_times.append(t_own)
         return time.perf_counter() - t0
 
     def over_ranks(ts):
@@ -536,6 +629,15 @@ def main():
     n_rep = args.repeats if args.repeats > 0 else repeats_for(block_times[0])
     block_times += over_ranks([timed_block() for _ in range(n_rep - 1)])
     elapsed, headline_spread = spread(block_times, args.steps)
+    gather_timing = pg.timing()
+    rank_fps = [args.steps / float(np.median(local_times))]
+    rank_gather_ms = [gather_timing.get("mean_ms", 0.0)]
+    rank_init_ms = [pg.init_ms]
+    if dist_on:   # every rank's own rate, collective cost and communicator set-up time, gathered OUTSIDE the timed region
+        t = torch.tensor([rank_fps[0], rank_gather_ms[0], rank_init_ms[0]], dtype=torch.float64, device="cpu" if shared else "cuda")
+        allr = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allr, t)
+        rank_fps, rank_gather_ms, rank_init_ms = ([float(a[i]) for a in allr] for i in range(3))
     prof, prof_all = {}, {}
     if not args.no_profile:
         prof = ctx.profile()
@@ -639,6 +741,13 @@ def main():
                                       + (" -- " + pg.transport_note if pg.transport_note else "")},
         }
         out.update(frame_summary(timed_records))
+        # the ranks apart (one entry per rank; N = 1: one entry): each rank's own frame rate over its median block BEFORE the closing barrier, what a batched pose
+        # collective costs its calling thread, and the one-off communicator creation (ncclCommInitRank + bootstrap), which is outside every timed region
+        out["per_rank_fps"] = {"min": round(min(rank_fps), 2), "median": round(float(np.median(rank_fps)), 2), "max": round(max(rank_fps), 2), "ranks": [round(v, 2) for v in rank_fps],
+                               "definition": "steps / this rank's median block time, measured before the block's closing barrier (value = all ranks' steps / max over ranks)"}
+        out["pose_gather_ms"] = {**gather_timing, "per_rank_mean_ms": [round(v, 4) for v in rank_gather_ms],
+                                 "definition": "host wall time of one spvo_pose_allgather_n (all ranks' poses of <= 64 frames, RCCL) inside the timed region, rank 0's distribution + every rank's mean"}
+        out["comm_init_ms"] = {"per_rank": [round(v, 1) for v in rank_init_ms], "where": "communicator creation (spvo_comm_create = ncclCommInitRank, id broadcast through torch.distributed) before warm-up: not in the timed region"}
         out["step_loop"] = ("one Python call per front-end call (--py-loop)" if args.py_loop else
                             "blocks of stereoCallbacks handed to the host library's C loop (host/harness_capi.cpp: spvo_host_run_device_block), as the reference's C++ node runs them")
         dom = prof.get("conv:1") if args.graph == "vgg" and args.precision != "INT8" else None
@@ -770,8 +879,12 @@ def main():
                 # one cv::Mat pair per POSITION of the cycle (the front end recognises an announced pair by its data pointers: see cycle_buffers)
                 mats = [(fe.make_image(frames[f][0]), fe.make_image(frames[f][1])) for f in order]
                 hi = {}
-                for name, depth in (("synchronous", 0), ("lookahead", args.depth)):
+                # images_dq / descriptors_dq: the class fills them inside addStereoImagePair by default (reference-observable state, nn.cpp:154,
+                # 494-498); "synchronous" and "lookahead" OPT IN to setDeferredHostCopies(true) -- the two bulk copies made while the solver's
+                # kernels run -- and say so; "synchronous_default_copies" is the class exactly as constructed.
+                for name, depth, defer in (("synchronous", 0, True), ("synchronous_default_copies", 0, False), ("lookahead", args.depth, True)):
                     lat, ann = [], {}
+                    fe.set_deferred_copies(defer)
 
                     def hstep(i, depth=depth, lat=lat, ann=ann):
                         a = [mats[(i + 1 + d) % len(mats)] if d < depth else None for d in range(4)]
@@ -792,9 +905,10 @@ def main():
                     e3, sp3 = leg(hstep, lambda: fe.finish_solve())
                     ls = np.sort(np.asarray(lat)) if lat else np.zeros(1)
                     hi[name] = {"value": round(args.steps / e3, 2), "ms_per_step": round(1e3 * e3 / args.steps, 4), **sp3,
+                                "deferred_host_copies": bool(defer),
                                 "latency_ms": {"p50": round(float(ls[ls.size // 2]), 3), "p99": round(float(ls[min(ls.size - 1, int(0.99 * ls.size))]), 3), "frames": int(ls.size),
                                                "definition": "first call that hands the pair over -> its pose returned (Python clock around the calls): the reference's t_total for the synchronous sequence"}}
-                    if depth == 0:
+                    if depth == 0 and defer:
                         # the stage table of THIS leg (the headline's `stages_ms` describes the pipelined loop): host wall time of the node's
                         # three kinds of calls, then -- a second short pass with every stage bracketed by events -- what the device did in them
                         import ctypes as C
@@ -835,7 +949,9 @@ def main():
                                                                     "frac": round(mg["flops"] / (mms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), "where": "alone on the chip (synchronous call sequence), HIP-event time"}
                 out["host_interface"] = {"unit": "stereo frames/s", **hi,
                                          "note": "addStereoImagePair(cv::Mat&, ...): 2 x 0.47 MB host images in, 2 x 0.42 MB resized images + 2 x 1 MB "
-                                                 "descriptors out per pair (PCIe inclusive); the headline `value` has the images resident in HBM"}
+                                                 "descriptors out per pair (PCIe inclusive); the headline `value` has the images resident in HBM.  "
+                                                 "deferred_host_copies: setDeferredHostCopies(true), an opt-in of this script -- the class's default fills "
+                                                 "images_dq / descriptors_dq inside addStereoImagePair as the reference does (synchronous_default_copies)"}
             except Exception as exc:   # the headline line must survive a failure of this informational part
                 out["host_interface"] = {"error": repr(exc)}
         if world == 1 and headline and not args.no_extras and "trained" in legs:
@@ -963,7 +1079,65 @@ def main():
                     out["other_configs"][oname] = {"error": repr(exc)}
         if not args.no_cpu_baseline and world == 1 and headline:
             try:
-                out["cpu_baseline"] = cpu_baseline(frames, P_l, P_r, engine_path, order)
+                # BASELINE.json's metric is "stereo frames/sec ...; ATE vs ref": the trajectory half, from an UNTIMED pass.  ATE_FRAMES synthetic frames
+                # with exact ground truth through the reference's TRAINED sp_squeeze graph (the seeded VGG weights of the headline track nothing), FP32,
+                # net size of the headline, the unchanged node's call sequence: once through the GPU front end, once end to end through oracle/cpu
+                # (its own network, NMS, matcher and solver: inside cpu_baseline, the only place this script touches oracle/).
+                import shutil
+                fe.close()
+                ate_frames, ate_poses = cached_ate_sequence(synth, tex)
+                sq_path = os.path.join(ROOT, "tests", "golden", "sp_squeeze.spvw")
+                os.makedirs(os.path.join(tmp, "ate", "laptop"), exist_ok=True)
+                shutil.copyfile(sq_path, os.path.join(tmp, "ate", "laptop", weights.engine_name("sp_squeeze", 2, NET_H, NET_W, "FP32")))
+                cb = cpu_baseline(frames, P_l, P_r, engine_path, order, ate_frames=ate_frames, ate_weights=sq_path)
+                cpu_rows, ate_cpu = cb.pop("_per_frame"), cb.pop("_ate_cpu")
+                out["cpu_baseline"] = cb
+                try:
+                    # like for like: the GPU front end (headline engine, synchronous call sequence, fresh state) over EXACTLY the frame indices the CPU
+                    # sample ran (its warm-ups included), outcome by outcome
+                    g = gpu_sequence(host, tmp, "superpoint_pretrained", [frames[order[k % len(order)]] for k in range(len(cpu_rows))], P_l, P_r)
+                    c = cpu_rows
+                    warm = 5
+                    cb["solver_stats_same_frames"] = {
+                        "frames": int(len(c) - warm), "frame_indices": f"frames {warm}..{len(c) - 1} of the ping-pong cycle after a reset, both sides (the CPU sample's frames; frames 0..{warm - 1} are run and not counted)",
+                        "gpu": outcome_stats(g[warm:]), "cpu": outcome_stats(c[warm:]),
+                        "accepted_flag_agreement": round(float((g[1:, 1] == c[1:, 1]).mean()), 4), "refined_flag_agreement": round(float((g[1:, 2] == c[1:, 2]).mean()), 4),
+                        "pnp_ok_agreement": round(float((g[1:, 0] == c[1:, 0]).mean()), 4),
+                        "mean_abs_inlier_difference": round(float(np.abs(g[1:, 4] - c[1:, 4]).mean()), 2),
+                        "pose_t_difference_m": {"median": float(np.median(np.abs(g[1:, 11:14] - c[1:, 11:14]).max(axis=1))), "max": float(np.abs(g[1:, 11:14] - c[1:, 11:14]).max())},
+                        "note": "GPU = libspvo through the host class, CPU = oracle/cpu, each on its OWN features (two fp32 networks that agree to ~1e-6: a few keypoints near the "
+                                "threshold differ, so inlier counts differ by a few; a flag that differs is a frame whose acceleration sat at the gate's threshold)"}
+                except Exception as exc:
+                    cb["solver_stats_same_frames"] = {"error": repr(exc)}
+                try:
+                    ga = gpu_sequence(host, os.path.join(tmp, "ate"), "sp_squeeze", ate_frames, P_l, P_r)
+                    gt_steps = []
+                    for k in range(1, ATE_FRAMES):
+                        gt_steps.append(synth.relative_pose(ate_poses[k - 1], ate_poses[k]))
+                    traj_gt = integrate_steps(gt_steps)
+                    traj_gpu = integrate_steps([(r[7:11], r[11:14]) for r in ga[1:]])
+                    path_len = float(np.sum(np.linalg.norm(np.diff(traj_gt, axis=0), axis=1)))
+                    rec = {"frames": ATE_FRAMES, "path_length_m": round(path_len, 2),
+                           "workload": f"sp_squeeze (the reference's trained ONNX graph) FP32, net {NET_H}x{NET_W}, 1241x376 synthetic stereo sequence with exact ground truth "
+                                       f"(spvo/synth.py, seed {ATE_SEED}), KNN 0.8, refinement degree 4, the unchanged node's call sequence; untimed",
+                           "gpu_vs_gt_rmse_m": round(ate_rmse(traj_gpu, traj_gt)[0], 5), "gpu_vs_gt_max_m": round(ate_rmse(traj_gpu, traj_gt)[1], 5),
+                           "gpu_solver": outcome_stats(ga[1:]),
+                           "definition": "RMSE of camera centres after chaining the per-frame cam0_curr_T_cam0_prev (visual_odometry_node.cpp:118-127), no alignment (both start at identity); "
+                                         "the reference publishes no ATE number (plots only, VO/figures), so there is no reference tolerance to quote"}
+                    if isinstance(ate_cpu, list) and len(ate_cpu) == ATE_FRAMES:
+                        ca = np.array(ate_cpu, np.float64)
+                        traj_cpu = integrate_steps([(r[7:11], r[11:14]) for r in ca[1:]])
+                        rec.update({"gpu_vs_cpu_rmse_m": round(ate_rmse(traj_gpu, traj_cpu)[0], 6), "gpu_vs_cpu_max_m": round(ate_rmse(traj_gpu, traj_cpu)[1], 6),
+                                    "cpu_vs_gt_rmse_m": round(ate_rmse(traj_cpu, traj_gt)[0], 5), "cpu_solver": outcome_stats(ca[1:]),
+                                    "accepted_flag_agreement": round(float((ga[1:, 1] == ca[1:, 1]).mean()), 4),
+                                    "cpu": "oracle/cpu end to end on its own features (kind: port)"})
+                    else:
+                        rec["cpu_error"] = str(ate_cpu)
+                    out["ate"] = rec
+                except Exception as exc:
+                    out["ate"] = {"error": repr(exc)}
+                fe = host.FrontEnd(tmp, prefix="superpoint_pretrained", selector="KNN", cross_check=True, batch=2, height=NET_H, width=NET_W, conf_thresh=0.015, dist_thresh=4,
+                                   border_remove=4, stereo_threshold=2.0, min_disparity=0.25, refinement_degree=4, precision="FP32")   # (closed below)
             except Exception as exc:   # the headline line must survive a failure of this informational part
                 out["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)

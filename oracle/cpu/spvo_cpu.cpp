@@ -1106,6 +1106,15 @@ int spvo_cpu_frontend_map(spvo_cpu *c, int match_type, int32_t *out, int cap) {
   return (int)m.size();
 }
 
+// keypoints of deque position -4..-1 (ImagePosition, hpp:66-72) after the last step: xy [cap][2]; returns their number (-1: no such entry)
+int spvo_cpu_frontend_keypoints(spvo_cpu *c, int position, float *xy, int cap) {
+  if (!c || position >= 0 || (int)c->kp_dq.size() + position < 0) return -1;
+  const std::vector<float> &k = c->kp_dq[c->kp_dq.size() + position];
+  const int n = (int)k.size() / 2;
+  for (int i = 0; i < n && i < cap; ++i) { xy[2 * i] = k[2 * i]; xy[2 * i + 1] = k[2 * i + 1]; }
+  return n;
+}
+
 int spvo_cpu_frontend_step(spvo_cpu *c, const uint8_t *img_l, const uint8_t *img_r, int rows, int cols, size_t stride, const double P_l[12],
                            const double P_r[12], spvo_cpu_step_result *res) {
   if (!c || !img_l || !img_r || !P_l || !P_r || !res) return fail(-1, "bad argument");

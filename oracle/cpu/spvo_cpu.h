@@ -74,6 +74,8 @@ int spvo_cpu_orb_tables(float *pattern, float *taps);
 int spvo_cpu_orb(spvo_cpu *c, const uint8_t *img, int rows, int cols, size_t stride, float *xy, float *angle_response_octave, uint8_t *desc, int cap, int *n);
 /* introspection for the parity tests: maps_of_indices[match_type] of the last step */
 int spvo_cpu_frontend_map(spvo_cpu *c, int match_type, int32_t *out, int cap);
+/* ... and the keypoints of deque position -4..-1 (prevL, prevR, currL, currR: hpp:66-72); returns their number */
+int spvo_cpu_frontend_keypoints(spvo_cpu *c, int position, float *xy, int cap);
 
 #ifdef __cplusplus
 }

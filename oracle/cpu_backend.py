@@ -79,6 +79,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.spvo_cpu_frontend_reset.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int]
     lib.spvo_cpu_frontend_step.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, dp, dp, C.POINTER(StepResult)]
     lib.spvo_cpu_frontend_map.argtypes = [vp, C.c_int, vp, C.c_int]
+    lib.spvo_cpu_frontend_keypoints.argtypes = [vp, C.c_int, vp, C.c_int]
     lib.spvo_cpu_frontend_reset_classic.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_int]
     lib.spvo_cpu_orb.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, vp, vp, C.c_int, ip]
     lib.spvo_cpu_orb_tables.argtypes = [vp, vp]
@@ -219,6 +220,13 @@ class CpuBackend:
         out = np.zeros(cap, np.int32)
         n = self.lib.spvo_cpu_frontend_map(self.h, match_type, _p(out), cap)
         return out[:n].copy()
+
+    def frontend_keypoints(self, position: int) -> np.ndarray:
+        """keypoints of deque position -4..-1 (prevL, prevR, currL, currR) after the last frontend_step: [n, 2] float32"""
+        cap = max(self.cap, 4096)
+        xy = np.zeros((cap, 2), np.float32)
+        n = self.lib.spvo_cpu_frontend_keypoints(self.h, position, _p(xy), cap)
+        return xy[:max(n, 0)].copy()
 
     def frontend_reset_classic(self, selector="KNN", cross_check=True, stereo_threshold=2.0, refinement_degree=4):
         """ClassicFeatureFrontEnd(ORB, ORB, BF, ...) of launch/visual_odometry_classic.launch on the CPU (BASELINE config 1)."""

@@ -389,14 +389,15 @@ public:
   void prefetchStereoImagePair(const cv::Mat &img_l, const cv::Mat &img_r);
   spvo_ctx *context() const { return ctx_; }
   // The resized images and the descriptors of a HOST-image pair are written by the GPU into pinned mirrors of the submission
-  // (spvo_detect_collect_mirrors) and copied ONCE into the matrices of images_dq / descriptors_dq.  By default those two copies
-  // (2 x 0.42 MB + 2 x 1 MB: ~0.1 ms of host time) are deferred: addStereoImagePair pushes matrices of the final size and returns;
-  // they are filled while the solver's kernels run (solveStereoOdometry, between its submit and its wait: 864 -> 929 frames/s on
-  // the synchronous call sequence; a helper thread for the copies measured the same, 931, and was not kept), or at the next call
+  // (spvo_detect_collect_mirrors) and copied ONCE into the matrices of images_dq / descriptors_dq -- by default INSIDE
+  // addStereoImagePair, as the reference fills both deques there (nn.cpp:154, 494-498): whatever reads the public deques after the
+  // call returns (a node's drawing code, a subclass) sees what the reference would show.
+  // Opt-in, setDeferredHostCopies(true): the two bulk copies (2 x 0.42 MB + 2 x 1 MB: ~0.1 ms of host time) are put off --
+  // addStereoImagePair pushes matrices of the final size and returns; they are filled while the solver's kernels run
+  // (solveStereoOdometry, between its submit and its wait: 864 -> 929 frames/s on the synchronous call sequence), or at the next call
   // that takes a pair, draws, clears or destroys -- always before the mirrors are reused and before anything this class hands
-  // out.  What the unchanged node can observe (visual_odometry_node.cpp:175-218 calls methods only) is unchanged; code that reads
-  // images_dq / descriptors_dq directly between addStereoImagePair and solveStereoOdometry calls completeHostCopies() first, or
-  // switches the deferral off here.  Keypoints, the image handed back to the caller and every index map are never deferred.
+  // out.  A caller that opts in and reads images_dq / descriptors_dq directly between addStereoImagePair and solveStereoOdometry
+  // calls completeHostCopies() first.  Keypoints, the image handed back to the caller and every index map are never deferred.
   void setDeferredHostCopies(bool on) { if (!on) completeHostCopies(); defer_host_copies_ = on; }
   void completeHostCopies() override;
   void completeImageCopies() override;
@@ -436,5 +437,5 @@ private:
   struct PendingCopy { const void *src = nullptr; cv::Mat dst; size_t bytes = 0; bool descriptors = false; };
   std::vector<PendingCopy> pending_copies_;   // mirror -> matrix copies not made yet (at most one pair's)
   spvo_detect_mirrors pending_mirrors_;       // ... and where they come from (spvo_detect_mirrors_wait before the descriptors are read)
-  bool defer_host_copies_ = true;
+  bool defer_host_copies_ = false;   // reference-observable deques by default (nn.cpp:154, 494-498); setDeferredHostCopies(true) opts in
 };

@@ -137,6 +137,25 @@ int spvo_host_image(void *h, int position, uint8_t *out, int cap) {
   return m.rows * m.cols;
 }
 
+// The deques exactly as a reader of the PUBLIC members finds them right now: no completeHostCopies() first (the test of the default
+// setDeferredHostCopies(false): images_dq.back() / descriptors_dq.back() are filled when addStereoImagePair returns, nn.cpp:154, 494-498)
+int spvo_host_descriptors_raw(void *h, int position, float *desc, int cap) {
+  auto *fe = static_cast<SuperPointFeatureFrontEnd *>(h);
+  if ((int)fe->descriptors_dq.size() + position < 0) return -1;
+  const auto &d = fe->descriptors_dq.end()[position];
+  const int n = d.rows < cap ? d.rows : cap;
+  if (n && d.cols == 256) std::memcpy(desc, d.data, (size_t)n * 256 * sizeof(float));
+  return d.rows;
+}
+
+int spvo_host_image_raw(void *h, int position, uint8_t *out, int cap) {
+  auto *fe = static_cast<SuperPointFeatureFrontEnd *>(h);
+  if ((int)fe->images_dq.size() + position < 0) return -1;
+  const auto &m = fe->images_dq.end()[position];
+  if (m.rows * m.cols <= cap && m.data) std::memcpy(out, m.data, (size_t)m.rows * m.cols);
+  return m.rows * m.cols;
+}
+
 int spvo_host_matches(void *h, int match_type, int *query, int *train, float *dist, int cap) {
   const auto &m = static_cast<SuperPointFeatureFrontEnd *>(h)->cv_DMatches_list[match_type];
   for (int i = 0; i < (int)m.size() && i < cap; ++i) { query[i] = m[i].queryIdx; train[i] = m[i].trainIdx; dist[i] = m[i].distance; }

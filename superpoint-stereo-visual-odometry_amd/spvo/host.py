@@ -67,6 +67,8 @@ def load():
         lib.spvo_host_keypoints.argtypes = [vp, C.c_int, vp, C.c_int]
         lib.spvo_host_descriptors.argtypes = [vp, C.c_int, vp, C.c_int]
         lib.spvo_host_image.argtypes = [vp, C.c_int, vp, C.c_int]
+        lib.spvo_host_descriptors_raw.argtypes = [vp, C.c_int, vp, C.c_int]
+        lib.spvo_host_image_raw.argtypes = [vp, C.c_int, vp, C.c_int]
         lib.spvo_host_matches.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int]
         lib.spvo_host_map.argtypes = [vp, C.c_int, vp, C.c_int]
         lib.spvo_host_inliers.argtypes = [vp, C.c_int, vp, C.c_int]
@@ -171,7 +173,8 @@ class FrontEnd:
                                                int(host_descriptors))
 
     def set_deferred_copies(self, on):
-        """SuperPointFeatureFrontEnd::setDeferredHostCopies: False = images_dq / descriptors_dq are filled inside addStereoImagePair"""
+        """SuperPointFeatureFrontEnd::setDeferredHostCopies: False (the default, the reference's behaviour) = images_dq / descriptors_dq are
+        filled inside addStereoImagePair; True = the two bulk copies are made while the solver's kernels run"""
         self.lib.spvo_host_set_deferred_copies(self.h, int(on))
 
     def context(self):
@@ -294,6 +297,18 @@ class FrontEnd:
     def image(self, position):
         out = np.zeros((self.H, self.W), np.uint8)
         n = self.lib.spvo_host_image(self.h, position, _p(out), out.size)
+        return out if n == out.size else None
+
+    def descriptors_raw(self, position):
+        """descriptors_dq.end()[position] as the public member holds it NOW (no completeHostCopies first)"""
+        d = np.zeros((self.cap, 256), np.float32)
+        n = self.lib.spvo_host_descriptors_raw(self.h, position, _p(d), self.cap)
+        return d[:max(n, 0)].copy()
+
+    def image_raw(self, position):
+        """images_dq.end()[position] as the public member holds it NOW (no completeHostCopies first)"""
+        out = np.zeros((self.H, self.W), np.uint8)
+        n = self.lib.spvo_host_image_raw(self.h, position, _p(out), out.size)
         return out if n == out.size else None
 
     def matches(self, match_type):

@@ -47,6 +47,11 @@ class PoseGather:
         self.comm = None
         self.transport = "local" if self.local_only else transport
         self.transport_note = ""
+        self.init_ms = 0.0                 # wall time of creating the communicator (ncclCommInitRank on every rank + the bootstrap exchange): once, outside any timed region
+        self.collective_ms: List[float] = []   # host wall time of every batched collective since reset_timing(): what a frame loop pays per BATCH frames
+        import time as _time
+        self._clock = _time.perf_counter
+        t_init = self._clock()
         if self.transport in ("auto", "c"):
             # Every rank takes the same decision: _make_comm agrees on it collectively (all ranks reach every broadcast /
             # all-reduce whatever happened locally), so no rank is left waiting in a collective its peers have abandoned.
@@ -57,6 +62,7 @@ class PoseGather:
                 raise RuntimeError("C-ABI communicator unavailable: " + why)
             else:
                 self.transport, self.transport_note = "torch", f"C-ABI communicator unavailable ({why}); torch.distributed used"
+        self.init_ms = 1e3 * (self._clock() - t_init)
         self.buf = torch.zeros(7, dtype=torch.float64, device=self.device)
         self.out: List[torch.Tensor] = [torch.zeros(7, dtype=torch.float64, device=self.device) for _ in range(self.world)]
         self._pending: list = []
@@ -142,8 +148,11 @@ class PoseGather:
             self._pending.append((self._host[:n].copy()[:, None, :], n))
             return
         if self.comm is not None:          # one spvo_pose_allgather_n per batch: [world, n, 7] -> [n, world, 7]
+            t0 = self._clock()
             self._pending.append((self.comm.allgather(self._host[:n]).transpose(1, 0, 2).copy(), n))
+            self.collective_ms.append(1e3 * (self._clock() - t0))
             return
+        t0 = self._clock()
         slot = self._slot
         self._slot = (slot + 1) % self.SLOTS
         if self._ready[slot] is not None:
@@ -164,6 +173,18 @@ class PoseGather:
             send.copy_(stage)
             dist.all_gather_into_tensor(out.view(self.world * self.BATCH, 7), send)
         self._pending.append((out, n))
+        self.collective_ms.append(1e3 * (self._clock() - t0))    # (torch transport on a side stream: the enqueue, not the completion)
+
+    def reset_timing(self) -> None:
+        self.collective_ms = []
+
+    def timing(self) -> dict:
+        """what the collectives cost the calling thread since reset_timing(): per batched collective of <= BATCH frames"""
+        a = np.asarray(self.collective_ms, np.float64)
+        if a.size == 0:
+            return {"collectives": 0, "frames_per_collective": self.BATCH}
+        return {"collectives": int(a.size), "frames_per_collective": self.BATCH, "mean_ms": round(float(a.mean()), 4), "p50_ms": round(float(np.median(a)), 4),
+                "max_ms": round(float(a.max()), 4), "total_ms": round(float(a.sum()), 3)}
 
     def gather_async(self, q_xyzw, t) -> None:
         if self._host is None:

@@ -117,10 +117,15 @@ def render(scene: Scene, R: np.ndarray, t: np.ndarray, rows: int = ROWS, cols: i
 
 
 def stereo_sequence(n_frames: int, texture_path: Optional[str] = None, seed: int = 0,
-                    rows: int = ROWS, cols: int = COLS):
-    """Returns (frames [(left u8, right u8)], poses [(R, t) world_T_cam], P_l, P_r)."""
+                    rows: int = ROWS, cols: int = COLS, drop=()):
+    """Returns (frames [(left u8, right u8)], poses [(R, t) world_T_cam], P_l, P_r).
+
+    `drop`: indices of the underlying ego-motion that are left out (never rendered): n_frames frames are still returned, and the step
+    across a gap is a PLANTED JUMP of (1 + gap) x the usual ~0.8 m -- what the reference's acceleration gate (base.cpp:251-260:
+    |t - t_pred| / 0.1 s > 8 m/s^2 once frame_count > IGNORE_FRAME_COUNT) exists to reject."""
     tex = load_texture(texture_path, seed + 1)
-    poses = ego_motion(n_frames, seed)
+    drop = set(int(d) for d in drop)
+    poses = [p for k, p in enumerate(ego_motion(n_frames + len(drop), seed)) if k not in drop]
     frames = []
     scene = Scene(tex, wall_z=poses[-1][1][2] + 45.0)     # static world: the wall stays put
     for R, t in poses:

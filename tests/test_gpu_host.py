@@ -128,13 +128,13 @@ def test_prefetch_pipeline_is_transparent(models_dir, sequence):
                 assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1])      # poses: bit-identical
 
 
-@pytest.mark.parametrize("arrangement", ["default", "eager_copies", "heads_on_tail", "heads_on_net"])
+@pytest.mark.parametrize("arrangement", ["default", "deferred_copies", "heads_on_tail", "heads_on_net"])
 def test_the_reference_entry_point_with_host_images_equals_the_device_entry(models_dir, sequence, arrangement, tuning):
     """addStereoImagePair(cv::Mat&, ...) -- the reference's own interface (node.cpp:175): host images in, resized images and
     descriptors back in images_dq / descriptors_dq -- without look-ahead, with one and with two pairs announced through
     prefetchStereoImagePair, and the device-resident entry: the same keypoints, descriptors, index maps, inliers and poses,
-    bit for bit.  Arrangements: the bulk copies into the deques deferred behind the solve (default) or made inside
-    addStereoImagePair (setDeferredHostCopies(false)); the heads on the tail / on the network stream (diagnostic switch)."""
+    bit for bit.  Arrangements: the bulk copies into the deques made inside addStereoImagePair (default, as the reference) or
+    deferred behind the solve (setDeferredHostCopies(true)); the heads on the tail / on the network stream (diagnostic switch)."""
     import torch
     frames, poses, P_l, P_r = sequence
     rows, cols = frames[0][0].shape
@@ -143,8 +143,8 @@ def test_the_reference_entry_point_with_host_images_equals_the_device_entry(mode
         tuning(heads_on_net=1 if arrangement == "heads_on_net" else 0)
     for mode in ("device", 0, 1, 2, 4):
         fe = host.FrontEnd(models_dir, prefix="sp_squeeze")
-        if arrangement == "eager_copies":
-            fe.set_deferred_copies(False)
+        if arrangement == "deferred_copies":
+            fe.set_deferred_copies(True)
         res = []
         if mode == "device":
             dev = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
@@ -178,6 +178,41 @@ def test_the_reference_entry_point_with_host_images_equals_the_device_entry(mode
             if a[0] is not None:
                 assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1])      # poses: bit-identical
             assert np.array_equal(b[6], ofe.preprocess(frames[k][0], P_l, 360, 1176)[0])           # images_dq holds the resized u8 image (nn.cpp:154)
+
+
+def test_public_deques_are_filled_when_add_stereo_image_pair_returns(models_dir, sequence):
+    """nn.cpp:154, 494-498: the reference fills images_dq and descriptors_dq INSIDE addStereoImagePair.  Read the public members
+    immediately after the call -- no completeHostCopies(), no match, no solve in between -- on the default configuration: the resized
+    u8 images are the oracle's, bit for bit, and the descriptors are those the device slots hold (the ones matchDescriptors reads);
+    both also one call later, when the pair has rolled to the PREV positions.  With the opt-in deferral the same reads agree once
+    completeHostCopies() has run (the accessor that calls it first)."""
+    from oracle import frontend as ofe
+    frames, poses, P_l, P_r = sequence
+    fe = host.FrontEnd(models_dir, prefix="sp_squeeze")
+    mats = [(fe.make_image(L), fe.make_image(R)) for L, R in frames[:3]]
+    prev = None
+    for k in range(3):
+        import ctypes as C
+        Pl, Pr = np.ascontiguousarray(P_l, np.float64), np.ascontiguousarray(P_r, np.float64)
+        fe.lib.spvo_host_add_stereo_pair_mat(fe.h, C.c_void_p(mats[k][0]), C.c_void_p(mats[k][1]), host._p(Pl), host._p(Pr))
+        raw = [(fe.image_raw(pos), fe.descriptors_raw(pos)) for pos in (host.CURR_LEFT, host.CURR_RIGHT)]          # straight from the deques
+        for (img, desc), src, pos in zip(raw, frames[k], (host.CURR_LEFT, host.CURR_RIGHT)):
+            assert np.array_equal(img, ofe.preprocess(src, P_l, 360, 1176)[0])
+            n = len(fe.keypoints(pos))
+            assert desc.shape == (n, 256) and n > 100
+            assert np.abs(np.linalg.norm(desc, axis=1) - 1.0).max() < 1e-5                                         # normalised rows: not uninitialised memory
+            assert np.array_equal(desc, fe.descriptors(pos))                                                       # = after completeHostCopies()
+        if prev is not None:                                                                                      # rolled to PREV_LEFT / PREV_RIGHT
+            for (img, desc), pos in zip(prev, (host.PREV_LEFT, host.PREV_RIGHT)):
+                assert np.array_equal(img, fe.image_raw(pos)) and np.array_equal(desc, fe.descriptors_raw(pos))
+        prev = raw
+        fe.match_descriptors(host.CURR_LEFT_CURR_RIGHT)
+        if k:
+            fe.match_descriptors(host.CURR_LEFT_PREV_LEFT)
+            fe.solve_stereo_odometry()
+    for m in mats:
+        fe.free_image(m[0]); fe.free_image(m[1])
+    fe.close()
 
 
 def test_fp16_engine_through_the_host_class(tmp_path, squeeze_weights_path, sequence):
