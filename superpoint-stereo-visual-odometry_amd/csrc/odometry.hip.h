@@ -99,8 +99,8 @@ __device__ inline bool solve_linear(double *A, double *b) {
 // synthetic data make it), then inverse iteration from e_w -- the wanted vector's w component is what a finite point never
 // lacks -- which contracts by (sigma_4 / sigma_3)^2 ~ 1e-4 .. 1e-8 per step; 4 steps.  ~300 f64 instructions, 8 divisions, no
 // square root in the loop.  The one-sided Jacobi SVD this replaces (30 sweeps at most, 3 square roots and 3 divisions per
-// rotation: ~10 k f64 instructions, 58 us inside the pipeline) gave the same vector; both agree with the oracle's SVD to
-// rounding level of the f32 result (tests/test_gpu_odometry.py: <= 2e-6 relative).  A^T A squares the condition number:
+// rotation: ~10 k f64 instructions, 58 us inside the pipeline) gave the same vector; with the SVD's unit 2-norm scaling (below) the
+// stored f32 points are the oracle's bit for bit on >= 98 % of the points and never more than two f32 units away (tests/test_gpu_odometry.py).  A^T A squares the condition number:
 // the direction error is ~ eps (sigma_1 / sigma_3)^2 <= 1e-16 x 1e8, far below the f32 rounding of the stored point.
 // one correspondence: (x0, y0) in the left, (x1, y1) in the right image -> out[0..2]
 __device__ __forceinline__ void triangulate_point(const double *Pl, const double *Pr, const double x0, const double y0, const double x1, const double y1, float *out) {
@@ -153,6 +153,15 @@ __device__ __forceinline__ void triangulate_point(const double *Pl, const double
   // to the start vector -- or a pair with a large vertical offset (sigma_4 / sigma_3 not small): keep iterating until the direction
   // stands still (the serial Jacobi SVD this replaced needed no such care; the result is the same vector)
   for (int it = 4; it < 200 && delta > 1e-13; ++it) inverse_step();
+  // cv::triangulatePoints stores the UNIT-NORM right-singular vector (a row of the SVD's V^T) as CV_32F BEFORE the division by w
+  // (base.cpp:212, 223): where each component's f32 rounding falls depends on the vector's scale.  Scaled to maximum norm 1, as the iteration
+  // leaves it, four of five points came out one to four f32 units away from the oracle's -- enough to move a point across the RANSAC
+  // threshold once in a few hundred frames (round 6: tests/test_gpu_long_sequence.py, frame 7).  With the 2-norm normalisation of the SVD
+  // the stored f32 bits agree except where the f64 directions (~1e-11 apart) straddle an f32 rounding boundary.
+  {
+    const double inv_n = 1.0 / sqrt(h0 * h0 + h1 * h1 + h2 * h2 + h3 * h3);
+    h0 *= inv_n; h1 *= inv_n; h2 *= inv_n; h3 *= inv_n;
+  }
   const float f0 = (float)h0, f1 = (float)h1, f2 = (float)h2, f3 = (float)h3;
   const float scale = (f3 != 0.f) ? __fdiv_rn(1.0f, f3) : 1.0f;
   out[0] = mul_rn(f0, scale);

@@ -177,10 +177,10 @@ def test_long_sequence_end_to_end_vs_cpu_restatement_with_its_own_features(gpu_r
     _log([f"(b) own features: keypoint-set IoU (left) mean {np.mean(ious):.4f} min {np.min(ious):.4f}; accepted flags agree on {np.mean(agree_acc) * 100:.1f} % of {len(agree_acc)} frames, "
           f"refined flags on {np.mean(agree_ref) * 100:.1f} %; |inliers GPU - CPU| mean {np.mean(d_inl):.1f} max {np.max(d_inl)}; per-frame |dt| median {np.median(dts):.2e} max {np.max(dts):.2e} m",
           f"    ATE(GPU, oracle/cpu end to end) rmse {ate_gc:.2e} m max {max_gc:.2e} m; vs ground truth over frames 0..{JUMP_GATED - 1}: GPU {ate_g:.4f} m, CPU {ate_c:.4f} m"])
-    assert np.mean(ious) >= 0.97 and np.min(ious) >= 0.93
+    assert np.mean(ious) >= 0.99 and np.min(ious) >= 0.95          # measured: 1.0000 on every frame (profiles/r06_long_sequence.log)
     assert all(agree_acc), "the gate decisions (base.cpp:251-260) are the same on every frame"
     assert np.mean(agree_ref) >= 0.95
-    assert ate_gc <= 0.05                                # metres over a ~36 m path: the same trajectory
+    assert ate_gc <= 1e-3                                # SURVEY.md section 8d's gate, here END TO END (measured 3e-15 m: identical keypoints, then identical arithmetic)
     assert abs(ate_g - ate_c) <= 0.03
 
 

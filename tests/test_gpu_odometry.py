@@ -17,7 +17,10 @@ def test_triangulate(ctx_vgg, golden_dir):
     got = ctx_vgg.triangulate(o["P_l"], o["P_r"], o["cl"], o["cr"])
     ref = od.triangulate(o["P_l"], o["P_r"], o["cl"], o["cr"])
     assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)) <= 1e-4     # north_star tolerance
-    assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)) <= 2e-6     # what is actually achieved
+    assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)) <= 3e-7     # what is actually achieved: never more than two f32 units ...
+    same = (got.view(np.int32) == ref.view(np.int32)).all(axis=1)
+    assert same.mean() >= 0.98, same.mean()                                       # ... and the oracle's f32 bits on (nearly) every point: the homogeneous vector is rounded
+    #                                                                               to f32 at the SVD's unit 2-norm scale, as cv::triangulatePoints stores it (base.cpp:212)
     assert len(ctx_vgg.triangulate(o["P_l"], o["P_r"], o["cl"][:0], o["cr"][:0])) == 0
     # bug-compatible projection matrices (denormal P[0][1]) go through unchanged
     P_l, P_r = o["P_l"].copy(), o["P_r"].copy()
