@@ -1127,7 +1127,8 @@ def main():
                     if isinstance(ate_cpu, list) and len(ate_cpu) == ATE_FRAMES:
                         ca = np.array(ate_cpu, np.float64)
                         traj_cpu = integrate_steps([(r[7:11], r[11:14]) for r in ca[1:]])
-                        rec.update({"gpu_vs_cpu_rmse_m": round(ate_rmse(traj_gpu, traj_cpu)[0], 6), "gpu_vs_cpu_max_m": round(ate_rmse(traj_gpu, traj_cpu)[1], 6),
+                        rec.update({"gpu_vs_cpu_rmse_m": float(f"{ate_rmse(traj_gpu, traj_cpu)[0]:.3e}"), "gpu_vs_cpu_max_m": float(f"{ate_rmse(traj_gpu, traj_cpu)[1]:.3e}"),
+                                    "gpu_vs_cpu_gate_m": 1e-3,
                                     "cpu_vs_gt_rmse_m": round(ate_rmse(traj_cpu, traj_gt)[0], 5), "cpu_solver": outcome_stats(ca[1:]),
                                     "accepted_flag_agreement": round(float((ga[1:, 1] == ca[1:, 1]).mean()), 4),
                                     "cpu": "oracle/cpu end to end on its own features (kind: port)"})

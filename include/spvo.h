@@ -312,7 +312,7 @@ int spvo_pnp_refine(spvo_ctx *ctx, const double P_l[12], const double P_r[12],
                     double t[3], spvo_refine_summary *summary);
 
 /* The numeric body of solveStereoOdometry after the correspondence join (base.cpp:209-375) in ONE
- * submission: triangulate -> RANSAC -> gating (base.cpp:241-272) -> residual blocks in the order
+ * submission: triangulate -> RANSAC -> gating (base.cpp:241-272; decided on the host when the results are collected) -> residual blocks in the order
  * of base.cpp:291-356 -> LM refinement -> "not converged => keep the RANSAC pose" (base.cpp:366-374).
  * Identical to calling spvo_triangulate, spvo_pnp_ransac and spvo_pnp_refine in sequence with the
  * host-side glue in between, minus the round trips. */
@@ -329,6 +329,12 @@ typedef struct {
   int refinement_degree;        /* hpp:143                                               */
   spvo_ransac_opts ransac;
   spvo_refine_opts refine;
+  /* Round 6 (both optional, zero = as before): */
+  const int32_t *prev_index;    /* [n] instead of prev_xyz / prev_valid: index of each correspondence's previous-frame point among the
+                                   points the PREVIOUS spvo_solve_submit of this context triangulated (its xyz output, still on the
+                                   device), -1 where there is none (base.cpp:323-332).  The host need not have collected them.   */
+  int late_prior;               /* 1: rvec_pred / tvec_pred / frame_count are not known yet (the previous frame's solve is still in
+                                   flight) -- they are ignored here and handed to spvo_solve_wait_prior instead                  */
 } spvo_solve_input;
 
 typedef struct {
@@ -347,14 +353,23 @@ int spvo_solve_stereo_odometry(spvo_ctx *ctx, const spvo_solve_input *in, spvo_s
 
 /* The same call in two halves, for a caller with something else to do in between (collecting the next pair's detector
  * output, publishing, bookkeeping).  spvo_solve_submit stages the inputs in pinned memory -- the caller's arrays are free
- * again when it returns -- and enqueues the whole chain on the solver's stream; spvo_solve_wait blocks until it is done and
- * hands out what spvo_solve_stereo_odometry would have.  ONE solve may be pending; until it has been waited for, the
- * stand-alone solver entry points (spvo_triangulate, spvo_pnp_ransac, spvo_pnp_refine) and another submit answer
- * SPVO_ERR_STATE.  The next frame's solve needs this one's pose as its prior (hpp:156-157), so the chain of solves itself
- * stays sequential; what overlaps is the host's other work.  The reference has no counterpart: solveStereoOdometry
- * (base.cpp:125-399) is one blocking call. */
+ * again when it returns -- and enqueues the whole chain on the solver's stream; spvo_solve_wait blocks until the OLDEST
+ * pending solve is done and hands out what spvo_solve_stereo_odometry would have.  While a solve is pending the stand-alone
+ * solver entry points (spvo_triangulate, spvo_pnp_ransac, spvo_pnp_refine) answer SPVO_ERR_STATE.
+ *
+ * TWO solves may be pending (round 6).  Nothing the device computes for frame k needs frame k - 1's POSE: the RANSAC's
+ * minimal solver is prior-free (as cv::solvePnPRansac's P3P is, base.cpp:237-239), the refinement starts from the RANSAC
+ * pose, and the one step that does need the motion prior -- the gate, base.cpp:241-272: three subtractions and a compare --
+ * is evaluated by the wait on the host.  What frame k needs of frame k - 1 are its 3-D points (base.cpp:323-332), and
+ * `prev_index` refers to them where they lie.  So a caller may submit frame k (late_prior = 1, prev_index) BEFORE it waits
+ * for frame k - 1, and hands the prior -- known once k - 1 has been collected -- to spvo_solve_wait_prior.  Results are
+ * those of the one-piece call, bit for bit (tests/test_gpu_odometry.py, tests/test_gpu_host.py).  The reference has no
+ * counterpart: solveStereoOdometry (base.cpp:125-399) is one blocking call. */
 int spvo_solve_submit(spvo_ctx *ctx, const spvo_solve_input *in);
 int spvo_solve_wait(spvo_ctx *ctx, spvo_solve_output *out, float *xyz, int32_t *inliers);
+int spvo_solve_wait_prior(spvo_ctx *ctx, const double rvec_pred[3], const double tvec_pred[3], int frame_count,
+                          spvo_solve_output *out, float *xyz, int32_t *inliers);
+int spvo_solve_pending(spvo_ctx *ctx);   /* solves submitted and not waited for yet (0, 1 or 2) */
 
 /* ------------------------------------------------------- multi-GPU: pose gather
  * The path shards by stereo stream: one process per GPU, each with its own FeatureFrontEnd

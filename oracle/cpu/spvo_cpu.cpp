@@ -372,8 +372,10 @@ int pnp_ransac(const double K[9], const float *xyz, const float *xy, int n, int 
   inliers.clear();
   ok = false;
   if (n < 4) return 0;
-  const Quat q0 = rvec_to_quat(rvec);
-  const double t0[3] = {tvec[0], tvec[1], tvec[2]};
+  // prior-free minimal solver (oracle/odometry.py: pnp_ransac): every sample's Newton iteration starts at the identity; rvec / tvec
+  // (the motion prior) are only what stays in place when no model is found
+  const Quat q0{0.0, 0.0, 0.0, 1.0};
+  const double t0[3] = {0.0, 0.0, 0.0};
   int best_count = -1;
   Quat best_q = q0;
   double best_t[3] = {t0[0], t0[1], t0[2]};

@@ -154,7 +154,7 @@ def _apply_delta(q, t, d):
 
 
 def minimal_solve(K, X3, uv3, q0, t0, max_iter=10):
-    """Newton iterations on the 6x6 system of a 3-point sample, from the prior."""
+    """Newton iterations on the 6x6 system of a 3-point sample, from (q0, t0) -- pnp_ransac starts every sample at the identity."""
     q, t = q0.copy(), t0.copy()
     ok = False
     for _ in range(max_iter):
@@ -219,14 +219,19 @@ def pnp_ransac(K, xyz, xy, rvec0, tvec0, iterations=500, reproj_error=2.0, seed=
     X = np.asarray(xyz, np.float32).astype(np.float64).reshape(-1, 3)
     uv = np.asarray(xy, np.float32).astype(np.float64).reshape(-1, 2)
     n = len(X)
-    q0 = rvec_to_quat(rvec0)
     t0 = np.asarray(tvec0, np.float64).reshape(3).copy()
     if n < 4:
         return False, np.asarray(rvec0, float).reshape(3), t0, np.zeros(0, np.int32)
+    # The minimal solver is PRIOR-FREE, as cv::solvePnPRansac's is (base.cpp:237-239: a closed-form P3P per sample; `useExtrinsicGuess` only
+    # seeds the model that is handed back when nothing better is found): every sample's Newton iteration starts at the identity -- "no
+    # motion", the P3P root a frame-to-frame step wants -- so hypotheses, scores, selection and refit of a frame do not depend on the
+    # previous frame's pose (round 6; rounds 1-5 started at the motion prior, which chained every frame's RANSAC to the solve before it).
+    # The prior (rvec0, tvec0) is what comes back when no model is found.
+    q_id, t_id = np.array([0.0, 0.0, 0.0, 1.0]), np.zeros(3)
     best = (-1, None, None, None)
     for it in range(iterations):
         s = sample_triplet(seed, it, n)
-        ok, q, t = minimal_solve(K, X[s], uv[s], q0, t0)
+        ok, q, t = minimal_solve(K, X[s], uv[s], q_id, t_id)
         if not ok:
             continue
         mask = reproj_inliers(K, q, t, X, uv, reproj_error)

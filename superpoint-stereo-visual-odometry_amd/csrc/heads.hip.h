@@ -29,6 +29,13 @@
 // above); two 5-wave workgroups per CU: 168 registers per lane, the compiler spills the epilogue's addresses and every reload between
 // two stores waits for the stores before it (50 / 83).
 // The two branches may read one tensor (VGG plan: channels 0..255 / 256..511 of the merged convPa + convDa output) or two.
+//
+// FP16 engines (round 6): the same kernel with F16 = true runs the products on v_mfma_f32_16x16x16_f16 -- a lane's four k-steps of a
+// group are four CONSECUTIVE input channels, which is that instruction's operand (four halves per lane, k = 4 (lane >> 4) + i), so ONE
+// matrix instruction replaces the four fp32 ones of a group; the weights are packed as fp16 (they were fp16-rounded values stored as
+// fp32 before: half the bytes per fetch), the loader moves the C8 activations into LDS as they are (8 bytes per lane instead of 16, no
+// conversion), accumulation, bias, norms and stores stay fp32.  Rounds 4-5 converted to fp32 and used the fp32 instruction: 22.7 us at
+// 192 x 640, the longest launch of config 3's forward pass, at 0.011 of the fp16 peak the engine is entitled to.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -66,8 +73,11 @@ constexpr int HEADS_LDS_BYTES = (2 * HEADS_CHUNK_FLOATS + HEADS_SRED_FLOATS) * 4
 // packer rounds them (biases stay fp32), and the lane's four k-steps are four CONSECUTIVE input channels -- 16 s4 + 4 (l >> 4) + e --
 // so that the loader's lane fetches them as one 8-byte piece of a C8 group.
 inline std::vector<float> pack_heads_weights(const float *w_det, const float *b_det, int cout_det, const float *w_desc, const float *b_desc, bool f16 = false) {
-  std::vector<float> out((size_t)HEADS_UNITS * 16 * 64 * 4 + HEADS_UNITS * 16, 0.f);
-  float *bias = out.data() + (size_t)HEADS_UNITS * 16 * 64 * 4;
+  // f16: [unit 21][s4 16][lane 64][4 halves] = two floats' worth of bits per lane, then the biases (fp32)
+  const size_t per_lane = f16 ? 2 : 4;
+  std::vector<float> out((size_t)HEADS_UNITS * 16 * 64 * per_lane + HEADS_UNITS * 16, 0.f);
+  float *bias = out.data() + (size_t)HEADS_UNITS * 16 * 64 * per_lane;
+  _Float16 *out_h = reinterpret_cast<_Float16 *>(out.data());
   for (int u = 0; u < HEADS_UNITS; ++u)
     for (int o = 0; o < 16; ++o) {
       const bool det = u < HEADS_DET_UNITS;
@@ -77,13 +87,23 @@ inline std::vector<float> pack_heads_weights(const float *w_det, const float *b_
       bias[16 * u + o] = det ? b_det[co] : b_desc[co];
       for (int ci = 0; ci < HEADS_CIN; ++ci) {
         const int s4 = ci >> 4, e = f16 ? ci & 3 : (ci >> 2) & 3, lane = 16 * (f16 ? (ci >> 2) & 3 : ci & 3) + o;
-        out[(((size_t)u * 16 + s4) * 64 + lane) * 4 + e] = f16 ? (float)(_Float16)w[ci] : w[ci];
+        const size_t at = (((size_t)u * 16 + s4) * 64 + lane) * 4 + e;
+        if (f16) out_h[at] = (_Float16)w[ci];
+        else out[at] = w[ci];
       }
     }
   return out;
 }
 
 typedef float heads_f4 __attribute__((ext_vector_type(4)));
+typedef _Float16 heads_h4 __attribute__((ext_vector_type(4)));
+template <bool F16> struct HeadsOperand { typedef heads_f4 T; };       // one lane's operand of a group of four k-steps: four floats ...
+template <> struct HeadsOperand<true> { typedef heads_h4 T; };          // ... or four halves (FP16 engines)
+template <bool F16> __device__ __forceinline__ typename HeadsOperand<F16>::T heads_abl_operand() {   // (HEADS_ABL & 2: constants instead of weight fetches)
+  typename HeadsOperand<F16>::T v;
+  v[0] = 1; v[1] = 2; v[2] = 3; v[3] = 4;
+  return v;
+}
 
 struct HeadsPix { int f[2], img[2]; size_t opix[2]; };   // the lane's pixel in the step's two tiles: flat index, image, offset in a padded plane
 
@@ -105,39 +125,51 @@ __device__ __forceinline__ HeadsPix heads_pix(const HeadsArgs &a, int t, int lan
 // computes, two bits per slot (bit 0: tile 0, bit 1: tile 1); slot s = unit u0 + s.  W0: slots 0..4 are detector units (wave 0), slot 5
 // and every slot of the other waves descriptor units.  `wa` holds the weights of the chunk's first group on entry and those of the
 // next chunk's first group on exit (LAST: nothing is fetched behind the step's last group).
-template <unsigned HM, bool W0>
-__device__ __forceinline__ void heads_wave_chunk(const HeadsArgs &a, const float *sx, const int u0, const int lane, const int c, heads_f4 (&acc)[6][2], heads_f4 (&wa)[6]) {
+template <unsigned HM, bool W0, bool F16>
+__device__ __forceinline__ void heads_wave_chunk(const HeadsArgs &a, const float *sx, const int u0, const int lane, const int c, heads_f4 (&acc)[6][2],
+                                                 typename HeadsOperand<F16>::T (&wa)[6]) {
+  typedef typename HeadsOperand<F16>::T op_t;
   constexpr auto hm = [](int s) { return (HM >> (2 * s)) & 3u; };
   constexpr unsigned any = hm(0) | hm(1) | hm(2) | hm(3) | hm(4) | hm(5);
   constexpr unsigned any_desc = W0 ? hm(5) : any;
-  const heads_f4 *wp4 = reinterpret_cast<const heads_f4 *>(a.wpack) + (size_t)u0 * 16 * 64 + lane;   // slot s, group s4: + (s * 16 + s4) * 64
-  const heads_f4 *xb4 = reinterpret_cast<const heads_f4 *>(sx) + lane;                               // [head][s4 of the chunk][tile]: + ((head * 4 + s4l) * 2 + tile) * 64
-  heads_f4 wb[6], ba[4], bb[4];   // activations: detector tile 0 / 1, descriptor tile 0 / 1
-  auto load_w = [&](heads_f4 (&wv)[6], int s4) {
+  const op_t *wp4 = reinterpret_cast<const op_t *>(a.wpack) + (size_t)u0 * 16 * 64 + lane;   // slot s, group s4: + (s * 16 + s4) * 64
+  const op_t *xb4 = reinterpret_cast<const op_t *>(sx) + lane;                               // [head][s4 of the chunk][tile]: + ((head * 4 + s4l) * 2 + tile) * 64
+  op_t wb[6], ba[4], bb[4];   // activations: detector tile 0 / 1, descriptor tile 0 / 1
+  auto load_w = [&](op_t (&wv)[6], int s4) {
 #pragma unroll
     for (int s = 0; s < 6; ++s)
-      if (hm(s)) wv[s] = (HEADS_ABL & 2) ? heads_f4{1.f, 2.f, 3.f, 4.f} : wp4[(s * 16 + s4) * 64];
+      if (hm(s)) wv[s] = (HEADS_ABL & 2) ? heads_abl_operand<F16>() : wp4[(s * 16 + s4) * 64];
   };
-  auto load_b = [&](heads_f4 (&bv)[4], int s4l) {
+  auto load_b = [&](op_t (&bv)[4], int s4l) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (W0 && (any >> h & 1)) bv[h] = xb4[((0 * 4 + s4l) * 2 + h) * 64];
       if (any_desc >> h & 1) bv[2 + h] = xb4[((1 * 4 + s4l) * 2 + h) * 64];
     }
   };
-  auto mfmas = [&](const heads_f4 (&wv)[6], const heads_f4 (&bv)[4]) {
+  auto mfmas = [&](const op_t (&wv)[6], const op_t (&bv)[4]) {
 #pragma unroll
-    for (int s = 0; s < 6; ++s)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
+    for (int s = 0; s < 6; ++s) {
+      // descriptor units D[co][px]: a lane ends up with four consecutive CHANNELS of its pixel (the [256] rows); detector units with
+      // the operands swapped, D[px][co]: four consecutive PIXELS of its channel (the planes) -- 16-byte stores both
+      if constexpr (F16) {   // the group's four k-steps in ONE instruction: k = 4 (lane >> 4) + i
 #pragma unroll
         for (int h = 0; h < 2; ++h)
           if (hm(s) >> h & 1) {
-            // descriptor units D[co][px]: a lane ends up with four consecutive CHANNELS of its pixel (the [256] rows); detector units with
-            // the operands swapped, D[px][co]: four consecutive PIXELS of its channel (the planes) -- 16-byte stores both
-            if (W0 && s < 5) acc[s][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[h][e], wv[s][e], acc[s][h], 0, 0, 0);
-            else acc[s][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s][e], bv[2 + h][e], acc[s][h], 0, 0, 0);
+            if (W0 && s < 5) acc[s][h] = __builtin_amdgcn_mfma_f32_16x16x16f16(bv[h], wv[s], acc[s][h], 0, 0, 0);
+            else acc[s][h] = __builtin_amdgcn_mfma_f32_16x16x16f16(wv[s], bv[2 + h], acc[s][h], 0, 0, 0);
           }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            if (hm(s) >> h & 1) {
+              if (W0 && s < 5) acc[s][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[h][e], wv[s][e], acc[s][h], 0, 0, 0);
+              else acc[s][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s][e], bv[2 + h][e], acc[s][h], 0, 0, 0);
+            }
+      }
+    }
   };
   // (the fences keep every fetch where it is written: one group of weights and activations in flight under the group being
   // multiplied -- the scheduler otherwise hoists all of a step's fetches to its top and spills)
@@ -167,11 +199,11 @@ __device__ __forceinline__ void heads_wave_chunk(const HeadsArgs &a, const float
 // pixel (read behind the next barrier).  Per UNIT, not per wave: which wave owns a unit depends on the step (two tiles or one, first
 // or second tile), and a pixel's result must not depend on where its tile falls in the launch -- one image alone, in a pair, or in a
 // group of four give bit-identical descriptors (tests/test_gpu_network.py, test_trunk_pairing_does_not_change_results)
-template <unsigned HM, bool W0>
+template <unsigned HM, bool W0, bool F16>
 __device__ __forceinline__ void heads_wave_norms(const HeadsArgs &a, float *sred, const int u0, const int lane, heads_f4 (&acc)[6][2]) {
   constexpr auto hm = [](int s) { return (HM >> (2 * s)) & 3u; };
   const int px = lane & 15, kk = lane >> 4;
-  const float *bias = a.wpack + (size_t)HEADS_UNITS * 16 * 64 * 4;
+  const float *bias = a.wpack + (size_t)HEADS_UNITS * 16 * 64 * (F16 ? 2 : 4);
 #pragma unroll
   for (int s = 0; s < 6; ++s) {
     if (!hm(s) || (W0 && s < 5)) continue;
@@ -194,7 +226,7 @@ __device__ __forceinline__ void heads_wave_norms(const HeadsArgs &a, float *sred
 }
 
 // ... behind that barrier: detector planes, normalisation, descriptor rows
-template <unsigned HM, bool W0>
+template <unsigned HM, bool W0, bool F16>
 __device__ __forceinline__ void heads_wave_finish(const HeadsArgs &a, const float *sred, const int u0, const int lane, const int npx, const int t,
                                                   const heads_f4 (&acc)[6][2]) {
   const int hw = a.H * a.W;
@@ -206,7 +238,7 @@ __device__ __forceinline__ void heads_wave_finish(const HeadsArgs &a, const floa
   // (opaque per step: the compiler otherwise hoists the ~100 channel indices and plane offsets of this phase out of the step loop as 64-bit
   // values and SPILLS them -- and a reload between two global stores waits, vmcnt being in order, for every store before it)
   asm volatile("" : "+v"(kk), "+s"(plane_i));
-  const float *bias = a.wpack + (size_t)HEADS_UNITS * 16 * 64 * 4;
+  const float *bias = a.wpack + (size_t)HEADS_UNITS * 16 * 64 * (F16 ? 2 : 4);
   const size_t plane = (size_t)plane_i;
   // register r of a unit: output channel 16 u + 4 kk + r, the lane's pixel px of tile h.
   // Every load of this phase goes out BEFORE its first store: vmcnt counts loads and stores in order, so a load's data is only there
@@ -319,7 +351,6 @@ constexpr unsigned HEADS_A1 = heads_hm(1, 1, 1, 1, 1, 1), HEADS_B1 = heads_hm(0,
 template <bool F16IN>
 struct HeadsLoader {
   typedef unsigned heads_u2 __attribute__((ext_vector_type(2)));
-  typedef _Float16 heads_h4 __attribute__((ext_vector_type(4)));
   const float *src[2][2];   // [tile][branch]: this lane's pixel, channel lane >> 4 (F16IN: channels 4 (lane >> 4) .. + 3 of the branch's first C8 groups)
   size_t plane;
   int lane, nh;
@@ -369,14 +400,12 @@ struct HeadsLoader {
       for (int head = 0; head < 2; ++head)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          heads_f4 val;
-          if constexpr (F16IN) {
-            const heads_h4 h4 = __builtin_bit_cast(heads_h4, hv[v][head * 2 + i]);
-            val = heads_f4{(float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]};
+          const size_t slot = (size_t)((head * 4 + 2 * i + (v >> 1)) * 2 + (v & 1)) * 64 + lane;   // operand order: [head][s4 of the chunk][tile][lane]
+          if constexpr (F16IN) {   // four halves = the f16 matrix instruction's operand, as they come
+            reinterpret_cast<heads_u2 *>(sx)[slot] = ok[v & 1] ? hv[v][head * 2 + i] : heads_u2{0u, 0u};
           } else {
-            val = sv[v][head * 2 + i];
+            reinterpret_cast<heads_f4 *>(sx)[slot] = ok[v & 1] ? sv[v][head * 2 + i] : heads_f4{0.f, 0.f, 0.f, 0.f};
           }
-          *reinterpret_cast<heads_f4 *>(sx + ((size_t)((head * 4 + 2 * i + (v >> 1)) * 2 + (v & 1)) * 64 + lane) * 4) = ok[v & 1] ? val : heads_f4{0.f, 0.f, 0.f, 0.f};
         }
     }
   }
@@ -388,16 +417,18 @@ __device__ __forceinline__ void heads_barrier() { asm volatile("s_waitcnt lgkmcn
 // One step of one computing wave: four chunks, the results.  Every wave of the workgroup passes the same barriers -- one per chunk --
 // each in its own instantiation (the branch that selects it is wave-uniform); the loader's are in the kernel body.
 // the weights of a step's first group of four k-steps, for every unit slot of the wave that exists
-__device__ __forceinline__ void heads_first_weights(const HeadsArgs &a, const int u0, const int lane, heads_f4 (&wa)[6]) {
-  const heads_f4 *wp4 = reinterpret_cast<const heads_f4 *>(a.wpack) + (size_t)u0 * 16 * 64 + lane;
+template <bool F16>
+__device__ __forceinline__ void heads_first_weights(const HeadsArgs &a, const int u0, const int lane, typename HeadsOperand<F16>::T (&wa)[6]) {
+  typedef typename HeadsOperand<F16>::T op_t;
+  const op_t *wp4 = reinterpret_cast<const op_t *>(a.wpack) + (size_t)u0 * 16 * 64 + lane;
 #pragma unroll
   for (int s = 0; s < 6; ++s)
-    if (u0 + s < HEADS_UNITS) wa[s] = (HEADS_ABL & 2) ? heads_f4{1.f, 2.f, 3.f, 4.f} : wp4[(s * 16) * 64];
+    if (u0 + s < HEADS_UNITS) wa[s] = (HEADS_ABL & 2) ? heads_abl_operand<F16>() : wp4[(s * 16) * 64];
 }
 
-template <unsigned HM, bool W0>
+template <unsigned HM, bool W0, bool F16>
 __device__ __forceinline__ void heads_wave_step(const HeadsArgs &a, float *smem, int &buf, const int u0, const int lane, const int w, const int t, const int npx,
-                                                const bool more, heads_f4 (&wa)[6]) {
+                                                const bool more, typename HeadsOperand<F16>::T (&wa)[6]) {
   float *sred = smem + 2 * HEADS_CHUNK_FLOATS;
   heads_f4 acc[6][2];
 #pragma unroll
@@ -406,19 +437,19 @@ __device__ __forceinline__ void heads_wave_step(const HeadsArgs &a, float *smem,
     for (int h = 0; h < 2; ++h) acc[s][h] = heads_f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
   for (int c = 0; c < 4; ++c) {
-    heads_wave_chunk<HM, W0>(a, smem + buf * HEADS_CHUNK_FLOATS, u0, lane, c, acc, wa);
-    if (c == 3) heads_wave_norms<HM, W0>(a, sred, u0, lane, acc);
+    heads_wave_chunk<HM, W0, F16>(a, smem + buf * HEADS_CHUNK_FLOATS, u0, lane, c, acc, wa);
+    if (c == 3) heads_wave_norms<HM, W0, F16>(a, sred, u0, lane, acc);
     heads_barrier();   // the buffer just read may be refilled, the other one may be read, the partial norms are complete
     buf ^= 1;
   }
-  if (more) heads_first_weights(a, u0, lane, wa);   // the next step's first weights: in front of this step's stores (vmcnt is in order)
-  heads_wave_finish<HM, W0>(a, sred, u0, lane, npx, t, acc);
+  if (more) heads_first_weights<F16>(a, u0, lane, wa);   // the next step's first weights: in front of this step's stores (vmcnt is in order)
+  heads_wave_finish<HM, W0, F16>(a, sred, u0, lane, npx, t, acc);
   // (the next step's partial norms are written three barriers from here: `sred` is free by then)
 }
 
 constexpr int HEADS_THREADS = 320;   // four computing waves + the loader
 
-template <bool F16IN = false>   // F16IN: the activations are C8 fp16 (FP16 engines); everything behind the loader is the same fp32 arithmetic
+template <bool F16IN = false>   // F16IN: the activations are C8 fp16 (FP16 engines): products on the f16 matrix instruction, fp32 accumulation and epilogue (the chunk buffers are then half full)
 __global__ __launch_bounds__(HEADS_THREADS) void heads_fused_kernel(const HeadsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // two chunk buffers, then [wave 4][tile 2][px 16] partial squared norms
   const int tid = threadIdx.x, lane = tid & 63;
@@ -452,21 +483,21 @@ __global__ __launch_bounds__(HEADS_THREADS) void heads_fused_kernel(const HeadsA
     return;
   }
   const int u0 = w == 0 ? 0 : w == 1 ? 5 : w == 2 ? 11 : 16;
-  heads_f4 wa[6];
-  heads_first_weights(a, u0, lane, wa);
+  typename HeadsOperand<F16IN>::T wa[6];
+  heads_first_weights<F16IN>(a, u0, lane, wa);
   heads_barrier();   // the first chunk is in LDS
   for (int t = tb; t < te; t += 2) {
     const int nh = te - t >= 2 ? 2 : 1;
     const bool more = t + 2 < te;
     // the instantiation that owns this wave's (tile, unit) pairs: wave-uniform branch
     if (nh == 2) {
-      if (w == 0) heads_wave_step<HEADS_A2, true>(a, smem, buf, u0, lane, w, t, npx, more, wa);
-      else if (w == 1) heads_wave_step<HEADS_B2, false>(a, smem, buf, u0, lane, w, t, npx, more, wa);
-      else heads_wave_step<HEADS_C2, false>(a, smem, buf, u0, lane, w, t, npx, more, wa);
+      if (w == 0) heads_wave_step<HEADS_A2, true, F16IN>(a, smem, buf, u0, lane, w, t, npx, more, wa);
+      else if (w == 1) heads_wave_step<HEADS_B2, false, F16IN>(a, smem, buf, u0, lane, w, t, npx, more, wa);
+      else heads_wave_step<HEADS_C2, false, F16IN>(a, smem, buf, u0, lane, w, t, npx, more, wa);
     } else {
-      if (w == 0) heads_wave_step<HEADS_A1, true>(a, smem, buf, u0, lane, w, t, npx, more, wa);
-      else if (w == 1) heads_wave_step<HEADS_B1, false>(a, smem, buf, u0, lane, w, t, npx, more, wa);
-      else heads_wave_step<HEADS_C1, false>(a, smem, buf, u0, lane, w, t, npx, more, wa);
+      if (w == 0) heads_wave_step<HEADS_A1, true, F16IN>(a, smem, buf, u0, lane, w, t, npx, more, wa);
+      else if (w == 1) heads_wave_step<HEADS_B1, false, F16IN>(a, smem, buf, u0, lane, w, t, npx, more, wa);
+      else heads_wave_step<HEADS_C1, false, F16IN>(a, smem, buf, u0, lane, w, t, npx, more, wa);
     }
   }
 }

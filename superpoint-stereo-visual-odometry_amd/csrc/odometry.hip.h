@@ -342,9 +342,11 @@ __global__ __launch_bounds__(64) void ransac_hypothesis_kernel(const double *__r
   const int pi = my_pt == 0 ? idx[0] : my_pt == 1 ? idx[1] : idx[2];
   const double X3[3] = {xyz[3 * pi], xyz[3 * pi + 1], xyz[3 * pi + 2]};
   const double uv3[2] = {xy[2 * pi], xy[2 * pi + 1]};
-  double sh[7];   // q (xyzw), t: identical in every lane
-  rvec_to_quat(prior, sh);
-  sh[4] = prior[3]; sh[5] = prior[4]; sh[6] = prior[5];
+  // q (xyzw), t: identical in every lane.  PRIOR-FREE (round 6): the Newton iteration of every sample starts at the identity, as
+  // cv::solvePnPRansac's closed-form minimal solver needs no guess either (base.cpp:237-239) -- a frame's hypotheses no longer depend
+  // on the previous frame's pose, so its whole RANSAC can run before that pose exists (oracle/odometry.py: pnp_ransac)
+  (void)prior;
+  double sh[7] = {0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0};
   bool ok = false, bad = false;
   auto wave_max6 = [&](double v) {   // max over lanes 0..5, in every lane
     double m = 0;
@@ -840,17 +842,21 @@ __global__ __launch_bounds__(NT) void pnp_refine_kernel(const double *__restrict
 }
 
 // ------------------------------------------------------------------------- fused solve glue
-// Gating (base.cpp:241-272), rvec -> quaternion (base.cpp:274-280) and the residual-block list in
-// the order base.cpp:291-356 adds it, all on the device so that triangulation, RANSAC and the
-// refinement run back to back.  One workgroup.
-//   hdr (doubles): [0..11] P_l, [12..23] P_r, [24..32] K, [33..38] prior rvec,tvec,
-//                  [39] frame_count, [40] refinement_degree, [41] max_acceleration, [42] time_interval,
-//                  [43] ignore_frame_count
-//   gate_out (doubles): [0..6] start q,t   [7] do_optmz   [8] pnp_ok   [9] accepted rvec/tvec follow in [10..15]
+// rvec -> quaternion (base.cpp:274-280) and the residual-block list in the order base.cpp:291-356 adds it, on the device so that
+// triangulation, RANSAC and the refinement run back to back.  One workgroup.
+// The GATE (base.cpp:241-272: keep the prediction when solvePnPRansac failed, or when frame_count > IGNORE_FRAME_COUNT and the
+// acceleration is too large) is NOT decided here since round 6: it is the only step of a frame's solve that needs the previous frame's
+// pose, it costs three subtractions, and the host evaluates it in spvo_solve_wait from the prior it holds by then.  The device goes on
+// as if the gate accepts whenever RANSAC found a model -- refinement included, which starts from the RANSAC pose, never from the prior --
+// and the host discards what a rejecting gate makes void.  So a frame's whole chain can be enqueued before the previous frame's has been
+// collected (spvo_solve_submit with `late_prior`).
+//   hdr (doubles): [0..11] P_l, [12..23] P_r, [24..32] K, [33..38] prior rvec,tvec (unused on the device), [40] refinement_degree
+//   gate_out (doubles): [0..6] start q,t = the RANSAC pose   [7] refinement enqueued (= pnp_ok)   [8] pnp_ok   [10..15] RANSAC rvec, tvec
 template <int NT>
 __device__ __forceinline__ void solve_gate_build_body(const double *hdr, const double *ransac_result, const int *inliers, const float *xyz,
                                                       const float *xy_cl, const float *xy_cr, const float *xy_pl, const float *xy_pr,
-                                                      const float *prev_xyz, const int *prev_valid, ObsDev *obs, int *ctl, double *gate_out) {
+                                                      const float *prev_xyz, const int *prev_valid, const int *prev_index, const float *prev_pts,
+                                                      ObsDev *obs, int *ctl, double *gate_out) {
   __shared__ int s_scan[NT];
   __shared__ int s_run, s_base;
   const int tid = threadIdx.x;
@@ -859,15 +865,8 @@ __device__ __forceinline__ void solve_gate_build_body(const double *hdr, const d
   if (tid == 0) {
     const bool ok = ransac_result[6] != 0;
     double r[3], t[3];
-    for (int k = 0; k < 3; ++k) { r[k] = ransac_result[k]; t[k] = ransac_result[3 + k]; }
-    const double dx = t[0] - hdr[36], dy = t[1] - hdr[37], dz = t[2] - hdr[38];
-    const double acc = sqrt(dx * dx + dy * dy + dz * dz) / hdr[42];
-    int do_opt = 0;
-    if (!ok || ((int)hdr[39] > (int)hdr[43] && acc > hdr[41])) {
-      for (int k = 0; k < 3; ++k) { r[k] = hdr[33 + k]; t[k] = hdr[36 + k]; }
-    } else {
-      do_opt = 1;
-    }
+    for (int k = 0; k < 3; ++k) { r[k] = ransac_result[k]; t[k] = ransac_result[3 + k]; }   // (no model: the host substitutes its prior)
+    const int do_opt = ok ? 1 : 0;                                                            // the gate itself: spvo_solve_wait (host)
     double q[4];
     rvec_to_quat(r, q);
     for (int k = 0; k < 4; ++k) gate_out[k] = q[k];
@@ -885,7 +884,9 @@ __device__ __forceinline__ void solve_gate_build_body(const double *hdr, const d
       int vi = 0, cnt = 0, pv = 0;
       if (k < ninl) {
         vi = inliers[k];
-        pv = (prev_xyz && prev_valid) ? (prev_valid[vi] != 0) : 0;
+        // previous-frame 3-D point of the correspondence (base.cpp:323-332): handed in by value (prev_xyz / prev_valid), or as an index
+        // into the points the PREVIOUS solve of this context triangulated -- they are still on the device, the host need not have seen them
+        pv = prev_index ? (prev_index[vi] >= 0) : ((prev_xyz && prev_valid) ? (prev_valid[vi] != 0) : 0);
         cnt = 1 + (degree >= 2 ? 1 : 0) + (pv ? ((degree >= 3 ? 1 : 0) + (degree >= 4 ? 1 : 0)) : 0);
       }
       s_scan[tid] = cnt;
@@ -907,8 +908,9 @@ __device__ __forceinline__ void solve_gate_build_body(const double *hdr, const d
         };
         put(xyz + 3 * vi, xy_pl + 2 * vi, 0, 0);
         if (degree >= 2) put(xyz + 3 * vi, xy_pr + 2 * vi, 1, 0);
-        if (pv && degree >= 3) put(prev_xyz + 3 * vi, xy_cl + 2 * vi, 0, 1);
-        if (pv && degree >= 4) put(prev_xyz + 3 * vi, xy_cr + 2 * vi, 1, 1);
+        const float *Xp = pv ? (prev_index ? prev_pts + 3 * prev_index[vi] : prev_xyz + 3 * vi) : nullptr;
+        if (pv && degree >= 3) put(Xp, xy_cl + 2 * vi, 0, 1);
+        if (pv && degree >= 4) put(Xp, xy_cr + 2 * vi, 1, 1);
       }
       __syncthreads();
       if (tid == NT - 1) s_base += s_scan[NT - 1];
@@ -923,13 +925,15 @@ __device__ __forceinline__ void solve_gate_build_body(const double *hdr, const d
 
 // The fused solve's TAIL: everything behind the hypotheses in ONE launch of one workgroup -- selection + refit (K15), gating and the
 // residual-block list, the Levenberg-Marquardt loop (K16), then the results into the call's pinned host buffers.  Three dependent launches
-// were three times the wait for a CU beside the other streams' kernels (the chain's latency is the cycle time of the small engines' frame
-// loop: a frame's solve needs the previous frame's pose).  The phases hand their results over through global memory exactly as the
+// were three times the wait for a CU beside the other streams' kernels (rounds 1-5: the chain's latency was the cycle time of the small
+// engines' frame loop; since round 6 nothing in it needs the previous frame's pose and two frames' chains may be in flight).  The phases hand their results over through global memory exactly as the
 // separate kernels do; __syncthreads() between them orders those writes within the workgroup.
 struct SolveTailArgs {
   const double *hdr;           // the call's header (device copy): P_l, P_r, K [24..32], prior [33..38], ...
   const float *xyz, *xy_cl, *xy_cr, *xy_pl, *xy_pr, *prev_xyz;
   const int *prev_valid;
+  const int *prev_index;       // or: index of each correspondence's previous-frame point in `prev_pts` (-1: none) ...
+  const float *prev_pts;       // ... the points the previous solve of this context triangulated (its output block on the device)
   int n, iterations;
   double thr2;
   RansacWork w;                // result = the 40-double result block, inliers = behind the points in the output block
@@ -949,7 +953,7 @@ __global__ __launch_bounds__(SOLVE_TAIL_THREADS) void solve_tail_kernel(const So
   ransac_select_body<NT>(a.hdr + 24, a.xyz, a.xy_pl, a.n, a.hdr + 33, a.iterations, a.thr2, a.w);
   __threadfence_block();
   __syncthreads();
-  solve_gate_build_body<NT>(a.hdr, a.res, a.w.inliers, a.xyz, a.xy_cl, a.xy_cr, a.xy_pl, a.xy_pr, a.prev_xyz, a.prev_valid, a.obs, a.ctl, a.res + 8);
+  solve_gate_build_body<NT>(a.hdr, a.res, a.w.inliers, a.xyz, a.xy_cl, a.xy_cr, a.xy_pl, a.xy_pr, a.prev_xyz, a.prev_valid, a.prev_index, a.prev_pts, a.obs, a.ctl, a.res + 8);
   __threadfence_block();
   __syncthreads();
   pnp_refine_body<NT>(a.hdr, a.hdr + 12, a.obs, 0, a.ctl, a.res + 8, a.max_iterations, a.huber_delta, reinterpret_cast<RefineOut *>(a.res + 24));

@@ -39,7 +39,7 @@ int stage_id(spvo_ctx *c, const std::string &name) {
 // ---- diagnostic switches (include/spvo.h: spvo_set_tuning).  One process-wide table, filled by explicit calls only.
 namespace {
 const char *const kTuningNames[] = {"winograd", "wino4", "wino_narrow", "wino_dynamic", "winograd_min_tiles", "wino4_min_tiles", "merge_siblings", "heads_fused",
-                                    "heads_on_net", "heads_split", "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing", "nms_first", "upload_side", "inject_launch_failure", "int8_fused", "pair_always", "preprocess_fused", "heads_keep_raw", "tail_streams"};
+                                    "heads_on_net", "heads_split", "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing", "nms_first", "upload_side", "inject_launch_failure", "int8_fused", "pair_always", "preprocess_fused", "heads_keep_raw", "tail_streams", "solve_collect_first"};
 constexpr int kTuningCount = sizeof kTuningNames / sizeof kTuningNames[0];
 std::mutex g_tuning_mutex;
 bool g_tuning_set[kTuningCount] = {};
@@ -291,7 +291,7 @@ void spvo_destroy(spvo_ctx *c) {
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   if (c->stream_t) (void)hipStreamSynchronize(c->stream_t);
   if (c->stream_tb) (void)hipStreamSynchronize(c->stream_tb);
-  if (c->ev_solve) (void)hipEventDestroy(c->ev_solve);
+  for (hipEvent_t e : c->ev_solve) if (e) (void)hipEventDestroy(e);
   if (c->ev_post) (void)hipEventDestroy(c->ev_post);
   if (c->ev_post_b) (void)hipEventDestroy(c->ev_post_b);
   for (int r = 0; r < RING; ++r) if (c->ev_heads[r]) (void)hipEventDestroy(c->ev_heads[r]);
@@ -330,8 +330,11 @@ void spvo_destroy(spvo_ctx *c) {
     void *q[] = {c->slots[i].d_xy, c->slots[i].d_xyf, c->slots[i].d_desc, c->slots[i].d_n, c->slots[i].d_sqn};
     for (void *p : q) if (p) (void)hipFree(p);
   }
-  for (void *hp : {(void *)c->h_solve_in, (void *)c->h_solve_res, (void *)c->h_solve_o}) if (hp) (void)hipHostFree(hp);
-  for (void *dp : {(void *)c->d_solve_in, (void *)c->d_solve_res, (void *)c->d_solve_o, (void *)c->d_ctl}) if (dp) (void)hipFree(dp);
+  for (int sl = 0; sl < spvo_ctx::SOLVE_SLOTS; ++sl) {
+    for (void *hp : {(void *)c->h_solve_in[sl], (void *)c->h_solve_res[sl], (void *)c->h_solve_o[sl]}) if (hp) (void)hipHostFree(hp);
+    for (void *dp : {(void *)c->d_solve_in[sl], (void *)c->d_solve_res[sl], (void *)c->d_solve_o[sl]}) if (dp) (void)hipFree(dp);
+  }
+  if (c->d_ctl) (void)hipFree(c->d_ctl);
   for (void *dp : {(void *)c->d_ham_a, (void *)c->d_ham_b, (void *)c->d_ham_idx, (void *)c->d_ham_dist, (void *)c->d_ham_vote}) if (dp) (void)hipFree(dp);
   for (void *dp : {(void *)c->orb.im, (void *)c->orb.score, (void *)c->orb.blur, (void *)c->orb.src, (void *)c->orb.tmp, (void *)c->orb.pattern, (void *)c->orb.taps, (void *)c->orb.keys,
                    (void *)c->orb.rank, (void *)c->orb.out_xy, (void *)c->orb.counters, (void *)c->orb.tab, (void *)c->orb.disc, (void *)c->orb.kps, (void *)c->orb.desc})

@@ -282,13 +282,18 @@ struct spvo_ctx {
   int *d_ham_idx = nullptr;
   float *d_ham_dist = nullptr;
   unsigned long long *d_ham_vote = nullptr;
-  // fused solve: one packed input, one packed result
-  struct SolvePending { bool active = false; int n = 0, refinement_degree = 0; double rvec[3] = {0, 0, 0}, tvec[3] = {0, 0, 0}; } solve_pending;   // spvo_solve_submit .. _wait
-  hipEvent_t ev_solve = nullptr;
+  // fused solve: one packed input, one packed result -- per SLOT: two solves may be in flight (spvo_solve_submit .. _wait), a frame's chain
+  // enqueued before the previous frame's has been collected; slots alternate, so the previous solve's points (prev_index) sit in the other one
+  static constexpr int SOLVE_SLOTS = 2;
+  struct SolvePending { int n = 0, refinement_degree = 0, slot = 0, frame_count = 0; bool late = false; double rvec[3] = {0, 0, 0}, tvec[3] = {0, 0, 0}; };
+  std::deque<SolvePending> solve_q;     // oldest first, at most SOLVE_SLOTS
+  int solve_next_slot = 0;
+  int solve_last_slot = -1, solve_last_n = 0;   // the most recent submission: where its triangulated points are and how many
+  hipEvent_t ev_solve[SOLVE_SLOTS] = {};
   int solve_cap = 0;
-  char *d_solve_in = nullptr, *h_solve_in = nullptr;    // 64 doubles + 12*cap words
-  double *d_solve_res = nullptr, *h_solve_res = nullptr;  // ransac[8] gate[16] refine[12] + pad
-  char *d_solve_o = nullptr, *h_solve_o = nullptr;      // xyz [3n] floats, inliers [n] ints
+  char *d_solve_in[SOLVE_SLOTS] = {}, *h_solve_in[SOLVE_SLOTS] = {};      // 64 doubles + 12*cap words
+  double *d_solve_res[SOLVE_SLOTS] = {}, *h_solve_res[SOLVE_SLOTS] = {};  // ransac[8] gate[16] refine[12] + pad
+  char *d_solve_o[SOLVE_SLOTS] = {}, *h_solve_o[SOLVE_SLOTS] = {};        // xyz [3n] floats, inliers [n] ints
   int *d_ctl = nullptr;
 
   // profiling

@@ -127,13 +127,16 @@ void FeatureFrontEnd::preprocessImageImpl(cv::Mat &img, cv::Mat &projection_matr
 
 // ------------------------------------------------------------------------- base.cpp:35-66
 void FeatureFrontEnd::clearLagecyData() {
-  if (solve_pending_ && ctx_) {   // a solve handed over and never collected: complete it, its result is dropped with the rest
+  while (!solve_q_.empty() && ctx_) {   // solves handed over and never collected: complete them, their results are dropped with the rest
     spvo_solve_output so;
-    std::vector<float> xyz((size_t)std::max(solve_n_, 1) * 3);
-    std::vector<int32_t> inl(std::max(solve_n_, 1));
-    (void)spvo_solve_wait(ctx_, &so, xyz.data(), inl.data());
+    std::vector<float> xyz((size_t)std::max(solve_q_.front().n, 1) * 3);
+    std::vector<int32_t> inl(std::max(solve_q_.front().n, 1));
+    const double zero[3] = {0, 0, 0};
+    (void)spvo_solve_wait_prior(ctx_, zero, zero, 0, &so, xyz.data(), inl.data());
+    solve_q_.pop_front();
   }
-  solve_pending_ = false;
+  solve_q_.clear();
+  prev_points_on_device_ = false;
   completeHostCopies();
   images_dq.clear();
   keypoints_dq.clear();
@@ -230,15 +233,18 @@ void FeatureFrontEnd::solveStereoOdometry(tf2::Transform &cam0_curr_T_cam0_prev)
 }
 
 // First half (extension): the correspondence join (base.cpp:127-207) and the hand-over of the numeric part to spvo_solve_submit.
-// Nothing of the front end's state changes here except the per-frame maps of the join; the result is taken by
-// solveStereoOdometryCollect, which has to run before the next frame's join (that one needs this frame's points and prior).
+// Since round 6 this half needs NOTHING of the previous frame's result: its 3-D points are referred to by index where they lie on the
+// device (spvo_solve_input::prev_index), the motion prior and the frame count are only needed by the gate, which the second half
+// evaluates (spvo_solve_wait_prior).  So the next frame may be submitted BEFORE this one has been collected: up to two solves in flight,
+// collected oldest first.  The join's own maps (base.cpp:388-392) roll here; pose, prior, frame count and the points' host copy roll in
+// solveStereoOdometryCollect.
 bool FeatureFrontEnd::solveStereoOdometrySubmit() {
   const bool timing = solve_timing_;   // diagnostic (spvo_set_tuning "solve_timing", read when this front end created its context)
   double *acc = solve_timing_acc_;
   long &calls = solve_timing_calls_;
   const double th0 = timing ? host_now_us() : 0;
-  if (solve_pending_) {
-    logError("solveStereoOdometrySubmit: the previous solve has not been collected");
+  if (solve_q_.size() >= 2) {
+    logError("solveStereoOdometrySubmit: two solves are in flight, collect the older one first");
     return false;
   }
   if (keypoints_dq.size() < 4 || !ensureContext()) {
@@ -290,42 +296,38 @@ bool FeatureFrontEnd::solveStereoOdometrySubmit() {
   // triangulation (base.cpp:211-223), PnP-RANSAC (227-239), gating (241-272), residual blocks
   // (291-356), refinement and the "not converged => keep RANSAC" rule (358-375)
   const double *Pl = projection_matrix_l_.ptr<double>(0), *Pr = projection_matrix_r_.ptr<double>(0);
-  std::vector<float> prev_xyz;
-  std::vector<int32_t> prev_valid;
-  solve_pts3d_.assign((size_t)std::max(n, 1) * 3, 0.f);
-  if (refinement_degree_ >= 3 && prev_left_points_3d_inited) {  // base.cpp:323-332
-    prev_xyz.assign((size_t)std::max(n, 1) * 3, 0.f);
-    prev_valid.assign(std::max(n, 1), 0);
+  std::vector<int32_t> prev_index;
+  if (refinement_degree_ >= 3 && prev_points_on_device_) {  // base.cpp:323-332: the previous frame's 3-D point of each correspondence, by index
+    prev_index.assign(std::max(n, 1), -1);
     for (int vi = 0; vi < n; ++vi) {
       const int matched_prev = map_from_curr_valid_to_prev_left_matched_index[vi];
       if (matched_prev < 0 || matched_prev >= (int)map_from_prev_left_matched_to_prev_valid_index.size()) continue;
-      const int valid_prev = map_from_prev_left_matched_to_prev_valid_index[matched_prev];
-      if (valid_prev == -1) continue;
-      for (int k = 0; k < 3; ++k) prev_xyz[3 * vi + k] = prev_left_points_3d[3 * valid_prev + k];
-      prev_valid[vi] = 1;
+      prev_index[vi] = map_from_prev_left_matched_to_prev_valid_index[matched_prev];   // (-1: that keypoint had no valid correspondence then)
     }
   }
   spvo_solve_input si;
   std::memset(&si, 0, sizeof si);
   si.n = n;
   si.xy_cl = kp_cl.data(); si.xy_cr = kp_cr.data(); si.xy_pl = kp_pl.data(); si.xy_pr = kp_pr.data();
-  si.prev_xyz = prev_xyz.empty() ? nullptr : prev_xyz.data();
-  si.prev_valid = prev_valid.empty() ? nullptr : prev_valid.data();
+  si.prev_index = prev_index.empty() ? nullptr : prev_index.data();
+  si.late_prior = 1;   // r_vec_pred / t_vec_pred / frame_count: handed over by solveStereoOdometryCollect (the previous frame's may not be in yet)
   for (int k = 0; k < 12; ++k) { si.P_l[k] = Pl[k]; si.P_r[k] = Pr[k]; }
-  for (int k = 0; k < 3; ++k) { si.rvec_pred[k] = r_vec_pred[k]; si.tvec_pred[k] = t_vec_pred[k]; }
-  si.frame_count = frame_count;
   si.refinement_degree = refinement_degree_;
   si.ransac = spvo_ransac_opts{500, 2.0, 0.999, ransac_seed};   // base.cpp:239
   si.refine = spvo_refine_opts{40, 1.0};                        // base.cpp:286, 362
-  inliers_pnp.assign(std::max(n, 1), 0);
   const double th1 = timing ? host_now_us() : 0;
   const int solve_rc = spvo_solve_submit(ctx_, &si);   // the inputs are staged: the vectors above may go
   if (solve_rc != SPVO_OK) {
     logError(std::string("spvo_solve_submit: ") + spvo_last_error(ctx_));
     return false;
   }
-  solve_pending_ = true;
-  solve_n_ = n;
+  solve_q_.emplace_back();
+  solve_q_.back().n = n;
+  solve_q_.back().inliers_postmatching = inliers_postmatching;
+  if (refinement_degree_ >= 3) {  // base.cpp:388-392 (the maps of the join; the points themselves stay on the device for the next frame's prev_index)
+    map_from_prev_left_matched_to_prev_valid_index = map_from_curr_left_matched_to_curr_valid_index;
+    prev_points_on_device_ = true;
+  }
   if (timing) {
     const double th2 = host_now_us();
     acc[0] += th1 - th0; acc[1] += th2 - th1;
@@ -339,18 +341,22 @@ bool FeatureFrontEnd::solveStereoOdometrySubmit() {
 
 // Second half (extension): waits for the solve, then base.cpp:241-272 (prior update), 377-396 (output, state roll)
 bool FeatureFrontEnd::solveStereoOdometryCollect(tf2::Transform &cam0_curr_T_cam0_prev) {
-  if (!solve_pending_) {
+  if (solve_q_.empty()) {
     logError("solveStereoOdometryCollect: no solve pending");
     return false;
   }
-  solve_pending_ = false;
-  const int n = solve_n_;
+  const int n = solve_q_.front().n;
+  inliers_postmatching.swap(solve_q_.front().inliers_postmatching);   // (introspection: the frame whose pose this call returns)
+  solve_q_.pop_front();
   std::vector<float> &pts3d = solve_pts3d_;
+  pts3d.assign((size_t)std::max(n, 1) * 3, 0.f);
+  inliers_pnp.assign(std::max(n, 1), 0);
   spvo_solve_output so;
   completeHostCopies();   // the solver's kernels are running: the bulk copies into images_dq / descriptors_dq cost nothing here
-  const int solve_rc = spvo_solve_wait(ctx_, &so, pts3d.data(), inliers_pnp.data());
+  // the gate (base.cpp:241-272) is evaluated in here, against the prior and the frame count as they stand NOW (every earlier frame collected)
+  const int solve_rc = spvo_solve_wait_prior(ctx_, r_vec_pred, t_vec_pred, frame_count, &so, pts3d.data(), inliers_pnp.data());
   if (solve_rc != SPVO_OK) {
-    logError(std::string("spvo_solve_wait: ") + spvo_last_error(ctx_));
+    logError(std::string("spvo_solve_wait_prior: ") + spvo_last_error(ctx_));
     return false;
   }
   inliers_pnp.resize(so.n_inliers);
@@ -367,8 +373,7 @@ bool FeatureFrontEnd::solveStereoOdometryCollect(tf2::Transform &cam0_curr_T_cam
   cam0_prev_T_cam0_curr.setOrigin(tf2::Vector3(t_opt[0], t_opt[1], t_opt[2]));
   cam0_curr_T_cam0_prev = cam0_prev_T_cam0_curr.inverse();
 
-  if (refinement_degree_ >= 3) {  // base.cpp:388-394
-    map_from_prev_left_matched_to_prev_valid_index = map_from_curr_left_matched_to_curr_valid_index;
+  if (refinement_degree_ >= 3) {  // base.cpp:393-394 (host copy of the points; the index maps rolled at the submit)
     prev_left_points_3d.assign(pts3d.begin(), pts3d.begin() + (size_t)n * 3);
     prev_left_points_3d_inited = true;
   }

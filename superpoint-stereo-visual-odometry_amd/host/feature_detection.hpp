@@ -208,12 +208,15 @@ public:
                                   const cv::Mat &projection_matrix_r) = 0;
   void matchDescriptors(const MatchType match_type);
   void solveStereoOdometry(tf2::Transform &cam0_curr_T_cam0_prev);
-  // Extension: the same call in two halves (spvo_solve_submit / spvo_solve_wait).  A caller that collects the pose of frame k
+  // Extension: the same call in two halves (spvo_solve_submit / spvo_solve_wait_prior).  A caller that collects the pose of frame k
   // after it has handed frame k+1's images over keeps the solver off its critical path; results are those of the one-piece
-  // call.  Collect before the next frame's submit (the join needs this frame's points and motion prior).
+  // call, bit for bit.  Since round 6 frame k+1 may even be SUBMITTED before frame k is collected (two solves in flight, collected
+  // oldest first): no step of a frame's device chain needs the previous frame's pose, and the gate (base.cpp:241-272) is evaluated
+  // by Collect against the prior as it stands then.
   bool solveStereoOdometrySubmit();
   bool solveStereoOdometryCollect(tf2::Transform &cam0_curr_T_cam0_prev);
-  bool solvePending() const { return solve_pending_; }
+  bool solvePending() const { return !solve_q_.empty(); }
+  int solvesPending() const { return (int)solve_q_.size(); }
   // Extension: the HIP device the front ends constructed AFTERWARDS create their context on (one process per GPU sets its local
   // rank here).  < 0 (default): environment variable SPVO_DEVICE, else device 0.
   static void setDevice(int device);
@@ -266,11 +269,12 @@ protected:
   // replaces cv::Ptr<cv::DescriptorMatcher> matcher_: for NORM_L2 descriptors the matcher lives behind the C ABI
   bool matcher_ready_ = false;
   bool matcher_cross_check_ = false;
-  bool solve_pending_ = false;     // solveStereoOdometrySubmit .. Collect
+  struct PendingSolve { int n = 0; std::vector<int> inliers_postmatching; };
+  std::deque<PendingSolve> solve_q_;       // solveStereoOdometrySubmit .. Collect, oldest first (at most two)
+  bool prev_points_on_device_ = false;     // a submit has left its triangulated points in the context: the next one refers to them by index
   bool solve_timing_ = false;      // tuning "solve_timing", read when the context is created
   double solve_timing_acc_[3] = {0, 0, 0};
   long solve_timing_calls_ = 0;
-  int solve_n_ = 0;
   std::vector<float> solve_pts3d_;
   bool matcher_hamming_ = false;   // NORM_HAMMING descriptors of the classic front end (base.cpp:13-28): spvo_match_hamming
   // creates ctx_ without an engine: preprocessImageImpl and solveStereoOdometry of a front end that has no network

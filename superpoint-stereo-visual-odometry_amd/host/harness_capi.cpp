@@ -100,7 +100,7 @@ int spvo_host_solve_collect(void *h, double *q, double *t) {
   t[0] = T.getOrigin().x(); t[1] = T.getOrigin().y(); t[2] = T.getOrigin().z();
   return 1;
 }
-int spvo_host_solve_pending(void *h) { return static_cast<SuperPointFeatureFrontEnd *>(h)->solvePending() ? 1 : 0; }
+int spvo_host_solve_pending(void *h) { return static_cast<SuperPointFeatureFrontEnd *>(h)->solvesPending(); }
 
 void spvo_host_clear(void *h) { static_cast<SuperPointFeatureFrontEnd *>(h)->clearLagecyData(); }
 
@@ -337,6 +337,7 @@ int spvo_host_run_device_block(void *h, const void *const *d_l, const void *cons
     r.pnp_inliers = (int)fe->inliersPnp().size();
   };
   int pending = -1;                   // frame of the block whose deferred solve is in flight
+  const bool collect_first = spvo_get_tuning("solve_collect_first", 0) != 0;
   for (int k = 0; k < n; ++k) {
     const long g = first + k;
     SpvoFrameRecord &r = rec[k];
@@ -365,12 +366,20 @@ int spvo_host_run_device_block(void *h, const void *const *d_l, const void *cons
       record_pose(k, T, true);
       continue;
     }
-    if (fe->solvePending()) {   // the previous frame's pose: its points and prior enter this frame's join
+    // this frame's chain goes out FIRST (it needs nothing of the previous frame's result: feature_detection.hpp), then the previous
+    // frame's pose is collected -- the solver's stream always has the next chain queued behind the running one
+    if (collect_first && fe->solvePending()) {   // (diagnostic, tuning "solve_collect_first": rounds 1-5's order, for A/B runs)
       const bool ok = fe->solveStereoOdometryCollect(T);
       if (pending >= 0) record_pose(pending, T, ok);
       pending = -1;
     }
-    if (fe->solveStereoOdometrySubmit()) pending = k;
+    const bool submitted = fe->solveStereoOdometrySubmit();
+    if (fe->solvesPending() > (submitted ? 1 : 0)) {
+      const bool ok = fe->solveStereoOdometryCollect(T);
+      if (pending >= 0) record_pose(pending, T, ok);
+      pending = -1;
+    }
+    if (submitted) pending = k;
   }
   if (fe->solvePending()) {
     tf2::Transform T;

@@ -47,7 +47,7 @@ class SolveInput(C.Structure):
     _fields_ = [("n", C.c_int), ("xy_cl", C.c_void_p), ("xy_cr", C.c_void_p), ("xy_pl", C.c_void_p), ("xy_pr", C.c_void_p),
                 ("prev_xyz", C.c_void_p), ("prev_valid", C.c_void_p), ("P_l", C.c_double * 12), ("P_r", C.c_double * 12),
                 ("rvec_pred", C.c_double * 3), ("tvec_pred", C.c_double * 3), ("frame_count", C.c_int),
-                ("refinement_degree", C.c_int), ("ransac", RansacOpts), ("refine", RefineOpts)]
+                ("refinement_degree", C.c_int), ("ransac", RansacOpts), ("refine", RefineOpts), ("prev_index", C.c_void_p), ("late_prior", C.c_int)]
 
 
 class SolveOutput(C.Structure):
@@ -63,7 +63,7 @@ SYMBOLS = [
     "spvo_default_config", "spvo_create", "spvo_destroy", "spvo_last_error", "spvo_load_weights", "spvo_engine_precision", "spvo_set_fp32_split",
     "spvo_preprocess", "spvo_forward", "spvo_debug_tensor", "spvo_heatmap", "spvo_nms",
     "spvo_sample_descriptors", "spvo_detect", "spvo_detect_dev", "spvo_detect_dev_submit", "spvo_detect_wait", "spvo_set_trunk_pairing", "spvo_detect_submit", "spvo_detect_collect", "spvo_detect_collect_mirrors", "spvo_detect_mirrors_wait", "spvo_match", "spvo_match_slots", "spvo_set_prematch", "spvo_set_match_fp8", "spvo_get_match_fp8",
-    "spvo_match_hamming", "spvo_orb_detect", "spvo_orb_tables", "spvo_triangulate", "spvo_pnp_ransac", "spvo_pnp_refine", "spvo_solve_stereo_odometry", "spvo_solve_submit", "spvo_solve_wait", "spvo_stream", "spvo_synchronize",
+    "spvo_match_hamming", "spvo_orb_detect", "spvo_orb_tables", "spvo_triangulate", "spvo_pnp_ransac", "spvo_pnp_refine", "spvo_solve_stereo_odometry", "spvo_solve_submit", "spvo_solve_wait", "spvo_solve_wait_prior", "spvo_solve_pending", "spvo_stream", "spvo_synchronize",
     "spvo_profile_enable", "spvo_profile_reset", "spvo_profile_only", "spvo_profile_count", "spvo_profile_get", "spvo_profile_stage_kernel",
     "spvo_set_tuning", "spvo_get_tuning", "spvo_clear_tuning",
     "spvo_comm_unique_id", "spvo_comm_available", "spvo_comm_create", "spvo_comm_create_host", "spvo_comm_rank", "spvo_comm_world", "spvo_comm_destroy",
@@ -124,6 +124,8 @@ def load() -> C.CDLL:
     lib.spvo_solve_stereo_odometry.argtypes = [vp, C.POINTER(SolveInput), C.POINTER(SolveOutput), vp, vp]
     lib.spvo_solve_submit.argtypes = [vp, C.POINTER(SolveInput)]
     lib.spvo_solve_wait.argtypes = [vp, C.POINTER(SolveOutput), vp, vp]
+    lib.spvo_solve_wait_prior.argtypes = [vp, vp, vp, C.c_int, C.POINTER(SolveOutput), vp, vp]
+    lib.spvo_solve_pending.argtypes = [vp]
     lib.spvo_stream.argtypes = [vp]
     lib.spvo_stream.restype = vp
     lib.spvo_synchronize.argtypes = [vp]
@@ -431,7 +433,10 @@ class Context:
         return q, t, s
 
     def solve(self, P_l, P_r, cl, cr, pl, pr, prev_xyz=None, prev_valid=None, rvec_pred=(0, 0, 0), tvec_pred=(0, 0, 0),
-              frame_count=0, refinement_degree=4, seed=0, iterations=500, reproj_error=2.0, max_iterations=40, split=None):
+              frame_count=0, refinement_degree=4, seed=0, iterations=500, reproj_error=2.0, max_iterations=40, split=None, prev_index=None, late_prior=False):
+        """spvo_solve_stereo_odometry, or (split="submit") spvo_solve_submit alone: complete with solve_wait(n) / solve_wait_prior(n, ...).
+        prev_index: instead of prev_xyz / prev_valid, indices into the points of the previous submit on this context (-1: none);
+        late_prior: the prior is handed to solve_wait_prior instead (the previous solve may still be in flight)."""
         arrs = [np.ascontiguousarray(a, np.float32).reshape(-1, 2) for a in (cl, cr, pl, pr)]
         n = len(arrs[0])
         si = SolveInput()
@@ -448,6 +453,10 @@ class Context:
         si.frame_count, si.refinement_degree = frame_count, refinement_degree
         si.ransac = RansacOpts(iterations, reproj_error, 0.999, seed)
         si.refine = RefineOpts(max_iterations, 1.0)
+        if prev_index is not None:
+            pi = np.ascontiguousarray(prev_index, np.int32)
+            si.prev_index = pi.ctypes.data
+        si.late_prior = int(late_prior)
         if split == "submit":      # spvo_solve_submit only: the inputs are staged, complete with solve_wait(n)
             self._check(self.lib.spvo_solve_submit(self.h, C.byref(si)))
             return n
@@ -464,6 +473,19 @@ class Context:
         inl = np.zeros(max(n, 1), np.int32)
         self._check(self.lib.spvo_solve_wait(self.h, C.byref(so), _ptr(xyz), _ptr(inl)))
         return self._solve_result(so, xyz, inl, n)
+
+    def solve_wait_prior(self, n, rvec_pred, tvec_pred, frame_count):
+        """spvo_solve_wait_prior: the oldest pending solve, gated against the prior given NOW."""
+        so = SolveOutput()
+        xyz = np.zeros((max(n, 1), 3), np.float32)
+        inl = np.zeros(max(n, 1), np.int32)
+        r = np.ascontiguousarray(rvec_pred, np.float64).reshape(3)
+        t = np.ascontiguousarray(tvec_pred, np.float64).reshape(3)
+        self._check(self.lib.spvo_solve_wait_prior(self.h, _dptr(r), _dptr(t), int(frame_count), C.byref(so), _ptr(xyz), _ptr(inl)))
+        return self._solve_result(so, xyz, inl, n)
+
+    def solve_pending(self):
+        return int(self.lib.spvo_solve_pending(self.h))
 
     @staticmethod
     def _solve_result(so, xyz, inl, n):

@@ -228,9 +228,11 @@ class FrontEnd:
         self.match_descriptors(CURR_LEFT_PREV_LEFT)
         if not deferred_solve:
             return self.solve_stereo_odometry()
-        prev = self.finish_solve()                   # the previous frame's pose: its points and prior enter this frame's join
-        self.lib.spvo_host_solve_submit(self.h)
-        return prev
+        # this frame's chain first (it needs nothing of the previous frame's result), then the previous frame's pose
+        submitted = bool(self.lib.spvo_host_solve_submit(self.h))
+        if self.lib.spvo_host_solve_pending(self.h) > (1 if submitted else 0):
+            return self.finish_solve()
+        return None
 
     def finish_solve(self):
         """Collects a deferred solve, if one is pending: (q, t) or None."""

@@ -177,7 +177,8 @@ def test_fused_solve_gating_and_small_inputs(ctx_vgg):
 
 def test_solve_in_two_halves(ctx_vgg):
     """spvo_solve_submit + spvo_solve_wait == spvo_solve_stereo_odometry bit for bit; the inputs may be overwritten between the
-    halves (they are staged at submit); one solve may be pending, and the stand-alone solver entry points refuse meanwhile."""
+    halves (they are staged at submit); TWO solves may be pending (round 6), a third is refused, and the stand-alone solver entry
+    points refuse while any is."""
     P_l, P_r, Xc, cl, cr, pl, pr, rv, tv, bad = _scene(seed=9, n=300, noise=0.3, outliers=0.2)
     prior_r, prior_t = np.zeros(3), np.array([0.0, 0.0, 0.9])
     ref = ctx_vgg.solve(P_l, P_r, cl, cr, pl, pr, None, None, prior_r, prior_t, frame_count=3, seed=4)
@@ -185,16 +186,19 @@ def test_solve_in_two_halves(ctx_vgg):
     n = ctx_vgg.solve(P_l, P_r, *arrs, None, None, prior_r, prior_t, frame_count=3, seed=4, split="submit")
     for a in arrs:
         a[:] = -1.0                                                     # the caller's arrays are free after submit
+    n2 = ctx_vgg.solve(P_l, P_r, cl, cr, pl, pr, None, None, prior_r, prior_t, frame_count=3, seed=4, split="submit")   # a second one behind it
+    assert ctx_vgg.solve_pending() == 2
     with pytest.raises(capi.SpvoError) as e:
         ctx_vgg.solve(P_l, P_r, cl, cr, pl, pr, None, None, prior_r, prior_t, split="submit")
     assert e.value.code == -4
     with pytest.raises(capi.SpvoError) as e:
         ctx_vgg.triangulate(P_l, P_r, cl, cr)
     assert e.value.code == -4
-    got = ctx_vgg.solve_wait(n)
-    for k in ("q", "t", "rvec", "tvec", "inliers", "xyz"):
-        assert np.array_equal(got[k], ref[k]), k
-    assert got["refined"] == ref["refined"] and got["iterations"] == ref["iterations"]
+    for got in (ctx_vgg.solve_wait(n), ctx_vgg.solve_wait(n2)):       # oldest first; both are the one-piece call's result
+        for k in ("q", "t", "rvec", "tvec", "inliers", "xyz"):
+            assert np.array_equal(got[k], ref[k]), k
+        assert got["refined"] == ref["refined"] and got["iterations"] == ref["iterations"]
+    assert ctx_vgg.solve_pending() == 0
     with pytest.raises(capi.SpvoError) as e:                            # nothing pending any more
         ctx_vgg.solve_wait(n)
     assert e.value.code == -4
@@ -202,3 +206,45 @@ def test_solve_in_two_halves(ctx_vgg):
     n0 = ctx_vgg.solve(P_l, P_r, cl[:0], cr[:0], pl[:0], pr[:0], None, None, [0, 0.1, 0], [1, 2, 3], split="submit")
     f = ctx_vgg.solve_wait(n0)
     assert not f["pnp_ok"] and np.allclose(f["t"], [1, 2, 3]) and np.allclose(f["q"], od.rvec_to_quat([0, 0.1, 0]))
+
+
+@pytest.mark.parametrize("degree", [4, 2])
+def test_two_frames_in_flight_with_late_prior_and_point_indices(ctx_vgg, degree):
+    """Round 6: frame k + 1 is submitted BEFORE frame k has been waited for -- its previous-frame points referred to by index where frame
+    k's submission left them on the device (prev_index), the motion prior and the frame count handed over at the wait
+    (spvo_solve_wait_prior), where the gate (base.cpp:241-272) is evaluated.  Against the sequential form (wait for k, copy its points
+    and its accepted pose into k + 1's input): every output bit for bit -- the device chain of a frame does not depend on the previous
+    frame's pose (prior-free RANSAC, refinement from the RANSAC pose), only the gate does."""
+    P_l, P_r, Xc, cl, cr, pl, pr, rv, tv, bad = _scene(seed=11, n=320, noise=0.3, outliers=0.2)
+    _, _, _, cl2, cr2, pl2, pr2, rv2, tv2, _ = _scene(seed=12, n=280, noise=0.3, outliers=0.2)
+    rng = np.random.RandomState(1)
+    idx = rng.randint(-1, 320, 280).astype(np.int32)                    # frame B's correspondences -> points of frame A (-1: none)
+    prior_r, prior_t = np.zeros(3), np.array([0.0, 0.0, 0.85])
+    for fc in (3, 11):                                                  # inside IGNORE_FRAME_COUNT / with the gate armed
+        # sequential reference
+        a = ctx_vgg.solve(P_l, P_r, cl, cr, pl, pr, None, None, prior_r, prior_t, frame_count=fc, refinement_degree=degree, seed=1)
+        pr_r, pr_t = (a["rvec"], a["tvec"]) if a["accepted"] else (prior_r, prior_t)
+        pxyz = np.where(idx[:, None] >= 0, a["xyz"][np.maximum(idx, 0)], 0).astype(np.float32)
+        b = ctx_vgg.solve(P_l, P_r, cl2, cr2, pl2, pr2, pxyz, (idx >= 0).astype(np.int32), pr_r, pr_t, frame_count=fc + 1, refinement_degree=degree, seed=1)
+        # two in flight
+        na = ctx_vgg.solve(P_l, P_r, cl, cr, pl, pr, None, None, refinement_degree=degree, seed=1, split="submit", late_prior=True)
+        nb = ctx_vgg.solve(P_l, P_r, cl2, cr2, pl2, pr2, None, None, refinement_degree=degree, seed=1, split="submit", late_prior=True, prev_index=idx)
+        with pytest.raises(capi.SpvoError):                             # a late submission has no prior of its own
+            ctx_vgg.solve_wait(na)
+        a2 = ctx_vgg.solve_wait_prior(na, prior_r, prior_t, fc)
+        pr_r2, pr_t2 = (a2["rvec"], a2["tvec"]) if a2["accepted"] else (prior_r, prior_t)
+        b2 = ctx_vgg.solve_wait_prior(nb, pr_r2, pr_t2, fc + 1)
+        for x, y in ((a, a2), (b, b2)):
+            for k in ("q", "t", "rvec", "tvec", "inliers", "xyz"):
+                assert np.array_equal(x[k], y[k]), (fc, k)
+            assert (x["pnp_ok"], x["accepted"], x["refined"], x["iterations"]) == (y["pnp_ok"], y["accepted"], y["refined"], y["iterations"])
+        assert b["accepted"] and (degree < 3 or (idx >= 0).any())
+    # the gate at the wait: the same submission accepted or rejected by the prior it is GIVEN
+    n1 = ctx_vgg.solve(P_l, P_r, cl, cr, pl, pr, None, None, refinement_degree=degree, seed=1, split="submit", late_prior=True)
+    f = ctx_vgg.solve_wait_prior(n1, np.zeros(3), [0, 0, 5.0], 11)
+    assert f["pnp_ok"] and not f["accepted"] and not f["refined"] and np.allclose(f["t"], [0, 0, 5.0]) and f["iterations"] == 0
+    # indices outside the previous submission's points are refused, and so is prev_index together with prev_xyz
+    bad_idx = idx.copy(); bad_idx[0] = 320
+    with pytest.raises(capi.SpvoError):
+        ctx_vgg.solve(P_l, P_r, cl2, cr2, pl2, pr2, None, None, split="submit", late_prior=True, prev_index=bad_idx)
+    assert ctx_vgg.solve_pending() == 0
