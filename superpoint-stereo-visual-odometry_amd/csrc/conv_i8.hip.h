@@ -4,7 +4,8 @@
 // The reference knows FP32 and FP16 engines only (feature_detection.hpp:124-126); config 5 is a build-side
 // extension, so the arithmetic is DEFINED by oracle/net_int8.py and reproduced here bit for bit: integer
 // accumulation is exact and every float operation of the requantisation is a separately rounded fp32 multiply or
-// add in the oracle's order (mul_rn / add_rn of conv_mfma.hip.h: hipcc would otherwise contract them into fused multiply-adds).
+// add in the oracle's order.  Round 6: every affine of the requantisation is ONE fused multiply-add (__builtin_fmaf = v_fma_f32, correctly
+// rounded, as oracle/net_int8.py's fma32), and the loader folds 1 / s_out into the chain's last affine where the oracle does (inv_s_out = 1 then).
 //
 // Activation layout "C16": act[img][C/16][Hp][Wp][16] of int8 -- 16 channels = the 16 bytes of one pixel, padded
 // group planes with the usual zero border (q = 0 is the real value 0: the quantisation is symmetric).  As in
@@ -229,12 +230,12 @@ __global__ __launch_bounds__(256) void conv_i8_kernel(const ConvArgs8 a) {
     const size_t res_plane = (size_t)a.in_hp * a.in_wp;
     auto tail = [&](int accv, int m, int r, int y, int x) -> float {   // requantisation chain up to (not including) pooling
       const int co = co_t + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
-      float v = add_rn(mul_rn((float)accv, a.qm[co]), a.bias[co]);
+      float v = __builtin_fmaf((float)accv, a.qm[co], a.bias[co]);   // one fused multiply-add per affine (oracle/net_int8.py)
       if (RELU) v = fmaxf(v, 0.f);
-      if constexpr (EPI == 1) v = fmaxf(add_rn(mul_rn(v, a.bn_scale[co]), a.bn_shift[co]), 0.f);
+      if constexpr (EPI == 1) v = fmaxf(__builtin_fmaf(v, a.bn_scale[co], a.bn_shift[co]), 0.f);
       if constexpr (EPI == 2) {
         const int rq = co < a.cout ? (int)a.residual[((((size_t)cur.img * (a.cout / 16) + co / 16) * res_plane + (size_t)(y + PADY) * a.in_wp + (x + PADX)) * 16) + (co & 15)] : 0;
-        v = fmaxf(add_rn(v, mul_rn((float)rq, a.s_res)), 0.f);
+        v = fmaxf(__builtin_fmaf((float)rq, a.s_res, v), 0.f);
       }
       return v;
     };
@@ -335,9 +336,9 @@ __global__ __launch_bounds__(256) void conv_first_i8_kernel(const float *__restr
   auto eval = [&](int co) {
     float s = bias[co];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) s = add_rn(s, mul_rn(w[co * TAPS + t], v[t]));
+    for (int t = 0; t < TAPS; ++t) s = __builtin_fmaf(w[co * TAPS + t], v[t], s);
     if (RELU) s = fmaxf(s, 0.f);
-    if (bn_scale) s = fmaxf(add_rn(mul_rn(s, bn_scale[co]), bn_shift[co]), 0.f);
+    if (bn_scale) s = fmaxf(__builtin_fmaf(s, bn_scale[co], bn_shift[co]), 0.f);
     return s;
   };
   if constexpr (OUT_Q) {
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_i8_kernel(const int8_t *__restr
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int c = g * 16 + 4 * d + e;
-      float r = add_rn(mul_rn((float)acc[4 * d + e], qm[c]), bias[c]);
+      float r = __builtin_fmaf((float)acc[4 * d + e], qm[c], bias[c]);
       if (RELU) r = fmaxf(r, 0.f);
       u |= ((unsigned)quantize_i8(r, inv_s_out) & 0xFFu) << (8 * e);
     }

@@ -11,9 +11,10 @@
 // against a DIAGONAL weight operand (below), and the requantised bytes are packed by v_cvt_pk_u8_f32 (integers in [0, 127] by then).
 //
 // The arithmetic is oracle/net_int8.py's, bit for bit (tests/test_gpu_network.py::test_int8_engine_is_bit_exact): exact int32
-// accumulation; r = f32(acc) * m; r = r + bias; ReLU; [r = r * bn_scale; r = r + bn_shift; ReLU]; [2x2 max]; q = min(rint(r * inv_s), 127),
-// every float operation separately rounded (mul_rn / add_rn).  The fp32 stem: bias first, then one separately rounded multiply and add per
-// tap in row-major order.  The synchronous entry points (spvo_forward / spvo_debug_tensor) pass pointers for the tensors a fused block
+// accumulation; r = fma(f32(acc), m, bias); ReLU; [r = fma(r, bn_scale, bn_shift); ReLU]; [2x2 max]; q = min(rint(r), 127) -- one fused
+// multiply-add per affine, 1 / s_out folded into the chain's last affine by the loader (round 6; rounds 2-5: separately rounded multiplies and
+// adds and a final multiply, nine vector instructions per value of the stem where there are five now).  The fp32 stem: bias first, then one
+// fused multiply-add per tap in row-major order.  The synchronous entry points (spvo_forward / spvo_debug_tensor) pass pointers for the tensors a fused block
 // skips (stem plane, stem output, depthwise output): the kernel then stores them too, so the test sees every tensor of the graph
 // computed by the kernels the pipeline runs.
 //
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(DWPW_THREADS) void dwpw_i8_kernel(const DwPwArgs8 a
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) x1 = add_rn(x1, mul_rn(c_w0[ky * 3 + kx], raw[(r + ky) * 36 + c + kx]));
+          for (int kx = 0; kx < 3; ++kx) x1 = __builtin_fmaf(c_w0[ky * 3 + kx], raw[(r + ky) * 36 + c + kx], x1);
         x1 = fmaxf(x1, 0.f);
         const bool own = inside && r >= 1 && r <= TH && c >= 1 && c <= TW;   // interior of the tile: this workgroup's pixel
         if (a.dbg_stem_plane && own) a.dbg_stem_plane[(size_t)cur.img * a.dbg_stem_plane_per_image + (size_t)(y + PADY) * a.wp + (x + PADX)] = x1;
@@ -222,9 +223,10 @@ __global__ __launch_bounds__(DWPW_THREADS) void dwpw_i8_kernel(const DwPwArgs8 a
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int ch = 16 * g + 4 * d + e;
-              float v = fmaxf(add_rn(c_b1[ch], mul_rn(c_w1[ch], x1)), 0.f);
-              v = fmaxf(add_rn(mul_rn(v, c_bn1s[ch]), c_bn1h[ch]), 0.f);
-              u = dwpw_pack_q(mul_rn(v, a.inv_s_stem), e, u);
+              // five instructions per value (rounds 2-5: nine): fma, max, fma with 1 / s folded into the BatchNorm constants, min, convert --
+              // the second ReLU is the conversion's saturation at 0
+              const float v = fmaxf(__builtin_fmaf(c_w1[ch], x1, c_b1[ch]), 0.f);
+              u = dwpw_pack_q(__builtin_fmaf(v, c_bn1s[ch], c_bn1h[ch]), e, u);
             }
             pk[d] = inside ? (int)u : 0;
           }
@@ -276,8 +278,7 @@ __global__ __launch_bounds__(DWPW_THREADS) void dwpw_i8_kernel(const DwPwArgs8 a
             unsigned u = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float v = fmaxf(add_rn(mul_rn((float)dacc[rr][4 * qq + e], qm4[e]), bi4[e]), 0.f);
-              u = dwpw_pack_q(mul_rn(v, a.inv_s_dw), e, u);
+              u = dwpw_pack_q(__builtin_fmaf((float)dacc[rr][4 * qq + e], qm4[e], bi4[e]), e, u);   // (1 / s folded into qm, bias; ReLU = the conversion's saturation at 0)
             }
             dq[qq] = u;
           }
@@ -319,8 +320,9 @@ __global__ __launch_bounds__(DWPW_THREADS) void dwpw_i8_kernel(const DwPwArgs8 a
       const int co_t = ct * CO_TILE;
       auto tail = [&](int accv, int m, int q) -> float {
         const int co = co_t + 32 * m + (q & 3) + 8 * (q >> 2) + 4 * half;
-        float v = fmaxf(add_rn(mul_rn((float)accv, s_par[co]), s_par[128 + co]), 0.f);
-        if constexpr (EPI == 1) v = fmaxf(add_rn(mul_rn(v, s_par[256 + co]), s_par[384 + co]), 0.f);
+        // the chain's last affine carries 1 / s_out (folded by the loader); the ReLU behind it is the conversion's saturation at 0
+        float v = __builtin_fmaf((float)accv, s_par[co], s_par[128 + co]);
+        if constexpr (EPI == 1) v = __builtin_fmaf(fmaxf(v, 0.f), s_par[256 + co], s_par[384 + co]);
         return v;
       };
       int8_t *g_base = a.out + (size_t)cur.img * a.out_per_image + (size_t)ct * (CO_TILE / 16) * out_plane * 16;
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(DWPW_THREADS) void dwpw_i8_kernel(const DwPwArgs8 a
           if (2 * m + (gq >> 1) < groups_valid && ok && !((DWPW_ABL & 4) && v[0] != 12345.f)) {
             unsigned pk = 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pk = dwpw_pack_q(mul_rn(v[4 * gq + e], a.inv_s_out), e, pk);
+            for (int e = 0; e < 4; ++e) pk = dwpw_pack_q(v[4 * gq + e], e, pk);
             *reinterpret_cast<unsigned *>(g_base + ((size_t)(2 * m + (gq >> 1)) * out_plane + pix) * 16 + 8 * (gq & 1) + 4 * half) = pk;
           }
         }

@@ -10,6 +10,7 @@
 #include "heads.hip.h"
 #include "conv_i8.hip.h"
 #include "conv_i8_fused.hip.h"
+#include "heads_i8.hip.h"
 
 namespace spvo_int {
 
@@ -150,7 +151,10 @@ void free_plan(spvo_ctx *c) {
     if (o.d_sched) (void)hipFree(o.d_sched);
   }
   if (c->d_heads_w) (void)hipFree(c->d_heads_w);
-  c->d_heads_w = nullptr; c->heads_fused = false;
+  if (c->d_heads_w8) (void)hipFree(c->d_heads_w8);
+  if (c->d_heads_qm) (void)hipFree(c->d_heads_qm);
+  if (c->d_heads_b) (void)hipFree(c->d_heads_b);
+  c->d_heads_w = nullptr; c->d_heads_w8 = nullptr; c->d_heads_qm = c->d_heads_b = nullptr; c->heads_fused = false;
   c->tensors.clear(); c->ops.clear(); c->weights = false; c->fp16 = false; c->int8 = false; c->s3 = false;
 }
 
@@ -405,6 +409,16 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
   static_assert(sizeof(Raw) == 72, "op record layout");
   std::vector<Raw> raws(no);
   for (uint32_t i = 0; i < no; ++i) { std::memcpy(&raws[i], buf.data() + pos, 72); pos += 72; }
+  // INT8 engines: the ONNX graphs list the two branches one after the other -- convPa, convPb, convDa, convDb, L2 norm -- so the trailing run
+  // of 1x1 layers the tail is made of (head_start below) would be convDb + norm only.  convPb does not feed convDa: it moves behind it,
+  // the tail becomes convPb, convDb, norm as in the VGG plan, and heads_i8_kernel runs it as one launch.  (Tensor ids do not change.)
+  if (hdr[5] == 2 && no >= 5) {
+    const Raw &A = raws[no - 5], &B = raws[no - 4], &C = raws[no - 3], &D = raws[no - 2], &N = raws[no - 1];
+    const bool branches = A.v[0] == OP_CONV && A.v[6] == 3 && B.v[0] == OP_CONV && B.v[6] == 1 && B.v[1] == A.v[2] && C.v[0] == OP_CONV && C.v[6] == 3 &&
+                          C.v[1] != B.v[2] && D.v[0] == OP_CONV && D.v[6] == 1 && D.v[1] == C.v[2] && N.v[0] == OP_L2NORM && N.v[1] == D.v[2] &&
+                          !(C.v[7] & FLAG_ADD) && !(B.v[7] & FLAG_ADD);
+    if (branches) std::swap(raws[no - 4], raws[no - 3]);
+  }
   uint64_t nfl;
   std::memcpy(&nfl, buf.data() + pos, 8);
   pos += 8;
@@ -503,9 +517,11 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
         std::vector<float> ws;
         quantize_conv_weights(payload + r.w_off, op.cout, 9, wq, ws);
         std::vector<int> wq32(wq.begin(), wq.end());
-        std::vector<float> qm(op.cout);
-        for (int o = 0; o < op.cout; ++o) qm[o] = ws[o] * ti.scale;
-        op.inv_s_out = 1.f / to.scale;
+        // r = fma(f32(acc), qm, bias) with 1 / s_out folded into both constants (oracle/net_int8.py: FOLDING): the kernels' final multiply is by 1
+        std::vector<float> qm(op.cout), bq(op.cout);
+        const float inv_dw = 1.f / to.scale;
+        for (int o = 0; o < op.cout; ++o) { qm[o] = ws[o] * ti.scale; qm[o] = qm[o] * inv_dw; bq[o] = (payload + r.b_off)[o] * inv_dw; }
+        op.inv_s_out = 1.f;
         int rc = dev_alloc(c, &op.d_wq32, wq32.size(), false);
         if (rc) return rc;
         if ((rc = dev_alloc(c, &op.d_qm, op.cout, false))) return rc;
@@ -515,7 +531,7 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
         if ((rc = dev_alloc(c, &op.d_wsel, wsel.size(), false))) return rc;
         HIP_TRY(c, hipMemcpy(op.d_wsel, wsel.data(), wsel.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(op.d_qm, qm.data(), qm.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(op.d_b, payload + r.b_off, (size_t)op.cout * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(op.d_b, bq.data(), (size_t)op.cout * 4, hipMemcpyHostToDevice));
         continue;
       }
       std::vector<float> wdw(payload + r.w_off, payload + r.w_off + (size_t)op.cout * 9);
@@ -549,6 +565,10 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
           const double k = (double)q[o] / std::sqrt((double)q[3 * op.cout + o] + (double)q[4 * op.cout]);
           sc[o] = (float)k;
           sh[o] = (float)((double)q[op.cout + o] - (double)q[2 * op.cout + o] * k);
+        }
+        if (c->int8 && to.i8 && !add) {   // INT8 engines: the chain's last affine absorbs 1 / s_out (oracle/net_int8.py: FOLDING), one fp32 multiply per constant
+          const float inv = 1.f / to.scale;
+          for (int o = 0; o < op.cout; ++o) { sc[o] = sc[o] * inv; sh[o] = sh[o] * inv; }
         }
         int rc = dev_alloc(c, &op.d_bn_scale, co_pad, false);
         if (rc) return rc;
@@ -589,7 +609,11 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
       }
       if (c->int8) {
         if (ti.i8 != (op.cin != 1)) return fail(c, SPVO_ERR_IO, "op %u: INT8 engine: a %d-channel input tensor stored as %s", i, op.cin, ti.i8 ? "int8" : "fp32");
-        op.inv_s_out = to.i8 ? 1.f / to.scale : 0.f;
+        // FOLDING (oracle/net_int8.py): quantised output, no residual, and an affine to fold into (the accumulator's, or a BatchNorm --
+        // folded where its constants are built, above): the kernels then multiply by 1 at the end
+        const bool fold = to.i8 && !add && (op.cin > 1 || bn);
+        const float inv_fold = to.i8 ? 1.f / to.scale : 0.f;
+        op.inv_s_out = fold ? 1.f : inv_fold;
         if (op.cin == 1) {   // fp32 stem
           if (pool || add || (to.i8 && ((op.out_c_off % 16) || (op.cout % 16)))) return fail(c, SPVO_ERR_IO, "op %u: unsupported single-channel-input layer for INT8", i);
           int rc = dev_alloc(c, &op.d_w, (size_t)op.cout * taps, false);
@@ -618,7 +642,10 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
         quantize_conv_weights(w, op.cout, op.cin * taps, wq, ws);
         const std::vector<int8_t> pk = pack_conv_weights_i8(wq.data(), op.cout, op.cin, op.ks, ckg);
         std::vector<float> qm((size_t)op.co_tiles * CO_TILE, 0.f), bp((size_t)op.co_tiles * CO_TILE, 0.f);
-        for (int o = 0; o < op.cout; ++o) { qm[o] = ws[o] * ti.scale; bp[o] = b[o]; }
+        for (int o = 0; o < op.cout; ++o) {
+          qm[o] = ws[o] * ti.scale; bp[o] = b[o];
+          if (fold && !bn) { qm[o] = qm[o] * inv_fold; bp[o] = bp[o] * inv_fold; }   // (with a BatchNorm the BatchNorm's constants carry the factor)
+        }
         int rc = dev_alloc(c, &op.d_w8, pk.size(), false);
         if (rc) return rc;
         if ((rc = dev_alloc(c, &op.d_qm, qm.size(), false))) return rc;
@@ -778,6 +805,35 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
       int rc = dev_alloc(c, &c->d_heads_w, pk.size(), false);
       if (rc) return rc;
       HIP_TRY(c, hipMemcpy(c->d_heads_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+      c->heads_fused = true;
+    }
+  }
+  // INT8 engines (round 6): the same tail as ONE launch of heads_i8_kernel (heads_i8.hip.h) -- int8 C16 activations of both branches in,
+  // fp32 detector planes, un-normalised and normalised descriptors out: oracle/net_int8.py's arithmetic for a layer with an fp32 output
+  if (c->int8 && c->head_start + 3 == c->ops.size() && tuning("heads_fused", 1)) {
+    const size_t hs = c->head_start;
+    const Op &pb = c->ops[hs], &db = c->ops[hs + 1], &nm = c->ops[hs + 2];
+    const bool plain = pb.type == OP_CONV && db.type == OP_CONV && nm.type == OP_L2NORM && pb.ks == 1 && db.ks == 1 && pb.flags == 0 && db.flags == 0 &&
+                       pb.cin == HEADS8_CIN && db.cin == HEADS8_CIN && pb.cout == 65 && db.cout == 256 && pb.out == c->t_det && pb.out_c_off == 0 &&
+                       db.out_c_off == 0 && nm.in == db.out && nm.out == c->t_desc && c->tensors[pb.in].level == 3 && c->tensors[db.in].level == 3 &&
+                       c->tensors[pb.in].i8 && c->tensors[db.in].i8 && !c->tensors[pb.out].i8 && !c->tensors[db.out].i8 && ((pb.in_c_off | db.in_c_off) % 16) == 0;
+    if (plain) {
+      std::vector<int8_t> wq_p, wq_d;
+      std::vector<float> ws_p, ws_d;
+      quantize_conv_weights(payload + raws[hs].w_off, pb.cout, pb.cin, wq_p, ws_p);
+      quantize_conv_weights(payload + raws[hs + 1].w_off, db.cout, db.cin, wq_d, ws_d);
+      const std::vector<int8_t> pk = pack_heads_weights_i8(wq_p.data(), pb.cout, wq_d.data());
+      std::vector<float> qm((size_t)HEADS8_UNITS * 16, 0.f), bp((size_t)HEADS8_UNITS * 16, 0.f);
+      const float *b_p = payload + raws[hs].b_off, *b_d = payload + raws[hs + 1].b_off;
+      for (int o = 0; o < pb.cout; ++o) { qm[o] = ws_p[o] * c->tensors[pb.in].scale; bp[o] = b_p[o]; }
+      for (int o = 0; o < db.cout; ++o) { qm[16 * HEADS8_DET_UNITS + o] = ws_d[o] * c->tensors[db.in].scale; bp[16 * HEADS8_DET_UNITS + o] = b_d[o]; }
+      int rc = dev_alloc(c, &c->d_heads_w8, pk.size(), false);
+      if (rc) return rc;
+      if ((rc = dev_alloc(c, &c->d_heads_qm, qm.size(), false))) return rc;
+      if ((rc = dev_alloc(c, &c->d_heads_b, bp.size(), false))) return rc;
+      HIP_TRY(c, hipMemcpy(c->d_heads_w8, pk.data(), pk.size(), hipMemcpyHostToDevice));
+      HIP_TRY(c, hipMemcpy(c->d_heads_qm, qm.data(), qm.size() * 4, hipMemcpyHostToDevice));
+      HIP_TRY(c, hipMemcpy(c->d_heads_b, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
       c->heads_fused = true;
     }
   }

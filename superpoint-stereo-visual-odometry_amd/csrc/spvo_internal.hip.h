@@ -189,6 +189,8 @@ struct spvo_ctx {
   bool heads_fused = false;        // ... as ONE launch (heads.hip.h): FP32 engines whose tail is convPb (256 -> 65), convDb (256 -> 256), L2 norm
   bool heads_keep_raw = false;     // the fused launch also stores the un-normalised descriptor planes (spvo_forward / spvo_debug_tensor)
   float *d_heads_w = nullptr;      // pack_heads_weights()
+  int8_t *d_heads_w8 = nullptr;    // INT8 engines (heads_i8.hip.h): pack_heads_weights_i8(), ...
+  float *d_heads_qm = nullptr, *d_heads_b = nullptr;   // ... and per output channel of the 21 units: weight scale x input scale of its branch, bias
   bool int8 = false;
   int H = 0, W = 0, Hc = 0, Wc = 0, B = 0;
   int num_cus = 256;
@@ -387,6 +389,7 @@ void free_plan(spvo_ctx *c);
 int launch_conv16(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream);
 int launch_conv_s3(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream);
 int launch_conv8(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stream);
+int launch_heads8(spvo_ctx *c, int batch, hipStream_t stream);   // spvo_net_i8.hip: the fused tail of an INT8 engine (heads_i8.hip.h)
 void plan_int8_fusion(spvo_ctx *c);   // spvo_net_i8.hip: marks the MobileNet blocks (and the stem) of a loaded INT8 plan that run as one launch
 int launch_maxpool_f16(spvo_ctx *c, const Tensor &ti, const Tensor &to, const float *tin, float *tout, int batch, hipStream_t stream);
 void launch_unpad_c8(const Tensor &t, int batch, float *dst, hipStream_t stream);    // spvo_debug_tensor

@@ -282,7 +282,7 @@ int launch_heads(spvo_ctx *c, int batch, hipStream_t stream) {
 int run_ops(spvo_ctx *c, int batch, size_t first, size_t last, hipStream_t stream) {
   for (size_t i = first; i < last && i < c->ops.size(); ++i) {
     if (c->heads_fused && i == c->head_start && last >= c->head_start + 3) {
-      int rc = launch_heads(c, batch, stream);
+      int rc = c->int8 ? launch_heads8(c, batch, stream) : launch_heads(c, batch, stream);
       if (rc) return rc;
       i += 2;
       continue;

@@ -2,6 +2,7 @@
 #include "spvo_internal.hip.h"
 #include "conv_i8.hip.h"
 #include "conv_i8_fused.hip.h"
+#include "heads_i8.hip.h"
 
 namespace spvo_int {
 
@@ -182,6 +183,28 @@ int launch_conv8(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t str
     case 12211: return launch_conv8_variant<1, 2, 2, 1, true>(c, a, relu, out_f32, epi, stream);
     default: return fail(c, SPVO_ERR_INVALID, "no int8 conv kernel variant for key %d", key);
   }
+}
+
+// the fused tail of an INT8 engine (heads_i8.hip.h): ops head_start .. head_start + 2 in one launch
+int launch_heads8(spvo_ctx *c, int batch, hipStream_t stream) {
+  const Op &pb = c->ops[c->head_start], &db = c->ops[c->head_start + 1];
+  const Tensor &ti = c->tensors[pb.in], &te = c->tensors[db.in], &tdet = c->tensors[pb.out], &traw = c->tensors[db.out], &tdesc = c->tensors[c->t_desc];
+  const size_t plane = (size_t)ti.hp * ti.wp;
+  HeadsArgs8 a;
+  a.in_det = (const int8_t *)(ring_ptr(c, ti)) + (size_t)(pb.in_c_off / 16) * plane * 16; a.det_in_per_image = ti.per_image * 4;
+  a.in_desc = (const int8_t *)(ring_ptr(c, te)) + (size_t)(db.in_c_off / 16) * plane * 16; a.desc_in_per_image = te.per_image * 4;
+  a.in_hp = ti.hp; a.in_wp = ti.wp;
+  a.wpack = c->d_heads_w8; a.qm = c->d_heads_qm; a.bias = c->d_heads_b;
+  a.det = ring_ptr(c, tdet); a.det_per_image = tdet.per_image;
+  a.desc_raw = c->heads_keep_raw ? ring_ptr(c, traw) : nullptr; a.raw_per_image = traw.per_image;
+  a.desc = ring_ptr(c, tdesc);
+  a.H = ti.H; a.W = ti.W; a.batch = batch;
+  const double hbytes = batch * ((double)(pb.cin + db.cin) * ti.H * ti.W + (double)(pb.cout + (a.desc_raw ? 2 : 1) * db.cout) * ti.H * ti.W * 4) + (double)(pb.cout * pb.cin + db.cout * db.cin);
+  ScopedStage st(c, stage_id(c, "heads"), (pb.flops_per_image + db.flops_per_image) * batch, hbytes, stream);
+  const int ntiles = (batch * ti.H * ti.W + 31) / 32;
+  hipLaunchKernelGGL(heads_i8_kernel<>, dim3(ntiles), dim3(HEADS8_THREADS), 0, stream, a);
+  HIP_TRY(c, hipGetLastError());
+  return SPVO_OK;
 }
 
 void launch_unpad_c16(const Tensor &t, int batch, float *dst, hipStream_t stream) {
