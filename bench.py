@@ -764,13 +764,13 @@ def main():
             # pipe EXECUTES per launch; the layer's ALGORITHMIC rate (direct 3x3 convolution) is reported
             # beside it under its own name and never enters `frac` (it exceeds the peak: that is the point of Winograd).
             kfam, kfactor = ctx.stage_kernel("conv:1")
-            # ... quoted only when the counter file was collected on THESE kernel sources: tools/collect_profiles_r05.sh stamps every
-            # profiles/r05_*.json with the hash of csrc/ (tools/csrc_hash.py); a stamp that differs from the sources the running library
+            # ... quoted only when the counter file was collected on THESE kernel sources: tools/collect_profiles_r06.sh stamps every
+            # profiles/r06_*.json with the hash of csrc/ (tools/csrc_hash.py); a stamp that differs from the sources the running library
             # was built from gives `traffic: null, traffic_stale: true` instead of a number nobody re-measured
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             from csrc_hash import csrc_sha16
             src_tag = csrc_sha16(ROOT)
-            pmc_file = {"conv_wino4_kernel": "r05_pmc.json"}.get(kfam)
+            pmc_file = {"conv_wino4_kernel": "r06_pmc.json"}.get(kfam)
             pmc = os.path.join(ROOT, "profiles", pmc_file) if pmc_file else None
             traffic_stale = None
             if pmc and os.path.exists(pmc) and (NET_H, NET_W) == (360, 1176):
@@ -828,7 +828,7 @@ def main():
             # north_star: "rocprof reports achieved HBM GB/s on the conv stack".  Bytes per forward pass from the committed counter passes
             # (FETCH_SIZE x 2 + WRITE_SIZE per layer, tools/pmc_layers.py) over the stack's time measured HERE (sum of the layers' HIP-event
             # times in the pass above); the algorithmic bytes beside it.
-            pl_path = os.path.join(ROOT, "profiles", "r05_pmc_layers.json")
+            pl_path = os.path.join(ROOT, "profiles", "r06_pmc_layers.json")
             if "roofline" in out and headline and (NET_H, NET_W) == (360, 1176) and os.path.exists(pl_path):
                 plj = json.load(open(pl_path))
                 cs = plj.get("conv_stack", {})
@@ -842,7 +842,7 @@ def main():
                     out["roofline"]["conv_stack_pairs_per_launch"] = round(pairs_per_launch, 3)
                     out["roofline"]["conv_stack_hbm_gbps"] = round(cs["traffic_MB"] * 1e6 * pairs_per_launch / (conv_ms * 1e-3) / 1e9, 1)
                     out["roofline"]["conv_stack_frac_of_hbm_peak"] = round(cs["traffic_MB"] * 1e6 * pairs_per_launch / (conv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
-                    out["roofline"]["conv_stack_traffic_source"] = "profiles/r05_pmc_layers.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over a forward-only loop, per layer; counters include Infinity-Cache hits; same csrc_sha16) / conv_stack_sum of this run"
+                    out["roofline"]["conv_stack_traffic_source"] = "profiles/r06_pmc_layers.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over a forward-only loop, per layer; counters include Infinity-Cache hits; same csrc_sha16) / conv_stack_sum of this run"
         if world == 1 and headline and not args.no_extras and "split" in legs:
             try:
                 # Informational, never `value`: the same workload with the FP32 engine in its opt-in split mode (every fp32 operand as
@@ -1074,6 +1074,31 @@ def main():
                                                   "algorithmic_GBps": round(ogbps, 1) if ogbps else None, "frac_of_hbm_peak": round(ogbps / HBM_PEAK_GBPS, 4) if ogbps else None,
                                                   "conv_stack_sum_ms": round(stack_ms, 4),
                                                   "_source": "separate pass of 50 steps with every stage bracketed by HIP events (runs ~7 % slower than the timed blocks)"}
+                        # HBM traffic of that launch from the committed per-layer counter pass of the same engine (two images per launch there; scaled to
+                        # this leg's mean images per launch by the algorithmic operations), quoted only when collected on THESE kernel sources
+                        pmc_name = {"config3_fp16_192x640": "r06_pmc_layers_fp16_192x640.json", "config5_int8_mbv1_2048kp_fp8": "r06_pmc_layers_int8.json",
+                                    "native_376x1240": None}.get(oname)
+                        ppath = os.path.join(ROOT, "profiles", pmc_name) if pmc_name else None
+                        if ppath and os.path.exists(ppath):
+                            sys.path.insert(0, os.path.join(ROOT, "tools"))
+                            from csrc_hash import csrc_sha16
+                            pj = json.load(open(ppath))
+                            stale = pj.get("csrc_sha16") != csrc_sha16(ROOT)
+                            layers_pj = pj.get("layers", [])
+                            # the counter file lists the engine's launches in order; the dominant stage "conv:<i>" is matched by its name (INT8) or its
+                            # position among the stages of this pass (FP16: the file names layers conv1a ...)
+                            stage_names = [k for k in oprof if k.startswith(("conv:", "heads")) and oprof[k]["calls"]]
+                            row = next((l for l in layers_pj if l.get("layer") == dk), None)
+                            if row is None and dk in stage_names and len(layers_pj) >= len(stage_names):
+                                row = layers_pj[stage_names.index(dk)]
+                            rec["dominant_kernel"]["traffic_stale"] = stale
+                            if row is not None and not stale and row.get("traffic_MB"):
+                                two_img_ops = convs[dk]["flops"]
+                                rec["dominant_kernel"].update({"traffic": int(row["traffic_MB"] * 1e6), "traffic_over_algorithmic": row.get("traffic_over_algorithmic"),
+                                                               "traffic_kernel": row.get("kernel_name", "")[:60],
+                                                               "traffic_source": "profiles/" + pmc_name + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, 2 x FETCH + WRITE; two images per launch; same csrc_sha16)"})
+                            else:
+                                rec["dominant_kernel"]["traffic"] = None
                     out["other_configs"][oname] = rec
                 except Exception as exc:   # the headline line must survive a failure of this informational part
                     out["other_configs"][oname] = {"error": repr(exc)}

@@ -11,6 +11,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "superpoint-ster
 import numpy as np
 from spvo import capi, quant, weights
 capi.tuning_from_env()
+capi.set_tuning("heads_keep_raw", 0)   # the fused blocks and heads as a detector submission runs them (spvo_forward would also store the tensors they skip)
 
 out_path = sys.argv[1]
 graph = sys.argv[2] if len(sys.argv) > 2 else "mbv1"

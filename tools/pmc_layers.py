@@ -12,7 +12,7 @@ import collections, csv, glob, json, os, sys
 
 fetch_dir, write_dir, lr_path, out_path = sys.argv[1:5]
 passes = int(sys.argv[5]) if len(sys.argv) > 5 else 30
-LAYER_KERNELS = ("conv_", "heads_fused", "l2norm", "dwconv", "dwpw_", "maxpool")
+LAYER_KERNELS = ("conv_", "heads_fused", "heads_i8", "l2norm", "dwconv", "dwpw_", "maxpool")
 
 
 def sequence(d, counter):
