@@ -360,7 +360,8 @@ int spvo_solve_stereo_odometry(spvo_ctx *ctx, const spvo_solve_input *in, spvo_s
  * TWO solves may be pending (round 6).  Nothing the device computes for frame k needs frame k - 1's POSE: the RANSAC's
  * minimal solver is prior-free (as cv::solvePnPRansac's P3P is, base.cpp:237-239), the refinement starts from the RANSAC
  * pose, and the one step that does need the motion prior -- the gate, base.cpp:241-272: three subtractions and a compare --
- * is evaluated by the wait on the host.  What frame k needs of frame k - 1 are its 3-D points (base.cpp:323-332), and
+ * is evaluated by the wait on the host (a submission that carries its prior, late_prior = 0, has it evaluated on the device instead, so
+ * that a rejected frame skips its refinement).  What frame k needs of frame k - 1 are its 3-D points (base.cpp:323-332), and
  * `prev_index` refers to them where they lie.  So a caller may submit frame k (late_prior = 1, prev_index) BEFORE it waits
  * for frame k - 1, and hands the prior -- known once k - 1 has been collected -- to spvo_solve_wait_prior.  Results are
  * those of the one-piece call, bit for bit (tests/test_gpu_odometry.py, tests/test_gpu_host.py).  The reference has no

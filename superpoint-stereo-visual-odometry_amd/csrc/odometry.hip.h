@@ -850,8 +850,11 @@ __global__ __launch_bounds__(NT) void pnp_refine_kernel(const double *__restrict
 // as if the gate accepts whenever RANSAC found a model -- refinement included, which starts from the RANSAC pose, never from the prior --
 // and the host discards what a rejecting gate makes void.  So a frame's whole chain can be enqueued before the previous frame's has been
 // collected (spvo_solve_submit with `late_prior`).
-//   hdr (doubles): [0..11] P_l, [12..23] P_r, [24..32] K, [33..38] prior rvec,tvec (unused on the device), [40] refinement_degree
-//   gate_out (doubles): [0..6] start q,t = the RANSAC pose   [7] refinement enqueued (= pnp_ok)   [8] pnp_ok   [10..15] RANSAC rvec, tvec
+// A submission whose prior IS known when it is made (`late_prior` = 0: the one-piece call, the synchronous call sequence) still has the gate
+// evaluated here ([44] = 1), so that a frame the gate rejects does not run a refinement nobody will use; the wait then takes this decision.
+//   hdr (doubles): [0..11] P_l, [12..23] P_r, [24..32] K, [33..38] prior rvec,tvec, [39] frame_count, [40] refinement_degree,
+//                  [41] max_acceleration, [42] time_interval, [43] ignore_frame_count, [44] 1 = gate on the device (the prior fields are valid)
+//   gate_out (doubles): [0..6] start q,t = the RANSAC pose   [7] refinement enqueued (pnp_ok, and the gate where it ran)   [8] pnp_ok   [10..15] RANSAC rvec, tvec
 template <int NT>
 __device__ __forceinline__ void solve_gate_build_body(const double *hdr, const double *ransac_result, const int *inliers, const float *xyz,
                                                       const float *xy_cl, const float *xy_cr, const float *xy_pl, const float *xy_pr,
@@ -866,7 +869,12 @@ __device__ __forceinline__ void solve_gate_build_body(const double *hdr, const d
     const bool ok = ransac_result[6] != 0;
     double r[3], t[3];
     for (int k = 0; k < 3; ++k) { r[k] = ransac_result[k]; t[k] = ransac_result[3 + k]; }   // (no model: the host substitutes its prior)
-    const int do_opt = ok ? 1 : 0;                                                            // the gate itself: spvo_solve_wait (host)
+    int do_opt = ok ? 1 : 0;                                                                  // late prior: the gate itself is spvo_solve_wait_prior's (host)
+    if (ok && hdr[44] != 0) {   // the prior was known at submit time (hdr[33..38], frame count hdr[39]): the gate right here, so that a rejected frame skips its refinement
+      const double dx = t[0] - hdr[36], dy = t[1] - hdr[37], dz = t[2] - hdr[38];
+      const double acc = sqrt(dx * dx + dy * dy + dz * dz) / hdr[42];
+      if ((int)hdr[39] > (int)hdr[43] && acc > hdr[41]) do_opt = 0;
+    }
     double q[4];
     rvec_to_quat(r, q);
     for (int k = 0; k < 4; ++k) gate_out[k] = q[k];

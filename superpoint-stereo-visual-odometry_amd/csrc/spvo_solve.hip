@@ -210,7 +210,10 @@ int spvo_solve_submit(spvo_ctx *c, const spvo_solve_input *in) {
   for (int k = 0; k < 12; ++k) { hdr[k] = in->P_l[k]; hdr[12 + k] = in->P_r[k]; }
   const int kidx[9] = {0, 1, 2, 4, 5, 6, 8, 9, 10};
   for (int k = 0; k < 9; ++k) hdr[24 + k] = in->P_l[kidx[k]];                      // K = P_l[:, :3]  (base.cpp:227)
-  if (!pend.late) for (int k = 0; k < 3; ++k) { hdr[33 + k] = in->rvec_pred[k]; hdr[36 + k] = in->tvec_pred[k]; }   // (carried along; the device does not use the prior)
+  if (!pend.late) {   // the prior is known now: the device evaluates the gate itself (a rejected frame then skips its refinement)
+    for (int k = 0; k < 3; ++k) { hdr[33 + k] = in->rvec_pred[k]; hdr[36 + k] = in->tvec_pred[k]; }
+    hdr[39] = in->frame_count; hdr[41] = 8.0; hdr[42] = 0.1; hdr[43] = 10; hdr[44] = 1;   // hpp:145-147
+  }
   hdr[40] = in->refinement_degree;
   float *fw = (float *)(c->h_solve_in[sl] + 64 * sizeof(double));
   if (n > 0) {
@@ -286,7 +289,7 @@ static int solve_wait_impl(spvo_ctx *c, const double *prior_rvec, const double *
   const int n = pend.n, sl = pend.slot;
   if (n > 0 && (!xyz || !inliers)) return fail(c, SPVO_ERR_INVALID, "bad argument");   // (the solve stays pending)
   if (pend.late && !have_prior) return fail(c, SPVO_ERR_STATE, "the pending solve was submitted with late_prior: complete it with spvo_solve_wait_prior");
-  if (have_prior) {
+  if (have_prior && pend.late) {   // (a submission that carried its own prior keeps it: the device has gated against it)
     for (int k = 0; k < 3; ++k) { pend.rvec[k] = prior_rvec[k]; pend.tvec[k] = prior_tvec[k]; }
     pend.frame_count = prior_frame_count;
   }
@@ -321,7 +324,9 @@ static int solve_wait_impl(spvo_ctx *c, const double *prior_rvec, const double *
   constexpr int IGNORE_FRAME_COUNT = 10;
   const double dx = gate[13] - pend.tvec[0], dy = gate[14] - pend.tvec[1], dz = gate[15] - pend.tvec[2];
   const double acc = std::sqrt(dx * dx + dy * dy + dz * dz) / TIME_INTERVAL;
-  out->accepted = out->pnp_ok && !(pend.frame_count > IGNORE_FRAME_COUNT && acc > MAX_ACCELERATION);
+  // (a submission that carried its prior had the same test evaluated on the device, which then skipped the refinement of a rejected frame: its
+  // decision is the one that counts -- gate[7]; the two evaluations are the same three subtractions, a square root and a division in double)
+  out->accepted = pend.late ? (out->pnp_ok && !(pend.frame_count > IGNORE_FRAME_COUNT && acc > MAX_ACCELERATION)) : (out->pnp_ok && gate[7] != 0);
   if (!out->accepted) { prior_pose(); return SPVO_OK; }                             // (whatever the device refined from the rejected pose is void)
   for (int k = 0; k < 3; ++k) { out->rvec[k] = gate[10 + k]; out->tvec[k] = gate[13 + k]; }
   const bool ran = pend.refinement_degree > 0;

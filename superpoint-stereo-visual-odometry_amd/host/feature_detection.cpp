@@ -310,7 +310,12 @@ bool FeatureFrontEnd::solveStereoOdometrySubmit() {
   si.n = n;
   si.xy_cl = kp_cl.data(); si.xy_cr = kp_cr.data(); si.xy_pl = kp_pl.data(); si.xy_pr = kp_pr.data();
   si.prev_index = prev_index.empty() ? nullptr : prev_index.data();
-  si.late_prior = 1;   // r_vec_pred / t_vec_pred / frame_count: handed over by solveStereoOdometryCollect (the previous frame's may not be in yet)
+  // r_vec_pred / t_vec_pred / frame_count: with an earlier solve still in flight they are not final yet and are handed over by
+  // solveStereoOdometryCollect (late prior: the gate is evaluated there); with none in flight -- the synchronous call sequence -- they go along
+  // now and the device gates (a frame the gate rejects then skips its refinement).  Same decision, same results either way.
+  si.late_prior = solve_q_.empty() ? 0 : 1;
+  for (int k = 0; k < 3; ++k) { si.rvec_pred[k] = r_vec_pred[k]; si.tvec_pred[k] = t_vec_pred[k]; }
+  si.frame_count = frame_count;
   for (int k = 0; k < 12; ++k) { si.P_l[k] = Pl[k]; si.P_r[k] = Pr[k]; }
   si.refinement_degree = refinement_degree_;
   si.ransac = spvo_ransac_opts{500, 2.0, 0.999, ransac_seed};   // base.cpp:239
