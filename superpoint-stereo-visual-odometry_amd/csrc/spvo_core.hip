@@ -1,5 +1,6 @@
 // spvo_core.hip -- context life cycle, engine files (the plan loader: SPVW0003 -> tensors, ops, repacked weights), profiling.
 // Part of the extern "C" shim declared in include/spvo.h; the kernels live in the headers next to this file.
+#include <atomic>
 #include "spvo_internal.hip.h"
 #include <mutex>
 #include "conv_mfma.hip.h"
@@ -40,9 +41,10 @@ int stage_id(spvo_ctx *c, const std::string &name) {
 // ---- diagnostic switches (include/spvo.h: spvo_set_tuning).  One process-wide table, filled by explicit calls only.
 namespace {
 const char *const kTuningNames[] = {"winograd", "wino4", "wino_narrow", "wino_dynamic", "winograd_min_tiles", "wino4_min_tiles", "merge_siblings", "heads_fused",
-                                    "heads_on_net", "heads_split", "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing", "nms_first", "upload_side", "inject_launch_failure", "int8_fused", "pair_always", "preprocess_fused", "heads_keep_raw", "tail_streams", "solve_collect_first"};
+                                    "heads_on_net", "heads_split", "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing", "nms_first", "upload_side", "inject_launch_failure", "int8_fused", "pair_always", "preprocess_fused", "heads_keep_raw", "tail_streams", "solve_collect_first", "graphs"};
 constexpr int kTuningCount = sizeof kTuningNames / sizeof kTuningNames[0];
 std::mutex g_tuning_mutex;
+std::atomic<unsigned> g_tuning_gen{1};   // grows with every spvo_set_tuning / spvo_clear_tuning: launch code reads switches as it goes, so recorded launch segments depend on them
 bool g_tuning_set[kTuningCount] = {};
 int g_tuning_value[kTuningCount] = {};
 int tuning_index(const char *name) {
@@ -134,7 +136,118 @@ void choose_variant(int ks, int H, int W, int co_tiles, int batch, bool pool, in
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- launch segments
+// (spvo_internal.hip.h, top: what they are and why)
+__thread LaunchRecorder *t_rec = nullptr;
+unsigned tuning_generation() { return g_tuning_gen.load(); }
+
+void rec_flush_direct(LaunchRecorder *r) {
+  for (const LaunchNode &n : r->nodes) {
+    void *params[33];
+    for (int i = 0; i < n.n_args; ++i) params[i] = r->arena.data() + n.arg_off[i];
+    (void)hipLaunchKernel(n.func, n.grid, n.block, params, n.lds, r->stream);
+  }
+  r->nodes.clear();
+  r->used = 0;
+}
+
+static void seg_drop(GraphEntry &e) {
+  if (e.exec) (void)hipGraphExecDestroy(e.exec);
+  if (e.graph) (void)hipGraphDestroy(e.graph);
+  e = GraphEntry();
+}
+
+void seg_free_all(spvo_ctx *c) {
+  for (int r = 0; r < RING; ++r) {
+    for (int k = 0; k < 2; ++k) { seg_drop(c->seg_T[r][k]); seg_drop(c->seg_H[r][k]); }
+    seg_drop(c->seg_A[r]);
+    seg_drop(c->seg_B[r]);
+  }
+}
+
+bool seg_begin(spvo_ctx *c, GraphEntry *e, unsigned long long key, hipStream_t stream) {
+  LaunchRecorder &r = c->rec;
+  if (!c->use_graphs || !e || e->never || t_rec) return false;   // (with the profiler on, a segment that holds a timed stage is flushed by the stage's first event)
+  if (r.arena.empty()) r.arena.resize(64 << 10);
+  r.active = true; r.poisoned = false; r.stream = stream; r.entry = e; r.key = key;
+  r.nodes.clear();
+  r.used = 0;
+  t_rec = &r;
+  return true;
+}
+
+int seg_end(spvo_ctx *c) {
+  LaunchRecorder &r = c->rec;
+  if (t_rec != &r) return SPVO_OK;
+  t_rec = nullptr;
+  const bool was_active = r.active;
+  r.active = false;
+  if (r.poisoned || !was_active) return SPVO_OK;   // (flushed already; what came behind went out as plain launches)
+  GraphEntry &e = *r.entry;
+  const size_t n = r.nodes.size();
+  if (n == 0) return SPVO_OK;
+  auto dim_code = [](const LaunchNode &q) {
+    return ((unsigned long long)q.grid.x << 40) ^ ((unsigned long long)q.grid.y << 28) ^ ((unsigned long long)q.grid.z << 20) ^ ((unsigned long long)q.block.x << 8) ^ (unsigned long long)q.lds * 0x9E3779B1ull;
+  };
+  if (e.valid && e.key == r.key && e.funcs.size() == n) {
+    bool same = true;
+    for (size_t i = 0; i < n && same; ++i) same = e.funcs[i] == r.nodes[i].func && e.dims[i] == dim_code(r.nodes[i]);
+    if (same && ::hipGraphLaunch(e.exec, r.stream) == hipSuccess) {
+      ++r.graph_launches;
+      c->stages[stage_id(c, "segment_graph_launch")].calls += 1;   // (counted with profiling off too: tests and bench.py read it)
+      r.nodes.clear();
+      r.used = 0;
+      return SPVO_OK;
+    }
+    seg_drop(e);   // not the segment it was recorded as (or the replay failed): plain launches now, a new graph next time
+  }
+  // plain launches; and a graph for the next time when this key comes by the second time in a row for this entry (a key that keeps changing
+  // would pay an instantiation per launch)
+  const bool build = e.seen_key == r.key && n >= 2;
+  e.seen_key = r.key;
+  ++r.direct_segments;
+  c->stages[stage_id(c, "segment_plain_launch")].calls += 1;
+  for (const LaunchNode &q : r.nodes) {   // (the nodes stay recorded: the graph below is built from them)
+    void *params[33];
+    for (int a = 0; a < q.n_args; ++a) params[a] = r.arena.data() + q.arg_off[a];
+    (void)hipLaunchKernel(q.func, q.grid, q.block, params, q.lds, r.stream);
+  }
+  if (build) {
+    seg_drop(e);
+    e.seen_key = r.key;
+    bool ok = ::hipGraphCreate(&e.graph, 0) == hipSuccess;
+    hipGraphNode_t prev = nullptr;
+    for (size_t i = 0; i < n && ok; ++i) {
+      const LaunchNode &q = r.nodes[i];
+      void *params[33];
+      for (int a = 0; a < q.n_args; ++a) params[a] = r.arena.data() + q.arg_off[a];
+      hipKernelNodeParams kp{};
+      kp.func = const_cast<void *>(q.func);
+      kp.gridDim = q.grid; kp.blockDim = q.block; kp.sharedMemBytes = q.lds;
+      kp.kernelParams = params; kp.extra = nullptr;
+      hipGraphNode_t node = nullptr;
+      ok = ::hipGraphAddKernelNode(&node, e.graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp) == hipSuccess;
+      prev = node;
+    }
+    if (ok) ok = ::hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0) == hipSuccess;
+    if (ok) {
+      e.valid = true; e.key = r.key;
+      e.funcs.clear(); e.dims.clear();
+      for (const LaunchNode &q : r.nodes) { e.funcs.push_back(q.func); e.dims.push_back(dim_code(q)); }
+    } else {
+      (void)hipGetLastError();
+      seg_drop(e);
+      e.never = true;   // this segment cannot be a graph here: never try again
+    }
+  }
+  r.nodes.clear();
+  r.used = 0;
+  return SPVO_OK;
+}
+
 void free_plan(spvo_ctx *c) {
+  seg_free_all(c);
+  ++c->plan_gen;
   for (auto &t : c->tensors) {
     if (t.d) (void)hipFree(t.d);
     for (int r = 1; r < RING; ++r) if (t.dr[r]) (void)hipFree(t.dr[r]);
@@ -857,6 +970,7 @@ int spvo_load_weights(spvo_ctx *c, const char *path) {
       // launches of one 512-thread workgroup per CU (conv_wino4.hip.h), beside which they would starve; on the tail stream otherwise
     double all = 0, big = 0;
     for (const auto &o : c->ops) if (o.type == OP_CONV) { all += o.flops_per_image; if (o.wino4) big += o.flops_per_image; }
+    c->use_graphs = tuning("graphs", 1) == 2 || ((c->fp16 || c->int8) && tuning("graphs", 1) != 0);   // launch segments as HIP graphs: where the host bounds the frame loop
     c->heads_on_net = big > 0.8 * all;   // VGG fp32 at 360x1176: 0.95 (on the network stream: 1308 against 1260 frames/s); sp_squeeze: 0.66 (tail stream: 1286 against 1248)
   }
   const Tensor &td = c->tensors[c->t_det];
@@ -936,6 +1050,7 @@ int spvo_set_tuning(const char *name, int value) {
   std::lock_guard<std::mutex> lock(g_tuning_mutex);
   g_tuning_set[i] = true;
   g_tuning_value[i] = value;
+  ++g_tuning_gen;
   return SPVO_OK;
 }
 
@@ -944,6 +1059,7 @@ int spvo_get_tuning(const char *name, int dflt) { return tuning(name, dflt); }
 void spvo_clear_tuning(void) {
   std::lock_guard<std::mutex> lock(g_tuning_mutex);
   for (int i = 0; i < kTuningCount; ++i) g_tuning_set[i] = false;
+  ++g_tuning_gen;
 }
 
 int spvo_profile_stage_kernel(spvo_ctx *c, const char *stage, char *name, size_t name_cap, double *executed_per_algorithmic) {

@@ -632,8 +632,18 @@ static int launch_group_body(spvo_ctx *c) {
   const bool prof_detect = c->prof && (c->prof_only < 0 || c->prof_only == stage_id(c, "detect"));
   if (prof_detect) { det_e0 = get_event(c); (void)hipEventRecord(det_e0, c->stream); }
   int rc;
+  const int hon = tuning("heads_on_net", -1);
+  const bool heads_on_net = hon < 0 ? c->heads_on_net : hon != 0;
+  bool any_res0 = false;
+  for (int m = 0; m < n; ++m) any_res0 = any_res0 || mem[m]->early_res;
+  const long long gen = ((long long)c->plan_gen << 32) | tuning_generation();
   {
     ScopedStage net(c, stage_id(c, "net"));
+    // launch segment T: the group's trunk (and its heads where they stay on the network stream) -- not for a group whose first layer also
+    // preprocesses (its arguments are the caller's image pointers) or whose resized images leave through the tail stream in between
+    const bool seg_t = !mem[0]->pre_pending && !any_res0 &&
+                       seg_begin(c, &c->seg_T[tring][n - 1], seg_key({1, tring, batch, gen, heads_on_net ? 1 : 0, (long long)c->head_start}), c->stream);
+    (void)seg_t;
     rc = mem[0]->pre_pending ? launch_first_pre(c, mem, n, c->stream) : run_ops(c, batch, 0, std::min<size_t>(1, c->head_start), c->stream);
     for (int m = 0; m < n; ++m) mem[m]->pre_pending = false;
     // The resized images leave for their sets' pinned mirrors UNDER the network: a copy kernel (16 bytes per lane, no SDMA engine involved)
@@ -655,19 +665,18 @@ static int launch_group_body(spvo_ctx *c) {
     }
     if (!rc) rc = run_ops(c, batch, std::min<size_t>(1, c->head_start), c->head_start, c->stream);
   }
-  if (rc) { c->cur_ring = 0; return rc; }
+  if (rc) { (void)seg_end(c); c->cur_ring = 0; return rc; }
   c->last_batch = batch;
   // The heads (2.2 GFLOP: the one heavy piece behind the trunk): on the network stream, in front of the next pair's trunk, when the
   // trunk is made of persistent one-workgroup-per-CU launches (VGG fp32: beside the next pair's conv1b they would have 12 CUs, the
   // tail would finish late and the network stream idle 50-70 us per pair: 1257-1265 against 1308 frames/s); on the tail stream
   // otherwise, where the overlap pays (sp_squeeze fp32 1286 against 1248 frames/s, INT8 sp_mbv1 2360 against 2237).  The plan
   // loader decides (spvo_ctx::heads_on_net); tuning "heads_on_net" = 0 / 1 overrides (measurements).
-  const int hon = tuning("heads_on_net", -1);
-  const bool heads_on_net = hon < 0 ? c->heads_on_net : hon != 0;
   if (heads_on_net) {
     rc = run_ops(c, batch, c->head_start, c->ops.size(), c->stream);
-    if (rc) { c->cur_ring = 0; return rc; }
+    if (rc) { (void)seg_end(c); c->cur_ring = 0; return rc; }
   }
+  if ((rc = seg_end(c))) { c->cur_ring = 0; return rc; }   // segment T goes out here: one graph launch, or its kernels one by one
   if (trunk_timing) (void)hipEventRecord(tt_e[tt_n % TT], c->stream);
   for (int m = 0; m < n; ++m) HIP_TRY(c, hipEventRecord(c->ev_net[mem[m]->ring], c->stream));
   c->last_launch_ring = mem[n - 1]->ring;
@@ -687,7 +696,9 @@ static int launch_group_body(spvo_ctx *c) {
   if (trunk_timing) (void)hipEventRecord(tt_tb[tt_n % TT], ts0);
   c->post = ts0;
   if (!heads_on_net) {
+    seg_begin(c, &c->seg_H[tring][n - 1], seg_key({2, tring, batch, gen, (long long)c->head_start}), ts0);   // launch segment H: the heads
     rc = run_ops(c, batch, c->head_start, c->ops.size(), ts0);   // heads: on the (first pair's) tail stream, reading this group's ring buffers
+    { const int rce = seg_end(c); if (!rc) rc = rce; }
     if (!rc && n == 2 && mem[1]->ts != mem[0]->ts) {
       HIP_TRY(c, hipEventRecord(c->ev_heads[tring], ts0));
       HIP_TRY(c, hipStreamWaitEvent(tstreams[mem[1]->ts], c->ev_heads[tring], 0));
@@ -704,6 +715,8 @@ static int launch_group_body(spvo_ctx *c) {
     hipStream_t tsm = tstreams[pd.ts];
     c->post = tsm;
     c->ms_set = pd.ts;
+    // launch segment A: heat map, NMS rounds + finish, rank, write, sampling -- eight dependent kernels up to ev_feat
+    seg_begin(c, &c->seg_A[ring], seg_key({3, ring, tring, pd.img0, pd.slot_l, pd.slot_r, gen, c->tail_streams, c->nms_first, c->cfg.max_keypoints}), tsm);
     {
       // heat map + threshold + candidate list in one kernel; the counter block of this set was
       // zeroed by the previous submission's last NMS kernel (or at allocation)
@@ -717,13 +730,19 @@ static int launch_group_body(spvo_ctx *c) {
       rc = launch_nms_rounds(c, 2, np, ring, c->nms_first, c->d_counters_all + (size_t)(((ring + c->tail_streams) % RING) * 2) * NMS_COUNTER_INTS);
     }
     if (!rc) rc = enqueue_sample(c, slots, np, ring, tring, pd.img0);
+    { const int rce = seg_end(c); if (!rc) rc = rce; }
     // Keypoints, counts and descriptors are final here: spvo_detect_wait / _collect waits for THIS point (ev_feat); the matches enqueued
     // behind it are waited for where they are asked for (spvo_match_slots, ev_tail).
     if (!rc) rc = hipEventRecord(c->ev_feat[ring], tsm) == hipSuccess ? SPVO_OK : fail(c, SPVO_ERR_DEVICE, "hipEventRecord failed");
     if (!rc && c->prematch) {
       // (two tail streams: the temporal partner's features come from the submission before, on the other stream)
       if (c->tail_streams == 2 && pd.prev_l >= 0) HIP_TRY(c, hipStreamWaitEvent(tsm, c->ev_feat[(ring + RING - 1) % RING], 0));
+      // launch segment B: the pair's two matches (distance GEMM + merge; the fp8 shortlist's conversions and re-rank)
+      unsigned ratio_bits;
+      std::memcpy(&ratio_bits, &c->pm_ratio, 4);
+      seg_begin(c, &c->seg_B[ring], seg_key({4, ring, pd.slot_l, pd.slot_r, pd.prev_l, gen, c->pm_selector, c->pm_cross, (long long)ratio_bits, c->match_fp8 ? 1 : 0, pd.ts}), tsm);
       rc = enqueue_prematch(c, pd.slot_l, pd.slot_r, pd.prev_l, ring);
+      { const int rce = seg_end(c); if (!rc) rc = rce; }
     }
     if (!rc && prof_detect) {   // "detect" spans both streams: first kernel on `stream` .. last kernel on the tail stream
       hipEvent_t e1 = get_event(c);

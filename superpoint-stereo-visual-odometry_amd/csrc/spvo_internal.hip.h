@@ -29,6 +29,8 @@
 #pragma GCC visibility push(hidden)
 using namespace spvo;
 
+#include "launch_segments.hip.h"
+
 namespace spvo_int {
 
 constexpr int RING = 8;          // buffer sets a detector submission owns (network outputs, heat map, NMS state, counters, host mirrors)
@@ -186,6 +188,11 @@ struct spvo_ctx {
   bool split_req = false;          // spvo_set_fp32_split / SPVO_FP32_SPLIT: FP32 engines loaded from now on run on the bf16x3 kernels
   bool s3 = false;                 // the loaded FP32 engine runs in split mode
   size_t head_start = 0;           // ops [head_start, end) = the 1x1 heads + L2 norm: a submission runs them on the tail stream
+  // launch segments replayed from HIP graphs (top of this file): on for FP16 / INT8 engines (tuning "graphs": 0 off, 2 on for every engine)
+  bool use_graphs = false;
+  unsigned plan_gen = 0;           // grows with every engine load: part of every segment key
+  LaunchRecorder rec;
+  GraphEntry seg_T[RING][2], seg_H[RING][2], seg_A[RING], seg_B[RING];   // trunk / heads per (network set, pairs in the group); tail halves per submission set
   bool heads_fused = false;        // ... as ONE launch (heads.hip.h): FP32 engines whose tail is convPb (256 -> 65), convDb (256 -> 256), L2 norm
   bool heads_keep_raw = false;     // the fused launch also stores the un-normalised descriptor planes (spvo_forward / spvo_debug_tensor)
   float *d_heads_w = nullptr;      // pack_heads_weights()
@@ -342,6 +349,17 @@ int tuning(const char *name, int dflt);
 int release_held_if_idle(spvo_ctx *c);
 hipEvent_t get_event(spvo_ctx *c);
 void resolve_pending(spvo_ctx *c);
+// launch segments (spvo_core.hip): seg_begin opens one on `stream` when graphs are on for this context (and the profiler is off) and returns
+// whether it did; seg_end closes it -- graph replay, or plain launches + a graph for the next time; seg_free_all drops every graph
+bool seg_begin(spvo_ctx *c, GraphEntry *e, unsigned long long key, hipStream_t stream);
+int seg_end(spvo_ctx *c);
+void seg_free_all(spvo_ctx *c);
+unsigned tuning_generation();
+inline unsigned long long seg_key(std::initializer_list<long long> v) {
+  unsigned long long h = 1469598103934665603ull;
+  for (long long x : v) { h ^= (unsigned long long)x + 0x9E3779B97F4A7C15ull; h *= 1099511628211ull; }
+  return h | 1ull;   // never 0
+}
 
 struct ScopedStage {
   spvo_ctx *c;

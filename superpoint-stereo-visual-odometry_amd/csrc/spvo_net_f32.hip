@@ -150,7 +150,7 @@ int launch_conv(spvo_ctx *c, const Op &op, int img0, int batch, hipStream_t stre
   if (op.cin == 1) {
     dim3 grid((ti.W + 63) / 64, (ti.H + 3) / 4, batch);
 #define SPVO_FIRST(KS, RELU) hipLaunchKernelGGL((conv_first_kernel<KS, RELU>), grid, dim3(256), 0, stream, tin, tout, op.d_w, op.d_b, \
-                                                op.d_bn_scale, op.d_bn_shift, ti.H, ti.W, ti.hp, ti.wp, to.ch, op.out_c_off, op.cout)
+                                                op.d_bn_scale, op.d_bn_shift, ti.H, ti.W, ti.hp, ti.wp, to.ch, op.out_c_off, op.cout, 0)
     if (op.ks == 3 && !op.d_bn_scale) {   // 4 pixels per thread: 16-byte stores
       dim3 g4((ti.W + 255) / 256, (ti.H + 3) / 4, batch);
       if (relu) hipLaunchKernelGGL(conv_first4_kernel<true>, g4, dim3(256), 0, stream, tin, tout, op.d_w, op.d_b, ti.H, ti.W, ti.hp, ti.wp, to.ch, op.out_c_off, op.cout);

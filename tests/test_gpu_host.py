@@ -508,3 +508,43 @@ def test_a_node_like_caller_linked_against_the_host_library_runs(tmp_path, squee
     got_c = run(True, 2.0, 0, 0)
     ref_c, stats, _ = host.classic_sequence(frames, P_l, P_r, "KNN", True, 2.0, 4)
     assert np.array_equal(got_c[1:], ref_c[1:]) and (stats[1:, 3] > 300).all()
+
+
+@pytest.mark.parametrize("precision", ["FP16", "INT8"])
+def test_launch_segments_replayed_from_graphs_do_not_change_results(tmp_path, squeeze_weights_path, sequence, precision, tuning):
+    """Round 6: for FP16 / INT8 engines the runs of kernel launches between two event operations of a submission -- a group's trunk, its heads,
+    a pair's heat map + NMS + sampling, its two matches -- are recorded and, from the third time the same run (same buffer set, slots, batch,
+    engine and tuning generation) comes by, replayed from a captured HIP graph: one hipGraphLaunch instead of up to eleven launches
+    (csrc/launch_segments.hip.h; tuning "graphs" = 0 keeps plain launches).  Over 48 frames of the block loop with four pairs announced
+    ahead and trunk pairing: every pose, every solver outcome and the keypoint / match counts of every frame are identical bit for bit with
+    and without, and most segments do go out as replays."""
+    import torch
+    from spvo import quant
+    from oracle import frontend as ofe
+    frames, poses, P_l, P_r = sequence
+    d = tmp_path / "models"
+    os.makedirs(d / "laptop")
+    plan = weights.load(squeeze_weights_path) if precision == "FP16" else weights.load(os.path.join(os.path.dirname(squeeze_weights_path), "sp_mbv1.spvw"))
+    prefix = "sp_squeeze" if precision == "FP16" else "sp_mbv1"
+    if precision == "INT8":
+        x = np.stack([ofe.to_network_input(ofe.preprocess(img, P_l, 360, 1176, True)[0]) for img in frames[0]])[:, None]
+        plan.act_scales = quant.calibrate(plan, [x], 360, 1176)
+    weights.save(plan, str(d / "laptop" / weights.engine_name(prefix, 2, 360, 1176, precision)), precision=precision)
+    order = [0, 1, 2, 3, 4, 3, 2, 1]
+    dev = [(torch.from_numpy(frames[f][0]).cuda().clone(), torch.from_numpy(frames[f][1]).cuda().clone()) for f in order]
+    dl, dr = [a.data_ptr() for a, _ in dev], [b.data_ptr() for _, b in dev]
+    rows, cols, stride = frames[0][0].shape[0], frames[0][0].shape[1], dev[0][0].stride(0)
+    out = {}
+    for graphs in (0, 1):
+        tuning(graphs=graphs)
+        fe = host.FrontEnd(str(d), prefix=prefix, precision=precision)
+        assert fe.engine_loaded, fe.last_error
+        recs = [fe.run_device_block(dl, dr, rows, cols, stride, P_l, P_r, first, 16, depth=4, deferred=True) for first in (0, 16, 32)]
+        prof = fe.context().profile()
+        out[graphs] = (np.concatenate(recs), prof.get("segment_graph_launch", {}).get("calls", 0), prof.get("segment_plain_launch", {}).get("calls", 0))
+        fe.close()
+    a, b = out[0][0], out[1][0]
+    for field in ("q", "t", "has_pose", "pnp_ok", "accepted", "refined", "lm_iterations", "pnp_inliers", "stereo_matches", "keypoints_left"):
+        assert np.array_equal(a[field], b[field]), field
+    assert out[0][1] == 0 and out[0][2] == 0                       # tuning "graphs" = 0: no segment is ever opened
+    assert out[1][1] > out[1][2] > 0, out[1][1:]                    # replays outnumber the plain launches of the first two rounds of every buffer set
