@@ -165,8 +165,17 @@ void seg_free_all(spvo_ctx *c) {
   }
 }
 
+void seg_abort(spvo_ctx *c) {
+  LaunchRecorder &r = c->rec;
+  if (t_rec == &r) t_rec = nullptr;
+  r.active = false; r.poisoned = false;
+  r.nodes.clear();
+  r.used = 0;
+}
+
 bool seg_begin(spvo_ctx *c, GraphEntry *e, unsigned long long key, hipStream_t stream) {
   LaunchRecorder &r = c->rec;
+  if (t_rec == &r) seg_abort(c);   // (an error return between a begin and its end left it open: what it held was never launched and belongs to a failed submission)
   if (!c->use_graphs || !e || e->never || t_rec) return false;   // (with the profiler on, a segment that holds a timed stage is flushed by the stage's first event)
   if (r.arena.empty()) r.arena.resize(64 << 10);
   r.active = true; r.poisoned = false; r.stream = stream; r.entry = e; r.key = key;
@@ -207,10 +216,17 @@ int seg_end(spvo_ctx *c) {
   e.seen_key = r.key;
   ++r.direct_segments;
   c->stages[stage_id(c, "segment_plain_launch")].calls += 1;
+  hipError_t first_err = hipSuccess;
   for (const LaunchNode &q : r.nodes) {   // (the nodes stay recorded: the graph below is built from them)
     void *params[33];
     for (int a = 0; a < q.n_args; ++a) params[a] = r.arena.data() + q.arg_off[a];
-    (void)hipLaunchKernel(q.func, q.grid, q.block, params, q.lds, r.stream);
+    const hipError_t le = hipLaunchKernel(q.func, q.grid, q.block, params, q.lds, r.stream);
+    if (le != hipSuccess && first_err == hipSuccess) first_err = le;
+  }
+  if (first_err != hipSuccess) {   // what the enqueueing code's own hipGetLastError checks would have seen with plain launches
+    r.nodes.clear();
+    r.used = 0;
+    return fail(c, SPVO_ERR_DEVICE, "kernel launch failed (%s) in a launch segment", hipGetErrorString(first_err));
   }
   if (build) {
     seg_drop(e);

@@ -526,6 +526,7 @@ static int launch_group(spvo_ctx *c, bool from_submit) {
   const int rc = launch_group_body(c);
   if (rc == SPVO_OK) return rc;
   const std::string why = c->error;
+  seg_abort(c);   // (a launch segment the failing path left open: its kernels were never launched)
   c->held = 0;
   c->post = c->stream;
   c->cur_ring = 0;
@@ -636,7 +637,7 @@ static int launch_group_body(spvo_ctx *c) {
   const bool heads_on_net = hon < 0 ? c->heads_on_net : hon != 0;
   bool any_res0 = false;
   for (int m = 0; m < n; ++m) any_res0 = any_res0 || mem[m]->early_res;
-  const long long gen = ((long long)c->plan_gen << 32) | tuning_generation();
+  const long long gen = ((long long)c->plan_gen << 40) ^ ((long long)c->alloc_gen << 20) ^ (long long)tuning_generation();   // engine, buffers, switches
   {
     ScopedStage net(c, stage_id(c, "net"));
     // launch segment T: the group's trunk (and its heads where they stay on the network stream) -- not for a group whose first layer also
@@ -878,6 +879,7 @@ static int detect_wait(spvo_ctx *c, double P_l[12], double P_r[12], spvo_feature
 static int ensure_host_sets(spvo_ctx *c, size_t image_bytes) {
   const size_t hw2 = (size_t)2 * c->H * c->W, desc = (size_t)2 * c->cfg.max_keypoints * 256;
   if (!c->host_sets_ready) {   // (a flag of its own: a failure half-way must not look like "allocated" to the next call)
+    ++c->alloc_gen;   // (pinned buffers recorded launch segments may point to: a new generation of segment keys)
     for (int r = 0; r < RING; ++r) {
       if (!c->d_resized_r[r]) { int rc = dev_alloc(c, &c->d_resized_r[r], hw2, false); if (rc) return rc; }
       if (!c->h_resized_r[r]) HIP_TRY(c, hipHostMalloc((void **)&c->h_resized_r[r], hw2));
@@ -886,6 +888,7 @@ static int ensure_host_sets(spvo_ctx *c, size_t image_bytes) {
     c->host_sets_ready = true;
   }
   if (image_bytes > c->img_cap_r) {
+    ++c->alloc_gen;
     if (!c->pendq.empty()) return fail(c, SPVO_ERR_STATE, "the image size grew while submissions are in flight");
     HIP_TRY(c, hipDeviceSynchronize());
     for (int r = 0; r < RING; ++r) {

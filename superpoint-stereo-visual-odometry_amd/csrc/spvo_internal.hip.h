@@ -191,6 +191,7 @@ struct spvo_ctx {
   // launch segments replayed from HIP graphs (top of this file): on for FP16 / INT8 engines (tuning "graphs": 0 off, 2 on for every engine)
   bool use_graphs = false;
   unsigned plan_gen = 0;           // grows with every engine load: part of every segment key
+  unsigned alloc_gen = 0;          // ... and so does this, with every device / pinned-host allocation of the context (dev_alloc, ensure_host_sets, the matcher's buffers)
   LaunchRecorder rec;
   GraphEntry seg_T[RING][2], seg_H[RING][2], seg_A[RING], seg_B[RING];   // trunk / heads per (network set, pairs in the group); tail halves per submission set
   bool heads_fused = false;        // ... as ONE launch (heads.hip.h): FP32 engines whose tail is convPb (256 -> 65), convDb (256 -> 256), L2 norm
@@ -335,6 +336,7 @@ int fail(spvo_ctx *c, int code, const char *fmt, ...);
 
 template <typename T>
 int dev_alloc(spvo_ctx *c, T **p, size_t count, bool zero = true) {
+  ++c->alloc_gen;   // (a recorded launch segment holds device pointers: every allocation starts a new generation of segment keys)
   HIP_TRY(c, hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T)));
   if (zero) HIP_TRY(c, hipMemsetAsync(*p, 0, std::max<size_t>(count, 1) * sizeof(T), c->stream));
   return SPVO_OK;
@@ -353,6 +355,7 @@ void resolve_pending(spvo_ctx *c);
 // whether it did; seg_end closes it -- graph replay, or plain launches + a graph for the next time; seg_free_all drops every graph
 bool seg_begin(spvo_ctx *c, GraphEntry *e, unsigned long long key, hipStream_t stream);
 int seg_end(spvo_ctx *c);
+void seg_abort(spvo_ctx *c);      // drops an open segment without launching it (a failed group launch; a stale one found at the next begin)
 void seg_free_all(spvo_ctx *c);
 unsigned tuning_generation();
 inline unsigned long long seg_key(std::initializer_list<long long> v) {

@@ -45,6 +45,7 @@ int ensure_match(spvo_ctx *c, int na, int nb) {
     if ((rc = dev_alloc(c, &m.d_qb8, cap))) return rc;
     m.d_out = c->d_match_out + (size_t)k4 * cap;
   }
+  ++c->alloc_gen;
   for (int r = 0; r < RING; ++r) HIP_TRY(c, hipHostMalloc((void **)&c->h_match_out[r], (size_t)2 * cap * sizeof(int2)));
   HIP_TRY(c, hipHostMalloc((void **)&c->h_match_tmp, (size_t)cap * sizeof(int2)));
   for (int par = 0; par < RING; ++par)
