@@ -191,3 +191,31 @@ def _rot_to_rvec(R):
         return np.zeros(3)
     ax = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / (2 * np.sin(a))
     return ax * a
+
+
+@pytest.mark.parametrize("depth", [2, 4])
+def test_long_sequence_block_loop_with_two_solves_in_flight_equals_the_call_sequence(gpu_run, long_sequence, models_dir, depth):
+    """The same 44 frames through the loop bench.py times (spvo_host_run_device_block: `depth` pairs announced ahead, trunk pairing at 4, the
+    solve of frame k submitted BEFORE frame k - 1's is collected -- late prior, the gate evaluated on the host at collect time, the previous
+    frame's points referred to by index on the device) against the synchronous call sequence of `gpu_run` (the gate on the device, one
+    solve at a time): every pose bit for bit, every pnp-ok / accepted / refined flag, LM iteration count, inlier and match count -- the
+    planted jump after frame 12 is rejected by the host-side gate exactly as by the device-side one."""
+    import torch
+    frames, poses, P_l, P_r = long_sequence
+    dev = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
+    dl, dr = [a.data_ptr() for a, _ in dev], [b.data_ptr() for _, b in dev]
+    rows, cols, stride = frames[0][0].shape[0], frames[0][0].shape[1], dev[0][0].stride(0)
+    fe = host.FrontEnd(models_dir, prefix="sp_squeeze", selector="KNN", cross_check=True)
+    assert fe.engine_loaded, fe.last_error
+    # (the cycle is the whole sequence: frame k of the block = pair k; the loop announces beyond the end, wrapping to pair 0, which is never collected)
+    rec = np.concatenate([fe.run_device_block(dl, dr, rows, cols, stride, P_l, P_r, first, n, depth=depth, deferred=True) for first, n in ((0, 20), (20, N_FRAMES - 20))])
+    fe.close()
+    assert rec["has_pose"][0] == 0 and rec["has_pose"][1:].all()
+    for k in range(1, N_FRAMES):
+        g = gpu_run[k]
+        gq, gt = g["res"]
+        assert np.array_equal(rec["q"][k], gq) and np.array_equal(rec["t"][k], gt), k          # poses: bit-identical
+        f = g["flags"]
+        assert (bool(rec["pnp_ok"][k]), bool(rec["accepted"][k]), bool(rec["refined"][k]), int(rec["lm_iterations"][k])) == (f["pnp_ok"], f["accepted"], f["refined"], f["lm_iterations"]), k
+        assert rec["pnp_inliers"][k] == len(g["pnp"]) and rec["keypoints_left"][k] == len(g["kp_l"]) and rec["stereo_matches"][k] == (g["maps"][0] >= 0).sum(), k
+    assert not rec["accepted"][JUMP_GATED] and rec["accepted"][JUMP_EARLY]
