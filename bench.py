@@ -477,6 +477,9 @@ def main():
     small_engine = args.precision in ("FP16", "INT8")
     if small_engine and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 8:
         capi.set_tuning("tail_streams", 2)   # (BASELINE configs 3 / 5 as this script's own workload: as in the `other_configs` legs below)
+    keep2_main = args.precision == "FP16"    # engines whose frame is shorter than the solver's chain (config 3); config 5's INT8 trunk paces its loop: no gain, one frame more latency
+    if keep2_main:
+        capi.set_tuning("solve_keep", 2)     # two solves stay pending behind every submit: a frame's last solver kernel goes out with the next frame's hypotheses
     capi.tuning_from_env()   # SPVO_TUNE_<NAME>=<int>: diagnostic switches for A/B runs of this script (the library itself never reads the environment)
     if args.fp32_split:
         capi.set_tuning("fp32_split", 1)   # engines loaded from here on run in split mode (the library reads no environment variable for it)
@@ -733,6 +736,7 @@ def main():
                        "host_cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),   # the HIP runtime's queue count this process asked for (used by the FP16 / INT8 legs' second tail stream)
                        "tail_streams": capi.get_tuning("tail_streams", 1),
+                       "solves_kept_pending": capi.get_tuning("solve_keep", 1),   # behind every submit of the block loop (2: a frame's last solver kernel goes out in one launch with the next frame's hypotheses)
                        "hand_over": ("images of the next %d pairs handed over ahead (prefetchStereoImagePairDevice)" % args.depth + ("; with four ahead the front end pairs trunks: a pair whose network would only queue waits for its successor and the two run through every layer in one launch (spvo_set_trunk_pairing)" if args.depth >= 4 else "") if not args.no_pipeline else "one pair at a time")
                                     + ("; each frame's solve handed over too, its pose collected during the next step (solveStereoOdometrySubmit / Collect), the last one before the closing barrier" if deferred else ""),
                        "pose_gather": {"local": "single stream, no collective", "c:rccl": "spvo_pose_allgather_n (C ABI, RCCL), one collective per 64 frames",
@@ -1029,6 +1033,9 @@ def main():
                     two_tails = oprec in ("FP16", "INT8") and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 8 and "SPVO_TUNE_TAIL_STREAMS" not in os.environ
                     if two_tails:
                         capi.set_tuning("tail_streams", 2)   # read when the engine is loaded; the FP32 legs keep one tail stream
+                    keep2 = oprec == "FP16" and "SPVO_TUNE_SOLVE_KEEP" not in os.environ
+                    if "SPVO_TUNE_SOLVE_KEEP" not in os.environ:
+                        capi.set_tuning("solve_keep", 2 if keep2 else 1)   # read when the front end creates its context, and by the block loop: reset behind the leg
                     try:
                         fe = host.FrontEnd(odir, prefix=oprefix, selector="KNN", cross_check=True, batch=2, height=oh, width=ow, conf_thresh=0.015,
                                            dist_thresh=4, border_remove=4, stereo_threshold=2.0, min_disparity=0.25, refinement_degree=4, precision=oprec)
@@ -1042,7 +1049,7 @@ def main():
                     fe.finish_solve()
                     eo, spo, fso = leg_frames()
                     rec = {"what": owhat, "value": round(args.steps / eo, 2), "unit": "stereo frames/s", "ms_per_step": round(1e3 * eo / args.steps, 4), **spo, **fso,
-                           "dtype": {"FP32": "f32", "FP16": "f16", "INT8": "i8"}[oprec], "tail_streams": 2 if two_tails else 1,
+                           "dtype": {"FP32": "f32", "FP16": "f16", "INT8": "i8"}[oprec], "tail_streams": 2 if two_tails else 1, "solves_kept_pending": 2 if keep2 else capi.get_tuning("solve_keep", 1),
                            "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                            "workload": (f"SuperPoint VGG {oprec.lower()} (seeded synthetic weights, {o_params} params)" if ograph == "vgg" else
                                         f"SuperPoint {ograph} {oprec.lower()} (the reference's TRAINED ONNX graph, {o_params} params; activation scales calibrated on this stream)")
@@ -1102,6 +1109,9 @@ def main():
                     out["other_configs"][oname] = rec
                 except Exception as exc:   # the headline line must survive a failure of this informational part
                     out["other_configs"][oname] = {"error": repr(exc)}
+                finally:
+                    if "SPVO_TUNE_SOLVE_KEEP" not in os.environ:
+                        capi.set_tuning("solve_keep", 2 if keep2_main else 1)   # (the leg's setting does not outlive it)
         if not args.no_cpu_baseline and world == 1 and headline:
             try:
                 # BASELINE.json's metric is "stereo frames/sec ...; ATE vs ref": the trajectory half, from an UNTIMED pass.  ATE_FRAMES synthetic frames

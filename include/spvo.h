@@ -334,7 +334,10 @@ typedef struct {
                                    points the PREVIOUS spvo_solve_submit of this context triangulated (its xyz output, still on the
                                    device), -1 where there is none (base.cpp:323-332).  The host need not have collected them.   */
   int late_prior;               /* 1: rvec_pred / tvec_pred / frame_count are not known yet (the previous frame's solve is still in
-                                   flight) -- they are ignored here and handed to spvo_solve_wait_prior instead                  */
+                                   flight) -- they are ignored here and handed to spvo_solve_wait_prior instead.
+                                   2: the same, and the chain's LAST kernel is held back: it goes out in one launch with the next
+                                   submission's hypotheses (beside which it runs), or alone when this solve is waited for first --
+                                   for callers that wait for frame k only after they have submitted frame k + 2 (see below)       */
 } spvo_solve_input;
 
 typedef struct {
@@ -357,20 +360,24 @@ int spvo_solve_stereo_odometry(spvo_ctx *ctx, const spvo_solve_input *in, spvo_s
  * pending solve is done and hands out what spvo_solve_stereo_odometry would have.  While a solve is pending the stand-alone
  * solver entry points (spvo_triangulate, spvo_pnp_ransac, spvo_pnp_refine) answer SPVO_ERR_STATE.
  *
- * TWO solves may be pending (round 6).  Nothing the device computes for frame k needs frame k - 1's POSE: the RANSAC's
+ * Up to THREE solves may be pending (round 6).  Nothing the device computes for frame k needs frame k - 1's POSE: the RANSAC's
  * minimal solver is prior-free (as cv::solvePnPRansac's P3P is, base.cpp:237-239), the refinement starts from the RANSAC
  * pose, and the one step that does need the motion prior -- the gate, base.cpp:241-272: three subtractions and a compare --
  * is evaluated by the wait on the host (a submission that carries its prior, late_prior = 0, has it evaluated on the device instead, so
  * that a rejected frame skips its refinement).  What frame k needs of frame k - 1 are its 3-D points (base.cpp:323-332), and
  * `prev_index` refers to them where they lie.  So a caller may submit frame k (late_prior = 1, prev_index) BEFORE it waits
  * for frame k - 1, and hands the prior -- known once k - 1 has been collected -- to spvo_solve_wait_prior.  Results are
- * those of the one-piece call, bit for bit (tests/test_gpu_odometry.py, tests/test_gpu_host.py).  The reference has no
- * counterpart: solveStereoOdometry (base.cpp:125-399) is one blocking call. */
+ * those of the one-piece call, bit for bit (tests/test_gpu_odometry.py, tests/test_gpu_host.py).  The last kernel of a
+ * late_prior = 2 submission's chain (selection, residual blocks, refinement: one workgroup, ~90 us) is held back and goes out in
+ * ONE launch with the hypotheses of the next submission, beside which it runs -- or alone, when the solve is waited for
+ * first: a caller that waits for frame k only after it has submitted frame k + 2 never waits for the solver's stream, whose
+ * work per frame is then max(hypotheses, tail) instead of their sum.  The reference has no counterpart: solveStereoOdometry
+ * (base.cpp:125-399) is one blocking call. */
 int spvo_solve_submit(spvo_ctx *ctx, const spvo_solve_input *in);
 int spvo_solve_wait(spvo_ctx *ctx, spvo_solve_output *out, float *xyz, int32_t *inliers);
 int spvo_solve_wait_prior(spvo_ctx *ctx, const double rvec_pred[3], const double tvec_pred[3], int frame_count,
                           spvo_solve_output *out, float *xyz, int32_t *inliers);
-int spvo_solve_pending(spvo_ctx *ctx);   /* solves submitted and not waited for yet (0, 1 or 2) */
+int spvo_solve_pending(spvo_ctx *ctx);   /* solves submitted and not waited for yet (0 .. 3) */
 
 /* ------------------------------------------------------- multi-GPU: pose gather
  * The path shards by stereo stream: one process per GPU, each with its own FeatureFrontEnd

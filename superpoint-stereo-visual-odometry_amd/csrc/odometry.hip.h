@@ -315,14 +315,12 @@ __device__ __forceinline__ bool wave_solve6(double (&a)[6], double rb, int lane,
   return true;
 }
 
-// one wave per hypothesis: the minimal problem is solved by lanes 0..5 together (one residual row each), all lanes score
-__global__ __launch_bounds__(64) void ransac_hypothesis_kernel(const double *__restrict__ Kd,
-                                                               const float *__restrict__ xyz,
-                                                               const float *__restrict__ xy, int n,
-                                                               const double *__restrict__ prior,  // rvec, tvec
-                                                               uint32_t seed, double thr2,
-                                                               RansacWork w) {
-  const int it = blockIdx.x, lane = threadIdx.x;
+// one wave per hypothesis: the minimal problem is solved by lanes 0..5 together (one residual row each), all lanes score.
+// A device function of (hypothesis, lane) -- nothing in it leaves the wave (no LDS, no barrier): ransac_hypothesis_kernel runs it with
+// one wave per workgroup, solve_hyp_tail_kernel with eight (the same instructions on the same data: identical bits)
+__device__ __forceinline__ void ransac_hypothesis_body(const double *__restrict__ Kd, const float *__restrict__ xyz, const float *__restrict__ xy, int n,
+                                                       const double *__restrict__ prior,  // rvec, tvec
+                                                       uint32_t seed, double thr2, RansacWork w, const int it, const int lane) {
   double K[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) K[k] = Kd[k];
@@ -399,6 +397,11 @@ __global__ __launch_bounds__(64) void ransac_hypothesis_kernel(const double *__r
     w.counts[it] = cnt;
     for (int k = 0; k < 7; ++k) w.poses[7 * it + k] = sh[k];
   }
+}
+
+__global__ __launch_bounds__(64) void ransac_hypothesis_kernel(const double *__restrict__ Kd, const float *__restrict__ xyz, const float *__restrict__ xy, int n,
+                                                               const double *__restrict__ prior, uint32_t seed, double thr2, RansacWork w) {
+  ransac_hypothesis_body(Kd, xyz, xy, n, prior, seed, thr2, w, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // deterministic block reduction of NV <= 32 doubles per thread; result in `out` (LDS), valid for every thread behind the closing barrier.
@@ -956,7 +959,7 @@ struct SolveTailArgs {
   double *h_res;
 };
 
-__global__ __launch_bounds__(SOLVE_TAIL_THREADS) void solve_tail_kernel(const SolveTailArgs a) {
+__device__ __forceinline__ void solve_tail_body(const SolveTailArgs &a) {
   constexpr int NT = SOLVE_TAIL_THREADS;
   ransac_select_body<NT>(a.hdr + 24, a.xyz, a.xy_pl, a.n, a.hdr + 33, a.iterations, a.thr2, a.w);
   __threadfence_block();
@@ -969,6 +972,22 @@ __global__ __launch_bounds__(SOLVE_TAIL_THREADS) void solve_tail_kernel(const So
   __syncthreads();   // (every thread comes back from the bodies: their early exits are workgroup-uniform)
   for (int k = threadIdx.x; k < a.o_words; k += NT) a.h_o[k] = a.d_o[k];
   if (threadIdx.x < 40) a.h_res[threadIdx.x] = reinterpret_cast<const volatile double *>(a.res)[threadIdx.x];
+}
+
+__global__ __launch_bounds__(SOLVE_TAIL_THREADS) void solve_tail_kernel(const SolveTailArgs a) { solve_tail_body(a); }
+
+// Frame k + 1's hypotheses BESIDE frame k's tail, in one launch (round 6): workgroup 0 is the tail of the solve submitted before, the other
+// workgroups run eight hypotheses each (one per wave) of the solve being submitted.  On one stream the chain of a frame was
+// 6 + 35 + 90 us of dependent kernels -- longer than a frame of the small engines, whose loop it paced (NOTES.md round 6) -- and a second
+// solver stream is not to be had (a fifth active stream slows the trunk by half): within one launch the two overlap, and the
+// stream carries max(35, 90) us per frame.  The two halves touch disjoint buffer sets (spvo_solve.hip).
+struct SolveHypArgs {
+  const double *Kd; const float *xyz; const float *xy; int n; const double *prior; uint32_t seed; double thr2; RansacWork w; int iterations;
+};
+__global__ __launch_bounds__(SOLVE_TAIL_THREADS) void solve_hyp_tail_kernel(const SolveHypArgs h, const SolveTailArgs t) {
+  if (blockIdx.x == 0) { solve_tail_body(t); return; }
+  const int it = ((int)blockIdx.x - 1) * (SOLVE_TAIL_THREADS / 64) + (int)(threadIdx.x >> 6);
+  if (it < h.iterations) ransac_hypothesis_body(h.Kd, h.xyz, h.xy, h.n, h.prior, h.seed, h.thr2, h.w, it, (int)(threadIdx.x & 63));
 }
 
 }  // namespace spvo

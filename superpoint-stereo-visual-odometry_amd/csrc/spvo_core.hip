@@ -41,7 +41,7 @@ int stage_id(spvo_ctx *c, const std::string &name) {
 // ---- diagnostic switches (include/spvo.h: spvo_set_tuning).  One process-wide table, filled by explicit calls only.
 namespace {
 const char *const kTuningNames[] = {"winograd", "wino4", "wino_narrow", "wino_dynamic", "winograd_min_tiles", "wino4_min_tiles", "merge_siblings", "heads_fused",
-                                    "heads_on_net", "heads_split", "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing", "nms_first", "upload_side", "inject_launch_failure", "int8_fused", "pair_always", "preprocess_fused", "heads_keep_raw", "tail_streams", "solve_collect_first", "graphs"};
+                                    "heads_on_net", "heads_split", "match_fused", "fp32_split", "prematch", "spin_wait", "trunk_timing", "solve_timing", "nms_first", "upload_side", "inject_launch_failure", "int8_fused", "pair_always", "preprocess_fused", "heads_keep_raw", "tail_streams", "solve_collect_first", "graphs", "solve_fuse", "solve_keep"};
 constexpr int kTuningCount = sizeof kTuningNames / sizeof kTuningNames[0];
 std::mutex g_tuning_mutex;
 std::atomic<unsigned> g_tuning_gen{1};   // grows with every spvo_set_tuning / spvo_clear_tuning: launch code reads switches as it goes, so recorded launch segments depend on them
@@ -334,6 +334,7 @@ int spvo_create(const spvo_config *cfg, spvo_ctx **out) {
   c->trunk_timing = tuning("trunk_timing", 0);
   c->solve_timing = tuning("solve_timing", 0);
   c->inject_launch_failure = tuning("inject_launch_failure", 0);
+  c->solve_fuse = tuning("solve_fuse", 1) != 0 ? 1 : 0;
   c->B = 4;   // images the activation buffers hold: two stereo pairs per trunk launch (spvo_set_trunk_pairing)
   // Non-blocking streams: work the caller puts on the NULL stream (a framework's default stream, a blocking hipMemcpy) must not
   // serialise the three streams of the pipeline against each other.  Device pointers handed to the *_dev entry points
@@ -463,7 +464,8 @@ void spvo_destroy(spvo_ctx *c) {
     void *q[] = {c->slots[i].d_xy, c->slots[i].d_xyf, c->slots[i].d_desc, c->slots[i].d_n, c->slots[i].d_sqn};
     for (void *p : q) if (p) (void)hipFree(p);
   }
-  for (int sl = 0; sl < spvo_ctx::SOLVE_SLOTS; ++sl) {
+  for (int sl = 0; sl < spvo_ctx::SOLVE_BUFS; ++sl) {
+    for (void *dp : {(void *)c->x_counts[sl], (void *)c->x_poses[sl], (void *)c->x_obs[sl]}) if (dp) (void)hipFree(dp);
     for (void *hp : {(void *)c->h_solve_in[sl], (void *)c->h_solve_res[sl], (void *)c->h_solve_o[sl]}) if (hp) (void)hipHostFree(hp);
     for (void *dp : {(void *)c->d_solve_in[sl], (void *)c->d_solve_res[sl], (void *)c->d_solve_o[sl]}) if (dp) (void)hipFree(dp);
   }

@@ -292,19 +292,29 @@ struct spvo_ctx {
   int *d_ham_idx = nullptr;
   float *d_ham_dist = nullptr;
   unsigned long long *d_ham_vote = nullptr;
-  // fused solve: one packed input, one packed result -- per SLOT: two solves may be in flight (spvo_solve_submit .. _wait), a frame's chain
-  // enqueued before the previous frame's has been collected; slots alternate, so the previous solve's points (prev_index) sit in the other one
-  static constexpr int SOLVE_SLOTS = 2;
+  // fused solve: one packed input, one packed result -- per buffer SET: up to three solves may be pending (spvo_solve_submit .. _wait), a frame's
+  // chain enqueued before the previous frames' have been collected; the sets rotate, so the previous solve's points (prev_index) sit in the set before.
+  // The TAIL kernel of a solve submitted with `late_prior` is held back (tail_deferred) and goes out in ONE launch with the hypotheses of the next
+  // submission (solve_hyp_tail_kernel: the two overlap) -- or alone, when the solve is waited for first.
+  static constexpr int SOLVE_SLOTS = 3;   // solves that may be pending
+  static constexpr int SOLVE_BUFS = 4;    // buffer sets they rotate through (a pending solve's tail reads the set before its own)
+  bool tail_deferred = false;             // the newest submission's tail kernel has not been launched yet ...
+  int tail_slot = -1;                     // ... its set, and its arguments (SolveTailArgs, odometry.hip.h: plain data)
+  alignas(16) char tail_args[320];
+  int solve_fuse = 1;                     // tuning "solve_fuse" (read at spvo_create): 0 = every tail is launched with its own submission
+  int *x_counts[SOLVE_BUFS] = {};         // RANSAC scratch of sets 1 .. (set 0: rw): a solve's hypotheses are written while its predecessor's are read
+  double *x_poses[SOLVE_BUFS] = {};
+  ObsDev *x_obs[SOLVE_BUFS] = {};         // residual blocks of sets 1 .. (set 0: d_obs)
   struct SolvePending { int n = 0, refinement_degree = 0, slot = 0, frame_count = 0; bool late = false; double rvec[3] = {0, 0, 0}, tvec[3] = {0, 0, 0}; };
   std::deque<SolvePending> solve_q;     // oldest first, at most SOLVE_SLOTS
   int solve_next_slot = 0;
   int solve_last_slot = -1, solve_last_n = 0;   // the most recent submission: where its triangulated points are and how many
-  hipEvent_t ev_solve[SOLVE_SLOTS] = {};
+  hipEvent_t ev_solve[SOLVE_BUFS] = {};
   int solve_cap = 0;
-  char *d_solve_in[SOLVE_SLOTS] = {}, *h_solve_in[SOLVE_SLOTS] = {};      // 64 doubles + 12*cap words
-  double *d_solve_res[SOLVE_SLOTS] = {}, *h_solve_res[SOLVE_SLOTS] = {};  // ransac[8] gate[16] refine[12] + pad
-  char *d_solve_o[SOLVE_SLOTS] = {}, *h_solve_o[SOLVE_SLOTS] = {};        // xyz [3n] floats, inliers [n] ints
-  int *d_ctl = nullptr;
+  char *d_solve_in[SOLVE_BUFS] = {}, *h_solve_in[SOLVE_BUFS] = {};      // 64 doubles + 12*cap words
+  double *d_solve_res[SOLVE_BUFS] = {}, *h_solve_res[SOLVE_BUFS] = {};  // ransac[8] gate[16] refine[12] + pad
+  char *d_solve_o[SOLVE_BUFS] = {}, *h_solve_o[SOLVE_BUFS] = {};        // xyz [3n] floats, inliers [n] ints
+  int *d_ctl = nullptr;                   // [SOLVE_BUFS][4]
 
   // profiling
   bool prof = false;

@@ -30,6 +30,11 @@ int ensure_odometry(spvo_ctx *c, int n, int iterations, int n_obs) {
     drop(c->rw.counts); drop(c->rw.poses);
     if ((rc = dev_alloc(c, &c->rw.counts, cap))) return rc;
     if ((rc = dev_alloc(c, &c->rw.poses, (size_t)cap * 7))) return rc;
+    for (int sl = 1; sl < spvo_ctx::SOLVE_BUFS; ++sl) {   // (the fused solve's sets 1 ..: spvo_solve_submit)
+      drop(c->x_counts[sl]); drop(c->x_poses[sl]);
+      if ((rc = dev_alloc(c, &c->x_counts[sl], cap))) return rc;
+      if ((rc = dev_alloc(c, &c->x_poses[sl], (size_t)cap * 7))) return rc;
+    }
     c->ransac_cap = cap;
   }
   if (n_obs > c->obs_cap) {
@@ -37,6 +42,10 @@ int ensure_odometry(spvo_ctx *c, int n, int iterations, int n_obs) {
     c->obs_cap = 0;
     drop(c->d_obs);
     if ((rc = dev_alloc(c, &c->d_obs, cap))) return rc;
+    for (int sl = 1; sl < spvo_ctx::SOLVE_BUFS; ++sl) {
+      drop(c->x_obs[sl]);
+      if ((rc = dev_alloc(c, &c->x_obs[sl], cap))) return rc;
+    }
     c->obs_cap = cap;
   }
   return SPVO_OK;
@@ -173,7 +182,7 @@ int spvo_solve_submit(spvo_ctx *c, const spvo_solve_input *in) {
   if (rc) return rc;
   if (n > c->solve_cap || !c->solve_cap) {
     const int cap = std::max(std::max(n, 2048), c->cfg.max_keypoints);
-    for (int sl = 0; sl < spvo_ctx::SOLVE_SLOTS; ++sl) {
+    for (int sl = 0; sl < spvo_ctx::SOLVE_BUFS; ++sl) {
       for (void *hp : {(void *)c->h_solve_in[sl], (void *)c->h_solve_res[sl], (void *)c->h_solve_o[sl]}) if (hp) (void)hipHostFree(hp);
       for (void *dp : {(void *)c->d_solve_in[sl], (void *)c->d_solve_res[sl], (void *)c->d_solve_o[sl]}) if (dp) (void)hipFree(dp);
       c->h_solve_in[sl] = c->h_solve_o[sl] = nullptr; c->h_solve_res[sl] = nullptr;
@@ -185,7 +194,7 @@ int spvo_solve_submit(spvo_ctx *c, const spvo_solve_input *in) {
     c->solve_last_slot = -1; c->solve_last_n = 0;
     if (in->prev_index) return fail(c, SPVO_ERR_STATE, "the solver's buffers grew: the previous solve's points are gone (pass prev_xyz for this frame)");
     const size_t in_bytes = 64 * sizeof(double) + (size_t)12 * cap * 4, o_bytes = (size_t)4 * cap * 4;
-    for (int sl = 0; sl < spvo_ctx::SOLVE_SLOTS; ++sl) {
+    for (int sl = 0; sl < spvo_ctx::SOLVE_BUFS; ++sl) {
       if ((rc = dev_alloc(c, &c->d_solve_in[sl], in_bytes))) return rc;
       if ((rc = dev_alloc(c, &c->d_solve_res[sl], 40))) return rc;
       if ((rc = dev_alloc(c, &c->d_solve_o[sl], o_bytes))) return rc;
@@ -193,7 +202,7 @@ int spvo_solve_submit(spvo_ctx *c, const spvo_solve_input *in) {
       HIP_TRY(c, hipHostMalloc((void **)&c->h_solve_res[sl], 40 * sizeof(double)));
       HIP_TRY(c, hipHostMalloc((void **)&c->h_solve_o[sl], o_bytes));
     }
-    if ((rc = dev_alloc(c, &c->d_ctl, 4))) return rc;
+    if ((rc = dev_alloc(c, &c->d_ctl, 4 * spvo_ctx::SOLVE_BUFS))) return rc;
     c->solve_cap = cap;
   }
   if (grow) HIP_TRY(c, hipDeviceSynchronize());
@@ -229,7 +238,7 @@ int spvo_solve_submit(spvo_ctx *c, const spvo_solve_input *in) {
   } else if (have_index && n > 0) {
     std::memcpy(fw + 11 * n, in->prev_index, (size_t)n * 4);
   }
-  const float *prev_pts = have_index ? (const float *)c->d_solve_o[c->solve_last_slot] : nullptr;   // (the other slot: slots alternate)
+  const float *prev_pts = have_index ? (const float *)c->d_solve_o[c->solve_last_slot] : nullptr;   // (the set before this one: nothing rewrites it while this solve is pending)
   if (n > 0) {
     const size_t used = 64 * sizeof(double) + (size_t)12 * n * 4;
     const double tm1 = solve_timing ? now_us() : 0;
@@ -238,6 +247,7 @@ int spvo_solve_submit(spvo_ctx *c, const spvo_solve_input *in) {
     float *d_xyz = (float *)c->d_solve_o[sl];
     int *d_inl = (int *)(c->d_solve_o[sl]) + 3 * n;
     RansacWork rw = c->rw;
+    if (sl) { rw.counts = c->x_counts[sl]; rw.poses = c->x_poses[sl]; }
     rw.result = c->d_solve_res[sl];
     rw.inliers = d_inl;
     const double thr2 = in->ransac.reproj_error * in->ransac.reproj_error;
@@ -247,22 +257,44 @@ int spvo_solve_submit(spvo_ctx *c, const spvo_solve_input *in) {
       hipLaunchKernelGGL(solve_in_triangulate_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream2, reinterpret_cast<const uint4 *>(c->h_solve_in[sl]),
                          reinterpret_cast<uint4 *>(c->d_solve_in[sl]), (int)(used / 16), n, d_xyz);
       if (n >= 4) {
-        hipLaunchKernelGGL(ransac_hypothesis_kernel, dim3(in->ransac.iterations), dim3(64), 0, c->stream2, dh + 24, d_xyz, df + 4 * n, n, dh + 33, in->ransac.seed, thr2, rw);
         SolveTailArgs ta;   // selection + refit, residual blocks, refinement, results to the pinned buffers: one launch (odometry.hip.h)
         ta.hdr = dh; ta.xyz = d_xyz; ta.xy_cl = df; ta.xy_cr = df + 2 * n; ta.xy_pl = df + 4 * n; ta.xy_pr = df + 6 * n;
         ta.prev_xyz = have_prev ? df + 8 * n : nullptr; ta.prev_valid = have_prev ? (const int *)(df + 11 * n) : nullptr;
         ta.prev_index = have_index ? (const int *)(df + 11 * n) : nullptr; ta.prev_pts = prev_pts;
         ta.n = n; ta.iterations = in->ransac.iterations; ta.thr2 = thr2; ta.w = rw;
-        ta.obs = c->d_obs; ta.ctl = c->d_ctl; ta.res = c->d_solve_res[sl];
+        ta.obs = sl ? c->x_obs[sl] : c->d_obs; ta.ctl = c->d_ctl + 4 * sl; ta.res = c->d_solve_res[sl];
         ta.max_iterations = in->refine.max_iterations; ta.huber_delta = in->refine.huber_delta;
         ta.d_o = reinterpret_cast<const unsigned *>(c->d_solve_o[sl]); ta.h_o = reinterpret_cast<unsigned *>(c->h_solve_o[sl]); ta.o_words = 4 * n; ta.h_res = c->h_solve_res[sl];
-        hipLaunchKernelGGL(solve_tail_kernel, dim3(1), dim3(SOLVE_TAIL_THREADS), 0, c->stream2, ta);
+        // The hypotheses of THIS solve -- in one launch with the tail of the solve submitted before, if that one is still held back
+        // (solve_hyp_tail_kernel: the two overlap; ev_solve of the older solve is recorded behind the launch) ...
+        if (c->tail_deferred) {
+          SolveTailArgs prev_ta;
+          std::memcpy(&prev_ta, c->tail_args, sizeof prev_ta);
+          const SolveHypArgs ha{dh + 24, d_xyz, df + 4 * n, n, dh + 33, in->ransac.seed, thr2, rw, in->ransac.iterations};
+          const int per_wg = SOLVE_TAIL_THREADS / 64;
+          hipLaunchKernelGGL(solve_hyp_tail_kernel, dim3(1 + (in->ransac.iterations + per_wg - 1) / per_wg), dim3(SOLVE_TAIL_THREADS), 0, c->stream2, ha, prev_ta);
+          HIP_TRY(c, hipGetLastError());
+          HIP_TRY(c, hipEventRecord(c->ev_solve[c->tail_slot], c->stream2));
+          c->tail_deferred = false;
+        } else {
+          hipLaunchKernelGGL(ransac_hypothesis_kernel, dim3(in->ransac.iterations), dim3(64), 0, c->stream2, dh + 24, d_xyz, df + 4 * n, n, dh + 33, in->ransac.seed, thr2, rw);
+        }
+        // ... and its own tail: held back for the next submission's launch when the caller asks for it (late_prior = 2: it keeps two solves
+        // pending behind every submit, so nobody waits for this one before the next is submitted), at once otherwise
+        if (in->late_prior == 2 && c->solve_fuse) {
+          static_assert(sizeof(SolveTailArgs) <= sizeof(spvo_ctx::tail_args) && std::is_trivially_copyable<SolveTailArgs>::value, "tail_args holds a SolveTailArgs");
+          std::memcpy(c->tail_args, &ta, sizeof ta);
+          c->tail_deferred = true;
+          c->tail_slot = sl;
+        } else {
+          hipLaunchKernelGGL(solve_tail_kernel, dim3(1), dim3(SOLVE_TAIL_THREADS), 0, c->stream2, ta);
+        }
       }
       HIP_TRY(c, hipGetLastError());
     }
     if (n < 4) HIP_TRY(c, hipMemcpyAsync(c->h_solve_o[sl], c->d_solve_o[sl], (size_t)4 * n * 4, hipMemcpyDeviceToHost, c->stream2));   // (no model possible: only the points travel)
     if (!c->ev_solve[sl]) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_solve[sl], hipEventDisableTiming));
-    HIP_TRY(c, hipEventRecord(c->ev_solve[sl], c->stream2));
+    if (!(c->tail_deferred && c->tail_slot == sl)) HIP_TRY(c, hipEventRecord(c->ev_solve[sl], c->stream2));   // (a held-back tail: the event follows its launch)
     if (solve_timing) {
       const double tm2 = now_us();
       tacc[0] += tm1 - tm0; tacc[1] += tm2 - tm1;
@@ -274,7 +306,7 @@ int spvo_solve_submit(spvo_ctx *c, const spvo_solve_input *in) {
   }   // (n == 0: nothing to enqueue, the wait answers with the prior)
   c->solve_q.push_back(pend);
   c->solve_last_slot = sl; c->solve_last_n = n;
-  c->solve_next_slot = (sl + 1) % spvo_ctx::SOLVE_SLOTS;
+  c->solve_next_slot = (sl + 1) % spvo_ctx::SOLVE_BUFS;
   return SPVO_OK;
 }
 
@@ -307,6 +339,14 @@ static int solve_wait_impl(spvo_ctx *c, const double *prior_rvec, const double *
   };
   if (n == 0) { prior_pose(); return SPVO_OK; }
   HIP_TRY(c, hipSetDevice(c->cfg.device));
+  if (c->tail_deferred && c->tail_slot == sl) {   // its tail was held back for a successor that did not come first: it goes out alone now
+    SolveTailArgs ta;
+    std::memcpy(&ta, c->tail_args, sizeof ta);
+    hipLaunchKernelGGL(solve_tail_kernel, dim3(1), dim3(SOLVE_TAIL_THREADS), 0, c->stream2, ta);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev_solve[sl], c->stream2));
+    c->tail_deferred = false;
+  }
   {
     const double tw0 = diag_now_us();
     HIP_TRY(c, wait_event(c->ev_solve[sl]));

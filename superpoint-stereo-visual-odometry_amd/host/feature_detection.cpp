@@ -93,6 +93,7 @@ bool FeatureFrontEnd::ensureContext() {
   spvo_default_config(&cfg);
   cfg.device = configured_device();
   solve_timing_ = spvo_get_tuning("solve_timing", 0) != 0;
+  solve_hold_tail_ = spvo_get_tuning("solve_keep", 1) == 2;
   if (input_height_ > 0 && input_width_ > 0) {
     cfg.net_height = (input_height_ + 7) / 8 * 8;   // only the pre-processing geometry matters to a context without an engine
     cfg.net_width = (input_width_ + 7) / 8 * 8;
@@ -235,16 +236,16 @@ void FeatureFrontEnd::solveStereoOdometry(tf2::Transform &cam0_curr_T_cam0_prev)
 // First half (extension): the correspondence join (base.cpp:127-207) and the hand-over of the numeric part to spvo_solve_submit.
 // Since round 6 this half needs NOTHING of the previous frame's result: its 3-D points are referred to by index where they lie on the
 // device (spvo_solve_input::prev_index), the motion prior and the frame count are only needed by the gate, which the second half
-// evaluates (spvo_solve_wait_prior).  So the next frame may be submitted BEFORE this one has been collected: up to two solves in flight,
-// collected oldest first.  The join's own maps (base.cpp:388-392) roll here; pose, prior, frame count and the points' host copy roll in
+// evaluates (spvo_solve_wait_prior).  So the next frames may be submitted BEFORE this one has been collected: up to three solves in flight,
+// collected oldest first (with two kept pending the library runs a frame's hypotheses and the previous frame's tail kernel as ONE launch).  The join's own maps (base.cpp:388-392) roll here; pose, prior, frame count and the points' host copy roll in
 // solveStereoOdometryCollect.
 bool FeatureFrontEnd::solveStereoOdometrySubmit() {
   const bool timing = solve_timing_;   // diagnostic (spvo_set_tuning "solve_timing", read when this front end created its context)
   double *acc = solve_timing_acc_;
   long &calls = solve_timing_calls_;
   const double th0 = timing ? host_now_us() : 0;
-  if (solve_q_.size() >= 2) {
-    logError("solveStereoOdometrySubmit: two solves are in flight, collect the older one first");
+  if (solve_q_.size() >= 3) {
+    logError("solveStereoOdometrySubmit: three solves are in flight, collect the oldest one first");
     return false;
   }
   if (keypoints_dq.size() < 4 || !ensureContext()) {
@@ -313,7 +314,7 @@ bool FeatureFrontEnd::solveStereoOdometrySubmit() {
   // r_vec_pred / t_vec_pred / frame_count: with an earlier solve still in flight they are not final yet and are handed over by
   // solveStereoOdometryCollect (late prior: the gate is evaluated there); with none in flight -- the synchronous call sequence -- they go along
   // now and the device gates (a frame the gate rejects then skips its refinement).  Same decision, same results either way.
-  si.late_prior = solve_q_.empty() ? 0 : 1;
+  si.late_prior = solve_q_.empty() ? 0 : (solve_hold_tail_ ? 2 : 1);   // (2: this frame's tail kernel goes out with the next frame's hypotheses, include/spvo.h)
   for (int k = 0; k < 3; ++k) { si.rvec_pred[k] = r_vec_pred[k]; si.tvec_pred[k] = t_vec_pred[k]; }
   si.frame_count = frame_count;
   for (int k = 0; k < 12; ++k) { si.P_l[k] = Pl[k]; si.P_r[k] = Pr[k]; }
@@ -606,6 +607,7 @@ void SuperPointFeatureFrontEnd::loadEngine() {
   spvo_default_config(&cfg);
   cfg.device = configured_device();
   solve_timing_ = spvo_get_tuning("solve_timing", 0) != 0;
+  solve_hold_tail_ = spvo_get_tuning("solve_keep", 1) == 2;
   cfg.net_height = input_height_;
   cfg.net_width = input_width_;
   // model_batch_size_ only changes how the reference batches its TensorRT calls (hpp:342-344);

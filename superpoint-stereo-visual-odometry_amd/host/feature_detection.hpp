@@ -270,9 +270,11 @@ protected:
   bool matcher_ready_ = false;
   bool matcher_cross_check_ = false;
   struct PendingSolve { int n = 0; std::vector<int> inliers_postmatching; };
-  std::deque<PendingSolve> solve_q_;       // solveStereoOdometrySubmit .. Collect, oldest first (at most two)
+  std::deque<PendingSolve> solve_q_;       // solveStereoOdometrySubmit .. Collect, oldest first (at most three)
   bool prev_points_on_device_ = false;     // a submit has left its triangulated points in the context: the next one refers to them by index
   bool solve_timing_ = false;      // tuning "solve_timing", read when the context is created
+  bool solve_hold_tail_ = false;   // tuning "solve_keep" = 2, read when the context is created: the caller keeps TWO solves pending behind every submit, so a
+                                   // frame's last solver kernel is held back for the next frame's launch (spvo_solve_input::late_prior = 2)
   double solve_timing_acc_[3] = {0, 0, 0};
   long solve_timing_calls_ = 0;
   std::vector<float> solve_pts3d_;

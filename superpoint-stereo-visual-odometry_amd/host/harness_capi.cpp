@@ -336,8 +336,9 @@ int spvo_host_run_device_block(void *h, const void *const *d_l, const void *cons
     r.pnp_ok = fe->lastPnpOk(); r.accepted = fe->lastAccepted(); r.refined = fe->lastRefined(); r.lm_iterations = fe->lastLmIterations();
     r.pnp_inliers = (int)fe->inliersPnp().size();
   };
-  int pending = -1;                   // frame of the block whose deferred solve is in flight
   const bool collect_first = spvo_get_tuning("solve_collect_first", 0) != 0;
+  const int keep = spvo_get_tuning("solve_keep", 1) == 2 ? 2 : 1;
+  std::deque<int> pend_q;   // frames of the block whose deferred solves are in flight, oldest first
   for (int k = 0; k < n; ++k) {
     const long g = first + k;
     SpvoFrameRecord &r = rec[k];
@@ -368,24 +369,22 @@ int spvo_host_run_device_block(void *h, const void *const *d_l, const void *cons
     }
     // this frame's chain goes out FIRST (it needs nothing of the previous frame's result: feature_detection.hpp), then the previous
     // frame's pose is collected -- the solver's stream always has the next chain queued behind the running one
-    if (collect_first && fe->solvePending()) {   // (diagnostic, tuning "solve_collect_first": rounds 1-5's order, for A/B runs)
+    auto collect_one = [&]() {
       const bool ok = fe->solveStereoOdometryCollect(T);
-      if (pending >= 0) record_pose(pending, T, ok);
-      pending = -1;
-    }
+      if (!pend_q.empty()) { record_pose(pend_q.front(), T, ok); pend_q.pop_front(); }
+    };
+    if (collect_first && fe->solvePending()) collect_one();   // (diagnostic, tuning "solve_collect_first": rounds 1-5's order, for A/B runs)
     const bool submitted = fe->solveStereoOdometrySubmit();
-    if (fe->solvesPending() > (submitted ? 1 : 0)) {
-      const bool ok = fe->solveStereoOdometryCollect(T);
-      if (pending >= 0) record_pose(pending, T, ok);
-      pending = -1;
-    }
-    if (submitted) pending = k;
+    if (submitted) pend_q.push_back(k);
+    // `keep` solves stay pending behind a submit (tuning "solve_keep", default 1; 2: the pose of frame k is collected behind the submit of
+    // frame k + 2 -- frame k's tail kernel then went out in ONE launch with frame k + 1's hypotheses and is long done: the small engines' setting)
+    while (fe->solvesPending() > (submitted ? keep : 0)) collect_one();
   }
-  if (fe->solvePending()) {
+  while (fe->solvePending()) {   // every frame of the block has its record when the call returns
     tf2::Transform T;
     T.setIdentity();
     const bool ok = fe->solveStereoOdometryCollect(T);
-    if (pending >= 0) record_pose(pending, T, ok);
+    if (!pend_q.empty()) { record_pose(pend_q.front(), T, ok); pend_q.pop_front(); }
   }
   return n;
 }

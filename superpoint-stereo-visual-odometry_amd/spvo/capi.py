@@ -436,7 +436,8 @@ class Context:
               frame_count=0, refinement_degree=4, seed=0, iterations=500, reproj_error=2.0, max_iterations=40, split=None, prev_index=None, late_prior=False):
         """spvo_solve_stereo_odometry, or (split="submit") spvo_solve_submit alone: complete with solve_wait(n) / solve_wait_prior(n, ...).
         prev_index: instead of prev_xyz / prev_valid, indices into the points of the previous submit on this context (-1: none);
-        late_prior: the prior is handed to solve_wait_prior instead (the previous solve may still be in flight)."""
+        late_prior: the prior is handed to solve_wait_prior instead (the previous solve may still be in flight); 2: and the chain's last kernel
+        is held back for the next submission's launch (include/spvo.h)."""
         arrs = [np.ascontiguousarray(a, np.float32).reshape(-1, 2) for a in (cl, cr, pl, pr)]
         n = len(arrs[0])
         si = SolveInput()

@@ -193,14 +193,17 @@ def _rot_to_rvec(R):
     return ax * a
 
 
-@pytest.mark.parametrize("depth", [2, 4])
-def test_long_sequence_block_loop_with_two_solves_in_flight_equals_the_call_sequence(gpu_run, long_sequence, models_dir, depth):
+@pytest.mark.parametrize("depth,keep", [(2, 1), (4, 1), (4, 2)])
+def test_long_sequence_block_loop_with_two_solves_in_flight_equals_the_call_sequence(gpu_run, long_sequence, models_dir, tuning, depth, keep):
     """The same 44 frames through the loop bench.py times (spvo_host_run_device_block: `depth` pairs announced ahead, trunk pairing at 4, the
     solve of frame k submitted BEFORE frame k - 1's is collected -- late prior, the gate evaluated on the host at collect time, the previous
     frame's points referred to by index on the device) against the synchronous call sequence of `gpu_run` (the gate on the device, one
     solve at a time): every pose bit for bit, every pnp-ok / accepted / refined flag, LM iteration count, inlier and match count -- the
-    planted jump after frame 12 is rejected by the host-side gate exactly as by the device-side one."""
+    planted jump after frame 12 is rejected by the host-side gate exactly as by the device-side one.  keep = 2 (tuning "solve_keep"): two
+    solves stay pending behind every submit -- three in flight, every frame's tail kernel in one launch with the next frame's hypotheses."""
     import torch
+    if keep == 2:
+        tuning(solve_keep=2)
     frames, poses, P_l, P_r = long_sequence
     dev = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
     dl, dr = [a.data_ptr() for a, _ in dev], [b.data_ptr() for _, b in dev]

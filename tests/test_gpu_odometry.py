@@ -177,7 +177,7 @@ def test_fused_solve_gating_and_small_inputs(ctx_vgg):
 
 def test_solve_in_two_halves(ctx_vgg):
     """spvo_solve_submit + spvo_solve_wait == spvo_solve_stereo_odometry bit for bit; the inputs may be overwritten between the
-    halves (they are staged at submit); TWO solves may be pending (round 6), a third is refused, and the stand-alone solver entry
+    halves (they are staged at submit); THREE solves may be pending (round 6), a fourth is refused, and the stand-alone solver entry
     points refuse while any is."""
     P_l, P_r, Xc, cl, cr, pl, pr, rv, tv, bad = _scene(seed=9, n=300, noise=0.3, outliers=0.2)
     prior_r, prior_t = np.zeros(3), np.array([0.0, 0.0, 0.9])
@@ -187,14 +187,15 @@ def test_solve_in_two_halves(ctx_vgg):
     for a in arrs:
         a[:] = -1.0                                                     # the caller's arrays are free after submit
     n2 = ctx_vgg.solve(P_l, P_r, cl, cr, pl, pr, None, None, prior_r, prior_t, frame_count=3, seed=4, split="submit")   # a second one behind it
-    assert ctx_vgg.solve_pending() == 2
+    n3 = ctx_vgg.solve(P_l, P_r, cl, cr, pl, pr, None, None, prior_r, prior_t, frame_count=3, seed=4, split="submit")   # ... and a third
+    assert ctx_vgg.solve_pending() == 3
     with pytest.raises(capi.SpvoError) as e:
         ctx_vgg.solve(P_l, P_r, cl, cr, pl, pr, None, None, prior_r, prior_t, split="submit")
     assert e.value.code == -4
     with pytest.raises(capi.SpvoError) as e:
         ctx_vgg.triangulate(P_l, P_r, cl, cr)
     assert e.value.code == -4
-    for got in (ctx_vgg.solve_wait(n), ctx_vgg.solve_wait(n2)):       # oldest first; both are the one-piece call's result
+    for got in (ctx_vgg.solve_wait(n), ctx_vgg.solve_wait(n2), ctx_vgg.solve_wait(n3)):       # oldest first; all are the one-piece call's result
         for k in ("q", "t", "rvec", "tvec", "inliers", "xyz"):
             assert np.array_equal(got[k], ref[k]), k
         assert got["refined"] == ref["refined"] and got["iterations"] == ref["iterations"]
@@ -248,3 +249,45 @@ def test_two_frames_in_flight_with_late_prior_and_point_indices(ctx_vgg, degree)
     with pytest.raises(capi.SpvoError):
         ctx_vgg.solve(P_l, P_r, cl2, cr2, pl2, pr2, None, None, split="submit", late_prior=True, prev_index=bad_idx)
     assert ctx_vgg.solve_pending() == 0
+
+
+@pytest.mark.parametrize("keep", [1, 2])
+def test_pipelined_solves_with_the_tail_in_the_next_submissions_launch(ctx_vgg, keep):
+    """Round 6: the tail kernel of a late_prior = 2 submission is held back and goes out in ONE launch with the hypotheses of the next submission
+    (solve_hyp_tail_kernel: workgroup 0 = the older solve's selection / residual blocks / refinement, the other workgroups = eight
+    hypotheses each of the newer one), or alone when the solve is waited for first.  Seven frames pipelined with `keep` solves left pending
+    behind every submit (1: every tail goes out alone at its wait or fused, as it comes; 2: three pending, every tail but the last two fused)
+    against the one-piece call sequence: every output bit for bit, whichever way a tail was launched."""
+    scenes = [_scene(seed=20 + k, n=260 + 10 * k, noise=0.3, outliers=0.2) for k in range(7)]
+    rng = np.random.RandomState(3)
+    idxs = [None] + [rng.randint(-1, 260 + 10 * (k - 1), 260 + 10 * k).astype(np.int32) for k in range(1, 7)]
+    # the one-piece reference: wait for k, copy its points and its accepted pose into k + 1's input
+    want, prior, prev = [], (np.zeros(3), np.array([0.0, 0.0, 0.85])), None
+    for k, (P_l, P_r, _, cl, cr, pl, pr, _, _, _) in enumerate(scenes):
+        pxyz = pval = None
+        if k:
+            pxyz = np.where(idxs[k][:, None] >= 0, prev["xyz"][np.maximum(idxs[k], 0)], 0).astype(np.float32)
+            pval = (idxs[k] >= 0).astype(np.int32)
+        o = ctx_vgg.solve(P_l, P_r, cl, cr, pl, pr, pxyz, pval, prior[0], prior[1], frame_count=11 + k, refinement_degree=4, seed=1)
+        if o["accepted"]: prior = (o["rvec"], o["tvec"])
+        want.append(o); prev = o
+    got, pend, prior = [], [], (np.zeros(3), np.array([0.0, 0.0, 0.85]))
+
+    def collect():
+        nonlocal prior
+        o = ctx_vgg.solve_wait_prior(pend.pop(0), prior[0], prior[1], 11 + len(got))
+        if o["accepted"]: prior = (o["rvec"], o["tvec"])
+        got.append(o)
+
+    for k, (P_l, P_r, _, cl, cr, pl, pr, _, _, _) in enumerate(scenes):
+        pend.append(ctx_vgg.solve(P_l, P_r, cl, cr, pl, pr, None, None, refinement_degree=4, seed=1, split="submit", late_prior=2, prev_index=idxs[k]))
+        assert ctx_vgg.solve_pending() == len(pend)
+        while len(pend) > keep:
+            collect()
+    while pend:
+        collect()
+    assert ctx_vgg.solve_pending() == 0 and sum(o["accepted"] for o in want) >= 5
+    for x, y in zip(want, got):
+        for f in ("q", "t", "rvec", "tvec", "inliers", "xyz"):
+            assert np.array_equal(x[f], y[f]), f
+        assert (x["pnp_ok"], x["accepted"], x["refined"], x["iterations"]) == (y["pnp_ok"], y["accepted"], y["refined"], y["iterations"])
